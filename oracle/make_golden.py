@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY (oracle/): generates tests/golden/*.npz by running the REAL reference
+(oracle/_ref/ref_dump_{std,evb}: /root/reference/src compiled by oracle/build_ref.sh, FFTs by
+Intel MKL) on seeded synthetic inputs.  Only runs in the dev container; the fixtures it writes are
+data (inputs + reference outputs) and are committed.
+
+    python oracle/make_golden.py            # regenerate everything
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_inputs  # noqa: E402
+from reactive_pb_nn_md_amd import forcefield, synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+BIG_TABLES = ("B6_spline", "B5_spline", "erfc_table", "ewaldscale_table", "Tang_Toennies_table",
+              "dTang_Toennies_table", "CB")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def pairs_hash(verlet_point, neighbor_list):
+    """Order-independent digest of the half Verlet list: per atom i the sorted j's."""
+    vp = verlet_point.astype(np.int64) - 1
+    h = hashlib.sha256()
+    for i in range(len(vp) - 1):
+        js = np.sort(neighbor_list[vp[i]:vp[i + 1]]).astype("<i4")
+        h.update(np.int32(i + 1).tobytes())
+        h.update(js.tobytes())
+    return h.hexdigest()
+
+
+def compact(d, keep_store=True):
+    out = {}
+    for k, v in d.items():
+        if k in BIG_TABLES:
+            out[k + "_sha256"] = np.array(sha(v))
+            flat = v.ravel()
+            out[k + "_sample_idx"] = np.arange(0, flat.size, 997, dtype=np.int64)
+            out[k + "_sample"] = flat[::997].copy()
+            out[k + "_shape"] = np.array(v.shape)
+        elif k == "neighbor_list":
+            out["neighbor_pairs_sha256"] = np.array(pairs_hash(d["verlet_point"], v))
+            out["neighbor_count"] = np.array(v.size)
+        elif k == "Q_grid_diabats":
+            D = v.shape[0]
+            base = v[0]
+            out["Qd_base_is_Q_grid"] = np.array(np.array_equal(base, d["Q_grid"]))
+            for i in range(1, D):
+                diff = (v[i] - base).ravel()
+                nz = np.nonzero(v[i].ravel() != base.ravel())[0]
+                out["Qd%d_idx" % (i + 1)] = nz.astype(np.int64)
+                out["Qd%d_val" % (i + 1)] = v[i].ravel()[nz]
+        elif k == "evb_forces_store" and not keep_store:
+            continue
+        elif k in ("evb_hamiltonian", "evb_forces_lookup_index") and "n_diabat" in d:
+            D = int(d["n_diabat"][0])
+            out[k] = v.T[:D, :D].copy()          # -> [i,j] = reference (i,j)
+        elif k == "evb_diabat_proton_log" and "n_diabat" in d:
+            D = int(d["n_diabat"][0])
+            out[k] = v.transpose(2, 1, 0)[:D].copy()   # [diabat, hop, 5]
+        elif k == "evb_diabat_coupling_matrix" and "n_diabat" in d:
+            out[k] = v[:int(d["n_diabat"][0])].copy()
+        else:
+            out[k] = v
+    return out
+
+
+def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, **simkw):
+    ff = forcefield.ch3so3h_water_forcefield()
+    s = synth.make_system(n_side, n_diabat=n_diabat, seed=seed)
+    vel = None
+    if md_steps:
+        p = forcefield.build_params(ff, moltype_order=["h2o", "so3h"])
+        idx = {n: i for i, n in enumerate(p.atype_names)}
+        mass = np.array([p.atype_mass[idx[a]] for a in s.atom_names])
+        vel = synth.maxwell_boltzmann(mass, 300.0, seed + 100)
+    d = ref_inputs.run_reference(s, ff, evb=evb, velocities=vel, nsteps=md_steps, **simkw)
+    out = compact(d, keep_store=keep_store)
+    out["gen_n_side"] = np.array(n_side)
+    out["gen_n_diabat"] = np.array(n_diabat)
+    out["gen_seed"] = np.array(seed)
+    out["gen_xyz"] = s.xyz
+    out["gen_hydronium"] = np.array(s.hydronium)
+    if vel is not None:
+        out["md_velocity0"] = vel
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-22s N=%5d  %s  %.0f kB" % (name, s.n_atom, "D=%d" % int(d["n_diabat"][0]) if evb else "std", os.path.getsize(path) / 1e3))
+
+
+def main():
+    small = dict(rc=7.0, rv=8.0, nslist=16, pme_grid=16)
+    case("std_n8_s0", 8, 1, 0, evb=False)
+    case("std_n6_s3", 6, 1, 3, evb=False, **small)
+    case("evb_n6_d1_s1", 6, 1, 1, evb=True, **small)
+    case("evb_n6_d2_s1", 6, 2, 1, evb=True, **small)
+    case("evb_n6_d4_s2", 6, 4, 2, evb=True, **small)
+    case("evb_n6_d8_s1", 6, 8, 1, evb=True, **small)
+    case("evb_n8_d8_s1", 8, 8, 1, evb=True, keep_store=False)
+    case("md_std_n6_s4", 6, 1, 4, evb=False, md_steps=4, **small)
+    case("md_evb_n6_d2_s5", 6, 2, 5, evb=True, md_steps=4, keep_store=False, **small)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,491 @@
+// C-ABI entry points of libmsevb_hip.so (include/msevb_hip.h): static-data setters, msevb_finalize, the force-call
+// orchestration of calculate_total_force_energy (src/total_energy_forces.f90:19-99) and read-back helpers.
+#include <algorithm>
+
+#include "ctx.hpp"
+
+
+namespace {
+
+__global__ void k_reduce_partials(int n, const double* __restrict__ part, double* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < n; k += 256) s += part[k];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+  if (threadIdx.x == 0) *out = red[0];
+}
+
+__global__ void k_half_to_full(int N, const unsigned* __restrict__ start, const int* __restrict__ nbr, const int* __restrict__ perm, int* __restrict__ counts) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  const int i = perm[k];
+  int n = 0;
+  for (unsigned q = start[k]; q < start[k + 1]; ++q) if (perm[nbr[q]] > i) ++n;
+  counts[i] = n;
+}
+
+}  // namespace
+
+int reduce_partials(msevb_ctx* c, int slot, int nblocks) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, nblocks, c->d_partials.p + (size_t)slot * MAX_BLOCKS, c->d_energies.p + slot);
+  HIPCHK(hipGetLastError());
+  return MSEVB_OK;
+}
+
+int fetch_energies(msevb_ctx* c) {
+  HIPCHK(hipMemcpyAsync(c->h_energies, c->d_energies.p, N_SLOTS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MSEVB_OK;
+}
+
+extern "C" {
+
+int msevb_create(msevb_ctx** out, int device_id) {
+  if (!out) return MSEVB_ERR_ARG;
+  msevb_ctx* c = new msevb_ctx();
+  *out = c;
+  c->device = device_id;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { c->err = "no HIP device visible: libmsevb_hip has no CPU fallback"; return MSEVB_ERR_HIP; }
+  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->own_stream = true;
+  HIPCHK(hipHostMalloc((void**)&c->h_energies, N_SLOTS * sizeof(double), hipHostMallocDefault));
+  memset(c->h_energies, 0, N_SLOTS * sizeof(double));
+  const char* names[PH_COUNT] = {"verlet list construction", "sorted atom refresh", "real space (pair loop)", "intra-molecular (non-bonded + bonded)",
+                                 "Q_grid (spread)", "Fourier transforms + B*C*FQ", "Q grid derivatives (gather)", "ms-evb diabat real space",
+                                 "ms-evb reciprocal space", "ms-evb Hellmann-Feynman blend", "md integration"};
+  for (int p = 0; p < PH_COUNT; ++p) c->ph[p].name = names[p];
+  c->timing = false;
+  return MSEVB_OK;
+}
+
+int msevb_destroy(msevb_ctx* c) {
+  if (!c) return MSEVB_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  pme_teardown(c);
+  DBuf<int>* ib[] = {&c->d_atype, &c->d_mol_type, &c->d_mol_natom, &c->d_mol_atoms, &c->d_mol_of, &c->d_cell_of, &c->d_perm, &c->d_cell_keys_tmp,
+                     &c->d_perm_tmp, &c->d_cell_start, &c->d_inv_perm, &c->d_nbr, &c->d_type_sorted, &c->d_mol_sorted, &c->d_base, &c->d_splindex};
+  for (auto b : ib) b->release();
+  DBuf<double>* db[] = {&c->d_chg, &c->d_mass, &c->d_B6, &c->d_B5, &c->d_tt, &c->d_dtt, &c->d_CB, &c->d_xyz, &c->d_vel, &c->d_force, &c->d_force_recip,
+                        &c->d_xyz_store, &c->d_disp, &c->d_maxdisp, &c->d_Q, &c->d_w, &c->d_dw, &c->d_uscale, &c->d_partials, &c->d_energies,
+                        &c->d_Fdiag, &c->d_Foff};
+  for (auto b : db) b->release();
+  c->d_pair_par.release(); c->d_moltypes.release(); c->d_ewald_tab.release(); c->d_nbr_count.release(); c->d_nbr_start.release();
+  c->d_sort_tmp.release(); c->d_posq.release(); c->d_grid.release(); c->d_fft_work.release();
+  for (int p = 0; p < PH_COUNT; ++p) { if (c->ph[p].e0) { (void)hipEventDestroy(c->ph[p].e0); (void)hipEventDestroy(c->ph[p].e1); } }
+  if (c->h_energies) (void)hipHostFree(c->h_energies);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return MSEVB_OK;
+}
+
+const char* msevb_last_error(const msevb_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int msevb_set_stream(msevb_ctx* c, void* s) {
+  if (!c) return MSEVB_ERR_ARG;
+  if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
+  else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+  if (c->fft_info) rocfft_execution_info_set_stream(c->fft_info, c->stream);
+  return MSEVB_OK;
+}
+int msevb_synchronize(msevb_ctx* c) { HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
+
+int msevb_set_system(msevb_ctx* c, int N, int M, const double* box, double rc, double rv, double alpha, int K, int order, int spline_grid, int erfc_grid) {
+  if (!c || N <= 0 || M <= 0 || !box || K <= 0) { if (c) c->err = "msevb_set_system: bad argument"; return MSEVB_ERR_ARG; }
+  // box(3,3) column-major; only orthorhombic boxes are supported, as in the reference (src/main_ms_evb.f90:62-68)
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) if (i != j && fabs(box[i + 3 * j]) > 1e-5) FAIL(MSEVB_ERR_ARG, "code assumes an orthorhombic box");
+  if (!(rc < rv)) FAIL(MSEVB_ERR_ARG, "verlet_cutoff must be set greater than real_space_cutoff");
+  for (int d = 0; d < 3; ++d) {
+    c->box[d] = box[d + 3 * d];
+    if (rv >= 0.5 * c->box[d]) FAIL(MSEVB_ERR_ARG, "verlet skin width is too big for this box");
+  }
+  c->N = N; c->M = M; c->rc = rc; c->rv = rv; c->alpha = alpha; c->K = K; c->order = order; c->spline_grid = spline_grid; c->erfc_grid = erfc_grid;
+  c->finalized = false;
+  return MSEVB_OK;
+}
+
+int msevb_set_atoms(msevb_ctx* c, const int* atype, const double* chg, const double* mass, const int* first, const int* natom, const int* mtype) {
+  if (!c || c->N <= 0) return MSEVB_ERR_STATE;
+  const int N = c->N, M = c->M;
+  c->h_atype.assign(N, 0); c->h_chg.assign(chg, chg + N); c->h_mass.assign(mass, mass + N);
+  for (int i = 0; i < N; ++i) c->h_atype[i] = atype[i] - 1;
+  c->h_mol_type.assign(M, 0); c->h_mol_natom.assign(natom, natom + M); c->h_mol_atoms.assign((size_t)M * MAX_MOL_ATOMS, -1); c->h_mol_of.assign(N, -1);
+  for (int m = 0; m < M; ++m) {
+    c->h_mol_type[m] = mtype[m] - 1;
+    if (natom[m] > MAX_MOL_ATOMS - 1) FAIL(MSEVB_ERR_LIMIT, "molecule with more than 7 atoms (one slot is reserved for an accepted proton)");
+    for (int k = 0; k < natom[m]; ++k) {
+      const int a = first[m] - 1 + k;
+      if (a < 0 || a >= N) FAIL(MSEVB_ERR_ARG, "molecule atom index out of range");
+      c->h_mol_atoms[(size_t)m * MAX_MOL_ATOMS + k] = a; c->h_mol_of[a] = m;
+    }
+  }
+  for (int i = 0; i < N; ++i) if (c->h_mol_of[i] < 0) FAIL(MSEVB_ERR_ARG, "atom not covered by any molecule");
+  c->finalized = false;
+  return MSEVB_OK;
+}
+
+int msevb_set_forcefield(msevb_ctx* c, int nt, int ld, const int* vt, const double* vp, const double* vp14, const int* bt, const double* bp, const double* chg) {
+  if (!c || nt <= 0 || nt > MAX_TYPES || ld < nt) return MSEVB_ERR_ARG;
+  c->nt = nt;
+  c->h_vdw_type.assign(nt * nt, 0); c->h_vdw_par.assign(nt * nt * 6, 0); c->h_vdw_par14.assign(nt * nt * 6, 0); c->h_bond_type.assign(nt * nt, 0);
+  c->h_bond_par.assign(nt * nt * 3, 0); c->h_atype_chg.assign(chg, chg + nt);
+  for (int i = 0; i < nt; ++i) for (int j = 0; j < nt; ++j) {
+    c->h_vdw_type[i * nt + j] = vt[i + ld * j]; c->h_bond_type[i * nt + j] = bt[i + ld * j];
+    for (int k = 0; k < 6; ++k) { c->h_vdw_par[(i * nt + j) * 6 + k] = vp[i + ld * (j + ld * k)]; c->h_vdw_par14[(i * nt + j) * 6 + k] = vp14[i + ld * (j + ld * k)]; }
+    for (int k = 0; k < 3; ++k) c->h_bond_par[(i * nt + j) * 3 + k] = bp[i + ld * (j + ld * k)];
+  }
+  c->finalized = false;
+  return MSEVB_OK;
+}
+
+int msevb_set_angle_types(msevb_ctx* c, int n, const int* idx, const double* par) {
+  c->h_ang_idx.assign(idx, idx + 4 * n); c->h_ang_par.assign(par, par + 2 * n);
+  for (int a = 0; a < n; ++a) for (int k = 0; k < 3; ++k) c->h_ang_idx[4 * a + k] -= 1;
+  c->finalized = false;
+  return MSEVB_OK;
+}
+int msevb_set_dihedral_types(msevb_ctx* c, int n, const int* idx, const double* par) {
+  c->h_dih_idx.assign(idx, idx + 5 * n); c->h_dih_par.assign(par, par + 6 * n);
+  for (int a = 0; a < n; ++a) for (int k = 0; k < 4; ++k) c->h_dih_idx[5 * a + k] -= 1;
+  c->finalized = false;
+  return MSEVB_OK;
+}
+
+int msevb_set_molecule_type(msevb_ctx* c, int it, int na, const int* atype, int nb, const int* bonds, int nang, const int* angles, int nd, const int* dihs,
+                            const int* excl, const int* rp, const int* rb) {
+  if (!c || it < 1 || it > MAX_MOLTYPES || na < 1 || na > MAX_MOL_ATOMS) return MSEVB_ERR_ARG;
+  if (nb > MAX_BONDED || nang > MAX_BONDED || nd > MAX_BONDED) FAIL(MSEVB_ERR_LIMIT, "too many bonded terms in one molecule type");
+  MolTypeHost& m = c->h_mt[it - 1];
+  m.natom = na;
+  m.atype.assign(na, 0); for (int i = 0; i < na; ++i) m.atype[i] = atype[i] - 1;
+  m.bonds.assign(bonds, bonds + 2 * nb); for (auto& v : m.bonds) v -= 1;
+  m.angles.assign(angles, angles + 3 * nang); for (auto& v : m.angles) v -= 1;
+  m.dihedrals.assign(dihs, dihs + 4 * nd); for (auto& v : m.dihedrals) v -= 1;
+  m.excl.assign(na * na, 0);
+  for (int i = 0; i < na; ++i) for (int j = 0; j < na; ++j) m.excl[i * na + j] = excl[i + na * j];   // pair_exclusions(i,j) column-major
+  m.reactive_protons.assign(na, 0); m.reactive_basic.assign(na, 0);
+  if (rp) m.reactive_protons.assign(rp, rp + na);
+  if (rb) m.reactive_basic.assign(rb, rb + na);
+  if (it > c->nmt) c->nmt = it;
+  c->finalized = false;
+  return MSEVB_OK;
+}
+
+int msevb_set_evb(msevb_ctx* c, int nmt, int ld_m, int ld_i, const int* acid, const int* base, const int* conj, const int* pidx, const int* hidx,
+                  const int* conj_at, const double* eref, const double* exa, const double* exp_, const int* da_i, const double* da_p, const int* pa_i,
+                  const double* pa_p, const int* cp_i, const double* cp_p, const int* cp_t, int hyd, int max_chain) {
+  if (!c || nmt > MAX_MOLTYPES || max_chain > MAX_CHAIN || max_chain < 1) return MSEVB_ERR_ARG;
+  if (nmt > c->nmt) c->nmt = nmt;
+  for (int i = 0; i < nmt; ++i) {
+    c->e_acid[i] = acid[i]; c->e_base[i] = base[i]; c->e_conj_mol[i] = conj[i] - 1; c->e_proton_type[i] = pidx[i] - 1; c->e_heavy_type[i] = hidx[i] - 1;
+    c->e_ref[i] = eref[i];
+    for (int j = 0; j < nmt; ++j) c->e_exch_proton[i][j] = exp_[i + ld_m * j];
+  }
+  for (int i = 0; i < c->nt; ++i) { c->e_conj_atype[i] = conj_at[i] - 1; c->e_exch_atomic[i] = exa[i]; }
+  c->n_da = c->n_pa = c->n_cp = 0;
+  for (int r = 0; r < ld_i && r < MAX_INTERACTION; ++r) { if (da_i[r] == 0) break;
+    for (int k = 0; k < 3; ++k) c->da_types[r][k] = da_i[r + ld_i * k] - 1;
+    for (int k = 0; k < 6; ++k) c->da_par[r][k] = da_p[r + ld_i * k];
+    c->n_da++; }
+  for (int r = 0; r < ld_i && r < MAX_INTERACTION; ++r) { if (pa_i[r] == 0) break;
+    for (int k = 0; k < 2; ++k) c->pa_types[r][k] = pa_i[r + ld_i * k] - 1;
+    for (int k = 0; k < 5; ++k) c->pa_par[r][k] = pa_p[r + ld_i * k];
+    c->n_pa++; }
+  for (int r = 0; r < ld_i && r < MAX_INTERACTION; ++r) { if (cp_i[r] == 0) break;
+    for (int k = 0; k < 3; ++k) c->cp_types[r][k] = cp_i[r + ld_i * k] - 1;
+    for (int k = 0; k < 10; ++k) c->cp_par[r][k] = cp_p[r + ld_i * k];
+    c->cp_func[r] = cp_t[r];
+    c->n_cp++; }
+  c->hydronium = hyd - 1; c->max_chain = max_chain; c->evb_set = true;
+  return MSEVB_OK;
+}
+
+static int resolve_moltypes(msevb_ctx* c, std::vector<MolTypeDev>& out) {
+  const int nt = c->nt;
+  out.assign(c->nmt, MolTypeDev());
+  for (int it = 0; it < c->nmt; ++it) {
+    const MolTypeHost& h = c->h_mt[it];
+    MolTypeDev& d = out[it];
+    memset(&d, 0, sizeof(d));
+    if (h.natom == 0) continue;
+    d.natom = h.natom; d.nb = (int)h.bonds.size() / 2; d.na = (int)h.angles.size() / 3; d.nd = (int)h.dihedrals.size() / 4;
+    for (int i = 0; i < h.natom; ++i) d.atype[i] = h.atype[i];
+    for (int b = 0; b < d.nb; ++b) {
+      const int i = h.bonds[2 * b], j = h.bonds[2 * b + 1], ti = h.atype[i], tj = h.atype[j];
+      d.bond[b][0] = i; d.bond[b][1] = j; d.bond_type[b] = c->h_bond_type[ti * nt + tj];
+      if (d.bond_type[b] < 1 || d.bond_type[b] > 3) FAIL(MSEVB_ERR_ARG, "bond type isn't implemented! Please select 1 (harmonic), 2 (GROMOS-96) or 3 (Morse)");
+      for (int k = 0; k < 3; ++k) d.bond_par[b][k] = c->h_bond_par[(ti * nt + tj) * 3 + k];
+    }
+    for (int a = 0; a < d.na; ++a) {
+      int t[3];
+      for (int k = 0; k < 3; ++k) { d.ang[a][k] = h.angles[3 * a + k]; t[k] = h.atype[d.ang[a][k]]; }
+      int found = -1;
+      for (size_t r = 0; r < c->h_ang_idx.size() / 4; ++r) if (c->h_ang_idx[4 * r] == t[0] && c->h_ang_idx[4 * r + 1] == t[1] && c->h_ang_idx[4 * r + 2] == t[2]) { found = (int)r; break; }
+      if (found < 0) FAIL(MSEVB_ERR_ARG, "requested angle type potential not implemented (no angletype for an angle of a molecule type)");
+      d.ang_type[a] = c->h_ang_idx[4 * found + 3]; d.ang_par[a][0] = c->h_ang_par[2 * found]; d.ang_par[a][1] = c->h_ang_par[2 * found + 1];
+    }
+    for (int q = 0; q < d.nd; ++q) {
+      int t[4];
+      for (int k = 0; k < 4; ++k) { d.dih[q][k] = h.dihedrals[4 * q + k]; t[k] = h.atype[d.dih[q][k]]; }
+      int found = -1;
+      for (size_t r = 0; r < c->h_dih_idx.size() / 5; ++r)
+        if (c->h_dih_idx[5 * r] == t[0] && c->h_dih_idx[5 * r + 1] == t[1] && c->h_dih_idx[5 * r + 2] == t[2] && c->h_dih_idx[5 * r + 3] == t[3]) { found = (int)r; break; }
+      if (found < 0) FAIL(MSEVB_ERR_ARG, "no dihedraltype for a dihedral of a molecule type");
+      d.dih_type[q] = c->h_dih_idx[5 * found + 4];
+      for (int k = 0; k < 6; ++k) d.dih_par[q][k] = c->h_dih_par[6 * found + k];
+    }
+    for (int i = 0; i < h.natom; ++i) for (int j = 0; j < h.natom; ++j) {
+      d.excl[i][j] = h.excl[i * h.natom + j];
+      const int ti = h.atype[i], tj = h.atype[j];
+      PairParam& pp = d.nb_par[i][j];
+      pp.type = c->h_vdw_type[ti * nt + tj];
+      const std::vector<double>& src = (d.excl[i][j] == 2 && pp.type == 0) ? c->h_vdw_par14 : c->h_vdw_par;
+      pp.nonzero = 0;
+      for (int k = 0; k < 6; ++k) { pp.p[k] = src[(ti * nt + tj) * 6 + k]; if (k != 1 && pp.p[k] != 0.0) pp.nonzero = 1; }
+      if (pp.type == 0) pp.nonzero = 1;
+    }
+  }
+  return MSEVB_OK;
+}
+
+int upload_topology(msevb_ctx* c) {   // atom types / charges / molecule membership (changes with the principal diabat)
+  const int N = c->N, M = c->M;
+  HIPCHK(hipMemcpyAsync(c->d_atype.p, c->h_atype.data(), N * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_chg.p, c->h_chg.data(), N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_mol_type.p, c->h_mol_type.data(), M * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_mol_natom.p, c->h_mol_natom.data(), M * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_mol_atoms.p, c->h_mol_atoms.data(), (size_t)M * MAX_MOL_ATOMS * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_mol_of.p, c->h_mol_of.data(), N * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MSEVB_OK;
+}
+
+int msevb_finalize(msevb_ctx* c) {
+  if (!c || c->N <= 0 || c->nt <= 0 || c->h_atype.empty()) { if (c) c->err = "msevb_finalize: system, atoms and force field must be set first"; return MSEVB_ERR_STATE; }
+  HIPCHK(hipSetDevice(c->device));
+  const int N = c->N, M = c->M, nt = c->nt;
+  for (int i = 0; i < N; ++i) if (c->h_atype[i] < 0 || c->h_atype[i] >= nt) FAIL(MSEVB_ERR_ARG, "atom_type_index out of range");
+  for (int m = 0; m < M; ++m) {
+    const int t = c->h_mol_type[m];
+    if (t < 0 || t >= c->nmt || c->h_mt[t].natom == 0) FAIL(MSEVB_ERR_ARG, "couldn't find '[ moleculetype ]' data for a molecule type in use");
+    if (c->h_mt[t].natom != c->h_mol_natom[m]) FAIL(MSEVB_ERR_ARG, "molecule size does not match its molecule type");
+  }
+  // B_max * rc must stay inside the Tang-Toennies table (src/initialize_routines.f90:553)
+  for (int k = 0; k < nt * nt; ++k) if (c->h_vdw_type[k] == 1 && c->h_vdw_par[k * 6 + 1] * c->rc > TT_MAX) FAIL(MSEVB_ERR_ARG, "Table size for damping function is smaller than B_max*the real space cutoff");
+  CHK(build_tables(c));
+  if (c->d_atype.alloc(N) || c->d_chg.alloc(N) || c->d_mass.alloc(N) || c->d_mol_type.alloc(M) || c->d_mol_natom.alloc(M) ||
+      c->d_mol_atoms.alloc((size_t)M * MAX_MOL_ATOMS) || c->d_mol_of.alloc(N) || c->d_xyz.alloc(3 * (size_t)N) || c->d_vel.alloc(3 * (size_t)N) ||
+      c->d_force.alloc(3 * (size_t)N) || c->d_posq.alloc(N) || c->d_type_sorted.alloc(N) || c->d_mol_sorted.alloc(N) ||
+      c->d_partials.alloc((size_t)N_SLOTS * MAX_BLOCKS) || c->d_energies.alloc(N_SLOTS) || c->d_pair_par.alloc(nt * nt) || c->d_moltypes.alloc(c->nmt) ||
+      c->d_ewald_tab.alloc(c->erfc_grid + 1) || c->d_B6.alloc(c->spline_grid) || c->d_B5.alloc(c->spline_grid) || c->d_tt.alloc(4 * TT_GRID) ||
+      c->d_dtt.alloc(4 * TT_GRID) || c->d_CB.alloc(c->t_CB.size()))
+    FAIL(MSEVB_ERR_HIP, "hipMalloc failed");
+  CHK(upload_topology(c));
+  HIPCHK(hipMemcpy(c->d_mass.p, c->h_mass.data(), N * sizeof(double), hipMemcpyHostToDevice));
+  std::vector<PairParam> pp(nt * nt);
+  for (int k = 0; k < nt * nt; ++k) {
+    pp[k].type = c->h_vdw_type[k];
+    pp[k].nonzero = pp[k].type == 0 ? 1 : 0;
+    for (int q = 0; q < 6; ++q) { pp[k].p[q] = c->h_vdw_par[k * 6 + q]; if (pp[k].type == 1 && q != 1 && pp[k].p[q] != 0.0) pp[k].nonzero = 1; }
+  }
+  HIPCHK(hipMemcpy(c->d_pair_par.p, pp.data(), pp.size() * sizeof(PairParam), hipMemcpyHostToDevice));
+  std::vector<MolTypeDev> mts;
+  CHK(resolve_moltypes(c, mts));
+  HIPCHK(hipMemcpy(c->d_moltypes.p, mts.data(), mts.size() * sizeof(MolTypeDev), hipMemcpyHostToDevice));
+  std::vector<double2> et(c->erfc_grid + 1);
+  for (int i = 0; i <= c->erfc_grid; ++i) et[i] = make_double2(c->t_erfc[i], c->t_scale[i]);
+  HIPCHK(hipMemcpy(c->d_ewald_tab.p, et.data(), et.size() * sizeof(double2), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_B6.p, c->t_B6.data(), c->t_B6.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_B5.p, c->t_B5.data(), c->t_B5.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_tt.p, c->t_tt.data(), c->t_tt.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_dtt.p, c->t_dtt.data(), c->t_dtt.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_CB.p, c->t_CB.data(), c->t_CB.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(c->d_vel.p, 0, 3 * (size_t)N * 8));
+  HIPCHK(hipMemset(c->d_force.p, 0, 3 * (size_t)N * 8));
+  HIPCHK(hipMemset(c->d_energies.p, 0, N_SLOTS * 8));
+  CHK(pme_setup(c));
+  c->h_xyz.assign(3 * (size_t)N, 0.0);
+  c->list_valid = false;
+  c->flag_verlet_list = 1;
+  c->finalized = true;
+  return MSEVB_OK;
+}
+
+int msevb_get_table(msevb_ctx* c, const char* name, double* out, int n) {
+  const std::vector<double>* t = nullptr;
+  const std::string s(name);
+  if (s == "B6_spline") t = &c->t_B6; else if (s == "B5_spline") t = &c->t_B5; else if (s == "erfc_table") t = &c->t_erfc;
+  else if (s == "ewaldscale_table") t = &c->t_scale; else if (s == "Tang_Toennies_table") t = &c->t_tt; else if (s == "dTang_Toennies_table") t = &c->t_dtt;
+  else if (s == "CB") t = &c->t_CB;
+  if (!t) return MSEVB_ERR_ARG;
+  if (out) memcpy(out, t->data(), sizeof(double) * (size_t)std::min<size_t>(n, t->size()));
+  return (int)t->size();
+}
+int msevb_get_ewald_self(msevb_ctx* c, double* e) { *e = c->ewald_self; return MSEVB_OK; }
+
+#define NEED_FINAL() do { if (!c || !c->finalized) { if (c) c->err = "context not finalized (msevb_finalize)"; return MSEVB_ERR_STATE; } (void)hipSetDevice(c->device); } while (0)
+
+int msevb_set_positions(msevb_ctx* c, const double* xyz) {
+  NEED_FINAL();
+  memcpy(c->h_xyz.data(), xyz, 3 * (size_t)c->N * 8);
+  HIPCHK(hipMemcpyAsync(c->d_xyz.p, xyz, 3 * (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MSEVB_OK;
+}
+int msevb_get_positions(msevb_ctx* c, double* xyz) { NEED_FINAL(); HIPCHK(hipMemcpyAsync(xyz, c->d_xyz.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
+int msevb_set_velocities(msevb_ctx* c, const double* v) { NEED_FINAL(); HIPCHK(hipMemcpyAsync(c->d_vel.p, v, 3 * (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
+int msevb_get_velocities(msevb_ctx* c, double* v) { NEED_FINAL(); HIPCHK(hipMemcpyAsync(v, c->d_vel.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
+int msevb_get_forces(msevb_ctx* c, double* f) { NEED_FINAL(); HIPCHK(hipMemcpyAsync(f, c->d_force.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
+void* msevb_device_forces(msevb_ctx* c) { return c ? c->d_force.p : nullptr; }
+void* msevb_device_positions(msevb_ctx* c) { return c ? c->d_xyz.p : nullptr; }
+
+int msevb_construct_verlet_list(msevb_ctx* c) { NEED_FINAL(); CHK(nb_build(c)); c->flag_verlet_list = 0; return MSEVB_OK; }
+
+int msevb_update_verlet_displacements(msevb_ctx* c, int* flag) {
+  NEED_FINAL();
+  CHK(nb_check_displacements(c, 0, nullptr));
+  CHK(fetch_energies(c));
+  const double skin = 1.2 * (c->rv - c->rc);   // verlet_thresh = 1.2d0 (src/glob_v.f90:394, src/general_routines.f90:1320)
+  c->flag_verlet_list = (c->h_energies[S_MAXD1] + c->h_energies[S_MAXD2]) > skin ? 1 : 0;
+  if (flag) *flag = c->flag_verlet_list;
+  return MSEVB_OK;
+}
+
+int msevb_get_verlet_list(msevb_ctx* c, int* vp, int* nl, long* nn) {
+  NEED_FINAL();
+  if (!c->list_valid) FAIL(MSEVB_ERR_STATE, "no Verlet list");
+  const int N = c->N;
+  std::vector<unsigned> st(N + 1);
+  std::vector<int> nb(c->n_nbr), perm(N);
+  HIPCHK(hipMemcpy(st.data(), c->d_nbr_start.p, (N + 1) * sizeof(unsigned), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(nb.data(), c->d_nbr.p, c->n_nbr * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(perm.data(), c->d_perm.p, N * sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<std::vector<int>> half(N);
+  for (int k = 0; k < N; ++k) { const int i = perm[k]; for (unsigned q = st[k]; q < st[k + 1]; ++q) { const int j = perm[nb[q]]; if (j > i) half[i].push_back(j); } }
+  long tot = 0;
+  for (int i = 0; i < N; ++i) { std::sort(half[i].begin(), half[i].end()); if (vp) vp[i] = (int)tot + 1; if (nl) for (int j : half[i]) nl[tot++] = j + 1; else tot += (long)half[i].size(); }
+  if (vp) vp[N] = (int)tot + 1;
+  if (nn) *nn = tot;
+  return MSEVB_OK;
+}
+
+int msevb_zero_forces(msevb_ctx* c) { NEED_FINAL(); HIPCHK(hipMemsetAsync(c->d_force.p, 0, 3 * (size_t)c->N * 8, c->stream)); return MSEVB_OK; }
+
+int msevb_real_space_energy_force(msevb_ctx* c, double* e) {
+  NEED_FINAL();
+  if (!c->list_valid) CHK(nb_build(c)); else CHK(nb_refresh_sorted(c));
+  CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
+  CHK(molecule_forces(c, S_ELEC_INTRA, true, false));
+  CHK(fetch_energies(c));
+  if (e) { e[0] = c->h_energies[S_ELEC_PAIR]; e[1] = c->h_energies[S_VDW_PAIR]; e[2] = c->h_energies[S_ELEC_INTRA]; e[3] = c->h_energies[S_VDW_INTRA]; }
+  return MSEVB_OK;
+}
+int msevb_pme_reciprocal_space_energy_force(msevb_ctx* c, double* e) {
+  NEED_FINAL();
+  CHK(pme_forces(c, S_RECIP));
+  CHK(fetch_energies(c));
+  c->E_recip = c->h_energies[S_RECIP];
+  if (e) *e = c->E_recip;
+  return MSEVB_OK;
+}
+int msevb_intra_molecular_energy_force(msevb_ctx* c, double* e) {
+  NEED_FINAL();
+  CHK(molecule_forces(c, S_ELEC_INTRA, false, true));
+  CHK(fetch_energies(c));
+  if (e) { e[0] = c->h_energies[S_BOND]; e[1] = c->h_energies[S_ANGLE]; e[2] = c->h_energies[S_DIH]; }
+  return MSEVB_OK;
+}
+
+// the principal-diabat force call, everything enqueued on the stream; energies land in c->h_energies after fetch_energies()
+int total_force_enqueue(msevb_ctx* c) {
+  // Verlet freshness: src/total_energy_forces.f90:30-39 (rebuild when the flag was raised by the previous call)
+  if (c->flag_verlet_list == 1 || !c->list_valid) { CHK(nb_build(c)); c->flag_verlet_list = 0; }
+  else { CHK(nb_check_displacements(c, 0, nullptr)); CHK(nb_refresh_sorted(c)); }
+  HIPCHK(hipMemsetAsync(c->d_force.p, 0, 3 * (size_t)c->N * 8, c->stream));
+  CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
+  CHK(molecule_forces(c, S_ELEC_INTRA, true, true));
+  CHK(pme_forces(c, S_RECIP));
+  return MSEVB_OK;
+}
+void total_force_collect(msevb_ctx* c, double* en) {
+  const double* h = c->h_energies;
+  if (c->list_valid) {   // flag for the NEXT call (src/general_routines.f90:1320-1326)
+    const double skin = 1.2 * (c->rv - c->rc);
+    if ((h[S_MAXD1] + h[S_MAXD2]) > skin) c->flag_verlet_list = 1;
+  }
+  c->E_recip = h[S_RECIP];
+  en[MSEVB_E_ELEC] = h[S_ELEC_PAIR] + h[S_ELEC_INTRA] + h[S_RECIP] + c->ewald_self;
+  en[MSEVB_E_VDW] = h[S_VDW_PAIR] + h[S_VDW_INTRA];
+  en[MSEVB_E_BOND] = h[S_BOND]; en[MSEVB_E_ANGLE] = h[S_ANGLE]; en[MSEVB_E_DIHEDRAL] = h[S_DIH]; en[MSEVB_E_RECIP] = h[S_RECIP];
+  en[MSEVB_E_POTENTIAL] = en[MSEVB_E_ELEC] + en[MSEVB_E_VDW] + en[MSEVB_E_BOND] + en[MSEVB_E_ANGLE] + en[MSEVB_E_DIHEDRAL];
+  en[7] = 0.0;
+}
+
+int msevb_calculate_total_force_energy(msevb_ctx* c, double* energies, double* force) {
+  NEED_FINAL();
+  CHK(total_force_enqueue(c));
+  if (force) HIPCHK(hipMemcpyAsync(force, c->d_force.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
+  CHK(fetch_energies(c));
+  double en[MSEVB_N_ENERGY];
+  total_force_collect(c, en);
+  if (energies) memcpy(energies, en, sizeof en);
+  return MSEVB_OK;
+}
+
+int msevb_get_pme_state(msevb_ctx* c, double* Q, double* theta, double* us, double* fr) {
+  NEED_FINAL();
+  const size_t K3 = (size_t)c->K * c->K * c->K;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (Q) HIPCHK(hipMemcpy(Q, c->d_Q.p, K3 * 8, hipMemcpyDeviceToHost));
+  if (theta) { std::vector<double2> g(K3); HIPCHK(hipMemcpy(g.data(), c->d_grid.p, K3 * 16, hipMemcpyDeviceToHost)); for (size_t k = 0; k < K3; ++k) theta[k] = g[k].x; }
+  if (us) HIPCHK(hipMemcpy(us, c->d_uscale.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost));
+  if (fr) HIPCHK(hipMemcpy(fr, c->d_force_recip.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost));
+  return MSEVB_OK;
+}
+int msevb_get_pme_indices(msevb_ctx* c, int* nearpt, int* splindex) {
+  NEED_FINAL();
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (nearpt) HIPCHK(hipMemcpy(nearpt, c->d_base.p, 3 * (size_t)c->N * 4, hipMemcpyDeviceToHost));
+  if (splindex) HIPCHK(hipMemcpy(splindex, c->d_splindex.p, 18 * (size_t)c->N * 4, hipMemcpyDeviceToHost));
+  return MSEVB_OK;
+}
+
+int msevb_get_topology(msevb_ctx* c, int* at, double* chg, int* mn, int* mt, int* ma, int* hyd) {
+  if (!c) return MSEVB_ERR_ARG;
+  if (at) for (int i = 0; i < c->N; ++i) at[i] = c->h_atype[i] + 1;
+  if (chg) memcpy(chg, c->h_chg.data(), c->N * 8);
+  if (mn) memcpy(mn, c->h_mol_natom.data(), c->M * 4);
+  if (mt) for (int m = 0; m < c->M; ++m) mt[m] = c->h_mol_type[m] + 1;
+  if (ma) for (size_t k = 0; k < (size_t)c->M * MAX_MOL_ATOMS; ++k) ma[k] = c->h_mol_atoms[k] + 1;
+  if (hyd) *hyd = c->hydronium + 1;
+  return MSEVB_OK;
+}
+
+int msevb_get_phase_times(msevb_ctx* c, int* n, const char** names, double* ms, long* calls) {
+  if (!c) return MSEVB_ERR_ARG;
+  (void)hipStreamSynchronize(c->stream);
+  for (int p = 0; p < PH_COUNT; ++p) {
+    PhaseTimer& t = c->ph[p];
+    if (t.pending) { float v = 0; if (hipEventSynchronize(t.e1) == hipSuccess && hipEventElapsedTime(&v, t.e0, t.e1) == hipSuccess) { t.ms += v; t.calls++; } t.pending = false; }
+    if (names) names[p] = t.name.c_str();
+    if (ms) ms[p] = t.calls ? t.ms / t.calls : 0.0;
+    if (calls) calls[p] = t.calls;
+  }
+  if (n) *n = PH_COUNT;
+  return MSEVB_OK;
+}
+int msevb_reset_phase_times(msevb_ctx* c) { for (int p = 0; p < PH_COUNT; ++p) { c->ph[p].ms = 0; c->ph[p].calls = 0; c->ph[p].pending = false; } return MSEVB_OK; }
+int msevb_set_option(msevb_ctx* c, const char* name, double v) {
+  const std::string s(name);
+  if (s == "phase_timing") { c->timing = v != 0.0; return MSEVB_OK; }
+  if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
+  c->err = "unknown option " + s;
+  return MSEVB_ERR_ARG;
+}
+
+}  // extern "C"

@@ -1,0 +1,228 @@
+// Private definitions of libmsevb_hip.so (gfx950 only).  Public ABI: include/msevb_hip.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/msevb_hip.h"
+
+constexpr int MAX_MOL_ATOMS = 8;
+constexpr int MAX_TYPES = 32;
+constexpr int MAX_MOLTYPES = 10;
+constexpr int MAX_BONDED = 16;
+constexpr int TT_GRID = 1000;
+constexpr double TT_MAX = 50.0;
+constexpr int MAX_INTERACTION = 15;
+constexpr int MAX_DIABATS = 80;
+constexpr int MAX_CHAIN = 4;
+constexpr int WAVE = 64;
+
+#define HIPCHK(call)                                                                                       \
+  do {                                                                                                     \
+    hipError_t e_ = (call);                                                                                \
+    if (e_ != hipSuccess) {                                                                                \
+      char b_[512];                                                                                        \
+      snprintf(b_, sizeof b_, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_));         \
+      c->err = b_;                                                                                         \
+      return MSEVB_ERR_HIP;                                                                                \
+    }                                                                                                      \
+  } while (0)
+#define FAIL(code, msg) do { c->err = (msg); return (code); } while (0)
+#define CHK(call) do { int r_ = (call); if (r_ != MSEVB_OK) return r_; } while (0)
+
+// ---- device-side parameter blocks -------------------------------------------------------------------
+struct PairParam {  // one (type_i,type_j) entry of atype_vdw_type / atype_vdw_parameter, 64 B
+  double p[6];      // LJ: C12,C6 ; SAPT: A,B,C6,C8,C10,C12
+  int type;         // 0 LJ, 1 SAPT, -1 none
+  int nonzero;      // 0: every coefficient is zero, the vdW term contributes exactly 0
+};
+
+struct MolTypeDev {
+  int natom, nb, na, nd;
+  int atype[MAX_MOL_ATOMS];
+  int bond[MAX_BONDED][2], bond_type[MAX_BONDED];
+  double bond_par[MAX_BONDED][3];
+  int ang[MAX_BONDED][3], ang_type[MAX_BONDED];
+  double ang_par[MAX_BONDED][2];
+  int dih[MAX_BONDED][4], dih_type[MAX_BONDED];
+  double dih_par[MAX_BONDED][6];
+  int excl[MAX_MOL_ATOMS][MAX_MOL_ATOMS];
+  PairParam nb_par[MAX_MOL_ATOMS][MAX_MOL_ATOMS];  // 1-4 parameters already substituted where excl==2
+};
+
+struct BoxDev { double L[3], invL[3]; };
+
+// host mirror of a molecule type (as set through the ABI)
+struct MolTypeHost {
+  int natom = 0;
+  std::vector<int> atype, bonds, angles, dihedrals, excl, reactive_protons, reactive_basic;
+};
+
+struct PhaseTimer {
+  std::string name;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  double ms = 0;
+  long calls = 0;
+  bool pending = false;
+};
+
+enum Phase { PH_VERLET = 0, PH_SORT, PH_PAIR, PH_MOLECULE, PH_SPREAD, PH_FFT, PH_GATHER, PH_EVB_REAL, PH_EVB_RECIP, PH_EVB_BLEND, PH_INTEGRATE, PH_COUNT };
+
+template <class T>
+struct DBuf {  // device buffer
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    if (count <= n && p) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    if (hipMalloc((void**)&p, (count ? count : 1) * sizeof(T)) != hipSuccess) return -1;
+    n = count;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct EvbHop { int donor_mol, proton_local, heavy_local, acceptor_mol, acceptor_heavy_local; };
+
+struct msevb_ctx {
+  std::string err;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool finalized = false;
+
+  // ---- configuration
+  int N = 0, M = 0, K = 0, order = 6, spline_grid = 100000, erfc_grid = 100000;
+  double box[3] = {0, 0, 0}, rc = 0, rv = 0, alpha = 0;
+  double pi = 3.141592654, pi_sqrt = 1.772453851, conv = (double)1389.35465f;
+  int nt = 0, nmt = 0;
+
+  // ---- host copies of static data (0-based internally)
+  std::vector<int> h_atype, h_mol_type, h_mol_natom, h_mol_atoms, h_mol_of;
+  std::vector<double> h_chg, h_mass, h_atype_chg;
+  std::vector<int> h_vdw_type, h_bond_type;
+  std::vector<double> h_vdw_par, h_vdw_par14, h_bond_par;
+  std::vector<int> h_ang_idx, h_dih_idx;
+  std::vector<double> h_ang_par, h_dih_par;
+  MolTypeHost h_mt[MAX_MOLTYPES];
+  std::vector<double> h_xyz;
+  // tables
+  std::vector<double> t_B6, t_B5, t_erfc, t_scale, t_tt, t_dtt, t_CB;
+  double erfc_dx = 0, ewald_self = 0, kk[3][3];
+
+  // ---- EVB host tables
+  bool evb_set = false;
+  int e_acid[MAX_MOLTYPES], e_base[MAX_MOLTYPES], e_conj_mol[MAX_MOLTYPES], e_proton_type[MAX_MOLTYPES], e_heavy_type[MAX_MOLTYPES];
+  int e_conj_atype[MAX_TYPES];
+  double e_ref[MAX_MOLTYPES], e_exch_atomic[MAX_TYPES], e_exch_proton[MAX_MOLTYPES][MAX_MOLTYPES];
+  int n_da = 0, da_types[MAX_INTERACTION][3]; double da_par[MAX_INTERACTION][6];
+  int n_pa = 0, pa_types[MAX_INTERACTION][2]; double pa_par[MAX_INTERACTION][5];
+  int n_cp = 0, cp_types[MAX_INTERACTION][3], cp_func[MAX_INTERACTION]; double cp_par[MAX_INTERACTION][10];
+  int hydronium = -1, max_chain = 3;
+
+  // ---- device: static
+  DBuf<int> d_atype, d_mol_type, d_mol_natom, d_mol_atoms, d_mol_of;
+  DBuf<double> d_chg, d_mass;
+  DBuf<PairParam> d_pair_par;
+  DBuf<MolTypeDev> d_moltypes;
+  DBuf<double2> d_ewald_tab;     // {erfc_table, ewaldscale_table} interleaved
+  DBuf<double> d_B6, d_B5, d_tt, d_dtt, d_CB;
+  // ---- device: per step
+  DBuf<double> d_xyz, d_vel, d_force, d_force_recip;
+  DBuf<double> d_xyz_store, d_disp;       // Verlet displacement bookkeeping
+  DBuf<double> d_maxdisp;
+  // neighbour structure (sorted order)
+  int ncell[3] = {1, 1, 1};
+  DBuf<int> d_cell_of, d_perm, d_cell_keys_tmp, d_perm_tmp, d_cell_start, d_inv_perm;
+  DBuf<unsigned> d_nbr_count, d_nbr_start;
+  DBuf<int> d_nbr;
+  DBuf<char> d_sort_tmp;
+  size_t n_nbr = 0;
+  bool list_valid = false;
+  int flag_verlet_list = 0;
+  DBuf<double4> d_posq;        // sorted {x,y,z,q}
+  DBuf<int> d_type_sorted, d_mol_sorted;
+  // PME
+  DBuf<double2> d_grid;        // complex K^3 (x fastest), in place FFT
+  DBuf<double> d_Q;            // real copy of the spread grid (kept for the EVB delta path)
+  DBuf<double> d_w, d_dw, d_uscale;   // per atom: B6 weights [N][3][6], derivative weights, scaled coords
+  DBuf<int> d_base, d_splindex;       // nearpt [N][3], B6 rows [N][3][6]
+  rocfft_plan plan_fwd = nullptr, plan_bwd = nullptr;
+  rocfft_execution_info fft_info = nullptr;
+  DBuf<char> d_fft_work;
+  int fft_batch = 1;
+  // reductions
+  DBuf<double> d_partials;     // [n_slots][MAX_BLOCKS]
+  DBuf<double> d_energies;     // [32]
+  double* h_energies = nullptr;  // pinned
+  double E_recip = 0;
+
+  // EVB state
+  int D = 0;
+  int plog[MAX_DIABATS][MAX_CHAIN][5];
+  int parent[MAX_DIABATS];
+  double H[MAX_DIABATS][MAX_DIABATS];
+  double eigvec[MAX_DIABATS];
+  int principal = 0, new_hydronium = -1;
+  DBuf<double> d_Fdiag, d_Foff;     // [D][N][3]
+  int evb_cap = 0;
+  int rank = 0, n_ranks = 1;
+  void* nccl_comm = nullptr;
+
+  PhaseTimer ph[PH_COUNT];
+  bool timing = true;
+};
+
+// ---- cross-file entry points (all enqueue on c->stream) ----------------------------------------------
+int nb_build(msevb_ctx* c);                        // neighbor.hip
+int nb_refresh_sorted(msevb_ctx* c);               // gather posq/type in sorted order
+int nb_check_displacements(msevb_ctx* c, int initialize, int* flag);
+int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw);              // pair.hip
+int molecule_forces(msevb_ctx* c, int slot0, bool do_nb, bool do_bonded);  // molecule.hip
+int pme_forces(msevb_ctx* c, int slot_recip);                           // pme.hip
+int pme_setup(msevb_ctx* c);
+void pme_teardown(msevb_ctx* c);
+int reduce_partials(msevb_ctx* c, int slot, int nblocks);                // reduce.hip (in api)
+int fetch_energies(msevb_ctx* c);
+int integrate_half_kick_drift(msevb_ctx* c, double dt);                  // integrate.hip
+int integrate_half_kick(msevb_ctx* c, double dt);
+int integrate_com_shift(msevb_ctx* c);
+int integrate_remove_momentum(msevb_ctx* c);
+int integrate_kinetic(msevb_ctx* c, double* ke);
+int evb_force_energy(msevb_ctx* c, double* epot);                        // evb.hip
+int build_tables(msevb_ctx* c);                                          // tables.cpp
+void recip_lattice(const double box[3], double vol, double kk[3][3]);
+double volume32(const double box[3]);
+
+// defined inside api.hip's extern "C" block
+extern "C" int total_force_enqueue(msevb_ctx* c);
+extern "C" void total_force_collect(msevb_ctx* c, double* en);
+extern "C" int upload_topology(msevb_ctx* c);
+int pme_convolve(msevb_ctx* c, double2* grid, int slot);
+int pme_prepare_atoms(msevb_ctx* c);
+int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add);
+
+constexpr int MAX_BLOCKS = 65536;
+enum Slot { S_ELEC_PAIR = 0, S_VDW_PAIR, S_ELEC_INTRA, S_VDW_INTRA, S_BOND, S_ANGLE, S_DIH, S_RECIP, S_KE, S_PX, S_PY, S_PZ, S_MAXD1, S_MAXD2, S_EVB0, N_SLOTS = 32 };
+
+inline void phase_begin(msevb_ctx* c, int p) {
+  if (!c->timing) return;
+  PhaseTimer& t = c->ph[p];
+  if (!t.e0) { (void)hipEventCreate(&t.e0); (void)hipEventCreate(&t.e1); }
+  if (t.pending) { float ms = 0; if (hipEventSynchronize(t.e1) == hipSuccess && hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) { t.ms += ms; t.calls++; } t.pending = false; }
+  (void)hipEventRecord(t.e0, c->stream);
+}
+inline void phase_end(msevb_ctx* c, int p) {
+  if (!c->timing) return;
+  PhaseTimer& t = c->ph[p];
+  (void)hipEventRecord(t.e1, c->stream);
+  t.pending = true;
+}

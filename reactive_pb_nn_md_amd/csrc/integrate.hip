@@ -1,0 +1,102 @@
+// Device-resident velocity Verlet (replaces md_integrate_atomic, NVE branch, src/md_integration.f90:438-541):
+// half kick + drift (:469-486), molecule COM update and wrap into the box (update_r_com src/general_routines.f90:420,
+// shift_molecules_into_box :1145), force call, second half kick with the |F| > 1e5 guard (:508-529), removal of the
+// centre-of-mass momentum (:125-177) and calculate_kinetic_energy (src/total_energy_forces.f90:106).
+#include "ctx.hpp"
+
+
+namespace {
+
+__global__ void k_kick_drift(int N, double dt, const double* __restrict__ mass, const double* __restrict__ F, double* __restrict__ v, double* __restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * N) return;
+  const double m = mass[i / 3];
+  const double vv = v[i] + dt / 2.0 / m * F[i] * 100.0;
+  v[i] = vv;
+  x[i] = x[i] + vv * dt;
+}
+// second half kick; flags forces > 1e5 ("force on atom is too big", src/md_integration.f90:523) in bad[0]
+__global__ void k_kick(int N, double dt, const double* __restrict__ mass, const double* __restrict__ F, double* __restrict__ v, int* __restrict__ bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * N) return;
+  const double f = F[i];
+  v[i] = v[i] + dt / 2.0 / mass[i / 3] * f * 100.0;
+  if (fabs(f) > 10e4) atomicExch(bad, i / 3 + 1);
+}
+__global__ void k_com_shift(int M, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms, const double* __restrict__ mass,
+                            double* __restrict__ x, BoxDev box) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int n = mol_natom[m];
+  double com[3] = {0, 0, 0}, mt = 0;
+  for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; const double ma = mass[a]; for (int d = 0; d < 3; ++d) com[d] += x[3 * a + d] * ma; mt += ma; }
+  double sh[3]; bool any = false;
+  for (int d = 0; d < 3; ++d) { const double f = com[d] / mt * box.invL[d]; sh[d] = f < 0.0 ? box.L[d] : (f > 1.0 ? -box.L[d] : 0.0); any |= sh[d] != 0.0; }
+  if (any) for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) x[3 * a + d] += sh[d]; }
+}
+// per-block partial sums of momentum (3) and kinetic energy
+__global__ __launch_bounds__(256) void k_momentum_ke(int N, const double* __restrict__ mass, const double* __restrict__ v, double* __restrict__ part) {
+  __shared__ double red[4][256];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double p[4] = {0, 0, 0, 0};
+  if (i < N) { const double m = mass[i]; for (int d = 0; d < 3; ++d) { p[d] = m * v[3 * i + d]; p[3] += 0.5 * m * v[3 * i + d] * v[3 * i + d] / 100.0; } }
+  for (int s = 0; s < 4; ++s) red[s][threadIdx.x] = p[s];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) for (int s = 0; s < 4; ++s) red[s][threadIdx.x] += red[s][threadIdx.x + st]; __syncthreads(); }
+  if (threadIdx.x == 0) { part[(size_t)S_PX * MAX_BLOCKS + blockIdx.x] = red[0][0]; part[(size_t)S_PY * MAX_BLOCKS + blockIdx.x] = red[1][0];
+    part[(size_t)S_PZ * MAX_BLOCKS + blockIdx.x] = red[2][0]; part[(size_t)S_KE * MAX_BLOCKS + blockIdx.x] = red[3][0]; }
+}
+__global__ void k_remove_momentum(int N, const double* __restrict__ mass, const double* __restrict__ en, double* __restrict__ v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * N) return;
+  v[i] -= en[S_PX + i % 3] / (double)N / mass[i / 3];
+}
+
+}  // namespace
+
+static int momentum_ke(msevb_ctx* c) {
+  const int nb = (c->N + 255) / 256;
+  hipLaunchKernelGGL(k_momentum_ke, dim3(nb), dim3(256), 0, c->stream, c->N, c->d_mass.p, c->d_vel.p, c->d_partials.p);
+  HIPCHK(hipGetLastError());
+  CHK(reduce_partials(c, S_PX, nb)); CHK(reduce_partials(c, S_PY, nb)); CHK(reduce_partials(c, S_PZ, nb)); CHK(reduce_partials(c, S_KE, nb));
+  return MSEVB_OK;
+}
+
+extern "C" int msevb_calculate_kinetic_energy(msevb_ctx* c, double* ke) {
+  if (!c || !c->finalized) return MSEVB_ERR_STATE;
+  CHK(momentum_ke(c));
+  CHK(fetch_energies(c));
+  *ke = c->h_energies[S_KE];
+  return MSEVB_OK;
+}
+
+extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, int use_evb, double* energies_out) {
+  if (!c || !c->finalized) { if (c) c->err = "context not finalized"; return MSEVB_ERR_STATE; }
+  (void)hipSetDevice(c->device);
+  const int N = c->N, M = c->M, n3 = 3 * N;
+  BoxDev box;
+  for (int d = 0; d < 3; ++d) { box.L[d] = c->box[d]; box.invL[d] = 1.0 / c->box[d]; }
+  static thread_local DBuf<int> d_bad;
+  if (d_bad.alloc(1)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed");
+  HIPCHK(hipMemsetAsync(d_bad.p, 0, sizeof(int), c->stream));
+  for (int s = 0; s < n_steps; ++s) {
+    phase_begin(c, PH_INTEGRATE);
+    hipLaunchKernelGGL(k_kick_drift, dim3((n3 + 255) / 256), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, c->d_xyz.p);
+    hipLaunchKernelGGL(k_com_shift, dim3((M + 255) / 256), dim3(256), 0, c->stream, M, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_mass.p, c->d_xyz.p, box);
+    phase_end(c, PH_INTEGRATE);
+    double epot = 0.0;
+    if (use_evb) { CHK(evb_force_energy(c, &epot)); }
+    else { CHK(total_force_enqueue(c)); }
+    hipLaunchKernelGGL(k_kick, dim3((n3 + 255) / 256), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p);
+    CHK(momentum_ke(c));
+    hipLaunchKernelGGL(k_remove_momentum, dim3((n3 + 255) / 256), dim3(256), 0, c->stream, N, c->d_mass.p, c->d_energies.p, c->d_vel.p);
+    HIPCHK(hipGetLastError());
+    CHK(fetch_energies(c));   // one host synchronisation per step: energies + Verlet flag
+    if (!use_evb) { double en[MSEVB_N_ENERGY]; total_force_collect(c, en); epot = en[MSEVB_E_POTENTIAL]; }
+    if (energies_out) { energies_out[2 * s] = epot; energies_out[2 * s + 1] = c->h_energies[S_KE]; }
+  }
+  int bad = 0;
+  HIPCHK(hipMemcpy(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (bad) { char b[96]; snprintf(b, sizeof b, "force on atom %d is too big", bad); FAIL(MSEVB_ERR_NUMERIC, b); }
+  return MSEVB_OK;
+}

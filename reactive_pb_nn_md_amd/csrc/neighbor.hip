@@ -1,0 +1,236 @@
+// Device neighbour structure (replaces construct_verlet_list_grid, src/general_routines.f90:1408, and
+// update_verlet_displacements, :1259).
+//
+// Layout in HBM: atoms are sorted by cell (cell edge >= verlet_cutoff) so that neighbours of consecutive atoms
+// are consecutive in memory; the list is a FULL CSR list in sorted numbering (every pair stored for both atoms),
+// so the pair kernel owns each atom's force and needs no fp64 atomics.  As a set of unordered pairs
+// {different molecule, r < verlet_cutoff} it is identical to the reference's half list.
+#include <hipcub/hipcub.hpp>
+
+#include "ctx.hpp"
+
+namespace {
+
+__global__ void k_cell_assign(int N, const double* __restrict__ xyz, BoxDev box, int3 nc, int* __restrict__ keys, int* __restrict__ vals) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int cc[3];
+  const int ncv[3] = {nc.x, nc.y, nc.z};
+  for (int d = 0; d < 3; ++d) {
+    double f = xyz[3 * i + d] * box.invL[d];
+    f = f - floor(f);
+    int v = (int)(f * ncv[d]);
+    if (v >= ncv[d]) v = ncv[d] - 1;
+    if (v < 0) v = 0;
+    cc[d] = v;
+  }
+  keys[i] = cc[0] + nc.x * (cc[1] + nc.y * cc[2]);
+  vals[i] = i;
+}
+
+__global__ void k_cell_bounds(int N, int ncell, const int* __restrict__ keys, int* __restrict__ cell_start) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  int key = keys[k];
+  int prev = k == 0 ? -1 : keys[k - 1];
+  for (int cidx = prev + 1; cidx <= key; ++cidx) cell_start[cidx] = k;
+  if (k == N - 1) for (int cidx = key + 1; cidx <= ncell; ++cidx) cell_start[cidx] = N;
+}
+
+__global__ void k_gather_sorted(int N, const int* __restrict__ perm, const double* __restrict__ xyz, const double* __restrict__ chg,
+                                const int* __restrict__ atype, const int* __restrict__ mol_of, double4* __restrict__ posq,
+                                int* __restrict__ type_s, int* __restrict__ mol_s, int* __restrict__ inv_perm) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  int i = perm[k];
+  posq[k] = make_double4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], chg[i]);
+  type_s[k] = atype[i];
+  mol_s[k] = mol_of[i];
+  if (inv_perm) inv_perm[i] = k;
+}
+
+// one wavefront per sorted atom; FILL=false counts, FILL=true writes neighbours compactly (ballot + mbcnt)
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_neighbors(int N, const double4* __restrict__ posq, const int* __restrict__ mol_s,
+                                                   const int* __restrict__ keys, const int* __restrict__ cell_start, BoxDev box, int3 nc,
+                                                   double rv2, unsigned* __restrict__ count, const unsigned* __restrict__ start,
+                                                   int* __restrict__ nbr) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const double4 pi = posq[i];
+  const int mi = mol_s[i];
+  const int key = keys[i];
+  const int cx = key % nc.x, cy = (key / nc.x) % nc.y, cz = key / (nc.x * nc.y);
+  unsigned total = 0;
+  const unsigned base = FILL ? start[i] : 0u;
+  for (int oz = -1; oz <= 1; ++oz) {
+    if ((nc.z < 3 && oz == 1) || (nc.z < 2 && oz == -1)) continue;
+    const int zz = (cz + oz + nc.z) % nc.z;
+    for (int oy = -1; oy <= 1; ++oy) {
+      if ((nc.y < 3 && oy == 1) || (nc.y < 2 && oy == -1)) continue;
+      const int yy = (cy + oy + nc.y) % nc.y;
+      for (int ox = -1; ox <= 1; ++ox) {
+        if ((nc.x < 3 && ox == 1) || (nc.x < 2 && ox == -1)) continue;
+        const int xx = (cx + ox + nc.x) % nc.x;
+        const int cidx = xx + nc.x * (yy + nc.y * zz);
+        const int s = cell_start[cidx], e = cell_start[cidx + 1];
+        for (int j0 = s; j0 < e; j0 += 64) {
+          const int j = j0 + lane;
+          bool hit = false;
+          if (j < e && j != i && mol_s[j] != mi) {
+            const double4 pj = posq[j];
+            double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            dx -= box.L[0] * floor(dx * box.invL[0] + 0.5);
+            dy -= box.L[1] * floor(dy * box.invL[1] + 0.5);
+            dz -= box.L[2] * floor(dz * box.invL[2] + 0.5);
+            hit = (dx * dx + dy * dy + dz * dz) < rv2;
+          }
+          const unsigned long long m = __ballot(hit);
+          if (FILL && hit) {
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            nbr[base + total + rank] = j;
+          }
+          total += (unsigned)__popcll(m);
+        }
+      }
+    }
+  }
+  if (!FILL && lane == 0) count[i] = total;
+}
+
+// accumulate displacements since the last list build and reduce the two largest norms per block
+__global__ __launch_bounds__(256) void k_displacements(int N, const double* __restrict__ xyz, double* __restrict__ store, double* __restrict__ disp,
+                                                       BoxDev box, int initialize, double* __restrict__ part1, double* __restrict__ part2) {
+  __shared__ double s1[256], s2[256];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double nrm = 0.0;
+  if (i < N) {
+    double a[3];
+    for (int d = 0; d < 3; ++d) {
+      const double x = xyz[3 * i + d];
+      if (initialize) { disp[3 * i + d] = 0.0; a[d] = 0.0; }
+      else {
+        const double dc = x - store[3 * i + d];
+        const double sh = floor(dc * box.invL[d] + 0.5) * box.L[d];
+        a[d] = disp[3 * i + d] + (dc - sh);
+        disp[3 * i + d] = a[d];
+      }
+      store[3 * i + d] = x;
+    }
+    nrm = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+  }
+  s1[threadIdx.x] = nrm;
+  s2[threadIdx.x] = 0.0;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+      double a1 = s1[threadIdx.x], a2 = s2[threadIdx.x], b1 = s1[threadIdx.x + st], b2 = s2[threadIdx.x + st];
+      double m1 = fmax(a1, b1), m2 = fmax(fmin(a1, b1), fmax(a2, b2));
+      s1[threadIdx.x] = m1;
+      s2[threadIdx.x] = m2;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part1[blockIdx.x] = s1[0]; part2[blockIdx.x] = s2[0]; }
+}
+
+__global__ void k_top2_final(int nb, const double* __restrict__ part1, const double* __restrict__ part2, double* __restrict__ out) {
+  __shared__ double s1[256], s2[256];
+  double m1 = 0, m2 = 0;
+  for (int k = threadIdx.x; k < nb; k += 256) {
+    double b1 = part1[k], b2 = part2[k];
+    double n1 = fmax(m1, b1), n2 = fmax(fmin(m1, b1), fmax(m2, b2));
+    m1 = n1; m2 = n2;
+  }
+  s1[threadIdx.x] = m1; s2[threadIdx.x] = m2;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+      double a1 = s1[threadIdx.x], a2 = s2[threadIdx.x], b1 = s1[threadIdx.x + st], b2 = s2[threadIdx.x + st];
+      s1[threadIdx.x] = fmax(a1, b1);
+      s2[threadIdx.x] = fmax(fmin(a1, b1), fmax(a2, b2));
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = s1[0]; out[1] = s2[0]; }
+}
+
+}  // namespace
+
+static BoxDev make_box(const msevb_ctx* c) {
+  BoxDev b;
+  for (int d = 0; d < 3; ++d) { b.L[d] = c->box[d]; b.invL[d] = 1.0 / c->box[d]; }
+  return b;
+}
+
+int nb_refresh_sorted(msevb_ctx* c) {
+  const int N = c->N;
+  hipLaunchKernelGGL(k_gather_sorted, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, c->d_perm.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p,
+                     c->d_mol_of.p, c->d_posq.p, c->d_type_sorted.p, c->d_mol_sorted.p, c->d_inv_perm.p);
+  HIPCHK(hipGetLastError());
+  return MSEVB_OK;
+}
+
+int nb_build(msevb_ctx* c) {
+  const int N = c->N;
+  phase_begin(c, PH_VERLET);
+  for (int d = 0; d < 3; ++d) { int n = (int)floor(c->box[d] / c->rv); c->ncell[d] = n < 1 ? 1 : n; }
+  const int3 nc = make_int3(c->ncell[0], c->ncell[1], c->ncell[2]);
+  const int ncell = nc.x * nc.y * nc.z;
+  const BoxDev box = make_box(c);
+  if (c->d_cell_of.alloc(N) || c->d_perm.alloc(N) || c->d_cell_keys_tmp.alloc(N) || c->d_perm_tmp.alloc(N) || c->d_cell_start.alloc(ncell + 1) ||
+      c->d_nbr_count.alloc(N + 1) || c->d_nbr_start.alloc(N + 1) || c->d_inv_perm.alloc(N))
+    FAIL(MSEVB_ERR_HIP, "hipMalloc failed (neighbour structure)");
+  hipLaunchKernelGGL(k_cell_assign, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, c->d_xyz.p, box, nc, c->d_cell_keys_tmp.p, c->d_perm_tmp.p);
+  int bits = 1;
+  while ((1 << bits) < ncell) ++bits;
+  size_t tmp = 0;
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, c->d_cell_keys_tmp.p, c->d_cell_of.p, c->d_perm_tmp.p, c->d_perm.p, N, 0, bits, c->stream));
+  size_t tmp2 = 0;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, c->d_nbr_count.p, c->d_nbr_start.p, N + 1, c->stream));
+  if (tmp2 > tmp) tmp = tmp2;
+  if (c->d_sort_tmp.alloc(tmp + 256)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (sort workspace)");
+  size_t tb = c->d_sort_tmp.n;
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tb, c->d_cell_keys_tmp.p, c->d_cell_of.p, c->d_perm_tmp.p, c->d_perm.p, N, 0, bits, c->stream));
+  hipLaunchKernelGGL(k_cell_bounds, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, ncell, c->d_cell_of.p, c->d_cell_start.p);
+  CHK(nb_refresh_sorted(c));
+  const int wpb = 4;
+  const dim3 grid((N + wpb - 1) / wpb), block(64 * wpb);
+  const double rv2 = c->rv * c->rv;
+  HIPCHK(hipMemsetAsync(c->d_nbr_count.p, 0, (N + 1) * sizeof(unsigned), c->stream));
+  hipLaunchKernelGGL(k_neighbors<false>, grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
+                     c->d_nbr_count.p, (const unsigned*)nullptr, (int*)nullptr);
+  tb = c->d_sort_tmp.n;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp.p, tb, c->d_nbr_count.p, c->d_nbr_start.p, N + 1, c->stream));
+  unsigned total = 0;
+  HIPCHK(hipMemcpyAsync(&total, c->d_nbr_start.p + N, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->n_nbr = total;
+  if (c->d_nbr.n < (size_t)total) {
+    if (c->d_nbr.alloc((size_t)(total * 1.2) + 1024)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (neighbour list)");
+  }
+  hipLaunchKernelGGL(k_neighbors<true>, grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
+                     (unsigned*)nullptr, c->d_nbr_start.p, c->d_nbr.p);
+  HIPCHK(hipGetLastError());
+  phase_end(c, PH_VERLET);
+  c->list_valid = true;
+  int flag;
+  CHK(nb_check_displacements(c, 1, &flag));
+  return MSEVB_OK;
+}
+
+// initialize != 0: reset the displacement store (no host sync).  Otherwise the flag is available in
+// c->h_energies[S_MAXD1..2] after the next fetch_energies().
+int nb_check_displacements(msevb_ctx* c, int initialize, int* flag) {
+  const int N = c->N, nb = (N + 255) / 256;
+  const BoxDev box = make_box(c);
+  if (c->d_xyz_store.alloc(3 * (size_t)N) || c->d_disp.alloc(3 * (size_t)N)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (displacements)");
+  hipLaunchKernelGGL(k_displacements, dim3(nb), dim3(256), 0, c->stream, N, c->d_xyz.p, c->d_xyz_store.p, c->d_disp.p, box, initialize,
+                     c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS);
+  hipLaunchKernelGGL(k_top2_final, dim3(1), dim3(256), 0, c->stream, nb, c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS,
+                     c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS, c->d_energies.p + S_MAXD1);
+  HIPCHK(hipGetLastError());
+  if (flag) *flag = 0;
+  return MSEVB_OK;
+}

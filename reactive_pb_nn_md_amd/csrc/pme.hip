@@ -1,0 +1,212 @@
+// Smooth PME reciprocal space (replaces pme_reciprocal_space_energy_force, src/pme.f90:28-179):
+//   k_pme_prep   scaled coordinates (create_scaled_direct_coordinates, src/general_routines.f90:497) and the per-atom
+//                B-spline stencil: nearpt = floor(u), 6 table rows per axis (bit-exact index arithmetic of src/pme.f90:220-247,
+//                :412-414) -> weights w[3][6] and derivative weights dw[3][6]
+//   k_pme_spread grid_Q (src/pme.f90:184): 216 grid points per atom, fp64 atomics into the real part of the complex grid
+//   rocFFT       3-D in-place double-complex forward / backward, unnormalised (MKL DFTI in the reference, :85/:113)
+//   k_pme_conv   FQ *= CB fused with the energy 0.5*sum_m CB(m)|FQ(m)|^2 (== 0.5*sum Q*theta, :128, by Parseval)
+//   k_pme_gather derivative_grid_Q (src/pme.f90:346): F = -K kk^T sum fac*theta*conv, one wavefront per atom
+// HBM layout: complex grid double2[K^3] with n1 fastest (reference Q(n1+1,n2+1,n3+1)); per-atom stencil 36 doubles.
+#include "ctx.hpp"
+
+namespace {
+
+// index arithmetic must round exactly like the reference: no FMA contraction in this function
+__global__ void k_pme_prep(int N, int K, int G, const double* __restrict__ xyz, const double* __restrict__ chg, double k00, double k01,
+                           double k02, double k10, double k11, double k12, double k20, double k21, double k22,
+                           const double* __restrict__ B6, const double* __restrict__ B5, double* __restrict__ uscale, int* __restrict__ base,
+                           int* __restrict__ splindex, double* __restrict__ w, double* __restrict__ dw) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  const double kk[3][3] = {{k00, k01, k02}, {k10, k11, k12}, {k20, k21, k22}};
+  for (int l = 0; l < 3; ++l) {
+    double u = (double)K * ((kk[l][0] * x + kk[l][1] * y) + kk[l][2] * z);
+    if (u < 0.0) u = u + (double)K; else if (u >= (double)K) u = u - (double)K;
+    if (fabs(fmod(u, 1.0)) < 1e-6) u = u + 1e-6;
+    uscale[3 * i + l] = u;
+    const int np = (int)floor(u);
+    base[3 * i + l] = np;
+    for (int k = 0; k < 6; ++k) {
+      const int n = np - k;
+      const double a1 = u - (double)n, a2 = a1 - 1.0;
+      const int g6 = (int)ceil(a1 / 6.0 * (double)G);
+      splindex[(3 * i + l) * 6 + k] = g6;
+      w[(3 * i + l) * 6 + k] = B6[g6 - 1];
+      double d = 0.0;
+      if (a1 < 5.0) d = B5[(int)ceil(a1 / 5.0 * (double)G) - 1];
+      if (0.0 < a2) d = d - B5[(int)ceil(a2 / 5.0 * (double)G) - 1];
+      dw[(3 * i + l) * 6 + k] = d;
+    }
+  }
+}
+
+// one thread per (atom, k3, k2); the 6 k1 taps are consecutive grid points (modulo wrap)
+__global__ __launch_bounds__(256) void k_pme_spread(int N, int K, const double* __restrict__ chg, const int* __restrict__ base,
+                                                    const double* __restrict__ w, double2* __restrict__ grid) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)N * 36) return;
+  const int i = (int)(t / 36), r = (int)(t % 36), k3 = r / 6, k2 = r % 6;
+  const double q = chg[i];
+  if (q == 0.0) return;
+  int n3 = base[3 * i + 2] - k3; if (n3 < 0) n3 += K;
+  int n2 = base[3 * i + 1] - k2; if (n2 < 0) n2 += K;
+  const double w23 = w[(3 * i + 1) * 6 + k2], w3 = w[(3 * i + 2) * 6 + k3];
+  const int b1 = base[3 * i];
+  double2* row = grid + (size_t)K * (n2 + (size_t)K * n3);
+  for (int k1 = 0; k1 < 6; ++k1) {
+    int n1 = b1 - k1; if (n1 < 0) n1 += K;
+    const double v = q * w[(3 * i) * 6 + k1] * w23 * w3;
+    atomicAdd(&row[n1].x, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pme_conv(size_t K3, const double* __restrict__ CB, double2* __restrict__ grid, double* __restrict__ Qreal,
+                                                  double* __restrict__ part, double half_conv) {
+  __shared__ double red[256];
+  double e = 0.0;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K3; k += (size_t)gridDim.x * blockDim.x) {
+    double2 v = grid[k];
+    const double cb = CB[k];
+    e += cb * (v.x * v.x + v.y * v.y);
+    v.x *= cb; v.y *= cb;
+    grid[k] = v;
+  }
+  red[threadIdx.x] = e;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] * half_conv;
+}
+
+__global__ void k_copy_real(size_t K3, const double2* __restrict__ grid, double* __restrict__ Q) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K3; k += (size_t)gridDim.x * blockDim.x) Q[k] = grid[k].x;
+}
+
+// one wavefront per atom: 216 stencil points over 64 lanes, shuffle reduction, F = -K kk^T Ftilde
+__global__ __launch_bounds__(256) void k_pme_gather(int N, int K, const double* __restrict__ chg, const int* __restrict__ base,
+                                                    const double* __restrict__ w, const double* __restrict__ dw, const double2* __restrict__ grid,
+                                                    double conv, double k00, double k01, double k02, double k10, double k11, double k12,
+                                                    double k20, double k21, double k22, double* __restrict__ F_recip, double* __restrict__ F) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const double q = chg[i];
+  const int b1 = base[3 * i], b2 = base[3 * i + 1], b3 = base[3 * i + 2];
+  const double* wi = w + (size_t)i * 18;
+  const double* dwi = dw + (size_t)i * 18;
+  double f1 = 0.0, f2 = 0.0, f3 = 0.0;
+  for (int t = lane; t < 216; t += 64) {
+    const int k1 = t % 6, k2 = (t / 6) % 6, k3 = t / 36;
+    int n1 = b1 - k1; if (n1 < 0) n1 += K;
+    int n2 = b2 - k2; if (n2 < 0) n2 += K;
+    int n3 = b3 - k3; if (n3 < 0) n3 += K;
+    const double th = grid[n1 + (size_t)K * (n2 + (size_t)K * n3)].x;
+    const double w1 = wi[k1], w2 = wi[6 + k2], w3 = wi[12 + k3];
+    f1 += dwi[k1] * w2 * w3 * th;
+    f2 += dwi[6 + k2] * w1 * w3 * th;
+    f3 += dwi[12 + k3] * w1 * w2 * th;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); f3 += __shfl_xor(f3, o, 64); }
+  if (lane == 0) {
+    const double s = q * conv;
+    f1 *= s; f2 *= s; f3 *= s;
+    const double Kd = (double)K;
+    const double fx = -Kd * (k00 * f1 + k10 * f2 + k20 * f3);
+    const double fy = -Kd * (k01 * f1 + k11 * f2 + k21 * f3);
+    const double fz = -Kd * (k02 * f1 + k12 * f2 + k22 * f3);
+    F_recip[3 * i] = fx; F_recip[3 * i + 1] = fy; F_recip[3 * i + 2] = fz;
+    if (F) { F[3 * i] += fx; F[3 * i + 1] += fy; F[3 * i + 2] += fz; }
+  }
+}
+
+}  // namespace
+
+#define FFTCHK(call) do { if ((call) != rocfft_status_success) FAIL(MSEVB_ERR_FFT, std::string("rocFFT failure: ") + #call); } while (0)
+
+static bool g_rocfft_ready = false;
+
+int pme_setup(msevb_ctx* c) {
+  const int K = c->K, N = c->N;
+  const size_t K3 = (size_t)K * K * K;
+  if (!g_rocfft_ready) { if (rocfft_setup() != rocfft_status_success) FAIL(MSEVB_ERR_FFT, "rocfft_setup failed"); g_rocfft_ready = true; }
+  const int batch = c->fft_batch < 1 ? 1 : c->fft_batch;
+  if (c->d_grid.alloc(K3 * batch) || c->d_Q.alloc(K3) || c->d_w.alloc(18 * (size_t)N) || c->d_dw.alloc(18 * (size_t)N) || c->d_uscale.alloc(3 * (size_t)N) ||
+      c->d_base.alloc(3 * (size_t)N) || c->d_splindex.alloc(18 * (size_t)N) || c->d_force_recip.alloc(3 * (size_t)N))
+    FAIL(MSEVB_ERR_HIP, "hipMalloc failed (PME)");
+  size_t len[3] = {(size_t)K, (size_t)K, (size_t)K};
+  pme_teardown(c);
+  FFTCHK(rocfft_plan_create(&c->plan_fwd, rocfft_placement_inplace, rocfft_transform_type_complex_forward, rocfft_precision_double, 3, len, 1, nullptr));
+  FFTCHK(rocfft_plan_create(&c->plan_bwd, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, rocfft_precision_double, 3, len, 1, nullptr));
+  size_t wf = 0, wb = 0;
+  FFTCHK(rocfft_plan_get_work_buffer_size(c->plan_fwd, &wf));
+  FFTCHK(rocfft_plan_get_work_buffer_size(c->plan_bwd, &wb));
+  if (wb > wf) wf = wb;
+  FFTCHK(rocfft_execution_info_create(&c->fft_info));
+  if (wf) {
+    if (c->d_fft_work.alloc(wf)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (FFT work buffer)");
+    FFTCHK(rocfft_execution_info_set_work_buffer(c->fft_info, c->d_fft_work.p, wf));
+  }
+  FFTCHK(rocfft_execution_info_set_stream(c->fft_info, c->stream));
+  return MSEVB_OK;
+}
+
+void pme_teardown(msevb_ctx* c) {
+  if (c->plan_fwd) { rocfft_plan_destroy(c->plan_fwd); c->plan_fwd = nullptr; }
+  if (c->plan_bwd) { rocfft_plan_destroy(c->plan_bwd); c->plan_bwd = nullptr; }
+  if (c->fft_info) { rocfft_execution_info_destroy(c->fft_info); c->fft_info = nullptr; }
+}
+
+// theta = IFFT(CB * FFT(grid)) in place on `grid`; energy partials -> slot
+int pme_convolve(msevb_ctx* c, double2* grid, int slot) {
+  const size_t K3 = (size_t)c->K * c->K * c->K;
+  void* buf[1] = {grid};
+  FFTCHK(rocfft_execute(c->plan_fwd, buf, nullptr, c->fft_info));
+  int nb = (int)((K3 + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(k_pme_conv, dim3(nb), dim3(256), 0, c->stream, K3, c->d_CB.p, grid, (double*)nullptr, c->d_partials.p + (size_t)slot * MAX_BLOCKS,
+                     0.5 * c->conv);
+  FFTCHK(rocfft_execute(c->plan_bwd, buf, nullptr, c->fft_info));
+  HIPCHK(hipGetLastError());
+  return reduce_partials(c, slot, nb);
+}
+
+int pme_prepare_atoms(msevb_ctx* c) {
+  const int N = c->N;
+  hipLaunchKernelGGL(k_pme_prep, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, c->K, c->spline_grid, c->d_xyz.p, c->d_chg.p, c->kk[0][0], c->kk[0][1],
+                     c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, c->d_uscale.p,
+                     c->d_base.p, c->d_splindex.p, c->d_w.p, c->d_dw.p);
+  HIPCHK(hipGetLastError());
+  return MSEVB_OK;
+}
+
+int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add) {
+  const int N = c->N;
+  hipLaunchKernelGGL(k_pme_gather, dim3((N + 3) / 4), dim3(256), 0, c->stream, N, c->K, chg, c->d_base.p, c->d_w.p, c->d_dw.p, grid, c->conv, c->kk[0][0],
+                     c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add);
+  HIPCHK(hipGetLastError());
+  return MSEVB_OK;
+}
+
+int pme_forces(msevb_ctx* c, int slot_recip) {
+  const int N = c->N, K = c->K;
+  const size_t K3 = (size_t)K * K * K;
+  phase_begin(c, PH_SPREAD);
+  CHK(pme_prepare_atoms(c));
+  HIPCHK(hipMemsetAsync(c->d_grid.p, 0, K3 * sizeof(double2), c->stream));
+  const long nt = (long)N * 36;
+  hipLaunchKernelGGL(k_pme_spread, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, N, K, c->d_chg.p, c->d_base.p, c->d_w.p, c->d_grid.p);
+  int nbc = (int)((K3 + 255) / 256);
+  if (nbc > 2048) nbc = 2048;
+  hipLaunchKernelGGL(k_copy_real, dim3(nbc), dim3(256), 0, c->stream, K3, c->d_grid.p, c->d_Q.p);
+  HIPCHK(hipGetLastError());
+  phase_end(c, PH_SPREAD);
+  phase_begin(c, PH_FFT);
+  CHK(pme_convolve(c, c->d_grid.p, slot_recip));
+  phase_end(c, PH_FFT);
+  phase_begin(c, PH_GATHER);
+  CHK(pme_gather(c, c->d_grid.p, c->d_chg.p, c->d_force_recip.p, c->d_force.p));
+  phase_end(c, PH_GATHER);
+  return MSEVB_OK;
+}

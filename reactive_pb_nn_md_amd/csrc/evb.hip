@@ -1,11 +1,1136 @@
-// placeholder, replaced below in this round
+// MS-EVB (replaces ms_evb_calculate_total_force_energy, src/ms_evb.f90:181, and everything under it).
+//
+// Design (MI355X-first, not the reference's array shifting):
+//   * atoms keep the PRINCIPAL numbering for the whole step; a diabat is a sparse delta: the <= (max_chain+1) molecules
+//     touched by its proton hops carry overridden types / charges / membership / proton image ("special atoms");
+//   * host: tiny work only - diabat enumeration on a device-gathered neighbourhood of the hydronium
+//     (evb_conduct_proton_transfer_recursive :498, find_evb_reactive_neighbors :702), hop bookkeeping
+//     (evb_change_data_structures_proton_transfer :843), Jacobi (:242);
+//   * device, batched over ALL evaluation units of all owned diabats in single launches:
+//       k_evb_env      donor/acceptor atoms x all other atoms real space (:1566) + MS-EVB3 repulsion (:2259-2478)
+//       k_evb_special  pairs among special atoms, intra-molecular non-bonded and bonded terms of donor/acceptor (:1849, :1900)
+//       k_evb_patch    Q_grid patches (modify_Q_grid, src/pme.f90:275) ; rocFFT ; xCB ; energy (:1962-2050)
+//       k_evb_gather   reciprocal force of every atom for up to 8 diabats per pass with the principal's stencil weights,
+//                      RECOMPUTED weights for special atoms instead of the reference's stored dQ_dr (:2055-2084, :2103)
+//       k_evb_coupling exchange-charge Coulomb sum of the off-diagonal element (:1276) + geometric factor (:1180)
+//       k_evb_blend    Hellmann-Feynman force (:293-309)
+//   * diabats d >= 2 are sharded over ranks ((d-2) mod n_ranks); force slots are laid out [rank][slot] so that one
+//     RCCL all-gather completes every rank's store.
+#include <algorithm>
+#include <functional>
+#include <map>
+
 #include "ctx.hpp"
-int evb_force_energy(msevb_ctx* c, double* epot) { (void)epot; FAIL(MSEVB_ERR_STATE, "EVB path not built"); }
-extern "C" {
-int msevb_ms_evb_calculate_total_force_energy(msevb_ctx* c, double* e, double* f) { (void)e; (void)f; FAIL(MSEVB_ERR_STATE, "EVB path not built"); }
-int msevb_get_evb_state(msevb_ctx* c, int*, int*, int*, double*, double*, int*, int*) { FAIL(MSEVB_ERR_STATE, "EVB path not built"); }
-int msevb_get_evb_element_force(msevb_ctx* c, int, int, double*) { FAIL(MSEVB_ERR_STATE, "EVB path not built"); }
-int msevb_comm_unique_id(void*) { return MSEVB_ERR_COMM; }
-int msevb_comm_init(msevb_ctx* c, const void*, int, int) { FAIL(MSEVB_ERR_COMM, "not built"); }
-int msevb_comm_set_virtual(msevb_ctx* c, int r, int n) { c->rank = r; c->n_ranks = n; return MSEVB_OK; }
+#include "devmath.hpp"
+
+#include "molecule_dev.hpp"
+
+namespace {
+
+constexpr int MAX_SPEC = (MAX_CHAIN + 1) * MAX_MOL_ATOMS;
+constexpr int REGION_CAP = 8192;
+
+struct SpecAtom { double x[3]; double q; int idx, type, mol, pad; };
+
+struct UnitDesc {
+  double sign;
+  int slot;          // force slot (index into the diagonal force store)
+  int do_rs;         // 0: repulsion only (principal diabat)
+  int do_rep;        // MS-EVB3 repulsion of this topology's hydronium (only the LAST topology of a chain needs it: the
+                     // repulsion of hop h's new side and of hop h+1's old side are the same topology and cancel)
+  int n_spec, n_mols;
+  int mols[MAX_CHAIN + 1];
+  int donor, acceptor, hyd;
+  int nD, nA, nH;
+  int D_at[MAX_MOL_ATOMS], A_at[MAX_MOL_ATOMS], H_at[MAX_MOL_ATOMS];   // indices into spec[], local molecule order
+  int mt_D, mt_A;
+  int heavy;         // spec index of the hydronium heavy atom
+  int type_H;        // atom type of the hydronium's last atom
+  SpecAtom spec[MAX_SPEC];
+};
+
+struct EvbTablesDev {
+  int n_da, n_pa;
+  int da_types[MAX_INTERACTION][3]; double da_par[MAX_INTERACTION][6];
+  int pa_types[MAX_INTERACTION][2]; double pa_par[MAX_INTERACTION][5];
+  double exch_atomic[MAX_TYPES];
+  double screen2;     // squared screening radius (heavy atom - any atom) beyond which every repulsion term is zero
+};
+
+struct CouplingDesc {   // one off-diagonal element, evaluated in the acceptor topology of diabat d
+  int slot;             // off-diagonal force slot
+  int n_spec, n_mols, mols[MAX_CHAIN + 1];
+  int nD, nA, D_at[MAX_MOL_ATOMS], A_at[MAX_MOL_ATOMS];
+  int gO1, gO2, gH;     // spec indices: donor heavy, acceptor heavy, transferring proton
+  int ftype;
+  double par[10];
+  double q_transfer;
+  double zc[3], shiftd[3], shifta[3];
+  double mol_com[MAX_CHAIN + 1][3];   // COM of each special molecule in this topology
+  SpecAtom spec[MAX_SPEC];
+};
+
+struct RecipAtom { int grid; int slot; int idx; int pad; double q_new; double x_new[3]; double q_old; };
+
+struct RegionRec { int mol, natom; double com[3]; double x[MAX_MOL_ATOMS][3]; };
+
+__device__ __forceinline__ void min_image(double* d, const BoxDev& b) {
+  for (int k = 0; k < 3; ++k) d[k] -= b.L[k] * floor(d[k] * b.invL[k] + 0.5);
 }
+__device__ __forceinline__ void rep_switch(double r, double rs, double rc, double& sw, double& dsw) {   // src/ms_evb.f90:2484
+  sw = 0.0; dsw = 0.0;
+  if (r < rc) {
+    if (r < rs) sw = 1.0;
+    else { const double c3 = (rc - rs) * (rc - rs) * (rc - rs), t1 = (r - rs) * (r - rs) / c3, t2 = 3.0 * rc - rs - 2.0 * r; sw = 1.0 - t1 * t2; dsw = -2.0 * (r - rs) * t2 / c3 + 2.0 * t1; }
+  }
+}
+
+// repulsion between the hydronium of unit u and ONE other atom j (type tj, position xj): three-atom term
+// (src/ms_evb.f90:2295-2399) + Born-Mayer terms (:2405-2478).  Adds the force on j to fj and the forces on hydronium
+// atoms to fh[k] (k over u.H_at).  pbc_shift of the reference = nearest image of j relative to the hydronium atom.
+__device__ __forceinline__ double evb_repulsion_atom(const UnitDesc& u, const EvbTablesDev& tb, const BoxDev& box, int tj, const double* xj, double* fj, double (*fh)[3]) {
+  double E = 0.0;
+  int idx = -1;
+  const SpecAtom& hv = u.spec[u.heavy];
+  for (int q = 0; q < tb.n_da; ++q) if (tb.da_types[q][0] == tj && tb.da_types[q][1] == hv.type && tb.da_types[q][2] == u.type_H) { idx = q; break; }
+  if (idx >= 0) {
+    const double* p = tb.da_par[idx];
+    double sh[3], rO[3];
+    for (int d = 0; d < 3; ++d) { const double dc = xj[d] - hv.x[d]; sh[d] = floor(dc * box.invL[d] + 0.5) * box.L[d]; rO[d] = -(dc - sh[d]); }
+    const double rOO = sqrt(rO[0] * rO[0] + rO[1] * rO[1] + rO[2] * rO[2]);
+    double sw, dsw;
+    rep_switch(rOO, p[4], p[5], sw, dsw);
+    if (sw != 0.0 || dsw != 0.0) {
+      const double fac = p[0] * exp(-p[1] * (rOO - p[2]));
+      double sum = 0.0;
+      int hk = -1;
+      for (int k = 0; k < u.nH; ++k) if (u.H_at[k] == u.heavy) hk = k;
+      for (int k = 0; k < u.nH; ++k) {
+        const SpecAtom& ha = u.spec[u.H_at[k]];
+        if (ha.type != u.type_H) continue;
+        double q[3];
+        for (int d = 0; d < 3; ++d) { const double rij = -(xj[d] - ha.x[d] - sh[d]); q[d] = (2.0 * xj[d] + rO[d]) / 2.0 - (xj[d] + rij); }
+        const double q2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2], eq = exp(-p[3] * q2);
+        sum += eq;
+        for (int d = 0; d < 3; ++d) {
+          const double g = sw * fac * eq * p[3] * q[d];
+          fh[k][d] += -2.0 * g; fh[hk][d] += g; fj[d] += g;
+        }
+      }
+      E += sw * fac * sum;
+      for (int d = 0; d < 3; ++d) { const double f = rO[d] / rOO * fac * sum * (sw * p[1] - dsw); fh[hk][d] += f; fj[d] -= f; }
+    }
+  }
+  for (int k = 0; k < u.nH; ++k) {
+    const SpecAtom& ha = u.spec[u.H_at[k]];
+    int ip = -1;
+    for (int q = 0; q < tb.n_pa; ++q) if (tb.pa_types[q][0] == tj && tb.pa_types[q][1] == ha.type) { ip = q; break; }
+    if (ip < 0) continue;
+    const double* p = tb.pa_par[ip];
+    double rij[3];
+    for (int d = 0; d < 3; ++d) { const double dc = xj[d] - ha.x[d]; rij[d] = -(dc - floor(dc * box.invL[d] + 0.5) * box.L[d]); }
+    const double r = sqrt(rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2]);
+    double sw, dsw;
+    rep_switch(r, p[3], p[4], sw, dsw);
+    if (sw == 0.0 && dsw == 0.0) continue;
+    const double fac = p[0] * exp(-p[1] * (r - p[2]));
+    E += sw * fac;
+    for (int d = 0; d < 3; ++d) { const double f = rij[d] / r * fac * (sw * p[1] - dsw); fh[k][d] += f; fj[d] -= f; }
+  }
+  return E;
+}
+
+// ---- environment kernel: special (donor+acceptor / hydronium) atoms of every unit against all NON-special atoms --------
+__global__ __launch_bounds__(256) void k_evb_env(int N, int n_units, const UnitDesc* __restrict__ units, const EvbTablesDev* __restrict__ tabs,
+                                                 const double* __restrict__ xyz, const double* __restrict__ chg, const int* __restrict__ atype,
+                                                 const int* __restrict__ mol_of, const PairParam* __restrict__ pairpar, int nt,
+                                                 const double2* __restrict__ etab, double inv_dx, const double* __restrict__ tt,
+                                                 const double* __restrict__ dtt, BoxDev box, double rc2, double* __restrict__ Fstore, size_t fstride,
+                                                 double* __restrict__ part, int part_stride) {
+  __shared__ UnitDesc u;
+  __shared__ EvbTablesDev tb;
+  __shared__ double sF[MAX_SPEC][3];
+  __shared__ double red[256];
+  const int iu = blockIdx.y;
+  {
+    const int* src = (const int*)&units[iu]; int* dst = (int*)&u;
+    for (int k = threadIdx.x; k < (int)(sizeof(UnitDesc) / 4); k += blockDim.x) dst[k] = src[k];
+    const int* s2 = (const int*)tabs; int* d2 = (int*)&tb;
+    for (int k = threadIdx.x; k < (int)(sizeof(EvbTablesDev) / 4); k += blockDim.x) d2[k] = s2[k];
+    for (int k = threadIdx.x; k < MAX_SPEC * 3; k += blockDim.x) (&sF[0][0])[k] = 0.0;
+  }
+  __syncthreads();
+  double* F = Fstore + (size_t)u.slot * fstride;
+  double e = 0.0;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+    const int mj = mol_of[j];
+    bool special = false;
+    for (int k = 0; k < u.n_mols; ++k) special |= (u.mols[k] == mj);
+    if (special) continue;
+    const double xj[3] = {xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]};
+    const double qj = chg[j];
+    const int tj = atype[j];
+    double fj[3] = {0, 0, 0};
+    bool touched = false;
+    if (u.do_rs) {
+      for (int side = 0; side < 2; ++side) {
+        const int n = side == 0 ? u.nD : u.nA;
+        const int* lst = side == 0 ? u.D_at : u.A_at;
+        for (int k = 0; k < n; ++k) {
+          const SpecAtom& a = u.spec[lst[k]];
+          double dr[3] = {a.x[0] - xj[0], a.x[1] - xj[1], a.x[2] - xj[2]};
+          min_image(dr, box);
+          const double r2 = dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2];
+          if (r2 < rc2) {
+            double fs, ee, ev;
+            pair_interaction(r2, a.q * qj, pairpar[a.type * nt + tj], etab, inv_dx, tt, dtt, fs, ee, ev);
+            e += ee + ev;
+            for (int d = 0; d < 3; ++d) { fj[d] -= fs * dr[d]; atomicAdd(&sF[lst[k]][d], fs * dr[d]); }
+            touched = true;
+          }
+        }
+      }
+    }
+    if (u.do_rep) {   // repulsion: only atoms near the hydronium matter; cheap distance screen first
+      const SpecAtom& hv = u.spec[u.heavy];
+      double dr[3] = {hv.x[0] - xj[0], hv.x[1] - xj[1], hv.x[2] - xj[2]};
+      min_image(dr, box);
+      if (dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2] < tb.screen2) {
+        double fh[MAX_MOL_ATOMS][3];
+        for (int k = 0; k < MAX_MOL_ATOMS; ++k) fh[k][0] = fh[k][1] = fh[k][2] = 0.0;
+        double fr[3] = {0, 0, 0};
+        const double er = evb_repulsion_atom(u, tb, box, tj, xj, fr, fh);
+        if (er != 0.0 || fr[0] != 0.0 || fr[1] != 0.0 || fr[2] != 0.0) {
+          e += er;
+          for (int d = 0; d < 3; ++d) fj[d] += fr[d];
+          for (int k = 0; k < u.nH; ++k) for (int d = 0; d < 3; ++d) if (fh[k][d] != 0.0) atomicAdd(&sF[u.H_at[k]][d], fh[k][d]);
+          touched = true;
+        }
+      }
+    }
+    if (touched) for (int d = 0; d < 3; ++d) atomicAdd(&F[3 * j + d], u.sign * fj[d]);
+  }
+  red[threadIdx.x] = e;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+  if (threadIdx.x == 0) part[(size_t)iu * part_stride + blockIdx.x] = red[0];
+  for (int k = threadIdx.x; k < u.n_spec * 3; k += blockDim.x) {
+    const double v = sF[k / 3][k % 3];
+    if (v != 0.0) atomicAdd(&F[3 * u.spec[k / 3].idx + k % 3], u.sign * v);
+  }
+}
+
+// ---- special-special kernel: one thread per unit (tiny work) ------------------------------------------------------
+__global__ void k_evb_special(int n_units, const UnitDesc* __restrict__ units, const EvbTablesDev* __restrict__ tabs, const MolTypeDev* __restrict__ mts,
+                              const PairParam* __restrict__ pairpar, int nt, const double2* __restrict__ etab, double inv_dx,
+                              const double* __restrict__ tt, const double* __restrict__ dtt, BoxDev box, double rc2, double alpha, double erf_factor,
+                              double conv, double pi_ref, double* __restrict__ Fstore, size_t fstride, double* __restrict__ Eout, double* __restrict__ dbg) {
+  const int iu = blockIdx.x;
+  if (iu >= n_units || threadIdx.x != 0) return;
+  double dcomp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const UnitDesc& u = units[iu];
+  const EvbTablesDev& tb = *tabs;
+  __shared__ double f[MAX_SPEC][3];
+  __shared__ double x[MAX_MOL_ATOMS][3], q[MAX_MOL_ATOMS], fl[MAX_MOL_ATOMS][3];
+  __shared__ bool inDA[MAX_SPEC];
+  for (int k = 0; k < u.n_spec; ++k) f[k][0] = f[k][1] = f[k][2] = 0.0;
+  double e = 0.0;
+  for (int k = 0; k < u.n_spec; ++k) inDA[k] = false;
+  if (u.do_rs) {
+    for (int k = 0; k < u.nD; ++k) inDA[u.D_at[k]] = true;
+    for (int k = 0; k < u.nA; ++k) inDA[u.A_at[k]] = true;
+    for (int a = 0; a < u.n_spec; ++a) {
+      if (!inDA[a]) continue;
+      for (int b = 0; b < u.n_spec; ++b) {
+        if (u.spec[b].mol == u.spec[a].mol) continue;
+        if (inDA[b] && b < a) continue;
+        double dr[3] = {u.spec[a].x[0] - u.spec[b].x[0], u.spec[a].x[1] - u.spec[b].x[1], u.spec[a].x[2] - u.spec[b].x[2]};
+        min_image(dr, box);
+        const double r2 = dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2];
+        if (r2 < rc2) {
+          double fs, ee, ev;
+          pair_interaction(r2, u.spec[a].q * u.spec[b].q, pairpar[u.spec[a].type * nt + u.spec[b].type], etab, inv_dx, tt, dtt, fs, ee, ev);
+          e += ee + ev; dcomp[0] += ee; dcomp[1] += ev;
+          for (int d = 0; d < 3; ++d) { f[a][d] += fs * dr[d]; f[b][d] -= fs * dr[d]; }
+        }
+      }
+    }
+    for (int side = 0; side < 2; ++side) {   // intra-molecular non-bonded + bonded of donor and acceptor
+      const int n = side == 0 ? u.nD : u.nA;
+      const int* lst = side == 0 ? u.D_at : u.A_at;
+      const MolTypeDev& mt = mts[side == 0 ? u.mt_D : u.mt_A];
+      for (int k = 0; k < n; ++k) { q[k] = u.spec[lst[k]].q; for (int d = 0; d < 3; ++d) { x[k][d] = u.spec[lst[k]].x[d]; fl[k][d] = 0.0; } }
+      double e1 = 0, e2 = 0, eb = 0, ea = 0, ed = 0;
+      if (n > 1) molecule_nonbonded(mt, n, x, q, fl, etab, inv_dx, tt, dtt, rc2, alpha, erf_factor, conv, e1, e2);
+      molecule_bonded(mt, x, fl, pi_ref, eb, ea, ed);
+      e += e1 + e2 + eb + ea + ed; dcomp[2 + side] += e1 + e2; dcomp[4 + side] += eb + ea + ed;
+      for (int k = 0; k < n; ++k) for (int d = 0; d < 3; ++d) f[lst[k]][d] += fl[k][d];
+    }
+  }
+  // repulsion of the hydronium with special atoms of OTHER molecules
+  for (int b = 0; b < u.n_spec && u.do_rep; ++b) {
+    if (u.spec[b].mol == u.hyd) continue;
+    double fh[MAX_MOL_ATOMS][3], fj[3] = {0, 0, 0};
+    for (int k = 0; k < MAX_MOL_ATOMS; ++k) fh[k][0] = fh[k][1] = fh[k][2] = 0.0;
+    { const double er = evb_repulsion_atom(u, tb, box, u.spec[b].type, u.spec[b].x, fj, fh); e += er; dcomp[6] += er; }
+    for (int d = 0; d < 3; ++d) f[b][d] += fj[d];
+    for (int k = 0; k < u.nH; ++k) for (int d = 0; d < 3; ++d) f[u.H_at[k]][d] += fh[k][d];
+  }
+  double* F = Fstore + (size_t)u.slot * fstride;
+  for (int k = 0; k < u.n_spec; ++k) for (int d = 0; d < 3; ++d) if (f[k][d] != 0.0) atomicAdd(&F[3 * u.spec[k].idx + d], u.sign * f[k][d]);
+  Eout[iu] = e;
+  if (dbg) for (int k = 0; k < 8; ++k) dbg[8 * iu + k] = dcomp[k];
+}
+
+// ---- reciprocal space -------------------------------------------------------------------------------------------------
+__global__ void k_evb_grid_init(size_t K3, int ng, const double* __restrict__ Q, double2* __restrict__ grids) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K3 * ng; k += (size_t)gridDim.x * blockDim.x) grids[k] = make_double2(Q[k % K3], 0.0);
+}
+
+// stencil of one special atom in its NEW state (one thread per entry): same index arithmetic as k_pme_prep
+__global__ void k_evb_spec_prep(int n, const RecipAtom* __restrict__ ra, int K, int G, double k00, double k01, double k02, double k10, double k11,
+                                double k12, double k20, double k21, double k22, const double* __restrict__ B6, const double* __restrict__ B5,
+                                int* __restrict__ sbase, double* __restrict__ sw, double* __restrict__ sdw) {
+#pragma clang fp contract(off)
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const double x = ra[e].x_new[0], y = ra[e].x_new[1], z = ra[e].x_new[2];
+  const double kk[3][3] = {{k00, k01, k02}, {k10, k11, k12}, {k20, k21, k22}};
+  for (int l = 0; l < 3; ++l) {
+    double u = (double)K * ((kk[l][0] * x + kk[l][1] * y) + kk[l][2] * z);
+    if (u < 0.0) u = u + (double)K; else if (u >= (double)K) u = u - (double)K;
+    if (fabs(fmod(u, 1.0)) < 1e-6) u = u + 1e-6;
+    const int np = (int)floor(u);
+    sbase[3 * e + l] = np;
+    for (int k = 0; k < 6; ++k) {
+      const double a1 = u - (double)(np - k), a2 = a1 - 1.0;
+      sw[(3 * e + l) * 6 + k] = B6[(int)ceil(a1 / 6.0 * (double)G) - 1];
+      double d = 0.0;
+      if (a1 < 5.0) d = B5[(int)ceil(a1 / 5.0 * (double)G) - 1];
+      if (0.0 < a2) d = d - B5[(int)ceil(a2 / 5.0 * (double)G) - 1];
+      sdw[(3 * e + l) * 6 + k] = d;
+    }
+  }
+}
+
+// one wavefront per entry: remove the atom's principal stencil, add its new stencil (modify_Q_grid, src/pme.f90:275)
+__global__ __launch_bounds__(256) void k_evb_patch(int n, const RecipAtom* __restrict__ ra, int K, size_t K3, const int* __restrict__ base,
+                                                   const double* __restrict__ w, const int* __restrict__ sbase, const double* __restrict__ sw,
+                                                   double2* __restrict__ grids) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (e >= n) return;
+  const RecipAtom r = ra[e];
+  double2* g = grids + (size_t)r.grid * K3;
+  for (int pass = 0; pass < 2; ++pass) {
+    const double q = pass == 0 ? -r.q_old : r.q_new;
+    if (fabs(q) <= 1e-6) continue;     // modify_Q_grid skips |chg| <= 1e-6 (src/pme.f90:296)
+    const int* b = pass == 0 ? base + 3 * r.idx : sbase + 3 * e;
+    const double* ww = pass == 0 ? w + 18 * (size_t)r.idx : sw + 18 * (size_t)e;
+    for (int t = lane; t < 216; t += 64) {
+      const int k1 = t % 6, k2 = (t / 6) % 6, k3 = t / 36;
+      int n1 = b[0] - k1; if (n1 < 0) n1 += K;
+      int n2 = b[1] - k2; if (n2 < 0) n2 += K;
+      int n3 = b[2] - k3; if (n3 < 0) n3 += K;
+      atomicAdd(&g[n1 + (size_t)K * (n2 + (size_t)K * n3)].x, q * ww[k1] * ww[6 + k2] * ww[12 + k3]);
+    }
+  }
+}
+
+// reciprocal force of EVERY atom against up to NG diabat grids with the principal stencil: one wavefront per atom.
+//   Fstore[slot_g][a] = F11[a] + (Frecip_g[a] - Frecip_1[a])
+template <int NG>
+__global__ __launch_bounds__(256) void k_evb_gather(int N, int K, size_t K3, int ng, const int* __restrict__ slots, const double* __restrict__ chg,
+                                                    const int* __restrict__ base, const double* __restrict__ w, const double* __restrict__ dw,
+                                                    const double2* __restrict__ grids, double conv, double k00, double k01, double k02, double k10,
+                                                    double k11, double k12, double k20, double k21, double k22, const double* __restrict__ F11,
+                                                    const double* __restrict__ Frecip1, double* __restrict__ Fstore, size_t fstride) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const int b1 = base[3 * i], b2 = base[3 * i + 1], b3 = base[3 * i + 2];
+  const double* wi = w + (size_t)i * 18;
+  const double* dwi = dw + (size_t)i * 18;
+  double acc[NG][3];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) acc[g][0] = acc[g][1] = acc[g][2] = 0.0;
+  for (int t = lane; t < 216; t += 64) {
+    const int k1 = t % 6, k2 = (t / 6) % 6, k3 = t / 36;
+    int n1 = b1 - k1; if (n1 < 0) n1 += K;
+    int n2 = b2 - k2; if (n2 < 0) n2 += K;
+    int n3 = b3 - k3; if (n3 < 0) n3 += K;
+    const size_t id = n1 + (size_t)K * (n2 + (size_t)K * n3);
+    const double w1 = wi[k1], w2 = wi[6 + k2], w3 = wi[12 + k3];
+    const double c1 = dwi[k1] * w2 * w3, c2 = dwi[6 + k2] * w1 * w3, c3 = dwi[12 + k3] * w1 * w2;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) if (g < ng) { const double th = grids[(size_t)g * K3 + id].x; acc[g][0] += c1 * th; acc[g][1] += c2 * th; acc[g][2] += c3 * th; }
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g >= ng) break;
+    double f1 = acc[g][0], f2 = acc[g][1], f3 = acc[g][2];
+    for (int o = 32; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); f3 += __shfl_xor(f3, o, 64); }
+    if (lane == 0) {
+      const double s = chg[i] * conv, Kd = (double)K;
+      f1 *= s; f2 *= s; f3 *= s;
+      double* F = Fstore + (size_t)slots[g] * fstride;
+      F[3 * i] = F11[3 * i] + (-Kd * (k00 * f1 + k10 * f2 + k20 * f3) - Frecip1[3 * i]);
+      F[3 * i + 1] = F11[3 * i + 1] + (-Kd * (k01 * f1 + k11 * f2 + k21 * f3) - Frecip1[3 * i + 1]);
+      F[3 * i + 2] = F11[3 * i + 2] + (-Kd * (k02 * f1 + k12 * f2 + k22 * f3) - Frecip1[3 * i + 2]);
+    }
+  }
+}
+
+// special atoms: replace the principal-stencil contribution by the new-state one (update_reciprocal_space_force_dQ_dr :2103)
+__global__ __launch_bounds__(256) void k_evb_recip_special(int n, const RecipAtom* __restrict__ ra, int K, size_t K3, const int* __restrict__ base,
+                                                           const double* __restrict__ w, const double* __restrict__ dw, const int* __restrict__ sbase,
+                                                           const double* __restrict__ sw, const double* __restrict__ sdw, const double2* __restrict__ grids,
+                                                           double conv, double k00, double k01, double k02, double k10, double k11, double k12, double k20,
+                                                           double k21, double k22, double* __restrict__ Fstore, size_t fstride) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (e >= n) return;
+  const RecipAtom r = ra[e];
+  const double2* g = grids + (size_t)r.grid * K3;
+  double tot[3] = {0, 0, 0};
+  for (int pass = 0; pass < 2; ++pass) {
+    const double q = pass == 0 ? -r.q_old : r.q_new;
+    const int* b = pass == 0 ? base + 3 * r.idx : sbase + 3 * e;
+    const double* ww = pass == 0 ? w + 18 * (size_t)r.idx : sw + 18 * (size_t)e;
+    const double* dd = pass == 0 ? dw + 18 * (size_t)r.idx : sdw + 18 * (size_t)e;
+    double f1 = 0, f2 = 0, f3 = 0;
+    for (int t = lane; t < 216; t += 64) {
+      const int k1 = t % 6, k2 = (t / 6) % 6, k3 = t / 36;
+      int n1 = b[0] - k1; if (n1 < 0) n1 += K;
+      int n2 = b[1] - k2; if (n2 < 0) n2 += K;
+      int n3 = b[2] - k3; if (n3 < 0) n3 += K;
+      const double th = g[n1 + (size_t)K * (n2 + (size_t)K * n3)].x;
+      f1 += dd[k1] * ww[6 + k2] * ww[12 + k3] * th; f2 += dd[6 + k2] * ww[k1] * ww[12 + k3] * th; f3 += dd[12 + k3] * ww[k1] * ww[6 + k2] * th;
+    }
+    for (int o = 32; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); f3 += __shfl_xor(f3, o, 64); }
+    const double s = q * conv, Kd = (double)K;
+    tot[0] += -Kd * (k00 * f1 + k10 * f2 + k20 * f3) * s; tot[1] += -Kd * (k01 * f1 + k11 * f2 + k21 * f3) * s; tot[2] += -Kd * (k02 * f1 + k12 * f2 + k22 * f3) * s;
+  }
+  if (lane == 0) { double* F = Fstore + (size_t)r.slot * fstride; for (int d = 0; d < 3; ++d) F[3 * r.idx + d] += tot[d]; }
+}
+
+// ---- off-diagonal element -------------------------------------------------------------------------------------------------
+// exchange-charge Coulomb sum over all NON-special molecules (evb_diabatic_coupling_electrostatics, src/ms_evb.f90:1276):
+// one thread per molecule (minimum image is taken per molecule, relative to the Zundel centre of mass).
+__global__ __launch_bounds__(256) void k_evb_coupling(int M, int n_cp, const CouplingDesc* __restrict__ cps, const int* __restrict__ mol_natom,
+                                                      const int* __restrict__ mol_atoms, const double* __restrict__ xyz, const double* __restrict__ chg,
+                                                      const double* __restrict__ mass, const int* __restrict__ atype, const double* __restrict__ exch_atomic,
+                                                      BoxDev box, double conv, double* __restrict__ Foff, size_t fstride, double* __restrict__ part,
+                                                      int part_stride, double* __restrict__ dVspec) {
+  __shared__ CouplingDesc cp;
+  __shared__ double sF[MAX_SPEC][3];
+  __shared__ double red[256];
+  const int ic = blockIdx.y;
+  {
+    const int* src = (const int*)&cps[ic]; int* dst = (int*)&cp;
+    for (int k = threadIdx.x; k < (int)(sizeof(CouplingDesc) / 4); k += blockDim.x) dst[k] = src[k];
+    for (int k = threadIdx.x; k < MAX_SPEC * 3; k += blockDim.x) (&sF[0][0])[k] = 0.0;
+  }
+  __syncthreads();
+  double* F = Foff + (size_t)cp.slot * fstride;
+  double vex = 0.0;
+  for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+    bool special = false;
+    for (int k = 0; k < cp.n_mols; ++k) special |= (cp.mols[k] == m);
+    if (special) continue;
+    const int n = mol_natom[m];
+    double com[3] = {0, 0, 0}, mt = 0;
+    for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; const double ma = mass[a]; for (int d = 0; d < 3; ++d) com[d] += xyz[3 * a + d] * ma; mt += ma; }
+    double sh[3];
+    for (int d = 0; d < 3; ++d) { com[d] /= mt; sh[d] = floor((com[d] - cp.zc[d]) * box.invL[d] + 0.5) * box.L[d]; }
+    for (int k = 0; k < n; ++k) {
+      const int j = mol_atoms[m * MAX_MOL_ATOMS + k];
+      const double qj = chg[j];
+      double fj[3] = {0, 0, 0};
+      for (int side = 0; side < 2; ++side) {
+        const int na = side == 0 ? cp.nD : cp.nA;
+        const int* lst = side == 0 ? cp.D_at : cp.A_at;
+        const double* shm = side == 0 ? cp.shiftd : cp.shifta;
+        for (int q = 0; q < na; ++q) {
+          const SpecAtom& a = cp.spec[lst[q]];
+          const double qi = (side == 1 && q == na - 1) ? cp.q_transfer : exch_atomic[a.type];
+          double rij[3];
+          for (int d = 0; d < 3; ++d) { const double xz = cp.zc[d] + (a.x[d] - cp.zc[d] - shm[d]); rij[d] = -(xyz[3 * j + d] - xz - sh[d]); }
+          const double r2 = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2], r = sqrt(r2);
+          vex += qi * qj / r * conv;
+          const double g = -qi * qj / (r2 * r) * conv;
+          for (int d = 0; d < 3; ++d) { fj[d] -= g * rij[d]; atomicAdd(&sF[lst[q]][d], g * rij[d]); }
+        }
+      }
+      for (int d = 0; d < 3; ++d) F[3 * j + d] = fj[d];    // dVex of this atom; scaled by -A in k_evb_coupling_finish
+    }
+  }
+  red[threadIdx.x] = vex;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+  if (threadIdx.x == 0) part[(size_t)ic * part_stride + blockIdx.x] = red[0];
+  for (int k = threadIdx.x; k < cp.n_spec * 3; k += blockDim.x) { const double v = sF[k / 3][k % 3]; if (v != 0.0) atomicAdd(&dVspec[(size_t)ic * MAX_SPEC * 3 + k], v); }
+}
+
+// evb_diabatic_coupling_function (src/ms_evb.f90:1180-1266)
+__device__ __forceinline__ void coupling_function(int ftype, const double* p, const double* q, const double* rOO, double& A, double& Vc, double dA[3][3]) {
+  const double rm = sqrt(rOO[0] * rOO[0] + rOO[1] * rOO[1] + rOO[2] * rOO[2]), q2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2], qm = sqrt(q2);
+  Vc = p[0];
+  if (ftype == 1) {
+    const double gamma = p[1], P = p[2], k = p[3], D = p[4], beta = p[5], R0 = p[6], Pp = p[7], alpha = p[8], rl0 = p[9];
+    const double f1 = exp(-gamma * q2), f2 = 1.0 + P * exp(-k * (rm - D) * (rm - D)), f3 = 0.5 * (1.0 - tanh(beta * (rm - R0))) + Pp * exp(-alpha * (rm - rl0));
+    const double ch = cosh(beta * (rm - R0));
+    const double d1 = -gamma * 2.0 * qm * f1, d2 = P * -k * 2.0 * (rm - D) * exp(-k * (rm - D) * (rm - D)), d3 = -0.5 * beta / (ch * ch) - Pp * alpha * exp(-alpha * (rm - rl0));
+    A = f1 * f2 * f3;
+    for (int d = 0; d < 3; ++d) {
+      const double tq = d1 * f2 * f3 * q[d] / qm, tr = (f1 * d2 * f3 + f1 * f2 * d3) * rOO[d] / rm;
+      dA[0][d] = 0.5 * tq + tr; dA[1][d] = 0.5 * tq - tr; dA[2][d] = -tq;
+    }
+  } else {
+    const double gamma = p[1], k = p[2], D = p[3];
+    const double f1 = exp(-gamma * q2), f2 = exp(-k * (rm - D) * (rm - D));
+    const double d1 = -gamma * 2.0 * qm * f1, d2 = -k * 2.0 * (rm - D) * f2;
+    A = f1 * f2;
+    for (int d = 0; d < 3; ++d) { const double tq = d1 * f2 * q[d] / qm, tr = f1 * d2 * rOO[d] / rm; dA[0][d] = 0.5 * tq + tr; dA[1][d] = 0.5 * tq - tr; dA[2][d] = -tq; }
+  }
+}
+
+// one thread per coupling: special-molecule part of Vex (molecules of the chain that are neither donor nor acceptor),
+// geometric factor, element energy; writes {A, Vc+Vex, H_pd} and the forces of the special atoms
+__global__ void k_evb_coupling_finish(int n_cp, const CouplingDesc* __restrict__ cps, const double* __restrict__ exch_atomic, const double* __restrict__ mass,
+                                      BoxDev box, double conv, const double* __restrict__ Vex_env, const double* __restrict__ dVspec,
+                                      double* __restrict__ Foff, size_t fstride, double* __restrict__ out /*[n_cp][3]*/) {
+  const int ic = blockIdx.x;
+  if (ic >= n_cp || threadIdx.x != 0) return;
+  const CouplingDesc& cp = cps[ic];
+  double vex = Vex_env[ic];
+  __shared__ double dV[MAX_SPEC][3];
+  __shared__ bool inDA[MAX_SPEC];
+  for (int k = 0; k < cp.n_spec; ++k) for (int d = 0; d < 3; ++d) dV[k][d] = dVspec[(size_t)ic * MAX_SPEC * 3 + 3 * k + d];
+  for (int k = 0; k < cp.n_spec; ++k) inDA[k] = false;
+  for (int k = 0; k < cp.nD; ++k) inDA[cp.D_at[k]] = true;
+  for (int k = 0; k < cp.nA; ++k) inDA[cp.A_at[k]] = true;
+  for (int im = 0; im < cp.n_mols; ++im) {       // special molecules other than donor / acceptor
+    const int m = cp.mols[im];
+    bool any = false, isDA = false;
+    for (int b = 0; b < cp.n_spec; ++b) if (cp.spec[b].mol == m) { any = true; isDA |= inDA[b]; }
+    if (!any || isDA) continue;
+    double sh[3];
+    for (int d = 0; d < 3; ++d) sh[d] = floor((cp.mol_com[im][d] - cp.zc[d]) * box.invL[d] + 0.5) * box.L[d];
+    for (int b = 0; b < cp.n_spec; ++b) {
+      if (cp.spec[b].mol != m) continue;
+      const double qj = cp.spec[b].q;
+      for (int side = 0; side < 2; ++side) {
+        const int na = side == 0 ? cp.nD : cp.nA;
+        const int* lst = side == 0 ? cp.D_at : cp.A_at;
+        const double* shm = side == 0 ? cp.shiftd : cp.shifta;
+        for (int q = 0; q < na; ++q) {
+          const SpecAtom& a = cp.spec[lst[q]];
+          const double qi = (side == 1 && q == na - 1) ? cp.q_transfer : exch_atomic[a.type];
+          double rij[3];
+          for (int d = 0; d < 3; ++d) { const double xz = cp.zc[d] + (a.x[d] - cp.zc[d] - shm[d]); rij[d] = -(cp.spec[b].x[d] - xz - sh[d]); }
+          const double r2 = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2], r = sqrt(r2);
+          vex += qi * qj / r * conv;
+          const double g = -qi * qj / (r2 * r) * conv;
+          for (int d = 0; d < 3; ++d) { dV[lst[q]][d] += g * rij[d]; dV[b][d] -= g * rij[d]; }
+        }
+      }
+    }
+  }
+  // geometric factor (evb_diabatic_coupling_geometric, src/ms_evb.f90:1117-1174)
+  const SpecAtom &O1 = cp.spec[cp.gO1], &O2 = cp.spec[cp.gO2], &H = cp.spec[cp.gH];
+  double sh[3], rO2[3], rH[3], rOO[3], q[3];
+  for (int d = 0; d < 3; ++d) {
+    sh[d] = floor((O2.x[d] - O1.x[d]) * box.invL[d] + 0.5) * box.L[d];
+    rO2[d] = O1.x[d] + (O2.x[d] - O1.x[d] - sh[d]); rH[d] = O1.x[d] + (H.x[d] - O1.x[d] - sh[d]);
+    rOO[d] = O1.x[d] - rO2[d]; q[d] = (O1.x[d] + rO2[d]) / 2.0 - rH[d];
+  }
+  double A, Vc, dA[3][3];
+  coupling_function(cp.ftype, cp.par, q, rOO, A, Vc, dA);
+  const double pre = Vc + vex;
+  for (int d = 0; d < 3; ++d) { dV[cp.gO1][d] += pre * dA[0][d] / A; dV[cp.gO2][d] += pre * dA[1][d] / A; dV[cp.gH][d] += pre * dA[2][d] / A; }
+  double* F = Foff + (size_t)cp.slot * fstride;
+  for (int k = 0; k < cp.n_spec; ++k) for (int d = 0; d < 3; ++d) F[3 * cp.spec[k].idx + d] = dV[k][d];   // still "dV"; scaled below with all atoms
+  out[3 * ic] = A; out[3 * ic + 1] = pre; out[3 * ic + 2] = pre * A;
+}
+__global__ void k_evb_scale(size_t n3, int n_cp, const CouplingDesc* __restrict__ cps, const double* __restrict__ out, double* __restrict__ Foff, size_t fstride) {
+  const int ic = blockIdx.y;
+  double* F = Foff + (size_t)cps[ic].slot * fstride;
+  const double mA = -out[3 * ic];
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (size_t)gridDim.x * blockDim.x) F[k] *= mA;
+}
+
+// Hellmann-Feynman blend: F = sum_d c_d^2 F_dd + 2 sum_(p,d) c_p c_d F_pd (src/ms_evb.f90:293-309)
+__global__ void k_evb_blend(size_t n3, int nterm, const int* __restrict__ slots, const int* __restrict__ isoff, const double* __restrict__ coef,
+                            const double* __restrict__ Fdiag, const double* __restrict__ Foff, size_t fstride, double* __restrict__ F) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (size_t)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int t = 0; t < nterm; ++t) s += coef[t] * (isoff[t] ? Foff : Fdiag)[(size_t)slots[t] * fstride + k];
+    F[k] = s;
+  }
+}
+
+__global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms, const double* __restrict__ xyz,
+                             const double* __restrict__ mass, BoxDev box, int* __restrict__ counter, RegionRec* __restrict__ out, int cap) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double ch[3] = {0, 0, 0}, mh = 0;
+  for (int k = 0; k < mol_natom[hyd]; ++k) { const int a = mol_atoms[hyd * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) ch[d] += xyz[3 * a + d] * mass[a]; mh += mass[a]; }
+  const int n = mol_natom[m];
+  double com[3] = {0, 0, 0}, mt = 0;
+  for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) com[d] += xyz[3 * a + d] * mass[a]; mt += mass[a]; }
+  double dr[3];
+  for (int d = 0; d < 3; ++d) { com[d] /= mt; dr[d] = com[d] - ch[d] / mh; }
+  min_image(dr, box);
+  if (dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2] < R2) {
+    const int slot = atomicAdd(counter, 1);
+    if (slot < cap) {
+      RegionRec r; r.mol = m; r.natom = n;
+      for (int d = 0; d < 3; ++d) r.com[d] = com[d];
+      for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) r.x[k][d] = xyz[3 * a + d]; }
+      out[slot] = r;
+    }
+  }
+}
+
+__global__ void k_sum_rows(int nrow, int ncol, int stride, const double* __restrict__ part, double* __restrict__ out) {
+  const int r = blockIdx.x;
+  __shared__ double red[256];
+  double s = 0;
+  for (int k = threadIdx.x; k < ncol; k += 256) s += part[(size_t)r * stride + k];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+  if (threadIdx.x == 0) out[r] = red[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------------- host side
+struct HMol { int id, type, natom; int atoms[MAX_MOL_ATOMS]; double com[3]; };
+struct HAtom { int type; double q; double x[3]; int mol; };
+struct HTopo {   // the molecules touched so far by a hop chain, in the topology reached so far
+  std::vector<HMol> mols;
+  std::map<int, HAtom> atoms;
+  int hydronium;
+};
+
+struct EvbWork {   // persistent device scratch of one context
+  DBuf<UnitDesc> d_units; DBuf<CouplingDesc> d_cps; DBuf<RecipAtom> d_ra; DBuf<EvbTablesDev> d_tabs; DBuf<double> d_exch;
+  DBuf<double> d_part, d_E, d_dVspec, d_cpout, d_coef; DBuf<int> d_slots, d_isoff, d_sbase, d_counter; DBuf<double> d_sw, d_sdw;
+  DBuf<double2> d_grids; DBuf<RegionRec> d_region;
+  DBuf<double> d_F11, d_dbg;
+  std::vector<double> h_dbg; int dbg_nu = 0;
+  int grids_cap = 0;
+  bool tabs_uploaded = false;
+  std::vector<RegionRec> region;
+  std::vector<double> h_E;
+};
+std::map<msevb_ctx*, EvbWork*> g_work;
+
+void pbc_shift_h(const msevb_ctx* c, const double* ri, const double* rj, double* sh) { for (int d = 0; d < 3; ++d) sh[d] = std::floor((rj[d] - ri[d]) * (1.0 / c->box[d]) + 0.5) * c->box[d]; }
+
+const RegionRec* find_region(const EvbWork* w, int mol) {
+  auto it = std::lower_bound(w->region.begin(), w->region.end(), mol, [](const RegionRec& r, int m) { return r.mol < m; });
+  return (it != w->region.end() && it->mol == mol) ? &*it : nullptr;
+}
+
+int ensure_mol(msevb_ctx* c, const EvbWork* w, HTopo& t, int m) {   // returns index in t.mols
+  for (size_t k = 0; k < t.mols.size(); ++k) if (t.mols[k].id == m) return (int)k;
+  const RegionRec* r = find_region(w, m);
+  if (!r) return -1;
+  HMol hm; hm.id = m; hm.type = c->h_mol_type[m]; hm.natom = c->h_mol_natom[m];
+  for (int k = 0; k < hm.natom; ++k) {
+    const int a = c->h_mol_atoms[(size_t)m * MAX_MOL_ATOMS + k];
+    hm.atoms[k] = a;
+    HAtom ha; ha.type = c->h_atype[a]; ha.q = c->h_chg[a]; ha.mol = m;
+    for (int d = 0; d < 3; ++d) ha.x[d] = r->x[k][d];
+    t.atoms[a] = ha;
+  }
+  for (int d = 0; d < 3; ++d) hm.com[d] = r->com[d];
+  t.mols.push_back(hm);
+  return (int)t.mols.size() - 1;
+}
+
+void mol_com_h(const msevb_ctx* c, const HTopo& t, HMol& m) {
+  double s[3] = {0, 0, 0}, mt = 0;
+  for (int k = 0; k < m.natom; ++k) { const HAtom& a = t.atoms.at(m.atoms[k]); const double ma = c->h_mass[m.atoms[k]]; for (int d = 0; d < 3; ++d) s[d] = s[d] + a.x[d] * ma; mt = mt + ma; }
+  for (int d = 0; d < 3; ++d) m.com[d] = s[d] / mt;
+}
+
+// evb_change_data_structures_proton_transfer (src/ms_evb.f90:843-932) on the compact topology
+int apply_hop_h(msevb_ctx* c, const EvbWork* w, HTopo& t, int md, int ip_local, int ma, int iheavy_local) {
+  const int kd = ensure_mol(c, w, t, md), ka0 = ensure_mol(c, w, t, ma);
+  if (kd < 0 || ka0 < 0) FAIL(MSEVB_ERR_LIMIT, "EVB: proton-hop molecule outside the gathered neighbourhood");
+  HMol& D = t.mols[kd];
+  HMol& A = t.mols[ka0];
+  const int gp = D.atoms[ip_local];
+  for (int k = ip_local; k < D.natom - 1; ++k) D.atoms[k] = D.atoms[k + 1];
+  D.natom -= 1;
+  if (A.natom >= MAX_MOL_ATOMS) FAIL(MSEVB_ERR_LIMIT, "EVB: acceptor molecule too large");
+  A.atoms[A.natom] = gp; A.natom += 1;
+  t.atoms[gp].mol = ma;
+  t.hydronium = ma;
+  for (int i = 1; i < A.natom; ++i) {    // make_molecule_whole (src/general_routines.f90:1065)
+    HAtom& prev = t.atoms[A.atoms[i - 1]];
+    HAtom& cur = t.atoms[A.atoms[i]];
+    double sh[3]; pbc_shift_h(c, prev.x, cur.x, sh);
+    if (std::fabs(sh[0]) > 1e-6 || std::fabs(sh[1]) > 1e-6 || std::fabs(sh[2]) > 1e-6) for (int d = 0; d < 3; ++d) cur.x[d] = prev.x[d] + (cur.x[d] - prev.x[d] - sh[d]);
+  }
+  mol_com_h(c, t, D); mol_com_h(c, t, A);
+  const int base_type = A.type, acid_type = c->e_conj_mol[base_type];
+  if (acid_type < 0) FAIL(MSEVB_ERR_ARG, "EVB: acceptor molecule type has no conjugate acid");
+  t.atoms[gp].type = c->e_proton_type[acid_type];
+  for (int i = 0; i < A.natom; ++i) {
+    HAtom& a = t.atoms[A.atoms[i]];
+    const int tn = (i != A.natom - 1) ? c->e_conj_atype[a.type] : a.type;
+    a.type = tn; a.q = c->h_atype_chg[tn];
+  }
+  t.atoms[A.atoms[iheavy_local]].type = c->e_heavy_type[acid_type];
+  for (int i = 0; i < D.natom; ++i) { HAtom& a = t.atoms[D.atoms[i]]; const int tn = c->e_conj_atype[a.type]; a.type = tn; a.q = c->h_atype_chg[tn]; }
+  D.type = c->e_conj_mol[D.type];
+  A.type = acid_type;
+  const MolTypeHost& mt = c->h_mt[acid_type];    // reorder_molecule_data_structures (src/ms_evb.f90:941)
+  for (int i = 0; i < mt.natom; ++i) {
+    if (mt.atype[i] != t.atoms[A.atoms[i]].type) {
+      int idx = -1;
+      for (int j = i + 1; j < A.natom; ++j) if (mt.atype[i] == t.atoms[A.atoms[j]].type) { idx = j; break; }
+      if (idx < 0) FAIL(MSEVB_ERR_ARG, "error in reorder_molecule_data_structures");
+      const int keep = A.atoms[idx];
+      for (int j = idx; j > i; --j) A.atoms[j] = A.atoms[j - 1];
+      A.atoms[i] = keep;
+    }
+  }
+  return MSEVB_OK;
+}
+
+int heavy_local_acid(const msevb_ctx* c, int acid_type) {   // get_heavy_atom_transfer_acid (src/ms_evb.f90:2917)
+  const MolTypeHost& mt = c->h_mt[acid_type];
+  for (int i = 0; i < mt.natom; ++i) if (mt.atype[i] == c->e_heavy_type[acid_type]) return i;
+  return -1;
+}
+
+int fill_spec(const HTopo& t, SpecAtom* spec, int* mols, int& n_spec, int& n_mols, std::map<int, int>& where) {
+  n_spec = 0; n_mols = 0;
+  for (const HMol& m : t.mols) {
+    mols[n_mols++] = m.id;
+    for (int k = 0; k < m.natom; ++k) {
+      const HAtom& a = t.atoms.at(m.atoms[k]);
+      SpecAtom& s = spec[n_spec];
+      s.idx = m.atoms[k]; s.type = a.type; s.mol = m.id; s.q = a.q; s.pad = 0;
+      for (int d = 0; d < 3; ++d) s.x[d] = a.x[d];
+      where[m.atoms[k]] = n_spec++;
+    }
+  }
+  return 0;
+}
+
+int make_unit(msevb_ctx* c, const HTopo& t, int donor, int acceptor, double sign, int slot, int do_rs, int do_rep, UnitDesc& u) {
+  memset(&u, 0, sizeof(u));
+  u.sign = sign; u.slot = slot; u.do_rs = do_rs; u.do_rep = do_rep; u.donor = donor; u.acceptor = acceptor; u.hyd = t.hydronium;
+  std::map<int, int> where;
+  fill_spec(t, u.spec, u.mols, u.n_spec, u.n_mols, where);
+  for (const HMol& m : t.mols) {
+    if (do_rs && m.id == donor) { u.nD = m.natom; u.mt_D = m.type; for (int k = 0; k < m.natom; ++k) u.D_at[k] = where[m.atoms[k]]; }
+    if (do_rs && m.id == acceptor) { u.nA = m.natom; u.mt_A = m.type; for (int k = 0; k < m.natom; ++k) u.A_at[k] = where[m.atoms[k]]; }
+    if (m.id == t.hydronium) {
+      u.nH = m.natom;
+      for (int k = 0; k < m.natom; ++k) u.H_at[k] = where[m.atoms[k]];
+      const int hl = heavy_local_acid(c, m.type);
+      if (hl < 0) FAIL(MSEVB_ERR_ARG, "couldn't find atom type in subroutine get_heavy_atom_transfer_acid");
+      u.heavy = u.H_at[hl];
+      u.type_H = t.atoms.at(m.atoms[m.natom - 1]).type;
+    }
+  }
+  return MSEVB_OK;
+}
+
+// symmetric Jacobi diagonalisation (jacobi, src/general_routines.f90:2013-2088)
+int jacobi_h(int n, std::vector<double>& a, std::vector<double>& d, std::vector<double>& v) {
+  std::vector<double> b(n), z(n, 0.0);
+  auto A = [&](int i, int j) -> double& { return a[(size_t)i * n + j]; };
+  auto V = [&](int i, int j) -> double& { return v[(size_t)i * n + j]; };
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V(i, j) = i == j ? 1.0 : 0.0;
+  for (int i = 0; i < n; ++i) { b[i] = A(i, i); d[i] = b[i]; }
+  auto rot = [&](double& x, double& y, double s, double tau) { const double g = x, h = y; x = g - s * (h + g * tau); y = h + s * (g - h * tau); };
+  for (int it = 1; it <= 50; ++it) {
+    double sm = 0.0;
+    for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) sm += std::fabs(A(i, j));
+    if (sm == 0.0) return 0;
+    const double tresh = it < 4 ? 0.2 * sm / double(n * n) : 0.0;
+    for (int ip = 0; ip < n - 1; ++ip) for (int iq = ip + 1; iq < n; ++iq) {
+      const double g = 100.0 * std::fabs(A(ip, iq));
+      if (it > 4 && std::fabs(d[ip]) + g == std::fabs(d[ip]) && std::fabs(d[iq]) + g == std::fabs(d[iq])) A(ip, iq) = 0.0;
+      else if (std::fabs(A(ip, iq)) > tresh) {
+        double h = d[iq] - d[ip], t;
+        if (std::fabs(h) + g == std::fabs(h)) t = A(ip, iq) / h;
+        else { const double theta = 0.5 * h / A(ip, iq); t = 1.0 / (std::fabs(theta) + std::sqrt(1.0 + theta * theta)); if (theta < 0.0) t = -t; }
+        const double cs = 1.0 / std::sqrt(1 + t * t), s = t * cs, tau = s / (1.0 + cs);
+        h = t * A(ip, iq);
+        z[ip] -= h; z[iq] += h; d[ip] -= h; d[iq] += h; A(ip, iq) = 0.0;
+        for (int k = 0; k < ip; ++k) rot(A(k, ip), A(k, iq), s, tau);
+        for (int k = ip + 1; k < iq; ++k) rot(A(ip, k), A(k, iq), s, tau);
+        for (int k = iq + 1; k < n; ++k) rot(A(ip, k), A(iq, k), s, tau);
+        for (int k = 0; k < n; ++k) rot(V(k, ip), V(k, iq), s, tau);
+      }
+    }
+    for (int i = 0; i < n; ++i) { b[i] += z[i]; d[i] = b[i]; z[i] = 0.0; }
+  }
+  return -1;
+}
+
+}  // namespace
+
+static BoxDev mkbox(const msevb_ctx* c) { BoxDev b; for (int d = 0; d < 3; ++d) { b.L[d] = c->box[d]; b.invL[d] = 1.0 / c->box[d]; } return b; }
+
+// slot helpers: diagonal store has 1 + R*S slots (0 = principal), off-diagonal store R*S; diabat d (0-based, d>=1)
+static inline int slots_per_rank(const msevb_ctx* c, int D) { return D <= 1 ? 0 : (D - 1 + c->n_ranks - 1) / c->n_ranks; }
+static inline int off_slot(const msevb_ctx* c, int D, int d) { return ((d - 1) % c->n_ranks) * slots_per_rank(c, D) + (d - 1) / c->n_ranks; }
+static inline int diag_slot(const msevb_ctx* c, int D, int d) { return d == 0 ? 0 : 1 + off_slot(c, D, d); }
+static inline bool owned(const msevb_ctx* c, int d) { return d == 0 || ((d - 1) % c->n_ranks) == c->rank; }
+
+extern "C" int msevb_comm_allgather_evb(msevb_ctx* c);   // comm.hip
+
+int evb_force_energy(msevb_ctx* c, double* epot_out) {
+  if (!c->evb_set) FAIL(MSEVB_ERR_STATE, "EVB tables not set (msevb_set_evb)");
+  EvbWork*& wp = g_work[c];
+  if (!wp) wp = new EvbWork();
+  EvbWork* w = wp;
+  const int N = c->N, M = c->M, K = c->K;
+  const size_t K3 = (size_t)K * K * K, n3 = 3 * (size_t)N;
+  const BoxDev box = mkbox(c);
+  // ---- 1. principal diabat (calculate_total_force_energy, src/ms_evb.f90:411)
+  CHK(total_force_enqueue(c));
+  // ---- 2. neighbourhood of the hydronium -> host (replaces the all-molecule scans of :724)
+  if (w->d_region.alloc(REGION_CAP) || w->d_counter.alloc(4)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB region)");
+  HIPCHK(hipMemsetAsync(w->d_counter.p, 0, sizeof(int), c->stream));
+  const double Rreg = 5.0 * c->max_chain + 5.0;
+  hipLaunchKernelGGL(k_evb_region, dim3((M + 255) / 256), dim3(256), 0, c->stream, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
+                     c->d_mass.p, box, w->d_counter.p, w->d_region.p, REGION_CAP);
+  int nreg = 0;
+  HIPCHK(hipMemcpyAsync(&nreg, w->d_counter.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (nreg > REGION_CAP) FAIL(MSEVB_ERR_LIMIT, "EVB neighbourhood buffer too small");
+  w->region.resize(nreg);
+  HIPCHK(hipMemcpyAsync(w->region.data(), w->d_region.p, nreg * sizeof(RegionRec), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::sort(w->region.begin(), w->region.end(), [](const RegionRec& a, const RegionRec& b) { return a.mol < b.mol; });
+  // ---- 3. diabat enumeration on the principal topology (evb_conduct_proton_transfer_recursive, :498)
+  for (int d = 0; d < MAX_DIABATS; ++d) { c->parent[d] = -1; for (int h = 0; h < MAX_CHAIN; ++h) for (int q = 0; q < 5; ++q) c->plog[d][h][q] = -1; }
+  c->D = 1;
+  {
+    struct Frame { int mol, diabat; };
+    // recursion implemented with an explicit lambda to keep the reference's DFS order
+    std::function<int(int, int)> rec = [&](int im_donor, int d_donor) -> int {
+      int count = 0;
+      for (int h = 0; h < c->max_chain; ++h) { if (c->plog[d_donor][h][0] < 0) break; count++; }
+      if (count >= c->max_chain) return MSEVB_OK;
+      const RegionRec* ri = find_region(w, im_donor);
+      if (!ri) FAIL(MSEVB_ERR_LIMIT, "EVB: donor outside the gathered neighbourhood");
+      const MolTypeHost& mt = c->h_mt[c->h_mol_type[im_donor]];
+      for (int ia = 0; ia < c->h_mol_natom[im_donor]; ++ia) {
+        if (mt.reactive_protons[ia] != 1) continue;
+        for (const RegionRec& rj : w->region) {      // ascending molecule index == the reference's j_mole loop
+          if (rj.mol == im_donor) continue;
+          double sh[3], dc[3]; pbc_shift_h(c, ri->com, rj.com, sh);
+          for (int d = 0; d < 3; ++d) dc[d] = rj.com[d] - ri->com[d] - sh[d];
+          if (dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2] >= 25.0) continue;       // evb_first_solvation_cutoff = 5 (src/glob_v.f90:54)
+          const MolTypeHost& mj = c->h_mt[c->h_mol_type[rj.mol]];
+          for (int ja = 0; ja < rj.natom; ++ja) {
+            if (mj.reactive_basic[ja] != 1) continue;
+            double r[3]; for (int d = 0; d < 3; ++d) r[d] = rj.x[ja][d] - ri->x[ia][d] - sh[d];
+            if (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] >= 6.25) continue;           // evb_reactive_pair_distance = 2.5 (src/glob_v.f90:55)
+            if (c->D >= MAX_DIABATS) FAIL(MSEVB_ERR_LIMIT, "Found more diabat states than evb_max_states");
+            const int d = c->D++;
+            c->parent[d] = d_donor;
+            for (int h = 0; h < count; ++h) for (int q = 0; q < 5; ++q) c->plog[d][h][q] = c->plog[d_donor][h][q];
+            int heavy = -1;
+            for (size_t b = 0; b < mt.bonds.size() / 2; ++b) { if (mt.bonds[2 * b] == ia) heavy = mt.bonds[2 * b + 1]; else if (mt.bonds[2 * b + 1] == ia) heavy = mt.bonds[2 * b]; }
+            c->plog[d][count][0] = im_donor; c->plog[d][count][1] = ia; c->plog[d][count][2] = heavy; c->plog[d][count][3] = rj.mol; c->plog[d][count][4] = ja;
+            if (rj.mol != c->hydronium) CHK(rec(rj.mol, d));
+          }
+        }
+      }
+      return MSEVB_OK;
+    };
+    CHK(rec(c->hydronium, 0));
+  }
+  const int D = c->D, S = slots_per_rank(c, D), n_off = c->n_ranks * S, n_diag = 1 + n_off;
+  // ---- 4. evaluation units / couplings / recip patches of the diabats owned by this rank
+  std::vector<UnitDesc> units;
+  std::vector<CouplingDesc> cps;
+  std::vector<RecipAtom> ras;
+  std::vector<int> grid_of(D, -1), cp_of(D, -1);
+  std::vector<double> eref_delta(D, 0.0);
+  std::vector<std::vector<int>> units_of(D);
+  HTopo P; P.hydronium = c->hydronium;
+  if (ensure_mol(c, w, P, c->hydronium) < 0) FAIL(MSEVB_ERR_LIMIT, "EVB: hydronium outside region");
+  { UnitDesc u; CHK(make_unit(c, P, -1, -1, +1.0, 0, 0, 1, u)); units_of[0].push_back((int)units.size()); units.push_back(u); }
+  int ngrid = 0;
+  for (int d = 1; d < D; ++d) {
+    if (!owned(c, d)) continue;
+    HTopo T = P;
+    const int slot = diag_slot(c, D, d);
+    int md = c->hydronium, ma = c->hydronium, nhop = 0;
+    for (int h = 0; h < c->max_chain; ++h) if (c->plog[d][h][0] >= 0) nhop = h + 1;
+    for (int h = 0; h < c->max_chain; ++h) {
+      if (c->plog[d][h][0] < 0) break;
+      md = T.hydronium; ma = c->plog[d][h][3];
+      if (ensure_mol(c, w, T, md) < 0 || ensure_mol(c, w, T, ma) < 0) FAIL(MSEVB_ERR_LIMIT, "EVB: hop molecule outside region");
+      { UnitDesc u; CHK(make_unit(c, T, md, ma, -1.0, slot, 1, 0, u)); units_of[d].push_back((int)units.size()); units.push_back(u); }
+      int typ_old = -1; for (const HMol& m : T.mols) if (m.id == T.hydronium) typ_old = m.type;
+      CHK(apply_hop_h(c, w, T, md, c->plog[d][h][1], ma, c->plog[d][h][4]));
+      { UnitDesc u; CHK(make_unit(c, T, md, ma, +1.0, slot, 1, h == nhop - 1 ? 1 : 0, u)); units_of[d].push_back((int)units.size()); units.push_back(u); }
+      int typ_new = -1; for (const HMol& m : T.mols) if (m.id == T.hydronium) typ_new = m.type;
+      eref_delta[d] += c->e_ref[typ_new] - c->e_ref[typ_old];
+    }
+    // reciprocal-space patches: every atom of a touched molecule
+    grid_of[d] = ngrid++;
+    for (const HMol& m : T.mols) for (int k = 0; k < m.natom; ++k) {
+      const int a = m.atoms[k]; const HAtom& ha = T.atoms.at(a);
+      RecipAtom r; r.grid = grid_of[d]; r.slot = slot; r.idx = a; r.pad = 0; r.q_new = ha.q; r.q_old = c->h_chg[a];
+      for (int q = 0; q < 3; ++q) r.x_new[q] = ha.x[q];
+      ras.push_back(r);
+    }
+    // off-diagonal element with the parent diabat, in this (acceptor) topology (evb_diabatic_coupling, :1021)
+    CouplingDesc cp; memset(&cp, 0, sizeof(cp));
+    cp.slot = off_slot(c, D, d);
+    std::map<int, int> where;
+    fill_spec(T, cp.spec, cp.mols, cp.n_spec, cp.n_mols, where);
+    const HMol *Dm = nullptr, *Am = nullptr;
+    for (size_t k = 0; k < T.mols.size(); ++k) { if (T.mols[k].id == md) Dm = &T.mols[k]; if (T.mols[k].id == ma) Am = &T.mols[k]; for (int q = 0; q < 3; ++q) cp.mol_com[k][q] = T.mols[k].com[q]; }
+    cp.nD = Dm->natom; cp.nA = Am->natom;
+    for (int k = 0; k < Dm->natom; ++k) cp.D_at[k] = where[Dm->atoms[k]];
+    for (int k = 0; k < Am->natom; ++k) cp.A_at[k] = where[Am->atoms[k]];
+    double mdt = 0, mat = 0;
+    for (int k = 0; k < Dm->natom; ++k) mdt = mdt + c->h_mass[Dm->atoms[k]];
+    for (int k = 0; k < Am->natom; ++k) mat = mat + c->h_mass[Am->atoms[k]];
+    double sha[3]; pbc_shift_h(c, Dm->com, Am->com, sha);      // zundel_r_com (src/ms_evb.f90:2946)
+    for (int q = 0; q < 3; ++q) { const double rca = Dm->com[q] + (Am->com[q] - Dm->com[q] - sha[q]); cp.zc[q] = (mdt * Dm->com[q] + mat * rca) / (mdt + mat); cp.shiftd[q] = 0.0; cp.shifta[q] = sha[q]; }
+    cp.q_transfer = c->e_exch_proton[Am->type][Dm->type];
+    const int i_don = heavy_local_acid(c, c->e_conj_mol[Dm->type]), i_acc = heavy_local_acid(c, Am->type);
+    if (i_don < 0 || i_acc < 0) FAIL(MSEVB_ERR_ARG, "couldn't find heavy atom for the diabatic coupling");
+    cp.gO1 = where[Dm->atoms[i_don]]; cp.gO2 = where[Am->atoms[i_acc]]; cp.gH = where[Am->atoms[Am->natom - 1]];
+    const int t1 = cp.spec[cp.gO1].type, t2 = cp.spec[cp.gO2].type, t3 = cp.spec[cp.gH].type;
+    int ic = -1;
+    for (int k = 0; k < c->n_cp; ++k) if (c->cp_types[k][0] == t1 && c->cp_types[k][1] == t2 && c->cp_types[k][2] == t3) { ic = k; break; }
+    if (ic < 0) FAIL(MSEVB_ERR_ARG, "couldn't find index in subroutine 'get_index_atom_set' (diabat coupling parameters)");
+    cp.ftype = c->cp_func[ic];
+    for (int k = 0; k < 10; ++k) cp.par[k] = c->cp_par[ic][k];
+    cp_of[d] = (int)cps.size();
+    cps.push_back(cp);
+  }
+  const int nu = (int)units.size(), ncp = (int)cps.size(), nra = (int)ras.size();
+  // ---- 5. device buffers
+  const int envb = std::min(512, (N + 255) / 256), cpb = std::min(256, (M + 255) / 256), convb = 1024;
+  const int part_stride = 1024;
+  const int n_rows = nu + ncp + ngrid + 8;
+  if (c->d_Fdiag.alloc((size_t)n_diag * n3) || c->d_Foff.alloc((size_t)std::max(n_off, 1) * n3) || w->d_units.alloc(nu) || w->d_cps.alloc(std::max(ncp, 1)) ||
+      w->d_ra.alloc(std::max(nra, 1)) || w->d_tabs.alloc(1) || w->d_exch.alloc(MAX_TYPES) || w->d_part.alloc((size_t)n_rows * part_stride) ||
+      w->d_E.alloc(2 * n_rows + 3 * std::max(ncp, 1)) || w->d_dVspec.alloc((size_t)std::max(ncp, 1) * MAX_SPEC * 3) || w->d_cpout.alloc(3 * std::max(ncp, 1)) ||
+      w->d_sbase.alloc(3 * std::max(nra, 1)) || w->d_sw.alloc(18 * (size_t)std::max(nra, 1)) || w->d_sdw.alloc(18 * (size_t)std::max(nra, 1)) ||
+      w->d_grids.alloc(K3 * std::max(ngrid, 1)) || w->d_dbg.alloc(8 * (size_t)nu) || w->d_coef.alloc(4 * MAX_DIABATS) || w->d_slots.alloc(4 * MAX_DIABATS) || w->d_isoff.alloc(4 * MAX_DIABATS))
+    FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB work buffers)");
+  c->evb_cap = D;
+  if (!w->tabs_uploaded) {
+    EvbTablesDev tb; memset(&tb, 0, sizeof tb);
+    tb.n_da = c->n_da; tb.n_pa = c->n_pa;
+    memcpy(tb.da_types, c->da_types, sizeof tb.da_types); memcpy(tb.da_par, c->da_par, sizeof tb.da_par);
+    memcpy(tb.pa_types, c->pa_types, sizeof tb.pa_types); memcpy(tb.pa_par, c->pa_par, sizeof tb.pa_par);
+    memcpy(tb.exch_atomic, c->e_exch_atomic, sizeof tb.exch_atomic);
+    double rmax = 0.0;
+    for (int k = 0; k < c->n_da; ++k) rmax = std::max(rmax, c->da_par[k][5]);
+    for (int k = 0; k < c->n_pa; ++k) rmax = std::max(rmax, c->pa_par[k][4] + 3.0);
+    tb.screen2 = (rmax + 0.5) * (rmax + 0.5);
+    HIPCHK(hipMemcpy(w->d_tabs.p, &tb, sizeof tb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(w->d_exch.p, c->e_exch_atomic, sizeof(double) * MAX_TYPES, hipMemcpyHostToDevice));
+    w->tabs_uploaded = true;
+  }
+  HIPCHK(hipMemcpyAsync(w->d_units.p, units.data(), nu * sizeof(UnitDesc), hipMemcpyHostToDevice, c->stream));
+  if (ncp) HIPCHK(hipMemcpyAsync(w->d_cps.p, cps.data(), ncp * sizeof(CouplingDesc), hipMemcpyHostToDevice, c->stream));
+  if (nra) HIPCHK(hipMemcpyAsync(w->d_ra.p, ras.data(), nra * sizeof(RecipAtom), hipMemcpyHostToDevice, c->stream));
+  double* part_units = w->d_part.p;
+  double* part_cp = w->d_part.p + (size_t)nu * part_stride;
+  double* part_grid = w->d_part.p + (size_t)(nu + ncp) * part_stride;
+  double* E_units_env = w->d_E.p;                 // [nu]
+  double* E_units_spec = w->d_E.p + nu;           // [nu]
+  double* E_cp_env = w->d_E.p + 2 * nu;           // [ncp]
+  double* E_grid = w->d_E.p + 2 * nu + ncp;       // [ngrid]
+  // principal slot <- principal force
+  HIPCHK(hipMemcpyAsync(c->d_Fdiag.p, c->d_force.p, n3 * 8, hipMemcpyDeviceToDevice, c->stream));
+  if (n_off) HIPCHK(hipMemsetAsync(c->d_Foff.p, 0, (size_t)n_off * n3 * 8, c->stream));
+  if (n_off && c->n_ranks > 1) HIPCHK(hipMemsetAsync(c->d_Fdiag.p + n3, 0, (size_t)n_off * n3 * 8, c->stream));
+  // ---- 6. reciprocal space of the owned diabats (calculate_reciprocal_space_pme, :1962)
+  phase_begin(c, PH_EVB_RECIP);
+  if (ngrid) {
+    hipLaunchKernelGGL(k_evb_grid_init, dim3(2048), dim3(256), 0, c->stream, K3, ngrid, c->d_Q.p, w->d_grids.p);
+    hipLaunchKernelGGL(k_evb_spec_prep, dim3((nra + 63) / 64), dim3(64), 0, c->stream, nra, w->d_ra.p, K, c->spline_grid, c->kk[0][0], c->kk[0][1], c->kk[0][2],
+                       c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p);
+    hipLaunchKernelGGL(k_evb_patch, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, w->d_ra.p, K, K3, c->d_base.p, c->d_w.p, w->d_sbase.p, w->d_sw.p, w->d_grids.p);
+    HIPCHK(hipGetLastError());
+    for (int g = 0; g < ngrid; ++g) {
+      // pme_convolve writes its energy partials to slot S_EVB0 of the shared buffer; move the reduced value to E_grid[g]
+      CHK(pme_convolve(c, w->d_grids.p + (size_t)g * K3, S_EVB0));
+      HIPCHK(hipMemcpyAsync(E_grid + g, c->d_energies.p + S_EVB0, 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    // all-atom gather, up to 8 grids per pass
+    std::vector<int> gslots(ngrid);
+    for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gslots[grid_of[d]] = diag_slot(c, D, d);
+    HIPCHK(hipMemcpyAsync(w->d_slots.p + 2 * MAX_DIABATS, gslots.data(), ngrid * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    for (int g0 = 0; g0 < ngrid; g0 += 8) {
+      const int ng = std::min(8, ngrid - g0);
+      hipLaunchKernelGGL(k_evb_gather<8>, dim3((N + 3) / 4), dim3(256), 0, c->stream, N, K, K3, ng, w->d_slots.p + 2 * MAX_DIABATS + g0, c->d_chg.p, c->d_base.p,
+                         c->d_w.p, c->d_dw.p, w->d_grids.p + (size_t)g0 * K3, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1],
+                         c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_force.p, c->d_force_recip.p, c->d_Fdiag.p, n3);
+    }
+    hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, w->d_ra.p, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
+                       w->d_sw.p, w->d_sdw.p, w->d_grids.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0],
+                       c->kk[2][1], c->kk[2][2], c->d_Fdiag.p, n3);
+    HIPCHK(hipGetLastError());
+  }
+  phase_end(c, PH_EVB_RECIP);
+  // ---- 7. real-space / bonded / repulsion deltas of all units (ms_evb_diabat_force_energy, :1421)
+  phase_begin(c, PH_EVB_REAL);
+  hipLaunchKernelGGL(k_evb_env, dim3(envb, nu), dim3(256), 0, c->stream, N, nu, w->d_units.p, w->d_tabs.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p, c->d_mol_of.p,
+                     c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->d_Fdiag.p, n3, part_units, part_stride);
+  hipLaunchKernelGGL(k_sum_rows, dim3(nu), dim3(256), 0, c->stream, nu, envb, part_stride, part_units, E_units_env);
+  hipLaunchKernelGGL(k_evb_special, dim3(nu), dim3(64), 0, c->stream, nu, w->d_units.p, w->d_tabs.p, c->d_moltypes.p, c->d_pair_par.p, c->nt,
+                     c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->alpha, 2.0 * c->alpha / c->pi_sqrt, c->conv, c->pi,
+                     c->d_Fdiag.p, n3, E_units_spec, w->d_dbg.p);
+  // ---- 8. off-diagonal elements
+  if (ncp) {
+    HIPCHK(hipMemsetAsync(w->d_dVspec.p, 0, (size_t)ncp * MAX_SPEC * 3 * 8, c->stream));
+    hipLaunchKernelGGL(k_evb_coupling, dim3(cpb, ncp), dim3(256), 0, c->stream, M, ncp, w->d_cps.p, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_chg.p,
+                       c->d_mass.p, c->d_atype.p, w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p);
+    hipLaunchKernelGGL(k_sum_rows, dim3(ncp), dim3(256), 0, c->stream, ncp, cpb, part_stride, part_cp, E_cp_env);
+    hipLaunchKernelGGL(k_evb_coupling_finish, dim3(ncp), dim3(64), 0, c->stream, ncp, w->d_cps.p, w->d_exch.p, c->d_mass.p, box, c->conv, E_cp_env,
+                       w->d_dVspec.p, c->d_Foff.p, n3, w->d_cpout.p);
+    hipLaunchKernelGGL(k_evb_scale, dim3(256, ncp), dim3(256), 0, c->stream, n3, ncp, w->d_cps.p, w->d_cpout.p, c->d_Foff.p, n3);
+  }
+  HIPCHK(hipGetLastError());
+  phase_end(c, PH_EVB_REAL);
+  // ---- 9. energies to the host, Hamiltonian
+  w->h_E.resize(2 * nu + ncp + ngrid + 3 * std::max(ncp, 1));
+  HIPCHK(hipMemcpyAsync(w->h_E.data(), w->d_E.p, (2 * nu + ncp + ngrid) * 8, hipMemcpyDeviceToHost, c->stream));
+  if (ncp) HIPCHK(hipMemcpyAsync(w->h_E.data() + 2 * nu + ncp + ngrid, w->d_cpout.p, 3 * ncp * 8, hipMemcpyDeviceToHost, c->stream));
+  w->h_dbg.resize(8 * (size_t)nu + 2 * nu + ngrid); w->dbg_nu = nu;
+  HIPCHK(hipMemcpyAsync(w->h_dbg.data(), w->d_dbg.p, 8 * (size_t)nu * 8, hipMemcpyDeviceToHost, c->stream));
+  CHK(fetch_energies(c));
+  for (int k = 0; k < 2 * nu + ncp + ngrid && k < 2 * nu + ngrid; ++k) w->h_dbg[8 * (size_t)nu + k] = k < 2 * nu ? w->h_E[k] : w->h_E[k + ncp];
+  double en[MSEVB_N_ENERGY];
+  total_force_collect(c, en);
+  const double E_recip1 = c->E_recip;
+  memset(c->H, 0, sizeof c->H);
+  auto unitE = [&](int iu) { return w->h_E[iu] + w->h_E[nu + iu]; };
+  const double H11_norep = en[MSEVB_E_POTENTIAL] + c->e_ref[c->h_mol_type[c->hydronium]];
+  const double H11 = H11_norep + unitE(units_of[0][0]);
+  c->H[0][0] = H11;
+  for (int d = 1; d < D; ++d) {
+    if (!owned(c, d)) continue;
+    double e = H11_norep + eref_delta[d];
+    for (int iu : units_of[d]) e += units[iu].sign * unitE(iu);
+    e += w->h_E[2 * nu + ncp + grid_of[d]] - E_recip1;
+    c->H[d][d] = e;
+    c->H[c->parent[d]][d] = w->h_E[2 * nu + ncp + ngrid + 3 * cp_of[d] + 2];
+  }
+  // ---- 10. multi-GPU: complete the Hamiltonian and the force stores on every rank
+  if (c->n_ranks > 1 && c->nccl_comm) CHK(msevb_comm_allgather_evb(c));
+  if (c->n_ranks > 1 && !c->nccl_comm) {   // virtual sharding (tests): leave foreign diabats empty; caller merges
+    if (epot_out) *epot_out = H11;
+    return MSEVB_OK;
+  }
+  // ---- 11. diagonalise, blend (diagonalize_evb_hamiltonian, :242)
+  std::vector<double> a((size_t)D * D), ev(D), v((size_t)D * D);
+  for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) { a[(size_t)i * D + j] = c->H[i][j]; a[(size_t)j * D + i] = c->H[i][j]; }
+  if (jacobi_h(D, a, ev, v) != 0) FAIL(MSEVB_ERR_NUMERIC, "too many iterations in jacobi");
+  int g = 0; double eg = ev[0];
+  for (int i = 1; i < D; ++i) if (ev[i] < eg) { eg = ev[i]; g = i; }
+  for (int i = 0; i < D; ++i) c->eigvec[i] = v[(size_t)i * D + g];
+  std::vector<double> coef; std::vector<int> slots, isoff;
+  for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) {
+    if (i == j) { coef.push_back(c->eigvec[i] * c->eigvec[j]); slots.push_back(diag_slot(c, D, i)); isoff.push_back(0); }
+    else if (c->parent[j] == i) { coef.push_back(2.0 * c->eigvec[i] * c->eigvec[j]); slots.push_back(off_slot(c, D, j)); isoff.push_back(1); }
+  }
+  const int nterm = (int)coef.size();
+  if (nterm > 4 * MAX_DIABATS / 2) FAIL(MSEVB_ERR_LIMIT, "too many non-zero ms-evb matrix elements");
+  phase_begin(c, PH_EVB_BLEND);
+  HIPCHK(hipMemcpyAsync(w->d_coef.p, coef.data(), nterm * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(w->d_slots.p, slots.data(), nterm * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(w->d_isoff.p, isoff.data(), nterm * 4, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, nterm, w->d_slots.p, w->d_isoff.p, w->d_coef.p,
+                     c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p);
+  HIPCHK(hipGetLastError());
+  phase_end(c, PH_EVB_BLEND);
+  int pr = 0; double sc = std::fabs(c->eigvec[0]);
+  for (int i = 0; i < D; ++i) if (sc < std::fabs(c->eigvec[i])) { sc = std::fabs(c->eigvec[i]); pr = i; }
+  c->principal = pr; c->new_hydronium = c->hydronium;
+  for (int h = 0; h < c->max_chain; ++h) { if (c->plog[pr][h][0] < 0) break; c->new_hydronium = c->plog[pr][h][3]; }
+  if (epot_out) *epot_out = eg;
+  // ---- 12. principal-diabat switch (src/ms_evb.f90:218-227): adopt the new topology, rebuild the Verlet list
+  if (c->new_hydronium != c->hydronium) {
+    HTopo T = P;
+    for (int h = 0; h < c->max_chain; ++h) { if (c->plog[pr][h][0] < 0) break; CHK(apply_hop_h(c, w, T, T.hydronium, c->plog[pr][h][1], c->plog[pr][h][3], c->plog[pr][h][4])); }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (const HMol& m : T.mols) {
+      c->h_mol_type[m.id] = m.type; c->h_mol_natom[m.id] = m.natom;
+      for (int k = 0; k < MAX_MOL_ATOMS; ++k) c->h_mol_atoms[(size_t)m.id * MAX_MOL_ATOMS + k] = k < m.natom ? m.atoms[k] : -1;
+      for (int k = 0; k < m.natom; ++k) {
+        const int a = m.atoms[k]; const HAtom& ha = T.atoms.at(a);
+        c->h_atype[a] = ha.type; c->h_chg[a] = ha.q; c->h_mol_of[a] = m.id;
+        HIPCHK(hipMemcpy(c->d_xyz.p + 3 * (size_t)a, ha.x, 24, hipMemcpyHostToDevice));
+      }
+    }
+    c->hydronium = T.hydronium;
+    CHK(upload_topology(c));
+    CHK(nb_build(c));
+    c->flag_verlet_list = 0;
+  }
+  return MSEVB_OK;
+}
+
+extern "C" {
+
+int msevb_ms_evb_calculate_total_force_energy(msevb_ctx* c, double* epot, double* force) {
+  if (!c || !c->finalized) { if (c) c->err = "context not finalized"; return MSEVB_ERR_STATE; }
+  (void)hipSetDevice(c->device);
+  double e = 0;
+  CHK(evb_force_energy(c, &e));
+  if (force) HIPCHK(hipMemcpyAsync(force, c->d_force.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (epot) *epot = e;
+  return MSEVB_OK;
+}
+
+int msevb_get_evb_state(msevb_ctx* c, int* nd, int* plog, int* cm, double* H, double* ev, int* pr, int* nh) {
+  if (!c) return MSEVB_ERR_ARG;
+  const int D = c->D;
+  if (nd) *nd = D;
+  if (plog) for (int d = 0; d < D; ++d) for (int h = 0; h < c->max_chain; ++h) for (int q = 0; q < 5; ++q) { const int v = c->plog[d][h][q]; plog[(d * c->max_chain + h) * 5 + q] = v < 0 ? -1 : v + 1; }
+  if (cm) for (int d = 0; d < D; ++d) cm[d] = c->parent[d] < 0 ? -1 : c->parent[d] + 1;
+  if (H) for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) H[i * D + j] = c->H[i][j];
+  if (ev) for (int d = 0; d < D; ++d) ev[d] = c->eigvec[d];
+  if (pr) *pr = c->principal + 1;
+  if (nh) *nh = c->new_hydronium + 1;
+  return MSEVB_OK;
+}
+
+int msevb_get_evb_element_force(msevb_ctx* c, int i, int j, double* force) {
+  if (!c || c->D <= 0 || i < 1 || j < i || j > c->D) { if (c) c->err = "bad element"; return MSEVB_ERR_ARG; }
+  const size_t n3 = 3 * (size_t)c->N;
+  const double* src;
+  if (i == j) src = c->d_Fdiag.p + (size_t)diag_slot(c, c->D, i - 1) * n3;
+  else { if (c->parent[j - 1] != i - 1) FAIL(MSEVB_ERR_ARG, "Hamiltonian element is zero"); src = c->d_Foff.p + (size_t)off_slot(c, c->D, j - 1) * n3; }
+  HIPCHK(hipMemcpyAsync(force, src, n3 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MSEVB_OK;
+}
+
+int msevb_get_evb_debug(msevb_ctx* c, double* out, int n) {
+  EvbWork* w = g_work[c];
+  if (!w) return 0;
+  const int m = (int)w->h_dbg.size();
+  if (out) memcpy(out, w->h_dbg.data(), sizeof(double) * std::min(n, m));
+  return w->dbg_nu;
+}
+
+int msevb_comm_set_virtual(msevb_ctx* c, int r, int n) { if (!c || n < 1 || r < 0 || r >= n) return MSEVB_ERR_ARG; c->rank = r; c->n_ranks = n; return MSEVB_OK; }
+
+}  // extern "C"

@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py - MD timesteps/s of the MS-EVB force/energy hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 32^3-site lattice water + CH3SO3H + planted
+H-bond tree -> ~98k atoms, 8 diabats, 64^3 PME grid, r_c 9 / r_v 10.5 A, dt 0.5 fs, NVE.  A step = one
+velocity-Verlet step of msevb_md_integrate_atomic with the EVB force call (principal diabat, 7 diabat deltas, Hamiltonian,
+Hellmann-Feynman blend), positions/velocities/forces resident in HBM.  With N > 1 the diabats are sharded over the ranks
+(principal replicated) and completed by one RCCL all-gather per step: total work is fixed -> "scaling": "strong".
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from reactive_pb_nn_md_amd import api, forcefield, synth, system  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
+
+
+def algorithmic_bytes(N, K, D, D_local, half_list_entries):
+    """SURVEY.md 8d per-step algorithmic bytes of each phase (fp64 data, int32 indices)"""
+    K3 = K ** 3
+    nd = max(D_local - 1, 0)
+    return {
+        "real space (pair loop)": 4 * half_list_entries + 60 * N,
+        "Q_grid (spread)": 32 * N + 8 * K3,
+        "Fourier transforms + B*C*FQ": 64 * K3 + 40 * K3,
+        "Q grid derivatives (gather)": 56 * N + 8 * K3,
+        "intra-molecular (non-bonded + bonded)": 52 * N,
+        "ms-evb reciprocal space": nd * ((8 + 64 + 40 + 8) * K3 + 56 * N),
+        "ms-evb diabat real space": nd * (60 * N + 56 * N + 24 * N),
+        "ms-evb Hellmann-Feynman blend": 24 * N * (2 * D - 1) + 24 * N,
+    }
+
+
+def cpu_baseline(spec):
+    """the CPU oracle ("port") timed on this host: bounded sample, see DESIGN.md"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    o = oracle_py.Oracle(spec, threads=cores)
+    t0 = time.time()
+    o.verlet_build()
+    t_list = time.time() - t0
+    calls, t0 = 0, time.time()
+    while calls < 2 or (time.time() - t0 < 8.0 and calls < 6):
+        o.total()
+        calls += 1
+    t_force = (time.time() - t0) / calls
+    cpu = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": 1.0 / t_force, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "%d calls of the oracle's calculate_total_force_energy restatement (principal diabat ONLY: pair loop + PME + bonded, "
+                      "OpenMP %d threads, %s) on the same %d-atom box, %.2f s each; Verlet build %.2f s not included; an EVB step "
+                      "(7 more diabats) costs the CPU strictly more, so this is an upper bound of CPU steps/s" % (calls, cores, cpu, spec.n_atom, t_force, t_list)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n-side", type=int, default=32)
+    ap.add_argument("--diabats", type=int, default=8)
+    ap.add_argument("--pme-grid", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-evb", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")      # rendezvous / barriers / timing reduction only; data path is RCCL inside the library
+
+    s = synth.make_system(args.n_side, n_diabat=args.diabats, seed=0, max_chain=3 if args.diabats <= 8 else 4)
+    p = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"])
+    spec = system.from_synth(s, p, rc=9.0, rv=10.5, alpha=0.3, pme_grid=args.pme_grid, max_chain=3 if args.diabats <= 8 else 4)
+    h = api.MsEvbHip(spec, device=local_rank)
+    if world > 1:
+        import torch
+        idbuf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            raw = (C.c_ubyte * 128)()
+            h._chk(h.L.msevb_comm_unique_id(raw))
+            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+        dist.broadcast(idbuf, 0)
+        raw = (C.c_ubyte * 128)(*idbuf.tolist())
+        h._chk(h.L.msevb_comm_init(h.ctx, raw, rank, world))
+    vel = synth.maxwell_boltzmann(spec.mass, 300.0, 12345)
+    h.set_velocities(vel)
+    use_evb = not args.no_evb
+
+    def barrier():
+        h.synchronize()
+        if dist is not None:
+            dist.barrier()
+        h.synchronize()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+
+    # initial forces + warm-up
+    if use_evb:
+        h.ms_evb_calculate_total_force_energy(want_force=False)
+    else:
+        h.calculate_total_force_energy(want_force=False)
+    if args.warmup > 0:
+        h.md_integrate_atomic(args.warmup, spec.delta_t, use_evb=use_evb)
+    h.set_option("phase_timing", 1.0)      # HIP events on the library's stream around every phase (live roofline input)
+    h.L.msevb_reset_phase_times(h.ctx)
+    barrier()
+    t0 = time.perf_counter()
+    en = h.md_integrate_atomic(args.steps, spec.delta_t, use_evb=use_evb)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    phases = h.phase_times()
+    st = h.evb_state() if use_evb else {"D": 1}
+    D = int(st["D"])
+    vp_n = C.c_long()
+    h._chk(h.L.msevb_get_verlet_list(h.ctx, None, None, C.byref(vp_n)))
+    D_local = 1 + sum(1 for d in range(1, D) if (d - 1) % world == rank)
+    ab = algorithmic_bytes(spec.n_atom, spec.pme_grid, D, D_local, vp_n.value)
+    kern = {k: v for k, v in phases.items() if v[1] > 0 and k in ab}
+    # dominant kernel = the phase with the largest device time per step
+    per_step = {k: v[0] * v[1] / args.steps for k, v in kern.items()}
+    dom = max(per_step, key=per_step.get) if per_step else None
+    roofline = None
+    if dom:
+        launches_per_step = kern[dom][1] / args.steps
+        avg_ms = kern[dom][0]
+        achieved = ab[dom] / launches_per_step / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(ab[dom] / launches_per_step)}
+    out = None
+    if rank == 0:
+        b_step = sum(ab.values())
+        out = {
+            "metric": "MD timesteps/sec", "value": round(args.steps / dt, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "CH3SO3H/H2O box %d atoms, %d diabats, %d^3 PME grid, r_c 9.0 / r_v 10.5 A, dt 0.5 fs, NVE, %s force call"
+                                   % (spec.n_atom, D, spec.pme_grid, "MS-EVB" if use_evb else "non-EVB"),
+                       "n_atoms": spec.n_atom, "n_diabats": D, "pme_grid": spec.pme_grid, "parallelism": "diabats sharded over %d GPU(s)" % world},
+            "roofline": roofline,
+            "step_roofline": {"algorithmic_bytes_per_step": int(b_step), "achieved_GBs": round(b_step / (dt / args.steps) / 1e9, 2),
+                              "frac_of_hbm_peak": round(b_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
+            "phases_ms_per_step": {k: round(v, 5) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+            "verlet_rebuilds": int(phases.get("verlet list construction", (0, 0))[1]),
+            "energy_first_last": [float(en[0, 0] + en[0, 1]), float(en[-1, 0] + en[-1, 1])],
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(spec)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    h.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -76,7 +76,7 @@ int msevb_destroy(msevb_ctx* c) {
   for (auto b : db) b->release();
   c->d_pair_par.release(); c->d_moltypes.release(); c->d_ewald_tab.release(); c->d_nbr_count.release(); c->d_nbr_start.release();
   c->d_sort_tmp.release(); c->d_posq.release(); c->d_grid.release(); c->d_fft_work.release();
-  for (int p = 0; p < PH_COUNT; ++p) { if (c->ph[p].e0) { (void)hipEventDestroy(c->ph[p].e0); (void)hipEventDestroy(c->ph[p].e1); } }
+  for (int p = 0; p < PH_COUNT; ++p) for (hipEvent_t e : c->ph[p].ev) (void)hipEventDestroy(e);
   if (c->h_energies) (void)hipHostFree(c->h_energies);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -469,9 +469,9 @@ int msevb_get_topology(msevb_ctx* c, int* at, double* chg, int* mn, int* mt, int
 int msevb_get_phase_times(msevb_ctx* c, int* n, const char** names, double* ms, long* calls) {
   if (!c) return MSEVB_ERR_ARG;
   (void)hipStreamSynchronize(c->stream);
+  phase_harvest(c);
   for (int p = 0; p < PH_COUNT; ++p) {
     PhaseTimer& t = c->ph[p];
-    if (t.pending) { float v = 0; if (hipEventSynchronize(t.e1) == hipSuccess && hipEventElapsedTime(&v, t.e0, t.e1) == hipSuccess) { t.ms += v; t.calls++; } t.pending = false; }
     if (names) names[p] = t.name.c_str();
     if (ms) ms[p] = t.calls ? t.ms / t.calls : 0.0;
     if (calls) calls[p] = t.calls;
@@ -479,7 +479,7 @@ int msevb_get_phase_times(msevb_ctx* c, int* n, const char** names, double* ms, 
   if (n) *n = PH_COUNT;
   return MSEVB_OK;
 }
-int msevb_reset_phase_times(msevb_ctx* c) { for (int p = 0; p < PH_COUNT; ++p) { c->ph[p].ms = 0; c->ph[p].calls = 0; c->ph[p].pending = false; } return MSEVB_OK; }
+int msevb_reset_phase_times(msevb_ctx* c) { (void)hipStreamSynchronize(c->stream); phase_harvest(c); for (int p = 0; p < PH_COUNT; ++p) { c->ph[p].ms = 0; c->ph[p].calls = 0; } return MSEVB_OK; }
 int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   const std::string s(name);
   if (s == "phase_timing") { c->timing = v != 0.0; return MSEVB_OK; }

@@ -64,12 +64,12 @@ struct MolTypeHost {
   std::vector<int> atype, bonds, angles, dihedrals, excl, reactive_protons, reactive_basic;
 };
 
-struct PhaseTimer {
+struct PhaseTimer {   // HIP events on the library's stream around a phase; harvested lazily (no host sync inside a step)
   std::string name;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  std::vector<hipEvent_t> ev;   // pairs (start, stop)
+  size_t used = 0;              // events handed out since the last harvest
   double ms = 0;
   long calls = 0;
-  bool pending = false;
 };
 
 enum Phase { PH_VERLET = 0, PH_SORT, PH_PAIR, PH_MOLECULE, PH_SPREAD, PH_FFT, PH_GATHER, PH_EVB_REAL, PH_EVB_RECIP, PH_EVB_BLEND, PH_INTEGRATE, PH_COUNT };
@@ -216,13 +216,25 @@ enum Slot { S_ELEC_PAIR = 0, S_VDW_PAIR, S_ELEC_INTRA, S_VDW_INTRA, S_BOND, S_AN
 inline void phase_begin(msevb_ctx* c, int p) {
   if (!c->timing) return;
   PhaseTimer& t = c->ph[p];
-  if (!t.e0) { (void)hipEventCreate(&t.e0); (void)hipEventCreate(&t.e1); }
-  if (t.pending) { float ms = 0; if (hipEventSynchronize(t.e1) == hipSuccess && hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) { t.ms += ms; t.calls++; } t.pending = false; }
-  (void)hipEventRecord(t.e0, c->stream);
+  if (t.used + 2 > 16384) return;   // pool exhausted: stop sampling until the next harvest
+  if (t.used + 2 > t.ev.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); t.ev.push_back(a); t.ev.push_back(b); }
+  (void)hipEventRecord(t.ev[t.used], c->stream);
+  t.used += 1;
 }
 inline void phase_end(msevb_ctx* c, int p) {
   if (!c->timing) return;
   PhaseTimer& t = c->ph[p];
-  (void)hipEventRecord(t.e1, c->stream);
-  t.pending = true;
+  if ((t.used & 1) == 0) return;
+  (void)hipEventRecord(t.ev[t.used], c->stream);
+  t.used += 1;
+}
+inline void phase_harvest(msevb_ctx* c) {
+  for (int p = 0; p < PH_COUNT; ++p) {
+    PhaseTimer& t = c->ph[p];
+    for (size_t k = 0; k + 1 < t.used; k += 2) {
+      float v = 0;
+      if (hipEventSynchronize(t.ev[k + 1]) == hipSuccess && hipEventElapsedTime(&v, t.ev[k], t.ev[k + 1]) == hipSuccess) { t.ms += v; t.calls++; }
+    }
+    t.used = 0;
+  }
 }

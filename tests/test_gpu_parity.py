@@ -1,0 +1,221 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).  Everything goes through the C-ABI
+(reactive_pb_nn_md_amd.api -> libmsevb_hip.so).  Checkers: golden vectors of the real reference, and the CPU oracle.
+
+Tolerances (fp64 path; the GPU sums in a different order and uses reciprocal multiplies in the pair kernel):
+  forces   abs 1e-9 kJ/mol/A  (measured 1e-12)     energies rel 1e-11 (measured 1e-15)
+  integer work (Verlet pair set, PME grid / table indices) bit-exact.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import all_golden, golden
+from reactive_pb_nn_md_amd import api, forcefield, synth, system
+
+pytestmark = pytest.mark.gpu
+
+F_TOL = 1e-9
+E_RTOL = 1e-11
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3"])
+def test_tables_bit_exact(name):
+    g = golden(name)
+    h = api.MsEvbHip(system.from_golden(g))
+    for key in ("B6_spline", "B5_spline", "erfc_table", "ewaldscale_table", "Tang_Toennies_table", "dTang_Toennies_table", "CB"):
+        assert sha(h.table(key)) == str(g[key + "_sha256"]), key
+    assert h.ewald_self() == g["Ewald_self"][0]
+    h.close()
+
+
+@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3"])
+def test_verlet_pair_set_identical(name):
+    g = golden(name)
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    h.construct_verlet_list()
+    vp, nl = h.get_verlet_list()
+    assert len(nl) == int(g["neighbor_count"]) and np.array_equal(vp, g["verlet_point"])
+    hh = hashlib.sha256()
+    for i in range(spec.n_atom):
+        hh.update(np.int32(i + 1).tobytes())
+        hh.update(np.sort(nl[vp[i] - 1:vp[i + 1] - 1]).astype("<i4").tobytes())
+    assert hh.hexdigest() == str(g["neighbor_pairs_sha256"])
+    h.close()
+
+
+@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3"])
+def test_stages_against_reference(name):
+    g = golden(name)
+    h = api.MsEvbHip(system.from_golden(g))
+    h.construct_verlet_list()
+    h.zero_forces()
+    e = h.real_space_energy_force()
+    assert np.abs(h.get_forces() - (g["F_pair"] + g["F_intra_nb"])).max() < F_TOL
+    assert rel(e[0], g["E_elec_pair"][0]) < E_RTOL and rel(e[1], g["E_vdw_pair"][0]) < E_RTOL and rel(e[2], g["E_elec_intra_nb"][0]) < E_RTOL
+    h.zero_forces()
+    er = h.pme_reciprocal_space_energy_force()
+    assert np.abs(h.get_forces() - g["F_recip"]).max() < F_TOL and rel(er, g["E_recip"][0]) < E_RTOL
+    Q, th, u, fr = h.pme_state()
+    assert np.array_equal(u, g["xyz_scale"])                       # scaled coordinates bit-exact
+    assert np.abs(Q - g["Q_grid"]).max() < 1e-14 and np.abs(th - g["theta_conv_Q"]).max() < 1e-13
+    near, spl = h.pme_indices()
+    assert np.array_equal(near, np.floor(g["xyz_scale"]).astype(np.int32))          # PME grid indices bit-exact
+    arg = g["xyz_scale"][:, :, None] - (np.floor(g["xyz_scale"])[:, :, None] - np.arange(6)[None, None, :])
+    assert np.array_equal(spl, np.ceil(arg / 6.0 * 100000.0).astype(np.int32))      # B-spline table rows bit-exact
+    h.zero_forces()
+    eb = h.intra_molecular_energy_force()
+    assert np.abs(h.get_forces() - g["F_bonded"]).max() < F_TOL
+    assert rel(eb[0], g["E_bond"][0]) < E_RTOL and rel(eb[1], g["E_angle"][0]) < E_RTOL and rel(eb[2], g["E_dihedral"][0]) < E_RTOL
+    en, F = h.calculate_total_force_energy()
+    assert np.abs(F - g["F_total"]).max() < F_TOL and rel(en["potential"], g["E_total"][0]) < E_RTOL
+    assert rel(en["elec"], g["E_elec_total"][0]) < E_RTOL and rel(en["vdw"], g["E_vdw_total"][0]) < E_RTOL
+    h.close()
+
+
+@pytest.mark.parametrize("name", all_golden("evb_"))
+def test_evb_against_reference(name):
+    g = golden(name)
+    h = api.MsEvbHip(system.from_golden(g))
+    e, F = h.ms_evb_calculate_total_force_energy()
+    st = h.evb_state()
+    D = int(g["n_diabat"][0])
+    assert st["D"] == D
+    assert np.array_equal(st["proton_log"][:, :g["evb_diabat_proton_log"].shape[1], :], g["evb_diabat_proton_log"])
+    assert np.array_equal(st["coupling_matrix"], g["evb_diabat_coupling_matrix"])
+    Href = g["evb_hamiltonian"]
+    assert np.abs(st["H"] - Href).max() < E_RTOL * np.abs(Href).max()
+    assert np.allclose(st["H"], np.triu(st["H"]))                  # upper triangle, tree couplings only
+    assert rel(e, g["E_adiabatic"][0]) < E_RTOL and np.abs(F - g["F_adiabatic"]).max() < F_TOL
+    assert st["principle_diabat"] == int(g["principle_diabat"][0]) and st["new_hydronium_molecule"] == int(g["new_hydronium_molecule"][0])
+    assert abs(np.linalg.norm(st["eigvec"]) - 1.0) < 1e-12
+    if "evb_forces_store" in g:
+        lk, sto = g["evb_forces_lookup_index"], g["evb_forces_store"]
+        for i in range(D):
+            for j in range(i, D):
+                if lk[i, j] > 0:
+                    assert np.abs(h.evb_element_force(i + 1, j + 1) - sto[lk[i, j] - 1]).max() < F_TOL, (i, j)
+    h.close()
+
+
+@pytest.mark.parametrize("name,evb", [("md_std_n6_s4", False), ("md_evb_n6_d2_s5", True)])
+def test_md_trajectory_against_reference(name, evb):
+    g = golden(name)
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    h.set_velocities(g["md_velocity0"])
+    if evb:
+        h.ms_evb_calculate_total_force_energy(want_force=False)
+    else:
+        h.calculate_total_force_energy(want_force=False)
+    assert np.abs(h.get_forces() - g["md_F0"]).max() < F_TOL
+    n = int(g["md_nsteps"][0])
+    en = h.md_integrate_atomic(n, spec.delta_t, use_evb=evb)
+    assert np.abs(en[:, 0] - g["md_energy"][:, 0]).max() < 1e-9 * np.abs(g["md_energy"][:, 0]).max()
+    assert np.abs(en[:, 1] - g["md_energy"][:, 1]).max() < 1e-8 * np.abs(g["md_energy"][:, 1]).max()
+    assert np.abs(h.get_positions() - g["md_xyz"]).max() < 1e-10
+    assert np.abs(h.get_velocities() - g["md_velocity"]).max() < 1e-9
+    assert np.abs(h.get_forces() - g["md_force"]).max() < 1e-7
+    h.close()
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3])
+def test_diabat_sharding_is_a_partition(n_ranks):
+    """virtual ranks: every Hamiltonian element is produced by exactly one rank and equals the single-rank result"""
+    g = golden("evb_n6_d8_s1")
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    h.ms_evb_calculate_total_force_energy(want_force=False)
+    full = h.evb_state()
+    D = full["D"]
+    Ffull = {(i, j): h.evb_element_force(i, j) for i in range(1, D + 1) for j in range(i, D + 1) if i == j or full["coupling_matrix"][j - 1] == i}
+    h.close()
+    Hsum = np.zeros((D, D))
+    for r in range(n_ranks):
+        hr = api.MsEvbHip(spec)
+        hr.comm_set_virtual(r, n_ranks)
+        hr.ms_evb_calculate_total_force_energy(want_force=False)
+        st = hr.evb_state()
+        for d in range(2, D + 1):
+            owner = (d - 2) % n_ranks
+            p = full["coupling_matrix"][d - 1]
+            if owner == r:
+                assert rel(st["H"][d - 1, d - 1], full["H"][d - 1, d - 1]) < 1e-13 and rel(st["H"][p - 1, d - 1], full["H"][p - 1, d - 1]) < 1e-13
+                assert np.abs(hr.evb_element_force(d, d) - Ffull[(d, d)]).max() < 1e-10
+                assert np.abs(hr.evb_element_force(p, d) - Ffull[(p, d)]).max() < 1e-10
+                Hsum[d - 1, d - 1] += st["H"][d - 1, d - 1]
+            else:
+                assert st["H"][d - 1, d - 1] == 0.0 and np.abs(hr.evb_element_force(d, d)).max() == 0.0
+        hr.close()
+    assert np.allclose(np.diag(Hsum)[1:], np.diag(full["H"])[1:], rtol=1e-13)
+
+
+def _synthetic(n_side, n_diabat, seed, K, rc=9.0, rv=10.5):
+    s = synth.make_system(n_side, n_diabat=n_diabat, seed=seed)
+    p = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"])
+    return system.from_synth(s, p, rc=rc, rv=rv, pme_grid=K)
+
+
+def test_config_A_against_oracle(oracle_lib):
+    """BASELINE.json configs[1]: ~10k atoms, 2 diabats, 32^3 grid - GPU vs CPU oracle (no reference run at this size)"""
+    spec = _synthetic(15, 2, 7, 32)
+    o = oracle_lib.Oracle(spec, threads=8)
+    o.verlet_build()
+    r = o.evb()
+    h = api.MsEvbHip(spec)
+    e, F = h.ms_evb_calculate_total_force_energy()
+    st = h.evb_state()
+    assert st["D"] == r["D"] == 2
+    assert np.abs(st["H"] - r["H"]).max() < E_RTOL * np.abs(r["H"]).max()
+    assert rel(e, r["E"]) < E_RTOL and np.abs(F - r["F"]).max() < 1e-8
+    h.close()
+
+
+def test_full_size_properties_config_B():
+    """BASELINE.json configs[2] (~100k atoms, 8 diabats, 64^3): size-independent properties"""
+    spec = _synthetic(32, 8, 11, 64)
+    h = api.MsEvbHip(spec)
+    h.construct_verlet_list()
+    h.zero_forces()
+    h.real_space_energy_force()
+    F = h.get_forces()
+    assert np.abs(F.sum(0)).max() < 1e-6 * np.abs(F).sum() / len(F) * 1e3      # Newton's third law: sum of pair forces vanishes
+    e, F = h.ms_evb_calculate_total_force_energy()
+    st = h.evb_state()
+    assert st["D"] == 8 and abs(np.linalg.norm(st["eigvec"]) - 1.0) < 1e-12
+    w = np.linalg.eigvalsh(np.triu(st["H"]) + np.triu(st["H"], 1).T)
+    assert rel(e, w[0]) < 1e-12                                              # Jacobi ground state == LAPACK ground state
+    # Hellmann-Feynman blend == explicit combination of the stored element forces
+    c = st["eigvec"]
+    Fb = sum(c[d] ** 2 * h.evb_element_force(d + 1, d + 1) for d in range(8))
+    Fb = Fb + sum(2 * c[st["coupling_matrix"][d] - 1] * c[d] * h.evb_element_force(st["coupling_matrix"][d], d + 1) for d in range(1, 8))
+    assert np.abs(Fb - F).max() < 1e-9
+    # idempotence: same positions -> same answer
+    e2, F2 = h.ms_evb_calculate_total_force_energy()
+    assert rel(e2, e) < 1e-13 and np.abs(F2 - F).max() < 1e-9
+    h.close()
+
+
+def test_verlet_rebuild_flag_and_error_paths():
+    g = golden("std_n6_s3")
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    h.construct_verlet_list()
+    assert h.update_verlet_displacements() == 0
+    x = spec.xyz.copy()
+    x[0] += 2.0
+    x[1] += 2.0          # two displacements of 3.46 A > 1.2 * skin
+    h.set_positions(x)
+    assert h.update_verlet_displacements() == 1
+    with pytest.raises(api.MsevbError):
+        h.ms_evb_calculate_total_force_energy()       # EVB tables were not set for a non-EVB fixture
+    h.close()

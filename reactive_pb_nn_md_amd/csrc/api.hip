@@ -28,13 +28,32 @@ __global__ void k_half_to_full(int N, const unsigned* __restrict__ start, const 
 
 }  // namespace
 
-int reduce_partials(msevb_ctx* c, int slot, int nblocks) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, nblocks, c->d_partials.p + (size_t)slot * MAX_BLOCKS, c->d_energies.p + slot);
+struct SlotCounts { int n[N_SLOTS]; };
+__global__ void k_reduce_slots(SlotCounts cnt, const double* __restrict__ part, double* __restrict__ out) {
+  const int slot = blockIdx.x, n = cnt.n[slot];
+  if (n <= 0) return;
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < n; k += 256) s += part[(size_t)slot * MAX_BLOCKS + k];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+  if (threadIdx.x == 0) out[slot] = red[0];
+}
+
+// partial sums are reduced lazily: one launch for all pending slots
+int reduce_partials(msevb_ctx* c, int slot, int nblocks) { c->slot_count[slot] = nblocks; return MSEVB_OK; }
+int flush_reductions(msevb_ctx* c) {
+  SlotCounts sc; bool any = false;
+  for (int s = 0; s < N_SLOTS; ++s) { sc.n[s] = c->slot_count[s]; any |= sc.n[s] > 0; c->slot_count[s] = 0; }
+  if (!any) return MSEVB_OK;
+  hipLaunchKernelGGL(k_reduce_slots, dim3(N_SLOTS), dim3(256), 0, c->stream, sc, c->d_partials.p, c->d_energies.p);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
 }
 
 int fetch_energies(msevb_ctx* c) {
+  CHK(flush_reductions(c));
   HIPCHK(hipMemcpyAsync(c->h_energies, c->d_energies.p, N_SLOTS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return MSEVB_OK;
@@ -484,6 +503,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   const std::string s(name);
   if (s == "phase_timing") { c->timing = v != 0.0; return MSEVB_OK; }
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
+  if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
   c->err = "unknown option " + s;
   return MSEVB_ERR_ARG;
 }

@@ -155,7 +155,9 @@ struct msevb_ctx {
   DBuf<double> d_Q;            // real copy of the spread grid (kept for the EVB delta path)
   DBuf<double> d_w, d_dw, d_uscale;   // per atom: B6 weights [N][3][6], derivative weights, scaled coords
   DBuf<int> d_base, d_splindex;       // nearpt [N][3], B6 rows [N][3][6]
-  rocfft_plan plan_fwd = nullptr, plan_bwd = nullptr;
+  rocfft_plan plan_fwd = nullptr, plan_bwd = nullptr, plan_fwd_b = nullptr, plan_bwd_b = nullptr;
+  int plan_batch = 0;
+  bool spread_tiles = true;
   rocfft_execution_info fft_info = nullptr;
   DBuf<char> d_fft_work;
   int fft_batch = 1;
@@ -163,6 +165,7 @@ struct msevb_ctx {
   DBuf<double> d_partials;     // [n_slots][MAX_BLOCKS]
   DBuf<double> d_energies;     // [32]
   double* h_energies = nullptr;  // pinned
+  int slot_count[32] = {0};      // pending per-slot partial counts (fused reduction)
   double E_recip = 0;
 
   // EVB state
@@ -190,7 +193,8 @@ int molecule_forces(msevb_ctx* c, int slot0, bool do_nb, bool do_bonded);  // mo
 int pme_forces(msevb_ctx* c, int slot_recip);                           // pme.hip
 int pme_setup(msevb_ctx* c);
 void pme_teardown(msevb_ctx* c);
-int reduce_partials(msevb_ctx* c, int slot, int nblocks);                // reduce.hip (in api)
+int reduce_partials(msevb_ctx* c, int slot, int nblocks);                // deferred: one fused launch in flush_reductions
+int flush_reductions(msevb_ctx* c);
 int fetch_energies(msevb_ctx* c);
 int integrate_half_kick_drift(msevb_ctx* c, double dt);                  // integrate.hip
 int integrate_half_kick(msevb_ctx* c, double dt);
@@ -206,7 +210,7 @@ double volume32(const double box[3]);
 extern "C" int total_force_enqueue(msevb_ctx* c);
 extern "C" void total_force_collect(msevb_ctx* c, double* en);
 extern "C" int upload_topology(msevb_ctx* c);
-int pme_convolve(msevb_ctx* c, double2* grid, int slot);
+int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part_stride, int* nblocks);
 int pme_prepare_atoms(msevb_ctx* c);
 int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add);
 

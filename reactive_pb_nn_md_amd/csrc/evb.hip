@@ -434,6 +434,9 @@ __global__ __launch_bounds__(256) void k_evb_coupling(int M, int n_cp, const Cou
   __syncthreads();
   double* F = Foff + (size_t)cp.slot * fstride;
   double vex = 0.0;
+  double fz[2 * MAX_MOL_ATOMS][3];
+#pragma unroll
+  for (int a = 0; a < 2 * MAX_MOL_ATOMS; ++a) fz[a][0] = fz[a][1] = fz[a][2] = 0.0;
   for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
     bool special = false;
     for (int k = 0; k < cp.n_mols; ++k) special |= (cp.mols[k] == m);
@@ -459,12 +462,19 @@ __global__ __launch_bounds__(256) void k_evb_coupling(int M, int n_cp, const Cou
           const double r2 = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2], r = sqrt(r2);
           vex += qi * qj / r * conv;
           const double g = -qi * qj / (r2 * r) * conv;
-          for (int d = 0; d < 3; ++d) { fj[d] -= g * rij[d]; atomicAdd(&sF[lst[q]][d], g * rij[d]); }
+          for (int d = 0; d < 3; ++d) { fj[d] -= g * rij[d]; fz[side * cp.nD + q][d] += g * rij[d]; }
         }
       }
       for (int d = 0; d < 3; ++d) F[3 * j + d] = fj[d];    // dVex of this atom; scaled by -A in k_evb_coupling_finish
     }
   }
+  // forces on the Zundel atoms: per-thread registers -> wave shuffle -> one LDS add per wave
+  for (int a = 0; a < cp.nD + cp.nA; ++a) for (int d = 0; d < 3; ++d) {
+    double v = fz[a][d];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(&sF[a < cp.nD ? cp.D_at[a] : cp.A_at[a - cp.nD]][d], v);
+  }
+  __syncthreads();
   red[threadIdx.x] = vex;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
@@ -966,11 +976,9 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
                        c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p);
     hipLaunchKernelGGL(k_evb_patch, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, w->d_ra.p, K, K3, c->d_base.p, c->d_w.p, w->d_sbase.p, w->d_sw.p, w->d_grids.p);
     HIPCHK(hipGetLastError());
-    for (int g = 0; g < ngrid; ++g) {
-      // pme_convolve writes its energy partials to slot S_EVB0 of the shared buffer; move the reduced value to E_grid[g]
-      CHK(pme_convolve(c, w->d_grids.p + (size_t)g * K3, S_EVB0));
-      HIPCHK(hipMemcpyAsync(E_grid + g, c->d_energies.p + S_EVB0, 8, hipMemcpyDeviceToDevice, c->stream));
-    }
+    int nbk = 0;
+    CHK(pme_convolve(c, w->d_grids.p, ngrid, part_grid, part_stride, &nbk));      // one batched FFT pair for all owned diabats
+    hipLaunchKernelGGL(k_sum_rows, dim3(ngrid), dim3(256), 0, c->stream, ngrid, nbk, part_stride, part_grid, E_grid);
     // all-atom gather, up to 8 grids per pass
     std::vector<int> gslots(ngrid);
     for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gslots[grid_of[d]] = diag_slot(c, D, d);

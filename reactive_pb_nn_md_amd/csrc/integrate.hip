@@ -59,7 +59,7 @@ static int momentum_ke(msevb_ctx* c) {
   hipLaunchKernelGGL(k_momentum_ke, dim3(nb), dim3(256), 0, c->stream, c->N, c->d_mass.p, c->d_vel.p, c->d_partials.p);
   HIPCHK(hipGetLastError());
   CHK(reduce_partials(c, S_PX, nb)); CHK(reduce_partials(c, S_PY, nb)); CHK(reduce_partials(c, S_PZ, nb)); CHK(reduce_partials(c, S_KE, nb));
-  return MSEVB_OK;
+  return flush_reductions(c);   // the momentum is consumed on the device right away
 }
 
 extern "C" int msevb_calculate_kinetic_energy(msevb_ctx* c, double* ke) {

@@ -1,0 +1,155 @@
+!==============================================================================
+! Drop-in replacement of the reference's module `total_energy_forces`
+! (src/total_energy_forces.f90) and of the hot entry point of module `ms_evb`
+! (ms_evb_calculate_total_force_energy, src/ms_evb.f90:181) that runs the force
+! call on an MI355X through libmsevb_hip.so.
+!
+! It is compiled AGAINST THE REFERENCE'S OWN, UNCHANGED glob_v.f90 /
+! general_routines.f90 (module global_variables, routines): the derived types,
+! force-field tables and EVB tables are read from there, so main_ms_evb.f90,
+! md_integration.f90 and initialize_routines.f90 stay untouched - see
+! INTEGRATION.md for the build line.  Same procedure names, same argument lists:
+!   calculate_total_force_energy(system_data, molecule_data, atom_data, verlet_list_data, PME_data)
+!   calculate_kinetic_energy(KE, n_atom, mass, vel_atom, conv_fac)
+!   msevb_hip_ms_evb_force_energy(...)   body for ms_evb_calculate_total_force_energy
+!==============================================================================
+module total_energy_forces
+  use global_variables
+  use routines
+  use msevb_hip_c
+  use iso_c_binding
+  implicit none
+  type(c_ptr), save, private :: ctx = c_null_ptr
+  logical, save, private :: uploaded = .false.
+
+contains
+
+  !-- push every table the hot path reads to the GPU library (once; again after a box change)
+  subroutine msevb_hip_upload(system_data, molecule_data, atom_data, verlet_list_data, PME_data, use_evb)
+    type(system_data_type), intent(in) :: system_data
+    type(molecule_data_type), dimension(:), intent(in) :: molecule_data
+    type(atom_data_type), intent(in) :: atom_data
+    type(verlet_list_data_type), intent(in) :: verlet_list_data
+    type(PME_data_type), intent(in) :: PME_data
+    logical, intent(in) :: use_evb
+    integer(c_int), allocatable :: mfirst(:), mnat(:), mtype(:), idx4(:,:), idx5(:,:), bl(:,:), al(:,:), dl(:,:), rp(:), rb(:)
+    real(c_double), allocatable :: par2(:,:), par6(:,:)
+    integer :: i, j, k, l, n, it, na, nb, nang, nd, dev
+
+    if (.not. c_associated(ctx)) then
+       dev = 0
+       call msevb_check(ctx, msevb_create(ctx, dev), "msevb_create")
+    end if
+    call msevb_check(ctx, msevb_set_system(ctx, system_data%total_atoms, system_data%n_mole, system_data%box, real_space_cutoff, &
+         verlet_list_data%verlet_cutoff, PME_data%alpha_sqrt, PME_data%pme_grid, PME_data%spline_order, PME_data%spline_grid, PME_data%erfc_grid), "msevb_set_system")
+    n = system_data%n_mole
+    allocate(mfirst(n), mnat(n), mtype(n))
+    do i = 1, n
+       mfirst(i) = molecule_data(i)%atom_index(1); mnat(i) = molecule_data(i)%n_atom; mtype(i) = molecule_data(i)%molecule_type_index
+    end do
+    call msevb_check(ctx, msevb_set_atoms(ctx, atom_data%atom_type_index, atom_data%charge, atom_data%mass, mfirst, mnat, mtype), "msevb_set_atoms")
+    call msevb_check(ctx, msevb_set_forcefield(ctx, n_atom_type, MAX_N_ATOM_TYPE, atype_vdw_type, atype_vdw_parameter, atype_vdw_parameter_14, &
+         atype_bond_type, atype_bond_parameter, atype_chg), "msevb_set_forcefield")
+    ! sparse form of the 25^3 / 25^4 tensors
+    n = count(atype_angle_type(1:n_atom_type,1:n_atom_type,1:n_atom_type) /= 0)
+    allocate(idx4(4,max(n,1)), par2(2,max(n,1)))
+    n = 0
+    do i=1,n_atom_type; do j=1,n_atom_type; do k=1,n_atom_type
+       if (atype_angle_type(i,j,k) /= 0) then
+          n = n + 1; idx4(:,n) = (/i,j,k,atype_angle_type(i,j,k)/); par2(:,n) = atype_angle_parameter(i,j,k,:)
+       end if
+    end do; end do; end do
+    call msevb_check(ctx, msevb_set_angle_types(ctx, n, idx4, par2), "msevb_set_angle_types")
+    n = count(atype_dihedral_type(1:n_atom_type,1:n_atom_type,1:n_atom_type,1:n_atom_type) /= 0)
+    allocate(idx5(5,max(n,1)), par6(6,max(n,1)))
+    n = 0
+    do i=1,n_atom_type; do j=1,n_atom_type; do k=1,n_atom_type; do l=1,n_atom_type
+       if (atype_dihedral_type(i,j,k,l) /= 0) then
+          n = n + 1; idx5(:,n) = (/i,j,k,l,atype_dihedral_type(i,j,k,l)/); par6(:,n) = atype_dihedral_parameter(i,j,k,l,:)
+       end if
+    end do; end do; end do; end do
+    call msevb_check(ctx, msevb_set_dihedral_types(ctx, n, idx5, par6), "msevb_set_dihedral_types")
+    do it = 1, n_molecule_type
+       na = molecule_type_data(it)%n_atom
+       nb = size(molecule_type_data(it)%bond_list); nang = size(molecule_type_data(it)%angle_list); nd = size(molecule_type_data(it)%dihedral_list)
+       allocate(bl(2,max(nb,1)), al(3,max(nang,1)), dl(4,max(nd,1)), rp(na), rb(na))
+       do i=1,nb; bl(:,i) = (/molecule_type_data(it)%bond_list(i)%i_atom, molecule_type_data(it)%bond_list(i)%j_atom/); end do
+       do i=1,nang; al(:,i) = (/molecule_type_data(it)%angle_list(i)%i_atom, molecule_type_data(it)%angle_list(i)%j_atom, molecule_type_data(it)%angle_list(i)%k_atom/); end do
+       do i=1,nd; dl(:,i) = (/molecule_type_data(it)%dihedral_list(i)%i_atom, molecule_type_data(it)%dihedral_list(i)%j_atom, &
+            molecule_type_data(it)%dihedral_list(i)%k_atom, molecule_type_data(it)%dihedral_list(i)%l_atom/); end do
+       rp = 0; rb = 0
+       if (allocated(molecule_type_data(it)%evb_reactive_protons)) rp = molecule_type_data(it)%evb_reactive_protons
+       if (allocated(molecule_type_data(it)%evb_reactive_basic_atoms)) rb = molecule_type_data(it)%evb_reactive_basic_atoms
+       call msevb_check(ctx, msevb_set_molecule_type(ctx, it, na, molecule_type_data(it)%atom_type_index, nb, bl, nang, al, nd, dl, &
+            molecule_type_data(it)%pair_exclusions, rp, rb), "msevb_set_molecule_type")
+       deallocate(bl, al, dl, rp, rb)
+    end do
+    if (use_evb) then
+       call msevb_check(ctx, msevb_set_evb(ctx, n_molecule_type, MAX_N_MOLE_TYPE, max_interaction_type, evb_acid_molecule, evb_basic_molecule, &
+            evb_conjugate_pairs, evb_proton_index, evb_heavy_acid_index, evb_conjugate_atom_index, evb_reference_energy, evb_exchange_charge_atomic, &
+            evb_exchange_charge_proton, evb_donor_acceptor_interaction, evb_donor_acceptor_parameters, evb_proton_acceptor_interaction, &
+            evb_proton_acceptor_parameters, evb_diabat_coupling_interaction, evb_diabat_coupling_parameters, evb_diabat_coupling_type, &
+            hydronium_molecule_index(1), evb_max_chain), "msevb_set_evb")
+    end if
+    call msevb_check(ctx, msevb_finalize(ctx), "msevb_finalize")
+    uploaded = .true.
+  end subroutine msevb_hip_upload
+
+  !***********************************************************
+  ! same interface as the reference (src/total_energy_forces.f90:19)
+  !***********************************************************
+  subroutine calculate_total_force_energy(system_data, molecule_data, atom_data, verlet_list_data, PME_data )
+    Type(system_data_type),intent(inout)                :: system_data
+    Type(molecule_data_type),dimension(:),intent(in)    :: molecule_data
+    Type(atom_data_type),intent(inout)                  :: atom_data
+    Type(verlet_list_data_type),intent(inout)           :: verlet_list_data
+    Type(PME_data_type), intent(inout)                  :: PME_data
+    real(c_double) :: e(MSEVB_N_ENERGY)
+
+    if (.not. uploaded) call msevb_hip_upload(system_data, molecule_data, atom_data, verlet_list_data, PME_data, .false.)
+    call msevb_check(ctx, msevb_set_positions(ctx, atom_data%xyz), "msevb_set_positions")
+    ! the Verlet list (and its freshness logic, :30-39) lives on the device
+    call msevb_check(ctx, msevb_calculate_total_force_energy(ctx, e, atom_data%force), "msevb_calculate_total_force_energy")
+    system_data%potential_energy = e(1); system_data%E_elec = e(2); system_data%E_vdw = e(3)
+    system_data%E_bond = e(4); system_data%E_angle = e(5); system_data%E_dihedral = e(6)
+    PME_data%E_recip = e(7)
+    verlet_list_data%flag_verlet_list = 0
+  end subroutine calculate_total_force_energy
+
+  !***********************************************************
+  ! body for ms_evb_calculate_total_force_energy (src/ms_evb.f90:181); the proton-hop re-topologisation of the host
+  ! arrays is read back from the library (msevb_get_topology) when the principal diabat changed
+  !***********************************************************
+  subroutine msevb_hip_ms_evb_force_energy(system_data, molecule_data, atom_data, verlet_list_data, PME_data, new_hydronium)
+    Type(system_data_type),intent(inout)                :: system_data
+    Type(molecule_data_type),dimension(:),intent(inout) :: molecule_data
+    Type(atom_data_type),intent(inout)                  :: atom_data
+    Type(verlet_list_data_type),intent(inout)           :: verlet_list_data
+    Type(PME_data_type), intent(inout)                  :: PME_data
+    integer, intent(out) :: new_hydronium
+    integer(c_int) :: nd, pr, nh
+
+    if (.not. uploaded) call msevb_hip_upload(system_data, molecule_data, atom_data, verlet_list_data, PME_data, .true.)
+    call msevb_check(ctx, msevb_set_positions(ctx, atom_data%xyz), "msevb_set_positions")
+    call msevb_check(ctx, msevb_ms_evb_calculate_total_force_energy(ctx, system_data%potential_energy, atom_data%force), "msevb_ms_evb_calculate_total_force_energy")
+    call msevb_check(ctx, msevb_get_evb_state(ctx, nd, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, pr, nh), "msevb_get_evb_state")
+    new_hydronium = nh
+  end subroutine msevb_hip_ms_evb_force_energy
+
+  !**************************************
+  ! same as the reference (src/total_energy_forces.f90:106); cheap, stays on the host
+  !**************************************
+  subroutine calculate_kinetic_energy( KE, n_atom, mass, vel_atom, conv_fac )
+    real*8,intent(out) :: KE
+    integer, intent(in) :: n_atom
+    real*8,dimension(:),intent(in) :: mass
+    real*8,dimension(:,:), intent(in) :: vel_atom
+    real*8,intent(in) :: conv_fac
+    integer :: i_atom
+    KE=0d0
+    do i_atom=1,n_atom
+       KE = KE + 0.5d0 * mass(i_atom) * dot_product(vel_atom(:,i_atom),vel_atom(:,i_atom))/ conv_fac
+    end do
+  end subroutine calculate_kinetic_energy
+
+end module total_energy_forces

@@ -29,6 +29,8 @@ namespace {
 
 constexpr int MAX_SPEC = (MAX_CHAIN + 1) * MAX_MOL_ATOMS;
 constexpr int REGION_CAP = 8192;
+constexpr int REGION_FAST = 2048;     // records fetched speculatively together with the count (one synchronisation)
+constexpr int MAX_UNITS = 2 * MAX_CHAIN * MAX_DIABATS + 1;
 
 struct SpecAtom { double x[3]; double q; int idx, type, mol, pad; };
 
@@ -220,66 +222,75 @@ __global__ __launch_bounds__(256) void k_evb_env(int N, int n_units, const UnitD
   }
 }
 
-// ---- special-special kernel: one thread per unit (tiny work) ------------------------------------------------------
-__global__ void k_evb_special(int n_units, const UnitDesc* __restrict__ units, const EvbTablesDev* __restrict__ tabs, const MolTypeDev* __restrict__ mts,
+// ---- special-special kernel: one wavefront per unit ---------------------------------------------------------------------
+// lanes share the special x special pair loop and the repulsion loop; lanes 0 / 1 do the intra-molecular + bonded terms of
+// donor / acceptor; forces are collected in LDS (ds_add_f64) and leave with one global atomic per component.
+__global__ __launch_bounds__(64) void k_evb_special(int n_units, const UnitDesc* __restrict__ units, const EvbTablesDev* __restrict__ tabs, const MolTypeDev* __restrict__ mts,
                               const PairParam* __restrict__ pairpar, int nt, const double2* __restrict__ etab, double inv_dx,
                               const double* __restrict__ tt, const double* __restrict__ dtt, BoxDev box, double rc2, double alpha, double erf_factor,
-                              double conv, double pi_ref, double* __restrict__ Fstore, size_t fstride, double* __restrict__ Eout, double* __restrict__ dbg) {
-  const int iu = blockIdx.x;
-  if (iu >= n_units || threadIdx.x != 0) return;
-  double dcomp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const UnitDesc& u = units[iu];
-  const EvbTablesDev& tb = *tabs;
+                              double conv, double pi_ref, double* __restrict__ Fstore, size_t fstride, double* __restrict__ Eout) {
+  const int iu = blockIdx.x, lane = threadIdx.x;
+  if (iu >= n_units) return;
+  __shared__ UnitDesc u;
+  __shared__ EvbTablesDev tb;
   __shared__ double f[MAX_SPEC][3];
-  __shared__ double x[MAX_MOL_ATOMS][3], q[MAX_MOL_ATOMS], fl[MAX_MOL_ATOMS][3];
+  __shared__ double xs[2][MAX_MOL_ATOMS][3], qs[2][MAX_MOL_ATOMS], fls[2][MAX_MOL_ATOMS][3];
   __shared__ bool inDA[MAX_SPEC];
-  for (int k = 0; k < u.n_spec; ++k) f[k][0] = f[k][1] = f[k][2] = 0.0;
+  {
+    const int* src = (const int*)&units[iu]; int* dst = (int*)&u;
+    for (int k = lane; k < (int)(sizeof(UnitDesc) / 4); k += 64) dst[k] = src[k];
+    const int* s2 = (const int*)tabs; int* d2 = (int*)&tb;
+    for (int k = lane; k < (int)(sizeof(EvbTablesDev) / 4); k += 64) d2[k] = s2[k];
+    for (int k = lane; k < MAX_SPEC * 3; k += 64) (&f[0][0])[k] = 0.0;
+    for (int k = lane; k < MAX_SPEC; k += 64) inDA[k] = false;
+  }
+  __syncthreads();
+  if (lane == 0 && u.do_rs) { for (int k = 0; k < u.nD; ++k) inDA[u.D_at[k]] = true; for (int k = 0; k < u.nA; ++k) inDA[u.A_at[k]] = true; }
+  __syncthreads();
   double e = 0.0;
-  for (int k = 0; k < u.n_spec; ++k) inDA[k] = false;
   if (u.do_rs) {
-    for (int k = 0; k < u.nD; ++k) inDA[u.D_at[k]] = true;
-    for (int k = 0; k < u.nA; ++k) inDA[u.A_at[k]] = true;
-    for (int a = 0; a < u.n_spec; ++a) {
-      if (!inDA[a]) continue;
-      for (int b = 0; b < u.n_spec; ++b) {
-        if (u.spec[b].mol == u.spec[a].mol) continue;
-        if (inDA[b] && b < a) continue;
-        double dr[3] = {u.spec[a].x[0] - u.spec[b].x[0], u.spec[a].x[1] - u.spec[b].x[1], u.spec[a].x[2] - u.spec[b].x[2]};
-        min_image(dr, box);
-        const double r2 = dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2];
-        if (r2 < rc2) {
-          double fs, ee, ev;
-          pair_interaction(r2, u.spec[a].q * u.spec[b].q, pairpar[u.spec[a].type * nt + u.spec[b].type], etab, inv_dx, tt, dtt, fs, ee, ev);
-          e += ee + ev; dcomp[0] += ee; dcomp[1] += ev;
-          for (int d = 0; d < 3; ++d) { f[a][d] += fs * dr[d]; f[b][d] -= fs * dr[d]; }
-        }
+    const int np = u.n_spec * u.n_spec;
+    for (int t = lane; t < np; t += 64) {
+      const int a = t / u.n_spec, b = t % u.n_spec;
+      if (!inDA[a] || u.spec[b].mol == u.spec[a].mol || (inDA[b] && b < a)) continue;
+      double dr[3] = {u.spec[a].x[0] - u.spec[b].x[0], u.spec[a].x[1] - u.spec[b].x[1], u.spec[a].x[2] - u.spec[b].x[2]};
+      min_image(dr, box);
+      const double r2 = dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2];
+      if (r2 < rc2) {
+        double fs, ee, ev;
+        pair_interaction(r2, u.spec[a].q * u.spec[b].q, pairpar[u.spec[a].type * nt + u.spec[b].type], etab, inv_dx, tt, dtt, fs, ee, ev);
+        e += ee + ev;
+        for (int d = 0; d < 3; ++d) { atomicAdd(&f[a][d], fs * dr[d]); atomicAdd(&f[b][d], -fs * dr[d]); }
       }
     }
-    for (int side = 0; side < 2; ++side) {   // intra-molecular non-bonded + bonded of donor and acceptor
+    if (lane < 2) {   // intra-molecular non-bonded + bonded of donor (lane 0) and acceptor (lane 1)
+      const int side = lane;
       const int n = side == 0 ? u.nD : u.nA;
       const int* lst = side == 0 ? u.D_at : u.A_at;
       const MolTypeDev& mt = mts[side == 0 ? u.mt_D : u.mt_A];
-      for (int k = 0; k < n; ++k) { q[k] = u.spec[lst[k]].q; for (int d = 0; d < 3; ++d) { x[k][d] = u.spec[lst[k]].x[d]; fl[k][d] = 0.0; } }
+      for (int k = 0; k < n; ++k) { qs[side][k] = u.spec[lst[k]].q; for (int d = 0; d < 3; ++d) { xs[side][k][d] = u.spec[lst[k]].x[d]; fls[side][k][d] = 0.0; } }
       double e1 = 0, e2 = 0, eb = 0, ea = 0, ed = 0;
-      if (n > 1) molecule_nonbonded(mt, n, x, q, fl, etab, inv_dx, tt, dtt, rc2, alpha, erf_factor, conv, e1, e2);
-      molecule_bonded(mt, x, fl, pi_ref, eb, ea, ed);
-      e += e1 + e2 + eb + ea + ed; dcomp[2 + side] += e1 + e2; dcomp[4 + side] += eb + ea + ed;
-      for (int k = 0; k < n; ++k) for (int d = 0; d < 3; ++d) f[lst[k]][d] += fl[k][d];
+      if (n > 1) molecule_nonbonded(mt, n, xs[side], qs[side], fls[side], etab, inv_dx, tt, dtt, rc2, alpha, erf_factor, conv, e1, e2);
+      molecule_bonded(mt, xs[side], fls[side], pi_ref, eb, ea, ed);
+      e += e1 + e2 + eb + ea + ed;
+      for (int k = 0; k < n; ++k) for (int d = 0; d < 3; ++d) atomicAdd(&f[lst[k]][d], fls[side][k][d]);
     }
   }
-  // repulsion of the hydronium with special atoms of OTHER molecules
-  for (int b = 0; b < u.n_spec && u.do_rep; ++b) {
-    if (u.spec[b].mol == u.hyd) continue;
-    double fh[MAX_MOL_ATOMS][3], fj[3] = {0, 0, 0};
-    for (int k = 0; k < MAX_MOL_ATOMS; ++k) fh[k][0] = fh[k][1] = fh[k][2] = 0.0;
-    { const double er = evb_repulsion_atom(u, tb, box, u.spec[b].type, u.spec[b].x, fj, fh); e += er; dcomp[6] += er; }
-    for (int d = 0; d < 3; ++d) f[b][d] += fj[d];
-    for (int k = 0; k < u.nH; ++k) for (int d = 0; d < 3; ++d) f[u.H_at[k]][d] += fh[k][d];
+  if (u.do_rep) {   // repulsion of the hydronium with special atoms of OTHER molecules
+    for (int b = lane; b < u.n_spec; b += 64) {
+      if (u.spec[b].mol == u.hyd) continue;
+      double fh[MAX_MOL_ATOMS][3], fj[3] = {0, 0, 0};
+      for (int k = 0; k < MAX_MOL_ATOMS; ++k) fh[k][0] = fh[k][1] = fh[k][2] = 0.0;
+      e += evb_repulsion_atom(u, tb, box, u.spec[b].type, u.spec[b].x, fj, fh);
+      for (int d = 0; d < 3; ++d) atomicAdd(&f[b][d], fj[d]);
+      for (int k = 0; k < u.nH; ++k) for (int d = 0; d < 3; ++d) if (fh[k][d] != 0.0) atomicAdd(&f[u.H_at[k]][d], fh[k][d]);
+    }
   }
+  for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+  __syncthreads();
   double* F = Fstore + (size_t)u.slot * fstride;
-  for (int k = 0; k < u.n_spec; ++k) for (int d = 0; d < 3; ++d) if (f[k][d] != 0.0) atomicAdd(&F[3 * u.spec[k].idx + d], u.sign * f[k][d]);
-  Eout[iu] = e;
-  if (dbg) for (int k = 0; k < 8; ++k) dbg[8 * iu + k] = dcomp[k];
+  for (int k = lane; k < u.n_spec * 3; k += 64) { const double v = f[k / 3][k % 3]; if (v != 0.0) atomicAdd(&F[3 * u.spec[k / 3].idx + k % 3], u.sign * v); }
+  if (lane == 0) Eout[iu] = e;
 }
 
 // ---- reciprocal space -------------------------------------------------------------------------------------------------
@@ -337,12 +348,20 @@ __global__ __launch_bounds__(256) void k_evb_patch(int n, const RecipAtom* __res
   }
 }
 
+// real parts of the ng diabat grids interleaved per grid point: pack[id*ng + g] (one contiguous read per stencil tap)
+__global__ void k_evb_pack(size_t K3, int ng, const double2* __restrict__ grids, double* __restrict__ pack) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K3 * ng; k += (size_t)gridDim.x * blockDim.x) {
+    const size_t id = k / ng; const int g = (int)(k % ng);
+    pack[k] = grids[(size_t)g * K3 + id].x;
+  }
+}
+
 // reciprocal force of EVERY atom against up to NG diabat grids with the principal stencil: one wavefront per atom.
 //   Fstore[slot_g][a] = F11[a] + (Frecip_g[a] - Frecip_1[a])
 template <int NG>
 __global__ __launch_bounds__(256) void k_evb_gather(int N, int K, size_t K3, int ng, const int* __restrict__ slots, const double* __restrict__ chg,
                                                     const int* __restrict__ base, const double* __restrict__ w, const double* __restrict__ dw,
-                                                    const double2* __restrict__ grids, double conv, double k00, double k01, double k02, double k10,
+                                                    const double* __restrict__ pack, int ngtot, int g0, double conv, double k00, double k01, double k02, double k10,
                                                     double k11, double k12, double k20, double k21, double k22, const double* __restrict__ F11,
                                                     const double* __restrict__ Frecip1, double* __restrict__ Fstore, size_t fstride) {
   const int lane = threadIdx.x & 63;
@@ -362,8 +381,9 @@ __global__ __launch_bounds__(256) void k_evb_gather(int N, int K, size_t K3, int
     const size_t id = n1 + (size_t)K * (n2 + (size_t)K * n3);
     const double w1 = wi[k1], w2 = wi[6 + k2], w3 = wi[12 + k3];
     const double c1 = dwi[k1] * w2 * w3, c2 = dwi[6 + k2] * w1 * w3, c3 = dwi[12 + k3] * w1 * w2;
+    const double* pk = pack + id * ngtot + g0;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) if (g < ng) { const double th = grids[(size_t)g * K3 + id].x; acc[g][0] += c1 * th; acc[g][1] += c2 * th; acc[g][2] += c3 * th; }
+    for (int g = 0; g < NG; ++g) if (g < ng) { const double th = pk[g]; acc[g][0] += c1 * th; acc[g][1] += c2 * th; acc[g][2] += c3 * th; }
   }
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
@@ -627,8 +647,10 @@ struct EvbWork {   // persistent device scratch of one context
   DBuf<UnitDesc> d_units; DBuf<CouplingDesc> d_cps; DBuf<RecipAtom> d_ra; DBuf<EvbTablesDev> d_tabs; DBuf<double> d_exch;
   DBuf<double> d_part, d_E, d_dVspec, d_cpout, d_coef; DBuf<int> d_slots, d_isoff, d_sbase, d_counter; DBuf<double> d_sw, d_sdw;
   DBuf<double2> d_grids; DBuf<RegionRec> d_region;
-  DBuf<double> d_F11, d_dbg;
-  std::vector<double> h_dbg; int dbg_nu = 0;
+  DBuf<double> d_F11, d_pack;
+  hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
+  RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
+  UnitDesc* h_units = nullptr; CouplingDesc* h_cps = nullptr; RecipAtom* h_ras = nullptr;   // pinned staging
   int grids_cap = 0;
   bool tabs_uploaded = false;
   std::vector<RegionRec> region;
@@ -807,21 +829,36 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   const int N = c->N, M = c->M, K = c->K;
   const size_t K3 = (size_t)K * K * K, n3 = 3 * (size_t)N;
   const BoxDev box = mkbox(c);
-  // ---- 1. principal diabat (calculate_total_force_energy, src/ms_evb.f90:411)
-  CHK(total_force_enqueue(c));
-  // ---- 2. neighbourhood of the hydronium -> host (replaces the all-molecule scans of :724)
+  // ---- 1. neighbourhood of the hydronium -> host on a side stream (replaces the all-molecule scans of src/ms_evb.f90:724);
+  //         it only needs the positions, so it overlaps with the principal diabat's force kernels
+  if (!w->stream2) {
+    HIPCHK(hipStreamCreateWithFlags(&w->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&w->ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&w->ev_region, hipEventDisableTiming));
+    HIPCHK(hipHostMalloc((void**)&w->h_region, REGION_FAST * sizeof(RegionRec), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&w->h_count, 64, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&w->h_units, MAX_UNITS * sizeof(UnitDesc), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&w->h_cps, MAX_DIABATS * sizeof(CouplingDesc), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&w->h_ras, MAX_DIABATS * MAX_SPEC * sizeof(RecipAtom), hipHostMallocDefault));
+  }
   if (w->d_region.alloc(REGION_CAP) || w->d_counter.alloc(4)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB region)");
-  HIPCHK(hipMemsetAsync(w->d_counter.p, 0, sizeof(int), c->stream));
   const double Rreg = 5.0 * c->max_chain + 5.0;
-  hipLaunchKernelGGL(k_evb_region, dim3((M + 255) / 256), dim3(256), 0, c->stream, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
+  HIPCHK(hipEventRecord(w->ev_in, c->stream));
+  HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_in, 0));
+  HIPCHK(hipMemsetAsync(w->d_counter.p, 0, sizeof(int), w->stream2));
+  hipLaunchKernelGGL(k_evb_region, dim3((M + 255) / 256), dim3(256), 0, w->stream2, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
                      c->d_mass.p, box, w->d_counter.p, w->d_region.p, REGION_CAP);
-  int nreg = 0;
-  HIPCHK(hipMemcpyAsync(&nreg, w->d_counter.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpyAsync(w->h_count, w->d_counter.p, sizeof(int), hipMemcpyDeviceToHost, w->stream2));
+  HIPCHK(hipMemcpyAsync(w->h_region, w->d_region.p, REGION_FAST * sizeof(RegionRec), hipMemcpyDeviceToHost, w->stream2));
+  HIPCHK(hipEventRecord(w->ev_region, w->stream2));
+  // ---- 2. principal diabat (calculate_total_force_energy, src/ms_evb.f90:411) - enqueued, not waited for
+  CHK(total_force_enqueue(c));
+  HIPCHK(hipEventSynchronize(w->ev_region));
+  const int nreg = *w->h_count;
   if (nreg > REGION_CAP) FAIL(MSEVB_ERR_LIMIT, "EVB neighbourhood buffer too small");
   w->region.resize(nreg);
-  HIPCHK(hipMemcpyAsync(w->region.data(), w->d_region.p, nreg * sizeof(RegionRec), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (nreg <= REGION_FAST) memcpy(w->region.data(), w->h_region, (size_t)nreg * sizeof(RegionRec));
+  else { HIPCHK(hipMemcpyAsync(w->region.data(), w->d_region.p, (size_t)nreg * sizeof(RegionRec), hipMemcpyDeviceToHost, w->stream2)); HIPCHK(hipStreamSynchronize(w->stream2)); }
   std::sort(w->region.begin(), w->region.end(), [](const RegionRec& a, const RegionRec& b) { return a.mol < b.mol; });
   // ---- 3. diabat enumeration on the principal topology (evb_conduct_proton_transfer_recursive, :498)
   for (int d = 0; d < MAX_DIABATS; ++d) { c->parent[d] = -1; for (int h = 0; h < MAX_CHAIN; ++h) for (int q = 0; q < 5; ++q) c->plog[d][h][q] = -1; }
@@ -937,7 +974,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
       w->d_ra.alloc(std::max(nra, 1)) || w->d_tabs.alloc(1) || w->d_exch.alloc(MAX_TYPES) || w->d_part.alloc((size_t)n_rows * part_stride) ||
       w->d_E.alloc(2 * n_rows + 3 * std::max(ncp, 1)) || w->d_dVspec.alloc((size_t)std::max(ncp, 1) * MAX_SPEC * 3) || w->d_cpout.alloc(3 * std::max(ncp, 1)) ||
       w->d_sbase.alloc(3 * std::max(nra, 1)) || w->d_sw.alloc(18 * (size_t)std::max(nra, 1)) || w->d_sdw.alloc(18 * (size_t)std::max(nra, 1)) ||
-      w->d_grids.alloc(K3 * std::max(ngrid, 1)) || w->d_dbg.alloc(8 * (size_t)nu) || w->d_coef.alloc(4 * MAX_DIABATS) || w->d_slots.alloc(4 * MAX_DIABATS) || w->d_isoff.alloc(4 * MAX_DIABATS))
+      w->d_grids.alloc(K3 * std::max(ngrid, 1)) || w->d_pack.alloc(K3 * std::max(ngrid, 1)) || w->d_coef.alloc(4 * MAX_DIABATS) || w->d_slots.alloc(4 * MAX_DIABATS) || w->d_isoff.alloc(4 * MAX_DIABATS))
     FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB work buffers)");
   c->evb_cap = D;
   if (!w->tabs_uploaded) {
@@ -954,9 +991,11 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipMemcpy(w->d_exch.p, c->e_exch_atomic, sizeof(double) * MAX_TYPES, hipMemcpyHostToDevice));
     w->tabs_uploaded = true;
   }
-  HIPCHK(hipMemcpyAsync(w->d_units.p, units.data(), nu * sizeof(UnitDesc), hipMemcpyHostToDevice, c->stream));
-  if (ncp) HIPCHK(hipMemcpyAsync(w->d_cps.p, cps.data(), ncp * sizeof(CouplingDesc), hipMemcpyHostToDevice, c->stream));
-  if (nra) HIPCHK(hipMemcpyAsync(w->d_ra.p, ras.data(), nra * sizeof(RecipAtom), hipMemcpyHostToDevice, c->stream));
+  if (nu > MAX_UNITS || ncp > MAX_DIABATS || nra > MAX_DIABATS * MAX_SPEC) FAIL(MSEVB_ERR_LIMIT, "EVB descriptor staging too small");
+  memcpy(w->h_units, units.data(), nu * sizeof(UnitDesc));
+  HIPCHK(hipMemcpyAsync(w->d_units.p, w->h_units, nu * sizeof(UnitDesc), hipMemcpyHostToDevice, c->stream));
+  if (ncp) { memcpy(w->h_cps, cps.data(), ncp * sizeof(CouplingDesc)); HIPCHK(hipMemcpyAsync(w->d_cps.p, w->h_cps, ncp * sizeof(CouplingDesc), hipMemcpyHostToDevice, c->stream)); }
+  if (nra) { memcpy(w->h_ras, ras.data(), nra * sizeof(RecipAtom)); HIPCHK(hipMemcpyAsync(w->d_ra.p, w->h_ras, nra * sizeof(RecipAtom), hipMemcpyHostToDevice, c->stream)); }
   double* part_units = w->d_part.p;
   double* part_cp = w->d_part.p + (size_t)nu * part_stride;
   double* part_grid = w->d_part.p + (size_t)(nu + ncp) * part_stride;
@@ -983,10 +1022,11 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     std::vector<int> gslots(ngrid);
     for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gslots[grid_of[d]] = diag_slot(c, D, d);
     HIPCHK(hipMemcpyAsync(w->d_slots.p + 2 * MAX_DIABATS, gslots.data(), ngrid * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_evb_pack, dim3(2048), dim3(256), 0, c->stream, K3, ngrid, w->d_grids.p, w->d_pack.p);
     for (int g0 = 0; g0 < ngrid; g0 += 8) {
       const int ng = std::min(8, ngrid - g0);
       hipLaunchKernelGGL(k_evb_gather<8>, dim3((N + 3) / 4), dim3(256), 0, c->stream, N, K, K3, ng, w->d_slots.p + 2 * MAX_DIABATS + g0, c->d_chg.p, c->d_base.p,
-                         c->d_w.p, c->d_dw.p, w->d_grids.p + (size_t)g0 * K3, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1],
+                         c->d_w.p, c->d_dw.p, w->d_pack.p, ngrid, g0, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1],
                          c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_force.p, c->d_force_recip.p, c->d_Fdiag.p, n3);
     }
     hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, w->d_ra.p, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
@@ -1002,7 +1042,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   hipLaunchKernelGGL(k_sum_rows, dim3(nu), dim3(256), 0, c->stream, nu, envb, part_stride, part_units, E_units_env);
   hipLaunchKernelGGL(k_evb_special, dim3(nu), dim3(64), 0, c->stream, nu, w->d_units.p, w->d_tabs.p, c->d_moltypes.p, c->d_pair_par.p, c->nt,
                      c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->alpha, 2.0 * c->alpha / c->pi_sqrt, c->conv, c->pi,
-                     c->d_Fdiag.p, n3, E_units_spec, w->d_dbg.p);
+                     c->d_Fdiag.p, n3, E_units_spec);
   // ---- 8. off-diagonal elements
   if (ncp) {
     HIPCHK(hipMemsetAsync(w->d_dVspec.p, 0, (size_t)ncp * MAX_SPEC * 3 * 8, c->stream));
@@ -1019,10 +1059,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   w->h_E.resize(2 * nu + ncp + ngrid + 3 * std::max(ncp, 1));
   HIPCHK(hipMemcpyAsync(w->h_E.data(), w->d_E.p, (2 * nu + ncp + ngrid) * 8, hipMemcpyDeviceToHost, c->stream));
   if (ncp) HIPCHK(hipMemcpyAsync(w->h_E.data() + 2 * nu + ncp + ngrid, w->d_cpout.p, 3 * ncp * 8, hipMemcpyDeviceToHost, c->stream));
-  w->h_dbg.resize(8 * (size_t)nu + 2 * nu + ngrid); w->dbg_nu = nu;
-  HIPCHK(hipMemcpyAsync(w->h_dbg.data(), w->d_dbg.p, 8 * (size_t)nu * 8, hipMemcpyDeviceToHost, c->stream));
   CHK(fetch_energies(c));
-  for (int k = 0; k < 2 * nu + ncp + ngrid && k < 2 * nu + ngrid; ++k) w->h_dbg[8 * (size_t)nu + k] = k < 2 * nu ? w->h_E[k] : w->h_E[k + ncp];
   double en[MSEVB_N_ENERGY];
   total_force_collect(c, en);
   const double E_recip1 = c->E_recip;
@@ -1129,14 +1166,6 @@ int msevb_get_evb_element_force(msevb_ctx* c, int i, int j, double* force) {
   HIPCHK(hipMemcpyAsync(force, src, n3 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return MSEVB_OK;
-}
-
-int msevb_get_evb_debug(msevb_ctx* c, double* out, int n) {
-  EvbWork* w = g_work[c];
-  if (!w) return 0;
-  const int m = (int)w->h_dbg.size();
-  if (out) memcpy(out, w->h_dbg.data(), sizeof(double) * std::min(n, m));
-  return w->dbg_nu;
 }
 
 int msevb_comm_set_virtual(msevb_ctx* c, int r, int n) { if (!c || n < 1 || r < 0 || r >= n) return MSEVB_ERR_ARG; c->rank = r; c->n_ranks = n; return MSEVB_OK; }

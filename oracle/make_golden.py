@@ -23,6 +23,7 @@ import ref_inputs  # noqa: E402
 from reactive_pb_nn_md_amd import forcefield, synth  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
+ONLY = set(sys.argv[1:])       # optional: names of the cases to (re)generate
 
 BIG_TABLES = ("B6_spline", "B5_spline", "erfc_table", "ewaldscale_table", "Tang_Toennies_table",
               "dTang_Toennies_table", "CB")
@@ -79,8 +80,12 @@ def compact(d, keep_store=True):
     return out
 
 
-def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, **simkw):
+def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, **simkw):
+    if ONLY and name not in ONLY:
+        return
     ff = forcefield.ch3so3h_water_forcefield()
+    if sapt:
+        ff = forcefield.with_test_sapt(ff)
     s = synth.make_system(n_side, n_diabat=n_diabat, seed=seed)
     vel = None
     if md_steps:
@@ -112,6 +117,8 @@ def main():
     case("evb_n6_d4_s2", 6, 4, 2, evb=True, **small)
     case("evb_n6_d8_s1", 6, 8, 1, evb=True, **small)
     case("evb_n8_d8_s1", 8, 8, 1, evb=True, keep_store=False)
+    case("std_n6_sapt_s6", 6, 1, 6, evb=False, sapt=True, **small)
+    case("evb_n6_d4_sapt_s7", 6, 4, 7, evb=True, sapt=True, **small)
     case("md_std_n6_s4", 6, 1, 4, evb=False, md_steps=4, **small)
     case("md_evb_n6_d2_s5", 6, 2, 5, evb=True, md_steps=4, keep_store=False, **small)
 

@@ -38,6 +38,10 @@ def write_ffpmt(path, ff):
         f.write("solute_species\natom_type_parameters\n%d\n" % len(ff.atypes))
         for a in ff.atypes:
             f.write("%s %r %r %r 0\n" % (a[0], a[1], a[2], a[3]))
+        if ff.sapt:
+            f.write("\ncustom_sapt_parameters\nname Aex Ael Aind Adhf B C6 C8 C10 C12\n")
+            for row in ff.sapt:
+                f.write(row[0] + " " + " ".join(repr(float(x)) for x in row[1:]) + "\n")
         f.write("\ncross_terms  c6 c12\n%d\n" % len(ff.cross_terms))
         for c in ff.cross_terms:
             f.write("%d %d %r %r 0\n" % c)

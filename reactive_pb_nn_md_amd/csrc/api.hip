@@ -90,7 +90,7 @@ int msevb_destroy(msevb_ctx* c) {
                      &c->d_perm_tmp, &c->d_cell_start, &c->d_inv_perm, &c->d_nbr, &c->d_type_sorted, &c->d_mol_sorted, &c->d_base, &c->d_splindex};
   for (auto b : ib) b->release();
   DBuf<double>* db[] = {&c->d_chg, &c->d_mass, &c->d_B6, &c->d_B5, &c->d_tt, &c->d_dtt, &c->d_CB, &c->d_xyz, &c->d_vel, &c->d_force, &c->d_force_recip,
-                        &c->d_xyz_store, &c->d_disp, &c->d_maxdisp, &c->d_Q, &c->d_w, &c->d_dw, &c->d_uscale, &c->d_partials, &c->d_energies,
+                        &c->d_xyz_store, &c->d_disp, &c->d_maxdisp, &c->d_Q, &c->d_theta, &c->d_w, &c->d_dw, &c->d_uscale, &c->d_partials, &c->d_energies,
                         &c->d_Fdiag, &c->d_Foff};
   for (auto b : db) b->release();
   c->d_pair_par.release(); c->d_moltypes.release(); c->d_ewald_tab.release(); c->d_nbr_count.release(); c->d_nbr_start.release();
@@ -312,6 +312,8 @@ int msevb_finalize(msevb_ctx* c) {
     pp[k].nonzero = pp[k].type == 0 ? 1 : 0;
     for (int q = 0; q < 6; ++q) { pp[k].p[q] = c->h_vdw_par[k * 6 + q]; if (pp[k].type == 1 && q != 1 && pp[k].p[q] != 0.0) pp[k].nonzero = 1; }
   }
+  c->has_sapt = false;
+  for (auto& q : pp) if (q.type == 1 && q.nonzero) c->has_sapt = true;
   HIPCHK(hipMemcpy(c->d_pair_par.p, pp.data(), pp.size() * sizeof(PairParam), hipMemcpyHostToDevice));
   std::vector<MolTypeDev> mts;
   CHK(resolve_moltypes(c, mts));
@@ -461,7 +463,7 @@ int msevb_get_pme_state(msevb_ctx* c, double* Q, double* theta, double* us, doub
   const size_t K3 = (size_t)c->K * c->K * c->K;
   HIPCHK(hipStreamSynchronize(c->stream));
   if (Q) HIPCHK(hipMemcpy(Q, c->d_Q.p, K3 * 8, hipMemcpyDeviceToHost));
-  if (theta) { std::vector<double2> g(K3); HIPCHK(hipMemcpy(g.data(), c->d_grid.p, K3 * 16, hipMemcpyDeviceToHost)); for (size_t k = 0; k < K3; ++k) theta[k] = g[k].x; }
+  if (theta) HIPCHK(hipMemcpy(theta, c->d_theta.p, K3 * 8, hipMemcpyDeviceToHost));
   if (us) HIPCHK(hipMemcpy(us, c->d_uscale.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost));
   if (fr) HIPCHK(hipMemcpy(fr, c->d_force_recip.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost));
   return MSEVB_OK;

@@ -153,11 +153,13 @@ struct msevb_ctx {
   // PME
   DBuf<double2> d_grid;        // complex K^3 (x fastest), in place FFT
   DBuf<double> d_Q;            // real copy of the spread grid (kept for the EVB delta path)
+  DBuf<double> d_theta;        // real part of the convolved grid (theta_conv_Q)
   DBuf<double> d_w, d_dw, d_uscale;   // per atom: B6 weights [N][3][6], derivative weights, scaled coords
   DBuf<int> d_base, d_splindex;       // nearpt [N][3], B6 rows [N][3][6]
   rocfft_plan plan_fwd = nullptr, plan_bwd = nullptr, plan_fwd_b = nullptr, plan_bwd_b = nullptr;
   int plan_batch = 0;
   bool spread_tiles = true;
+  bool has_sapt = false;     // some (type_i,type_j) entry has non-zero SAPT coefficients
   rocfft_execution_info fft_info = nullptr;
   DBuf<char> d_fft_work;
   int fft_batch = 1;

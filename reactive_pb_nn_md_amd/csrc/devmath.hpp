@@ -8,6 +8,7 @@
 //   LJ: E = C12/r^12 - C6/r^6 ; f = dr/r^2 (12 C12/r^12 - 6 C6/r^6) (:621-645)
 //   SAPT: E = A exp(-B r) - sum_n f_n(B r) C_n / r^n, f_n from the Tang-Toennies table row ceil(B r/50*1000),
 //     no interpolation (:651-690)
+template <bool SAPT = true>
 __device__ __forceinline__ void pair_interaction(double r2, double qq, const PairParam& pp, const double2* __restrict__ etab, double inv_dx,
                                                  const double* __restrict__ tt, const double* __restrict__ dtt, double& fs, double& e_el,
                                                  double& e_vdw) {
@@ -27,7 +28,7 @@ __device__ __forceinline__ void pair_interaction(double r2, double qq, const Pai
     const double r6i = inv_r2 * inv_r2 * inv_r2, r12i = r6i * r6i;
     e_vdw = pp.p[0] * r12i - pp.p[1] * r6i;
     fs += inv_r2 * (12.0 * pp.p[0] * r12i - 6.0 * pp.p[1] * r6i);
-  } else if (pp.type == 1 && pp.nonzero) {
+  } else if (SAPT && pp.type == 1 && pp.nonzero) {
     const double A = pp.p[0], B = pp.p[1];
     const int ti = (int)ceil(B * r / TT_MAX * (double)TT_GRID);
     const double* t = tt + 4 * (ti - 1);

@@ -356,7 +356,8 @@ __global__ void k_evb_pack(size_t K3, int ng, const double2* __restrict__ grids,
   }
 }
 
-// reciprocal force of EVERY atom against up to NG diabat grids with the principal stencil: one wavefront per atom.
+// reciprocal force of EVERY atom against up to NG diabat grids with the principal stencil.  8 lanes per atom, lane s < 6 owns
+// the k3 = s plane (36 taps); the NG grids are read from the interleaved `pack` array (NG contiguous doubles per grid point).
 //   Fstore[slot_g][a] = F11[a] + (Frecip_g[a] - Frecip_1[a])
 template <int NG>
 __global__ __launch_bounds__(256) void k_evb_gather(int N, int K, size_t K3, int ng, const int* __restrict__ slots, const double* __restrict__ chg,
@@ -364,33 +365,39 @@ __global__ __launch_bounds__(256) void k_evb_gather(int N, int K, size_t K3, int
                                                     const double* __restrict__ pack, int ngtot, int g0, double conv, double k00, double k01, double k02, double k10,
                                                     double k11, double k12, double k20, double k21, double k22, const double* __restrict__ F11,
                                                     const double* __restrict__ Frecip1, double* __restrict__ Fstore, size_t fstride) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (i >= N) return;
-  const int b1 = base[3 * i], b2 = base[3 * i + 1], b3 = base[3 * i + 2];
-  const double* wi = w + (size_t)i * 18;
-  const double* dwi = dw + (size_t)i * 18;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 3, sub = t & 7;
   double acc[NG][3];
 #pragma unroll
   for (int g = 0; g < NG; ++g) acc[g][0] = acc[g][1] = acc[g][2] = 0.0;
-  for (int t = lane; t < 216; t += 64) {
-    const int k1 = t % 6, k2 = (t / 6) % 6, k3 = t / 36;
-    int n1 = b1 - k1; if (n1 < 0) n1 += K;
-    int n2 = b2 - k2; if (n2 < 0) n2 += K;
-    int n3 = b3 - k3; if (n3 < 0) n3 += K;
-    const size_t id = n1 + (size_t)K * (n2 + (size_t)K * n3);
-    const double w1 = wi[k1], w2 = wi[6 + k2], w3 = wi[12 + k3];
-    const double c1 = dwi[k1] * w2 * w3, c2 = dwi[6 + k2] * w1 * w3, c3 = dwi[12 + k3] * w1 * w2;
-    const double* pk = pack + id * ngtot + g0;
+  if (i < N && sub < 6) {
+    const int b1 = base[3 * i], b2 = base[3 * i + 1];
+    int n3 = base[3 * i + 2] - sub; if (n3 < 0) n3 += K;
+    const double* wi = w + (size_t)i * 18;
+    const double* dwi = dw + (size_t)i * 18;
+    const double w3 = wi[12 + sub], d3 = dwi[12 + sub];
+    for (int k2 = 0; k2 < 6; ++k2) {
+      int n2 = b2 - k2; if (n2 < 0) n2 += K;
+      const size_t rowid = (size_t)K * (n2 + (size_t)K * n3);
+      const double w2 = wi[6 + k2], d2 = dwi[6 + k2];
+      const double c1 = w2 * w3, c2 = d2 * w3, c3 = w2 * d3;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) if (g < ng) { const double th = pk[g]; acc[g][0] += c1 * th; acc[g][1] += c2 * th; acc[g][2] += c3 * th; }
+      for (int k1 = 0; k1 < 6; ++k1) {
+        int n1 = b1 - k1; if (n1 < 0) n1 += K;
+        const double* pk = pack + (rowid + n1) * ngtot + g0;
+        const double a1 = dwi[k1] * c1, a2 = wi[k1] * c2, a3 = wi[k1] * c3;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) if (g < ng) { const double th = pk[g]; acc[g][0] += a1 * th; acc[g][1] += a2 * th; acc[g][2] += a3 * th; }
+      }
+    }
   }
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     if (g >= ng) break;
     double f1 = acc[g][0], f2 = acc[g][1], f3 = acc[g][2];
-    for (int o = 32; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); f3 += __shfl_xor(f3, o, 64); }
-    if (lane == 0) {
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); f3 += __shfl_xor(f3, o, 64); }
+    if (i < N && sub == 0) {
       const double s = chg[i] * conv, Kd = (double)K;
       f1 *= s; f2 *= s; f3 *= s;
       double* F = Fstore + (size_t)slots[g] * fstride;
@@ -1025,7 +1032,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     hipLaunchKernelGGL(k_evb_pack, dim3(2048), dim3(256), 0, c->stream, K3, ngrid, w->d_grids.p, w->d_pack.p);
     for (int g0 = 0; g0 < ngrid; g0 += 8) {
       const int ng = std::min(8, ngrid - g0);
-      hipLaunchKernelGGL(k_evb_gather<8>, dim3((N + 3) / 4), dim3(256), 0, c->stream, N, K, K3, ng, w->d_slots.p + 2 * MAX_DIABATS + g0, c->d_chg.p, c->d_base.p,
+      hipLaunchKernelGGL(k_evb_gather<8>, dim3((N * 8 + 255) / 256), dim3(256), 0, c->stream, N, K, K3, ng, w->d_slots.p + 2 * MAX_DIABATS + g0, c->d_chg.p, c->d_base.p,
                          c->d_w.p, c->d_dw.p, w->d_pack.p, ngrid, g0, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1],
                          c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_force.p, c->d_force_recip.p, c->d_Fdiag.p, n3);
     }

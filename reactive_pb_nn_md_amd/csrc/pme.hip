@@ -136,34 +136,44 @@ __global__ void k_copy_real(size_t K3, const double2* __restrict__ grid, double*
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K3; k += (size_t)gridDim.x * blockDim.x) Q[k] = grid[k].x;
 }
 
-// one wavefront per atom: 216 stencil points over 64 lanes, shuffle reduction, F = -K kk^T Ftilde
+// real part of the convolved grid, contiguous (the gathers read 6 consecutive doubles per stencil row)
+__global__ void k_pme_real(size_t K3, const double2* __restrict__ grid, double* __restrict__ theta) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K3; k += (size_t)gridDim.x * blockDim.x) theta[k] = grid[k].x;
+}
+
+// derivative_grid_Q: 8 lanes per atom (8 atoms per wavefront); lane s < 6 owns the k3 = s plane of the stencil (36 taps, 6 rows
+// of 6 consecutive grid points), 3-step shuffle reduction inside the 8-lane group, F = -K kk^T Ftilde.
 __global__ __launch_bounds__(256) void k_pme_gather(int N, int K, const double* __restrict__ chg, const int* __restrict__ base,
-                                                    const double* __restrict__ w, const double* __restrict__ dw, const double2* __restrict__ grid,
+                                                    const double* __restrict__ w, const double* __restrict__ dw, const double* __restrict__ theta,
                                                     double conv, double k00, double k01, double k02, double k10, double k11, double k12,
                                                     double k20, double k21, double k22, double* __restrict__ F_recip, double* __restrict__ F) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (i >= N) return;
-  const double q = chg[i];
-  const int b1 = base[3 * i], b2 = base[3 * i + 1], b3 = base[3 * i + 2];
-  const double* wi = w + (size_t)i * 18;
-  const double* dwi = dw + (size_t)i * 18;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 3, sub = t & 7;
   double f1 = 0.0, f2 = 0.0, f3 = 0.0;
-  for (int t = lane; t < 216; t += 64) {
-    const int k1 = t % 6, k2 = (t / 6) % 6, k3 = t / 36;
-    int n1 = b1 - k1; if (n1 < 0) n1 += K;
-    int n2 = b2 - k2; if (n2 < 0) n2 += K;
-    int n3 = b3 - k3; if (n3 < 0) n3 += K;
-    const double th = grid[n1 + (size_t)K * (n2 + (size_t)K * n3)].x;
-    const double w1 = wi[k1], w2 = wi[6 + k2], w3 = wi[12 + k3];
-    f1 += dwi[k1] * w2 * w3 * th;
-    f2 += dwi[6 + k2] * w1 * w3 * th;
-    f3 += dwi[12 + k3] * w1 * w2 * th;
+  if (i < N && sub < 6) {
+    const int b1 = base[3 * i], b2 = base[3 * i + 1];
+    int n3 = base[3 * i + 2] - sub; if (n3 < 0) n3 += K;
+    const double* wi = w + (size_t)i * 18;
+    const double* dwi = dw + (size_t)i * 18;
+    double w1[6], d1[6]; int n1[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { w1[k] = wi[k]; d1[k] = dwi[k]; int n = b1 - k; if (n < 0) n += K; n1[k] = n; }
+    const double w3 = wi[12 + sub], d3 = dwi[12 + sub];
+#pragma unroll
+    for (int k2 = 0; k2 < 6; ++k2) {
+      int n2 = b2 - k2; if (n2 < 0) n2 += K;
+      const double* row = theta + (size_t)K * (n2 + (size_t)K * n3);
+      const double w2 = wi[6 + k2], d2 = dwi[6 + k2];
+      double s0 = 0.0, s1 = 0.0;    // sum_k1 w1*theta, sum_k1 d1*theta
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { const double th = row[n1[k]]; s0 += w1[k] * th; s1 += d1[k] * th; }
+      f1 += s1 * w2 * w3; f2 += s0 * d2 * w3; f3 += s0 * w2 * d3;
+    }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); f3 += __shfl_xor(f3, o, 64); }
-  if (lane == 0) {
-    const double s = q * conv;
+  for (int o = 4; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); f3 += __shfl_xor(f3, o, 64); }
+  if (i < N && sub == 0) {
+    const double s = chg[i] * conv;
     f1 *= s; f2 *= s; f3 *= s;
     const double Kd = (double)K;
     const double fx = -Kd * (k00 * f1 + k10 * f2 + k20 * f3);
@@ -185,7 +195,7 @@ int pme_setup(msevb_ctx* c) {
   const size_t K3 = (size_t)K * K * K;
   if (!g_rocfft_ready) { if (rocfft_setup() != rocfft_status_success) FAIL(MSEVB_ERR_FFT, "rocfft_setup failed"); g_rocfft_ready = true; }
   const int batch = c->fft_batch < 1 ? 1 : c->fft_batch;
-  if (c->d_grid.alloc(K3 * batch) || c->d_Q.alloc(K3) || c->d_w.alloc(18 * (size_t)N) || c->d_dw.alloc(18 * (size_t)N) || c->d_uscale.alloc(3 * (size_t)N) ||
+  if (c->d_grid.alloc(K3 * batch) || c->d_Q.alloc(K3) || c->d_theta.alloc(K3) || c->d_w.alloc(18 * (size_t)N) || c->d_dw.alloc(18 * (size_t)N) || c->d_uscale.alloc(3 * (size_t)N) ||
       c->d_base.alloc(3 * (size_t)N) || c->d_splindex.alloc(18 * (size_t)N) || c->d_force_recip.alloc(3 * (size_t)N))
     FAIL(MSEVB_ERR_HIP, "hipMalloc failed (PME)");
   size_t len[3] = {(size_t)K, (size_t)K, (size_t)K};
@@ -261,7 +271,9 @@ int pme_prepare_atoms(msevb_ctx* c) {
 
 int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add) {
   const int N = c->N;
-  hipLaunchKernelGGL(k_pme_gather, dim3((N + 3) / 4), dim3(256), 0, c->stream, N, c->K, chg, c->d_base.p, c->d_w.p, c->d_dw.p, grid, c->conv, c->kk[0][0],
+  const size_t K3 = (size_t)c->K * c->K * c->K;
+  hipLaunchKernelGGL(k_pme_real, dim3(1024), dim3(256), 0, c->stream, K3, grid, c->d_theta.p);
+  hipLaunchKernelGGL(k_pme_gather, dim3((N * 8 + 255) / 256), dim3(256), 0, c->stream, N, c->K, chg, c->d_base.p, c->d_w.p, c->d_dw.p, c->d_theta.p, c->conv, c->kk[0][0],
                      c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;

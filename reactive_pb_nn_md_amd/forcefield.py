@@ -71,6 +71,21 @@ class ForceField:
     exchange_charge_atomic: dict
     exchange_charge_proton: list      # [(mol1,mol2,q)]
     evb_pairs: list                   # [EvbPair]
+    sapt: list = field(default_factory=list)   # optional [(name, A_ex, A_el, A_ind, A_dhf, B, C6, C8, C10, C12)] 'custom_sapt_parameters'
+
+
+def with_test_sapt(ff: ForceField) -> ForceField:
+    """adds a synthetic 'custom_sapt_parameters' block (test values, not a fitted force field) so that the SAPT/Tang-Toennies
+    branch of the pair kernel is exercised with non-zero coefficients: every pair involving a zero-epsilon (hydrogen) type
+    becomes a live Buckingham + damped-dispersion interaction."""
+    rows = []
+    for (name, q, eps, sig) in ff.atypes:
+        if eps == 0.0:
+            rows.append((name, 2000.0, 50.0, 10.0, 5.0, 3.5, 50.0, 100.0, 20.0, 5.0))
+        else:
+            rows.append((name, 100000.0, 500.0, 100.0, 50.0, 3.6, 1500.0, 8000.0, 40000.0, 100000.0))
+    ff.sapt = rows
+    return ff
 
 
 def ch3so3h_water_forcefield() -> ForceField:
@@ -216,6 +231,9 @@ def build_params(ff: ForceField, moltype_order=None, lj_comb_rule="opls", n_excl
     vdw = np.zeros((nt, nt, 6))
     tmp = np.zeros((nt, nt, 9))
     tmp[:, :, 4] = EXP_INIT
+    for row in ff.sapt:          # src/initialize_routines.f90:359-382
+        i = idx[row[0]]
+        tmp[i, i, :9] = row[1:10]
     vtype = np.zeros((nt, nt), dtype=np.int32)
     gen_cross = np.zeros((nt, nt), dtype=np.int32)
     for i, a in enumerate(ff.atypes):

@@ -387,7 +387,7 @@ int msevb_get_verlet_list(msevb_ctx* c, int* vp, int* nl, long* nn) {
   HIPCHK(hipMemcpy(nb.data(), c->d_nbr.p, c->n_nbr * sizeof(int), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(perm.data(), c->d_perm.p, N * sizeof(int), hipMemcpyDeviceToHost));
   std::vector<std::vector<int>> half(N);
-  for (int k = 0; k < N; ++k) { const int i = perm[k]; for (unsigned q = st[k]; q < st[k + 1]; ++q) { const int j = perm[nb[q]]; if (j > i) half[i].push_back(j); } }
+  for (int k = 0; k < N; ++k) { const int i = perm[k]; for (unsigned q = st[k]; q < st[k + 1]; ++q) { const int j = perm[(unsigned)nb[q] & NBR_IDX_MASK]; if (j > i) half[i].push_back(j); } }
   long tot = 0;
   for (int i = 0; i < N; ++i) { std::sort(half[i].begin(), half[i].end()); if (vp) vp[i] = (int)tot + 1; if (nl) for (int j : half[i]) nl[tot++] = j + 1; else tot += (long)half[i].size(); }
   if (vp) vp[N] = (int)tot + 1;
@@ -470,6 +470,7 @@ int msevb_get_pme_state(msevb_ctx* c, double* Q, double* theta, double* us, doub
 }
 int msevb_get_pme_indices(msevb_ctx* c, int* nearpt, int* splindex) {
   NEED_FINAL();
+  CHK(pme_prepare_atoms(c, true));      // the B6 table rows are not kept by the force path: recompute them from the current positions
   HIPCHK(hipStreamSynchronize(c->stream));
   if (nearpt) HIPCHK(hipMemcpy(nearpt, c->d_base.p, 3 * (size_t)c->N * 4, hipMemcpyDeviceToHost));
   if (splindex) HIPCHK(hipMemcpy(splindex, c->d_splindex.p, 18 * (size_t)c->N * 4, hipMemcpyDeviceToHost));

@@ -58,6 +58,20 @@ struct MolTypeDev {
 
 struct BoxDev { double L[3], invL[3]; };
 
+// XCD-aware block order: the dispatcher deals workgroups round-robin over the 8 XCDs (block b -> XCD b % 8), each with its
+// own 4 MB L2.  Kernels that walk the cell-sorted atoms map hardware block b to logical block (b % 8) * (nb / 8) + b / 8, so
+// one XCD works on one contiguous eighth of the sorted range (a slab of cells) and its L2 holds only that slab's data.
+// nb must be a multiple of 8 (launch helpers round up; surplus blocks exit).
+#ifdef __HIPCC__
+__device__ __forceinline__ int xcd_block(int b, int nb) { return (b & 7) * (nb >> 3) + (b >> 3); }
+#endif
+inline int round_up8(int n) { return (n + 7) & ~7; }
+
+// Verlet-list entry: sorted index of the neighbour in the low 24 bits, its atom type in the high 8 (the pair kernel then needs
+// no per-neighbour type gather).  Limits: N < 2^24 atoms, MAX_TYPES <= 256; the list is rebuilt whenever the topology changes.
+constexpr int NBR_IDX_BITS = 24;
+constexpr unsigned NBR_IDX_MASK = (1u << NBR_IDX_BITS) - 1u;
+
 // host mirror of a molecule type (as set through the ABI)
 struct MolTypeHost {
   int natom = 0;
@@ -213,7 +227,7 @@ extern "C" int total_force_enqueue(msevb_ctx* c);
 extern "C" void total_force_collect(msevb_ctx* c, double* en);
 extern "C" int upload_topology(msevb_ctx* c);
 int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part_stride, int* nblocks);
-int pme_prepare_atoms(msevb_ctx* c);
+int pme_prepare_atoms(msevb_ctx* c, bool with_indices);
 int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add);
 
 constexpr int MAX_BLOCKS = 65536;

@@ -24,6 +24,7 @@
 #include "devmath.hpp"
 
 #include "molecule_dev.hpp"
+#include "gather_dev.hpp"
 
 namespace {
 
@@ -142,8 +143,30 @@ __device__ __forceinline__ double evb_repulsion_atom(const UnitDesc& u, const Ev
   return E;
 }
 
-// ---- environment kernel: special (donor+acceptor / hydronium) atoms of every unit against all NON-special atoms --------
-__global__ __launch_bounds__(256) void k_evb_env(int N, int n_units, const UnitDesc* __restrict__ units, const EvbTablesDev* __restrict__ tabs,
+// ---- candidate atoms: everything within R of the hydronium centre of mass (R = farthest special atom + cutoff), compacted once
+// per step so that the environment kernel of every unit walks ~2 % of the box instead of all atoms.  Also re-arms the counter
+// of k_evb_region for the next step.
+__global__ __launch_bounds__(256) void k_evb_candidates(int N, double cx, double cy, double cz, double R2, const double* __restrict__ xyz, BoxDev box,
+                                                        int* __restrict__ counter, int* __restrict__ cand, int* __restrict__ region_counter) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *region_counter = 0;
+  bool in = false;
+  if (i < N) {
+    double dr[3] = {xyz[3 * i] - cx, xyz[3 * i + 1] - cy, xyz[3 * i + 2] - cz};
+    min_image(dr, box);
+    in = dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2] < R2;
+  }
+  const unsigned long long m = __ballot(in);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  int b = 0;
+  if (lane == 0) b = atomicAdd(counter, __popcll(m));
+  b = __shfl(b, 0, 64);
+  if (in) cand[b + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = i;
+}
+
+// ---- environment kernel: special (donor+acceptor / hydronium) atoms of every unit against the candidate NON-special atoms --
+__global__ __launch_bounds__(256) void k_evb_env(const int* __restrict__ n_cand, const int* __restrict__ cand, int n_units, const UnitDesc* __restrict__ units, const EvbTablesDev* __restrict__ tabs,
                                                  const double* __restrict__ xyz, const double* __restrict__ chg, const int* __restrict__ atype,
                                                  const int* __restrict__ mol_of, const PairParam* __restrict__ pairpar, int nt,
                                                  const double2* __restrict__ etab, double inv_dx, const double* __restrict__ tt,
@@ -164,7 +187,9 @@ __global__ __launch_bounds__(256) void k_evb_env(int N, int n_units, const UnitD
   __syncthreads();
   double* F = Fstore + (size_t)u.slot * fstride;
   double e = 0.0;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+  const int ncand = *n_cand;
+  for (int cj = blockIdx.x * blockDim.x + threadIdx.x; cj < ncand; cj += gridDim.x * blockDim.x) {
+    const int j = cand[cj];
     const int mj = mol_of[j];
     bool special = false;
     for (int k = 0; k < u.n_mols; ++k) special |= (u.mols[k] == mj);
@@ -353,58 +378,6 @@ __global__ void k_evb_pack(size_t K3, int ng, const double2* __restrict__ grids,
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K3 * ng; k += (size_t)gridDim.x * blockDim.x) {
     const size_t id = k / ng; const int g = (int)(k % ng);
     pack[k] = grids[(size_t)g * K3 + id].x;
-  }
-}
-
-// reciprocal force of EVERY atom against up to NG diabat grids with the principal stencil.  8 lanes per atom, lane s < 6 owns
-// the k3 = s plane (36 taps); the NG grids are read from the interleaved `pack` array (NG contiguous doubles per grid point).
-//   Fstore[slot_g][a] = F11[a] + (Frecip_g[a] - Frecip_1[a])
-template <int NG>
-__global__ __launch_bounds__(256) void k_evb_gather(int N, int K, size_t K3, int ng, const int* __restrict__ slots, const double* __restrict__ chg,
-                                                    const int* __restrict__ base, const double* __restrict__ w, const double* __restrict__ dw,
-                                                    const double* __restrict__ pack, int ngtot, int g0, double conv, double k00, double k01, double k02, double k10,
-                                                    double k11, double k12, double k20, double k21, double k22, const double* __restrict__ F11,
-                                                    const double* __restrict__ Frecip1, double* __restrict__ Fstore, size_t fstride) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = t >> 3, sub = t & 7;
-  double acc[NG][3];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) acc[g][0] = acc[g][1] = acc[g][2] = 0.0;
-  if (i < N && sub < 6) {
-    const int b1 = base[3 * i], b2 = base[3 * i + 1];
-    int n3 = base[3 * i + 2] - sub; if (n3 < 0) n3 += K;
-    const double* wi = w + (size_t)i * 18;
-    const double* dwi = dw + (size_t)i * 18;
-    const double w3 = wi[12 + sub], d3 = dwi[12 + sub];
-    for (int k2 = 0; k2 < 6; ++k2) {
-      int n2 = b2 - k2; if (n2 < 0) n2 += K;
-      const size_t rowid = (size_t)K * (n2 + (size_t)K * n3);
-      const double w2 = wi[6 + k2], d2 = dwi[6 + k2];
-      const double c1 = w2 * w3, c2 = d2 * w3, c3 = w2 * d3;
-#pragma unroll
-      for (int k1 = 0; k1 < 6; ++k1) {
-        int n1 = b1 - k1; if (n1 < 0) n1 += K;
-        const double* pk = pack + (rowid + n1) * ngtot + g0;
-        const double a1 = dwi[k1] * c1, a2 = wi[k1] * c2, a3 = wi[k1] * c3;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) if (g < ng) { const double th = pk[g]; acc[g][0] += a1 * th; acc[g][1] += a2 * th; acc[g][2] += a3 * th; }
-      }
-    }
-  }
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    if (g >= ng) break;
-    double f1 = acc[g][0], f2 = acc[g][1], f3 = acc[g][2];
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); f3 += __shfl_xor(f3, o, 64); }
-    if (i < N && sub == 0) {
-      const double s = chg[i] * conv, Kd = (double)K;
-      f1 *= s; f2 *= s; f3 *= s;
-      double* F = Fstore + (size_t)slots[g] * fstride;
-      F[3 * i] = F11[3 * i] + (-Kd * (k00 * f1 + k10 * f2 + k20 * f3) - Frecip1[3 * i]);
-      F[3 * i + 1] = F11[3 * i + 1] + (-Kd * (k01 * f1 + k11 * f2 + k21 * f3) - Frecip1[3 * i + 1]);
-      F[3 * i + 2] = F11[3 * i + 2] + (-Kd * (k02 * f1 + k12 * f2 + k22 * f3) - Frecip1[3 * i + 2]);
-    }
   }
 }
 
@@ -608,8 +581,10 @@ __global__ void k_evb_blend(size_t n3, int nterm, const int* __restrict__ slots,
 }
 
 __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms, const double* __restrict__ xyz,
-                             const double* __restrict__ mass, BoxDev box, int* __restrict__ counter, RegionRec* __restrict__ out, int cap) {
+                             const double* __restrict__ mass, BoxDev box, int* __restrict__ counter, RegionRec* __restrict__ out, int cap,
+                             int* __restrict__ cand_counter) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m == 0) *cand_counter = 0;      // re-arm k_evb_candidates (which in turn re-arms `counter` for the next step)
   if (m >= M) return;
   double ch[3] = {0, 0, 0}, mh = 0;
   for (int k = 0; k < mol_natom[hyd]; ++k) { const int a = mol_atoms[hyd * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) ch[d] += xyz[3 * a + d] * mass[a]; mh += mass[a]; }
@@ -653,13 +628,15 @@ struct HTopo {   // the molecules touched so far by a hop chain, in the topology
 struct EvbWork {   // persistent device scratch of one context
   DBuf<UnitDesc> d_units; DBuf<CouplingDesc> d_cps; DBuf<RecipAtom> d_ra; DBuf<EvbTablesDev> d_tabs; DBuf<double> d_exch;
   DBuf<double> d_part, d_E, d_dVspec, d_cpout, d_coef; DBuf<int> d_slots, d_isoff, d_sbase, d_counter; DBuf<double> d_sw, d_sdw;
-  DBuf<double2> d_grids; DBuf<RegionRec> d_region;
+  DBuf<double2> d_grids; DBuf<RegionRec> d_region; DBuf<int> d_cand;
   DBuf<double> d_F11, d_pack;
   hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
   RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
   UnitDesc* h_units = nullptr; CouplingDesc* h_cps = nullptr; RecipAtom* h_ras = nullptr;   // pinned staging
   int grids_cap = 0;
   bool tabs_uploaded = false;
+  double screen_r = 0.0;
+  bool counters_dirty = true;
   std::vector<RegionRec> region;
   std::vector<double> h_E;
 };
@@ -848,13 +825,17 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipHostMalloc((void**)&w->h_cps, MAX_DIABATS * sizeof(CouplingDesc), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&w->h_ras, MAX_DIABATS * MAX_SPEC * sizeof(RecipAtom), hipHostMallocDefault));
   }
-  if (w->d_region.alloc(REGION_CAP) || w->d_counter.alloc(4)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB region)");
+  if (w->d_region.alloc(REGION_CAP) || w->d_counter.alloc(4) || w->d_cand.alloc(N)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB region)");
+  if (w->counters_dirty) {     // first call, or the previous call failed half-way: afterwards the two kernels re-arm each other's counter
+    HIPCHK(hipMemsetAsync(w->d_counter.p, 0, 4 * sizeof(int), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  struct Rearm { EvbWork* w; bool ok; ~Rearm() { w->counters_dirty = !ok; } } rearm{w, false};
   const double Rreg = 5.0 * c->max_chain + 5.0;
   HIPCHK(hipEventRecord(w->ev_in, c->stream));
   HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_in, 0));
-  HIPCHK(hipMemsetAsync(w->d_counter.p, 0, sizeof(int), w->stream2));
   hipLaunchKernelGGL(k_evb_region, dim3((M + 255) / 256), dim3(256), 0, w->stream2, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
-                     c->d_mass.p, box, w->d_counter.p, w->d_region.p, REGION_CAP);
+                     c->d_mass.p, box, w->d_counter.p, w->d_region.p, REGION_CAP, w->d_counter.p + 1);
   HIPCHK(hipMemcpyAsync(w->h_count, w->d_counter.p, sizeof(int), hipMemcpyDeviceToHost, w->stream2));
   HIPCHK(hipMemcpyAsync(w->h_region, w->d_region.p, REGION_FAST * sizeof(RegionRec), hipMemcpyDeviceToHost, w->stream2));
   HIPCHK(hipEventRecord(w->ev_region, w->stream2));
@@ -974,7 +955,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   }
   const int nu = (int)units.size(), ncp = (int)cps.size(), nra = (int)ras.size();
   // ---- 5. device buffers
-  const int envb = std::min(512, (N + 255) / 256), cpb = std::min(256, (M + 255) / 256), convb = 1024;
+  const int envb = std::min(64, (N + 255) / 256), cpb = std::min(256, (M + 255) / 256), convb = 1024;
   const int part_stride = 1024;
   const int n_rows = nu + ncp + ngrid + 8;
   if (c->d_Fdiag.alloc((size_t)n_diag * n3) || c->d_Foff.alloc((size_t)std::max(n_off, 1) * n3) || w->d_units.alloc(nu) || w->d_cps.alloc(std::max(ncp, 1)) ||
@@ -994,6 +975,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     for (int k = 0; k < c->n_da; ++k) rmax = std::max(rmax, c->da_par[k][5]);
     for (int k = 0; k < c->n_pa; ++k) rmax = std::max(rmax, c->pa_par[k][4] + 3.0);
     tb.screen2 = (rmax + 0.5) * (rmax + 0.5);
+    w->screen_r = rmax + 0.5;
     HIPCHK(hipMemcpy(w->d_tabs.p, &tb, sizeof tb, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(w->d_exch.p, c->e_exch_atomic, sizeof(double) * MAX_TYPES, hipMemcpyHostToDevice));
     w->tabs_uploaded = true;
@@ -1030,9 +1012,12 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gslots[grid_of[d]] = diag_slot(c, D, d);
     HIPCHK(hipMemcpyAsync(w->d_slots.p + 2 * MAX_DIABATS, gslots.data(), ngrid * sizeof(int), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_evb_pack, dim3(2048), dim3(256), 0, c->stream, K3, ngrid, w->d_grids.p, w->d_pack.p);
+    if ((double)K3 * ngrid >= 2147483648.0) FAIL(MSEVB_ERR_LIMIT, "EVB gather: K^3 * n_grids exceeds the 32-bit offset range");
+    const int* permp = c->list_valid ? c->d_perm.p : nullptr;     // cell-sorted traversal keeps the stencils of co-resident waves in L2
     for (int g0 = 0; g0 < ngrid; g0 += 8) {
       const int ng = std::min(8, ngrid - g0);
-      hipLaunchKernelGGL(k_evb_gather<8>, dim3((N * 8 + 255) / 256), dim3(256), 0, c->stream, N, K, K3, ng, w->d_slots.p + 2 * MAX_DIABATS + g0, c->d_chg.p, c->d_base.p,
+      auto kern = ng > 4 ? k_stencil_gather<8> : ng > 2 ? k_stencil_gather<4> : ng > 1 ? k_stencil_gather<2> : k_stencil_gather<1>;
+      hipLaunchKernelGGL(kern, dim3(round_up8((N + 3) / 4)), dim3(256), 0, c->stream, N, K, ng, w->d_slots.p + 2 * MAX_DIABATS + g0, permp, c->d_chg.p, c->d_base.p,
                          c->d_w.p, c->d_dw.p, w->d_pack.p, ngrid, g0, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1],
                          c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_force.p, c->d_force_recip.p, c->d_Fdiag.p, n3);
     }
@@ -1044,7 +1029,20 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   phase_end(c, PH_EVB_RECIP);
   // ---- 7. real-space / bonded / repulsion deltas of all units (ms_evb_diabat_force_energy, :1421)
   phase_begin(c, PH_EVB_REAL);
-  hipLaunchKernelGGL(k_evb_env, dim3(envb, nu), dim3(256), 0, c->stream, N, nu, w->d_units.p, w->d_tabs.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p, c->d_mol_of.p,
+  {
+    // candidate sphere: centre = hydronium COM, radius = farthest special atom + max(cutoff, repulsion screen) + a little
+    const RegionRec* rh = find_region(w, c->hydronium);
+    double far2 = 0.0;
+    for (const UnitDesc& u : units) for (int k = 0; k < u.n_spec; ++k) {
+      double d2 = 0.0;
+      for (int q = 0; q < 3; ++q) { double d = u.spec[k].x[q] - rh->com[q]; d -= c->box[q] * std::floor(d / c->box[q] + 0.5); d2 += d * d; }
+      far2 = std::max(far2, d2);
+    }
+    const double Renv = std::sqrt(far2) + std::max(c->rc, w->screen_r) + 0.5;
+    hipLaunchKernelGGL(k_evb_candidates, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, rh->com[0], rh->com[1], rh->com[2], Renv * Renv, c->d_xyz.p, box,
+                       w->d_counter.p + 1, w->d_cand.p, w->d_counter.p);
+  }
+  hipLaunchKernelGGL(k_evb_env, dim3(envb, nu), dim3(256), 0, c->stream, w->d_counter.p + 1, w->d_cand.p, nu, w->d_units.p, w->d_tabs.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p, c->d_mol_of.p,
                      c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->d_Fdiag.p, n3, part_units, part_stride);
   hipLaunchKernelGGL(k_sum_rows, dim3(nu), dim3(256), 0, c->stream, nu, envb, part_stride, part_units, E_units_env);
   hipLaunchKernelGGL(k_evb_special, dim3(nu), dim3(64), 0, c->stream, nu, w->d_units.p, w->d_tabs.p, c->d_moltypes.p, c->d_pair_par.p, c->nt,
@@ -1087,6 +1085,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   if (c->n_ranks > 1 && c->nccl_comm) CHK(msevb_comm_allgather_evb(c));
   if (c->n_ranks > 1 && !c->nccl_comm) {   // virtual sharding (tests): leave foreign diabats empty; caller merges
     if (epot_out) *epot_out = H11;
+    rearm.ok = true;
     return MSEVB_OK;
   }
   // ---- 11. diagonalise, blend (diagonalize_evb_hamiltonian, :242)
@@ -1135,6 +1134,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     CHK(nb_build(c));
     c->flag_verlet_list = 0;
   }
+  rearm.ok = true;
   return MSEVB_OK;
 }
 

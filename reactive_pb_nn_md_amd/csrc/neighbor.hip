@@ -51,7 +51,7 @@ __global__ void k_gather_sorted(int N, const int* __restrict__ perm, const doubl
 
 // one wavefront per sorted atom; FILL=false counts, FILL=true writes neighbours compactly (ballot + mbcnt)
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_neighbors(int N, const double4* __restrict__ posq, const int* __restrict__ mol_s,
+__global__ __launch_bounds__(256) void k_neighbors(int N, const double4* __restrict__ posq, const int* __restrict__ mol_s, const int* __restrict__ type_s,
                                                    const int* __restrict__ keys, const int* __restrict__ cell_start, BoxDev box, int3 nc,
                                                    double rv2, unsigned* __restrict__ count, const unsigned* __restrict__ start,
                                                    int* __restrict__ nbr) {
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void k_neighbors(int N, const double4* __restr
           const unsigned long long m = __ballot(hit);
           if (FILL && hit) {
             const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            nbr[base + total + rank] = j;
+            nbr[base + total + rank] = (int)((unsigned)j | ((unsigned)type_s[j] << NBR_IDX_BITS));
           }
           total += (unsigned)__popcll(m);
         }
@@ -174,6 +174,7 @@ int nb_refresh_sorted(msevb_ctx* c) {
 
 int nb_build(msevb_ctx* c) {
   const int N = c->N;
+  if ((unsigned)N > NBR_IDX_MASK || c->nt > 256) FAIL(MSEVB_ERR_LIMIT, "Verlet list entries hold 24-bit atom indices and 8-bit atom types");
   phase_begin(c, PH_VERLET);
   for (int d = 0; d < 3; ++d) { int n = (int)floor(c->box[d] / c->rv); c->ncell[d] = n < 1 ? 1 : n; }
   const int3 nc = make_int3(c->ncell[0], c->ncell[1], c->ncell[2]);
@@ -199,7 +200,7 @@ int nb_build(msevb_ctx* c) {
   const dim3 grid((N + wpb - 1) / wpb), block(64 * wpb);
   const double rv2 = c->rv * c->rv;
   HIPCHK(hipMemsetAsync(c->d_nbr_count.p, 0, (N + 1) * sizeof(unsigned), c->stream));
-  hipLaunchKernelGGL(k_neighbors<false>, grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
+  hipLaunchKernelGGL(k_neighbors<false>, grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
                      c->d_nbr_count.p, (const unsigned*)nullptr, (int*)nullptr);
   tb = c->d_sort_tmp.n;
   HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp.p, tb, c->d_nbr_count.p, c->d_nbr_start.p, N + 1, c->stream));
@@ -210,7 +211,7 @@ int nb_build(msevb_ctx* c) {
   if (c->d_nbr.n < (size_t)total) {
     if (c->d_nbr.alloc((size_t)(total * 1.2) + 1024)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (neighbour list)");
   }
-  hipLaunchKernelGGL(k_neighbors<true>, grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
+  hipLaunchKernelGGL(k_neighbors<true>, grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
                      (unsigned*)nullptr, c->d_nbr_start.p, c->d_nbr.p);
   HIPCHK(hipGetLastError());
   phase_end(c, PH_VERLET);

@@ -30,7 +30,10 @@ __global__ __launch_bounds__(256) void k_pair(int N, const double4* __restrict__
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   double e_el = 0.0, e_vdw = 0.0;
-  for (int i = blockIdx.x * wpb + wave; i < N; i += gridDim.x * wpb) {
+  // contiguous chunk of sorted atoms per block, blocks in XCD-aware order (neighbourhoods of one slab stay in one L2)
+  const int per_block = (N + gridDim.x - 1) / gridDim.x;
+  const int i0 = xcd_block(blockIdx.x, gridDim.x) * per_block, i1 = min(N, i0 + per_block);
+  for (int i = i0 + wave; i < i1; i += wpb) {
     const double4 pi = posq[i];
     const int ti = type_s[i];
     const unsigned s = nbr_start[i], e = nbr_start[i + 1];
@@ -38,9 +41,9 @@ __global__ __launch_bounds__(256) void k_pair(int N, const double4* __restrict__
     // two list entries per lane and trip: both index loads, then both {x,y,z,q} gathers are in flight before the arithmetic
     for (unsigned k = s + lane; k < e; k += 128) {
       const bool two = (k + 64) < e;
-      const int j0 = nbr[k], j1 = two ? nbr[k + 64] : j0;
-      const double4 pa = posq[j0], pb = posq[j1];
-      const int ta = type_s[j0], tb = type_s[j1];
+      const unsigned e0 = (unsigned)nbr[k], e1 = two ? (unsigned)nbr[k + 64] : e0;
+      const double4 pa = posq[e0 & NBR_IDX_MASK], pb = posq[e1 & NBR_IDX_MASK];
+      const int ta = (int)(e0 >> NBR_IDX_BITS), tb = (int)(e1 >> NBR_IDX_BITS);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const double4 pj = h ? pb : pa;
@@ -83,7 +86,7 @@ int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw) {
   if (!c->list_valid) FAIL(MSEVB_ERR_STATE, "pair_forces: no Verlet list (call msevb_construct_verlet_list)");
   BoxDev box;
   for (int d = 0; d < 3; ++d) { box.L[d] = c->box[d]; box.invL[d] = 1.0 / c->box[d]; }
-  int nblocks = (N + 3) / 4;
+  int nblocks = round_up8((N + 7) / 8);      // 8 atoms per block, two per wave
   if (nblocks > 16384) nblocks = 16384;
   phase_begin(c, PH_PAIR);
   // force fields without a live SAPT term (every Buckingham coefficient zero, as in the CH3SO3H/H2O example) run the lean instantiation

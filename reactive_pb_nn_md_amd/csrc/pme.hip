@@ -11,35 +11,34 @@
 
 namespace {
 
-// index arithmetic must round exactly like the reference: no FMA contraction in this function
-__global__ void k_pme_prep(int N, int K, int G, const double* __restrict__ xyz, const double* __restrict__ chg, double k00, double k01,
+// index arithmetic must round exactly like the reference: no FMA contraction in this function.
+// One thread per (atom, axis, tap): t = (3 i + l) 6 + k is also the element index of w / dw / splindex, so every store is
+// coalesced (the thread-per-atom version wrote 36 doubles at a 288-B stride and cost 8x its bytes in HBM write traffic).
+// splindex (the B6 table rows, kept for msevb_get_pme_indices) is only written when asked for.
+__global__ __launch_bounds__(256) void k_pme_prep(int N, int K, int G, const double* __restrict__ xyz, double k00, double k01,
                            double k02, double k10, double k11, double k12, double k20, double k21, double k22,
                            const double* __restrict__ B6, const double* __restrict__ B5, double* __restrict__ uscale, int* __restrict__ base,
                            int* __restrict__ splindex, double* __restrict__ w, double* __restrict__ dw) {
 #pragma clang fp contract(off)
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 18 * N) return;
+  const int i = t / 18, r = t - 18 * i, l = r / 6, k = r - 6 * l;
   const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-  const double kk[3][3] = {{k00, k01, k02}, {k10, k11, k12}, {k20, k21, k22}};
-  for (int l = 0; l < 3; ++l) {
-    double u = (double)K * ((kk[l][0] * x + kk[l][1] * y) + kk[l][2] * z);
-    if (u < 0.0) u = u + (double)K; else if (u >= (double)K) u = u - (double)K;
-    if (fabs(fmod(u, 1.0)) < 1e-6) u = u + 1e-6;
-    uscale[3 * i + l] = u;
-    const int np = (int)floor(u);
-    base[3 * i + l] = np;
-    for (int k = 0; k < 6; ++k) {
-      const int n = np - k;
-      const double a1 = u - (double)n, a2 = a1 - 1.0;
-      const int g6 = (int)ceil(a1 / 6.0 * (double)G);
-      splindex[(3 * i + l) * 6 + k] = g6;
-      w[(3 * i + l) * 6 + k] = B6[g6 - 1];
-      double d = 0.0;
-      if (a1 < 5.0) d = B5[(int)ceil(a1 / 5.0 * (double)G) - 1];
-      if (0.0 < a2) d = d - B5[(int)ceil(a2 / 5.0 * (double)G) - 1];
-      dw[(3 * i + l) * 6 + k] = d;
-    }
-  }
+  const double ka = l == 0 ? k00 : l == 1 ? k10 : k20, kb = l == 0 ? k01 : l == 1 ? k11 : k21, kc = l == 0 ? k02 : l == 1 ? k12 : k22;
+  double u = (double)K * ((ka * x + kb * y) + kc * z);
+  if (u < 0.0) u = u + (double)K; else if (u >= (double)K) u = u - (double)K;
+  if (fabs(fmod(u, 1.0)) < 1e-6) u = u + 1e-6;
+  const int np = (int)floor(u);
+  if (k == 0) { uscale[3 * i + l] = u; base[3 * i + l] = np; }
+  const int n = np - k;
+  const double a1 = u - (double)n, a2 = a1 - 1.0;
+  const int g6 = (int)ceil(a1 / 6.0 * (double)G);
+  if (splindex) splindex[t] = g6;
+  w[t] = B6[g6 - 1];
+  double d = 0.0;
+  if (a1 < 5.0) d = B5[(int)ceil(a1 / 5.0 * (double)G) - 1];
+  if (0.0 < a2) d = d - B5[(int)ceil(a2 / 5.0 * (double)G) - 1];
+  dw[t] = d;
 }
 
 // one thread per (atom, k3, k2); the 6 k1 taps are consecutive grid points (modulo wrap)
@@ -260,11 +259,12 @@ int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part
   return MSEVB_OK;
 }
 
-int pme_prepare_atoms(msevb_ctx* c) {
+int pme_prepare_atoms(msevb_ctx* c, bool with_indices) {
   const int N = c->N;
-  hipLaunchKernelGGL(k_pme_prep, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, c->K, c->spline_grid, c->d_xyz.p, c->d_chg.p, c->kk[0][0], c->kk[0][1],
+  const long nt = 18L * N;
+  hipLaunchKernelGGL(k_pme_prep, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, N, c->K, c->spline_grid, c->d_xyz.p, c->kk[0][0], c->kk[0][1],
                      c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, c->d_uscale.p,
-                     c->d_base.p, c->d_splindex.p, c->d_w.p, c->d_dw.p);
+                     c->d_base.p, with_indices ? c->d_splindex.p : (int*)nullptr, c->d_w.p, c->d_dw.p);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
 }
@@ -283,7 +283,7 @@ int pme_forces(msevb_ctx* c, int slot_recip) {
   const int N = c->N, K = c->K;
   const size_t K3 = (size_t)K * K * K;
   phase_begin(c, PH_SPREAD);
-  CHK(pme_prepare_atoms(c));
+  CHK(pme_prepare_atoms(c, false));
   HIPCHK(hipMemsetAsync(c->d_grid.p, 0, K3 * sizeof(double2), c->stream));
   {
     int3 T;

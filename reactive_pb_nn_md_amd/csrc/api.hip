@@ -71,6 +71,9 @@ int msevb_create(msevb_ctx** out, int device_id) {
   HIPCHK(hipSetDevice(device_id));
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->own_stream = true;
+  HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   HIPCHK(hipHostMalloc((void**)&c->h_energies, N_SLOTS * sizeof(double), hipHostMallocDefault));
   memset(c->h_energies, 0, N_SLOTS * sizeof(double));
   const char* names[PH_COUNT] = {"verlet list construction", "sorted atom refresh", "real space (pair loop)", "intra-molecular (non-bonded + bonded)",
@@ -85,6 +88,9 @@ int msevb_destroy(msevb_ctx* c) {
   if (!c) return MSEVB_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); c->aux = nullptr; }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   pme_teardown(c);
   DBuf<int>* ib[] = {&c->d_atype, &c->d_mol_type, &c->d_mol_natom, &c->d_mol_atoms, &c->d_mol_of, &c->d_cell_of, &c->d_perm, &c->d_cell_keys_tmp,
                      &c->d_perm_tmp, &c->d_cell_start, &c->d_inv_perm, &c->d_nbr, &c->d_type_sorted, &c->d_mol_sorted, &c->d_base, &c->d_splindex};
@@ -428,9 +434,16 @@ int total_force_enqueue(msevb_ctx* c) {
   if (c->flag_verlet_list == 1 || !c->list_valid) { CHK(nb_build(c)); c->flag_verlet_list = 0; }
   else { CHK(nb_check_displacements(c, 0, nullptr)); CHK(nb_refresh_sorted(c)); }
   HIPCHK(hipMemsetAsync(c->d_force.p, 0, 3 * (size_t)c->N * 8, c->stream));
-  CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
-  CHK(molecule_forces(c, S_ELEC_INTRA, true, true));
-  CHK(pme_forces(c, S_RECIP));
+  if (c->overlap) {     // per-molecule terms (few, long threads) on the side stream beside the pair loop and the charge spreading
+    HIPCHK(aux_fork(c));
+    CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux));
+    CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
+    CHK(pme_forces(c, S_RECIP, true));
+  } else {
+    CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
+    CHK(molecule_forces(c, S_ELEC_INTRA, true, true));
+    CHK(pme_forces(c, S_RECIP, false));
+  }
   return MSEVB_OK;
 }
 void total_force_collect(msevb_ctx* c, double* en) {
@@ -507,6 +520,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "phase_timing") { c->timing = v != 0.0; return MSEVB_OK; }
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
+  if (s == "overlap") { c->overlap = v != 0.0; return MSEVB_OK; }
   c->err = "unknown option " + s;
   return MSEVB_ERR_ARG;
 }

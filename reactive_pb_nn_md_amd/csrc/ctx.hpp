@@ -111,6 +111,11 @@ struct msevb_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // internal side stream for small latency-bound kernels that are independent of the main chain (per-molecule terms next to
+  // the pair loop / charge spreading, off-diagonal EVB elements next to the diabat reciprocal space); fork/join by events
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap = true;
   bool finalized = false;
 
   // ---- configuration
@@ -205,8 +210,8 @@ int nb_build(msevb_ctx* c);                        // neighbor.hip
 int nb_refresh_sorted(msevb_ctx* c);               // gather posq/type in sorted order
 int nb_check_displacements(msevb_ctx* c, int initialize, int* flag);
 int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw);              // pair.hip
-int molecule_forces(msevb_ctx* c, int slot0, bool do_nb, bool do_bonded);  // molecule.hip
-int pme_forces(msevb_ctx* c, int slot_recip);                           // pme.hip
+int molecule_forces(msevb_ctx* c, int slot0, bool do_nb, bool do_bonded, hipStream_t st = nullptr);  // molecule.hip
+int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux = false);                           // pme.hip
 int pme_setup(msevb_ctx* c);
 void pme_teardown(msevb_ctx* c);
 int reduce_partials(msevb_ctx* c, int slot, int nblocks);                // deferred: one fused launch in flush_reductions
@@ -233,21 +238,26 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
 constexpr int MAX_BLOCKS = 65536;
 enum Slot { S_ELEC_PAIR = 0, S_VDW_PAIR, S_ELEC_INTRA, S_VDW_INTRA, S_BOND, S_ANGLE, S_DIH, S_RECIP, S_KE, S_PX, S_PY, S_PZ, S_MAXD1, S_MAXD2, S_EVB0, N_SLOTS = 32 };
 
-inline void phase_begin(msevb_ctx* c, int p) {
+inline void phase_begin(msevb_ctx* c, int p, hipStream_t st = nullptr) {
   if (!c->timing) return;
+  if (!st) st = c->stream;
   PhaseTimer& t = c->ph[p];
   if (t.used + 2 > 16384) return;   // pool exhausted: stop sampling until the next harvest
   if (t.used + 2 > t.ev.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); t.ev.push_back(a); t.ev.push_back(b); }
-  (void)hipEventRecord(t.ev[t.used], c->stream);
+  (void)hipEventRecord(t.ev[t.used], st);
   t.used += 1;
 }
-inline void phase_end(msevb_ctx* c, int p) {
+inline void phase_end(msevb_ctx* c, int p, hipStream_t st = nullptr) {
   if (!c->timing) return;
+  if (!st) st = c->stream;
   PhaseTimer& t = c->ph[p];
   if ((t.used & 1) == 0) return;
-  (void)hipEventRecord(t.ev[t.used], c->stream);
+  (void)hipEventRecord(t.ev[t.used], st);
   t.used += 1;
 }
+// fork: the side stream starts after everything enqueued so far on the main stream; join: the main stream waits for it
+inline hipError_t aux_fork(msevb_ctx* c) { hipError_t e = hipEventRecord(c->ev_fork, c->stream); return e != hipSuccess ? e : hipStreamWaitEvent(c->aux, c->ev_fork, 0); }
+inline hipError_t aux_join(msevb_ctx* c) { hipError_t e = hipEventRecord(c->ev_join, c->aux); return e != hipSuccess ? e : hipStreamWaitEvent(c->stream, c->ev_join, 0); }
 inline void phase_harvest(msevb_ctx* c) {
   for (int p = 0; p < PH_COUNT; ++p) {
     PhaseTimer& t = c->ph[p];

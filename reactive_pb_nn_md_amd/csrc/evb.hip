@@ -416,8 +416,9 @@ __global__ __launch_bounds__(256) void k_evb_recip_special(int n, const RecipAto
 
 // ---- off-diagonal element -------------------------------------------------------------------------------------------------
 // exchange-charge Coulomb sum over all NON-special molecules (evb_diabatic_coupling_electrostatics, src/ms_evb.f90:1276):
-// one thread per molecule (minimum image is taken per molecule, relative to the Zundel centre of mass).
-__global__ __launch_bounds__(256) void k_evb_coupling(int M, int n_cp, const CouplingDesc* __restrict__ cps, const int* __restrict__ mol_natom,
+// one thread per atom (coalesced dVex stores); the minimum image is taken per molecule, relative to the Zundel centre of mass,
+// so every thread re-derives the centre of mass of its (<= 8 atom) molecule.
+__global__ __launch_bounds__(256) void k_evb_coupling(int N, int n_cp, const CouplingDesc* __restrict__ cps, const int* __restrict__ mol_of, const int* __restrict__ mol_natom,
                                                       const int* __restrict__ mol_atoms, const double* __restrict__ xyz, const double* __restrict__ chg,
                                                       const double* __restrict__ mass, const int* __restrict__ atype, const double* __restrict__ exch_atomic,
                                                       BoxDev box, double conv, double* __restrict__ Foff, size_t fstride, double* __restrict__ part,
@@ -437,7 +438,8 @@ __global__ __launch_bounds__(256) void k_evb_coupling(int M, int n_cp, const Cou
   double fz[2 * MAX_MOL_ATOMS][3];
 #pragma unroll
   for (int a = 0; a < 2 * MAX_MOL_ATOMS; ++a) fz[a][0] = fz[a][1] = fz[a][2] = 0.0;
-  for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+    const int m = mol_of[j];
     bool special = false;
     for (int k = 0; k < cp.n_mols; ++k) special |= (cp.mols[k] == m);
     if (special) continue;
@@ -446,27 +448,24 @@ __global__ __launch_bounds__(256) void k_evb_coupling(int M, int n_cp, const Cou
     for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; const double ma = mass[a]; for (int d = 0; d < 3; ++d) com[d] += xyz[3 * a + d] * ma; mt += ma; }
     double sh[3];
     for (int d = 0; d < 3; ++d) { com[d] /= mt; sh[d] = floor((com[d] - cp.zc[d]) * box.invL[d] + 0.5) * box.L[d]; }
-    for (int k = 0; k < n; ++k) {
-      const int j = mol_atoms[m * MAX_MOL_ATOMS + k];
-      const double qj = chg[j];
-      double fj[3] = {0, 0, 0};
-      for (int side = 0; side < 2; ++side) {
-        const int na = side == 0 ? cp.nD : cp.nA;
-        const int* lst = side == 0 ? cp.D_at : cp.A_at;
-        const double* shm = side == 0 ? cp.shiftd : cp.shifta;
-        for (int q = 0; q < na; ++q) {
-          const SpecAtom& a = cp.spec[lst[q]];
-          const double qi = (side == 1 && q == na - 1) ? cp.q_transfer : exch_atomic[a.type];
-          double rij[3];
-          for (int d = 0; d < 3; ++d) { const double xz = cp.zc[d] + (a.x[d] - cp.zc[d] - shm[d]); rij[d] = -(xyz[3 * j + d] - xz - sh[d]); }
-          const double r2 = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2], r = sqrt(r2);
-          vex += qi * qj / r * conv;
-          const double g = -qi * qj / (r2 * r) * conv;
-          for (int d = 0; d < 3; ++d) { fj[d] -= g * rij[d]; fz[side * cp.nD + q][d] += g * rij[d]; }
-        }
+    const double qj = chg[j];
+    double fj[3] = {0, 0, 0};
+    for (int side = 0; side < 2; ++side) {
+      const int na = side == 0 ? cp.nD : cp.nA;
+      const int* lst = side == 0 ? cp.D_at : cp.A_at;
+      const double* shm = side == 0 ? cp.shiftd : cp.shifta;
+      for (int q = 0; q < na; ++q) {
+        const SpecAtom& a = cp.spec[lst[q]];
+        const double qi = (side == 1 && q == na - 1) ? cp.q_transfer : exch_atomic[a.type];
+        double rij[3];
+        for (int d = 0; d < 3; ++d) { const double xz = cp.zc[d] + (a.x[d] - cp.zc[d] - shm[d]); rij[d] = -(xyz[3 * j + d] - xz - sh[d]); }
+        const double r2 = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2], r = sqrt(r2);
+        vex += qi * qj / r * conv;
+        const double g = -qi * qj / (r2 * r) * conv;
+        for (int d = 0; d < 3; ++d) { fj[d] -= g * rij[d]; fz[side * cp.nD + q][d] += g * rij[d]; }
       }
-      for (int d = 0; d < 3; ++d) F[3 * j + d] = fj[d];    // dVex of this atom; scaled by -A in k_evb_coupling_finish
     }
+    for (int d = 0; d < 3; ++d) F[3 * j + d] = fj[d];    // dVex of this atom; scaled by -A in k_evb_coupling_finish
   }
   // forces on the Zundel atoms: per-thread registers -> wave shuffle -> one LDS add per wave
   for (int a = 0; a < cp.nD + cp.nA; ++a) for (int d = 0; d < 3; ++d) {
@@ -955,7 +954,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   }
   const int nu = (int)units.size(), ncp = (int)cps.size(), nra = (int)ras.size();
   // ---- 5. device buffers
-  const int envb = std::min(64, (N + 255) / 256), cpb = std::min(256, (M + 255) / 256), convb = 1024;
+  const int envb = std::min(64, (N + 255) / 256), cpb = std::min(512, (N + 255) / 256), convb = 1024;
   const int part_stride = 1024;
   const int n_rows = nu + ncp + ngrid + 8;
   if (c->d_Fdiag.alloc((size_t)n_diag * n3) || c->d_Foff.alloc((size_t)std::max(n_off, 1) * n3) || w->d_units.alloc(nu) || w->d_cps.alloc(std::max(ncp, 1)) ||
@@ -996,6 +995,19 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   HIPCHK(hipMemcpyAsync(c->d_Fdiag.p, c->d_force.p, n3 * 8, hipMemcpyDeviceToDevice, c->stream));
   if (n_off) HIPCHK(hipMemsetAsync(c->d_Foff.p, 0, (size_t)n_off * n3 * 8, c->stream));
   if (n_off && c->n_ranks > 1) HIPCHK(hipMemsetAsync(c->d_Fdiag.p + n3, 0, (size_t)n_off * n3 * 8, c->stream));
+  // ---- 5b. off-diagonal elements (evb_diabatic_coupling, :1021)
+  if (ncp) {
+    hipStream_t so = c->overlap ? c->aux : c->stream;
+    if (c->overlap) HIPCHK(aux_fork(c));
+    HIPCHK(hipMemsetAsync(w->d_dVspec.p, 0, (size_t)ncp * MAX_SPEC * 3 * 8, so));
+    hipLaunchKernelGGL(k_evb_coupling, dim3(cpb, ncp), dim3(256), 0, so, N, ncp, w->d_cps.p, c->d_mol_of.p, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_chg.p,
+                       c->d_mass.p, c->d_atype.p, w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p);
+    hipLaunchKernelGGL(k_sum_rows, dim3(ncp), dim3(256), 0, so, ncp, cpb, part_stride, part_cp, E_cp_env);
+    hipLaunchKernelGGL(k_evb_coupling_finish, dim3(ncp), dim3(64), 0, so, ncp, w->d_cps.p, w->d_exch.p, c->d_mass.p, box, c->conv, E_cp_env,
+                       w->d_dVspec.p, c->d_Foff.p, n3, w->d_cpout.p);
+    hipLaunchKernelGGL(k_evb_scale, dim3(256, ncp), dim3(256), 0, so, n3, ncp, w->d_cps.p, w->d_cpout.p, c->d_Foff.p, n3);
+    HIPCHK(hipGetLastError());
+  }
   // ---- 6. reciprocal space of the owned diabats (calculate_reciprocal_space_pme, :1962)
   phase_begin(c, PH_EVB_RECIP);
   if (ngrid) {
@@ -1048,18 +1060,11 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   hipLaunchKernelGGL(k_evb_special, dim3(nu), dim3(64), 0, c->stream, nu, w->d_units.p, w->d_tabs.p, c->d_moltypes.p, c->d_pair_par.p, c->nt,
                      c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->alpha, 2.0 * c->alpha / c->pi_sqrt, c->conv, c->pi,
                      c->d_Fdiag.p, n3, E_units_spec);
-  // ---- 8. off-diagonal elements
-  if (ncp) {
-    HIPCHK(hipMemsetAsync(w->d_dVspec.p, 0, (size_t)ncp * MAX_SPEC * 3 * 8, c->stream));
-    hipLaunchKernelGGL(k_evb_coupling, dim3(cpb, ncp), dim3(256), 0, c->stream, M, ncp, w->d_cps.p, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_chg.p,
-                       c->d_mass.p, c->d_atype.p, w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p);
-    hipLaunchKernelGGL(k_sum_rows, dim3(ncp), dim3(256), 0, c->stream, ncp, cpb, part_stride, part_cp, E_cp_env);
-    hipLaunchKernelGGL(k_evb_coupling_finish, dim3(ncp), dim3(64), 0, c->stream, ncp, w->d_cps.p, w->d_exch.p, c->d_mass.p, box, c->conv, E_cp_env,
-                       w->d_dVspec.p, c->d_Foff.p, n3, w->d_cpout.p);
-    hipLaunchKernelGGL(k_evb_scale, dim3(256, ncp), dim3(256), 0, c->stream, n3, ncp, w->d_cps.p, w->d_cpout.p, c->d_Foff.p, n3);
-  }
+  // ---- 8. off-diagonal elements: few, latency-bound kernels writing only d_Foff -> side stream, beside the reciprocal space
+  //         and the diagonal real-space deltas (forked in step 5b, joined here)
   HIPCHK(hipGetLastError());
   phase_end(c, PH_EVB_REAL);
+  if (ncp && c->overlap) HIPCHK(aux_join(c));
   // ---- 9. energies to the host, Hamiltonian
   w->h_E.resize(2 * nu + ncp + ngrid + 3 * std::max(ncp, 1));
   HIPCHK(hipMemcpyAsync(w->h_E.data(), w->d_E.p, (2 * nu + ncp + ngrid) * 8, hipMemcpyDeviceToHost, c->stream));

@@ -1,7 +1,7 @@
 // Per-molecule terms: bonded (bond / angle / dihedral; replaces intra_molecular_energy_force,
 // src/intra_bonded_interactions.f90:17-552) and intra-molecular non-bonded with exclusions (replaces
 // intra_molecular_pairwise_energy_force, src/pair_int_real_space.f90:386-588, and intra_pme_exclusion :781).
-// One thread per molecule: molecules own disjoint atoms, so forces are written without atomics; all parameters of a
+// One thread per molecule (forces are added with fp64 atomics because the kernel may overlap the pair loop); all parameters of a
 // molecule type are pre-resolved into one MolTypeDev record (L2 / scalar-cache resident, <= 10 types).
 #include "ctx.hpp"
 #include "devmath.hpp"
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_molecules(int M, const int* __restrict_
     }
     if (do_nb && n > 1) molecule_nonbonded(mt, n, x, q, f, etab, inv_dx, tt, dtt, rc2, alpha, erf_factor, conv, e[0], e[1]);
     if (do_bonded) molecule_bonded(mt, x, f, pi_ref, e[2], e[3], e[4]);
-    for (int k = 0; k < n; ++k) for (int d = 0; d < 3; ++d) F[3 * idx[k] + d] += f[k][d];
+    for (int k = 0; k < n; ++k) for (int d = 0; d < 3; ++d) atomicAdd(&F[3 * idx[k] + d], f[k][d]);   // may run beside the pair loop
   }
   for (int s = 0; s < 5; ++s) red[s][threadIdx.x] = e[s];
   __syncthreads();
@@ -45,14 +45,15 @@ __global__ __launch_bounds__(256) void k_molecules(int M, const int* __restrict_
 }  // namespace
 
 // slots slot0..slot0+4 = E_elec(intra), E_vdw(intra), E_bond, E_angle, E_dihedral
-int molecule_forces(msevb_ctx* c, int slot0, bool do_nb, bool do_bonded) {
+int molecule_forces(msevb_ctx* c, int slot0, bool do_nb, bool do_bonded, hipStream_t st) {
   const int M = c->M, nb = (M + 255) / 256;
-  phase_begin(c, PH_MOLECULE);
-  hipLaunchKernelGGL(k_molecules, dim3(nb), dim3(256), 0, c->stream, M, c->d_mol_type.p, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_moltypes.p,
+  if (!st) st = c->stream;
+  phase_begin(c, PH_MOLECULE, st);
+  hipLaunchKernelGGL(k_molecules, dim3(nb), dim3(256), 0, st, M, c->d_mol_type.p, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_moltypes.p,
                      c->d_xyz.p, c->d_chg.p, c->d_force.p, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, c->rc * c->rc, c->alpha,
                      2.0 * c->alpha / c->pi_sqrt, c->conv, c->pi, do_nb ? 1 : 0, do_bonded ? 1 : 0, c->d_partials.p, slot0);
   HIPCHK(hipGetLastError());
-  phase_end(c, PH_MOLECULE);
+  phase_end(c, PH_MOLECULE, st);
   for (int s = 0; s < 5; ++s) CHK(reduce_partials(c, slot0 + s, nb));
   return MSEVB_OK;
 }

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_pair(int N, const double4* __restrict__
     fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
     if (lane == 0) {
       const int o = perm[i];
-      F[3 * o] += fx; F[3 * o + 1] += fy; F[3 * o + 2] += fz;
+      atomicAdd(&F[3 * o], fx); atomicAdd(&F[3 * o + 1], fy); atomicAdd(&F[3 * o + 2], fz);   // the per-molecule kernel may run concurrently
     }
   }
   e_el = wave_sum(e_el);

@@ -279,7 +279,7 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
   return MSEVB_OK;
 }
 
-int pme_forces(msevb_ctx* c, int slot_recip) {
+int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux) {
   const int N = c->N, K = c->K;
   const size_t K3 = (size_t)K * K * K;
   phase_begin(c, PH_SPREAD);
@@ -308,6 +308,7 @@ int pme_forces(msevb_ctx* c, int slot_recip) {
   CHK(pme_convolve(c, c->d_grid.p, 1, c->d_partials.p + (size_t)slot_recip * MAX_BLOCKS, MAX_BLOCKS, &nbk));
   CHK(reduce_partials(c, slot_recip, nbk));
   phase_end(c, PH_FFT);
+  if (join_aux) HIPCHK(aux_join(c));       // the gather adds to the total force without atomics: the side stream must be done
   phase_begin(c, PH_GATHER);
   CHK(pme_gather(c, c->d_grid.p, c->d_chg.p, c->d_force_recip.p, c->d_force.p));
   phase_end(c, PH_GATHER);

@@ -507,7 +507,7 @@ __device__ __forceinline__ void coupling_function(int ftype, const double* p, co
 // one thread per coupling: special-molecule part of Vex (molecules of the chain that are neither donor nor acceptor),
 // geometric factor, element energy; writes {A, Vc+Vex, H_pd} and the forces of the special atoms
 __global__ void k_evb_coupling_finish(int n_cp, const CouplingDesc* __restrict__ cps, const double* __restrict__ exch_atomic, const double* __restrict__ mass,
-                                      BoxDev box, double conv, const double* __restrict__ Vex_env, const double* __restrict__ dVspec,
+                                      BoxDev box, double conv, const double* __restrict__ Vex_env, double* __restrict__ dVspec,
                                       double* __restrict__ Foff, size_t fstride, double* __restrict__ out /*[n_cp][3]*/) {
   const int ic = blockIdx.x;
   if (ic >= n_cp || threadIdx.x != 0) return;
@@ -515,7 +515,7 @@ __global__ void k_evb_coupling_finish(int n_cp, const CouplingDesc* __restrict__
   double vex = Vex_env[ic];
   __shared__ double dV[MAX_SPEC][3];
   __shared__ bool inDA[MAX_SPEC];
-  for (int k = 0; k < cp.n_spec; ++k) for (int d = 0; d < 3; ++d) dV[k][d] = dVspec[(size_t)ic * MAX_SPEC * 3 + 3 * k + d];
+  for (int k = 0; k < cp.n_spec; ++k) for (int d = 0; d < 3; ++d) { dV[k][d] = dVspec[(size_t)ic * MAX_SPEC * 3 + 3 * k + d]; dVspec[(size_t)ic * MAX_SPEC * 3 + 3 * k + d] = 0.0; }
   for (int k = 0; k < cp.n_spec; ++k) inDA[k] = false;
   for (int k = 0; k < cp.nD; ++k) inDA[cp.D_at[k]] = true;
   for (int k = 0; k < cp.nA; ++k) inDA[cp.A_at[k]] = true;
@@ -570,11 +570,11 @@ __global__ void k_evb_scale(size_t n3, int n_cp, const CouplingDesc* __restrict_
 }
 
 // Hellmann-Feynman blend: F = sum_d c_d^2 F_dd + 2 sum_(p,d) c_p c_d F_pd (src/ms_evb.f90:293-309)
-__global__ void k_evb_blend(size_t n3, int nterm, const int* __restrict__ slots, const int* __restrict__ isoff, const double* __restrict__ coef,
-                            const double* __restrict__ Fdiag, const double* __restrict__ Foff, size_t fstride, double* __restrict__ F) {
+struct BlendTerms { int n; int slot[2 * MAX_DIABATS]; double coef[2 * MAX_DIABATS]; };   // slot < 0: off-diagonal store, index -slot-1 (kernel argument, no upload)
+__global__ void k_evb_blend(size_t n3, BlendTerms bt, const double* __restrict__ Fdiag, const double* __restrict__ Foff, size_t fstride, double* __restrict__ F) {
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (size_t)gridDim.x * blockDim.x) {
     double s = 0.0;
-    for (int t = 0; t < nterm; ++t) s += coef[t] * (isoff[t] ? Foff : Fdiag)[(size_t)slots[t] * fstride + k];
+    for (int t = 0; t < bt.n; ++t) { const int sl = bt.slot[t]; s += bt.coef[t] * (sl < 0 ? Foff[(size_t)(-sl - 1) * fstride + k] : Fdiag[(size_t)sl * fstride + k]); }
     F[k] = s;
   }
 }
@@ -625,19 +625,19 @@ struct HTopo {   // the molecules touched so far by a hop chain, in the topology
 };
 
 struct EvbWork {   // persistent device scratch of one context
-  DBuf<UnitDesc> d_units; DBuf<CouplingDesc> d_cps; DBuf<RecipAtom> d_ra; DBuf<EvbTablesDev> d_tabs; DBuf<double> d_exch;
-  DBuf<double> d_part, d_E, d_dVspec, d_cpout, d_coef; DBuf<int> d_slots, d_isoff, d_sbase, d_counter; DBuf<double> d_sw, d_sdw;
+  DBuf<EvbTablesDev> d_tabs; DBuf<double> d_exch;
+  DBuf<double> d_part, d_E, d_dVspec; DBuf<int> d_sbase, d_counter; DBuf<double> d_sw, d_sdw;
   DBuf<double2> d_grids; DBuf<RegionRec> d_region; DBuf<int> d_cand;
   DBuf<double> d_F11, d_pack;
   hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
   RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
-  UnitDesc* h_units = nullptr; CouplingDesc* h_cps = nullptr; RecipAtom* h_ras = nullptr;   // pinned staging
+  char* h_desc = nullptr; DBuf<char> d_desc; size_t desc_cap = 0;   // units | couplings | recip atoms, one pinned block -> one upload
+  double* h_E = nullptr; size_t hE_cap = 0;                         // pinned
   int grids_cap = 0;
   bool tabs_uploaded = false;
   double screen_r = 0.0;
-  bool counters_dirty = true;
+  bool counters_dirty = true, dv_dirty = true;
   std::vector<RegionRec> region;
-  std::vector<double> h_E;
 };
 std::map<msevb_ctx*, EvbWork*> g_work;
 
@@ -820,16 +820,13 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipEventCreateWithFlags(&w->ev_region, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&w->h_region, REGION_FAST * sizeof(RegionRec), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&w->h_count, 64, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&w->h_units, MAX_UNITS * sizeof(UnitDesc), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&w->h_cps, MAX_DIABATS * sizeof(CouplingDesc), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&w->h_ras, MAX_DIABATS * MAX_SPEC * sizeof(RecipAtom), hipHostMallocDefault));
   }
   if (w->d_region.alloc(REGION_CAP) || w->d_counter.alloc(4) || w->d_cand.alloc(N)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB region)");
   if (w->counters_dirty) {     // first call, or the previous call failed half-way: afterwards the two kernels re-arm each other's counter
     HIPCHK(hipMemsetAsync(w->d_counter.p, 0, 4 * sizeof(int), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
-  struct Rearm { EvbWork* w; bool ok; ~Rearm() { w->counters_dirty = !ok; } } rearm{w, false};
+  struct Rearm { EvbWork* w; bool ok; ~Rearm() { w->counters_dirty = !ok; if (!ok) w->dv_dirty = true; } } rearm{w, false};
   const double Rreg = 5.0 * c->max_chain + 5.0;
   HIPCHK(hipEventRecord(w->ev_in, c->stream));
   HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_in, 0));
@@ -957,11 +954,11 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   const int envb = std::min(64, (N + 255) / 256), cpb = std::min(512, (N + 255) / 256), convb = 1024;
   const int part_stride = 1024;
   const int n_rows = nu + ncp + ngrid + 8;
-  if (c->d_Fdiag.alloc((size_t)n_diag * n3) || c->d_Foff.alloc((size_t)std::max(n_off, 1) * n3) || w->d_units.alloc(nu) || w->d_cps.alloc(std::max(ncp, 1)) ||
-      w->d_ra.alloc(std::max(nra, 1)) || w->d_tabs.alloc(1) || w->d_exch.alloc(MAX_TYPES) || w->d_part.alloc((size_t)n_rows * part_stride) ||
-      w->d_E.alloc(2 * n_rows + 3 * std::max(ncp, 1)) || w->d_dVspec.alloc((size_t)std::max(ncp, 1) * MAX_SPEC * 3) || w->d_cpout.alloc(3 * std::max(ncp, 1)) ||
+  if (c->d_Fdiag.alloc((size_t)n_diag * n3) || c->d_Foff.alloc((size_t)std::max(n_off, 1) * n3) || 
+      w->d_tabs.alloc(1) || w->d_exch.alloc(MAX_TYPES) || w->d_part.alloc((size_t)n_rows * part_stride) ||
+      w->d_E.alloc(2 * n_rows + 3 * std::max(ncp, 1) + 8) || w->d_dVspec.alloc((size_t)MAX_DIABATS * MAX_SPEC * 3) ||
       w->d_sbase.alloc(3 * std::max(nra, 1)) || w->d_sw.alloc(18 * (size_t)std::max(nra, 1)) || w->d_sdw.alloc(18 * (size_t)std::max(nra, 1)) ||
-      w->d_grids.alloc(K3 * std::max(ngrid, 1)) || w->d_pack.alloc(K3 * std::max(ngrid, 1)) || w->d_coef.alloc(4 * MAX_DIABATS) || w->d_slots.alloc(4 * MAX_DIABATS) || w->d_isoff.alloc(4 * MAX_DIABATS))
+      w->d_grids.alloc(K3 * std::max(ngrid, 1)) || w->d_pack.alloc(K3 * std::max(ngrid, 1)))
     FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB work buffers)");
   c->evb_cap = D;
   if (!w->tabs_uploaded) {
@@ -980,10 +977,21 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     w->tabs_uploaded = true;
   }
   if (nu > MAX_UNITS || ncp > MAX_DIABATS || nra > MAX_DIABATS * MAX_SPEC) FAIL(MSEVB_ERR_LIMIT, "EVB descriptor staging too small");
-  memcpy(w->h_units, units.data(), nu * sizeof(UnitDesc));
-  HIPCHK(hipMemcpyAsync(w->d_units.p, w->h_units, nu * sizeof(UnitDesc), hipMemcpyHostToDevice, c->stream));
-  if (ncp) { memcpy(w->h_cps, cps.data(), ncp * sizeof(CouplingDesc)); HIPCHK(hipMemcpyAsync(w->d_cps.p, w->h_cps, ncp * sizeof(CouplingDesc), hipMemcpyHostToDevice, c->stream)); }
-  if (nra) { memcpy(w->h_ras, ras.data(), nra * sizeof(RecipAtom)); HIPCHK(hipMemcpyAsync(w->d_ra.p, w->h_ras, nra * sizeof(RecipAtom), hipMemcpyHostToDevice, c->stream)); }
+  const size_t off_u = 0, off_c = off_u + (size_t)nu * sizeof(UnitDesc), off_r = off_c + (size_t)ncp * sizeof(CouplingDesc), desc_bytes = off_r + (size_t)nra * sizeof(RecipAtom);
+  if (desc_bytes > w->desc_cap) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (w->h_desc) HIPCHK(hipHostFree(w->h_desc));
+    w->desc_cap = desc_bytes + desc_bytes / 2 + 4096;
+    HIPCHK(hipHostMalloc((void**)&w->h_desc, w->desc_cap, hipHostMallocDefault));
+    if (w->d_desc.alloc(w->desc_cap)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB descriptors)");
+  }
+  memcpy(w->h_desc + off_u, units.data(), (size_t)nu * sizeof(UnitDesc));
+  if (ncp) memcpy(w->h_desc + off_c, cps.data(), (size_t)ncp * sizeof(CouplingDesc));
+  if (nra) memcpy(w->h_desc + off_r, ras.data(), (size_t)nra * sizeof(RecipAtom));
+  HIPCHK(hipMemcpyAsync(w->d_desc.p, w->h_desc, desc_bytes, hipMemcpyHostToDevice, c->stream));
+  const UnitDesc* d_units = (const UnitDesc*)(w->d_desc.p + off_u);
+  const CouplingDesc* d_cps = (const CouplingDesc*)(w->d_desc.p + off_c);
+  const RecipAtom* d_ra = (const RecipAtom*)(w->d_desc.p + off_r);
   double* part_units = w->d_part.p;
   double* part_cp = w->d_part.p + (size_t)nu * part_stride;
   double* part_grid = w->d_part.p + (size_t)(nu + ncp) * part_stride;
@@ -991,30 +999,32 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   double* E_units_spec = w->d_E.p + nu;           // [nu]
   double* E_cp_env = w->d_E.p + 2 * nu;           // [ncp]
   double* E_grid = w->d_E.p + 2 * nu + ncp;       // [ngrid]
+  double* d_cpout = w->d_E.p + 2 * nu + ncp + ngrid;   // [ncp][3]: one download fetches everything
   // principal slot <- principal force
   HIPCHK(hipMemcpyAsync(c->d_Fdiag.p, c->d_force.p, n3 * 8, hipMemcpyDeviceToDevice, c->stream));
-  if (n_off) HIPCHK(hipMemsetAsync(c->d_Foff.p, 0, (size_t)n_off * n3 * 8, c->stream));
+  // every element of an owned off-diagonal slot is written by k_evb_coupling / k_evb_coupling_finish; foreign slots are zeroed for the all-gather
+  if (n_off && c->n_ranks > 1) HIPCHK(hipMemsetAsync(c->d_Foff.p, 0, (size_t)n_off * n3 * 8, c->stream));
   if (n_off && c->n_ranks > 1) HIPCHK(hipMemsetAsync(c->d_Fdiag.p + n3, 0, (size_t)n_off * n3 * 8, c->stream));
   // ---- 5b. off-diagonal elements (evb_diabatic_coupling, :1021)
   if (ncp) {
     hipStream_t so = c->overlap ? c->aux : c->stream;
     if (c->overlap) HIPCHK(aux_fork(c));
-    HIPCHK(hipMemsetAsync(w->d_dVspec.p, 0, (size_t)ncp * MAX_SPEC * 3 * 8, so));
-    hipLaunchKernelGGL(k_evb_coupling, dim3(cpb, ncp), dim3(256), 0, so, N, ncp, w->d_cps.p, c->d_mol_of.p, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_chg.p,
+    if (w->dv_dirty) { HIPCHK(hipMemsetAsync(w->d_dVspec.p, 0, w->d_dVspec.n * 8, so)); w->dv_dirty = false; }   // afterwards k_evb_coupling_finish leaves it zeroed
+    hipLaunchKernelGGL(k_evb_coupling, dim3(cpb, ncp), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_chg.p,
                        c->d_mass.p, c->d_atype.p, w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p);
     hipLaunchKernelGGL(k_sum_rows, dim3(ncp), dim3(256), 0, so, ncp, cpb, part_stride, part_cp, E_cp_env);
-    hipLaunchKernelGGL(k_evb_coupling_finish, dim3(ncp), dim3(64), 0, so, ncp, w->d_cps.p, w->d_exch.p, c->d_mass.p, box, c->conv, E_cp_env,
-                       w->d_dVspec.p, c->d_Foff.p, n3, w->d_cpout.p);
-    hipLaunchKernelGGL(k_evb_scale, dim3(256, ncp), dim3(256), 0, so, n3, ncp, w->d_cps.p, w->d_cpout.p, c->d_Foff.p, n3);
+    hipLaunchKernelGGL(k_evb_coupling_finish, dim3(ncp), dim3(64), 0, so, ncp, d_cps, w->d_exch.p, c->d_mass.p, box, c->conv, E_cp_env,
+                       w->d_dVspec.p, c->d_Foff.p, n3, d_cpout);
+    hipLaunchKernelGGL(k_evb_scale, dim3(256, ncp), dim3(256), 0, so, n3, ncp, d_cps, d_cpout, c->d_Foff.p, n3);
     HIPCHK(hipGetLastError());
   }
   // ---- 6. reciprocal space of the owned diabats (calculate_reciprocal_space_pme, :1962)
   phase_begin(c, PH_EVB_RECIP);
   if (ngrid) {
     hipLaunchKernelGGL(k_evb_grid_init, dim3(2048), dim3(256), 0, c->stream, K3, ngrid, c->d_Q.p, w->d_grids.p);
-    hipLaunchKernelGGL(k_evb_spec_prep, dim3((nra + 63) / 64), dim3(64), 0, c->stream, nra, w->d_ra.p, K, c->spline_grid, c->kk[0][0], c->kk[0][1], c->kk[0][2],
+    hipLaunchKernelGGL(k_evb_spec_prep, dim3((nra + 63) / 64), dim3(64), 0, c->stream, nra, d_ra, K, c->spline_grid, c->kk[0][0], c->kk[0][1], c->kk[0][2],
                        c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p);
-    hipLaunchKernelGGL(k_evb_patch, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, w->d_ra.p, K, K3, c->d_base.p, c->d_w.p, w->d_sbase.p, w->d_sw.p, w->d_grids.p);
+    hipLaunchKernelGGL(k_evb_patch, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, w->d_sbase.p, w->d_sw.p, w->d_grids.p);
     HIPCHK(hipGetLastError());
     int nbk = 0;
     CHK(pme_convolve(c, w->d_grids.p, ngrid, part_grid, part_stride, &nbk));      // one batched FFT pair for all owned diabats
@@ -1022,18 +1032,18 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     // all-atom gather, up to 8 grids per pass
     std::vector<int> gslots(ngrid);
     for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gslots[grid_of[d]] = diag_slot(c, D, d);
-    HIPCHK(hipMemcpyAsync(w->d_slots.p + 2 * MAX_DIABATS, gslots.data(), ngrid * sizeof(int), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_evb_pack, dim3(2048), dim3(256), 0, c->stream, K3, ngrid, w->d_grids.p, w->d_pack.p);
     if ((double)K3 * ngrid >= 2147483648.0) FAIL(MSEVB_ERR_LIMIT, "EVB gather: K^3 * n_grids exceeds the 32-bit offset range");
     const int* permp = c->list_valid ? c->d_perm.p : nullptr;     // cell-sorted traversal keeps the stencils of co-resident waves in L2
     for (int g0 = 0; g0 < ngrid; g0 += 8) {
       const int ng = std::min(8, ngrid - g0);
       auto kern = ng > 4 ? k_stencil_gather<8> : ng > 2 ? k_stencil_gather<4> : ng > 1 ? k_stencil_gather<2> : k_stencil_gather<1>;
-      hipLaunchKernelGGL(kern, dim3(round_up8((N + 3) / 4)), dim3(256), 0, c->stream, N, K, ng, w->d_slots.p + 2 * MAX_DIABATS + g0, permp, c->d_chg.p, c->d_base.p,
+      GatherSlots gs; for (int q = 0; q < 8; ++q) gs.s[q] = q < ng ? gslots[g0 + q] : 0;
+      hipLaunchKernelGGL(kern, dim3(round_up8((N + 3) / 4)), dim3(256), 0, c->stream, N, K, ng, gs, permp, c->d_chg.p, c->d_base.p,
                          c->d_w.p, c->d_dw.p, w->d_pack.p, ngrid, g0, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1],
                          c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_force.p, c->d_force_recip.p, c->d_Fdiag.p, n3);
     }
-    hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, w->d_ra.p, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
+    hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
                        w->d_sw.p, w->d_sdw.p, w->d_grids.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0],
                        c->kk[2][1], c->kk[2][2], c->d_Fdiag.p, n3);
     HIPCHK(hipGetLastError());
@@ -1054,10 +1064,10 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     hipLaunchKernelGGL(k_evb_candidates, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, rh->com[0], rh->com[1], rh->com[2], Renv * Renv, c->d_xyz.p, box,
                        w->d_counter.p + 1, w->d_cand.p, w->d_counter.p);
   }
-  hipLaunchKernelGGL(k_evb_env, dim3(envb, nu), dim3(256), 0, c->stream, w->d_counter.p + 1, w->d_cand.p, nu, w->d_units.p, w->d_tabs.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p, c->d_mol_of.p,
+  hipLaunchKernelGGL(k_evb_env, dim3(envb, nu), dim3(256), 0, c->stream, w->d_counter.p + 1, w->d_cand.p, nu, d_units, w->d_tabs.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p, c->d_mol_of.p,
                      c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->d_Fdiag.p, n3, part_units, part_stride);
   hipLaunchKernelGGL(k_sum_rows, dim3(nu), dim3(256), 0, c->stream, nu, envb, part_stride, part_units, E_units_env);
-  hipLaunchKernelGGL(k_evb_special, dim3(nu), dim3(64), 0, c->stream, nu, w->d_units.p, w->d_tabs.p, c->d_moltypes.p, c->d_pair_par.p, c->nt,
+  hipLaunchKernelGGL(k_evb_special, dim3(nu), dim3(64), 0, c->stream, nu, d_units, w->d_tabs.p, c->d_moltypes.p, c->d_pair_par.p, c->nt,
                      c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->alpha, 2.0 * c->alpha / c->pi_sqrt, c->conv, c->pi,
                      c->d_Fdiag.p, n3, E_units_spec);
   // ---- 8. off-diagonal elements: few, latency-bound kernels writing only d_Foff -> side stream, beside the reciprocal space
@@ -1066,9 +1076,13 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   phase_end(c, PH_EVB_REAL);
   if (ncp && c->overlap) HIPCHK(aux_join(c));
   // ---- 9. energies to the host, Hamiltonian
-  w->h_E.resize(2 * nu + ncp + ngrid + 3 * std::max(ncp, 1));
-  HIPCHK(hipMemcpyAsync(w->h_E.data(), w->d_E.p, (2 * nu + ncp + ngrid) * 8, hipMemcpyDeviceToHost, c->stream));
-  if (ncp) HIPCHK(hipMemcpyAsync(w->h_E.data() + 2 * nu + ncp + ngrid, w->d_cpout.p, 3 * ncp * 8, hipMemcpyDeviceToHost, c->stream));
+  const size_t nE = (size_t)2 * nu + ncp + ngrid + 3 * (size_t)ncp;
+  if (nE > w->hE_cap) {
+    if (w->h_E) HIPCHK(hipHostFree(w->h_E));
+    w->hE_cap = 2 * nE + 64;
+    HIPCHK(hipHostMalloc((void**)&w->h_E, w->hE_cap * sizeof(double), hipHostMallocDefault));
+  }
+  HIPCHK(hipMemcpyAsync(w->h_E, w->d_E.p, nE * 8, hipMemcpyDeviceToHost, c->stream));
   CHK(fetch_energies(c));
   double en[MSEVB_N_ENERGY];
   total_force_collect(c, en);
@@ -1100,19 +1114,13 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   int g = 0; double eg = ev[0];
   for (int i = 1; i < D; ++i) if (ev[i] < eg) { eg = ev[i]; g = i; }
   for (int i = 0; i < D; ++i) c->eigvec[i] = v[(size_t)i * D + g];
-  std::vector<double> coef; std::vector<int> slots, isoff;
+  BlendTerms bt; bt.n = 0;
   for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) {
-    if (i == j) { coef.push_back(c->eigvec[i] * c->eigvec[j]); slots.push_back(diag_slot(c, D, i)); isoff.push_back(0); }
-    else if (c->parent[j] == i) { coef.push_back(2.0 * c->eigvec[i] * c->eigvec[j]); slots.push_back(off_slot(c, D, j)); isoff.push_back(1); }
+    if (i == j) { bt.coef[bt.n] = c->eigvec[i] * c->eigvec[j]; bt.slot[bt.n++] = diag_slot(c, D, i); }
+    else if (c->parent[j] == i) { bt.coef[bt.n] = 2.0 * c->eigvec[i] * c->eigvec[j]; bt.slot[bt.n++] = -off_slot(c, D, j) - 1; }
   }
-  const int nterm = (int)coef.size();
-  if (nterm > 4 * MAX_DIABATS / 2) FAIL(MSEVB_ERR_LIMIT, "too many non-zero ms-evb matrix elements");
   phase_begin(c, PH_EVB_BLEND);
-  HIPCHK(hipMemcpyAsync(w->d_coef.p, coef.data(), nterm * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(w->d_slots.p, slots.data(), nterm * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(w->d_isoff.p, isoff.data(), nterm * 4, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, nterm, w->d_slots.p, w->d_isoff.p, w->d_coef.p,
-                     c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p);
+  hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p);
   HIPCHK(hipGetLastError());
   phase_end(c, PH_EVB_BLEND);
   int pr = 0; double sc = std::fabs(c->eigvec[0]);

@@ -4,6 +4,8 @@
 
 namespace {
 
+struct GatherSlots { int s[8]; };     // force-store slot of each grid of a pass (kernel argument)
+
 // All-atom reciprocal force of up to NGP owned diabats in one pass (update_reciprocal_space_force_dQ_dr for the atoms whose
 // stencil did not change, src/ms_evb.f90:2055-2084): Fstore[slot_g] = F11 + (f_g - Frecip1).
 // ONE WAVEFRONT PER ATOM; lane = (row r, grid g, tap k1): a stencil row of
@@ -11,7 +13,7 @@ namespace {
 // one line per lane (the per-lane-plane layout this replaces was bound by the L1 tag rate: 48 lines per load).  With NGP = 8
 // the row index is wave-uniform and the k2/k3 weights come through scalar loads.
 template <int NGP>
-__global__ __launch_bounds__(256) void k_stencil_gather(int N, int K, int ng, const int* __restrict__ slots, const int* __restrict__ perm,
+__global__ __launch_bounds__(256) void k_stencil_gather(int N, int K, int ng, GatherSlots slots, const int* __restrict__ perm,
                                                     const double* __restrict__ chg, const int* __restrict__ base, const double* __restrict__ w,
                                                     const double* __restrict__ dw, const double* __restrict__ pack, int ngtot, int g0, double conv, double k00,
                                                     double k01, double k02, double k10, double k11, double k12, double k20, double k21, double k22,
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void k_stencil_gather(int N, int K, int ng, co
     f1 *= sc; f2 *= sc; f3 *= sc;
     const double fx = -Kd * (k00 * f1 + k10 * f2 + k20 * f3), fy = -Kd * (k01 * f1 + k11 * f2 + k21 * f3), fz = -Kd * (k02 * f1 + k12 * f2 + k22 * f3);
     {
-      double* F = Fstore + (size_t)slots[g] * fstride;
+      double* F = Fstore + (size_t)slots.s[g] * fstride;
       F[3 * i] = F11[3 * i] + (fx - Frecip1[3 * i]);
       F[3 * i + 1] = F11[3 * i + 1] + (fy - Frecip1[3 * i + 1]);
       F[3 * i + 2] = F11[3 * i + 2] + (fz - Frecip1[3 * i + 2]);

@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--pme-grid", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-evb", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value (msevb_set_option), e.g. pair_tiles=0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,6 +133,9 @@ def main():
         h.calculate_total_force_energy(want_force=False)
     if args.warmup > 0:
         h.md_integrate_atomic(args.warmup, spec.delta_t, use_evb=use_evb)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        h.set_option(k, float(v))
     h.set_option("phase_timing", 1.0)      # HIP events on the library's stream around every phase (live roofline input)
     h.L.msevb_reset_phase_times(h.ctx)
     barrier()

@@ -5,29 +5,6 @@
 #include "ctx.hpp"
 
 
-namespace {
-
-__global__ void k_reduce_partials(int n, const double* __restrict__ part, double* __restrict__ out) {
-  __shared__ double red[256];
-  double s = 0.0;
-  for (int k = threadIdx.x; k < n; k += 256) s += part[k];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
-  if (threadIdx.x == 0) *out = red[0];
-}
-
-__global__ void k_half_to_full(int N, const unsigned* __restrict__ start, const int* __restrict__ nbr, const int* __restrict__ perm, int* __restrict__ counts) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= N) return;
-  const int i = perm[k];
-  int n = 0;
-  for (unsigned q = start[k]; q < start[k + 1]; ++q) if (perm[nbr[q]] > i) ++n;
-  counts[i] = n;
-}
-
-}  // namespace
-
 struct SlotCounts { int n[N_SLOTS]; };
 __global__ void k_reduce_slots(SlotCounts cnt, const double* __restrict__ part, double* __restrict__ out) {
   const int slot = blockIdx.x, n = cnt.n[slot];
@@ -93,7 +70,7 @@ int msevb_destroy(msevb_ctx* c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   pme_teardown(c);
   DBuf<int>* ib[] = {&c->d_atype, &c->d_mol_type, &c->d_mol_natom, &c->d_mol_atoms, &c->d_mol_of, &c->d_cell_of, &c->d_perm, &c->d_cell_keys_tmp,
-                     &c->d_perm_tmp, &c->d_cell_start, &c->d_inv_perm, &c->d_nbr, &c->d_type_sorted, &c->d_mol_sorted, &c->d_base, &c->d_splindex};
+                     &c->d_perm_tmp, &c->d_cell_start, &c->d_inv_perm, &c->d_tile_max, &c->d_nbr, &c->d_type_sorted, &c->d_mol_sorted, &c->d_base, &c->d_splindex};
   for (auto b : ib) b->release();
   DBuf<double>* db[] = {&c->d_chg, &c->d_mass, &c->d_B6, &c->d_B5, &c->d_tt, &c->d_dtt, &c->d_CB, &c->d_xyz, &c->d_vel, &c->d_force, &c->d_force_recip,
                         &c->d_xyz_store, &c->d_disp, &c->d_maxdisp, &c->d_Q, &c->d_theta, &c->d_w, &c->d_dw, &c->d_uscale, &c->d_partials, &c->d_energies,
@@ -393,7 +370,28 @@ int msevb_get_verlet_list(msevb_ctx* c, int* vp, int* nl, long* nn) {
   HIPCHK(hipMemcpy(nb.data(), c->d_nbr.p, c->n_nbr * sizeof(int), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(perm.data(), c->d_perm.p, N * sizeof(int), hipMemcpyDeviceToHost));
   std::vector<std::vector<int>> half(N);
-  for (int k = 0; k < N; ++k) { const int i = perm[k]; for (unsigned q = st[k]; q < st[k + 1]; ++q) { const int j = perm[(unsigned)nb[q] & NBR_IDX_MASK]; if (j > i) half[i].push_back(j); } }
+  std::vector<int> cstart, keys;
+  if (c->pair_tiles) {     // local (tile) indices: decode with the cell structure
+    const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
+    cstart.resize(ncell + 1); keys.resize(N);
+    HIPCHK(hipMemcpy(cstart.data(), c->d_cell_start.p, (ncell + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(keys.data(), c->d_cell_of.p, N * sizeof(int), hipMemcpyDeviceToHost));
+  }
+  for (int k = 0; k < N; ++k) {
+    const int i = perm[k];
+    int slots[27], off[28], ns = 0;
+    if (c->pair_tiles) {
+      ns = cell_neighbourhood(keys[k], c->ncell[0], c->ncell[1], c->ncell[2], slots);
+      off[0] = 0;
+      for (int s = 0; s < ns; ++s) off[s + 1] = off[s] + cstart[slots[s] + 1] - cstart[slots[s]];
+    }
+    for (unsigned q = st[k]; q < st[k + 1]; ++q) {
+      int js = (int)((unsigned)nb[q] & NBR_IDX_MASK);
+      if (c->pair_tiles) { int s = 0; while (s + 1 < ns && js >= off[s + 1]) ++s; js = cstart[slots[s]] + (js - off[s]); }
+      const int j = perm[js];
+      if (j > i) half[i].push_back(j);
+    }
+  }
   long tot = 0;
   for (int i = 0; i < N; ++i) { std::sort(half[i].begin(), half[i].end()); if (vp) vp[i] = (int)tot + 1; if (nl) for (int j : half[i]) nl[tot++] = j + 1; else tot += (long)half[i].size(); }
   if (vp) vp[N] = (int)tot + 1;
@@ -434,11 +432,11 @@ int total_force_enqueue(msevb_ctx* c) {
   if (c->flag_verlet_list == 1 || !c->list_valid) { CHK(nb_build(c)); c->flag_verlet_list = 0; }
   else { CHK(nb_check_displacements(c, 0, nullptr)); CHK(nb_refresh_sorted(c)); }
   HIPCHK(hipMemsetAsync(c->d_force.p, 0, 3 * (size_t)c->N * 8, c->stream));
-  if (c->overlap) {     // per-molecule terms (few, long threads) on the side stream beside the pair loop and the charge spreading
+  if (c->overlap) {     // the pair loop (latency-bound) on the main stream; per-molecule terms and the PME front end beside it on the side stream
     HIPCHK(aux_fork(c));
-    CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux));
-    CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
-    CHK(pme_forces(c, S_RECIP, true));
+    CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));                // main stream
+    CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux));   // side stream, beside the pair loop ...
+    CHK(pme_forces(c, S_RECIP, true));                           // ... followed by the PME front end; joined before the gather
   } else {
     CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
     CHK(molecule_forces(c, S_ELEC_INTRA, true, true));
@@ -521,6 +519,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
   if (s == "overlap") { c->overlap = v != 0.0; return MSEVB_OK; }
+  if (s == "pair_tiles") { c->pair_tiles_opt = (int)v; c->list_valid = false; return MSEVB_OK; }
   c->err = "unknown option " + s;
   return MSEVB_ERR_ARG;
 }

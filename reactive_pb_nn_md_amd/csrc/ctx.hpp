@@ -67,10 +67,38 @@ __device__ __forceinline__ int xcd_block(int b, int nb) { return (b & 7) * (nb >
 #endif
 inline int round_up8(int n) { return (n + 7) & ~7; }
 
+// The (up to 27) distinct neighbour cells of cell cidx, in the canonical order shared by the list build, the LDS-tiled pair
+// kernel and the host-side decoder of msevb_get_verlet_list.  Returns the number of slots.
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline int cell_neighbourhood(int cidx, int ncx, int ncy, int ncz, int* slots) {
+  const int cx = cidx % ncx, cy = (cidx / ncx) % ncy, cz = cidx / (ncx * ncy);
+  int n = 0;
+  for (int oz = -1; oz <= 1; ++oz) {
+    if ((ncz < 3 && oz == 1) || (ncz < 2 && oz == -1)) continue;
+    const int zz = (cz + oz + ncz) % ncz;
+    for (int oy = -1; oy <= 1; ++oy) {
+      if ((ncy < 3 && oy == 1) || (ncy < 2 && oy == -1)) continue;
+      const int yy = (cy + oy + ncy) % ncy;
+      for (int ox = -1; ox <= 1; ++ox) {
+        if ((ncx < 3 && ox == 1) || (ncx < 2 && ox == -1)) continue;
+        const int xx = (cx + ox + ncx) % ncx;
+        slots[n++] = xx + ncx * (yy + ncy * zz);
+      }
+    }
+  }
+  return n;
+}
+
 // Verlet-list entry: sorted index of the neighbour in the low 24 bits, its atom type in the high 8 (the pair kernel then needs
 // no per-neighbour type gather).  Limits: N < 2^24 atoms, MAX_TYPES <= 256; the list is rebuilt whenever the topology changes.
 constexpr int NBR_IDX_BITS = 24;
 constexpr unsigned NBR_IDX_MASK = (1u << NBR_IDX_BITS) - 1u;
+// In tile mode (c->pair_tiles) the index is LOCAL: the position of the neighbour inside the concatenation of the neighbour cells
+// of the owning atom's cell (cell_neighbourhood order) - exactly the layout of the LDS tile the pair kernel stages per cell.
+constexpr int PAIR_TILE_LDS_BYTES = 144 * 1024;      // of the 160 KiB per CU; the rest holds the pair-parameter table and reductions
+constexpr int PAIR_TILE_MIN_CELLS = 128;             // fewer cells than this cannot fill the chip with one block per cell
 
 // host mirror of a molecule type (as set through the ABI)
 struct MolTypeHost {
@@ -115,7 +143,11 @@ struct msevb_ctx {
   // the pair loop / charge spreading, off-diagonal EVB elements next to the diabat reciprocal space); fork/join by events
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t pme_st = nullptr;      // non-null while the PME front end is being enqueued on the side stream
   bool overlap = true;
+  int pair_tiles_opt = 0;        // 0 off (default: measured slower than the global-gather kernel once the PME front end overlaps it), 1 on when it fits, -1 auto
+  bool pair_tiles = false;       // format of the current list
+  int tile_atoms_max = 0;
   bool finalized = false;
 
   // ---- configuration
@@ -160,7 +192,7 @@ struct msevb_ctx {
   DBuf<double> d_maxdisp;
   // neighbour structure (sorted order)
   int ncell[3] = {1, 1, 1};
-  DBuf<int> d_cell_of, d_perm, d_cell_keys_tmp, d_perm_tmp, d_cell_start, d_inv_perm;
+  DBuf<int> d_cell_of, d_perm, d_cell_keys_tmp, d_perm_tmp, d_cell_start, d_inv_perm, d_tile_max;
   DBuf<unsigned> d_nbr_count, d_nbr_start;
   DBuf<int> d_nbr;
   DBuf<char> d_sort_tmp;

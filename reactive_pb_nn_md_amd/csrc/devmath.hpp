@@ -42,6 +42,61 @@ __device__ __forceinline__ void pair_interaction(double r2, double qq, const Pai
   }
 }
 
+// Two-stage form for the pair kernels: ewald_fetch issues the two table-row loads of a pair UNCONDITIONALLY (row index clamped
+// into the table, so lanes outside the cutoff load harmless rows) - several pairs' loads are then in flight before any of them
+// is consumed; pair_interaction_rows finishes the pair with exactly the arithmetic of pair_interaction.
+struct EwaldRows { double r, inv_r, x1; int idx; double2 t0, t1; };
+// r = sqrt(r2) and 1/r from ONE v_rsq_f64 seed and two coupled Newton (Goldschmidt) steps, all FMAs: ~10 VALU instructions instead
+// of ~45 for an IEEE sqrt plus an IEEE division; both results are within 1-2 ulp (the pair loop is VALU-bound on these).
+__device__ __forceinline__ void sqrt_rsqrt(double a, double& g, double& y) {
+#pragma clang fp contract(fast)
+  const double y0 = __builtin_amdgcn_rsq(a);
+  g = a * y0;
+  double h = 0.5 * y0;
+  double e = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, e, g); h = __builtin_fma(h, e, h);
+  e = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, e, g); h = __builtin_fma(h, e, h);
+  y = h + h;
+}
+__device__ __forceinline__ void ewald_fetch(double r2, double inv_dx, int emax, const double2* __restrict__ etab, EwaldRows& w) {
+  sqrt_rsqrt(r2, w.r, w.inv_r);
+  w.x1 = w.r * inv_dx;
+  w.idx = (int)ceil(w.x1);
+  const int row = min(max(w.idx, 1), emax);
+  w.t0 = etab[row - 1]; w.t1 = etab[row];
+}
+template <bool SAPT = true>
+__device__ __forceinline__ void pair_interaction_rows(double r2, double qq, const PairParam& pp, const EwaldRows& w, const double* __restrict__ tt,
+                                                      const double* __restrict__ dtt, double& fs, double& e_el, double& e_vdw) {
+#pragma clang fp contract(fast)
+  const double r = w.r;
+  const double inv_r = w.inv_r;
+  const double inv_r2 = inv_r * inv_r;
+  const double c2 = (w.x1 + 1.0) - (double)w.idx, c1 = 1.0 - c2;
+  const double ev = c1 * w.t0.x + c2 * w.t1.x, sv = c1 * w.t0.y + c2 * w.t1.y;
+  const double qr = qq * inv_r;
+  e_el = qr * ev;
+  fs = qr * inv_r2 * sv;
+  e_vdw = 0.0;
+  if (pp.type == 0) {
+    const double r6i = inv_r2 * inv_r2 * inv_r2, r12i = r6i * r6i;
+    e_vdw = pp.p[0] * r12i - pp.p[1] * r6i;
+    fs += inv_r2 * (12.0 * pp.p[0] * r12i - 6.0 * pp.p[1] * r6i);
+  } else if (SAPT && pp.type == 1 && pp.nonzero) {
+    const double A = pp.p[0], B = pp.p[1];
+    const int ti = (int)ceil(B * r / TT_MAX * (double)TT_GRID);
+    const double* t = tt + 4 * (ti - 1);
+    const double* dt = dtt + 4 * (ti - 1);
+    const double r6i = inv_r2 * inv_r2 * inv_r2, r8i = r6i * inv_r2, r10i = r8i * inv_r2, r12i = r10i * inv_r2;
+    const double ex = exp(-B * r);
+    e_vdw = A * ex - t[0] * pp.p[2] * r6i - t[1] * pp.p[3] * r8i - t[2] * pp.p[4] * r10i - t[3] * pp.p[5] * r12i;
+    const double fac = r * A * B * ex + (r * B * dt[0] - 6.0 * t[0]) * pp.p[2] * r6i + (r * B * dt[1] - 8.0 * t[1]) * pp.p[3] * r8i +
+                       (r * B * dt[2] - 10.0 * t[2]) * pp.p[4] * r10i + (r * B * dt[3] - 12.0 * t[3]) * pp.p[5] * r12i;
+    fs += inv_r2 * fac;
+  }
+}
+
 // vdW-only part (intra-molecular non-bonded pairs have no cutoff on the vdW term, src/pair_int_real_space.f90:535-544)
 __device__ __forceinline__ void vdw_interaction(double r2, const PairParam& pp, const double* __restrict__ tt, const double* __restrict__ dtt,
                                                 double& fs, double& e_vdw) {

@@ -951,7 +951,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   }
   const int nu = (int)units.size(), ncp = (int)cps.size(), nra = (int)ras.size();
   // ---- 5. device buffers
-  const int envb = std::min(64, (N + 255) / 256), cpb = std::min(512, (N + 255) / 256), convb = 1024;
+  const int envb = std::min(64, (N + 255) / 256), cpb = std::min(512, (N + 255) / 256);
   const int part_stride = 1024;
   const int n_rows = nu + ncp + ngrid + 8;
   if (c->d_Fdiag.alloc((size_t)n_diag * n3) || c->d_Foff.alloc((size_t)std::max(n_off, 1) * n3) || 

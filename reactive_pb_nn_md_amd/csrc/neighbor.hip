@@ -49,8 +49,20 @@ __global__ void k_gather_sorted(int N, const int* __restrict__ perm, const doubl
   if (inv_perm) inv_perm[i] = k;
 }
 
-// one wavefront per sorted atom; FILL=false counts, FILL=true writes neighbours compactly (ballot + mbcnt)
-template <bool FILL>
+// largest number of atoms in the neighbourhood (distinct neighbour cells) of any cell = LDS tile size of the tiled pair kernel
+__global__ void k_tile_max(int ncell, int3 nc, const int* __restrict__ cell_start, int* __restrict__ out) {
+  const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cidx >= ncell) return;
+  int slots[27];
+  const int ns = cell_neighbourhood(cidx, nc.x, nc.y, nc.z, slots);
+  int tot = 0;
+  for (int s = 0; s < ns; ++s) tot += cell_start[slots[s] + 1] - cell_start[slots[s]];
+  atomicMax(out, tot);
+}
+
+// one wavefront per sorted atom; FILL=false counts, FILL=true writes neighbours compactly (ballot + mbcnt).
+// LOCAL: entries hold the neighbour's position inside the cell-neighbourhood tile instead of its sorted index.
+template <bool FILL, bool LOCAL>
 __global__ __launch_bounds__(256) void k_neighbors(int N, const double4* __restrict__ posq, const int* __restrict__ mol_s, const int* __restrict__ type_s,
                                                    const int* __restrict__ keys, const int* __restrict__ cell_start, BoxDev box, int3 nc,
                                                    double rv2, unsigned* __restrict__ count, const unsigned* __restrict__ start,
@@ -60,41 +72,33 @@ __global__ __launch_bounds__(256) void k_neighbors(int N, const double4* __restr
   if (i >= N) return;
   const double4 pi = posq[i];
   const int mi = mol_s[i];
-  const int key = keys[i];
-  const int cx = key % nc.x, cy = (key / nc.x) % nc.y, cz = key / (nc.x * nc.y);
+  int slots[27];
+  const int ns = cell_neighbourhood(keys[i], nc.x, nc.y, nc.z, slots);
   unsigned total = 0;
   const unsigned base = FILL ? start[i] : 0u;
-  for (int oz = -1; oz <= 1; ++oz) {
-    if ((nc.z < 3 && oz == 1) || (nc.z < 2 && oz == -1)) continue;
-    const int zz = (cz + oz + nc.z) % nc.z;
-    for (int oy = -1; oy <= 1; ++oy) {
-      if ((nc.y < 3 && oy == 1) || (nc.y < 2 && oy == -1)) continue;
-      const int yy = (cy + oy + nc.y) % nc.y;
-      for (int ox = -1; ox <= 1; ++ox) {
-        if ((nc.x < 3 && ox == 1) || (nc.x < 2 && ox == -1)) continue;
-        const int xx = (cx + ox + nc.x) % nc.x;
-        const int cidx = xx + nc.x * (yy + nc.y * zz);
-        const int s = cell_start[cidx], e = cell_start[cidx + 1];
-        for (int j0 = s; j0 < e; j0 += 64) {
-          const int j = j0 + lane;
-          bool hit = false;
-          if (j < e && j != i && mol_s[j] != mi) {
-            const double4 pj = posq[j];
-            double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            dx -= box.L[0] * floor(dx * box.invL[0] + 0.5);
-            dy -= box.L[1] * floor(dy * box.invL[1] + 0.5);
-            dz -= box.L[2] * floor(dz * box.invL[2] + 0.5);
-            hit = (dx * dx + dy * dy + dz * dz) < rv2;
-          }
-          const unsigned long long m = __ballot(hit);
-          if (FILL && hit) {
-            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            nbr[base + total + rank] = (int)((unsigned)j | ((unsigned)type_s[j] << NBR_IDX_BITS));
-          }
-          total += (unsigned)__popcll(m);
-        }
+  int off = 0;     // running offset of the current cell inside the tile
+  for (int sl = 0; sl < ns; ++sl) {
+    const int s = cell_start[slots[sl]], e = cell_start[slots[sl] + 1];
+    for (int j0 = s; j0 < e; j0 += 64) {
+      const int j = j0 + lane;
+      bool hit = false;
+      if (j < e && j != i && mol_s[j] != mi) {
+        const double4 pj = posq[j];
+        double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        dx -= box.L[0] * floor(dx * box.invL[0] + 0.5);
+        dy -= box.L[1] * floor(dy * box.invL[1] + 0.5);
+        dz -= box.L[2] * floor(dz * box.invL[2] + 0.5);
+        hit = (dx * dx + dy * dy + dz * dz) < rv2;
       }
+      const unsigned long long m = __ballot(hit);
+      if (FILL && hit) {
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        const unsigned idx = LOCAL ? (unsigned)(off + (j - s)) : (unsigned)j;
+        nbr[base + total + rank] = (int)(idx | ((unsigned)type_s[j] << NBR_IDX_BITS));
+      }
+      total += (unsigned)__popcll(m);
     }
+    off += e - s;
   }
   if (!FILL && lane == 0) count[i] = total;
 }
@@ -200,19 +204,32 @@ int nb_build(msevb_ctx* c) {
   const dim3 grid((N + wpb - 1) / wpb), block(64 * wpb);
   const double rv2 = c->rv * c->rv;
   HIPCHK(hipMemsetAsync(c->d_nbr_count.p, 0, (N + 1) * sizeof(unsigned), c->stream));
-  hipLaunchKernelGGL(k_neighbors<false>, grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
+  hipLaunchKernelGGL((k_neighbors<false, false>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
                      c->d_nbr_count.p, (const unsigned*)nullptr, (int*)nullptr);
   tb = c->d_sort_tmp.n;
   HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp.p, tb, c->d_nbr_count.p, c->d_nbr_start.p, N + 1, c->stream));
+  // tile size of the LDS-staged pair kernel (slot N of the count array is unused by the scan's consumers: reuse it as the max cell)
+  if (c->d_tile_max.alloc(1)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (tile size)");
+  HIPCHK(hipMemsetAsync(c->d_tile_max.p, 0, sizeof(int), c->stream));
+  hipLaunchKernelGGL(k_tile_max, dim3((ncell + 255) / 256), dim3(256), 0, c->stream, ncell, nc, c->d_cell_start.p, c->d_tile_max.p);
   unsigned total = 0;
+  int tile_max = 0;
   HIPCHK(hipMemcpyAsync(&total, c->d_nbr_start.p + N, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(&tile_max, c->d_tile_max.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   c->n_nbr = total;
+  c->tile_atoms_max = tile_max;
+  const size_t tile_bytes = (size_t)tile_max * sizeof(double4) + (size_t)c->nt * c->nt * sizeof(PairParam) + 1024;
+  c->pair_tiles = c->pair_tiles_opt != 0 && tile_bytes <= (size_t)PAIR_TILE_LDS_BYTES && (c->pair_tiles_opt == 1 || ncell >= PAIR_TILE_MIN_CELLS);
   if (c->d_nbr.n < (size_t)total) {
     if (c->d_nbr.alloc((size_t)(total * 1.2) + 1024)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (neighbour list)");
   }
-  hipLaunchKernelGGL(k_neighbors<true>, grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
-                     (unsigned*)nullptr, c->d_nbr_start.p, c->d_nbr.p);
+  if (c->pair_tiles)
+    hipLaunchKernelGGL((k_neighbors<true, true>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
+                       (unsigned*)nullptr, c->d_nbr_start.p, c->d_nbr.p);
+  else
+    hipLaunchKernelGGL((k_neighbors<true, false>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
+                       (unsigned*)nullptr, c->d_nbr_start.p, c->d_nbr.p);
   HIPCHK(hipGetLastError());
   phase_end(c, PH_VERLET);
   c->list_valid = true;

@@ -185,6 +185,9 @@ __global__ __launch_bounds__(256) void k_pme_gather(int N, int K, const double* 
 
 }  // namespace
 
+// stream of the PME front end (prep ... inverse FFT): the side stream while the principal pair loop runs on the main one
+static inline hipStream_t pme_stream(const msevb_ctx* c) { return c->pme_st ? c->pme_st : c->stream; }
+
 #define FFTCHK(call) do { if ((call) != rocfft_status_success) FAIL(MSEVB_ERR_FFT, std::string("rocFFT failure: ") + #call); } while (0)
 
 static bool g_rocfft_ready = false;
@@ -249,10 +252,11 @@ int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part
     pf = c->plan_fwd_b; pb = c->plan_bwd_b;
   }
   void* buf[1] = {grids};
+  FFTCHK(rocfft_execution_info_set_stream(c->fft_info, pme_stream(c)));
   FFTCHK(rocfft_execute(pf, buf, nullptr, c->fft_info));
   int nb = (int)((K3 + 255) / 256);
   if (nb > 512) nb = 512;
-  hipLaunchKernelGGL(k_pme_conv, dim3(nb, batch), dim3(256), 0, c->stream, K3, c->d_CB.p, grids, part_stride, part, 0.5 * c->conv);
+  hipLaunchKernelGGL(k_pme_conv, dim3(nb, batch), dim3(256), 0, pme_stream(c), K3, c->d_CB.p, grids, part_stride, part, 0.5 * c->conv);
   FFTCHK(rocfft_execute(pb, buf, nullptr, c->fft_info));
   HIPCHK(hipGetLastError());
   if (nblocks) *nblocks = nb;
@@ -262,7 +266,7 @@ int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part
 int pme_prepare_atoms(msevb_ctx* c, bool with_indices) {
   const int N = c->N;
   const long nt = 18L * N;
-  hipLaunchKernelGGL(k_pme_prep, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, N, c->K, c->spline_grid, c->d_xyz.p, c->kk[0][0], c->kk[0][1],
+  hipLaunchKernelGGL(k_pme_prep, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, pme_stream(c), N, c->K, c->spline_grid, c->d_xyz.p, c->kk[0][0], c->kk[0][1],
                      c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, c->d_uscale.p,
                      c->d_base.p, with_indices ? c->d_splindex.p : (int*)nullptr, c->d_w.p, c->d_dw.p);
   HIPCHK(hipGetLastError());
@@ -271,8 +275,6 @@ int pme_prepare_atoms(msevb_ctx* c, bool with_indices) {
 
 int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add) {
   const int N = c->N;
-  const size_t K3 = (size_t)c->K * c->K * c->K;
-  hipLaunchKernelGGL(k_pme_real, dim3(1024), dim3(256), 0, c->stream, K3, grid, c->d_theta.p);
   hipLaunchKernelGGL(k_pme_gather, dim3((N * 8 + 255) / 256), dim3(256), 0, c->stream, N, c->K, chg, c->d_base.p, c->d_w.p, c->d_dw.p, c->d_theta.p, c->conv, c->kk[0][0],
                      c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add);
   HIPCHK(hipGetLastError());
@@ -282,33 +284,39 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
 int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux) {
   const int N = c->N, K = c->K;
   const size_t K3 = (size_t)K * K * K;
-  phase_begin(c, PH_SPREAD);
+  // join_aux: the caller has forked the side stream; the whole front end (stencils, spreading, FFTs, convolution) goes there and
+  // overlaps the pair loop on the main stream; the gather (adds to the total force without atomics) runs on the main stream after the join
+  c->pme_st = join_aux ? c->aux : nullptr;
+  const hipStream_t st = pme_stream(c);
+  phase_begin(c, PH_SPREAD, st);
   CHK(pme_prepare_atoms(c, false));
-  HIPCHK(hipMemsetAsync(c->d_grid.p, 0, K3 * sizeof(double2), c->stream));
+  HIPCHK(hipMemsetAsync(c->d_grid.p, 0, K3 * sizeof(double2), st));
   {
     int3 T;
     T.x = (int)ceil((double)K / c->ncell[0]) + 8; T.y = (int)ceil((double)K / c->ncell[1]) + 8; T.z = (int)ceil((double)K / c->ncell[2]) + 8;
     const size_t tile_bytes = (size_t)T.x * T.y * T.z * sizeof(double);
     if (c->list_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= K && T.y <= K && T.z <= K) {
       const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
-      hipLaunchKernelGGL(k_pme_spread_tiles, dim3(ncell), dim3(256), tile_bytes, c->stream, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T,
+      hipLaunchKernelGGL(k_pme_spread_tiles, dim3(ncell), dim3(256), tile_bytes, st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T,
                          c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_base.p, c->d_w.p, c->d_grid.p);
     } else {
       const long nt = (long)N * 36;
-      hipLaunchKernelGGL(k_pme_spread, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, N, K, c->d_chg.p, c->d_base.p, c->d_w.p, c->d_grid.p);
+      hipLaunchKernelGGL(k_pme_spread, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, N, K, c->d_chg.p, c->d_base.p, c->d_w.p, c->d_grid.p);
     }
   }
   int nbc = (int)((K3 + 255) / 256);
   if (nbc > 2048) nbc = 2048;
-  hipLaunchKernelGGL(k_copy_real, dim3(nbc), dim3(256), 0, c->stream, K3, c->d_grid.p, c->d_Q.p);
+  hipLaunchKernelGGL(k_copy_real, dim3(nbc), dim3(256), 0, st, K3, c->d_grid.p, c->d_Q.p);
   HIPCHK(hipGetLastError());
-  phase_end(c, PH_SPREAD);
-  phase_begin(c, PH_FFT);
+  phase_end(c, PH_SPREAD, st);
+  phase_begin(c, PH_FFT, st);
   int nbk = 0;
   CHK(pme_convolve(c, c->d_grid.p, 1, c->d_partials.p + (size_t)slot_recip * MAX_BLOCKS, MAX_BLOCKS, &nbk));
   CHK(reduce_partials(c, slot_recip, nbk));
-  phase_end(c, PH_FFT);
-  if (join_aux) HIPCHK(aux_join(c));       // the gather adds to the total force without atomics: the side stream must be done
+  hipLaunchKernelGGL(k_pme_real, dim3(1024), dim3(256), 0, st, K3, c->d_grid.p, c->d_theta.p);
+  phase_end(c, PH_FFT, st);
+  c->pme_st = nullptr;
+  if (join_aux) HIPCHK(aux_join(c));
   phase_begin(c, PH_GATHER);
   CHK(pme_gather(c, c->d_grid.p, c->d_chg.p, c->d_force_recip.p, c->d_force.p));
   phase_end(c, PH_GATHER);

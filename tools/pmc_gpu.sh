@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 n=0
 for grp in "$@"; do
   n=$((n+1))
-  timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace -d $OUT/g$n -o p -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/g$n.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace -d $OUT/g$n -o p -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline $BENCH_ARGS > $OUT/g$n.log 2>&1
 done
 python3 $R/tools/summarize_pmc.py $OUT > $OUT/summary.txt 2>&1 || true
 tail -60 $OUT/summary.txt

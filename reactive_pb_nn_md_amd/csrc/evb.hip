@@ -570,6 +570,11 @@ __global__ void k_evb_scale(size_t n3, int n_cp, const CouplingDesc* __restrict_
 }
 
 // Hellmann-Feynman blend: F = sum_d c_d^2 F_dd + 2 sum_(p,d) c_p c_d F_pd (src/ms_evb.f90:293-309)
+// principal slot = principal force + its repulsion delta (consumes and re-zeroes the delta)
+__global__ void k_evb_slot0(size_t n3, const double* __restrict__ F11, double* __restrict__ delta0, double* __restrict__ Fdiag0) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (size_t)gridDim.x * blockDim.x) { Fdiag0[k] = F11[k] + delta0[k]; delta0[k] = 0.0; }
+}
+
 struct BlendTerms { int n; int slot[2 * MAX_DIABATS]; double coef[2 * MAX_DIABATS]; };   // slot < 0: off-diagonal store, index -slot-1 (kernel argument, no upload)
 __global__ void k_evb_blend(size_t n3, BlendTerms bt, const double* __restrict__ Fdiag, const double* __restrict__ Foff, size_t fstride, double* __restrict__ F) {
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (size_t)gridDim.x * blockDim.x) {
@@ -628,6 +633,8 @@ struct EvbWork {   // persistent device scratch of one context
   DBuf<EvbTablesDev> d_tabs; DBuf<double> d_exch;
   DBuf<double> d_part, d_E, d_dVspec; DBuf<int> d_sbase, d_counter; DBuf<double> d_sw, d_sdw;
   DBuf<double2> d_grids; DBuf<RegionRec> d_region; DBuf<int> d_cand;
+  DBuf<double> d_Fdelta;      // [n_diag][3N] real-space deltas of the diabats, accumulated on stream2 beside the reciprocal space
+  hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr; bool delta_dirty = true;
   DBuf<double> d_F11, d_pack;
   hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
   RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
@@ -818,6 +825,8 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipStreamCreateWithFlags(&w->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&w->ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_region, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&w->ev_fork2, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&w->ev_join2, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&w->h_region, REGION_FAST * sizeof(RegionRec), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&w->h_count, 64, hipHostMallocDefault));
   }
@@ -826,7 +835,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipMemsetAsync(w->d_counter.p, 0, 4 * sizeof(int), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
-  struct Rearm { EvbWork* w; bool ok; ~Rearm() { w->counters_dirty = !ok; if (!ok) w->dv_dirty = true; } } rearm{w, false};
+  struct Rearm { EvbWork* w; bool ok; ~Rearm() { w->counters_dirty = !ok; if (!ok) { w->dv_dirty = true; w->delta_dirty = true; } } } rearm{w, false};
   const double Rreg = 5.0 * c->max_chain + 5.0;
   HIPCHK(hipEventRecord(w->ev_in, c->stream));
   HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_in, 0));
@@ -1000,8 +1009,11 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   double* E_cp_env = w->d_E.p + 2 * nu;           // [ncp]
   double* E_grid = w->d_E.p + 2 * nu + ncp;       // [ngrid]
   double* d_cpout = w->d_E.p + 2 * nu + ncp + ngrid;   // [ncp][3]: one download fetches everything
-  // principal slot <- principal force
-  HIPCHK(hipMemcpyAsync(c->d_Fdiag.p, c->d_force.p, n3 * 8, hipMemcpyDeviceToDevice, c->stream));
+  {   // delta store of the diagonal real-space terms: zero on first use / after a resize / after a failed call, then self-cleaning
+    const size_t need = (size_t)n_diag * n3;
+    if (w->d_Fdelta.n < need) { if (w->d_Fdelta.alloc(need)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB delta store)"); w->delta_dirty = true; }
+    if (w->delta_dirty) { HIPCHK(hipMemsetAsync(w->d_Fdelta.p, 0, w->d_Fdelta.n * 8, c->stream)); w->delta_dirty = false; }
+  }
   // every element of an owned off-diagonal slot is written by k_evb_coupling / k_evb_coupling_finish; foreign slots are zeroed for the all-gather
   if (n_off && c->n_ranks > 1) HIPCHK(hipMemsetAsync(c->d_Foff.p, 0, (size_t)n_off * n3 * 8, c->stream));
   if (n_off && c->n_ranks > 1) HIPCHK(hipMemsetAsync(c->d_Fdiag.p + n3, 0, (size_t)n_off * n3 * 8, c->stream));
@@ -1018,7 +1030,33 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     hipLaunchKernelGGL(k_evb_scale, dim3(256, ncp), dim3(256), 0, so, n3, ncp, d_cps, d_cpout, c->d_Foff.p, n3);
     HIPCHK(hipGetLastError());
   }
-  // ---- 6. reciprocal space of the owned diabats (calculate_reciprocal_space_pme, :1962)
+  // ---- 6a. real-space / bonded / repulsion deltas of all units (ms_evb_diabat_force_energy, :1421)
+  const hipStream_t sr = c->overlap ? w->stream2 : c->stream;     // beside the reciprocal space of the diabats (joined before the gather)
+  if (c->overlap) { HIPCHK(hipEventRecord(w->ev_fork2, c->stream)); HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_fork2, 0)); }
+  phase_begin(c, PH_EVB_REAL, sr);
+  {
+    // candidate sphere: centre = hydronium COM, radius = farthest special atom + max(cutoff, repulsion screen) + a little
+    const RegionRec* rh = find_region(w, c->hydronium);
+    double far2 = 0.0;
+    for (const UnitDesc& u : units) for (int k = 0; k < u.n_spec; ++k) {
+      double d2 = 0.0;
+      for (int q = 0; q < 3; ++q) { double d = u.spec[k].x[q] - rh->com[q]; d -= c->box[q] * std::floor(d / c->box[q] + 0.5); d2 += d * d; }
+      far2 = std::max(far2, d2);
+    }
+    const double Renv = std::sqrt(far2) + std::max(c->rc, w->screen_r) + 0.5;
+    hipLaunchKernelGGL(k_evb_candidates, dim3((N + 255) / 256), dim3(256), 0, sr, N, rh->com[0], rh->com[1], rh->com[2], Renv * Renv, c->d_xyz.p, box,
+                       w->d_counter.p + 1, w->d_cand.p, w->d_counter.p);
+  }
+  hipLaunchKernelGGL(k_evb_env, dim3(envb, nu), dim3(256), 0, sr, w->d_counter.p + 1, w->d_cand.p, nu, d_units, w->d_tabs.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p, c->d_mol_of.p,
+                     c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, w->d_Fdelta.p, n3, part_units, part_stride);
+  hipLaunchKernelGGL(k_sum_rows, dim3(nu), dim3(256), 0, sr, nu, envb, part_stride, part_units, E_units_env);
+  hipLaunchKernelGGL(k_evb_special, dim3(nu), dim3(64), 0, sr, nu, d_units, w->d_tabs.p, c->d_moltypes.p, c->d_pair_par.p, c->nt,
+                     c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->alpha, 2.0 * c->alpha / c->pi_sqrt, c->conv, c->pi,
+                     w->d_Fdelta.p, n3, E_units_spec);
+  HIPCHK(hipGetLastError());
+  phase_end(c, PH_EVB_REAL, sr);
+  if (c->overlap) HIPCHK(hipEventRecord(w->ev_join2, w->stream2));
+  // ---- 6b. reciprocal space of the owned diabats (calculate_reciprocal_space_pme, :1962)
   phase_begin(c, PH_EVB_RECIP);
   if (ngrid) {
     hipLaunchKernelGGL(k_evb_grid_init, dim3(2048), dim3(256), 0, c->stream, K3, ngrid, c->d_Q.p, w->d_grids.p);
@@ -1034,6 +1072,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gslots[grid_of[d]] = diag_slot(c, D, d);
     hipLaunchKernelGGL(k_evb_pack, dim3(2048), dim3(256), 0, c->stream, K3, ngrid, w->d_grids.p, w->d_pack.p);
     if ((double)K3 * ngrid >= 2147483648.0) FAIL(MSEVB_ERR_LIMIT, "EVB gather: K^3 * n_grids exceeds the 32-bit offset range");
+    if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));      // the gather folds the real-space deltas in
     const int* permp = c->list_valid ? c->d_perm.p : nullptr;     // cell-sorted traversal keeps the stencils of co-resident waves in L2
     for (int g0 = 0; g0 < ngrid; g0 += 8) {
       const int ng = std::min(8, ngrid - g0);
@@ -1041,39 +1080,19 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
       GatherSlots gs; for (int q = 0; q < 8; ++q) gs.s[q] = q < ng ? gslots[g0 + q] : 0;
       hipLaunchKernelGGL(kern, dim3(round_up8((N + 3) / 4)), dim3(256), 0, c->stream, N, K, ng, gs, permp, c->d_chg.p, c->d_base.p,
                          c->d_w.p, c->d_dw.p, w->d_pack.p, ngrid, g0, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1],
-                         c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_force.p, c->d_force_recip.p, c->d_Fdiag.p, n3);
+                         c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_force.p, c->d_force_recip.p, c->d_Fdiag.p, w->d_Fdelta.p, n3);
     }
     hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
                        w->d_sw.p, w->d_sdw.p, w->d_grids.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0],
                        c->kk[2][1], c->kk[2][2], c->d_Fdiag.p, n3);
     HIPCHK(hipGetLastError());
   }
+  if (c->overlap && !ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));
+  hipLaunchKernelGGL(k_evb_slot0, dim3(std::min<size_t>(1024, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, c->d_force.p, w->d_Fdelta.p, c->d_Fdiag.p);
   phase_end(c, PH_EVB_RECIP);
-  // ---- 7. real-space / bonded / repulsion deltas of all units (ms_evb_diabat_force_energy, :1421)
-  phase_begin(c, PH_EVB_REAL);
-  {
-    // candidate sphere: centre = hydronium COM, radius = farthest special atom + max(cutoff, repulsion screen) + a little
-    const RegionRec* rh = find_region(w, c->hydronium);
-    double far2 = 0.0;
-    for (const UnitDesc& u : units) for (int k = 0; k < u.n_spec; ++k) {
-      double d2 = 0.0;
-      for (int q = 0; q < 3; ++q) { double d = u.spec[k].x[q] - rh->com[q]; d -= c->box[q] * std::floor(d / c->box[q] + 0.5); d2 += d * d; }
-      far2 = std::max(far2, d2);
-    }
-    const double Renv = std::sqrt(far2) + std::max(c->rc, w->screen_r) + 0.5;
-    hipLaunchKernelGGL(k_evb_candidates, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, rh->com[0], rh->com[1], rh->com[2], Renv * Renv, c->d_xyz.p, box,
-                       w->d_counter.p + 1, w->d_cand.p, w->d_counter.p);
-  }
-  hipLaunchKernelGGL(k_evb_env, dim3(envb, nu), dim3(256), 0, c->stream, w->d_counter.p + 1, w->d_cand.p, nu, d_units, w->d_tabs.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p, c->d_mol_of.p,
-                     c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->d_Fdiag.p, n3, part_units, part_stride);
-  hipLaunchKernelGGL(k_sum_rows, dim3(nu), dim3(256), 0, c->stream, nu, envb, part_stride, part_units, E_units_env);
-  hipLaunchKernelGGL(k_evb_special, dim3(nu), dim3(64), 0, c->stream, nu, d_units, w->d_tabs.p, c->d_moltypes.p, c->d_pair_par.p, c->nt,
-                     c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->alpha, 2.0 * c->alpha / c->pi_sqrt, c->conv, c->pi,
-                     c->d_Fdiag.p, n3, E_units_spec);
   // ---- 8. off-diagonal elements: few, latency-bound kernels writing only d_Foff -> side stream, beside the reciprocal space
   //         and the diagonal real-space deltas (forked in step 5b, joined here)
   HIPCHK(hipGetLastError());
-  phase_end(c, PH_EVB_REAL);
   if (ncp && c->overlap) HIPCHK(aux_join(c));
   // ---- 9. energies to the host, Hamiltonian
   const size_t nE = (size_t)2 * nu + ncp + ngrid + 3 * (size_t)ncp;

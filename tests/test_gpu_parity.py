@@ -107,6 +107,31 @@ def test_evb_against_reference(name):
     h.close()
 
 
+@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_sapt_s6"])
+def test_lds_tiled_pair_kernel(name):
+    """The optional LDS-staged pair kernel (one workgroup per cell, list entries local to the cell-neighbourhood tile; off by
+    default) against the reference, including the decode of its list back to the reference's half list."""
+    g = golden(name)
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    h.set_option("pair_tiles", 1)
+    h.construct_verlet_list()
+    vp, nl = h.get_verlet_list()
+    assert len(nl) == int(g["neighbor_count"]) and np.array_equal(vp, g["verlet_point"])
+    hh = hashlib.sha256()
+    for i in range(spec.n_atom):
+        hh.update(np.int32(i + 1).tobytes())
+        hh.update(np.sort(nl[vp[i] - 1:vp[i + 1] - 1]).astype("<i4").tobytes())
+    assert hh.hexdigest() == str(g["neighbor_pairs_sha256"])
+    h.zero_forces()
+    e = h.real_space_energy_force()
+    assert np.abs(h.get_forces() - (g["F_pair"] + g["F_intra_nb"])).max() < F_TOL
+    assert rel(e[0], g["E_elec_pair"][0]) < E_RTOL and rel(e[1], g["E_vdw_pair"][0]) < E_RTOL
+    en, F = h.calculate_total_force_energy()
+    assert np.abs(F - g["F_total"]).max() < F_TOL and rel(en["potential"], g["E_total"][0]) < E_RTOL
+    h.close()
+
+
 @pytest.mark.parametrize("name,evb", [("md_std_n6_s4", False), ("md_evb_n6_d2_s5", True)])
 def test_md_trajectory_against_reference(name, evb):
     g = golden(name)

@@ -364,10 +364,11 @@ int msevb_get_verlet_list(msevb_ctx* c, int* vp, int* nl, long* nn) {
   NEED_FINAL();
   if (!c->list_valid) FAIL(MSEVB_ERR_STATE, "no Verlet list");
   const int N = c->N;
-  std::vector<unsigned> st(N + 1);
-  std::vector<int> nb(c->n_nbr), perm(N);
-  HIPCHK(hipMemcpy(st.data(), c->d_nbr_start.p, (N + 1) * sizeof(unsigned), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(nb.data(), c->d_nbr.p, c->n_nbr * sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<unsigned> st(N), cnt(N);
+  std::vector<int> nb((size_t)N * c->nbr_cap), perm(N);
+  HIPCHK(hipMemcpy(st.data(), c->d_nbr_start.p, N * sizeof(unsigned), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(cnt.data(), c->d_nbr_count.p, N * sizeof(unsigned), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(nb.data(), c->d_nbr.p, nb.size() * sizeof(int), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(perm.data(), c->d_perm.p, N * sizeof(int), hipMemcpyDeviceToHost));
   std::vector<std::vector<int>> half(N);
   std::vector<int> cstart, keys;
@@ -385,7 +386,7 @@ int msevb_get_verlet_list(msevb_ctx* c, int* vp, int* nl, long* nn) {
       off[0] = 0;
       for (int s = 0; s < ns; ++s) off[s + 1] = off[s] + cstart[slots[s] + 1] - cstart[slots[s]];
     }
-    for (unsigned q = st[k]; q < st[k + 1]; ++q) {
+    for (unsigned q = st[k]; q < st[k] + cnt[k]; ++q) {
       int js = (int)((unsigned)nb[q] & NBR_IDX_MASK);
       if (c->pair_tiles) { int s = 0; while (s + 1 < ns && js >= off[s + 1]) ++s; js = cstart[slots[s]] + (js - off[s]); }
       const int j = perm[js];

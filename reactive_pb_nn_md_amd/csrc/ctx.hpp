@@ -197,6 +197,7 @@ struct msevb_ctx {
   DBuf<int> d_nbr;
   DBuf<char> d_sort_tmp;
   size_t n_nbr = 0;
+  unsigned nbr_cap = 0;          // row stride of the Verlet list (0: not sized yet)
   bool list_valid = false;
   int flag_verlet_list = 0;
   DBuf<double4> d_posq;        // sorted {x,y,z,q}

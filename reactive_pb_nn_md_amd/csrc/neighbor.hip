@@ -2,9 +2,10 @@
 // update_verlet_displacements, :1259).
 //
 // Layout in HBM: atoms are sorted by cell (cell edge >= verlet_cutoff) so that neighbours of consecutive atoms
-// are consecutive in memory; the list is a FULL CSR list in sorted numbering (every pair stored for both atoms),
-// so the pair kernel owns each atom's force and needs no fp64 atomics.  As a set of unordered pairs
-// {different molecule, r < verlet_cutoff} it is identical to the reference's half list.
+// are consecutive in memory; the list is a FULL list in sorted numbering (every pair stored for both atoms, so the
+// pair kernel owns each atom's force) with fixed-stride rows: row i = nbr[i * cap .. i * cap + count[i]), which lets a
+// rebuild run in one pass (no count + scan + fill).  As a set of unordered pairs {different molecule,
+// r < verlet_cutoff} it is identical to the reference's half list.
 #include <hipcub/hipcub.hpp>
 
 #include "ctx.hpp"
@@ -60,12 +61,14 @@ __global__ void k_tile_max(int ncell, int3 nc, const int* __restrict__ cell_star
   atomicMax(out, tot);
 }
 
-// one wavefront per sorted atom; FILL=false counts, FILL=true writes neighbours compactly (ballot + mbcnt).
+// One wavefront per sorted atom.  Rows have a fixed stride `cap` (row i starts at i * cap), so a rebuild is ONE pass: hits are
+// written compactly (ballot + mbcnt) while they fit, the true count goes to count[i], and the host re-runs with a larger stride only
+// when max(count) > cap.  FILL = false only counts (first build: sizes cap).
 // LOCAL: entries hold the neighbour's position inside the cell-neighbourhood tile instead of its sorted index.
 template <bool FILL, bool LOCAL>
 __global__ __launch_bounds__(256) void k_neighbors(int N, const double4* __restrict__ posq, const int* __restrict__ mol_s, const int* __restrict__ type_s,
                                                    const int* __restrict__ keys, const int* __restrict__ cell_start, BoxDev box, int3 nc,
-                                                   double rv2, unsigned* __restrict__ count, const unsigned* __restrict__ start,
+                                                   double rv2, unsigned cap, unsigned* __restrict__ count, unsigned* __restrict__ start,
                                                    int* __restrict__ nbr) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void k_neighbors(int N, const double4* __restr
   int slots[27];
   const int ns = cell_neighbourhood(keys[i], nc.x, nc.y, nc.z, slots);
   unsigned total = 0;
-  const unsigned base = FILL ? start[i] : 0u;
+  const unsigned base = (unsigned)i * cap;
   int off = 0;     // running offset of the current cell inside the tile
   for (int sl = 0; sl < ns; ++sl) {
     const int s = cell_start[slots[sl]], e = cell_start[slots[sl] + 1];
@@ -92,15 +95,25 @@ __global__ __launch_bounds__(256) void k_neighbors(int N, const double4* __restr
       }
       const unsigned long long m = __ballot(hit);
       if (FILL && hit) {
-        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        const unsigned slot = total + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         const unsigned idx = LOCAL ? (unsigned)(off + (j - s)) : (unsigned)j;
-        nbr[base + total + rank] = (int)(idx | ((unsigned)type_s[j] << NBR_IDX_BITS));
+        if (slot < cap) nbr[base + slot] = (int)(idx | ((unsigned)type_s[j] << NBR_IDX_BITS));
       }
       total += (unsigned)__popcll(m);
     }
     off += e - s;
   }
-  if (!FILL && lane == 0) count[i] = total;
+  if (lane == 0) { count[i] = total; if (FILL) start[i] = base; }
+}
+
+// {max, sum} of the row counts -> out[0] (unsigned), out[1..2] (64-bit sum)
+__global__ void k_count_stats(int N, const unsigned* __restrict__ count, unsigned* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned v = i < N ? count[i] : 0u;
+  unsigned mx = v;
+  unsigned long long sm = v;
+  for (int o = 32; o > 0; o >>= 1) { mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64)); sm += (unsigned long long)__shfl_xor((long long)sm, o, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], mx); atomicAdd((unsigned long long*)(out + 2), sm); }
 }
 
 // accumulate displacements since the last list build and reduce the two largest norms per block
@@ -192,9 +205,6 @@ int nb_build(msevb_ctx* c) {
   while ((1 << bits) < ncell) ++bits;
   size_t tmp = 0;
   HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, c->d_cell_keys_tmp.p, c->d_cell_of.p, c->d_perm_tmp.p, c->d_perm.p, N, 0, bits, c->stream));
-  size_t tmp2 = 0;
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, c->d_nbr_count.p, c->d_nbr_start.p, N + 1, c->stream));
-  if (tmp2 > tmp) tmp = tmp2;
   if (c->d_sort_tmp.alloc(tmp + 256)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (sort workspace)");
   size_t tb = c->d_sort_tmp.n;
   HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tb, c->d_cell_keys_tmp.p, c->d_cell_of.p, c->d_perm_tmp.p, c->d_perm.p, N, 0, bits, c->stream));
@@ -203,33 +213,51 @@ int nb_build(msevb_ctx* c) {
   const int wpb = 4;
   const dim3 grid((N + wpb - 1) / wpb), block(64 * wpb);
   const double rv2 = c->rv * c->rv;
-  HIPCHK(hipMemsetAsync(c->d_nbr_count.p, 0, (N + 1) * sizeof(unsigned), c->stream));
-  hipLaunchKernelGGL((k_neighbors<false, false>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
-                     c->d_nbr_count.p, (const unsigned*)nullptr, (int*)nullptr);
-  tb = c->d_sort_tmp.n;
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp.p, tb, c->d_nbr_count.p, c->d_nbr_start.p, N + 1, c->stream));
-  // tile size of the LDS-staged pair kernel (slot N of the count array is unused by the scan's consumers: reuse it as the max cell)
-  if (c->d_tile_max.alloc(1)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (tile size)");
-  HIPCHK(hipMemsetAsync(c->d_tile_max.p, 0, sizeof(int), c->stream));
-  hipLaunchKernelGGL(k_tile_max, dim3((ncell + 255) / 256), dim3(256), 0, c->stream, ncell, nc, c->d_cell_start.p, c->d_tile_max.p);
-  unsigned total = 0;
-  int tile_max = 0;
-  HIPCHK(hipMemcpyAsync(&total, c->d_nbr_start.p + N, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(&tile_max, c->d_tile_max.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  c->n_nbr = total;
-  c->tile_atoms_max = tile_max;
-  const size_t tile_bytes = (size_t)tile_max * sizeof(double4) + (size_t)c->nt * c->nt * sizeof(PairParam) + 1024;
-  c->pair_tiles = c->pair_tiles_opt != 0 && tile_bytes <= (size_t)PAIR_TILE_LDS_BYTES && (c->pair_tiles_opt == 1 || ncell >= PAIR_TILE_MIN_CELLS);
-  if (c->d_nbr.n < (size_t)total) {
-    if (c->d_nbr.alloc((size_t)(total * 1.2) + 1024)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (neighbour list)");
+  // tile size of the LDS-staged pair kernel + row statistics scratch: {tile_max, pad, count_max, pad, count_sum(64-bit)}
+  if (c->d_tile_max.alloc(8)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (list statistics)");
+  int* d_stats = c->d_tile_max.p;
+  int h_stats[8];
+  auto stats = [&](bool with_tile) -> int {       // one synchronisation per (re)build
+    HIPCHK(hipMemsetAsync(d_stats, 0, 8 * sizeof(int), c->stream));
+    if (with_tile) hipLaunchKernelGGL(k_tile_max, dim3((ncell + 255) / 256), dim3(256), 0, c->stream, ncell, nc, c->d_cell_start.p, d_stats);
+    hipLaunchKernelGGL(k_count_stats, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, c->d_nbr_count.p, (unsigned*)d_stats + 2);
+    HIPCHK(hipMemcpyAsync(h_stats, d_stats, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MSEVB_OK;
+  };
+  auto fill = [&]() -> int {
+    if (c->d_nbr.alloc((size_t)N * c->nbr_cap)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (neighbour list)");
+    if (c->pair_tiles)
+      hipLaunchKernelGGL((k_neighbors<true, true>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
+                         c->nbr_cap, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p);
+    else
+      hipLaunchKernelGGL((k_neighbors<true, false>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
+                         c->nbr_cap, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p);
+    return MSEVB_OK;
+  };
+  auto set_cap = [&](unsigned maxcount) { c->nbr_cap = ((unsigned)(maxcount * 1.15) + 64u + 63u) & ~63u; };
+  auto decide_tiles = [&](int tile_max) {
+    c->tile_atoms_max = tile_max;
+    const size_t tile_bytes = (size_t)tile_max * sizeof(double4) + (size_t)c->nt * c->nt * sizeof(PairParam) + 1024;
+    const bool fits = tile_bytes <= (size_t)PAIR_TILE_LDS_BYTES;
+    c->pair_tiles = fits && (c->pair_tiles_opt == 1 || (c->pair_tiles_opt == -1 && ncell >= PAIR_TILE_MIN_CELLS));
+  };
+  if (c->nbr_cap == 0) {      // first build: a counting pass sizes the row stride
+    hipLaunchKernelGGL((k_neighbors<false, false>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
+                       0u, c->d_nbr_count.p, (unsigned*)nullptr, (int*)nullptr);
+    CHK(stats(true));
+    set_cap((unsigned)h_stats[2]);
+    decide_tiles(h_stats[0]);
+    CHK(fill());
+  } else {                    // rebuild: one pass; the stride only grows when a row overflowed
+    if (c->pair_tiles_opt != 0) { CHK(stats(true)); decide_tiles(h_stats[0]); }    // the tile size fixes the entry format of this build
+    else c->pair_tiles = false;
+    CHK(fill());
+    CHK(stats(false));
+    if ((unsigned)h_stats[2] > c->nbr_cap) { set_cap((unsigned)h_stats[2]); CHK(fill()); CHK(stats(false)); }
   }
-  if (c->pair_tiles)
-    hipLaunchKernelGGL((k_neighbors<true, true>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
-                       (unsigned*)nullptr, c->d_nbr_start.p, c->d_nbr.p);
-  else
-    hipLaunchKernelGGL((k_neighbors<true, false>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
-                       (unsigned*)nullptr, c->d_nbr_start.p, c->d_nbr.p);
+  if ((double)N * c->nbr_cap >= 4294967296.0) FAIL(MSEVB_ERR_LIMIT, "Verlet list exceeds 32-bit row offsets");
+  c->n_nbr = (size_t)(((unsigned long long)(unsigned)h_stats[5] << 32) | (unsigned)h_stats[4]);
   HIPCHK(hipGetLastError());
   phase_end(c, PH_VERLET);
   c->list_valid = true;

@@ -24,16 +24,16 @@ constexpr unsigned NBR_NONE = 0xffffffffu;     // padding entry of a partial tri
 // and the Ewald table rows of both entries of a trip are fetched before either pair is finished.  `src` is the {x,y,z,q} array the
 // entries index: the cell-sorted array in HBM (k_pair) or the cell-neighbourhood tile in LDS (k_pair_tiles).
 template <bool SAPT, class PosPtr>
-__device__ __forceinline__ void pair_row(PosPtr src, const double4 pi, int ti, unsigned s, unsigned e, int lane, const int* __restrict__ nbr, unsigned nmask,
+__device__ __forceinline__ void pair_row(PosPtr src, const double4 pi, int ti, unsigned s, unsigned e, int lane, const int* __restrict__ nbr,
                                          const PairParam* sp, int nt, const double2* __restrict__ etab, double inv_dx, int emax,
                                          const double* __restrict__ tt, const double* __restrict__ dtt, const BoxDev& box, double rc2,
                                          double& fx, double& fy, double& fz, double& e_el, double& e_vdw) {
 #pragma clang fp contract(fast)
   unsigned k = s + lane;
-  unsigned e0 = k < e ? (unsigned)nbr[k & nmask] : NBR_NONE, e1 = k + 64 < e ? (unsigned)nbr[(k + 64) & nmask] : NBR_NONE;
+  unsigned e0 = k < e ? (unsigned)nbr[k] : NBR_NONE, e1 = k + 64 < e ? (unsigned)nbr[k + 64] : NBR_NONE;
   for (unsigned k0 = s; k0 < e; k0 += 128) {      // wave-uniform trip count
     const unsigned kn = k + 128;
-    const unsigned n0 = kn < e ? (unsigned)nbr[kn & nmask] : NBR_NONE, n1 = kn + 64 < e ? (unsigned)nbr[(kn + 64) & nmask] : NBR_NONE;
+    const unsigned n0 = kn < e ? (unsigned)nbr[kn] : NBR_NONE, n1 = kn + 64 < e ? (unsigned)nbr[kn + 64] : NBR_NONE;
     const bool va = e0 != NBR_NONE, vb = e1 != NBR_NONE;
     const double4 pa = src[va ? (e0 & NBR_IDX_MASK) : 0u], pb = src[vb ? (e1 & NBR_IDX_MASK) : 0u];
     double dxa = pi.x - pa.x, dya = pi.y - pa.y, dza = pi.z - pa.z;
@@ -59,81 +59,13 @@ __device__ __forceinline__ void pair_row(PosPtr src, const double4 pi, int ti, u
   }
 }
 
-// The list rows of the atoms i_begin, i_begin + stride, ... < i_end of one wavefront, 64 lanes x 2 entries per trip, as ONE
-// software-pipelined stream: while a trip is evaluated the entries of the next trip are already in flight - the next trip of the
-// same row or, on a row's last trip, the first trip of the wave's next atom, whose row bounds / position / type were requested one
-// row earlier.  (Per-atom loops left a two-latency bubble - row bounds, then first entries - in front of only ~4 trips of work.)
-// The Ewald table rows of both entries of a trip are fetched before either pair is finished.  `src` is the {x,y,z,q} array the
-// entries index: the cell-sorted array in HBM (k_pair) or the cell-neighbourhood tile in LDS (k_pair_tiles).
-template <bool SAPT, class PosPtr>
-__device__ __forceinline__ void pair_rows_stream(PosPtr src, int i_begin, int i_end, int stride, int lane, const double4* __restrict__ posq,
-                                                 const int* __restrict__ type_s, const unsigned* __restrict__ nbr_start, const int* __restrict__ nbr,
-                                                 const PairParam* sp, int nt, const double2* __restrict__ etab, double inv_dx, int emax,
-                                                 const double* __restrict__ tt, const double* __restrict__ dtt, const BoxDev& box, double rc2,
-                                                 const int* __restrict__ perm, double* __restrict__ F, double& e_el, double& e_vdw) {
-#pragma clang fp contract(fast)
-  int i = i_begin;
-  if (i >= i_end) return;
-  unsigned s = nbr_start[i], e = nbr_start[i + 1];
-  double4 pi = posq[i];
-  int ti = type_s[i];
-  int in = i + stride;
-  bool hn = in < i_end;
-  unsigned sn = hn ? nbr_start[in] : 0u, en = hn ? nbr_start[in + 1] : 0u;
-  double4 pn = hn ? posq[in] : pi;
-  int tn = hn ? type_s[in] : 0;
-  unsigned k = s;     // wave-uniform base of the current trip
-  unsigned e0 = k + lane < e ? (unsigned)nbr[k + lane] : NBR_NONE, e1 = k + 64 + lane < e ? (unsigned)nbr[k + 64 + lane] : NBR_NONE;
-  double fx = 0.0, fy = 0.0, fz = 0.0;
-  for (;;) {
-    const bool last = k + 128 >= e;
-    const unsigned nk = last ? sn : k + 128, nend = last ? en : e;     // an exhausted stream has sn == en == 0: nothing is loaded
-    const unsigned n0 = nk + lane < nend ? (unsigned)nbr[nk + lane] : NBR_NONE, n1 = nk + 64 + lane < nend ? (unsigned)nbr[nk + 64 + lane] : NBR_NONE;
-    const bool va = e0 != NBR_NONE, vb = e1 != NBR_NONE;
-    const double4 pa = src[va ? (e0 & NBR_IDX_MASK) : 0u], pb = src[vb ? (e1 & NBR_IDX_MASK) : 0u];
-    double dxa = pi.x - pa.x, dya = pi.y - pa.y, dza = pi.z - pa.z;
-    double dxb = pi.x - pb.x, dyb = pi.y - pb.y, dzb = pi.z - pb.z;
-    dxa -= box.L[0] * floor(dxa * box.invL[0] + 0.5); dya -= box.L[1] * floor(dya * box.invL[1] + 0.5); dza -= box.L[2] * floor(dza * box.invL[2] + 0.5);
-    dxb -= box.L[0] * floor(dxb * box.invL[0] + 0.5); dyb -= box.L[1] * floor(dyb * box.invL[1] + 0.5); dzb -= box.L[2] * floor(dzb * box.invL[2] + 0.5);
-    const double r2a = dxa * dxa + dya * dya + dza * dza, r2b = dxb * dxb + dyb * dyb + dzb * dzb;
-    const bool ina = va && r2a < rc2, inb = vb && r2b < rc2;
-    EwaldRows wa, wb;
-    ewald_fetch(ina ? r2a : rc2, inv_dx, emax, etab, wa);
-    ewald_fetch(inb ? r2b : rc2, inv_dx, emax, etab, wb);
-    if (ina) {
-      double fs, ee, ev;
-      pair_interaction_rows<SAPT>(r2a, pi.w * pa.w, sp[ti * nt + (int)(e0 >> NBR_IDX_BITS)], wa, tt, dtt, fs, ee, ev);
-      fx += fs * dxa; fy += fs * dya; fz += fs * dza; e_el += ee; e_vdw += ev;
-    }
-    if (inb) {
-      double fs, ee, ev;
-      pair_interaction_rows<SAPT>(r2b, pi.w * pb.w, sp[ti * nt + (int)(e1 >> NBR_IDX_BITS)], wb, tt, dtt, fs, ee, ev);
-      fx += fs * dxb; fy += fs * dyb; fz += fs * dzb; e_el += ee; e_vdw += ev;
-    }
-    e0 = n0; e1 = n1;
-    if (last) {      // row finished: reduce the 64 partial forces, hand the atom's force over, switch to the prefetched next row
-      fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
-      if (lane == 0) {
-        const int o = perm[i];
-        atomicAdd(&F[3 * o], fx); atomicAdd(&F[3 * o + 1], fy); atomicAdd(&F[3 * o + 2], fz);   // the per-molecule kernel may run concurrently
-      }
-      if (!hn) break;
-      i = in; s = sn; e = en; pi = pn; ti = tn; k = s;
-      fx = fy = fz = 0.0;
-      in = i + stride; hn = in < i_end;
-      sn = hn ? nbr_start[in] : 0u; en = hn ? nbr_start[in + 1] : 0u;
-      if (hn) { pn = posq[in]; tn = type_s[in]; }
-    } else k += 128;
-  }
-}
-
 template <bool SAPT>
 __global__ __launch_bounds__(256) void k_pair(int N, const double4* __restrict__ posq, const int* __restrict__ type_s,
-                                              const unsigned* __restrict__ nbr_start, const int* __restrict__ nbr,
+                                              const unsigned* __restrict__ nbr_start, const unsigned* __restrict__ nbr_count, const int* __restrict__ nbr,
                                               const PairParam* __restrict__ pairpar, int nt, const double2* __restrict__ etab, double inv_dx, int emax,
                                               const double* __restrict__ tt, const double* __restrict__ dtt, BoxDev box, double rc2,
                                               const int* __restrict__ perm, double* __restrict__ F, double* __restrict__ part_el,
-                                              double* __restrict__ part_vdw, unsigned nmask) {
+                                              double* __restrict__ part_vdw) {
   extern __shared__ PairParam sp[];
   for (int k = threadIdx.x; k < nt * nt; k += blockDim.x) sp[k] = pairpar[k];
   __shared__ double red[2][4];
@@ -146,9 +78,9 @@ __global__ __launch_bounds__(256) void k_pair(int N, const double4* __restrict__
   for (int i = i0 + wave; i < i1; i += wpb) {
     const double4 pi = posq[i];
     const int ti = type_s[i];
-    const unsigned s = nbr_start[i], e = nbr_start[i + 1];
+    const unsigned s = nbr_start[i], e = s + nbr_count[i];
     double fx = 0.0, fy = 0.0, fz = 0.0;
-    pair_row<SAPT>(posq, pi, ti, s, e, lane, nbr, nmask, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, fx, fy, fz, e_el, e_vdw);
+    pair_row<SAPT>(posq, pi, ti, s, e, lane, nbr, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, fx, fy, fz, e_el, e_vdw);
     fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
     if (lane == 0) {
       const int o = perm[i];
@@ -175,10 +107,10 @@ __global__ __launch_bounds__(256) void k_pair(int N, const double4* __restrict__
 // Waves of the block take the cell's atoms round-robin; everything else is as in k_pair.
 template <bool SAPT, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_pair_tiles(int3 nc, const int* __restrict__ cell_start, const double4* __restrict__ posq, const int* __restrict__ type_s,
-                                                     const unsigned* __restrict__ nbr_start, const int* __restrict__ nbr, const PairParam* __restrict__ pairpar, int nt,
+                                                     const unsigned* __restrict__ nbr_start, const unsigned* __restrict__ nbr_count, const int* __restrict__ nbr, const PairParam* __restrict__ pairpar, int nt,
                                                      const double2* __restrict__ etab, double inv_dx, int emax, const double* __restrict__ tt, const double* __restrict__ dtt,
                                                      BoxDev box, double rc2, const int* __restrict__ perm, double* __restrict__ F, double* __restrict__ part_el,
-                                                     double* __restrict__ part_vdw, unsigned nmask) {
+                                                     double* __restrict__ part_vdw) {
   extern __shared__ double4 tile[];                     // [tile atoms] then the pair-parameter table
   __shared__ int s_lo[27], s_off[28], s_ns;
   __shared__ double red[2][16];
@@ -201,24 +133,19 @@ __global__ __launch_bounds__(THREADS) void k_pair_tiles(int3 nc, const int* __re
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   double e_el = 0.0, e_vdw = 0.0;
-#ifdef PAIR_STREAM
-  pair_rows_stream<SAPT>(tile, cell_start[cidx] + wave, cell_start[cidx + 1], wpb, lane, posq, type_s, nbr_start, nbr, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, perm, F,
-                         e_el, e_vdw);
-#else
   const int i1 = cell_start[cidx + 1];
   for (int i = cell_start[cidx] + wave; i < i1; i += wpb) {
     const double4 pi = posq[i];
     const int ti = type_s[i];
-    const unsigned s = nbr_start[i], e = nbr_start[i + 1];
+    const unsigned s = nbr_start[i], e = s + nbr_count[i];
     double fx = 0.0, fy = 0.0, fz = 0.0;
-    pair_row<SAPT>(tile, pi, ti, s, e, lane, nbr, nmask, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, fx, fy, fz, e_el, e_vdw);
+    pair_row<SAPT>(tile, pi, ti, s, e, lane, nbr, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, fx, fy, fz, e_el, e_vdw);
     fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
     if (lane == 0) {
       const int o = perm[i];
       atomicAdd(&F[3 * o], fx); atomicAdd(&F[3 * o + 1], fy); atomicAdd(&F[3 * o + 2], fz);
     }
   }
-#endif
   e_el = wave_sum(e_el);
   e_vdw = wave_sum(e_vdw);
   if (lane == 0) { red[0][wave] = e_el; red[1][wave] = e_vdw; }
@@ -253,17 +180,17 @@ int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw) {
       attr_set[c->has_sapt ? 1 : 0] = true;
     }
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(c->has_sapt ? 512 : 1024), lds, c->stream, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), c->d_cell_start.p, c->d_posq.p, c->d_type_sorted.p,
-                       c->d_nbr_start.p, c->d_nbr.p, c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->erfc_grid, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->d_perm.p,
-                       c->d_force.p, c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS, c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS, 0xffffffffu);
+                       c->d_nbr_start.p, c->d_nbr_count.p, c->d_nbr.p, c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->erfc_grid, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->d_perm.p,
+                       c->d_force.p, c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS, c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS);
   } else {
     nblocks = round_up8((N + 7) / 8);      // 8 atoms per block, two per wave
     if (nblocks > 16384) nblocks = 16384;
     // force fields without a live SAPT term (every Buckingham coefficient zero, as in the CH3SO3H/H2O example) run the lean instantiation
     auto kern = c->has_sapt ? k_pair<true> : k_pair<false>;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), c->nt * c->nt * sizeof(PairParam), c->stream, N, c->d_posq.p, c->d_type_sorted.p,
-                       c->d_nbr_start.p, c->d_nbr.p, c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->erfc_grid, c->d_tt.p, c->d_dtt.p, box,
+                       c->d_nbr_start.p, c->d_nbr_count.p, c->d_nbr.p, c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->erfc_grid, c->d_tt.p, c->d_dtt.p, box,
                        c->rc * c->rc, c->d_perm.p, c->d_force.p, c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS,
-                       c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS, 0xffffffffu);
+                       c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS);
   }
   HIPCHK(hipGetLastError());
   phase_end(c, PH_PAIR);

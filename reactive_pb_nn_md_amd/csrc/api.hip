@@ -6,15 +6,18 @@
 
 
 struct SlotCounts { int n[N_SLOTS]; };
-__global__ void k_reduce_slots(SlotCounts cnt, const double* __restrict__ part, double* __restrict__ out) {
+__global__ __launch_bounds__(1024) void k_reduce_slots(SlotCounts cnt, const double* __restrict__ part, double* __restrict__ out) {
   const int slot = blockIdx.x, n = cnt.n[slot];
   if (n <= 0) return;
-  __shared__ double red[256];
-  double s = 0.0;
-  for (int k = threadIdx.x; k < n; k += 256) s += part[(size_t)slot * MAX_BLOCKS + k];
-  red[threadIdx.x] = s;
+  __shared__ double red[1024];
+  const double* p = part + (size_t)slot * MAX_BLOCKS;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;      // independent chains: the loads of a trip are all in flight together
+  int k = threadIdx.x;
+  for (; k + 3072 < n; k += 4096) { s0 += p[k]; s1 += p[k + 1024]; s2 += p[k + 2048]; s3 += p[k + 3072]; }
+  for (; k < n; k += 1024) s0 += p[k];
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+  for (int st = 512; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
   if (threadIdx.x == 0) out[slot] = red[0];
 }
 
@@ -24,7 +27,7 @@ int flush_reductions(msevb_ctx* c) {
   SlotCounts sc; bool any = false;
   for (int s = 0; s < N_SLOTS; ++s) { sc.n[s] = c->slot_count[s]; any |= sc.n[s] > 0; c->slot_count[s] = 0; }
   if (!any) return MSEVB_OK;
-  hipLaunchKernelGGL(k_reduce_slots, dim3(N_SLOTS), dim3(256), 0, c->stream, sc, c->d_partials.p, c->d_energies.p);
+  hipLaunchKernelGGL(k_reduce_slots, dim3(N_SLOTS), dim3(1024), 0, c->stream, sc, c->d_partials.p, c->d_energies.p);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
 }

@@ -634,7 +634,7 @@ struct EvbWork {   // persistent device scratch of one context
   DBuf<double> d_part, d_E, d_dVspec; DBuf<int> d_sbase, d_counter; DBuf<double> d_sw, d_sdw;
   DBuf<double2> d_grids; DBuf<RegionRec> d_region; DBuf<int> d_cand;
   DBuf<double> d_Fdelta;      // [n_diag][3N] real-space deltas of the diabats, accumulated on stream2 beside the reciprocal space
-  hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr; bool delta_dirty = true;
+  hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_E = nullptr, ev_fetch = nullptr; bool delta_dirty = true;
   DBuf<double> d_F11, d_pack;
   hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
   RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
@@ -827,6 +827,8 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipEventCreateWithFlags(&w->ev_region, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_fork2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_join2, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&w->ev_E, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&w->ev_fetch, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&w->h_region, REGION_FAST * sizeof(RegionRec), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&w->h_count, 64, hipHostMallocDefault));
   }
@@ -1056,6 +1058,30 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   HIPCHK(hipGetLastError());
   phase_end(c, PH_EVB_REAL, sr);
   if (c->overlap) HIPCHK(hipEventRecord(w->ev_join2, w->stream2));
+  // The Hamiltonian needs energies only, and all of them exist before the all-atom gather (the longest kernel of the EVB phase)
+  // starts: fetch them now on stream2 and let the host diagonalise while the gather runs.
+  const size_t nE = (size_t)2 * nu + ncp + ngrid + 3 * (size_t)ncp;
+  if (nE > w->hE_cap) {
+    if (w->h_E) HIPCHK(hipHostFree(w->h_E));
+    w->hE_cap = 2 * nE + 64;
+    HIPCHK(hipHostMalloc((void**)&w->h_E, w->hE_cap * sizeof(double), hipHostMallocDefault));
+  }
+  auto early_fetch = [&]() -> int {
+    CHK(flush_reductions(c));                                   // principal energy slots (main stream)
+    if (!c->overlap) {
+      HIPCHK(hipMemcpyAsync(w->h_E, w->d_E.p, nE * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpyAsync(c->h_energies, c->d_energies.p, N_SLOTS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      return MSEVB_OK;
+    }
+    HIPCHK(hipEventRecord(w->ev_E, c->stream));
+    HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0));        // stream2 is already behind the unit energies (6a)
+    if (ncp) { HIPCHK(hipEventRecord(c->ev_join, c->aux)); HIPCHK(hipStreamWaitEvent(w->stream2, c->ev_join, 0)); }   // couplings
+    HIPCHK(hipMemcpyAsync(w->h_E, w->d_E.p, nE * 8, hipMemcpyDeviceToHost, w->stream2));
+    HIPCHK(hipMemcpyAsync(c->h_energies, c->d_energies.p, N_SLOTS * sizeof(double), hipMemcpyDeviceToHost, w->stream2));
+    HIPCHK(hipEventRecord(w->ev_fetch, w->stream2));
+    return MSEVB_OK;
+  };
   // ---- 6b. reciprocal space of the owned diabats (calculate_reciprocal_space_pme, :1962)
   phase_begin(c, PH_EVB_RECIP);
   if (ngrid) {
@@ -1067,6 +1093,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     int nbk = 0;
     CHK(pme_convolve(c, w->d_grids.p, ngrid, part_grid, part_stride, &nbk));      // one batched FFT pair for all owned diabats
     hipLaunchKernelGGL(k_sum_rows, dim3(ngrid), dim3(256), 0, c->stream, ngrid, nbk, part_stride, part_grid, E_grid);
+    CHK(early_fetch());
     // all-atom gather, up to 8 grids per pass
     std::vector<int> gslots(ngrid);
     for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gslots[grid_of[d]] = diag_slot(c, D, d);
@@ -1087,22 +1114,16 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
                        c->kk[2][1], c->kk[2][2], c->d_Fdiag.p, n3);
     HIPCHK(hipGetLastError());
   }
+  if (!ngrid) CHK(early_fetch());
   if (c->overlap && !ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));
   hipLaunchKernelGGL(k_evb_slot0, dim3(std::min<size_t>(1024, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, c->d_force.p, w->d_Fdelta.p, c->d_Fdiag.p);
   phase_end(c, PH_EVB_RECIP);
   // ---- 8. off-diagonal elements: few, latency-bound kernels writing only d_Foff -> side stream, beside the reciprocal space
   //         and the diagonal real-space deltas (forked in step 5b, joined here)
   HIPCHK(hipGetLastError());
-  if (ncp && c->overlap) HIPCHK(aux_join(c));
+  if (ncp && c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));      // recorded on the side stream in early_fetch
   // ---- 9. energies to the host, Hamiltonian
-  const size_t nE = (size_t)2 * nu + ncp + ngrid + 3 * (size_t)ncp;
-  if (nE > w->hE_cap) {
-    if (w->h_E) HIPCHK(hipHostFree(w->h_E));
-    w->hE_cap = 2 * nE + 64;
-    HIPCHK(hipHostMalloc((void**)&w->h_E, w->hE_cap * sizeof(double), hipHostMallocDefault));
-  }
-  HIPCHK(hipMemcpyAsync(w->h_E, w->d_E.p, nE * 8, hipMemcpyDeviceToHost, c->stream));
-  CHK(fetch_energies(c));
+  if (c->overlap) HIPCHK(hipEventSynchronize(w->ev_fetch));     // energies left before the gather started (early_fetch)
   double en[MSEVB_N_ENERGY];
   total_force_collect(c, en);
   const double E_recip1 = c->E_recip;

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""GPU timeline of one MD step from a rocprofv3 kernel-trace database: union-busy time, idle gaps and what surrounds them."""
+import glob, os, sqlite3, sys
+d = sys.argv[1]
+f = glob.glob(os.path.join(d, "kt", "**", "*results.db"), recursive=True)[0]
+c = sqlite3.connect(f)
+rows = c.execute("select name,start,end,stream_id from kernels order by start").fetchall() if False else None
+cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+q = "select name,start,end from kernels order by start"
+rows = c.execute(q).fetchall()
+def short(n): return n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:38]
+# steps are delimited by k_evb_blend launches
+blend = [i for i, r in enumerate(rows) if "k_evb_blend" in r[0]]
+a, b = blend[-3], blend[-2]          # one full step between two blends (skip the last, possibly truncated)
+seg = rows[a:b + 1]
+t0 = seg[0][1]
+busy = 0; cur_end = seg[0][1]; gaps = []
+last = seg[0]
+for r in seg:
+    if r[1] > cur_end:
+        gaps.append((r[1] - cur_end, short(last[0]), short(r[0]), (cur_end - t0) / 1e3))
+        busy += 0
+    if r[2] > cur_end:
+        busy += r[2] - max(r[1], cur_end); cur_end = r[2]; last = r
+span = seg[-1][2] - seg[0][1]
+print("step span %.1f us, union busy %.1f us, idle %.1f us, kernels %d" % (span / 1e3, busy / 1e3, (span - busy) / 1e3, len(seg)))
+for g in sorted(gaps, reverse=True)[:14]:
+    print("  gap %7.1f us at t=%7.1f  after %-38s before %s" % (g[0] / 1e3, g[3], g[1], g[2]))
+print("-- sequence --")
+for r in seg:
+    print("%8.1f %8.1f  %s" % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, short(r[0])))

@@ -433,9 +433,10 @@ int msevb_intra_molecular_energy_force(msevb_ctx* c, double* e) {
 // the principal-diabat force call, everything enqueued on the stream; energies land in c->h_energies after fetch_energies()
 int total_force_enqueue(msevb_ctx* c) {
   // Verlet freshness: src/total_energy_forces.f90:30-39 (rebuild when the flag was raised by the previous call)
-  if (c->flag_verlet_list == 1 || !c->list_valid) { CHK(nb_build(c)); c->flag_verlet_list = 0; }
-  else { CHK(nb_check_displacements(c, 0, nullptr)); CHK(nb_refresh_sorted(c)); }
-  HIPCHK(hipMemsetAsync(c->d_force.p, 0, 3 * (size_t)c->N * 8, c->stream));
+  if (c->flag_verlet_list == 1 || !c->list_valid) {
+    CHK(nb_build(c)); c->flag_verlet_list = 0;
+    HIPCHK(hipMemsetAsync(c->d_force.p, 0, 3 * (size_t)c->N * 8, c->stream));
+  } else CHK(nb_step_refresh(c));
   if (c->overlap) {     // the pair loop (latency-bound) on the main stream; per-molecule terms and the PME front end beside it on the side stream
     HIPCHK(aux_fork(c));
     CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));                // main stream

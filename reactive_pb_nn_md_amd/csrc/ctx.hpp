@@ -241,6 +241,7 @@ struct msevb_ctx {
 // ---- cross-file entry points (all enqueue on c->stream) ----------------------------------------------
 int nb_build(msevb_ctx* c);                        // neighbor.hip
 int nb_refresh_sorted(msevb_ctx* c);               // gather posq/type in sorted order
+int nb_step_refresh(msevb_ctx* c);      // refresh + displacement check + zero forces (neighbor.hip)
 int nb_check_displacements(msevb_ctx* c, int initialize, int* flag);
 int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw);              // pair.hip
 int molecule_forces(msevb_ctx* c, int slot0, bool do_nb, bool do_bonded, hipStream_t st = nullptr);  // molecule.hip

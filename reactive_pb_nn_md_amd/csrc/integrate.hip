@@ -7,33 +7,6 @@
 
 namespace {
 
-__global__ void k_kick_drift(int N, double dt, const double* __restrict__ mass, const double* __restrict__ F, double* __restrict__ v, double* __restrict__ x) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 3 * N) return;
-  const double m = mass[i / 3];
-  const double vv = v[i] + dt / 2.0 / m * F[i] * 100.0;
-  v[i] = vv;
-  x[i] = x[i] + vv * dt;
-}
-// second half kick; flags forces > 1e5 ("force on atom is too big", src/md_integration.f90:523) in bad[0]
-__global__ void k_kick(int N, double dt, const double* __restrict__ mass, const double* __restrict__ F, double* __restrict__ v, int* __restrict__ bad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 3 * N) return;
-  const double f = F[i];
-  v[i] = v[i] + dt / 2.0 / mass[i / 3] * f * 100.0;
-  if (fabs(f) > 10e4) atomicExch(bad, i / 3 + 1);
-}
-__global__ void k_com_shift(int M, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms, const double* __restrict__ mass,
-                            double* __restrict__ x, BoxDev box) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
-  const int n = mol_natom[m];
-  double com[3] = {0, 0, 0}, mt = 0;
-  for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; const double ma = mass[a]; for (int d = 0; d < 3; ++d) com[d] += x[3 * a + d] * ma; mt += ma; }
-  double sh[3]; bool any = false;
-  for (int d = 0; d < 3; ++d) { const double f = com[d] / mt * box.invL[d]; sh[d] = f < 0.0 ? box.L[d] : (f > 1.0 ? -box.L[d] : 0.0); any |= sh[d] != 0.0; }
-  if (any) for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) x[3 * a + d] += sh[d]; }
-}
 // per-block partial sums of momentum (3) and kinetic energy
 __global__ __launch_bounds__(256) void k_momentum_ke(int N, const double* __restrict__ mass, const double* __restrict__ v, double* __restrict__ part) {
   __shared__ double red[4][256];
@@ -50,6 +23,58 @@ __global__ void k_remove_momentum(int N, const double* __restrict__ mass, const 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 3 * N) return;
   v[i] -= en[S_PX + i % 3] / (double)N / mass[i / 3];
+}
+
+// Fused step kernels of the device-resident MD loop -----------------------------------------------------------------------------
+// first half: one thread per molecule - removal of the centre-of-mass momentum measured at the end of the previous step (:125-177),
+// half kick + drift of the molecule's atoms (:469-486), then the molecule is shifted back into the box by its centre of mass
+__global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt, int remove, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms,
+                                                         const double* __restrict__ mass, const double* __restrict__ F, const double* __restrict__ en,
+                                                         double* __restrict__ v, double* __restrict__ x, BoxDev box) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int n = mol_natom[m];
+  double com[3] = {0, 0, 0}, mt = 0;
+  for (int k = 0; k < n; ++k) {
+    const int a = mol_atoms[m * MAX_MOL_ATOMS + k];
+    const double ma = mass[a];
+    for (int d = 0; d < 3; ++d) {
+      double vv = v[3 * a + d];
+      if (remove) vv -= en[S_PX + d] / (double)N / ma;
+      vv = vv + dt / 2.0 / ma * F[3 * a + d] * 100.0;
+      v[3 * a + d] = vv;
+      const double xx = x[3 * a + d] + vv * dt;
+      x[3 * a + d] = xx;
+      com[d] += xx * ma;
+    }
+    mt += ma;
+  }
+  double sh[3]; bool any = false;
+  for (int d = 0; d < 3; ++d) { const double f = com[d] / mt * box.invL[d]; sh[d] = f < 0.0 ? box.L[d] : (f > 1.0 ? -box.L[d] : 0.0); any |= sh[d] != 0.0; }
+  if (any) for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) x[3 * a + d] += sh[d]; }
+}
+// second half: one thread per atom - half kick with the |F| > 1e5 guard (:508-529) and the per-block partial sums of momentum and
+// kinetic energy of the kicked velocities (calculate_kinetic_energy, src/total_energy_forces.f90:106)
+__global__ __launch_bounds__(256) void k_step_second_half(int N, double dt, const double* __restrict__ mass, const double* __restrict__ F, double* __restrict__ v,
+                                                          int* __restrict__ bad, double* __restrict__ part) {
+  __shared__ double red[4][256];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double p[4] = {0, 0, 0, 0};
+  if (i < N) {
+    const double m = mass[i];
+    for (int d = 0; d < 3; ++d) {
+      const double f = F[3 * i + d];
+      const double vv = v[3 * i + d] + dt / 2.0 / m * f * 100.0;
+      v[3 * i + d] = vv;
+      if (fabs(f) > 10e4) atomicExch(bad, i + 1);
+      p[d] = m * vv; p[3] += 0.5 * m * vv * vv / 100.0;
+    }
+  }
+  for (int s = 0; s < 4; ++s) red[s][threadIdx.x] = p[s];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) for (int s = 0; s < 4; ++s) red[s][threadIdx.x] += red[s][threadIdx.x + st]; __syncthreads(); }
+  if (threadIdx.x == 0) { part[(size_t)S_PX * MAX_BLOCKS + blockIdx.x] = red[0][0]; part[(size_t)S_PY * MAX_BLOCKS + blockIdx.x] = red[1][0];
+    part[(size_t)S_PZ * MAX_BLOCKS + blockIdx.x] = red[2][0]; part[(size_t)S_KE * MAX_BLOCKS + blockIdx.x] = red[3][0]; }
 }
 
 }  // namespace
@@ -79,22 +104,40 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
   static thread_local DBuf<int> d_bad;
   if (d_bad.alloc(1)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed");
   HIPCHK(hipMemsetAsync(d_bad.p, 0, sizeof(int), c->stream));
+  // trajectory energies come back asynchronously: the EVB force call synchronises with the host on its own (Hamiltonian), so the loop
+  // itself never waits; without EVB the host needs the Verlet flag of every step and fetches the energies at its end
+  static thread_local double* h_ke = nullptr; static thread_local int h_ke_cap = 0;
+  if (n_steps > h_ke_cap) {
+    if (h_ke) HIPCHK(hipHostFree(h_ke));
+    h_ke_cap = n_steps + 64;
+    HIPCHK(hipHostMalloc((void**)&h_ke, h_ke_cap * sizeof(double), hipHostMallocDefault));
+  }
+  const int nbm = (M + 255) / 256, nba = (N + 255) / 256;
   for (int s = 0; s < n_steps; ++s) {
     phase_begin(c, PH_INTEGRATE);
-    hipLaunchKernelGGL(k_kick_drift, dim3((n3 + 255) / 256), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, c->d_xyz.p);
-    hipLaunchKernelGGL(k_com_shift, dim3((M + 255) / 256), dim3(256), 0, c->stream, M, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_mass.p, c->d_xyz.p, box);
+    hipLaunchKernelGGL(k_step_first_half, dim3(nbm), dim3(256), 0, c->stream, M, N, dt, s > 0 ? 1 : 0, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_mass.p, c->d_force.p,
+                       c->d_energies.p, c->d_vel.p, c->d_xyz.p, box);
     phase_end(c, PH_INTEGRATE);
     double epot = 0.0;
     if (use_evb) { CHK(evb_force_energy(c, &epot)); }
     else { CHK(total_force_enqueue(c)); }
-    hipLaunchKernelGGL(k_kick, dim3((n3 + 255) / 256), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p);
-    CHK(momentum_ke(c));
-    hipLaunchKernelGGL(k_remove_momentum, dim3((n3 + 255) / 256), dim3(256), 0, c->stream, N, c->d_mass.p, c->d_energies.p, c->d_vel.p);
+    hipLaunchKernelGGL(k_step_second_half, dim3(nba), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p, c->d_partials.p);
     HIPCHK(hipGetLastError());
-    CHK(fetch_energies(c));   // one host synchronisation per step: energies + Verlet flag
-    if (!use_evb) { double en[MSEVB_N_ENERGY]; total_force_collect(c, en); epot = en[MSEVB_E_POTENTIAL]; }
-    if (energies_out) { energies_out[2 * s] = epot; energies_out[2 * s + 1] = c->h_energies[S_KE]; }
+    CHK(reduce_partials(c, S_PX, nba)); CHK(reduce_partials(c, S_PY, nba)); CHK(reduce_partials(c, S_PZ, nba)); CHK(reduce_partials(c, S_KE, nba));
+    if (use_evb) {
+      CHK(flush_reductions(c));
+      HIPCHK(hipMemcpyAsync(h_ke + s, c->d_energies.p + S_KE, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      if (energies_out) energies_out[2 * s] = epot;
+    } else {
+      CHK(fetch_energies(c));   // one host synchronisation per step: energies + Verlet flag
+      double en[MSEVB_N_ENERGY]; total_force_collect(c, en);
+      if (energies_out) { energies_out[2 * s] = en[MSEVB_E_POTENTIAL]; energies_out[2 * s + 1] = c->h_energies[S_KE]; }
+    }
   }
+  if (n_steps > 0) hipLaunchKernelGGL(k_remove_momentum, dim3((n3 + 255) / 256), dim3(256), 0, c->stream, N, c->d_mass.p, c->d_energies.p, c->d_vel.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (use_evb && energies_out) for (int s = 0; s < n_steps; ++s) energies_out[2 * s + 1] = h_ke[s];
   int bad = 0;
   HIPCHK(hipMemcpy(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost));
   if (bad) { char b[96]; snprintf(b, sizeof b, "force on atom %d is too big", bad); FAIL(MSEVB_ERR_NUMERIC, b); }

@@ -152,6 +152,48 @@ __global__ __launch_bounds__(256) void k_displacements(int N, const double* __re
   if (threadIdx.x == 0) { part1[blockIdx.x] = s1[0]; part2[blockIdx.x] = s2[0]; }
 }
 
+// Per-step refresh between list builds, one launch: thread k = sorted slot k (atom i = perm[k]) re-gathers {x,y,z,q}, type and
+// molecule into the cell-sorted arrays, accumulates the atom's displacement since the last build (update_verlet_displacements,
+// src/general_routines.f90:1259) with the per-block top-2 norms, and zeroes the atom's force accumulator.
+__global__ __launch_bounds__(256) void k_step_refresh(int N, const int* __restrict__ perm, const double* __restrict__ xyz, const double* __restrict__ chg,
+                                                      const int* __restrict__ atype, const int* __restrict__ mol_of, double4* __restrict__ posq, int* __restrict__ type_s,
+                                                      int* __restrict__ mol_s, double* __restrict__ store, double* __restrict__ disp, BoxDev box,
+                                                      double* __restrict__ F, double* __restrict__ part1, double* __restrict__ part2) {
+  __shared__ double s1[256], s2[256];
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  double nrm = 0.0;
+  if (k < N) {
+    const int i = perm[k];
+    const double x[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    posq[k] = make_double4(x[0], x[1], x[2], chg[i]);
+    type_s[k] = atype[i];
+    mol_s[k] = mol_of[i];
+    double a[3];
+    for (int d = 0; d < 3; ++d) {
+      const double dc = x[d] - store[3 * i + d];
+      const double sh = floor(dc * box.invL[d] + 0.5) * box.L[d];
+      a[d] = disp[3 * i + d] + (dc - sh);
+      disp[3 * i + d] = a[d];
+      store[3 * i + d] = x[d];
+      F[3 * i + d] = 0.0;
+    }
+    nrm = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+  }
+  s1[threadIdx.x] = nrm;
+  s2[threadIdx.x] = 0.0;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+      double a1 = s1[threadIdx.x], a2 = s2[threadIdx.x], b1 = s1[threadIdx.x + st], b2 = s2[threadIdx.x + st];
+      double m1 = fmax(a1, b1), m2 = fmax(fmin(a1, b1), fmax(a2, b2));
+      s1[threadIdx.x] = m1;
+      s2[threadIdx.x] = m2;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part1[blockIdx.x] = s1[0]; part2[blockIdx.x] = s2[0]; }
+}
+
 __global__ void k_top2_final(int nb, const double* __restrict__ part1, const double* __restrict__ part2, double* __restrict__ out) {
   __shared__ double s1[256], s2[256];
   double m1 = 0, m2 = 0;
@@ -185,6 +227,18 @@ int nb_refresh_sorted(msevb_ctx* c) {
   const int N = c->N;
   hipLaunchKernelGGL(k_gather_sorted, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, c->d_perm.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p,
                      c->d_mol_of.p, c->d_posq.p, c->d_type_sorted.p, c->d_mol_sorted.p, c->d_inv_perm.p);
+  HIPCHK(hipGetLastError());
+  return MSEVB_OK;
+}
+
+// displacement check + sorted-array refresh + force zeroing of a step that keeps the current list (one kernel + the tiny top-2 finish)
+int nb_step_refresh(msevb_ctx* c) {
+  const int N = c->N, nb = (N + 255) / 256;
+  hipLaunchKernelGGL(k_step_refresh, dim3(nb), dim3(256), 0, c->stream, N, c->d_perm.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p, c->d_mol_of.p, c->d_posq.p,
+                     c->d_type_sorted.p, c->d_mol_sorted.p, c->d_xyz_store.p, c->d_disp.p, make_box(c), c->d_force.p,
+                     c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS);
+  hipLaunchKernelGGL(k_top2_final, dim3(1), dim3(256), 0, c->stream, nb, c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS,
+                     c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS, c->d_energies.p + S_MAXD1);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
 }

@@ -52,8 +52,10 @@ int msevb_create(msevb_ctx** out, int device_id) {
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->own_stream = true;
   HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
   HIPCHK(hipHostMalloc((void**)&c->h_energies, N_SLOTS * sizeof(double), hipHostMallocDefault));
   memset(c->h_energies, 0, N_SLOTS * sizeof(double));
   const char* names[PH_COUNT] = {"verlet list construction", "sorted atom refresh", "real space (pair loop)", "intra-molecular (non-bonded + bonded)",
@@ -68,7 +70,11 @@ int msevb_destroy(msevb_ctx* c) {
   if (!c) return MSEVB_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->aux2) (void)hipStreamSynchronize(c->aux2);
+  evb_release(c);
   if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); c->aux = nullptr; }
+  if (c->aux2) { (void)hipStreamSynchronize(c->aux2); (void)hipStreamDestroy(c->aux2); c->aux2 = nullptr; }
+  if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   pme_teardown(c);
@@ -437,11 +443,12 @@ int total_force_enqueue(msevb_ctx* c) {
     CHK(nb_build(c)); c->flag_verlet_list = 0;
     HIPCHK(hipMemsetAsync(c->d_force.p, 0, 3 * (size_t)c->N * 8, c->stream));
   } else CHK(nb_step_refresh(c));
-  if (c->overlap) {     // the pair loop (latency-bound) on the main stream; per-molecule terms and the PME front end beside it on the side stream
+  if (c->overlap) {     // three independent chains, all adding to the force with fp64 atomics; joined at the end
     HIPCHK(aux_fork(c));
-    CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));                // main stream
-    CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux));   // side stream, beside the pair loop ...
-    CHK(pme_forces(c, S_RECIP, true));                           // ... followed by the PME front end; joined before the gather
+    CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));                    // main: the pair loop (longest)
+    CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux2));      // aux2: per-molecule terms (few, long threads)
+    CHK(pme_forces(c, S_RECIP, true));                               // aux: stencils, spreading, FFTs, convolution, gather
+    HIPCHK(aux_join(c));
   } else {
     CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
     CHK(molecule_forces(c, S_ELEC_INTRA, true, true));

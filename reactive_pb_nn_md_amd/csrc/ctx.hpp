@@ -141,8 +141,11 @@ struct msevb_ctx {
   bool own_stream = false;
   // internal side stream for small latency-bound kernels that are independent of the main chain (per-molecule terms next to
   // the pair loop / charge spreading, off-diagonal EVB elements next to the diabat reciprocal space); fork/join by events
-  hipStream_t aux = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // aux : PME front end + principal reciprocal gather, later the off-diagonal EVB elements
+  // aux2: per-molecule terms, and for EVB the neighbourhood fetch, descriptor upload, diagonal real-space deltas, energy download
+  // (three streams in all: with more, ROCm's 4 hardware queues alias and the intended overlap is lost)
+  hipStream_t aux = nullptr, aux2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   hipStream_t pme_st = nullptr;      // non-null while the PME front end is being enqueued on the side stream
   bool overlap = true;
   int pair_tiles_opt = 0;        // 0 off (default: measured slower than the global-gather kernel once the PME front end overlaps it), 1 on when it fits, -1 auto
@@ -241,6 +244,7 @@ struct msevb_ctx {
 // ---- cross-file entry points (all enqueue on c->stream) ----------------------------------------------
 int nb_build(msevb_ctx* c);                        // neighbor.hip
 int nb_refresh_sorted(msevb_ctx* c);               // gather posq/type in sorted order
+void evb_release(msevb_ctx* c);        // evb.hip: per-context EVB scratch
 int nb_step_refresh(msevb_ctx* c);      // refresh + displacement check + zero forces (neighbor.hip)
 int nb_check_displacements(msevb_ctx* c, int initialize, int* flag);
 int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw);              // pair.hip
@@ -289,9 +293,19 @@ inline void phase_end(msevb_ctx* c, int p, hipStream_t st = nullptr) {
   (void)hipEventRecord(t.ev[t.used], st);
   t.used += 1;
 }
-// fork: the side stream starts after everything enqueued so far on the main stream; join: the main stream waits for it
-inline hipError_t aux_fork(msevb_ctx* c) { hipError_t e = hipEventRecord(c->ev_fork, c->stream); return e != hipSuccess ? e : hipStreamWaitEvent(c->aux, c->ev_fork, 0); }
-inline hipError_t aux_join(msevb_ctx* c) { hipError_t e = hipEventRecord(c->ev_join, c->aux); return e != hipSuccess ? e : hipStreamWaitEvent(c->stream, c->ev_join, 0); }
+inline hipError_t aux_fork(msevb_ctx* c) {     // both side streams continue from the current end of the main stream
+  hipError_t e = hipEventRecord(c->ev_fork, c->stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(c->aux, c->ev_fork, 0);
+  if (e == hipSuccess) e = hipStreamWaitEvent(c->aux2, c->ev_fork, 0);
+  return e;
+}
+inline hipError_t aux_join(msevb_ctx* c) {     // the main stream waits for what both side streams hold so far
+  hipError_t e = hipEventRecord(c->ev_join, c->aux);
+  if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+  if (e == hipSuccess) e = hipEventRecord(c->ev_join2, c->aux2);
+  if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join2, 0);
+  return e;
+}
 inline void phase_harvest(msevb_ctx* c) {
   for (int p = 0; p < PH_COUNT; ++p) {
     PhaseTimer& t = c->ph[p];

@@ -822,7 +822,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   // ---- 1. neighbourhood of the hydronium -> host on a side stream (replaces the all-molecule scans of src/ms_evb.f90:724);
   //         it only needs the positions, so it overlaps with the principal diabat's force kernels
   if (!w->stream2) {
-    HIPCHK(hipStreamCreateWithFlags(&w->stream2, hipStreamNonBlocking));
+    w->stream2 = c->aux2;
     HIPCHK(hipEventCreateWithFlags(&w->ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_region, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_fork2, hipEventDisableTiming));
@@ -989,8 +989,11 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   }
   if (nu > MAX_UNITS || ncp > MAX_DIABATS || nra > MAX_DIABATS * MAX_SPEC) FAIL(MSEVB_ERR_LIMIT, "EVB descriptor staging too small");
   const size_t off_u = 0, off_c = off_u + (size_t)nu * sizeof(UnitDesc), off_r = off_c + (size_t)ncp * sizeof(CouplingDesc), desc_bytes = off_r + (size_t)nra * sizeof(RecipAtom);
+  // "setup" stream: aux2 when overlapping - it already holds this step's neighbourhood fetch and per-molecule kernel; descriptors,
+  // zero-fills and everything that needs only positions + descriptors follow there, beside the principal force still running elsewhere
+  const hipStream_t ss = c->overlap ? w->stream2 : c->stream;
   if (desc_bytes > w->desc_cap) {
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipDeviceSynchronize());
     if (w->h_desc) HIPCHK(hipHostFree(w->h_desc));
     w->desc_cap = desc_bytes + desc_bytes / 2 + 4096;
     HIPCHK(hipHostMalloc((void**)&w->h_desc, w->desc_cap, hipHostMallocDefault));
@@ -999,7 +1002,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   memcpy(w->h_desc + off_u, units.data(), (size_t)nu * sizeof(UnitDesc));
   if (ncp) memcpy(w->h_desc + off_c, cps.data(), (size_t)ncp * sizeof(CouplingDesc));
   if (nra) memcpy(w->h_desc + off_r, ras.data(), (size_t)nra * sizeof(RecipAtom));
-  HIPCHK(hipMemcpyAsync(w->d_desc.p, w->h_desc, desc_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(w->d_desc.p, w->h_desc, desc_bytes, hipMemcpyHostToDevice, ss));
   const UnitDesc* d_units = (const UnitDesc*)(w->d_desc.p + off_u);
   const CouplingDesc* d_cps = (const CouplingDesc*)(w->d_desc.p + off_c);
   const RecipAtom* d_ra = (const RecipAtom*)(w->d_desc.p + off_r);
@@ -1014,16 +1017,24 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   {   // delta store of the diagonal real-space terms: zero on first use / after a resize / after a failed call, then self-cleaning
     const size_t need = (size_t)n_diag * n3;
     if (w->d_Fdelta.n < need) { if (w->d_Fdelta.alloc(need)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB delta store)"); w->delta_dirty = true; }
-    if (w->delta_dirty) { HIPCHK(hipMemsetAsync(w->d_Fdelta.p, 0, w->d_Fdelta.n * 8, c->stream)); w->delta_dirty = false; }
+    if (w->delta_dirty) { HIPCHK(hipMemsetAsync(w->d_Fdelta.p, 0, w->d_Fdelta.n * 8, ss)); w->delta_dirty = false; }
   }
   // every element of an owned off-diagonal slot is written by k_evb_coupling / k_evb_coupling_finish; foreign slots are zeroed for the all-gather
-  if (n_off && c->n_ranks > 1) HIPCHK(hipMemsetAsync(c->d_Foff.p, 0, (size_t)n_off * n3 * 8, c->stream));
-  if (n_off && c->n_ranks > 1) HIPCHK(hipMemsetAsync(c->d_Fdiag.p + n3, 0, (size_t)n_off * n3 * 8, c->stream));
-  // ---- 5b. off-diagonal elements (evb_diabatic_coupling, :1021)
+  if (n_off && c->n_ranks > 1) HIPCHK(hipMemsetAsync(c->d_Foff.p, 0, (size_t)n_off * n3 * 8, ss));
+  if (n_off && c->n_ranks > 1) HIPCHK(hipMemsetAsync(c->d_Fdiag.p + n3, 0, (size_t)n_off * n3 * 8, ss));
+  if (w->dv_dirty) { HIPCHK(hipMemsetAsync(w->d_dVspec.p, 0, w->d_dVspec.n * 8, ss)); w->dv_dirty = false; }   // afterwards k_evb_coupling_finish leaves it zeroed
+  // B-spline stencils of the special atoms in their new states (needs descriptors only)
+  if (ngrid) hipLaunchKernelGGL(k_evb_spec_prep, dim3((nra + 63) / 64), dim3(64), 0, ss, nra, d_ra, K, c->spline_grid, c->kk[0][0], c->kk[0][1], c->kk[0][2],
+                                c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p);
+  if (c->overlap) {      // descriptors + special stencils are on the device: the main stream and the off-diagonal chain may use them
+    HIPCHK(hipEventRecord(w->ev_fork2, ss));
+    HIPCHK(hipStreamWaitEvent(c->stream, w->ev_fork2, 0));
+    HIPCHK(hipStreamWaitEvent(c->aux, w->ev_fork2, 0));
+  }
+  // ---- 5b. off-diagonal elements (evb_diabatic_coupling, :1021): few, latency-bound kernels writing only d_Foff; on `aux` behind the
+  //          principal reciprocal space
   if (ncp) {
     hipStream_t so = c->overlap ? c->aux : c->stream;
-    if (c->overlap) HIPCHK(aux_fork(c));
-    if (w->dv_dirty) { HIPCHK(hipMemsetAsync(w->d_dVspec.p, 0, w->d_dVspec.n * 8, so)); w->dv_dirty = false; }   // afterwards k_evb_coupling_finish leaves it zeroed
     hipLaunchKernelGGL(k_evb_coupling, dim3(cpb, ncp), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_chg.p,
                        c->d_mass.p, c->d_atype.p, w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p);
     hipLaunchKernelGGL(k_sum_rows, dim3(ncp), dim3(256), 0, so, ncp, cpb, part_stride, part_cp, E_cp_env);
@@ -1033,8 +1044,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipGetLastError());
   }
   // ---- 6a. real-space / bonded / repulsion deltas of all units (ms_evb_diabat_force_energy, :1421)
-  const hipStream_t sr = c->overlap ? w->stream2 : c->stream;     // beside the reciprocal space of the diabats (joined before the gather)
-  if (c->overlap) { HIPCHK(hipEventRecord(w->ev_fork2, c->stream)); HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_fork2, 0)); }
+  const hipStream_t sr = ss;     // on aux2 behind the descriptors: beside the principal force and the reciprocal space of the diabats
   phase_begin(c, PH_EVB_REAL, sr);
   {
     // candidate sphere: centre = hydronium COM, radius = farthest special atom + max(cutoff, repulsion screen) + a little
@@ -1086,8 +1096,6 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   phase_begin(c, PH_EVB_RECIP);
   if (ngrid) {
     hipLaunchKernelGGL(k_evb_grid_init, dim3(2048), dim3(256), 0, c->stream, K3, ngrid, c->d_Q.p, w->d_grids.p);
-    hipLaunchKernelGGL(k_evb_spec_prep, dim3((nra + 63) / 64), dim3(64), 0, c->stream, nra, d_ra, K, c->spline_grid, c->kk[0][0], c->kk[0][1], c->kk[0][2],
-                       c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p);
     hipLaunchKernelGGL(k_evb_patch, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, w->d_sbase.p, w->d_sw.p, w->d_grids.p);
     HIPCHK(hipGetLastError());
     int nbk = 0;
@@ -1189,6 +1197,26 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   }
   rearm.ok = true;
   return MSEVB_OK;
+}
+
+// frees the per-context EVB scratch (called by msevb_destroy while the context's streams still exist)
+void evb_release(msevb_ctx* c) {
+  auto it = g_work.find(c);
+  if (it == g_work.end()) return;
+  EvbWork* w = it->second;
+  if (w) {
+    DBuf<double>* db[] = {&w->d_exch, &w->d_part, &w->d_E, &w->d_dVspec, &w->d_sw, &w->d_sdw, &w->d_Fdelta, &w->d_F11, &w->d_pack};
+    for (auto b : db) b->release();
+    w->d_tabs.release(); w->d_sbase.release(); w->d_counter.release(); w->d_grids.release(); w->d_region.release(); w->d_cand.release(); w->d_desc.release();
+    hipEvent_t* ev[] = {&w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region};
+    for (auto e : ev) if (*e) (void)hipEventDestroy(*e);
+    if (w->h_region) (void)hipHostFree(w->h_region);
+    if (w->h_count) (void)hipHostFree(w->h_count);
+    if (w->h_desc) (void)hipHostFree(w->h_desc);
+    if (w->h_E) (void)hipHostFree(w->h_E);
+    delete w;
+  }
+  g_work.erase(it);
 }
 
 extern "C" {

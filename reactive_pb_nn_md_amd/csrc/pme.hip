@@ -145,7 +145,7 @@ __global__ void k_pme_real(size_t K3, const double2* __restrict__ grid, double* 
 __global__ __launch_bounds__(256) void k_pme_gather(int N, int K, const double* __restrict__ chg, const int* __restrict__ base,
                                                     const double* __restrict__ w, const double* __restrict__ dw, const double* __restrict__ theta,
                                                     double conv, double k00, double k01, double k02, double k10, double k11, double k12,
-                                                    double k20, double k21, double k22, double* __restrict__ F_recip, double* __restrict__ F) {
+                                                    double k20, double k21, double k22, double* __restrict__ F_recip, double* __restrict__ F, int atomic) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = t >> 3, sub = t & 7;
   double f1 = 0.0, f2 = 0.0, f3 = 0.0;
@@ -179,7 +179,10 @@ __global__ __launch_bounds__(256) void k_pme_gather(int N, int K, const double* 
     const double fy = -Kd * (k01 * f1 + k11 * f2 + k21 * f3);
     const double fz = -Kd * (k02 * f1 + k12 * f2 + k22 * f3);
     F_recip[3 * i] = fx; F_recip[3 * i + 1] = fy; F_recip[3 * i + 2] = fz;
-    if (F) { F[3 * i] += fx; F[3 * i + 1] += fy; F[3 * i + 2] += fz; }
+    if (F) {
+      if (atomic) { atomicAdd(&F[3 * i], fx); atomicAdd(&F[3 * i + 1], fy); atomicAdd(&F[3 * i + 2], fz); }     // beside the pair loop
+      else { F[3 * i] += fx; F[3 * i + 1] += fy; F[3 * i + 2] += fz; }
+    }
   }
 }
 
@@ -275,8 +278,8 @@ int pme_prepare_atoms(msevb_ctx* c, bool with_indices) {
 
 int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add) {
   const int N = c->N;
-  hipLaunchKernelGGL(k_pme_gather, dim3((N * 8 + 255) / 256), dim3(256), 0, c->stream, N, c->K, chg, c->d_base.p, c->d_w.p, c->d_dw.p, c->d_theta.p, c->conv, c->kk[0][0],
-                     c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add);
+  hipLaunchKernelGGL(k_pme_gather, dim3((N * 8 + 255) / 256), dim3(256), 0, pme_stream(c), N, c->K, chg, c->d_base.p, c->d_w.p, c->d_dw.p, c->d_theta.p, c->conv, c->kk[0][0],
+                     c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, c->pme_st ? 1 : 0);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
 }
@@ -284,8 +287,8 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
 int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux) {
   const int N = c->N, K = c->K;
   const size_t K3 = (size_t)K * K * K;
-  // join_aux: the caller has forked the side stream; the whole front end (stencils, spreading, FFTs, convolution) goes there and
-  // overlaps the pair loop on the main stream; the gather (adds to the total force without atomics) runs on the main stream after the join
+  // join_aux: the caller has forked the side streams; the whole reciprocal space goes to `aux` and overlaps the pair loop on the main
+  // stream (the gather then adds to the total force with atomics); the caller joins
   c->pme_st = join_aux ? c->aux : nullptr;
   const hipStream_t st = pme_stream(c);
   phase_begin(c, PH_SPREAD, st);
@@ -315,10 +318,9 @@ int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux) {
   CHK(reduce_partials(c, slot_recip, nbk));
   hipLaunchKernelGGL(k_pme_real, dim3(1024), dim3(256), 0, st, K3, c->d_grid.p, c->d_theta.p);
   phase_end(c, PH_FFT, st);
-  c->pme_st = nullptr;
-  if (join_aux) HIPCHK(aux_join(c));
-  phase_begin(c, PH_GATHER);
+  phase_begin(c, PH_GATHER, st);
   CHK(pme_gather(c, c->d_grid.p, c->d_chg.p, c->d_force_recip.p, c->d_force.p));
-  phase_end(c, PH_GATHER);
+  phase_end(c, PH_GATHER, st);
+  c->pme_st = nullptr;
   return MSEVB_OK;
 }

@@ -447,8 +447,9 @@ int total_force_enqueue(msevb_ctx* c) {
     HIPCHK(aux_fork(c));
     CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));                    // main: the pair loop (longest)
     CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux2));      // aux2: per-molecule terms (few, long threads)
-    CHK(pme_forces(c, S_RECIP, true));                               // aux: stencils, spreading, FFTs, convolution, gather
-    HIPCHK(aux_join(c));
+    CHK(pme_forces(c, S_RECIP, true));                               // aux: stencils, spreading, FFTs, convolution; gather on main
+    HIPCHK(hipEventRecord(c->ev_join2, c->aux2));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
   } else {
     CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
     CHK(molecule_forces(c, S_ELEC_INTRA, true, true));

@@ -271,7 +271,7 @@ extern "C" void total_force_collect(msevb_ctx* c, double* en);
 extern "C" int upload_topology(msevb_ctx* c);
 int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part_stride, int* nblocks);
 int pme_prepare_atoms(msevb_ctx* c, bool with_indices);
-int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add);
+int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic = false);
 
 constexpr int MAX_BLOCKS = 65536;
 enum Slot { S_ELEC_PAIR = 0, S_VDW_PAIR, S_ELEC_INTRA, S_VDW_INTRA, S_BOND, S_ANGLE, S_DIH, S_RECIP, S_KE, S_PX, S_PY, S_PZ, S_MAXD1, S_MAXD2, S_EVB0, N_SLOTS = 32 };

@@ -426,6 +426,7 @@ __global__ __launch_bounds__(256) void k_evb_coupling(int N, int n_cp, const Cou
   __shared__ CouplingDesc cp;
   __shared__ double sF[MAX_SPEC][3];
   __shared__ double red[256];
+  __shared__ double stage[3 * 256];
   const int ic = blockIdx.y;
   {
     const int* src = (const int*)&cps[ic]; int* dst = (int*)&cp;
@@ -438,18 +439,21 @@ __global__ __launch_bounds__(256) void k_evb_coupling(int N, int n_cp, const Cou
   double fz[2 * MAX_MOL_ATOMS][3];
 #pragma unroll
   for (int a = 0; a < 2 * MAX_MOL_ATOMS; ++a) fz[a][0] = fz[a][1] = fz[a][2] = 0.0;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
-    const int m = mol_of[j];
-    bool special = false;
+  // block-uniform trip count: the 256 x 3 forces of a trip are staged through LDS and stored as 768 consecutive doubles (three
+  // 8-B stores per thread at a 24-B stride cost 10x their bytes in HBM write traffic)
+  for (int j0 = blockIdx.x * blockDim.x; j0 < N; j0 += gridDim.x * blockDim.x) {
+    const int j = j0 + threadIdx.x;
+    double fj[3] = {0, 0, 0};
+    bool special = j >= N;
+    const int m = special ? 0 : mol_of[j];
     for (int k = 0; k < cp.n_mols; ++k) special |= (cp.mols[k] == m);
-    if (special) continue;
+    if (!special) {
     const int n = mol_natom[m];
     double com[3] = {0, 0, 0}, mt = 0;
     for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; const double ma = mass[a]; for (int d = 0; d < 3; ++d) com[d] += xyz[3 * a + d] * ma; mt += ma; }
     double sh[3];
     for (int d = 0; d < 3; ++d) { com[d] /= mt; sh[d] = floor((com[d] - cp.zc[d]) * box.invL[d] + 0.5) * box.L[d]; }
     const double qj = chg[j];
-    double fj[3] = {0, 0, 0};
     for (int side = 0; side < 2; ++side) {
       const int na = side == 0 ? cp.nD : cp.nA;
       const int* lst = side == 0 ? cp.D_at : cp.A_at;
@@ -465,7 +469,11 @@ __global__ __launch_bounds__(256) void k_evb_coupling(int N, int n_cp, const Cou
         for (int d = 0; d < 3; ++d) { fj[d] -= g * rij[d]; fz[side * cp.nD + q][d] += g * rij[d]; }
       }
     }
-    for (int d = 0; d < 3; ++d) F[3 * j + d] = fj[d];    // dVex of this atom; scaled by -A in k_evb_coupling_finish
+    }
+    __syncthreads();
+    for (int d = 0; d < 3; ++d) stage[3 * threadIdx.x + d] = fj[d];    // dVex of this atom (0 for special atoms: k_evb_coupling_finish assigns them); scaled by -A later
+    __syncthreads();
+    for (int q = threadIdx.x; q < 3 * (int)blockDim.x; q += blockDim.x) if (3 * j0 + q < 3 * N) F[3 * (size_t)j0 + q] = stage[q];
   }
   // forces on the Zundel atoms: per-thread registers -> wave shuffle -> one LDS add per wave
   for (int a = 0; a < cp.nD + cp.nA; ++a) for (int d = 0; d < 3; ++d) {
@@ -634,7 +642,7 @@ struct EvbWork {   // persistent device scratch of one context
   DBuf<double> d_part, d_E, d_dVspec; DBuf<int> d_sbase, d_counter; DBuf<double> d_sw, d_sdw;
   DBuf<double2> d_grids; DBuf<RegionRec> d_region; DBuf<int> d_cand;
   DBuf<double> d_Fdelta;      // [n_diag][3N] real-space deltas of the diabats, accumulated on stream2 beside the reciprocal space
-  hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_E = nullptr, ev_fetch = nullptr; bool delta_dirty = true;
+  hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_E = nullptr, ev_fetch = nullptr, ev_cpl = nullptr, ev_flush = nullptr; bool delta_dirty = true;
   DBuf<double> d_F11, d_pack;
   hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
   RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
@@ -827,6 +835,8 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipEventCreateWithFlags(&w->ev_region, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_fork2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_join2, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&w->ev_cpl, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&w->ev_flush, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_E, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_fetch, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&w->h_region, REGION_FAST * sizeof(RegionRec), hipHostMallocDefault));
@@ -1031,18 +1041,6 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipStreamWaitEvent(c->stream, w->ev_fork2, 0));
     HIPCHK(hipStreamWaitEvent(c->aux, w->ev_fork2, 0));
   }
-  // ---- 5b. off-diagonal elements (evb_diabatic_coupling, :1021): few, latency-bound kernels writing only d_Foff; on `aux` behind the
-  //          principal reciprocal space
-  if (ncp) {
-    hipStream_t so = c->overlap ? c->aux : c->stream;
-    hipLaunchKernelGGL(k_evb_coupling, dim3(cpb, ncp), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_chg.p,
-                       c->d_mass.p, c->d_atype.p, w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p);
-    hipLaunchKernelGGL(k_sum_rows, dim3(ncp), dim3(256), 0, so, ncp, cpb, part_stride, part_cp, E_cp_env);
-    hipLaunchKernelGGL(k_evb_coupling_finish, dim3(ncp), dim3(64), 0, so, ncp, d_cps, w->d_exch.p, c->d_mass.p, box, c->conv, E_cp_env,
-                       w->d_dVspec.p, c->d_Foff.p, n3, d_cpout);
-    hipLaunchKernelGGL(k_evb_scale, dim3(256, ncp), dim3(256), 0, so, n3, ncp, d_cps, d_cpout, c->d_Foff.p, n3);
-    HIPCHK(hipGetLastError());
-  }
   // ---- 6a. real-space / bonded / repulsion deltas of all units (ms_evb_diabat_force_energy, :1421)
   const hipStream_t sr = ss;     // on aux2 behind the descriptors: beside the principal force and the reciprocal space of the diabats
   phase_begin(c, PH_EVB_REAL, sr);
@@ -1068,6 +1066,19 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   HIPCHK(hipGetLastError());
   phase_end(c, PH_EVB_REAL, sr);
   if (c->overlap) HIPCHK(hipEventRecord(w->ev_join2, w->stream2));
+  // ---- 6a'. off-diagonal elements (evb_diabatic_coupling, :1021): few, latency-bound kernels writing only d_Foff; on aux2 behind the
+  //           diagonal deltas (the all-atom gather waits for those, only the blend for these)
+  if (ncp) {
+    hipStream_t so = ss;
+    hipLaunchKernelGGL(k_evb_coupling, dim3(cpb, ncp), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_chg.p,
+                       c->d_mass.p, c->d_atype.p, w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p);
+    hipLaunchKernelGGL(k_sum_rows, dim3(ncp), dim3(256), 0, so, ncp, cpb, part_stride, part_cp, E_cp_env);
+    hipLaunchKernelGGL(k_evb_coupling_finish, dim3(ncp), dim3(64), 0, so, ncp, d_cps, w->d_exch.p, c->d_mass.p, box, c->conv, E_cp_env,
+                       w->d_dVspec.p, c->d_Foff.p, n3, d_cpout);
+    hipLaunchKernelGGL(k_evb_scale, dim3(256, ncp), dim3(256), 0, so, n3, ncp, d_cps, d_cpout, c->d_Foff.p, n3);
+    HIPCHK(hipGetLastError());
+    if (c->overlap) HIPCHK(hipEventRecord(w->ev_cpl, so));
+  }
   // The Hamiltonian needs energies only, and all of them exist before the all-atom gather (the longest kernel of the EVB phase)
   // starts: fetch them now on stream2 and let the host diagonalise while the gather runs.
   const size_t nE = (size_t)2 * nu + ncp + ngrid + 3 * (size_t)ncp;
@@ -1076,36 +1087,45 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     w->hE_cap = 2 * nE + 64;
     HIPCHK(hipHostMalloc((void**)&w->h_E, w->hE_cap * sizeof(double), hipHostMallocDefault));
   }
-  auto early_fetch = [&]() -> int {
-    CHK(flush_reductions(c));                                   // principal energy slots (main stream)
+  const hipStream_t sg = c->overlap ? c->aux : c->stream;      // diabat grids: `aux` is free once the principal convolution is done
+  auto early_fetch = [&]() -> int {      // call after everything that produces an energy has been enqueued
+    CHK(flush_reductions(c));                                   // principal energy slots (main stream, behind the principal gather)
     if (!c->overlap) {
       HIPCHK(hipMemcpyAsync(w->h_E, w->d_E.p, nE * 8, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipMemcpyAsync(c->h_energies, c->d_energies.p, N_SLOTS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       return MSEVB_OK;
     }
-    HIPCHK(hipEventRecord(w->ev_E, c->stream));
-    HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0));        // stream2 is already behind the unit energies (6a)
-    if (ncp) { HIPCHK(hipEventRecord(c->ev_join, c->aux)); HIPCHK(hipStreamWaitEvent(w->stream2, c->ev_join, 0)); }   // couplings
+    HIPCHK(hipEventRecord(w->ev_flush, c->stream));
+    HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_flush, 0));     // stream2 itself is behind the unit and coupling energies
+    if (ngrid) HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0));   // grid energies (aux)
     HIPCHK(hipMemcpyAsync(w->h_E, w->d_E.p, nE * 8, hipMemcpyDeviceToHost, w->stream2));
     HIPCHK(hipMemcpyAsync(c->h_energies, c->d_energies.p, N_SLOTS * sizeof(double), hipMemcpyDeviceToHost, w->stream2));
     HIPCHK(hipEventRecord(w->ev_fetch, w->stream2));
     return MSEVB_OK;
   };
   // ---- 6b. reciprocal space of the owned diabats (calculate_reciprocal_space_pme, :1962)
-  phase_begin(c, PH_EVB_RECIP);
+  phase_begin(c, PH_EVB_RECIP, sg);
   if (ngrid) {
-    hipLaunchKernelGGL(k_evb_grid_init, dim3(2048), dim3(256), 0, c->stream, K3, ngrid, c->d_Q.p, w->d_grids.p);
-    hipLaunchKernelGGL(k_evb_patch, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, w->d_sbase.p, w->d_sw.p, w->d_grids.p);
+    hipLaunchKernelGGL(k_evb_grid_init, dim3(2048), dim3(256), 0, sg, K3, ngrid, c->d_Q.p, w->d_grids.p);
+    hipLaunchKernelGGL(k_evb_patch, dim3((nra + 3) / 4), dim3(256), 0, sg, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, w->d_sbase.p, w->d_sw.p, w->d_grids.p);
     HIPCHK(hipGetLastError());
     int nbk = 0;
-    CHK(pme_convolve(c, w->d_grids.p, ngrid, part_grid, part_stride, &nbk));      // one batched FFT pair for all owned diabats
-    hipLaunchKernelGGL(k_sum_rows, dim3(ngrid), dim3(256), 0, c->stream, ngrid, nbk, part_stride, part_grid, E_grid);
-    CHK(early_fetch());
+    c->pme_st = c->overlap ? sg : nullptr;
+    const int rc_conv = pme_convolve(c, w->d_grids.p, ngrid, part_grid, part_stride, &nbk);      // one batched FFT pair for all owned diabats
+    c->pme_st = nullptr;
+    CHK(rc_conv);
+    hipLaunchKernelGGL(k_sum_rows, dim3(ngrid), dim3(256), 0, sg, ngrid, nbk, part_stride, part_grid, E_grid);
+    hipLaunchKernelGGL(k_evb_pack, dim3(2048), dim3(256), 0, sg, K3, ngrid, w->d_grids.p, w->d_pack.p);
+    if (c->overlap) HIPCHK(hipEventRecord(w->ev_E, sg));
+  }
+  phase_end(c, PH_EVB_RECIP, sg);
+  CHK(early_fetch());
+  if (ngrid) {
+    if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // packed potentials of the diabat grids
     // all-atom gather, up to 8 grids per pass
     std::vector<int> gslots(ngrid);
     for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gslots[grid_of[d]] = diag_slot(c, D, d);
-    hipLaunchKernelGGL(k_evb_pack, dim3(2048), dim3(256), 0, c->stream, K3, ngrid, w->d_grids.p, w->d_pack.p);
     if ((double)K3 * ngrid >= 2147483648.0) FAIL(MSEVB_ERR_LIMIT, "EVB gather: K^3 * n_grids exceeds the 32-bit offset range");
     if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));      // the gather folds the real-space deltas in
     const int* permp = c->list_valid ? c->d_perm.p : nullptr;     // cell-sorted traversal keeps the stencils of co-resident waves in L2
@@ -1122,14 +1142,12 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
                        c->kk[2][1], c->kk[2][2], c->d_Fdiag.p, n3);
     HIPCHK(hipGetLastError());
   }
-  if (!ngrid) CHK(early_fetch());
   if (c->overlap && !ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));
   hipLaunchKernelGGL(k_evb_slot0, dim3(std::min<size_t>(1024, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, c->d_force.p, w->d_Fdelta.p, c->d_Fdiag.p);
-  phase_end(c, PH_EVB_RECIP);
   // ---- 8. off-diagonal elements: few, latency-bound kernels writing only d_Foff -> side stream, beside the reciprocal space
   //         and the diagonal real-space deltas (forked in step 5b, joined here)
   HIPCHK(hipGetLastError());
-  if (ncp && c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));      // recorded on the side stream in early_fetch
+  if (ncp && c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_cpl, 0));      // off-diagonal force stores complete
   // ---- 9. energies to the host, Hamiltonian
   if (c->overlap) HIPCHK(hipEventSynchronize(w->ev_fetch));     // energies left before the gather started (early_fetch)
   double en[MSEVB_N_ENERGY];
@@ -1208,7 +1226,7 @@ void evb_release(msevb_ctx* c) {
     DBuf<double>* db[] = {&w->d_exch, &w->d_part, &w->d_E, &w->d_dVspec, &w->d_sw, &w->d_sdw, &w->d_Fdelta, &w->d_F11, &w->d_pack};
     for (auto b : db) b->release();
     w->d_tabs.release(); w->d_sbase.release(); w->d_counter.release(); w->d_grids.release(); w->d_region.release(); w->d_cand.release(); w->d_desc.release();
-    hipEvent_t* ev[] = {&w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region};
+    hipEvent_t* ev[] = {&w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush};
     for (auto e : ev) if (*e) (void)hipEventDestroy(*e);
     if (w->h_region) (void)hipHostFree(w->h_region);
     if (w->h_count) (void)hipHostFree(w->h_count);

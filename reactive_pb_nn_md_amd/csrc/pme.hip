@@ -276,10 +276,10 @@ int pme_prepare_atoms(msevb_ctx* c, bool with_indices) {
   return MSEVB_OK;
 }
 
-int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add) {
+int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic) {
   const int N = c->N;
-  hipLaunchKernelGGL(k_pme_gather, dim3((N * 8 + 255) / 256), dim3(256), 0, pme_stream(c), N, c->K, chg, c->d_base.p, c->d_w.p, c->d_dw.p, c->d_theta.p, c->conv, c->kk[0][0],
-                     c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, c->pme_st ? 1 : 0);
+  hipLaunchKernelGGL(k_pme_gather, dim3((N * 8 + 255) / 256), dim3(256), 0, c->stream, N, c->K, chg, c->d_base.p, c->d_w.p, c->d_dw.p, c->d_theta.p, c->conv, c->kk[0][0],
+                     c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, atomic ? 1 : 0);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
 }
@@ -287,8 +287,9 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
 int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux) {
   const int N = c->N, K = c->K;
   const size_t K3 = (size_t)K * K * K;
-  // join_aux: the caller has forked the side streams; the whole reciprocal space goes to `aux` and overlaps the pair loop on the main
-  // stream (the gather then adds to the total force with atomics); the caller joins
+  // join_aux: the caller has forked the side streams; the front end (stencils, spreading, FFTs, convolution) goes to `aux` beside the
+  // pair loop on the main stream; the gather follows on the main stream behind the pair loop (atomic adds: the per-molecule kernel
+  // may still be running on aux2), which leaves `aux` free for the diabat grids of the EVB phase
   c->pme_st = join_aux ? c->aux : nullptr;
   const hipStream_t st = pme_stream(c);
   phase_begin(c, PH_SPREAD, st);
@@ -318,9 +319,10 @@ int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux) {
   CHK(reduce_partials(c, slot_recip, nbk));
   hipLaunchKernelGGL(k_pme_real, dim3(1024), dim3(256), 0, st, K3, c->d_grid.p, c->d_theta.p);
   phase_end(c, PH_FFT, st);
-  phase_begin(c, PH_GATHER, st);
-  CHK(pme_gather(c, c->d_grid.p, c->d_chg.p, c->d_force_recip.p, c->d_force.p));
-  phase_end(c, PH_GATHER, st);
   c->pme_st = nullptr;
+  if (join_aux) { HIPCHK(hipEventRecord(c->ev_join, c->aux)); HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
+  phase_begin(c, PH_GATHER);
+  CHK(pme_gather(c, c->d_grid.p, c->d_chg.p, c->d_force_recip.p, c->d_force.p, join_aux));
+  phase_end(c, PH_GATHER);
   return MSEVB_OK;
 }

@@ -17,6 +17,8 @@
 //   * diabats d >= 2 are sharded over ranks ((d-2) mod n_ranks); force slots are laid out [rank][slot] so that one
 //     RCCL all-gather completes every rank's store.
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <functional>
 #include <map>
 
@@ -594,7 +596,7 @@ __global__ void k_evb_blend(size_t n3, BlendTerms bt, const double* __restrict__
 
 __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms, const double* __restrict__ xyz,
                              const double* __restrict__ mass, BoxDev box, int* __restrict__ counter, RegionRec* __restrict__ out, int cap,
-                             int* __restrict__ cand_counter) {
+                             int* __restrict__ cand_counter, RegionRec* __restrict__ out_host, int cap_host) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m == 0) *cand_counter = 0;      // re-arm k_evb_candidates (which in turn re-arms `counter` for the next step)
   if (m >= M) return;
@@ -613,9 +615,13 @@ __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ 
       for (int d = 0; d < 3; ++d) r.com[d] = com[d];
       for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) r.x[k][d] = xyz[3 * a + d]; }
       out[slot] = r;
+      if (slot < cap_host) out_host[slot] = r;      // pinned host memory, written directly: no copy command behind the kernel
     }
   }
 }
+
+// publishes the record count of k_evb_region to pinned host memory
+__global__ void k_evb_publish_count(const int* __restrict__ counter, int* __restrict__ host_count) { *host_count = *counter; }
 
 __global__ void k_sum_rows(int nrow, int ncol, int stride, const double* __restrict__ part, double* __restrict__ out) {
   const int r = blockIdx.x;
@@ -655,6 +661,10 @@ struct EvbWork {   // persistent device scratch of one context
   std::vector<RegionRec> region;
 };
 std::map<msevb_ctx*, EvbWork*> g_work;
+// host-side section timing (MSEVB_HOST_TIMING=1): where the CPU thread spends the step
+struct HostTimes { double t[12] = {0}; long n = 0; };
+HostTimes g_ht;
+inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 void pbc_shift_h(const msevb_ctx* c, const double* ri, const double* rj, double* sh) { for (int d = 0; d < 3; ++d) sh[d] = std::floor((rj[d] - ri[d]) * (1.0 / c->box[d]) + 0.5) * c->box[d]; }
 
@@ -820,6 +830,10 @@ static inline bool owned(const msevb_ctx* c, int d) { return d == 0 || ((d - 1) 
 extern "C" int msevb_comm_allgather_evb(msevb_ctx* c);   // comm.hip
 
 int evb_force_energy(msevb_ctx* c, double* epot_out) {
+  static const bool ht_on = getenv("MSEVB_HOST_TIMING") != nullptr;
+  double ht_last = ht_on ? now_us() : 0.0;
+  auto HT = [&](int k) { if (ht_on) { const double t = now_us(); g_ht.t[k] += t - ht_last; ht_last = t; } };
+
   if (!c->evb_set) FAIL(MSEVB_ERR_STATE, "EVB tables not set (msevb_set_evb)");
   EvbWork*& wp = g_work[c];
   if (!wp) wp = new EvbWork();
@@ -827,6 +841,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   const int N = c->N, M = c->M, K = c->K;
   const size_t K3 = (size_t)K * K * K, n3 = 3 * (size_t)N;
   const BoxDev box = mkbox(c);
+  HT(0);
   // ---- 1. neighbourhood of the hydronium -> host on a side stream (replaces the all-molecule scans of src/ms_evb.f90:724);
   //         it only needs the positions, so it overlaps with the principal diabat's force kernels
   if (!w->stream2) {
@@ -852,12 +867,13 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   HIPCHK(hipEventRecord(w->ev_in, c->stream));
   HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_in, 0));
   hipLaunchKernelGGL(k_evb_region, dim3((M + 255) / 256), dim3(256), 0, w->stream2, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
-                     c->d_mass.p, box, w->d_counter.p, w->d_region.p, REGION_CAP, w->d_counter.p + 1);
-  HIPCHK(hipMemcpyAsync(w->h_count, w->d_counter.p, sizeof(int), hipMemcpyDeviceToHost, w->stream2));
-  HIPCHK(hipMemcpyAsync(w->h_region, w->d_region.p, REGION_FAST * sizeof(RegionRec), hipMemcpyDeviceToHost, w->stream2));
+                     c->d_mass.p, box, w->d_counter.p, w->d_region.p, REGION_CAP, w->d_counter.p + 1, w->h_region, REGION_FAST);
+  hipLaunchKernelGGL(k_evb_publish_count, dim3(1), dim3(1), 0, w->stream2, w->d_counter.p, w->h_count);
   HIPCHK(hipEventRecord(w->ev_region, w->stream2));
+  HT(1);
   // ---- 2. principal diabat (calculate_total_force_energy, src/ms_evb.f90:411) - enqueued, not waited for
   CHK(total_force_enqueue(c));
+  HT(2);
   HIPCHK(hipEventSynchronize(w->ev_region));
   const int nreg = *w->h_count;
   if (nreg > REGION_CAP) FAIL(MSEVB_ERR_LIMIT, "EVB neighbourhood buffer too small");
@@ -865,6 +881,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   if (nreg <= REGION_FAST) memcpy(w->region.data(), w->h_region, (size_t)nreg * sizeof(RegionRec));
   else { HIPCHK(hipMemcpyAsync(w->region.data(), w->d_region.p, (size_t)nreg * sizeof(RegionRec), hipMemcpyDeviceToHost, w->stream2)); HIPCHK(hipStreamSynchronize(w->stream2)); }
   std::sort(w->region.begin(), w->region.end(), [](const RegionRec& a, const RegionRec& b) { return a.mol < b.mol; });
+  HT(3);
   // ---- 3. diabat enumeration on the principal topology (evb_conduct_proton_transfer_recursive, :498)
   for (int d = 0; d < MAX_DIABATS; ++d) { c->parent[d] = -1; for (int h = 0; h < MAX_CHAIN; ++h) for (int q = 0; q < 5; ++q) c->plog[d][h][q] = -1; }
   c->D = 1;
@@ -906,6 +923,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     CHK(rec(c->hydronium, 0));
   }
   const int D = c->D, S = slots_per_rank(c, D), n_off = c->n_ranks * S, n_diag = 1 + n_off;
+  HT(4);
   // ---- 4. evaluation units / couplings / recip patches of the diabats owned by this rank
   std::vector<UnitDesc> units;
   std::vector<CouplingDesc> cps;
@@ -971,6 +989,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     cps.push_back(cp);
   }
   const int nu = (int)units.size(), ncp = (int)cps.size(), nra = (int)ras.size();
+  HT(5);
   // ---- 5. device buffers
   const int envb = std::min(64, (N + 255) / 256), cpb = std::min(512, (N + 255) / 256);
   const int part_stride = 1024;
@@ -1041,6 +1060,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipStreamWaitEvent(c->stream, w->ev_fork2, 0));
     HIPCHK(hipStreamWaitEvent(c->aux, w->ev_fork2, 0));
   }
+  HT(6);
   // ---- 6a. real-space / bonded / repulsion deltas of all units (ms_evb_diabat_force_energy, :1421)
   const hipStream_t sr = ss;     // on aux2 behind the descriptors: beside the principal force and the reciprocal space of the diabats
   phase_begin(c, PH_EVB_REAL, sr);
@@ -1104,6 +1124,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipEventRecord(w->ev_fetch, w->stream2));
     return MSEVB_OK;
   };
+  HT(7);
   // ---- 6b. reciprocal space of the owned diabats (calculate_reciprocal_space_pme, :1962)
   phase_begin(c, PH_EVB_RECIP, sg);
   if (ngrid) {
@@ -1148,6 +1169,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   //         and the diagonal real-space deltas (forked in step 5b, joined here)
   HIPCHK(hipGetLastError());
   if (ncp && c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_cpl, 0));      // off-diagonal force stores complete
+  HT(8);
   // ---- 9. energies to the host, Hamiltonian
   if (c->overlap) HIPCHK(hipEventSynchronize(w->ev_fetch));     // energies left before the gather started (early_fetch)
   double en[MSEVB_N_ENERGY];
@@ -1166,6 +1188,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     c->H[d][d] = e;
     c->H[c->parent[d]][d] = w->h_E[2 * nu + ncp + ngrid + 3 * cp_of[d] + 2];
   }
+  HT(9);
   // ---- 10. multi-GPU: complete the Hamiltonian and the force stores on every rank
   if (c->n_ranks > 1 && c->nccl_comm) CHK(msevb_comm_allgather_evb(c));
   if (c->n_ranks > 1 && !c->nccl_comm) {   // virtual sharding (tests): leave foreign diabats empty; caller merges
@@ -1194,6 +1217,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   c->principal = pr; c->new_hydronium = c->hydronium;
   for (int h = 0; h < c->max_chain; ++h) { if (c->plog[pr][h][0] < 0) break; c->new_hydronium = c->plog[pr][h][3]; }
   if (epot_out) *epot_out = eg;
+  HT(10);
   // ---- 12. principal-diabat switch (src/ms_evb.f90:218-227): adopt the new topology, rebuild the Verlet list
   if (c->new_hydronium != c->hydronium) {
     HTopo T = P;
@@ -1214,11 +1238,13 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     c->flag_verlet_list = 0;
   }
   rearm.ok = true;
+  HT(11); g_ht.n++;
   return MSEVB_OK;
 }
 
 // frees the per-context EVB scratch (called by msevb_destroy while the context's streams still exist)
 void evb_release(msevb_ctx* c) {
+  if (getenv("MSEVB_HOST_TIMING") && g_ht.n) { fprintf(stderr, "[msevb host us/step]"); for (int k = 0; k < 12; ++k) fprintf(stderr, " %d:%.1f", k, g_ht.t[k] / g_ht.n); fprintf(stderr, "\n"); }
   auto it = g_work.find(c);
   if (it == g_work.end()) return;
   EvbWork* w = it->second;

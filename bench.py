@@ -164,8 +164,15 @@ def main():
         launches_per_step = kern[dom][1] / args.steps
         avg_ms = kern[dom][0]
         achieved = ab[dom] / launches_per_step / (avg_ms * 1e-3) / 1e9
+        traffic = None        # HBM bytes per launch from the committed PMC passes (profiles/traffic.json, tools/make_traffic_json.py)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if dom in tj and world == 1:
+                traffic = int(tj[dom]["hbm_bytes_per_launch"])
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(ab[dom] / launches_per_step)}
     out = None
     if rank == 0:

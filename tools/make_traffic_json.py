@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from a tools/profile_gpu.sh output directory: per-launch HBM traffic of the kernels bench.py may report as
+dominant (FETCH_SIZE and WRITE_SIZE from their own --pmc passes, KiB -> bytes, NO gfx950 x2 correction applied: the pair loop's loads
+are 4-B coalesced and 32-B gathers, not the 16-B/lane streaming pattern that correction is calibrated for - MI355X_MICROARCH.md)."""
+import glob, json, os, sqlite3, sys
+d = sys.argv[1]
+phase_of = {"k_pair": "real space (pair loop)", "k_stencil_gather": "ms-evb reciprocal space", "k_pme_spread_tiles": "Q_grid (spread)",
+            "k_pme_gather": "Q grid derivatives (gather)", "k_molecules": "intra-molecular (non-bonded + bonded)"}
+out = {}
+for sub, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = glob.glob(os.path.join(d, sub, "**", "*results.db"), recursive=True)[0]
+    c = sqlite3.connect(f)
+    for name, n, v in c.execute("select kernel_name,count(*),sum(value) from counters_collection where counter_name=? group by kernel_name", (key,)):
+        short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+        if short in phase_of:
+            e = out.setdefault(phase_of[short], {"kernel": short, "source": os.path.basename(d.rstrip("/"))})
+            e[key.lower() + "_bytes_per_launch"] = v / n * 1024.0
+for e in out.values():
+    e["hbm_bytes_per_launch"] = e.get("fetch_size_bytes_per_launch", 0.0) + e.get("write_size_bytes_per_launch", 0.0)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))

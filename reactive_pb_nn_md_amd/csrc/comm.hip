@@ -49,4 +49,14 @@ int msevb_comm_allgather_evb(msevb_ctx* c) {
   return MSEVB_OK;
 }
 
+// Keeps the replicas bit-identical: every rank integrates all atoms, and its forces carry the rounding of its own atomic-add order;
+// without this, trajectories could drift apart in the last bits until two ranks enumerate different diabat sets (different
+// all-gather sizes).  One 24-byte-per-atom broadcast per step over xGMI.
+int msevb_comm_broadcast_forces(msevb_ctx* c) {
+  if (!c || !c->nccl_comm || c->n_ranks < 2) return MSEVB_OK;
+  if (ncclBroadcast(c->d_force.p, c->d_force.p, 3 * (size_t)c->N, ncclDouble, 0, (ncclComm_t)c->nccl_comm, c->stream) != ncclSuccess)
+    FAIL(MSEVB_ERR_COMM, "ncclBroadcast failed");
+  return MSEVB_OK;
+}
+
 }  // extern "C"

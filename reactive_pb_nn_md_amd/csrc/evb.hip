@@ -1211,6 +1211,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   phase_begin(c, PH_EVB_BLEND);
   hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p);
   HIPCHK(hipGetLastError());
+  if (c->n_ranks > 1 && c->nccl_comm) CHK(msevb_comm_broadcast_forces(c));
   phase_end(c, PH_EVB_BLEND);
   int pr = 0; double sc = std::fabs(c->eigvec[0]);
   for (int i = 0; i < D; ++i) if (sc < std::fabs(c->eigvec[i])) { sc = std::fabs(c->eigvec[i]); pr = i; }

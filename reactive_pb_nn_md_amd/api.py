@@ -262,6 +262,13 @@ class MsEvbHip:
         self._chk(self.L.msevb_get_evb_element_force(self.ctx, int(i), int(j), _dp(f)))
         return f
 
+    def evb_partial_blend(self, eigvec):
+        """this rank's share of the Hellmann-Feynman force for a given ground-state vector (sharding tests)"""
+        ev = np.ascontiguousarray(eigvec, dtype=np.float64)
+        f = np.zeros((self.N, 3))
+        self._chk(self.L.msevb_evb_partial_blend(self.ctx, _dp(ev), _dp(f)))
+        return f
+
     def topology(self):
         at, ch = np.zeros(self.N, dtype=np.int32), np.zeros(self.N)
         mn, mt, ma = np.zeros(self.M, dtype=np.int32), np.zeros(self.M, dtype=np.int32), np.zeros((self.M, 8), dtype=np.int32)

@@ -1,6 +1,6 @@
 // Multi-GPU exchange for the diabat-sharded EVB step: one process per GPU, RCCL over xGMI.
-// Diabats d >= 2 live on rank (d-2) mod R; force slots are laid out [rank][slot] so a single in-place ncclAllGather per
-// store completes it on every rank.  The Hamiltonian entries travel the same way (2 doubles per slot).
+// Diabats d >= 2 live on rank (d-2) mod R.  Per step: one tiny all-gather of the Hamiltonian entries, one all-reduce of the partial
+// Hellmann-Feynman forces (24 B per atom).  Force stores never travel.
 #include <rccl/rccl.h>
 
 #include "ctx.hpp"
@@ -28,34 +28,30 @@ int msevb_comm_init(msevb_ctx* c, const void* id128, int rank, int n_ranks) {
   return MSEVB_OK;
 }
 
+// Hamiltonian entries of the diabats owned by other ranks (2 doubles per slot: H_dd, H_pd).  The force stores stay where they were
+// computed: every rank blends ITS diabats with the common eigenvector and the partial forces are summed (msevb_comm_allreduce_forces).
 int msevb_comm_allgather_evb(msevb_ctx* c) {
   const int D = c->D, S = slots_per_rank(c, D), R = c->n_ranks;
   if (S == 0) return MSEVB_OK;
-  const size_t n3 = 3 * (size_t)c->N;
   ncclComm_t comm = (ncclComm_t)c->nccl_comm;
   static thread_local DBuf<double> d_h;
   if (d_h.alloc((size_t)R * S * 2)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (comm)");
   std::vector<double> h((size_t)R * S * 2, 0.0);
   for (int d = 1; d < D; ++d) if ((d - 1) % R == c->rank) { const int s = (d - 1) / R; h[((size_t)c->rank * S + s) * 2] = c->H[d][d]; h[((size_t)c->rank * S + s) * 2 + 1] = c->H[c->parent[d]][d]; }
-  HIPCHK(hipMemcpyAsync(d_h.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->stream));
-  if (ncclGroupStart() != ncclSuccess) FAIL(MSEVB_ERR_COMM, "ncclGroupStart");
-  ncclResult_t r1 = ncclAllGather(d_h.p + (size_t)c->rank * S * 2, d_h.p, (size_t)S * 2, ncclDouble, comm, c->stream);
-  ncclResult_t r2 = ncclAllGather(c->d_Fdiag.p + n3 + (size_t)c->rank * S * n3, c->d_Fdiag.p + n3, (size_t)S * n3, ncclDouble, comm, c->stream);
-  ncclResult_t r3 = ncclAllGather(c->d_Foff.p + (size_t)c->rank * S * n3, c->d_Foff.p, (size_t)S * n3, ncclDouble, comm, c->stream);
-  if (ncclGroupEnd() != ncclSuccess || r1 != ncclSuccess || r2 != ncclSuccess || r3 != ncclSuccess) FAIL(MSEVB_ERR_COMM, "ncclAllGather failed");
-  HIPCHK(hipMemcpyAsync(h.data(), d_h.p, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpyAsync(d_h.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->aux2));
+  if (ncclAllGather(d_h.p + (size_t)c->rank * S * 2, d_h.p, (size_t)S * 2, ncclDouble, comm, c->aux2) != ncclSuccess) FAIL(MSEVB_ERR_COMM, "ncclAllGather failed");
+  HIPCHK(hipMemcpyAsync(h.data(), d_h.p, h.size() * 8, hipMemcpyDeviceToHost, c->aux2));
+  HIPCHK(hipStreamSynchronize(c->aux2));      // aux2 already holds the energy download: the all-atom gather on the main stream keeps running
   for (int d = 1; d < D; ++d) { const int r = (d - 1) % R, s = (d - 1) / R; c->H[d][d] = h[((size_t)r * S + s) * 2]; c->H[c->parent[d]][d] = h[((size_t)r * S + s) * 2 + 1]; }
   return MSEVB_OK;
 }
 
-// Keeps the replicas bit-identical: every rank integrates all atoms, and its forces carry the rounding of its own atomic-add order;
-// without this, trajectories could drift apart in the last bits until two ranks enumerate different diabat sets (different
-// all-gather sizes).  One 24-byte-per-atom broadcast per step over xGMI.
-int msevb_comm_broadcast_forces(msevb_ctx* c) {
+// Sum of the ranks' partial Hellmann-Feynman forces, in place; the result is bit-identical on every rank, which keeps the replicated
+// trajectories identical (every rank integrates all atoms).  24 bytes per atom over xGMI instead of all-gathering 2 (D-1) force stores.
+int msevb_comm_allreduce_forces(msevb_ctx* c) {
   if (!c || !c->nccl_comm || c->n_ranks < 2) return MSEVB_OK;
-  if (ncclBroadcast(c->d_force.p, c->d_force.p, 3 * (size_t)c->N, ncclDouble, 0, (ncclComm_t)c->nccl_comm, c->stream) != ncclSuccess)
-    FAIL(MSEVB_ERR_COMM, "ncclBroadcast failed");
+  if (ncclAllReduce(c->d_force.p, c->d_force.p, 3 * (size_t)c->N, ncclDouble, ncclSum, (ncclComm_t)c->nccl_comm, c->stream) != ncclSuccess)
+    FAIL(MSEVB_ERR_COMM, "ncclAllReduce failed");
   return MSEVB_OK;
 }
 

@@ -244,7 +244,7 @@ struct msevb_ctx {
 // ---- cross-file entry points (all enqueue on c->stream) ----------------------------------------------
 int nb_build(msevb_ctx* c);                        // neighbor.hip
 int nb_refresh_sorted(msevb_ctx* c);               // gather posq/type in sorted order
-extern "C" int msevb_comm_broadcast_forces(msevb_ctx* c);   // comm.hip
+extern "C" int msevb_comm_allreduce_forces(msevb_ctx* c);   // comm.hip
 void evb_release(msevb_ctx* c);        // evb.hip: per-context EVB scratch
 int nb_step_refresh(msevb_ctx* c);      // refresh + displacement check + zero forces (neighbor.hip)
 int nb_check_displacements(msevb_ctx* c, int initialize, int* flag);

@@ -579,16 +579,20 @@ __global__ void k_evb_scale(size_t n3, int n_cp, const CouplingDesc* __restrict_
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (size_t)gridDim.x * blockDim.x) F[k] *= mA;
 }
 
-// Hellmann-Feynman blend: F = sum_d c_d^2 F_dd + 2 sum_(p,d) c_p c_d F_pd (src/ms_evb.f90:293-309)
-// principal slot = principal force + its repulsion delta (consumes and re-zeroes the delta)
-__global__ void k_evb_slot0(size_t n3, const double* __restrict__ F11, double* __restrict__ delta0, double* __restrict__ Fdiag0) {
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (size_t)gridDim.x * blockDim.x) { Fdiag0[k] = F11[k] + delta0[k]; delta0[k] = 0.0; }
+// Hellmann-Feynman blend: F = sum_d c_d^2 F_dd + 2 sum_(p,d) c_p c_d F_pd (src/ms_evb.f90:293-309).
+// principal slot = repulsion delta of the principal diabat (consumes and re-zeroes the delta store); keeps a copy of the principal
+// force for msevb_get_evb_element_force (the blend overwrites it in place)
+__global__ void k_evb_slot0(size_t n3, const double* __restrict__ F11, double* __restrict__ delta0, double* __restrict__ Fdiag0, double* __restrict__ F11_copy) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (size_t)gridDim.x * blockDim.x) { Fdiag0[k] = delta0[k]; delta0[k] = 0.0; F11_copy[k] = F11[k]; }
 }
 
 struct BlendTerms { int n; int slot[2 * MAX_DIABATS]; double coef[2 * MAX_DIABATS]; };   // slot < 0: off-diagonal store, index -slot-1 (kernel argument, no upload)
-__global__ void k_evb_blend(size_t n3, BlendTerms bt, const double* __restrict__ Fdiag, const double* __restrict__ Foff, size_t fstride, double* __restrict__ F) {
+// The diagonal store holds differences to the principal force F11 (F_dd = F11 + store_d) and sum_d c_d^2 = 1, so
+// F = w11 F11 + sum_d c_d^2 store_d + 2 sum c_p c_d F_pd with w11 = 1 (w11 < 1 only for a rank's PARTIAL blend, see evb_partial terms);
+// F holds F11 on entry and the blended force on exit.
+__global__ void k_evb_blend(size_t n3, BlendTerms bt, double w11, const double* __restrict__ Fdiag, const double* __restrict__ Foff, size_t fstride, double* __restrict__ F) {
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (size_t)gridDim.x * blockDim.x) {
-    double s = 0.0;
+    double s = w11 * F[k];
     for (int t = 0; t < bt.n; ++t) { const int sl = bt.slot[t]; s += bt.coef[t] * (sl < 0 ? Foff[(size_t)(-sl - 1) * fstride + k] : Fdiag[(size_t)sl * fstride + k]); }
     F[k] = s;
   }
@@ -825,6 +829,16 @@ static BoxDev mkbox(const msevb_ctx* c) { BoxDev b; for (int d = 0; d < 3; ++d) 
 static inline int slots_per_rank(const msevb_ctx* c, int D) { return D <= 1 ? 0 : (D - 1 + c->n_ranks - 1) / c->n_ranks; }
 static inline int off_slot(const msevb_ctx* c, int D, int d) { return ((d - 1) % c->n_ranks) * slots_per_rank(c, D) + (d - 1) / c->n_ranks; }
 static inline int diag_slot(const msevb_ctx* c, int D, int d) { return d == 0 ? 0 : 1 + off_slot(c, D, d); }
+static inline bool owned(const msevb_ctx* c, int d);
+// terms of this rank's share of the Hellmann-Feynman blend; returns the weight of the principal force F11 in it (rank 0 carries it)
+static double blend_terms(const msevb_ctx* c, int D, const double* ev, BlendTerms& bt) {
+  bt.n = 0;
+  for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) {
+    if (i == j) { if (i == 0 ? c->rank == 0 : owned(c, i)) { bt.coef[bt.n] = ev[i] * ev[j]; bt.slot[bt.n++] = diag_slot(c, D, i); } }
+    else if (c->parent[j] == i && owned(c, j)) { bt.coef[bt.n] = 2.0 * ev[i] * ev[j]; bt.slot[bt.n++] = -off_slot(c, D, j) - 1; }
+  }
+  return c->rank == 0 ? 1.0 : 0.0;
+}
 static inline bool owned(const msevb_ctx* c, int d) { return d == 0 || ((d - 1) % c->n_ranks) == c->rank; }
 
 extern "C" int msevb_comm_allgather_evb(msevb_ctx* c);   // comm.hip
@@ -998,7 +1012,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
       w->d_tabs.alloc(1) || w->d_exch.alloc(MAX_TYPES) || w->d_part.alloc((size_t)n_rows * part_stride) ||
       w->d_E.alloc(2 * n_rows + 3 * std::max(ncp, 1) + 8) || w->d_dVspec.alloc((size_t)MAX_DIABATS * MAX_SPEC * 3) ||
       w->d_sbase.alloc(3 * std::max(nra, 1)) || w->d_sw.alloc(18 * (size_t)std::max(nra, 1)) || w->d_sdw.alloc(18 * (size_t)std::max(nra, 1)) ||
-      w->d_grids.alloc(K3 * std::max(ngrid, 1)) || w->d_pack.alloc(K3 * std::max(ngrid, 1)))
+      w->d_grids.alloc(K3 * std::max(ngrid, 1)) || w->d_pack.alloc(K3 * std::max(ngrid, 1)) || w->d_F11.alloc(n3))
     FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB work buffers)");
   c->evb_cap = D;
   if (!w->tabs_uploaded) {
@@ -1048,9 +1062,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     if (w->d_Fdelta.n < need) { if (w->d_Fdelta.alloc(need)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB delta store)"); w->delta_dirty = true; }
     if (w->delta_dirty) { HIPCHK(hipMemsetAsync(w->d_Fdelta.p, 0, w->d_Fdelta.n * 8, ss)); w->delta_dirty = false; }
   }
-  // every element of an owned off-diagonal slot is written by k_evb_coupling / k_evb_coupling_finish; foreign slots are zeroed for the all-gather
-  if (n_off && c->n_ranks > 1) HIPCHK(hipMemsetAsync(c->d_Foff.p, 0, (size_t)n_off * n3 * 8, ss));
-  if (n_off && c->n_ranks > 1) HIPCHK(hipMemsetAsync(c->d_Fdiag.p + n3, 0, (size_t)n_off * n3 * 8, ss));
+  // every element of an owned slot is written by its kernels; slots of other ranks' diabats are never read (partial blend + all-reduce)
   if (w->dv_dirty) { HIPCHK(hipMemsetAsync(w->d_dVspec.p, 0, w->d_dVspec.n * 8, ss)); w->dv_dirty = false; }   // afterwards k_evb_coupling_finish leaves it zeroed
   // B-spline stencils of the special atoms in their new states (needs descriptors only)
   if (ngrid) hipLaunchKernelGGL(k_evb_spec_prep, dim3((nra + 63) / 64), dim3(64), 0, ss, nra, d_ra, K, c->spline_grid, c->kk[0][0], c->kk[0][1], c->kk[0][2],
@@ -1156,7 +1168,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
       GatherSlots gs; for (int q = 0; q < 8; ++q) gs.s[q] = q < ng ? gslots[g0 + q] : 0;
       hipLaunchKernelGGL(kern, dim3(round_up8((N + 3) / 4)), dim3(256), 0, c->stream, N, K, ng, gs, permp, c->d_chg.p, c->d_base.p,
                          c->d_w.p, c->d_dw.p, w->d_pack.p, ngrid, g0, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1],
-                         c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_force.p, c->d_force_recip.p, c->d_Fdiag.p, w->d_Fdelta.p, n3);
+                         c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_force_recip.p, c->d_Fdiag.p, w->d_Fdelta.p, n3);
     }
     hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
                        w->d_sw.p, w->d_sdw.p, w->d_grids.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0],
@@ -1164,7 +1176,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipGetLastError());
   }
   if (c->overlap && !ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));
-  hipLaunchKernelGGL(k_evb_slot0, dim3(std::min<size_t>(1024, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, c->d_force.p, w->d_Fdelta.p, c->d_Fdiag.p);
+  hipLaunchKernelGGL(k_evb_slot0, dim3(std::min<size_t>(1024, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, c->d_force.p, w->d_Fdelta.p, c->d_Fdiag.p, w->d_F11.p);
   // ---- 8. off-diagonal elements: few, latency-bound kernels writing only d_Foff -> side stream, beside the reciprocal space
   //         and the diagonal real-space deltas (forked in step 5b, joined here)
   HIPCHK(hipGetLastError());
@@ -1203,15 +1215,12 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   int g = 0; double eg = ev[0];
   for (int i = 1; i < D; ++i) if (ev[i] < eg) { eg = ev[i]; g = i; }
   for (int i = 0; i < D; ++i) c->eigvec[i] = v[(size_t)i * D + g];
-  BlendTerms bt; bt.n = 0;
-  for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) {
-    if (i == j) { bt.coef[bt.n] = c->eigvec[i] * c->eigvec[j]; bt.slot[bt.n++] = diag_slot(c, D, i); }
-    else if (c->parent[j] == i) { bt.coef[bt.n] = 2.0 * c->eigvec[i] * c->eigvec[j]; bt.slot[bt.n++] = -off_slot(c, D, j) - 1; }
-  }
+  BlendTerms bt;
+  const double w11 = blend_terms(c, D, c->eigvec, bt);
   phase_begin(c, PH_EVB_BLEND);
-  hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p);
+  hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p);
   HIPCHK(hipGetLastError());
-  if (c->n_ranks > 1 && c->nccl_comm) CHK(msevb_comm_broadcast_forces(c));
+  if (c->n_ranks > 1 && c->nccl_comm) CHK(msevb_comm_allreduce_forces(c));
   phase_end(c, PH_EVB_BLEND);
   int pr = 0; double sc = std::fabs(c->eigvec[0]);
   for (int i = 0; i < D; ++i) if (sc < std::fabs(c->eigvec[i])) { sc = std::fabs(c->eigvec[i]); pr = i; }
@@ -1290,13 +1299,37 @@ int msevb_get_evb_state(msevb_ctx* c, int* nd, int* plog, int* cm, double* H, do
   return MSEVB_OK;
 }
 
+int msevb_evb_partial_blend(msevb_ctx* c, const double* eigvec, double* force) {
+  if (!c || c->D <= 0 || !eigvec || !force) { if (c) c->err = "bad argument"; return MSEVB_ERR_ARG; }
+  auto it = g_work.find(c);
+  if (it == g_work.end() || !it->second->d_F11.p) FAIL(MSEVB_ERR_STATE, "no EVB force call yet");
+  const size_t n3 = 3 * (size_t)c->N;
+  BlendTerms bt;
+  const double w11 = blend_terms(c, c->D, eigvec, bt);
+  HIPCHK(hipMemcpyAsync(c->d_force.p, it->second->d_F11.p, n3 * 8, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p);
+  HIPCHK(hipMemcpyAsync(force, c->d_force.p, n3 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MSEVB_OK;
+}
+
 int msevb_get_evb_element_force(msevb_ctx* c, int i, int j, double* force) {
   if (!c || c->D <= 0 || i < 1 || j < i || j > c->D) { if (c) c->err = "bad element"; return MSEVB_ERR_ARG; }
   const size_t n3 = 3 * (size_t)c->N;
-  const double* src;
-  if (i == j) src = c->d_Fdiag.p + (size_t)diag_slot(c, c->D, i - 1) * n3;
-  else { if (c->parent[j - 1] != i - 1) FAIL(MSEVB_ERR_ARG, "Hamiltonian element is zero"); src = c->d_Foff.p + (size_t)off_slot(c, c->D, j - 1) * n3; }
-  HIPCHK(hipMemcpyAsync(force, src, n3 * 8, hipMemcpyDeviceToHost, c->stream));
+  if (i == j) {      // diagonal: principal force (copy kept by k_evb_slot0) + the stored difference; zero on ranks that do not own the diabat
+    auto it = g_work.find(c);
+    if (it == g_work.end() || !it->second->d_F11.p) FAIL(MSEVB_ERR_STATE, "no EVB force call yet");
+    if (i > 1 && !owned(c, i - 1)) { memset(force, 0, n3 * 8); return MSEVB_OK; }
+    std::vector<double> d(n3);
+    HIPCHK(hipMemcpyAsync(force, it->second->d_F11.p, n3 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(d.data(), c->d_Fdiag.p + (size_t)diag_slot(c, c->D, i - 1) * n3, n3 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < n3; ++k) force[k] = force[k] + d[k];
+    return MSEVB_OK;
+  }
+  if (c->parent[j - 1] != i - 1) FAIL(MSEVB_ERR_ARG, "Hamiltonian element is zero");
+  if (!owned(c, j - 1)) { memset(force, 0, n3 * 8); return MSEVB_OK; }
+  HIPCHK(hipMemcpyAsync(force, c->d_Foff.p + (size_t)off_slot(c, c->D, j - 1) * n3, n3 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return MSEVB_OK;
 }

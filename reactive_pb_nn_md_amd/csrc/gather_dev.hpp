@@ -7,7 +7,8 @@ namespace {
 struct GatherSlots { int s[8]; };     // force-store slot of each grid of a pass (kernel argument)
 
 // All-atom reciprocal force of up to NGP owned diabats in one pass (update_reciprocal_space_force_dQ_dr for the atoms whose
-// stencil did not change, src/ms_evb.f90:2055-2084): Fstore[slot_g] = F11 + (f_g - Frecip1) + Fdelta[slot_g].
+// stencil did not change, src/ms_evb.f90:2055-2084).  The store holds DIFFERENCES to the principal force:
+// Fstore[slot_g] = (f_g - Frecip1) + Fdelta[slot_g]  (F_gg = F11 + Fstore[slot_g]; the blend needs F11 only once because sum c_d^2 = 1).
 // ONE WAVEFRONT PER ATOM; lane = (row r, grid g, tap k1): a stencil row of
 // the packed potential [point][grid] is 6 x ngtot consecutive doubles, so a wave-wide load touches 3-6 cache lines instead of
 // one line per lane (the per-lane-plane layout this replaces was bound by the L1 tag rate: 48 lines per load).  With NGP = 8
@@ -17,7 +18,7 @@ __global__ __launch_bounds__(256) void k_stencil_gather(int N, int K, int ng, Ga
                                                     const double* __restrict__ chg, const int* __restrict__ base, const double* __restrict__ w,
                                                     const double* __restrict__ dw, const double* __restrict__ pack, int ngtot, int g0, double conv, double k00,
                                                     double k01, double k02, double k10, double k11, double k12, double k20, double k21, double k22,
-                                                    const double* __restrict__ F11, const double* Frecip1, double* __restrict__ Fstore, double* __restrict__ Fdelta, size_t fstride) {
+                                                    const double* Frecip1, double* __restrict__ Fstore, double* __restrict__ Fdelta, size_t fstride) {
   constexpr int RPW = 64 / (8 * NGP);    // stencil rows per wave-wide load
   const int lane = threadIdx.x & 63;
   const int s = xcd_block(blockIdx.x, gridDim.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -76,9 +77,9 @@ __global__ __launch_bounds__(256) void k_stencil_gather(int N, int K, int ng, Ga
       // re-zeroed here so that it is clean for the next step
       double* F = Fstore + (size_t)slots.s[g] * fstride;
       double* D = Fdelta + (size_t)slots.s[g] * fstride;
-      F[3 * i] = F11[3 * i] + (fx - Frecip1[3 * i]) + D[3 * i];
-      F[3 * i + 1] = F11[3 * i + 1] + (fy - Frecip1[3 * i + 1]) + D[3 * i + 1];
-      F[3 * i + 2] = F11[3 * i + 2] + (fz - Frecip1[3 * i + 2]) + D[3 * i + 2];
+      F[3 * i] = (fx - Frecip1[3 * i]) + D[3 * i];
+      F[3 * i + 1] = (fy - Frecip1[3 * i + 1]) + D[3 * i + 1];
+      F[3 * i + 2] = (fz - Frecip1[3 * i + 2]) + D[3 * i + 2];
       D[3 * i] = 0.0; D[3 * i + 1] = 0.0; D[3 * i + 2] = 0.0;
     }
   }

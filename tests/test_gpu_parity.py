@@ -155,16 +155,19 @@ def test_md_trajectory_against_reference(name, evb):
 
 @pytest.mark.parametrize("n_ranks", [2, 3])
 def test_diabat_sharding_is_a_partition(n_ranks):
-    """virtual ranks: every Hamiltonian element is produced by exactly one rank and equals the single-rank result"""
+    """virtual ranks: every Hamiltonian element is produced by exactly one rank and equals the single-rank result, and the ranks'
+    partial Hellmann-Feynman forces (what msevb_comm_allreduce_forces sums) add up to the single-rank force"""
     g = golden("evb_n6_d8_s1")
     spec = system.from_golden(g)
     h = api.MsEvbHip(spec)
-    h.ms_evb_calculate_total_force_energy(want_force=False)
+    _e, Fblend = h.ms_evb_calculate_total_force_energy()
     full = h.evb_state()
     D = full["D"]
     Ffull = {(i, j): h.evb_element_force(i, j) for i in range(1, D + 1) for j in range(i, D + 1) if i == j or full["coupling_matrix"][j - 1] == i}
+    assert np.abs(h.evb_partial_blend(full["eigvec"]) - Fblend).max() < 1e-10      # one rank: the partial blend is the blend
     h.close()
     Hsum = np.zeros((D, D))
+    Fsum = np.zeros_like(Fblend)
     for r in range(n_ranks):
         hr = api.MsEvbHip(spec)
         hr.comm_set_virtual(r, n_ranks)
@@ -180,8 +183,10 @@ def test_diabat_sharding_is_a_partition(n_ranks):
                 Hsum[d - 1, d - 1] += st["H"][d - 1, d - 1]
             else:
                 assert st["H"][d - 1, d - 1] == 0.0 and np.abs(hr.evb_element_force(d, d)).max() == 0.0
+        Fsum += hr.evb_partial_blend(full["eigvec"])
         hr.close()
     assert np.allclose(np.diag(Hsum)[1:], np.diag(full["H"])[1:], rtol=1e-13)
+    assert np.abs(Fsum - Fblend).max() < 1e-10
 
 
 def _synthetic(n_side, n_diabat, seed, K, rc=9.0, rv=10.5):

@@ -1,6 +1,7 @@
 """world_size-2 `gloo` test of the diabat sharding used on N>1 GPUs: rank r owns diabats d>=2 with
-(d-2) mod R == r, slots are laid out [rank][slot], one all-gather completes the store, every rank blends.  The per-element
-numbers come from the CPU oracle here (no GPU in this container); the layout logic under test is bench.py's / comm.hip's."""
+(d-2) mod R == r; the Hamiltonian entries are all-gathered (2 doubles per slot), every rank diagonalises the same matrix, blends ITS
+diabats and the partial forces are all-reduced.  The per-element numbers come from the CPU oracle here (no GPU in this container);
+the protocol under test is comm.hip's / evb.hip's (blend_terms)."""
 import os
 import socket
 import sys
@@ -27,32 +28,32 @@ def _worker(rank, world, port, name, q):
     D, N = r["D"], spec.n_atom
     S = sharding.slots_per_rank(D, world)
     Hloc = np.zeros((S, 2))
-    Floc = np.zeros((S, 2, N, 3))
     for d in range(1, D):
         if sharding.owner(d, world) == rank:
-            s = sharding.local_slot(d, world)
-            Hloc[s] = (r["H"][d, d], r["H"][r["parent"][d], d])
-            Floc[s, 0], Floc[s, 1] = r["F_diag"][d], r["F_off"][d]
+            Hloc[sharding.local_slot(d, world)] = (r["H"][d, d], r["H"][r["parent"][d], d])
     Hall = [torch.zeros(S, 2, dtype=torch.float64) for _ in range(world)]
-    Fall = [torch.zeros(S, 2, N, 3, dtype=torch.float64) for _ in range(world)]
-    dist.all_gather(Hall, torch.from_numpy(Hloc))
-    dist.all_gather(Fall, torch.from_numpy(Floc))
+    dist.all_gather(Hall, torch.from_numpy(Hloc))                    # msevb_comm_allgather_evb
     H = np.zeros((D, D))
     H[0, 0] = r["H"][0, 0]
-    Fd, Fo = np.zeros((D, N, 3)), np.zeros((D, N, 3))
-    Fd[0] = r["F_diag"][0]
     for d in range(1, D):
         ow, s = sharding.owner(d, world), sharding.local_slot(d, world)
         H[d, d], H[r["parent"][d], d] = Hall[ow][s].numpy()
-        Fd[d], Fo[d] = Fall[ow][s, 0].numpy(), Fall[ow][s, 1].numpy()
-    E, F, c = sharding.diagonalise_and_blend(H, r["parent"], Fd, Fo)
+    E, c = sharding.ground_state(H)
+    # this rank only has ITS stores: zero the others to prove they are not needed
+    Fd, Fo = np.zeros((D, N, 3)), np.zeros((D, N, 3))
+    for d in range(D):
+        if (d == 0 and rank == 0) or (d > 0 and sharding.owner(d, world) == rank):
+            Fd[d], Fo[d] = r["F_diag"][d], r["F_off"][d]
+    Fp = torch.from_numpy(sharding.partial_blend(c, r["parent"], Fd, Fo, rank, world))
+    dist.all_reduce(Fp)                                               # msevb_comm_allreduce_forces
+    F = Fp.numpy()
     q.put((rank, float(E), float(np.abs(F - r["F"]).max()), float(abs(E - r["E"])), float(np.abs(H - r["H"]).max())))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("name", ["evb_n6_d8_s1", "evb_n6_d4_s2"])
-def test_two_rank_allgather_reproduces_single_rank(name):
+def test_two_rank_exchange_reproduces_single_rank(name):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -8,7 +8,7 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 
 H-bond tree -> ~98k atoms, 8 diabats, 64^3 PME grid, r_c 9 / r_v 10.5 A, dt 0.5 fs, NVE.  A step = one
 velocity-Verlet step of msevb_md_integrate_atomic with the EVB force call (principal diabat, 7 diabat deltas, Hamiltonian,
 Hellmann-Feynman blend), positions/velocities/forces resident in HBM.  With N > 1 the diabats are sharded over the ranks
-(principal replicated); per step one small RCCL all-gather of Hamiltonian entries and one all-reduce of the partial
+(and the principal diabat's pair loop / per-molecule terms by atom ranges); per step one small RCCL all-gather of Hamiltonian entries and one all-reduce of the partial
 Hellmann-Feynman forces: total work is fixed -> "scaling": "strong".
 Prints ONE JSON line on rank 0.
 """

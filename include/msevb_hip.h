@@ -138,6 +138,7 @@ int msevb_calculate_kinetic_energy(msevb_ctx* ctx, double* kinetic_energy);   /*
 int msevb_comm_unique_id(void* id_bytes_128);                                       /* ncclGetUniqueId */
 int msevb_comm_init(msevb_ctx* ctx, const void* id_bytes_128, int rank, int n_ranks); /* ncclCommInitRank (RCCL) */
 int msevb_comm_set_virtual(msevb_ctx* ctx, int rank, int n_ranks);   /* shard without a communicator (tests) */
+int msevb_comm_allreduce_energies(msevb_ctx* ctx); /* principal energy slots when the principal real space is sharded (internal) */
 int msevb_comm_allreduce_forces(msevb_ctx* ctx);   /* sum of the ranks' partial Hellmann-Feynman forces (called by the EVB force call itself) */
 int msevb_evb_partial_blend(msevb_ctx* ctx, const double* eigvec, double* force);   /* this rank's share of the blend for a given eigenvector (src/ms_evb.f90:293-309; tests of the sharding) */
 

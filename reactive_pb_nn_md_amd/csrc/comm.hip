@@ -25,6 +25,7 @@ int msevb_comm_init(msevb_ctx* c, const void* id128, int rank, int n_ranks) {
   ncclComm_t comm;
   if (ncclCommInitRank(&comm, n_ranks, id, rank) != ncclSuccess) FAIL(MSEVB_ERR_COMM, "ncclCommInitRank failed");
   c->nccl_comm = comm; c->rank = rank; c->n_ranks = n_ranks;
+  c->shard_principal = n_ranks > 1;      // the partial principal forces meet in the all-reduce of the blend
   return MSEVB_OK;
 }
 
@@ -43,6 +44,19 @@ int msevb_comm_allgather_evb(msevb_ctx* c) {
   HIPCHK(hipMemcpyAsync(h.data(), d_h.p, h.size() * 8, hipMemcpyDeviceToHost, c->aux2));
   HIPCHK(hipStreamSynchronize(c->aux2));      // aux2 already holds the energy download: the all-atom gather on the main stream keeps running
   for (int d = 1; d < D; ++d) { const int r = (d - 1) % R, s = (d - 1) / R; c->H[d][d] = h[((size_t)r * S + s) * 2]; c->H[c->parent[d]][d] = h[((size_t)r * S + s) * 2 + 1]; }
+  return MSEVB_OK;
+}
+
+// Principal-diabat energies when the principal real space is sharded: the eight energy slots are summed over the ranks (replicated
+// slots were zeroed on ranks != 0 by the caller), so every rank assembles the same H11.
+int msevb_comm_allreduce_energies(msevb_ctx* c) {
+  if (!c || !c->nccl_comm || c->n_ranks < 2) return MSEVB_OK;
+  static thread_local DBuf<double> d_e;
+  if (d_e.alloc(8)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (comm)");
+  HIPCHK(hipMemcpyAsync(d_e.p, c->h_energies + S_ELEC_PAIR, 8 * sizeof(double), hipMemcpyHostToDevice, c->aux2));      // S_ELEC_PAIR .. S_RECIP are contiguous
+  if (ncclAllReduce(d_e.p, d_e.p, 8, ncclDouble, ncclSum, (ncclComm_t)c->nccl_comm, c->aux2) != ncclSuccess) FAIL(MSEVB_ERR_COMM, "ncclAllReduce failed");
+  HIPCHK(hipMemcpyAsync(c->h_energies + S_ELEC_PAIR, d_e.p, 8 * sizeof(double), hipMemcpyDeviceToHost, c->aux2));
+  HIPCHK(hipStreamSynchronize(c->aux2));
   return MSEVB_OK;
 }
 

@@ -66,6 +66,7 @@ struct BoxDev { double L[3], invL[3]; };
 __device__ __forceinline__ int xcd_block(int b, int nb) { return (b & 7) * (nb >> 3) + (b >> 3); }
 #endif
 inline int round_up8(int n) { return (n + 7) & ~7; }
+struct msevb_ctx;
 
 // The (up to 27) distinct neighbour cells of cell cidx, in the canonical order shared by the list build, the LDS-tiled pair
 // kernel and the host-side decoder of msevb_get_verlet_list.  Returns the number of slots.
@@ -148,6 +149,11 @@ struct msevb_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   hipStream_t pme_st = nullptr;      // non-null while the PME front end is being enqueued on the side stream
   bool overlap = true;
+  // multi-rank EVB: the principal diabat's pair loop, per-molecule terms and reciprocal-force accumulation are split over the ranks by
+  // atom / molecule ranges (the partial principal forces meet in the all-reduce of the blend); set by msevb_comm_init, or by the
+  // "shard_principal" option for virtual ranks (tests)
+  bool shard_principal = false;
+  bool shard_now = false;        // true while the EVB force call enqueues the principal diabat
   int pair_tiles_opt = 0;        // 0 off (default: measured slower than the global-gather kernel once the PME front end overlaps it), 1 on when it fits, -1 auto
   bool pair_tiles = false;       // format of the current list
   int tile_atoms_max = 0;
@@ -293,6 +299,11 @@ inline void phase_end(msevb_ctx* c, int p, hipStream_t st = nullptr) {
   if ((t.used & 1) == 0) return;
   (void)hipEventRecord(t.ev[t.used], st);
   t.used += 1;
+}
+// [lo, hi) of n items owned by this rank while the principal diabat is sharded, everything otherwise
+inline void shard_range(const msevb_ctx* c, int n, int& lo, int& hi) {
+  if (!c->shard_now || c->n_ranks < 2) { lo = 0; hi = n; return; }
+  lo = (int)((long)n * c->rank / c->n_ranks); hi = (int)((long)n * (c->rank + 1) / c->n_ranks);
 }
 inline hipError_t aux_fork(msevb_ctx* c) {     // both side streams continue from the current end of the main stream
   hipError_t e = hipEventRecord(c->ev_fork, c->stream);

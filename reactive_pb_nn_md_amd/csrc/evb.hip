@@ -837,11 +837,12 @@ static double blend_terms(const msevb_ctx* c, int D, const double* ev, BlendTerm
     if (i == j) { if (i == 0 ? c->rank == 0 : owned(c, i)) { bt.coef[bt.n] = ev[i] * ev[j]; bt.slot[bt.n++] = diag_slot(c, D, i); } }
     else if (c->parent[j] == i && owned(c, j)) { bt.coef[bt.n] = 2.0 * ev[i] * ev[j]; bt.slot[bt.n++] = -off_slot(c, D, j) - 1; }
   }
-  return c->rank == 0 ? 1.0 : 0.0;
+  return (c->rank == 0 || (c->shard_principal && c->n_ranks > 1)) ? 1.0 : 0.0;      // sharded principal: every rank holds a part of F11
 }
 static inline bool owned(const msevb_ctx* c, int d) { return d == 0 || ((d - 1) % c->n_ranks) == c->rank; }
 
 extern "C" int msevb_comm_allgather_evb(msevb_ctx* c);   // comm.hip
+extern "C" int msevb_comm_allreduce_energies(msevb_ctx* c);
 
 int evb_force_energy(msevb_ctx* c, double* epot_out) {
   static const bool ht_on = getenv("MSEVB_HOST_TIMING") != nullptr;
@@ -886,7 +887,10 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   HIPCHK(hipEventRecord(w->ev_region, w->stream2));
   HT(1);
   // ---- 2. principal diabat (calculate_total_force_energy, src/ms_evb.f90:411) - enqueued, not waited for
-  CHK(total_force_enqueue(c));
+  c->shard_now = c->shard_principal && c->n_ranks > 1;
+  const int rc_tfe = total_force_enqueue(c);
+  c->shard_now = false;
+  CHK(rc_tfe);
   HT(2);
   HIPCHK(hipEventSynchronize(w->ev_region));
   const int nreg = *w->h_count;
@@ -1184,13 +1188,19 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   HT(8);
   // ---- 9. energies to the host, Hamiltonian
   if (c->overlap) HIPCHK(hipEventSynchronize(w->ev_fetch));     // energies left before the gather started (early_fetch)
+  const double E_recip1 = c->h_energies[S_RECIP];      // this rank's own (complete) principal reciprocal energy
+  // sharded principal diabat: the real-space energy slots are partial sums; replicated terms count once (rank 0)
+  const bool sharded = c->shard_principal && c->n_ranks > 1;
+  if (sharded && c->rank != 0) c->h_energies[S_RECIP] = 0.0;
+  if (sharded && c->nccl_comm) CHK(msevb_comm_allreduce_energies(c));      // -> complete and identical on every rank
+  const bool partial = sharded && !c->nccl_comm;                            // virtual ranks (tests): the caller sums
   double en[MSEVB_N_ENERGY];
   total_force_collect(c, en);
-  const double E_recip1 = c->E_recip;
   memset(c->H, 0, sizeof c->H);
   auto unitE = [&](int iu) { return w->h_E[iu] + w->h_E[nu + iu]; };
-  const double H11_norep = en[MSEVB_E_POTENTIAL] + c->e_ref[c->h_mol_type[c->hydronium]];
-  const double H11 = H11_norep + unitE(units_of[0][0]);
+  const double once = (partial && c->rank != 0) ? 0.0 : 1.0;
+  const double H11_norep = en[MSEVB_E_POTENTIAL] - (1.0 - once) * c->ewald_self + once * c->e_ref[c->h_mol_type[c->hydronium]];
+  const double H11 = H11_norep + once * unitE(units_of[0][0]);
   c->H[0][0] = H11;
   for (int d = 1; d < D; ++d) {
     if (!owned(c, d)) continue;

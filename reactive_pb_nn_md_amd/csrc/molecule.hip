@@ -10,14 +10,14 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void k_molecules(int M, const int* __restrict__ mol_type, const int* __restrict__ mol_natom,
+__global__ __launch_bounds__(256) void k_molecules(int m_lo, int M, const int* __restrict__ mol_type, const int* __restrict__ mol_natom,
                                                    const int* __restrict__ mol_atoms, const MolTypeDev* __restrict__ mts,
                                                    const double* __restrict__ xyz, const double* __restrict__ chg, double* __restrict__ F,
                                                    const double2* __restrict__ etab, double inv_dx, const double* __restrict__ tt,
                                                    const double* __restrict__ dtt, double rc2, double alpha, double erf_factor, double conv,
                                                    double pi_ref, int do_nb, int do_bonded, double* __restrict__ partials, int slot0) {
   __shared__ double red[5][256];
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = m_lo + blockIdx.x * blockDim.x + threadIdx.x;
   double e[5] = {0, 0, 0, 0, 0};
   if (m < M) {
     const MolTypeDev& mt = mts[mol_type[m]];
@@ -46,10 +46,12 @@ __global__ __launch_bounds__(256) void k_molecules(int M, const int* __restrict_
 
 // slots slot0..slot0+4 = E_elec(intra), E_vdw(intra), E_bond, E_angle, E_dihedral
 int molecule_forces(msevb_ctx* c, int slot0, bool do_nb, bool do_bonded, hipStream_t st) {
-  const int M = c->M, nb = (M + 255) / 256;
+  int m_lo, m_hi;
+  shard_range(c, c->M, m_lo, m_hi);
+  const int nb = (m_hi - m_lo + 255) / 256;
   if (!st) st = c->stream;
   phase_begin(c, PH_MOLECULE, st);
-  hipLaunchKernelGGL(k_molecules, dim3(nb), dim3(256), 0, st, M, c->d_mol_type.p, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_moltypes.p,
+  hipLaunchKernelGGL(k_molecules, dim3(nb), dim3(256), 0, st, m_lo, m_hi, c->d_mol_type.p, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_moltypes.p,
                      c->d_xyz.p, c->d_chg.p, c->d_force.p, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, c->rc * c->rc, c->alpha,
                      2.0 * c->alpha / c->pi_sqrt, c->conv, c->pi, do_nb ? 1 : 0, do_bonded ? 1 : 0, c->d_partials.p, slot0);
   HIPCHK(hipGetLastError());

@@ -60,7 +60,7 @@ __device__ __forceinline__ void pair_row(PosPtr src, const double4 pi, int ti, u
 }
 
 template <bool SAPT>
-__global__ __launch_bounds__(256) void k_pair(int N, const double4* __restrict__ posq, const int* __restrict__ type_s,
+__global__ __launch_bounds__(256) void k_pair(int i_lo, int N, const double4* __restrict__ posq, const int* __restrict__ type_s,
                                               const unsigned* __restrict__ nbr_start, const unsigned* __restrict__ nbr_count, const int* __restrict__ nbr,
                                               const PairParam* __restrict__ pairpar, int nt, const double2* __restrict__ etab, double inv_dx, int emax,
                                               const double* __restrict__ tt, const double* __restrict__ dtt, BoxDev box, double rc2,
@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void k_pair(int N, const double4* __restrict__
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   double e_el = 0.0, e_vdw = 0.0;
   // contiguous chunk of sorted atoms per block, blocks in XCD-aware order (neighbourhoods of one slab stay in one L2)
-  const int per_block = (N + gridDim.x - 1) / gridDim.x;
-  const int i0 = xcd_block(blockIdx.x, gridDim.x) * per_block, i1 = min(N, i0 + per_block);
+  const int per_block = (N - i_lo + gridDim.x - 1) / gridDim.x;      // [i_lo, N): this rank's share of the sorted atoms
+  const int i0 = i_lo + xcd_block(blockIdx.x, gridDim.x) * per_block, i1 = min(N, i0 + per_block);
   for (int i = i0 + wave; i < i1; i += wpb) {
     const double4 pi = posq[i];
     const int ti = type_s[i];
@@ -167,7 +167,7 @@ int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw) {
   for (int d = 0; d < 3; ++d) { box.L[d] = c->box[d]; box.invL[d] = 1.0 / c->box[d]; }
   int nblocks;
   phase_begin(c, PH_PAIR);
-  if (c->pair_tiles) {
+  if (c->pair_tiles && !(c->shard_now && c->n_ranks > 1)) {
     const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
     if (ncell > MAX_BLOCKS) FAIL(MSEVB_ERR_LIMIT, "pair_forces: too many cells");
     nblocks = ncell;
@@ -183,11 +183,13 @@ int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw) {
                        c->d_nbr_start.p, c->d_nbr_count.p, c->d_nbr.p, c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->erfc_grid, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->d_perm.p,
                        c->d_force.p, c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS, c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS);
   } else {
-    nblocks = round_up8((N + 7) / 8);      // 8 atoms per block, two per wave
+    int i_lo, i_hi;
+    shard_range(c, N, i_lo, i_hi);
+    nblocks = round_up8((i_hi - i_lo + 7) / 8);      // 8 atoms per block, two per wave
     if (nblocks > 16384) nblocks = 16384;
     // force fields without a live SAPT term (every Buckingham coefficient zero, as in the CH3SO3H/H2O example) run the lean instantiation
     auto kern = c->has_sapt ? k_pair<true> : k_pair<false>;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), c->nt * c->nt * sizeof(PairParam), c->stream, N, c->d_posq.p, c->d_type_sorted.p,
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), c->nt * c->nt * sizeof(PairParam), c->stream, i_lo, i_hi, c->d_posq.p, c->d_type_sorted.p,
                        c->d_nbr_start.p, c->d_nbr_count.p, c->d_nbr.p, c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->erfc_grid, c->d_tt.p, c->d_dtt.p, box,
                        c->rc * c->rc, c->d_perm.p, c->d_force.p, c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS,
                        c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS);

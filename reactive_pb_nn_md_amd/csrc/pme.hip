@@ -145,7 +145,7 @@ __global__ void k_pme_real(size_t K3, const double2* __restrict__ grid, double* 
 __global__ __launch_bounds__(256) void k_pme_gather(int N, int K, const double* __restrict__ chg, const int* __restrict__ base,
                                                     const double* __restrict__ w, const double* __restrict__ dw, const double* __restrict__ theta,
                                                     double conv, double k00, double k01, double k02, double k10, double k11, double k12,
-                                                    double k20, double k21, double k22, double* __restrict__ F_recip, double* __restrict__ F, int atomic) {
+                                                    double k20, double k21, double k22, double* __restrict__ F_recip, double* __restrict__ F, int atomic, int add_lo, int add_hi) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = t >> 3, sub = t & 7;
   double f1 = 0.0, f2 = 0.0, f3 = 0.0;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_pme_gather(int N, int K, const double* 
     const double fy = -Kd * (k01 * f1 + k11 * f2 + k21 * f3);
     const double fz = -Kd * (k02 * f1 + k12 * f2 + k22 * f3);
     F_recip[3 * i] = fx; F_recip[3 * i + 1] = fy; F_recip[3 * i + 2] = fz;
-    if (F) {
+    if (F && i >= add_lo && i < add_hi) {      // the total force takes this atom only on the rank that owns it
       if (atomic) { atomicAdd(&F[3 * i], fx); atomicAdd(&F[3 * i + 1], fy); atomicAdd(&F[3 * i + 2], fz); }     // beside the pair loop
       else { F[3 * i] += fx; F[3 * i + 1] += fy; F[3 * i + 2] += fz; }
     }
@@ -278,8 +278,10 @@ int pme_prepare_atoms(msevb_ctx* c, bool with_indices) {
 
 int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic) {
   const int N = c->N;
+  int add_lo, add_hi;
+  shard_range(c, N, add_lo, add_hi);
   hipLaunchKernelGGL(k_pme_gather, dim3((N * 8 + 255) / 256), dim3(256), 0, c->stream, N, c->K, chg, c->d_base.p, c->d_w.p, c->d_dw.p, c->d_theta.p, c->conv, c->kk[0][0],
-                     c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, atomic ? 1 : 0);
+                     c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, atomic ? 1 : 0, add_lo, add_hi);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
 }

@@ -189,6 +189,29 @@ def test_diabat_sharding_is_a_partition(n_ranks):
     assert np.abs(Fsum - Fblend).max() < 1e-10
 
 
+@pytest.mark.parametrize("n_ranks", [2, 3])
+def test_sharded_principal_partial_sums(n_ranks):
+    """multi-rank layout with the principal diabat's pair loop / per-molecule terms / reciprocal-force accumulation split over the ranks
+    (what msevb_comm_init switches on): the ranks' partial blends and partial H11 add up to the single-rank force and energy"""
+    g = golden("evb_n6_d8_s1")
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    _e, Fblend = h.ms_evb_calculate_total_force_energy()
+    full = h.evb_state()
+    h.close()
+    Fsum, Esum = np.zeros_like(Fblend), 0.0
+    for r in range(n_ranks):
+        hr = api.MsEvbHip(spec)
+        hr.set_option("shard_principal", 1)
+        hr.comm_set_virtual(r, n_ranks)
+        e_part, _ = hr.ms_evb_calculate_total_force_energy(want_force=False)      # virtual ranks return their share of H11
+        Esum += e_part
+        Fsum += hr.evb_partial_blend(full["eigvec"])
+        hr.close()
+    assert np.abs(Fsum - Fblend).max() < 1e-10
+    assert rel(Esum, full["H"][0, 0]) < 1e-13
+
+
 def _synthetic(n_side, n_diabat, seed, K, rc=9.0, rv=10.5):
     s = synth.make_system(n_side, n_diabat=n_diabat, seed=seed)
     p = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"])

@@ -465,9 +465,12 @@ __global__ __launch_bounds__(256) void k_evb_coupling(int N, int n_cp, const Cou
         const double qi = (side == 1 && q == na - 1) ? cp.q_transfer : exch_atomic[a.type];
         double rij[3];
         for (int d = 0; d < 3; ++d) { const double xz = cp.zc[d] + (a.x[d] - cp.zc[d] - shm[d]); rij[d] = -(xyz[3 * j + d] - xz - sh[d]); }
-        const double r2 = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2], r = sqrt(r2);
-        vex += qi * qj / r * conv;
-        const double g = -qi * qj / (r2 * r) * conv;
+        const double r2 = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2];
+        double r, inv_r;
+        sqrt_rsqrt(r2, r, inv_r);                     // one v_rsq_f64 + two Newton steps instead of an IEEE sqrt and two divisions
+        const double qq = qi * qj * conv * inv_r;
+        vex += qq;
+        const double g = -qq * inv_r * inv_r;
         for (int d = 0; d < 3; ++d) { fj[d] -= g * rij[d]; fz[side * cp.nD + q][d] += g * rij[d]; }
       }
     }

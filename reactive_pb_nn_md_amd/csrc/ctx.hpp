@@ -152,6 +152,7 @@ struct msevb_ctx {
   // multi-rank EVB: the principal diabat's pair loop, per-molecule terms and reciprocal-force accumulation are split over the ranks by
   // atom / molecule ranges (the partial principal forces meet in the all-reduce of the blend); set by msevb_comm_init, or by the
   // "shard_principal" option for virtual ranks (tests)
+  double cpl_A[MAX_DIABATS] = {0};   // geometric coupling factor A of each owned diabat (off-diagonal stores hold dV, F_pd = -A dV)
   bool shard_principal = false;
   bool shard_now = false;        // true while the EVB force call enqueues the principal diabat
   int pair_tiles_opt = 0;        // 0 off (default: measured slower than the global-gather kernel once the PME front end overlaps it), 1 on when it fits, -1 auto

@@ -572,14 +572,8 @@ __global__ void k_evb_coupling_finish(int n_cp, const CouplingDesc* __restrict__
   const double pre = Vc + vex;
   for (int d = 0; d < 3; ++d) { dV[cp.gO1][d] += pre * dA[0][d] / A; dV[cp.gO2][d] += pre * dA[1][d] / A; dV[cp.gH][d] += pre * dA[2][d] / A; }
   double* F = Foff + (size_t)cp.slot * fstride;
-  for (int k = 0; k < cp.n_spec; ++k) for (int d = 0; d < 3; ++d) F[3 * cp.spec[k].idx + d] = dV[k][d];   // still "dV"; scaled below with all atoms
+  for (int k = 0; k < cp.n_spec; ++k) for (int d = 0; d < 3; ++d) F[3 * cp.spec[k].idx + d] = dV[k][d];   // still "dV": the factor -A goes into the blend coefficient
   out[3 * ic] = A; out[3 * ic + 1] = pre; out[3 * ic + 2] = pre * A;
-}
-__global__ void k_evb_scale(size_t n3, int n_cp, const CouplingDesc* __restrict__ cps, const double* __restrict__ out, double* __restrict__ Foff, size_t fstride) {
-  const int ic = blockIdx.y;
-  double* F = Foff + (size_t)cps[ic].slot * fstride;
-  const double mA = -out[3 * ic];
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (size_t)gridDim.x * blockDim.x) F[k] *= mA;
 }
 
 // Hellmann-Feynman blend: F = sum_d c_d^2 F_dd + 2 sum_(p,d) c_p c_d F_pd (src/ms_evb.f90:293-309).
@@ -838,7 +832,7 @@ static double blend_terms(const msevb_ctx* c, int D, const double* ev, BlendTerm
   bt.n = 0;
   for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) {
     if (i == j) { if (i == 0 ? c->rank == 0 : owned(c, i)) { bt.coef[bt.n] = ev[i] * ev[j]; bt.slot[bt.n++] = diag_slot(c, D, i); } }
-    else if (c->parent[j] == i && owned(c, j)) { bt.coef[bt.n] = 2.0 * ev[i] * ev[j]; bt.slot[bt.n++] = -off_slot(c, D, j) - 1; }
+    else if (c->parent[j] == i && owned(c, j)) { bt.coef[bt.n] = 2.0 * ev[i] * ev[j] * -c->cpl_A[j]; bt.slot[bt.n++] = -off_slot(c, D, j) - 1; }
   }
   return (c->rank == 0 || (c->shard_principal && c->n_ranks > 1)) ? 1.0 : 0.0;      // sharded principal: every rank holds a part of F11
 }
@@ -1114,7 +1108,6 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     hipLaunchKernelGGL(k_sum_rows, dim3(ncp), dim3(256), 0, so, ncp, cpb, part_stride, part_cp, E_cp_env);
     hipLaunchKernelGGL(k_evb_coupling_finish, dim3(ncp), dim3(64), 0, so, ncp, d_cps, w->d_exch.p, c->d_mass.p, box, c->conv, E_cp_env,
                        w->d_dVspec.p, c->d_Foff.p, n3, d_cpout);
-    hipLaunchKernelGGL(k_evb_scale, dim3(256, ncp), dim3(256), 0, so, n3, ncp, d_cps, d_cpout, c->d_Foff.p, n3);
     HIPCHK(hipGetLastError());
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_cpl, so));
   }
@@ -1212,6 +1205,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     e += w->h_E[2 * nu + ncp + grid_of[d]] - E_recip1;
     c->H[d][d] = e;
     c->H[c->parent[d]][d] = w->h_E[2 * nu + ncp + ngrid + 3 * cp_of[d] + 2];
+    c->cpl_A[d] = w->h_E[2 * nu + ncp + ngrid + 3 * cp_of[d]];      // geometric factor A: the off-diagonal store holds dV, F_pd = -A dV
   }
   HT(9);
   // ---- 10. multi-GPU: complete the Hamiltonian and the force stores on every rank
@@ -1344,6 +1338,7 @@ int msevb_get_evb_element_force(msevb_ctx* c, int i, int j, double* force) {
   if (!owned(c, j - 1)) { memset(force, 0, n3 * 8); return MSEVB_OK; }
   HIPCHK(hipMemcpyAsync(force, c->d_Foff.p + (size_t)off_slot(c, c->D, j - 1) * n3, n3 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  for (size_t k = 0; k < n3; ++k) force[k] *= -c->cpl_A[j - 1];      // the store holds dV of the coupling; F_pd = -A dV
   return MSEVB_OK;
 }
 

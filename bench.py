@@ -168,7 +168,8 @@ def main():
         traffic = None        # HBM bytes per launch from the committed PMC passes (profiles/traffic.json, tools/make_traffic_json.py)
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if dom in tj and world == 1:
+            wl = tj.get("_workload", {})
+            if dom in tj and world == 1 and wl.get("n_atoms") == spec.n_atom and wl.get("pme_grid") == spec.pme_grid and use_evb:
                 traffic = int(tj[dom]["hbm_bytes_per_launch"])
         except (OSError, ValueError, KeyError):
             pass

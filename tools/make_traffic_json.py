@@ -17,5 +17,6 @@ for sub, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             e[key.lower() + "_bytes_per_launch"] = v / n * 1024.0
 for e in out.values():
     e["hbm_bytes_per_launch"] = e.get("fetch_size_bytes_per_launch", 0.0) + e.get("write_size_bytes_per_launch", 0.0)
+out["_workload"] = {"n_atoms": 98220, "n_diabats": 8, "pme_grid": 64, "note": "bench.py default workload (configs[2])"}
 json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -144,6 +144,23 @@ module msevb_hip_c
        type(c_ptr), value :: ctx
        real(c_double), intent(out) :: ke
      end function
+     ! ---- multi-GPU (one process per GPU; the id is created on rank 0 and broadcast by the host, e.g. with MPI_Bcast of 128 bytes)
+     integer(c_int) function msevb_comm_unique_id(id_bytes_128) bind(C, name="msevb_comm_unique_id")
+       import :: c_int, c_signed_char
+       integer(c_signed_char), intent(out) :: id_bytes_128(128)
+     end function
+     integer(c_int) function msevb_comm_init(ctx, id_bytes_128, rank, n_ranks) bind(C, name="msevb_comm_init")
+       import :: c_ptr, c_int, c_signed_char
+       type(c_ptr), value :: ctx
+       integer(c_signed_char), intent(in) :: id_bytes_128(128)
+       integer(c_int), value :: rank, n_ranks
+     end function
+     integer(c_int) function msevb_set_option(ctx, name, value) bind(C, name="msevb_set_option")
+       import :: c_ptr, c_int, c_double, c_char
+       type(c_ptr), value :: ctx
+       character(kind=c_char), intent(in) :: name(*)      ! NUL-terminated, e.g. "overlap"//c_null_char
+       real(c_double), value :: value
+     end function
   end interface
 contains
   ! the reference `stop`s on error (SURVEY.md 8b); the shim keeps that convention for the Fortran caller

@@ -255,6 +255,23 @@ def test_full_size_properties_config_B():
     # idempotence: same positions -> same answer
     e2, F2 = h.ms_evb_calculate_total_force_energy()
     assert rel(e2, e) < 1e-13 and np.abs(F2 - F).max() < 1e-9
+    # the three-stream schedule is only a schedule: everything in call order on one stream gives the same numbers
+    h.set_option("overlap", 0)
+    e3, F3 = h.ms_evb_calculate_total_force_energy()
+    assert rel(e3, e) < 1e-13 and np.abs(F3 - F).max() < 1e-9
+    h.set_option("overlap", 1)
+    # ... also along a trajectory (list rebuilds, self-cleaning delta store, asynchronous kinetic energies): 40 steps from the same
+    # state with and without overlap give the same energies
+    x0 = h.get_positions()
+    v0 = synth.maxwell_boltzmann(spec.mass, 300.0, 4321)
+    h.set_velocities(v0)
+    tr1 = h.md_integrate_atomic(40, spec.delta_t, use_evb=True)       # starts from the forces of the call above (same positions)
+    h.set_positions(x0)
+    h.set_velocities(v0)
+    h.set_option("overlap", 0)
+    h.ms_evb_calculate_total_force_energy(want_force=False)           # velocity Verlet starts from the forces at the current positions
+    tr2 = h.md_integrate_atomic(40, spec.delta_t, use_evb=True)
+    assert np.abs(tr1 - tr2).max() < 1e-6 * np.abs(tr1).max()
     h.close()
 
 

@@ -78,8 +78,18 @@ def _plant_tree(acid_xyz, n_water, max_chain):
     return waters
 
 
+def _random_rotations(rng, n):
+    """n uniformly distributed rotation matrices (normalised Gaussian quaternions)"""
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    w, x, y, z = q.T
+    return np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                     np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                     np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], 1)
+
+
 def make_system(n_side: int, n_diabat: int = 1, seed: int = 0, max_chain: int = 3,
-                acid_position: str = "middle", quantize_gro: bool = True) -> System:
+                acid_position: str = "middle", quantize_gro: bool = True, liquid_like: bool = False) -> System:
     """n_side^3 lattice sites (box = n_side*3.1 A); n_diabat = 1 + number of planted waters
     (1, 2, 4 -> partial tree, 8 -> full depth-3 binary tree, 16 needs max_chain=4)."""
     rng = np.random.default_rng(seed)
@@ -109,7 +119,15 @@ def make_system(n_side: int, n_diabat: int = 1, seed: int = 0, max_chain: int = 
             keep &= (d ** 2).sum(1) > 3.3 ** 2
     sites = sites[keep]
     nl = len(sites)
-    lat = sites[:, None, :] + _WATER[None, :, :] + rng.uniform(-0.15, 0.15, size=(nl, 3, 3))
+    if liquid_like:
+        # rigid molecules at the force field's equilibrium geometry (r0 = 1.012 A, 113.24 deg), random orientation, rigid jitter:
+        # no intramolecular strain and no systematic H...H contacts (the default per-atom jitter starts ~60 kJ/mol per molecule hot)
+        half = np.deg2rad(113.24) / 2.0
+        tmpl = np.array([[0.0, 0.0, 0.0], [1.012 * np.sin(half), 1.012 * np.cos(half), 0.0], [-1.012 * np.sin(half), 1.012 * np.cos(half), 0.0]])
+        R = _random_rotations(rng, nl)
+        lat = sites[:, None, :] + np.einsum("mij,aj->mai", R, tmpl) + rng.uniform(-0.15, 0.15, size=(nl, 1, 3))
+    else:
+        lat = sites[:, None, :] + _WATER[None, :, :] + rng.uniform(-0.15, 0.15, size=(nl, 3, 3))
 
     # molecule order: lattice waters with the acid (and alternating planted waters) in the middle
     mols = []  # (name, coords)

@@ -1,0 +1,15 @@
+import sys, os
+sys.path.insert(0, "/root/repo")
+import numpy as np
+from reactive_pb_nn_md_amd import api, forcefield, synth, system
+s = synth.make_system(32, n_diabat=8, seed=0, max_chain=3, liquid_like=("liquid" in sys.argv))
+p = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"])
+spec = system.from_synth(s, p, rc=9.0, rv=10.5, alpha=0.3, pme_grid=64, max_chain=3)
+h = api.MsEvbHip(spec)
+h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 12345))
+h.ms_evb_calculate_total_force_energy(want_force=False)
+tr = h.md_integrate_atomic(300, spec.delta_t, use_evb=True)
+e = tr.sum(1)
+print("D", h.evb_state()["D"])
+for k in (0, 1, 2, 5, 10, 20, 50, 100, 150, 200, 250, 299):
+    print(k, "Epot %.1f KE %.1f Etot %.1f" % (tr[k, 0], tr[k, 1], e[k]))

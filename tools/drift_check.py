@@ -13,3 +13,10 @@ e = tr.sum(1)
 print("D", h.evb_state()["D"])
 for k in (0, 1, 2, 5, 10, 20, 50, 100, 150, 200, 250, 299):
     print(k, "Epot %.1f KE %.1f Etot %.1f" % (tr[k, 0], tr[k, 1], e[k]))
+de = np.abs(np.diff(e))
+j = int(np.argmax(de))
+print("largest one-step change of Etot: %.1f at step %d" % (de[j], j + 1))
+for k in range(max(0, j - 3), min(len(e), j + 4)):
+    print("  ", k, "Epot %.1f KE %.1f Etot %.1f" % (tr[k, 0], tr[k, 1], e[k]))
+st = h.evb_state()
+print("final D", st["D"], "principal", st["principle_diabat"], "hydronium", st["new_hydronium_molecule"])

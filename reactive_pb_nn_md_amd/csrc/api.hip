@@ -50,15 +50,10 @@ int msevb_create(msevb_ctx** out, int device_id) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { c->err = "no HIP device visible: libmsevb_hip has no CPU fallback"; return MSEVB_ERR_HIP; }
   HIPCHK(hipSetDevice(device_id));
-  // the main stream carries the critical chain (pair loop, all-atom gather, blend): highest priority, so its workgroups are dispatched
-  // first and the side streams fill what is left
-  int prio_lo = 0, prio_hi = 0;
-  HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-  const char* pe = getenv("MSEVB_NO_PRIORITY");
-  HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pe ? prio_lo : prio_hi));
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));      // equal priorities: a favoured main stream starves the side chains
   c->own_stream = true;
-  HIPCHK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_lo));
-  HIPCHK(hipStreamCreateWithPriority(&c->aux2, hipStreamNonBlocking, prio_lo));
+  HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));

@@ -416,77 +416,94 @@ __global__ __launch_bounds__(256) void k_evb_recip_special(int n, const RecipAto
   if (lane == 0) { double* F = Fstore + (size_t)r.slot * fstride; for (int d = 0; d < 3; ++d) F[3 * r.idx + d] += tot[d]; }
 }
 
+// centre of mass of every molecule, stored per ATOM (coalesced reads in k_evb_coupling, which takes the minimum image per molecule)
+__global__ void k_mol_com(int M, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms, const double* __restrict__ xyz, const double* __restrict__ mass,
+                          double* __restrict__ com_atom) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int n = mol_natom[m];
+  double com[3] = {0, 0, 0}, mt = 0;
+  for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; const double ma = mass[a]; for (int d = 0; d < 3; ++d) com[d] += xyz[3 * a + d] * ma; mt += ma; }
+  for (int d = 0; d < 3; ++d) com[d] /= mt;
+  for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) com_atom[3 * a + d] = com[d]; }
+}
+
 // ---- off-diagonal element -------------------------------------------------------------------------------------------------
-// exchange-charge Coulomb sum over all NON-special molecules (evb_diabatic_coupling_electrostatics, src/ms_evb.f90:1276):
-// one thread per atom (coalesced dVex stores); the minimum image is taken per molecule, relative to the Zundel centre of mass,
-// so every thread re-derives the centre of mass of its (<= 8 atom) molecule.
-__global__ __launch_bounds__(256) void k_evb_coupling(int N, int n_cp, const CouplingDesc* __restrict__ cps, const int* __restrict__ mol_of, const int* __restrict__ mol_natom,
-                                                      const int* __restrict__ mol_atoms, const double* __restrict__ xyz, const double* __restrict__ chg,
-                                                      const double* __restrict__ mass, const int* __restrict__ atype, const double* __restrict__ exch_atomic,
+// exchange-charge Coulomb sum over all NON-special molecules (evb_diabatic_coupling_electrostatics, src/ms_evb.f90:1276).
+// lane = (atom j, Zundel atom q): QL q-lanes x 64/QL atoms per wavefront trip.  Every lane evaluates ONE pair; the force on atom j is the
+// butterfly sum over its 16 q-lanes (lanes q = 0..2 store x,y,z: the atoms of a trip are consecutive, so the store is contiguous), the
+// force on Zundel atom q accumulates per lane over the trips and is reduced over the 4 atom-lanes at the end.  No private arrays: the
+// thread-per-atom version kept 16 x 3 Zundel accumulators in scratch memory (dynamic indexing) and ran 4x longer.  The minimum image is
+// taken per molecule, relative to the Zundel centre of mass, with the molecular centres of mass precomputed per atom by k_mol_com.
+template <int QL>      // q-lanes per atom: 8 when every coupling has <= 8 Zundel atoms (water / hydronium), else 16
+__global__ __launch_bounds__(256) void k_evb_coupling(int N, int n_cp, const CouplingDesc* __restrict__ cps, const int* __restrict__ mol_of,
+                                                      const double* __restrict__ com_atom, const double* __restrict__ xyz, const double* __restrict__ chg,
+                                                      const double* __restrict__ exch_atomic,
                                                       BoxDev box, double conv, double* __restrict__ Foff, size_t fstride, double* __restrict__ part,
-                                                      int part_stride, double* __restrict__ dVspec) {
+                                                      int part_stride, double* __restrict__ dVspec, int ic0) {
+  constexpr int APW = 64 / QL;      // atoms per wavefront trip
   __shared__ CouplingDesc cp;
   __shared__ double sF[MAX_SPEC][3];
   __shared__ double red[256];
-  __shared__ double stage[3 * 256];
-  const int ic = blockIdx.y;
+  __shared__ double zx[QL][3], zq[QL];                      // Zundel atoms: image next to the Zundel centre, exchange charge
+  __shared__ int zspec[QL];
+  const int ic = ic0 + blockIdx.y;
   {
     const int* src = (const int*)&cps[ic]; int* dst = (int*)&cp;
     for (int k = threadIdx.x; k < (int)(sizeof(CouplingDesc) / 4); k += blockDim.x) dst[k] = src[k];
     for (int k = threadIdx.x; k < MAX_SPEC * 3; k += blockDim.x) (&sF[0][0])[k] = 0.0;
   }
   __syncthreads();
+  const int nz = cp.nD + cp.nA;
+  if ((int)threadIdx.x < QL) {
+    const int q = threadIdx.x;
+    if (q < nz) {
+      const bool acc = q >= cp.nD;
+      const int sp = acc ? cp.A_at[q - cp.nD] : cp.D_at[q];
+      const SpecAtom& a = cp.spec[sp];
+      const double* shm = acc ? cp.shifta : cp.shiftd;
+      for (int d = 0; d < 3; ++d) zx[q][d] = cp.zc[d] + (a.x[d] - cp.zc[d] - shm[d]);
+      zq[q] = (acc && q == nz - 1) ? cp.q_transfer : exch_atomic[a.type];
+      zspec[q] = sp;
+    } else { zx[q][0] = zx[q][1] = zx[q][2] = 0.0; zq[q] = 0.0; zspec[q] = 0; }
+  }
+  __syncthreads();
   double* F = Foff + (size_t)cp.slot * fstride;
-  double vex = 0.0;
-  double fz[2 * MAX_MOL_ATOMS][3];
-#pragma unroll
-  for (int a = 0; a < 2 * MAX_MOL_ATOMS; ++a) fz[a][0] = fz[a][1] = fz[a][2] = 0.0;
-  // block-uniform trip count: the 256 x 3 forces of a trip are staged through LDS and stored as 768 consecutive doubles (three
-  // 8-B stores per thread at a 24-B stride cost 10x their bytes in HBM write traffic)
-  for (int j0 = blockIdx.x * blockDim.x; j0 < N; j0 += gridDim.x * blockDim.x) {
-    const int j = j0 + threadIdx.x;
-    double fj[3] = {0, 0, 0};
+  const int lane = threadIdx.x & 63, q = lane & (QL - 1), js = lane / QL;
+  const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+  const bool qlive = q < nz;
+  const double zxq[3] = {zx[q][0], zx[q][1], zx[q][2]}, zqq = zq[q];
+  double vex = 0.0, fzx = 0.0, fzy = 0.0, fzz = 0.0;
+  for (int j0 = wave_g * APW; j0 < N; j0 += n_waves * APW) {      // wave-uniform trip count
+    const int j = j0 + js;
+    double fx = 0.0, fy = 0.0, fz = 0.0;
     bool special = j >= N;
     const int m = special ? 0 : mol_of[j];
     for (int k = 0; k < cp.n_mols; ++k) special |= (cp.mols[k] == m);
-    if (!special) {
-    const int n = mol_natom[m];
-    double com[3] = {0, 0, 0}, mt = 0;
-    for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; const double ma = mass[a]; for (int d = 0; d < 3; ++d) com[d] += xyz[3 * a + d] * ma; mt += ma; }
-    double sh[3];
-    for (int d = 0; d < 3; ++d) { com[d] /= mt; sh[d] = floor((com[d] - cp.zc[d]) * box.invL[d] + 0.5) * box.L[d]; }
-    const double qj = chg[j];
-    for (int side = 0; side < 2; ++side) {
-      const int na = side == 0 ? cp.nD : cp.nA;
-      const int* lst = side == 0 ? cp.D_at : cp.A_at;
-      const double* shm = side == 0 ? cp.shiftd : cp.shifta;
-      for (int q = 0; q < na; ++q) {
-        const SpecAtom& a = cp.spec[lst[q]];
-        const double qi = (side == 1 && q == na - 1) ? cp.q_transfer : exch_atomic[a.type];
-        double rij[3];
-        for (int d = 0; d < 3; ++d) { const double xz = cp.zc[d] + (a.x[d] - cp.zc[d] - shm[d]); rij[d] = -(xyz[3 * j + d] - xz - sh[d]); }
-        const double r2 = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2];
-        double r, inv_r;
-        sqrt_rsqrt(r2, r, inv_r);                     // one v_rsq_f64 + two Newton steps instead of an IEEE sqrt and two divisions
-        const double qq = qi * qj * conv * inv_r;
-        vex += qq;
-        const double g = -qq * inv_r * inv_r;
-        for (int d = 0; d < 3; ++d) { fj[d] -= g * rij[d]; fz[side * cp.nD + q][d] += g * rij[d]; }
+    if (!special && qlive) {
+      double rij[3];
+      for (int d = 0; d < 3; ++d) {
+        const double sh = floor((com_atom[3 * j + d] - cp.zc[d]) * box.invL[d] + 0.5) * box.L[d];
+        rij[d] = -(xyz[3 * j + d] - zxq[d] - sh);
       }
+      const double r2 = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2];
+      double r, inv_r;
+      sqrt_rsqrt(r2, r, inv_r);                     // one v_rsq_f64 + two Newton steps instead of an IEEE sqrt and two divisions
+      const double qq = zqq * chg[j] * conv * inv_r;
+      vex += qq;
+      const double g = -qq * inv_r * inv_r;
+      fx = -g * rij[0]; fy = -g * rij[1]; fz = -g * rij[2];
+      fzx -= fx; fzy -= fy; fzz -= fz;
     }
-    }
-    __syncthreads();
-    for (int d = 0; d < 3; ++d) stage[3 * threadIdx.x + d] = fj[d];    // dVex of this atom (0 for special atoms: k_evb_coupling_finish assigns them); scaled by -A later
-    __syncthreads();
-    for (int q = threadIdx.x; q < 3 * (int)blockDim.x; q += blockDim.x) if (3 * j0 + q < 3 * N) F[3 * (size_t)j0 + q] = stage[q];
+#pragma unroll
+    for (int o = 1; o < QL; o <<= 1) { fx += __shfl_xor(fx, o, 64); fy += __shfl_xor(fy, o, 64); fz += __shfl_xor(fz, o, 64); }
+    // dVex of atom j (0 for special atoms: k_evb_coupling_finish assigns them); the factor -A goes into the blend coefficient
+    if (j < N && q < 3) F[3 * (size_t)j + q] = q == 0 ? fx : q == 1 ? fy : fz;
   }
-  // forces on the Zundel atoms: per-thread registers -> wave shuffle -> one LDS add per wave
-  for (int a = 0; a < cp.nD + cp.nA; ++a) for (int d = 0; d < 3; ++d) {
-    double v = fz[a][d];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(&sF[a < cp.nD ? cp.D_at[a] : cp.A_at[a - cp.nD]][d], v);
-  }
-  __syncthreads();
+  // forces on the Zundel atoms: sum over the atom-lanes of the wave, one LDS add per (wave, q, component)
+#pragma unroll
+  for (int o = QL; o < 64; o <<= 1) { fzx += __shfl_xor(fzx, o, 64); fzy += __shfl_xor(fzy, o, 64); fzz += __shfl_xor(fzz, o, 64); }
+  if (js == 0 && qlive) { atomicAdd(&sF[zspec[q]][0], fzx); atomicAdd(&sF[zspec[q]][1], fzy); atomicAdd(&sF[zspec[q]][2], fzz); }
   red[threadIdx.x] = vex;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
@@ -650,7 +667,7 @@ struct EvbWork {   // persistent device scratch of one context
   DBuf<double2> d_grids; DBuf<RegionRec> d_region; DBuf<int> d_cand;
   DBuf<double> d_Fdelta;      // [n_diag][3N] real-space deltas of the diabats, accumulated on stream2 beside the reciprocal space
   hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_E = nullptr, ev_fetch = nullptr, ev_cpl = nullptr, ev_flush = nullptr; bool delta_dirty = true;
-  DBuf<double> d_F11, d_pack;
+  DBuf<double> d_F11, d_pack, d_com_atom;
   hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
   RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
   char* h_desc = nullptr; DBuf<char> d_desc; size_t desc_cap = 0;   // units | couplings | recip atoms, one pinned block -> one upload
@@ -1003,17 +1020,29 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     cp_of[d] = (int)cps.size();
     cps.push_back(cp);
   }
+  // couplings with more than 8 Zundel atoms first: they take the 16-lane instantiation of k_evb_coupling, the rest the 8-lane one
+  int ncp_big = 0;
+  {
+    std::vector<int> order(cps.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = (int)k;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return (cps[a].nD + cps[a].nA > 8) > (cps[b].nD + cps[b].nA > 8); });
+    std::vector<CouplingDesc> sorted(cps.size());
+    std::vector<int> newpos(cps.size());
+    for (size_t k = 0; k < order.size(); ++k) { sorted[k] = cps[order[k]]; newpos[order[k]] = (int)k; if (sorted[k].nD + sorted[k].nA > 8) ncp_big++; }
+    cps.swap(sorted);
+    for (int d = 0; d < D; ++d) if (cp_of[d] >= 0) cp_of[d] = newpos[cp_of[d]];
+  }
   const int nu = (int)units.size(), ncp = (int)cps.size(), nra = (int)ras.size();
   HT(5);
   // ---- 5. device buffers
-  const int envb = std::min(64, (N + 255) / 256), cpb = std::min(512, (N + 255) / 256);
+  const int envb = std::min(64, (N + 255) / 256), cpb = 1024 /* partial-sum row stride; the coupling launches use up to this many blocks per element */;
   const int part_stride = 1024;
   const int n_rows = nu + ncp + ngrid + 8;
   if (c->d_Fdiag.alloc((size_t)n_diag * n3) || c->d_Foff.alloc((size_t)std::max(n_off, 1) * n3) || 
       w->d_tabs.alloc(1) || w->d_exch.alloc(MAX_TYPES) || w->d_part.alloc((size_t)n_rows * part_stride) ||
       w->d_E.alloc(2 * n_rows + 3 * std::max(ncp, 1) + 8) || w->d_dVspec.alloc((size_t)MAX_DIABATS * MAX_SPEC * 3) ||
       w->d_sbase.alloc(3 * std::max(nra, 1)) || w->d_sw.alloc(18 * (size_t)std::max(nra, 1)) || w->d_sdw.alloc(18 * (size_t)std::max(nra, 1)) ||
-      w->d_grids.alloc(K3 * std::max(ngrid, 1)) || w->d_pack.alloc(K3 * std::max(ngrid, 1)) || w->d_F11.alloc(n3))
+      w->d_grids.alloc(K3 * std::max(ngrid, 1)) || w->d_pack.alloc(K3 * std::max(ngrid, 1)) || w->d_F11.alloc(n3) || w->d_com_atom.alloc(n3))
     FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB work buffers)");
   c->evb_cap = D;
   if (!w->tabs_uploaded) {
@@ -1103,9 +1132,15 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   //           diagonal deltas (the all-atom gather waits for those, only the blend for these)
   if (ncp) {
     hipStream_t so = ss;
-    hipLaunchKernelGGL(k_evb_coupling, dim3(cpb, ncp), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_chg.p,
-                       c->d_mass.p, c->d_atype.p, w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p);
-    hipLaunchKernelGGL(k_sum_rows, dim3(ncp), dim3(256), 0, so, ncp, cpb, part_stride, part_cp, E_cp_env);
+    hipLaunchKernelGGL(k_mol_com, dim3((M + 255) / 256), dim3(256), 0, so, M, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_mass.p, w->d_com_atom.p);
+    // ~1000 workgroups per launch in all: every block pays a descriptor copy, two barriers and the Zundel reductions
+    const int cpb_big = std::min(cpb, std::max(64, 1024 / std::max(ncp_big, 1))), cpb_small = std::min(cpb, std::max(64, 1024 / std::max(ncp - ncp_big, 1)));
+    if (ncp_big) hipLaunchKernelGGL(k_evb_coupling<16>, dim3(cpb_big, ncp_big), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, w->d_com_atom.p, c->d_xyz.p, c->d_chg.p,
+                                    w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p, 0);
+    if (ncp > ncp_big) hipLaunchKernelGGL(k_evb_coupling<8>, dim3(cpb_small, ncp - ncp_big), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, w->d_com_atom.p, c->d_xyz.p, c->d_chg.p,
+                                          w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p, ncp_big);
+    if (ncp_big) hipLaunchKernelGGL(k_sum_rows, dim3(ncp_big), dim3(256), 0, so, ncp_big, cpb_big, part_stride, part_cp, E_cp_env);
+    if (ncp > ncp_big) hipLaunchKernelGGL(k_sum_rows, dim3(ncp - ncp_big), dim3(256), 0, so, ncp - ncp_big, cpb_small, part_stride, part_cp + (size_t)ncp_big * part_stride, E_cp_env + ncp_big);
     hipLaunchKernelGGL(k_evb_coupling_finish, dim3(ncp), dim3(64), 0, so, ncp, d_cps, w->d_exch.p, c->d_mass.p, box, c->conv, E_cp_env,
                        w->d_dVspec.p, c->d_Foff.p, n3, d_cpout);
     HIPCHK(hipGetLastError());
@@ -1266,7 +1301,7 @@ void evb_release(msevb_ctx* c) {
   if (it == g_work.end()) return;
   EvbWork* w = it->second;
   if (w) {
-    DBuf<double>* db[] = {&w->d_exch, &w->d_part, &w->d_E, &w->d_dVspec, &w->d_sw, &w->d_sdw, &w->d_Fdelta, &w->d_F11, &w->d_pack};
+    DBuf<double>* db[] = {&w->d_exch, &w->d_part, &w->d_E, &w->d_dVspec, &w->d_sw, &w->d_sdw, &w->d_Fdelta, &w->d_F11, &w->d_pack, &w->d_com_atom};
     for (auto b : db) b->release();
     w->d_tabs.release(); w->d_sbase.release(); w->d_counter.release(); w->d_grids.release(); w->d_region.release(); w->d_cand.release(); w->d_desc.release();
     hipEvent_t* ev[] = {&w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush};

@@ -5,8 +5,24 @@
 
 __device__ __forceinline__ double d3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
+// Per-thread [atom][3] / [atom] arrays kept in LDS with the thread index fastest (conflict-free, and dynamically indexable: the bonded
+// terms address atoms through the molecule-type tables, which forces private arrays into scratch memory).  x[i][d] / q[i] syntax as for
+// plain arrays, so the molecule functions below are templates over the array type.
+template <int STRIDE>
+struct LdsRows {
+  double* p;      // base + thread index
+  struct Row { double* q; __device__ __forceinline__ double& operator[](int d) const { return q[d * STRIDE]; } };
+  __device__ __forceinline__ Row operator[](int i) const { return Row{p + i * 3 * STRIDE}; }
+};
+template <int STRIDE>
+struct LdsVec {
+  double* p;
+  __device__ __forceinline__ double& operator[](int i) const { return p[i * STRIDE]; }
+};
+
 // bond / angle / dihedral energy+force of one molecule whose atom coordinates are x[k][3]; adds into f[k][3]
-__device__ __forceinline__ void molecule_bonded(const MolTypeDev& mt, const double (*x)[3], double (*f)[3], double pi_ref, double& eb, double& ea, double& ed) {
+template <class X, class F>
+__device__ __forceinline__ void molecule_bonded(const MolTypeDev& mt, X x, F f, double pi_ref, double& eb, double& ea, double& ed) {
   eb = ea = ed = 0.0;
   for (int b = 0; b < mt.nb; ++b) {   // pairwise_bond_energy_force (src/intra_bonded_interactions.f90:125-168)
     const int i = mt.bond[b][0], j = mt.bond[b][1];
@@ -85,7 +101,8 @@ __device__ __forceinline__ void molecule_bonded(const MolTypeDev& mt, const doub
 }
 
 // intra-molecular non-bonded pairs of one molecule (no minimum image: molecules are whole)
-__device__ __forceinline__ void molecule_nonbonded(const MolTypeDev& mt, int n, const double (*x)[3], const double* q, double (*f)[3], const double2* __restrict__ etab,
+template <class X, class Q, class F>
+__device__ __forceinline__ void molecule_nonbonded(const MolTypeDev& mt, int n, X x, Q q, F f, const double2* __restrict__ etab,
                                    double inv_dx, const double* __restrict__ tt, const double* __restrict__ dtt, double rc2, double alpha,
                                    double erf_factor, double conv, double& e_el, double& e_vdw) {
   e_el = e_vdw = 0.0;

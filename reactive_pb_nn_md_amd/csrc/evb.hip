@@ -92,8 +92,8 @@ __device__ __forceinline__ void rep_switch(double r, double rs, double rc, doubl
 
 // repulsion between the hydronium of unit u and ONE other atom j (type tj, position xj): three-atom term
 // (src/ms_evb.f90:2295-2399) + Born-Mayer terms (:2405-2478).  Adds the force on j to fj and the forces on hydronium
-// atoms to fh[k] (k over u.H_at).  pbc_shift of the reference = nearest image of j relative to the hydronium atom.
-__device__ __forceinline__ double evb_repulsion_atom(const UnitDesc& u, const EvbTablesDev& tb, const BoxDev& box, int tj, const double* xj, double* fj, double (*fh)[3]) {
+// atoms atomically to the LDS table sF[spec index] (k over u.H_at).  pbc_shift of the reference = nearest image of j relative to the hydronium atom.
+__device__ __forceinline__ double evb_repulsion_atom(const UnitDesc& u, const EvbTablesDev& tb, const BoxDev& box, int tj, const double* xj, double* fj, double (*sF)[3]) {
   double E = 0.0;
   int idx = -1;
   const SpecAtom& hv = u.spec[u.heavy];
@@ -119,11 +119,11 @@ __device__ __forceinline__ double evb_repulsion_atom(const UnitDesc& u, const Ev
         sum += eq;
         for (int d = 0; d < 3; ++d) {
           const double g = sw * fac * eq * p[3] * q[d];
-          fh[k][d] += -2.0 * g; fh[hk][d] += g; fj[d] += g;
+          atomicAdd(&sF[u.H_at[k]][d], -2.0 * g); atomicAdd(&sF[u.H_at[hk]][d], g); fj[d] += g;
         }
       }
       E += sw * fac * sum;
-      for (int d = 0; d < 3; ++d) { const double f = rO[d] / rOO * fac * sum * (sw * p[1] - dsw); fh[hk][d] += f; fj[d] -= f; }
+      for (int d = 0; d < 3; ++d) { const double f = rO[d] / rOO * fac * sum * (sw * p[1] - dsw); atomicAdd(&sF[u.H_at[hk]][d], f); fj[d] -= f; }
     }
   }
   for (int k = 0; k < u.nH; ++k) {
@@ -140,7 +140,7 @@ __device__ __forceinline__ double evb_repulsion_atom(const UnitDesc& u, const Ev
     if (sw == 0.0 && dsw == 0.0) continue;
     const double fac = p[0] * exp(-p[1] * (r - p[2]));
     E += sw * fac;
-    for (int d = 0; d < 3; ++d) { const double f = rij[d] / r * fac * (sw * p[1] - dsw); fh[k][d] += f; fj[d] -= f; }
+    for (int d = 0; d < 3; ++d) { const double f = rij[d] / r * fac * (sw * p[1] - dsw); atomicAdd(&sF[u.H_at[k]][d], f); fj[d] -= f; }
   }
   return E;
 }
@@ -168,12 +168,17 @@ __global__ __launch_bounds__(256) void k_evb_candidates(int N, double cx, double
 }
 
 // ---- environment kernel: special (donor+acceptor / hydronium) atoms of every unit against the candidate NON-special atoms --
+// lane = (candidate j, special atom q): 16 q-lanes x 4 candidates per wavefront trip, one pair per lane; the force on j is the butterfly
+// sum over its q-lanes (one atomic triple per candidate), the force on special atom q accumulates per lane and meets in LDS at the end.
+// The MS-EVB3 repulsion (rare: candidates within the screening radius of the hydronium) is done by the q = 0 lane and adds straight into
+// the LDS table.  No private arrays (the thread-per-candidate version kept the hydronium force block in scratch memory).
 __global__ __launch_bounds__(256) void k_evb_env(const int* __restrict__ n_cand, const int* __restrict__ cand, int n_units, const UnitDesc* __restrict__ units, const EvbTablesDev* __restrict__ tabs,
                                                  const double* __restrict__ xyz, const double* __restrict__ chg, const int* __restrict__ atype,
                                                  const int* __restrict__ mol_of, const PairParam* __restrict__ pairpar, int nt,
                                                  const double2* __restrict__ etab, double inv_dx, const double* __restrict__ tt,
                                                  const double* __restrict__ dtt, BoxDev box, double rc2, double* __restrict__ Fstore, size_t fstride,
                                                  double* __restrict__ part, int part_stride) {
+  constexpr int QL = 2 * MAX_MOL_ATOMS, CPW = 64 / QL;
   __shared__ UnitDesc u;
   __shared__ EvbTablesDev tb;
   __shared__ double sF[MAX_SPEC][3];
@@ -188,57 +193,54 @@ __global__ __launch_bounds__(256) void k_evb_env(const int* __restrict__ n_cand,
   }
   __syncthreads();
   double* F = Fstore + (size_t)u.slot * fstride;
-  double e = 0.0;
+  const int lane = threadIdx.x & 63, q = lane & (QL - 1), cs = lane / QL;
+  const int nz = u.do_rs ? u.nD + u.nA : 0;
+  const bool qlive = q < nz;
+  const int sp = qlive ? (q < u.nD ? u.D_at[q] : u.A_at[q - u.nD]) : 0;
+  const double ax = u.spec[sp].x[0], ay = u.spec[sp].x[1], az = u.spec[sp].x[2], aq = u.spec[sp].q;
+  const int atyp = u.spec[sp].type;
+  double e = 0.0, fsx = 0.0, fsy = 0.0, fsz = 0.0;
   const int ncand = *n_cand;
-  for (int cj = blockIdx.x * blockDim.x + threadIdx.x; cj < ncand; cj += gridDim.x * blockDim.x) {
-    const int j = cand[cj];
+  const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+  for (int c0 = wave_g * CPW; c0 < ncand; c0 += n_waves * CPW) {      // wave-uniform trip count
+    const int cj = c0 + cs;
+    const bool have = cj < ncand;
+    const int j = have ? cand[cj] : 0;
+    bool special = !have;
     const int mj = mol_of[j];
-    bool special = false;
     for (int k = 0; k < u.n_mols; ++k) special |= (u.mols[k] == mj);
-    if (special) continue;
     const double xj[3] = {xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]};
-    const double qj = chg[j];
     const int tj = atype[j];
-    double fj[3] = {0, 0, 0};
-    bool touched = false;
-    if (u.do_rs) {
-      for (int side = 0; side < 2; ++side) {
-        const int n = side == 0 ? u.nD : u.nA;
-        const int* lst = side == 0 ? u.D_at : u.A_at;
-        for (int k = 0; k < n; ++k) {
-          const SpecAtom& a = u.spec[lst[k]];
-          double dr[3] = {a.x[0] - xj[0], a.x[1] - xj[1], a.x[2] - xj[2]};
-          min_image(dr, box);
-          const double r2 = dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2];
-          if (r2 < rc2) {
-            double fs, ee, ev;
-            pair_interaction(r2, a.q * qj, pairpar[a.type * nt + tj], etab, inv_dx, tt, dtt, fs, ee, ev);
-            e += ee + ev;
-            for (int d = 0; d < 3; ++d) { fj[d] -= fs * dr[d]; atomicAdd(&sF[lst[k]][d], fs * dr[d]); }
-            touched = true;
-          }
-        }
+    double fx = 0.0, fy = 0.0, fz = 0.0;
+    if (!special && qlive) {
+      double dr[3] = {ax - xj[0], ay - xj[1], az - xj[2]};
+      min_image(dr, box);
+      const double r2 = dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2];
+      if (r2 < rc2) {
+        double fs, ee, ev;
+        pair_interaction(r2, aq * chg[j], pairpar[atyp * nt + tj], etab, inv_dx, tt, dtt, fs, ee, ev);
+        e += ee + ev;
+        fx = -fs * dr[0]; fy = -fs * dr[1]; fz = -fs * dr[2];
+        fsx -= fx; fsy -= fy; fsz -= fz;
       }
     }
-    if (u.do_rep) {   // repulsion: only atoms near the hydronium matter; cheap distance screen first
+    if (u.do_rep && !special && q == 0) {   // repulsion: only atoms near the hydronium matter; cheap distance screen first
       const SpecAtom& hv = u.spec[u.heavy];
       double dr[3] = {hv.x[0] - xj[0], hv.x[1] - xj[1], hv.x[2] - xj[2]};
       min_image(dr, box);
       if (dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2] < tb.screen2) {
-        double fh[MAX_MOL_ATOMS][3];
-        for (int k = 0; k < MAX_MOL_ATOMS; ++k) fh[k][0] = fh[k][1] = fh[k][2] = 0.0;
         double fr[3] = {0, 0, 0};
-        const double er = evb_repulsion_atom(u, tb, box, tj, xj, fr, fh);
-        if (er != 0.0 || fr[0] != 0.0 || fr[1] != 0.0 || fr[2] != 0.0) {
-          e += er;
-          for (int d = 0; d < 3; ++d) fj[d] += fr[d];
-          for (int k = 0; k < u.nH; ++k) for (int d = 0; d < 3; ++d) if (fh[k][d] != 0.0) atomicAdd(&sF[u.H_at[k]][d], fh[k][d]);
-          touched = true;
-        }
+        e += evb_repulsion_atom(u, tb, box, tj, xj, fr, sF);
+        fx += fr[0]; fy += fr[1]; fz += fr[2];
       }
     }
-    if (touched) for (int d = 0; d < 3; ++d) atomicAdd(&F[3 * j + d], u.sign * fj[d]);
+#pragma unroll
+    for (int o = 1; o < QL; o <<= 1) { fx += __shfl_xor(fx, o, 64); fy += __shfl_xor(fy, o, 64); fz += __shfl_xor(fz, o, 64); }
+    if (!special && q < 3) { const double v = q == 0 ? fx : q == 1 ? fy : fz; if (v != 0.0) atomicAdd(&F[3 * j + q], u.sign * v); }
   }
+#pragma unroll
+  for (int o = QL; o < 64; o <<= 1) { fsx += __shfl_xor(fsx, o, 64); fsy += __shfl_xor(fsy, o, 64); fsz += __shfl_xor(fsz, o, 64); }
+  if (cs == 0 && qlive) { atomicAdd(&sF[sp][0], fsx); atomicAdd(&sF[sp][1], fsy); atomicAdd(&sF[sp][2], fsz); }
   red[threadIdx.x] = e;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
@@ -306,11 +308,9 @@ __global__ __launch_bounds__(64) void k_evb_special(int n_units, const UnitDesc*
   if (u.do_rep) {   // repulsion of the hydronium with special atoms of OTHER molecules
     for (int b = lane; b < u.n_spec; b += 64) {
       if (u.spec[b].mol == u.hyd) continue;
-      double fh[MAX_MOL_ATOMS][3], fj[3] = {0, 0, 0};
-      for (int k = 0; k < MAX_MOL_ATOMS; ++k) fh[k][0] = fh[k][1] = fh[k][2] = 0.0;
-      e += evb_repulsion_atom(u, tb, box, u.spec[b].type, u.spec[b].x, fj, fh);
+      double fj[3] = {0, 0, 0};
+      e += evb_repulsion_atom(u, tb, box, u.spec[b].type, u.spec[b].x, fj, f);      // hydronium forces go straight into the LDS table
       for (int d = 0; d < 3; ++d) atomicAdd(&f[b][d], fj[d]);
-      for (int k = 0; k < u.nH; ++k) for (int d = 0; d < 3; ++d) if (fh[k][d] != 0.0) atomicAdd(&f[u.H_at[k]][d], fh[k][d]);
     }
   }
   for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
@@ -1035,7 +1035,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   const int nu = (int)units.size(), ncp = (int)cps.size(), nra = (int)ras.size();
   HT(5);
   // ---- 5. device buffers
-  const int envb = std::min(64, (N + 255) / 256), cpb = 1024 /* partial-sum row stride; the coupling launches use up to this many blocks per element */;
+  const int envb = std::min(16, (N + 255) / 256), cpb = 1024 /* partial-sum row stride; the coupling launches use up to this many blocks per element */;
   const int part_stride = 1024;
   const int n_rows = nu + ncp + ngrid + 8;
   if (c->d_Fdiag.alloc((size_t)n_diag * n3) || c->d_Foff.alloc((size_t)std::max(n_off, 1) * n3) || 

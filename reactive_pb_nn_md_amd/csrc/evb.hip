@@ -292,17 +292,21 @@ __global__ __launch_bounds__(64) void k_evb_special(int n_units, const UnitDesc*
         for (int d = 0; d < 3; ++d) { atomicAdd(&f[a][d], fs * dr[d]); atomicAdd(&f[b][d], -fs * dr[d]); }
       }
     }
-    if (lane < 2) {   // intra-molecular non-bonded + bonded of donor (lane 0) and acceptor (lane 1)
-      const int side = lane;
+    // intra-molecular non-bonded + bonded terms of donor (lanes 0-31) and acceptor (lanes 32-63), the terms of a molecule spread over
+    // its 32 lanes (the 8-atom acid has 28 pairs and a dozen bonded terms: one lane per molecule was the longest path of this kernel)
+    {
+      const int side = lane >> 5, sl = lane & 31;
       const int n = side == 0 ? u.nD : u.nA;
       const int* lst = side == 0 ? u.D_at : u.A_at;
       const MolTypeDev& mt = mts[side == 0 ? u.mt_D : u.mt_A];
-      for (int k = 0; k < n; ++k) { qs[side][k] = u.spec[lst[k]].q; for (int d = 0; d < 3; ++d) { xs[side][k][d] = u.spec[lst[k]].x[d]; fls[side][k][d] = 0.0; } }
+      for (int k = sl; k < n; k += 32) { qs[side][k] = u.spec[lst[k]].q; for (int d = 0; d < 3; ++d) { xs[side][k][d] = u.spec[lst[k]].x[d]; fls[side][k][d] = 0.0; } }
+      __syncthreads();
       double e1 = 0, e2 = 0, eb = 0, ea = 0, ed = 0;
-      if (n > 1) molecule_nonbonded(mt, n, xs[side], qs[side], fls[side], etab, inv_dx, tt, dtt, rc2, alpha, erf_factor, conv, e1, e2);
-      molecule_bonded(mt, xs[side], fls[side], pi_ref, eb, ea, ed);
+      if (n > 1) molecule_nonbonded<true>(mt, n, xs[side], qs[side], fls[side], etab, inv_dx, tt, dtt, rc2, alpha, erf_factor, conv, e1, e2, sl, 32);
+      molecule_bonded<true>(mt, xs[side], fls[side], pi_ref, eb, ea, ed, sl, 32);
       e += e1 + e2 + eb + ea + ed;
-      for (int k = 0; k < n; ++k) for (int d = 0; d < 3; ++d) atomicAdd(&f[lst[k]][d], fls[side][k][d]);
+      __syncthreads();
+      for (int k = sl; k < n; k += 32) for (int d = 0; d < 3; ++d) atomicAdd(&f[lst[k]][d], fls[side][k][d]);
     }
   }
   if (u.do_rep) {   // repulsion of the hydronium with special atoms of OTHER molecules

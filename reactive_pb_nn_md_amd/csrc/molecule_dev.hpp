@@ -20,11 +20,16 @@ struct LdsVec {
   __device__ __forceinline__ double& operator[](int i) const { return p[i * STRIDE]; }
 };
 
+// force accumulation: plain add when one thread owns the molecule, LDS atomic add when the terms of one molecule are spread over lanes
+template <bool SHARED>
+__device__ __forceinline__ void fadd(double& dst, double v) { if (SHARED) atomicAdd(&dst, v); else dst += v; }
+
 // bond / angle / dihedral energy+force of one molecule whose atom coordinates are x[k][3]; adds into f[k][3]
-template <class X, class F>
-__device__ __forceinline__ void molecule_bonded(const MolTypeDev& mt, X x, F f, double pi_ref, double& eb, double& ea, double& ed) {
+// (SHARED: the caller's lanes t0, t0 + tstep, ... share the terms, f lives in LDS and the energies are per-lane partial sums)
+template <bool SHARED = false, class X, class F>
+__device__ __forceinline__ void molecule_bonded(const MolTypeDev& mt, X x, F f, double pi_ref, double& eb, double& ea, double& ed, int t0 = 0, int tstep = 1) {
   eb = ea = ed = 0.0;
-  for (int b = 0; b < mt.nb; ++b) {   // pairwise_bond_energy_force (src/intra_bonded_interactions.f90:125-168)
+  for (int b = t0; b < mt.nb; b += tstep) {   // pairwise_bond_energy_force (src/intra_bonded_interactions.f90:125-168)
     const int i = mt.bond[b][0], j = mt.bond[b][1];
     double r[3] = {x[i][0] - x[j][0], x[i][1] - x[j][1], x[i][2] - x[j][2]};
     const double rm = sqrt(d3(r, r));
@@ -33,9 +38,9 @@ __device__ __forceinline__ void molecule_bonded(const MolTypeDev& mt, X x, F f, 
     if (mt.bond_type[b] == 1) { eb += 0.5 * p[1] * (rm - p[0]) * (rm - p[0]); fs = -p[1] * (rm - p[0]) / rm; }
     else if (mt.bond_type[b] == 2) { const double t = rm * rm - p[0] * p[0]; eb += 0.25 * p[1] * t * t; fs = -p[1] * t; }
     else { const double ex = exp(-p[1] * (rm - p[2])); eb += p[0] * (1.0 - ex) * (1.0 - ex); fs = -2.0 * p[0] * p[1] * ex * (1.0 - ex) / rm; }
-    for (int d = 0; d < 3; ++d) { f[i][d] += fs * r[d]; f[j][d] -= fs * r[d]; }
+    for (int d = 0; d < 3; ++d) { fadd<SHARED>(f[i][d], fs * r[d]); fadd<SHARED>(f[j][d], -(fs * r[d])); }
   }
-  for (int a = 0; a < mt.na; ++a) {   // trimer_angle_energy_force (:219-284)
+  for (int a = t0; a < mt.na; a += tstep) {   // trimer_angle_energy_force (:219-284)
     const int i = mt.ang[a][0], j = mt.ang[a][1], k = mt.ang[a][2];
     double rij[3], rkj[3];
     for (int d = 0; d < 3; ++d) { rij[d] = x[i][d] - x[j][d]; rkj[d] = x[k][d] - x[j][d]; }
@@ -56,10 +61,10 @@ __device__ __forceinline__ void molecule_bonded(const MolTypeDev& mt, X x, F f, 
     for (int d = 0; d < 3; ++d) {
       const double fi = fac * (rkj[d] / rij_m / rkj_m - cosine * rij[d] / (rij_m * rij_m));
       const double fk = fac * (rij[d] / rij_m / rkj_m - cosine * rkj[d] / (rkj_m * rkj_m));
-      f[i][d] += fi; f[k][d] += fk; f[j][d] -= fi + fk;
+      fadd<SHARED>(f[i][d], fi); fadd<SHARED>(f[k][d], fk); fadd<SHARED>(f[j][d], -(fi + fk));
     }
   }
-  for (int q = 0; q < mt.nd; ++q) {   // quartet_dihedral_energy_force (:343-552), dot-product formulation
+  for (int q = t0; q < mt.nd; q += tstep) {   // quartet_dihedral_energy_force (:343-552), dot-product formulation
     const int i = mt.dih[q][0], j = mt.dih[q][1], k = mt.dih[q][2], l = mt.dih[q][3];
     double rji[3], rkj[3], rlk[3];
     for (int d = 0; d < 3; ++d) { rji[d] = x[j][d] - x[i][d]; rkj[d] = x[k][d] - x[j][d]; rlk[d] = x[l][d] - x[k][d]; }
@@ -95,19 +100,21 @@ __device__ __forceinline__ void molecule_bonded(const MolTypeDev& mt, X x, F f, 
       const double fji = fac * (dab_ji * g0 - ga * daa_ji);
       const double fkj = fac * (dab_kj * g0 - ga * daa_kj - gb * dbb_kj);
       const double flk = fac * (dab_lk * g0 - gb * dbb_lk);
-      f[i][d] -= fji; f[j][d] += fji - fkj; f[k][d] += fkj - flk; f[l][d] += flk;
+      fadd<SHARED>(f[i][d], -fji); fadd<SHARED>(f[j][d], fji - fkj); fadd<SHARED>(f[k][d], fkj - flk); fadd<SHARED>(f[l][d], flk);
     }
   }
 }
 
 // intra-molecular non-bonded pairs of one molecule (no minimum image: molecules are whole)
-template <class X, class Q, class F>
+template <bool SHARED = false, class X, class Q, class F>
 __device__ __forceinline__ void molecule_nonbonded(const MolTypeDev& mt, int n, X x, Q q, F f, const double2* __restrict__ etab,
                                    double inv_dx, const double* __restrict__ tt, const double* __restrict__ dtt, double rc2, double alpha,
-                                   double erf_factor, double conv, double& e_el, double& e_vdw) {
+                                   double erf_factor, double conv, double& e_el, double& e_vdw, int t0 = 0, int tstep = 1) {
   e_el = e_vdw = 0.0;
+  int t = 0;
   for (int i = 0; i < n; ++i)
-    for (int j = i + 1; j < n; ++j) {
+    for (int j = i + 1; j < n; ++j, ++t) {
+      if (SHARED && (t % tstep) != t0) continue;
       double dr[3] = {x[i][0] - x[j][0], x[i][1] - x[j][1], x[i][2] - x[j][2]};
       const double r2 = d3(dr, dr), qq = q[i] * q[j];
       double fs = 0.0, e1, f1;
@@ -117,7 +124,7 @@ __device__ __forceinline__ void molecule_nonbonded(const MolTypeDev& mt, int n, 
         vdw_interaction(r2, mt.nb_par[i][j], tt, dtt, f1, e1);
         fs += f1; e_vdw += e1;
       }
-      for (int d = 0; d < 3; ++d) { f[i][d] += fs * dr[d]; f[j][d] -= fs * dr[d]; }
+      for (int d = 0; d < 3; ++d) { fadd<SHARED>(f[i][d], fs * dr[d]); fadd<SHARED>(f[j][d], -(fs * dr[d])); }
     }
 }
 

@@ -153,6 +153,8 @@ struct msevb_ctx {
   // atom / molecule ranges (the partial principal forces meet in the all-reduce of the blend); set by msevb_comm_init, or by the
   // "shard_principal" option for virtual ranks (tests)
   double cpl_A[MAX_DIABATS] = {0};   // geometric coupling factor A of each owned diabat (off-diagonal stores hold dV, F_pd = -A dV)
+  bool evb_element_stores = false;   // keep F_dd / F_pd of every Hamiltonian element (needed by msevb_get_evb_element_force); default: blended-potential path
+  bool skip_gather_now = false;      // EVB fast path: the principal reciprocal force comes with the blended gather
   bool shard_principal = false;
   bool shard_now = false;        // true while the EVB force call enqueues the principal diabat
   int pair_tiles_opt = 0;        // 0 off (default: measured slower than the global-gather kernel once the PME front end overlaps it), 1 on when it fits, -1 auto
@@ -279,7 +281,7 @@ extern "C" void total_force_collect(msevb_ctx* c, double* en);
 extern "C" int upload_topology(msevb_ctx* c);
 int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part_stride, int* nblocks);
 int pme_prepare_atoms(msevb_ctx* c, bool with_indices);
-int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic = false);
+int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic = false, const double* theta = nullptr);
 
 constexpr int MAX_BLOCKS = 65536;
 enum Slot { S_ELEC_PAIR = 0, S_VDW_PAIR, S_ELEC_INTRA, S_VDW_INTRA, S_BOND, S_ANGLE, S_DIH, S_RECIP, S_KE, S_PX, S_PY, S_PZ, S_MAXD1, S_MAXD2, S_EVB0, N_SLOTS = 32 };

@@ -604,14 +604,30 @@ __global__ void k_evb_slot0(size_t n3, const double* __restrict__ F11, double* _
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (size_t)gridDim.x * blockDim.x) { Fdiag0[k] = delta0[k]; delta0[k] = 0.0; F11_copy[k] = F11[k]; }
 }
 
+// Fast path (no per-element force stores): the stencil gather is LINEAR in the potential, so sum_d c_d^2 (recip force of diabat d) is the
+// gather of the BLENDED potential  c_0^2 theta_1 + sum_{d>=1} c_d^2 theta_d  - one gather over one grid instead of one per diabat.
+struct GridCoefs { int n; double c0; double c[MAX_DIABATS]; };
+__global__ void k_evb_blend_grids(size_t K3, GridCoefs gc, const double* __restrict__ theta1, const double2* __restrict__ grids, double* __restrict__ out) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K3; k += (size_t)gridDim.x * blockDim.x) {
+    double s = gc.c0 * theta1[k];
+    for (int g = 0; g < gc.n; ++g) s += gc.c[g] * grids[(size_t)g * K3 + k].x;
+    out[k] = s;
+  }
+}
+
 struct BlendTerms { int n; int slot[2 * MAX_DIABATS]; double coef[2 * MAX_DIABATS]; };   // slot < 0: off-diagonal store, index -slot-1 (kernel argument, no upload)
 // The diagonal store holds differences to the principal force F11 (F_dd = F11 + store_d) and sum_d c_d^2 = 1, so
 // F = w11 F11 + sum_d c_d^2 store_d + 2 sum c_p c_d F_pd with w11 = 1 (w11 < 1 only for a rank's PARTIAL blend, see evb_partial terms);
 // F holds F11 on entry and the blended force on exit.
-__global__ void k_evb_blend(size_t n3, BlendTerms bt, double w11, const double* __restrict__ Fdiag, const double* __restrict__ Foff, size_t fstride, double* __restrict__ F) {
+// zero_diag: Fdiag is the self-cleaning delta store itself (fast path): every diagonal slot read is reset for the next step.
+__global__ void k_evb_blend(size_t n3, BlendTerms bt, double w11, double* __restrict__ Fdiag, const double* __restrict__ Foff, size_t fstride, double* __restrict__ F, int zero_diag) {
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (size_t)gridDim.x * blockDim.x) {
     double s = w11 * F[k];
-    for (int t = 0; t < bt.n; ++t) { const int sl = bt.slot[t]; s += bt.coef[t] * (sl < 0 ? Foff[(size_t)(-sl - 1) * fstride + k] : Fdiag[(size_t)sl * fstride + k]); }
+    for (int t = 0; t < bt.n; ++t) {
+      const int sl = bt.slot[t];
+      if (sl < 0) s += bt.coef[t] * Foff[(size_t)(-sl - 1) * fstride + k];
+      else { double* p = Fdiag + (size_t)sl * fstride + k; s += bt.coef[t] * *p; if (zero_diag) *p = 0.0; }
+    }
     F[k] = s;
   }
 }
@@ -905,9 +921,11 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   HIPCHK(hipEventRecord(w->ev_region, w->stream2));
   HT(1);
   // ---- 2. principal diabat (calculate_total_force_energy, src/ms_evb.f90:411) - enqueued, not waited for
+  const bool fast = !c->evb_element_stores;      // no per-element force stores: one gather of the blended potential (k_evb_blend_grids)
   c->shard_now = c->shard_principal && c->n_ranks > 1;
+  c->skip_gather_now = fast;
   const int rc_tfe = total_force_enqueue(c);
-  c->shard_now = false;
+  c->shard_now = false; c->skip_gather_now = false;
   CHK(rc_tfe);
   HT(2);
   HIPCHK(hipEventSynchronize(w->ev_region));
@@ -1188,34 +1206,36 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     c->pme_st = nullptr;
     CHK(rc_conv);
     hipLaunchKernelGGL(k_sum_rows, dim3(ngrid), dim3(256), 0, sg, ngrid, nbk, part_stride, part_grid, E_grid);
-    hipLaunchKernelGGL(k_evb_pack, dim3(2048), dim3(256), 0, sg, K3, ngrid, w->d_grids.p, w->d_pack.p);
+    if (!fast) hipLaunchKernelGGL(k_evb_pack, dim3(2048), dim3(256), 0, sg, K3, ngrid, w->d_grids.p, w->d_pack.p);
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_E, sg));
   }
   phase_end(c, PH_EVB_RECIP, sg);
   CHK(early_fetch());
-  if (ngrid) {
-    if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // packed potentials of the diabat grids
-    // all-atom gather, up to 8 grids per pass
-    std::vector<int> gslots(ngrid);
-    for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gslots[grid_of[d]] = diag_slot(c, D, d);
-    if ((double)K3 * ngrid >= 2147483648.0) FAIL(MSEVB_ERR_LIMIT, "EVB gather: K^3 * n_grids exceeds the 32-bit offset range");
-    if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));      // the gather folds the real-space deltas in
-    const int* permp = c->list_valid ? c->d_perm.p : nullptr;     // cell-sorted traversal keeps the stencils of co-resident waves in L2
-    for (int g0 = 0; g0 < ngrid; g0 += 8) {
-      const int ng = std::min(8, ngrid - g0);
-      auto kern = ng > 4 ? k_stencil_gather<8> : ng > 2 ? k_stencil_gather<4> : ng > 1 ? k_stencil_gather<2> : k_stencil_gather<1>;
-      GatherSlots gs; for (int q = 0; q < 8; ++q) gs.s[q] = q < ng ? gslots[g0 + q] : 0;
-      hipLaunchKernelGGL(kern, dim3(round_up8((N + 3) / 4)), dim3(256), 0, c->stream, N, K, ng, gs, permp, c->d_chg.p, c->d_base.p,
-                         c->d_w.p, c->d_dw.p, w->d_pack.p, ngrid, g0, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1],
-                         c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_force_recip.p, c->d_Fdiag.p, w->d_Fdelta.p, n3);
+  if (!fast) {      // per-element force stores (msevb_get_evb_element_force, sharding tests)
+    if (ngrid) {
+      if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // packed potentials of the diabat grids
+      // all-atom gather, up to 8 grids per pass
+      std::vector<int> gslots(ngrid);
+      for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gslots[grid_of[d]] = diag_slot(c, D, d);
+      if ((double)K3 * ngrid >= 2147483648.0) FAIL(MSEVB_ERR_LIMIT, "EVB gather: K^3 * n_grids exceeds the 32-bit offset range");
+      if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));      // the gather folds the real-space deltas in
+      const int* permp = c->list_valid ? c->d_perm.p : nullptr;     // cell-sorted traversal keeps the stencils of co-resident waves in L2
+      for (int g0 = 0; g0 < ngrid; g0 += 8) {
+        const int ng = std::min(8, ngrid - g0);
+        auto kern = ng > 4 ? k_stencil_gather<8> : ng > 2 ? k_stencil_gather<4> : ng > 1 ? k_stencil_gather<2> : k_stencil_gather<1>;
+        GatherSlots gs; for (int q = 0; q < 8; ++q) gs.s[q] = q < ng ? gslots[g0 + q] : 0;
+        hipLaunchKernelGGL(kern, dim3(round_up8((N + 3) / 4)), dim3(256), 0, c->stream, N, K, ng, gs, permp, c->d_chg.p, c->d_base.p,
+                           c->d_w.p, c->d_dw.p, w->d_pack.p, ngrid, g0, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1],
+                           c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_force_recip.p, c->d_Fdiag.p, w->d_Fdelta.p, n3);
+      }
+      hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
+                         w->d_sw.p, w->d_sdw.p, w->d_grids.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0],
+                         c->kk[2][1], c->kk[2][2], c->d_Fdiag.p, n3);
+      HIPCHK(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
-                       w->d_sw.p, w->d_sdw.p, w->d_grids.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0],
-                       c->kk[2][1], c->kk[2][2], c->d_Fdiag.p, n3);
-    HIPCHK(hipGetLastError());
+    if (c->overlap && !ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));
+    hipLaunchKernelGGL(k_evb_slot0, dim3(std::min<size_t>(1024, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, c->d_force.p, w->d_Fdelta.p, c->d_Fdiag.p, w->d_F11.p);
   }
-  if (c->overlap && !ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));
-  hipLaunchKernelGGL(k_evb_slot0, dim3(std::min<size_t>(1024, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, c->d_force.p, w->d_Fdelta.p, c->d_Fdiag.p, w->d_F11.p);
   // ---- 8. off-diagonal elements: few, latency-bound kernels writing only d_Foff -> side stream, beside the reciprocal space
   //         and the diagonal real-space deltas (forked in step 5b, joined here)
   HIPCHK(hipGetLastError());
@@ -1264,7 +1284,23 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   BlendTerms bt;
   const double w11 = blend_terms(c, D, c->eigvec, bt);
   phase_begin(c, PH_EVB_BLEND);
-  hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p);
+  if (fast) {
+    // reciprocal space of the blend in ONE gather: blended potential of this rank's diabats (+ the principal one on rank 0) ...
+    GridCoefs gc; gc.n = ngrid; gc.c0 = c->rank == 0 ? c->eigvec[0] * c->eigvec[0] : 0.0;
+    for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gc.c[grid_of[d]] = c->eigvec[d] * c->eigvec[d];
+    if (c->overlap && ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // convolved diabat grids (aux)
+    if (w->d_pack.alloc(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended potential)");
+    hipLaunchKernelGGL(k_evb_blend_grids, dim3(1024), dim3(256), 0, c->stream, K3, gc, c->d_theta.p, w->d_grids.p, w->d_pack.p);
+    CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p));
+    // ... the special atoms' own-stencil corrections per diabat go to the delta store, which the blend consumes and re-zeroes
+    if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));
+    if (ngrid) hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
+                                  w->d_sw.p, w->d_sdw.p, w->d_grids.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0],
+                                  c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3);
+    hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p, 1);
+  } else {
+    hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0);
+  }
   HIPCHK(hipGetLastError());
   if (c->n_ranks > 1 && c->nccl_comm) CHK(msevb_comm_allreduce_forces(c));
   phase_end(c, PH_EVB_BLEND);
@@ -1347,13 +1383,14 @@ int msevb_get_evb_state(msevb_ctx* c, int* nd, int* plog, int* cm, double* H, do
 
 int msevb_evb_partial_blend(msevb_ctx* c, const double* eigvec, double* force) {
   if (!c || c->D <= 0 || !eigvec || !force) { if (c) c->err = "bad argument"; return MSEVB_ERR_ARG; }
+  if (!c->evb_element_stores) FAIL(MSEVB_ERR_STATE, "per-element force stores are off: msevb_set_option(ctx, \"evb_element_stores\", 1) before the EVB force call");
   auto it = g_work.find(c);
   if (it == g_work.end() || !it->second->d_F11.p) FAIL(MSEVB_ERR_STATE, "no EVB force call yet");
   const size_t n3 = 3 * (size_t)c->N;
   BlendTerms bt;
   const double w11 = blend_terms(c, c->D, eigvec, bt);
   HIPCHK(hipMemcpyAsync(c->d_force.p, it->second->d_F11.p, n3 * 8, hipMemcpyDeviceToDevice, c->stream));
-  hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p);
+  hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0);
   HIPCHK(hipMemcpyAsync(force, c->d_force.p, n3 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return MSEVB_OK;
@@ -1361,6 +1398,7 @@ int msevb_evb_partial_blend(msevb_ctx* c, const double* eigvec, double* force) {
 
 int msevb_get_evb_element_force(msevb_ctx* c, int i, int j, double* force) {
   if (!c || c->D <= 0 || i < 1 || j < i || j > c->D) { if (c) c->err = "bad element"; return MSEVB_ERR_ARG; }
+  if (!c->evb_element_stores) FAIL(MSEVB_ERR_STATE, "per-element force stores are off: msevb_set_option(ctx, \"evb_element_stores\", 1) before the EVB force call");
   const size_t n3 = 3 * (size_t)c->N;
   if (i == j) {      // diagonal: principal force (copy kept by k_evb_slot0) + the stored difference; zero on ranks that do not own the diabat
     auto it = g_work.find(c);

@@ -276,11 +276,11 @@ int pme_prepare_atoms(msevb_ctx* c, bool with_indices) {
   return MSEVB_OK;
 }
 
-int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic) {
+int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic, const double* theta) {
   const int N = c->N;
   int add_lo, add_hi;
   shard_range(c, N, add_lo, add_hi);
-  hipLaunchKernelGGL(k_pme_gather, dim3((N * 8 + 255) / 256), dim3(256), 0, c->stream, N, c->K, chg, c->d_base.p, c->d_w.p, c->d_dw.p, c->d_theta.p, c->conv, c->kk[0][0],
+  hipLaunchKernelGGL(k_pme_gather, dim3((N * 8 + 255) / 256), dim3(256), 0, c->stream, N, c->K, chg, c->d_base.p, c->d_w.p, c->d_dw.p, theta ? theta : c->d_theta.p, c->conv, c->kk[0][0],
                      c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, atomic ? 1 : 0, add_lo, add_hi);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
@@ -323,6 +323,7 @@ int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux) {
   phase_end(c, PH_FFT, st);
   c->pme_st = nullptr;
   if (join_aux) { HIPCHK(hipEventRecord(c->ev_join, c->aux)); HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
+  if (c->skip_gather_now) return MSEVB_OK;      // EVB fast path: the reciprocal force comes with the gather of the blended potential
   phase_begin(c, PH_GATHER);
   CHK(pme_gather(c, c->d_grid.p, c->d_chg.p, c->d_force_recip.p, c->d_force.p, join_aux));
   phase_end(c, PH_GATHER);

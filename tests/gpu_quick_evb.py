@@ -9,6 +9,7 @@ for fx in ("evb_n6_d1_s1", "evb_n6_d2_s1", "evb_n6_d4_s2", "evb_n6_d8_s1", "evb_
     g = np.load(os.path.join(ROOT, "tests", "golden", fx + ".npz"))
     spec = system.from_golden(g)
     h = api.MsEvbHip(spec)
+    h.set_option("evb_element_stores", 1)
     e, F = h.ms_evb_calculate_total_force_energy()
     st = h.evb_state()
     D = int(g["n_diabat"][0])

@@ -82,10 +82,14 @@ def test_stages_against_reference(name):
     h.close()
 
 
+@pytest.mark.parametrize("stores", [0, 1])
 @pytest.mark.parametrize("name", all_golden("evb_"))
-def test_evb_against_reference(name):
+def test_evb_against_reference(name, stores):
+    """stores = 0: default path (one stencil gather of the blended potential, no per-element forces);
+    stores = 1: F_dd / F_pd of every Hamiltonian element kept, as the reference does (evb_forces_store)"""
     g = golden(name)
     h = api.MsEvbHip(system.from_golden(g))
+    h.set_option("evb_element_stores", stores)
     e, F = h.ms_evb_calculate_total_force_energy()
     st = h.evb_state()
     D = int(g["n_diabat"][0])
@@ -98,7 +102,10 @@ def test_evb_against_reference(name):
     assert rel(e, g["E_adiabatic"][0]) < E_RTOL and np.abs(F - g["F_adiabatic"]).max() < F_TOL
     assert st["principle_diabat"] == int(g["principle_diabat"][0]) and st["new_hydronium_molecule"] == int(g["new_hydronium_molecule"][0])
     assert abs(np.linalg.norm(st["eigvec"]) - 1.0) < 1e-12
-    if "evb_forces_store" in g:
+    if stores == 0:
+        with pytest.raises(api.MsevbError):
+            h.evb_element_force(1, 1)
+    if stores and "evb_forces_store" in g:
         lk, sto = g["evb_forces_lookup_index"], g["evb_forces_store"]
         for i in range(D):
             for j in range(i, D):
@@ -160,6 +167,7 @@ def test_diabat_sharding_is_a_partition(n_ranks):
     g = golden("evb_n6_d8_s1")
     spec = system.from_golden(g)
     h = api.MsEvbHip(spec)
+    h.set_option("evb_element_stores", 1)
     _e, Fblend = h.ms_evb_calculate_total_force_energy()
     full = h.evb_state()
     D = full["D"]
@@ -170,6 +178,7 @@ def test_diabat_sharding_is_a_partition(n_ranks):
     Fsum = np.zeros_like(Fblend)
     for r in range(n_ranks):
         hr = api.MsEvbHip(spec)
+        hr.set_option("evb_element_stores", 1)
         hr.comm_set_virtual(r, n_ranks)
         hr.ms_evb_calculate_total_force_energy(want_force=False)
         st = hr.evb_state()
@@ -202,6 +211,7 @@ def test_sharded_principal_partial_sums(n_ranks):
     Fsum, Esum = np.zeros_like(Fblend), 0.0
     for r in range(n_ranks):
         hr = api.MsEvbHip(spec)
+        hr.set_option("evb_element_stores", 1)
         hr.set_option("shard_principal", 1)
         hr.comm_set_virtual(r, n_ranks)
         e_part, _ = hr.ms_evb_calculate_total_force_energy(want_force=False)      # virtual ranks return their share of H11
@@ -242,7 +252,10 @@ def test_full_size_properties_config_B():
     h.real_space_energy_force()
     F = h.get_forces()
     assert np.abs(F.sum(0)).max() < 1e-6 * np.abs(F).sum() / len(F) * 1e3      # Newton's third law: sum of pair forces vanishes
+    e_fast, F_fast = h.ms_evb_calculate_total_force_energy()      # default: blended-potential path
+    h.set_option("evb_element_stores", 1)
     e, F = h.ms_evb_calculate_total_force_energy()
+    assert rel(e_fast, e) < 1e-13 and np.abs(F_fast - F).max() < 1e-9
     st = h.evb_state()
     assert st["D"] == 8 and abs(np.linalg.norm(st["eigvec"]) - 1.0) < 1e-12
     w = np.linalg.eigvalsh(np.triu(st["H"]) + np.triu(st["H"], 1).T)

@@ -33,6 +33,18 @@ int flush_reductions(msevb_ctx* c) {
   return MSEVB_OK;
 }
 
+// reduces ONE slot now, on the given stream (its partial sums must be complete there)
+int flush_one(msevb_ctx* c, int slot, hipStream_t st) {
+  if (c->slot_count[slot] <= 0) return MSEVB_OK;
+  SlotCounts sc;
+  for (int s = 0; s < N_SLOTS; ++s) sc.n[s] = 0;
+  sc.n[slot] = c->slot_count[slot];
+  c->slot_count[slot] = 0;
+  hipLaunchKernelGGL(k_reduce_slots, dim3(N_SLOTS), dim3(1024), 0, st, sc, c->d_partials.p, c->d_energies.p);
+  HIPCHK(hipGetLastError());
+  return MSEVB_OK;
+}
+
 int fetch_energies(msevb_ctx* c) {
   CHK(flush_reductions(c));
   HIPCHK(hipMemcpyAsync(c->h_energies, c->d_energies.p, N_SLOTS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -54,6 +66,7 @@ int msevb_create(msevb_ctx** out, int device_id) {
   c->own_stream = true;
   HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c->aux3, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
@@ -75,6 +88,7 @@ int msevb_destroy(msevb_ctx* c) {
   evb_release(c);
   if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); c->aux = nullptr; }
   if (c->aux2) { (void)hipStreamSynchronize(c->aux2); (void)hipStreamDestroy(c->aux2); c->aux2 = nullptr; }
+  if (c->aux3) { (void)hipStreamSynchronize(c->aux3); (void)hipStreamDestroy(c->aux3); c->aux3 = nullptr; }
   if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);

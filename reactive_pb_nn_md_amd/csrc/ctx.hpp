@@ -145,7 +145,7 @@ struct msevb_ctx {
   // aux : PME front end + principal reciprocal gather, later the off-diagonal EVB elements
   // aux2: per-molecule terms, and for EVB the neighbourhood fetch, descriptor upload, diagonal real-space deltas, energy download
   // (three streams in all: with more, ROCm's 4 hardware queues alias and the intended overlap is lost)
-  hipStream_t aux = nullptr, aux2 = nullptr;
+  hipStream_t aux = nullptr, aux2 = nullptr, aux3 = nullptr;      // aux3: off-diagonal EVB chain (4 streams = ROCm's 4 hardware queues)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   hipStream_t pme_st = nullptr;      // non-null while the PME front end is being enqueued on the side stream
   bool overlap = true;
@@ -255,6 +255,7 @@ int nb_build(msevb_ctx* c);                        // neighbor.hip
 int nb_refresh_sorted(msevb_ctx* c);               // gather posq/type in sorted order
 extern "C" int msevb_comm_allreduce_forces(msevb_ctx* c);   // comm.hip
 void evb_release(msevb_ctx* c);        // evb.hip: per-context EVB scratch
+int flush_one(msevb_ctx* c, int slot, hipStream_t st);      // api.hip
 int nb_step_refresh(msevb_ctx* c);      // refresh + displacement check + zero forces (neighbor.hip)
 int nb_check_displacements(msevb_ctx* c, int initialize, int* flag);
 int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw);              // pair.hip

@@ -658,6 +658,12 @@ __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ 
   }
 }
 
+// copies two small device arrays into pinned host memory (zero-copy stores): the energy downloads, without copy commands
+__global__ void k_evb_publish(const double* __restrict__ a, int na, double* __restrict__ ha, const double* __restrict__ b, int nb, double* __restrict__ hb) {
+  for (int k = threadIdx.x; k < na; k += blockDim.x) ha[k] = a[k];
+  for (int k = threadIdx.x; k < nb; k += blockDim.x) hb[k] = b[k];
+}
+
 // publishes the record count of k_evb_region to pinned host memory
 __global__ void k_evb_publish_count(const int* __restrict__ counter, int* __restrict__ host_count) { *host_count = *counter; }
 
@@ -686,7 +692,7 @@ struct EvbWork {   // persistent device scratch of one context
   DBuf<double> d_part, d_E, d_dVspec; DBuf<int> d_sbase, d_counter; DBuf<double> d_sw, d_sdw;
   DBuf<double2> d_grids; DBuf<RegionRec> d_region; DBuf<int> d_cand;
   DBuf<double> d_Fdelta;      // [n_diag][3N] real-space deltas of the diabats, accumulated on stream2 beside the reciprocal space
-  hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_E = nullptr, ev_fetch = nullptr, ev_cpl = nullptr, ev_flush = nullptr; bool delta_dirty = true;
+  hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_E = nullptr, ev_fetch = nullptr, ev_cpl = nullptr, ev_flush = nullptr, ev_fetchA = nullptr; bool delta_dirty = true;
   DBuf<double> d_F11, d_pack, d_com_atom;
   hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
   RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
@@ -901,6 +907,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipEventCreateWithFlags(&w->ev_join2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_cpl, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_flush, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&w->ev_fetchA, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_E, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_fetch, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&w->h_region, REGION_FAST * sizeof(RegionRec), hipHostMallocDefault));
@@ -1153,7 +1160,9 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   // ---- 6a'. off-diagonal elements (evb_diabatic_coupling, :1021): few, latency-bound kernels writing only d_Foff; on aux2 behind the
   //           diagonal deltas (the all-atom gather waits for those, only the blend for these)
   if (ncp) {
-    hipStream_t so = ss;
+    // own stream (aux3): beside the diagonal deltas on aux2 - both chains feed fetch A, which the blend waits for
+    hipStream_t so = c->overlap ? c->aux3 : c->stream;
+    if (c->overlap) HIPCHK(hipStreamWaitEvent(so, w->ev_fork2, 0));
     hipLaunchKernelGGL(k_mol_com, dim3((M + 255) / 256), dim3(256), 0, so, M, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_mass.p, w->d_com_atom.p);
     // ~1000 workgroups per launch in all: every block pays a descriptor copy, two barriers and the Zundel reductions
     const int cpb_big = std::min(cpb, std::max(64, 1024 / std::max(ncp_big, 1))), cpb_small = std::min(cpb, std::max(64, 1024 / std::max(ncp - ncp_big, 1)));
@@ -1171,29 +1180,34 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   // The Hamiltonian needs energies only, and all of them exist before the all-atom gather (the longest kernel of the EVB phase)
   // starts: fetch them now on stream2 and let the host diagonalise while the gather runs.
   const size_t nE = (size_t)2 * nu + ncp + ngrid + 3 * (size_t)ncp;
-  if (nE > w->hE_cap) {
+  if (nE + 1 > w->hE_cap) {
     if (w->h_E) HIPCHK(hipHostFree(w->h_E));
-    w->hE_cap = 2 * nE + 64;
+    w->hE_cap = 2 * nE + 64;      // + 1: the principal reciprocal energy rides along (fetch A)
     HIPCHK(hipHostMalloc((void**)&w->h_E, w->hE_cap * sizeof(double), hipHostMallocDefault));
   }
   const hipStream_t sg = c->overlap ? c->aux : c->stream;      // diabat grids: `aux` is free once the principal convolution is done
-  auto early_fetch = [&]() -> int {      // call after everything that produces an energy has been enqueued
-    CHK(flush_reductions(c));                                   // principal energy slots (main stream, behind the principal gather)
-    if (!c->overlap) {
-      HIPCHK(hipMemcpyAsync(w->h_E, w->d_E.p, nE * 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipMemcpyAsync(c->h_energies, c->d_energies.p, N_SLOTS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
-      return MSEVB_OK;
-    }
-    HIPCHK(hipEventRecord(w->ev_flush, c->stream));
-    HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_flush, 0));     // stream2 itself is behind the unit and coupling energies
-    if (ngrid) HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0));   // grid energies (aux)
-    HIPCHK(hipMemcpyAsync(w->h_E, w->d_E.p, nE * 8, hipMemcpyDeviceToHost, w->stream2));
-    HIPCHK(hipMemcpyAsync(c->h_energies, c->d_energies.p, N_SLOTS * sizeof(double), hipMemcpyDeviceToHost, w->stream2));
-    HIPCHK(hipEventRecord(w->ev_fetch, w->stream2));
+  // The ground-state VECTOR does not depend on the principal diabat's energy E0: it sits on the whole diagonal (H = H' + E0 I).  So the
+  // host diagonalises H' from the energies that exist long before the pair loop ends (unit, coupling and grid energies, fetch A) and
+  // the blend kernels queue up directly behind the pair loop; E0 (fetch B: the principal energy slots, complete only after the pair
+  // loop) is added to the eigenvalue and to the reported Hamiltonian afterwards, off the critical path.  Both downloads are kernels that
+  // write into pinned host memory (no copy commands).
+  auto fetch_A = [&]() -> int {      // call after everything that produces a unit / coupling / grid energy has been enqueued
+    CHK(flush_one(c, S_RECIP, sg));                              // principal reciprocal energy: its partial sums are complete on `sg`
+    if (c->overlap) { HIPCHK(hipEventRecord(w->ev_E, sg)); HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0)); }
+    if (c->overlap && ncp) HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_cpl, 0));      // coupling energies (aux3)
+    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, ss, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE);
+    HIPCHK(hipGetLastError());
+    if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, ss));
     return MSEVB_OK;
   };
-  HT(7);
+  auto fetch_B = [&]() -> int {      // principal energy slots + Verlet displacement flag (main stream, behind the pair loop)
+    CHK(flush_reductions(c));
+    if (c->overlap) { HIPCHK(hipEventRecord(w->ev_flush, c->stream)); HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_flush, 0)); }
+    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, ss, c->d_energies.p, (int)N_SLOTS, c->h_energies, (const double*)nullptr, 0, (double*)nullptr);
+    HIPCHK(hipGetLastError());
+    if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetch, ss));
+    return MSEVB_OK;
+  };
   // ---- 6b. reciprocal space of the owned diabats (calculate_reciprocal_space_pme, :1962)
   phase_begin(c, PH_EVB_RECIP, sg);
   if (ngrid) {
@@ -1207,10 +1221,10 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     CHK(rc_conv);
     hipLaunchKernelGGL(k_sum_rows, dim3(ngrid), dim3(256), 0, sg, ngrid, nbk, part_stride, part_grid, E_grid);
     if (!fast) hipLaunchKernelGGL(k_evb_pack, dim3(2048), dim3(256), 0, sg, K3, ngrid, w->d_grids.p, w->d_pack.p);
-    if (c->overlap) HIPCHK(hipEventRecord(w->ev_E, sg));
   }
   phase_end(c, PH_EVB_RECIP, sg);
-  CHK(early_fetch());
+  CHK(fetch_A());
+  CHK(fetch_B());
   if (!fast) {      // per-element force stores (msevb_get_evb_element_force, sharding tests)
     if (ngrid) {
       if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // packed potentials of the diabat grids
@@ -1241,25 +1255,19 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   HIPCHK(hipGetLastError());
   if (ncp && c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_cpl, 0));      // off-diagonal force stores complete
   HT(8);
-  // ---- 9. energies to the host, Hamiltonian
-  if (c->overlap) HIPCHK(hipEventSynchronize(w->ev_fetch));     // energies left before the gather started (early_fetch)
-  const double E_recip1 = c->h_energies[S_RECIP];      // this rank's own (complete) principal reciprocal energy
-  // sharded principal diabat: the real-space energy slots are partial sums; replicated terms count once (rank 0)
+  // ---- 9. Hamiltonian without the principal diabat's energy (H' = H - E0 I), from fetch A
+  if (c->overlap) HIPCHK(hipEventSynchronize(w->ev_fetchA)); else HIPCHK(hipStreamSynchronize(c->stream));
+  const double E_recip1 = w->h_E[nE];                  // this rank's own (complete) principal reciprocal energy
   const bool sharded = c->shard_principal && c->n_ranks > 1;
-  if (sharded && c->rank != 0) c->h_energies[S_RECIP] = 0.0;
-  if (sharded && c->nccl_comm) CHK(msevb_comm_allreduce_energies(c));      // -> complete and identical on every rank
-  const bool partial = sharded && !c->nccl_comm;                            // virtual ranks (tests): the caller sums
-  double en[MSEVB_N_ENERGY];
-  total_force_collect(c, en);
+  const bool partial = sharded && !c->nccl_comm;       // virtual ranks (tests): the caller sums the ranks' shares
   memset(c->H, 0, sizeof c->H);
   auto unitE = [&](int iu) { return w->h_E[iu] + w->h_E[nu + iu]; };
-  const double once = (partial && c->rank != 0) ? 0.0 : 1.0;
-  const double H11_norep = en[MSEVB_E_POTENTIAL] - (1.0 - once) * c->ewald_self + once * c->e_ref[c->h_mol_type[c->hydronium]];
-  const double H11 = H11_norep + once * unitE(units_of[0][0]);
-  c->H[0][0] = H11;
+  const double once = (partial && c->rank != 0) ? 0.0 : 1.0;      // replicated terms count once over virtual ranks
+  const double Hp_norep = once * c->e_ref[c->h_mol_type[c->hydronium]];
+  c->H[0][0] = Hp_norep + once * unitE(units_of[0][0]);
   for (int d = 1; d < D; ++d) {
     if (!owned(c, d)) continue;
-    double e = H11_norep + eref_delta[d];
+    double e = c->e_ref[c->h_mol_type[c->hydronium]] + eref_delta[d];
     for (int iu : units_of[d]) e += units[iu].sign * unitE(iu);
     e += w->h_E[2 * nu + ncp + grid_of[d]] - E_recip1;
     c->H[d][d] = e;
@@ -1267,14 +1275,27 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     c->cpl_A[d] = w->h_E[2 * nu + ncp + ngrid + 3 * cp_of[d]];      // geometric factor A: the off-diagonal store holds dV, F_pd = -A dV
   }
   HT(9);
-  // ---- 10. multi-GPU: complete the Hamiltonian and the force stores on every rank
+  // ---- 10. multi-GPU: Hamiltonian entries of the other ranks' diabats
   if (c->n_ranks > 1 && c->nccl_comm) CHK(msevb_comm_allgather_evb(c));
+  // E0 = potential energy of the principal diabat (fetch B); added to the diagonal and to the eigenvalue
+  auto principal_energy = [&](double& E0) -> int {
+    if (c->overlap) HIPCHK(hipEventSynchronize(w->ev_fetch)); else HIPCHK(hipStreamSynchronize(c->stream));
+    if (sharded && c->rank != 0) c->h_energies[S_RECIP] = 0.0;      // sharded principal diabat: replicated terms count once (rank 0)
+    if (sharded && c->nccl_comm) CHK(msevb_comm_allreduce_energies(c));      // -> complete and identical on every rank
+    double en[MSEVB_N_ENERGY];
+    total_force_collect(c, en);
+    E0 = en[MSEVB_E_POTENTIAL] - (1.0 - once) * c->ewald_self;
+    return MSEVB_OK;
+  };
   if (c->n_ranks > 1 && !c->nccl_comm) {   // virtual sharding (tests): leave foreign diabats empty; caller merges
-    if (epot_out) *epot_out = H11;
+    double E0 = 0.0;
+    CHK(principal_energy(E0));
+    for (int d = 0; d < D; ++d) if (d == 0 || owned(c, d)) c->H[d][d] += E0;
+    if (epot_out) *epot_out = c->H[0][0];
     rearm.ok = true;
     return MSEVB_OK;
   }
-  // ---- 11. diagonalise, blend (diagonalize_evb_hamiltonian, :242)
+  // ---- 11. diagonalise H', blend (diagonalize_evb_hamiltonian, :242)
   std::vector<double> a((size_t)D * D), ev(D), v((size_t)D * D);
   for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) { a[(size_t)i * D + j] = c->H[i][j]; a[(size_t)j * D + i] = c->H[i][j]; }
   if (jacobi_h(D, a, ev, v) != 0) FAIL(MSEVB_ERR_NUMERIC, "too many iterations in jacobi");
@@ -1304,6 +1325,12 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   HIPCHK(hipGetLastError());
   if (c->n_ranks > 1 && c->nccl_comm) CHK(msevb_comm_allreduce_forces(c));
   phase_end(c, PH_EVB_BLEND);
+  {   // the blend is enqueued: now the principal energy (it shifts the whole diagonal, not the ground-state vector)
+    double E0 = 0.0;
+    CHK(principal_energy(E0));
+    for (int d = 0; d < D; ++d) c->H[d][d] += E0;
+    eg += E0;
+  }
   int pr = 0; double sc = std::fabs(c->eigvec[0]);
   for (int i = 0; i < D; ++i) if (sc < std::fabs(c->eigvec[i])) { sc = std::fabs(c->eigvec[i]); pr = i; }
   c->principal = pr; c->new_hydronium = c->hydronium;
@@ -1344,7 +1371,7 @@ void evb_release(msevb_ctx* c) {
     DBuf<double>* db[] = {&w->d_exch, &w->d_part, &w->d_E, &w->d_dVspec, &w->d_sw, &w->d_sdw, &w->d_Fdelta, &w->d_F11, &w->d_pack, &w->d_com_atom};
     for (auto b : db) b->release();
     w->d_tabs.release(); w->d_sbase.release(); w->d_counter.release(); w->d_grids.release(); w->d_region.release(); w->d_cand.release(); w->d_desc.release();
-    hipEvent_t* ev[] = {&w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush};
+    hipEvent_t* ev[] = {&w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA};
     for (auto e : ev) if (*e) (void)hipEventDestroy(*e);
     if (w->h_region) (void)hipHostFree(w->h_region);
     if (w->h_count) (void)hipHostFree(w->h_count);

@@ -453,6 +453,7 @@ int msevb_intra_molecular_energy_force(msevb_ctx* c, double* e) {
 
 // the principal-diabat force call, everything enqueued on the stream; energies land in c->h_energies after fetch_energies()
 int total_force_enqueue(msevb_ctx* c) {
+  c->timing_now = c->timing && (c->timing_tick++ % c->timing_stride) == 0;
   // Verlet freshness: src/total_energy_forces.f90:30-39 (rebuild when the flag was raised by the previous call)
   if (c->flag_verlet_list == 1 || !c->list_valid) {
     CHK(nb_build(c)); c->flag_verlet_list = 0;
@@ -543,7 +544,8 @@ int msevb_get_phase_times(msevb_ctx* c, int* n, const char** names, double* ms, 
 int msevb_reset_phase_times(msevb_ctx* c) { (void)hipStreamSynchronize(c->stream); phase_harvest(c); for (int p = 0; p < PH_COUNT; ++p) { c->ph[p].ms = 0; c->ph[p].calls = 0; } return MSEVB_OK; }
 int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   const std::string s(name);
-  if (s == "phase_timing") { c->timing = v != 0.0; return MSEVB_OK; }
+  if (s == "phase_timing") { c->timing = v != 0.0; c->timing_now = false; return MSEVB_OK; }
+  if (s == "phase_timing_stride") { c->timing_stride = v < 1.0 ? 1 : (int)v; return MSEVB_OK; }
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
   if (s == "overlap") { c->overlap = v != 0.0; return MSEVB_OK; }

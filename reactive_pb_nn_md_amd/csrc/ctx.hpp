@@ -248,6 +248,8 @@ struct msevb_ctx {
 
   PhaseTimer ph[PH_COUNT];
   bool timing = true;
+  // phase events are SAMPLED: one force call in timing_stride records them (every record costs ~2 us of host time, 25 per step)
+  bool timing_now = false; int timing_stride = 8; long timing_tick = 0;
 };
 
 // ---- cross-file entry points (all enqueue on c->stream) ----------------------------------------------
@@ -288,7 +290,7 @@ constexpr int MAX_BLOCKS = 65536;
 enum Slot { S_ELEC_PAIR = 0, S_VDW_PAIR, S_ELEC_INTRA, S_VDW_INTRA, S_BOND, S_ANGLE, S_DIH, S_RECIP, S_KE, S_PX, S_PY, S_PZ, S_MAXD1, S_MAXD2, S_EVB0, N_SLOTS = 32 };
 
 inline void phase_begin(msevb_ctx* c, int p, hipStream_t st = nullptr) {
-  if (!c->timing) return;
+  if (!(c->timing_now || (c->timing && p == PH_VERLET))) return;      // list rebuilds are rare: always timed (and counted)
   if (!st) st = c->stream;
   PhaseTimer& t = c->ph[p];
   if (t.used + 2 > 16384) return;   // pool exhausted: stop sampling until the next harvest
@@ -297,7 +299,7 @@ inline void phase_begin(msevb_ctx* c, int p, hipStream_t st = nullptr) {
   t.used += 1;
 }
 inline void phase_end(msevb_ctx* c, int p, hipStream_t st = nullptr) {
-  if (!c->timing) return;
+  if (!(c->timing_now || (c->timing && p == PH_VERLET))) return;
   if (!st) st = c->stream;
   PhaseTimer& t = c->ph[p];
   if ((t.used & 1) == 0) return;

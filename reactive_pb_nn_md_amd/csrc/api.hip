@@ -86,6 +86,7 @@ int msevb_destroy(msevb_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->aux2) (void)hipStreamSynchronize(c->aux2);
   evb_release(c);
+  if (c->pme_graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)c->pme_graph_exec); c->pme_graph_exec = nullptr; }
   if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); c->aux = nullptr; }
   if (c->aux2) { (void)hipStreamSynchronize(c->aux2); (void)hipStreamDestroy(c->aux2); c->aux2 = nullptr; }
   if (c->aux3) { (void)hipStreamSynchronize(c->aux3); (void)hipStreamDestroy(c->aux3); c->aux3 = nullptr; }
@@ -549,6 +550,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
   if (s == "overlap") { c->overlap = v != 0.0; return MSEVB_OK; }
+  if (s == "graphs") { c->graphs = v != 0.0; return MSEVB_OK; }
   if (s == "evb_element_stores") { c->evb_element_stores = v != 0.0; return MSEVB_OK; }
   if (s == "shard_principal") { c->shard_principal = v != 0.0; return MSEVB_OK; }
   if (s == "pair_tiles") { c->pair_tiles_opt = (int)v; c->list_valid = false; return MSEVB_OK; }

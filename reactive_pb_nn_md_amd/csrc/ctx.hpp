@@ -149,6 +149,8 @@ struct msevb_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   hipStream_t pme_st = nullptr;      // non-null while the PME front end is being enqueued on the side stream
   bool overlap = true;
+  bool graphs = true;            // replay the PME front end as a hipGraph on the side stream
+  void* pme_graph_exec = nullptr; char pme_graph_key[128] = {0}; int pme_graph_nbk = 0;
   // multi-rank EVB: the principal diabat's pair loop, per-molecule terms and reciprocal-force accumulation are split over the ranks by
   // atom / molecule ranges (the partial principal forces meet in the all-reduce of the blend); set by msevb_comm_init, or by the
   // "shard_principal" option for virtual ranks (tests)

@@ -294,33 +294,61 @@ int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux) {
   // may still be running on aux2), which leaves `aux` free for the diabat grids of the EVB phase
   c->pme_st = join_aux ? c->aux : nullptr;
   const hipStream_t st = pme_stream(c);
-  phase_begin(c, PH_SPREAD, st);
-  CHK(pme_prepare_atoms(c, false));
-  HIPCHK(hipMemsetAsync(c->d_grid.p, 0, K3 * sizeof(double2), st));
-  {
-    int3 T;
-    T.x = (int)ceil((double)K / c->ncell[0]) + 8; T.y = (int)ceil((double)K / c->ncell[1]) + 8; T.z = (int)ceil((double)K / c->ncell[2]) + 8;
-    const size_t tile_bytes = (size_t)T.x * T.y * T.z * sizeof(double);
-    if (c->list_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= K && T.y <= K && T.z <= K) {
-      const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
-      hipLaunchKernelGGL(k_pme_spread_tiles, dim3(ncell), dim3(256), tile_bytes, st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T,
-                         c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_base.p, c->d_w.p, c->d_grid.p);
-    } else {
-      const long nt = (long)N * 36;
-      hipLaunchKernelGGL(k_pme_spread, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, N, K, c->d_chg.p, c->d_base.p, c->d_w.p, c->d_grid.p);
+  // The front end is the same ~14 launches with the same arguments every step (all its inputs live at fixed device addresses): on the
+  // side stream it is captured once into a hipGraph and replayed with one launch (the ~14 launches cost the host ~80 us per step, and
+  // the host is what decides when the EVB chains behind them can start).  Steps that sample the phase timers launch directly.
+  struct Key { const void* p[8]; int v[8]; } key = {{c->d_grid.p, c->d_Q.p, c->d_theta.p, c->d_w.p, c->d_base.p, c->d_cell_start.p, c->d_perm.p, c->d_chg.p},
+                                               {N, K, c->ncell[0], c->ncell[1], c->ncell[2], c->list_valid ? 1 : 0, c->spread_tiles ? 1 : 0, slot_recip}};
+  const bool use_graph = join_aux && c->graphs && !c->timing_now;
+  bool capturing = false;
+  int nbk = 0;
+  if (use_graph && c->pme_graph_exec && memcmp(&key, c->pme_graph_key, sizeof key) == 0) {
+    HIPCHK(hipGraphLaunch((hipGraphExec_t)c->pme_graph_exec, st));
+    nbk = c->pme_graph_nbk;
+  } else {
+    if (use_graph) {
+      if (c->pme_graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)c->pme_graph_exec); c->pme_graph_exec = nullptr; }
+      capturing = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    }
+    phase_begin(c, PH_SPREAD, st);
+    CHK(pme_prepare_atoms(c, false));
+    HIPCHK(hipMemsetAsync(c->d_grid.p, 0, K3 * sizeof(double2), st));
+    {
+      int3 T;
+      T.x = (int)ceil((double)K / c->ncell[0]) + 8; T.y = (int)ceil((double)K / c->ncell[1]) + 8; T.z = (int)ceil((double)K / c->ncell[2]) + 8;
+      const size_t tile_bytes = (size_t)T.x * T.y * T.z * sizeof(double);
+      if (c->list_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= K && T.y <= K && T.z <= K) {
+        const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
+        hipLaunchKernelGGL(k_pme_spread_tiles, dim3(ncell), dim3(256), tile_bytes, st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T,
+                           c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_base.p, c->d_w.p, c->d_grid.p);
+      } else {
+        const long nt = (long)N * 36;
+        hipLaunchKernelGGL(k_pme_spread, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, N, K, c->d_chg.p, c->d_base.p, c->d_w.p, c->d_grid.p);
+      }
+    }
+    int nbc = (int)((K3 + 255) / 256);
+    if (nbc > 2048) nbc = 2048;
+    hipLaunchKernelGGL(k_copy_real, dim3(nbc), dim3(256), 0, st, K3, c->d_grid.p, c->d_Q.p);
+    HIPCHK(hipGetLastError());
+    phase_end(c, PH_SPREAD, st);
+    phase_begin(c, PH_FFT, st);
+    CHK(pme_convolve(c, c->d_grid.p, 1, c->d_partials.p + (size_t)slot_recip * MAX_BLOCKS, MAX_BLOCKS, &nbk));
+    hipLaunchKernelGGL(k_pme_real, dim3(1024), dim3(256), 0, st, K3, c->d_grid.p, c->d_theta.p);
+    phase_end(c, PH_FFT, st);
+    if (capturing) {
+      hipGraph_t g = nullptr;
+      if (hipStreamEndCapture(st, &g) == hipSuccess && g) {
+        hipGraphExec_t ex = nullptr;
+        if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess && ex) {
+          c->pme_graph_exec = ex; memcpy(c->pme_graph_key, &key, sizeof key); c->pme_graph_nbk = nbk;
+          HIPCHK(hipGraphLaunch(ex, st));       // the capture itself executed nothing
+        } else c->graphs = false;
+        (void)hipGraphDestroy(g);
+      } else c->graphs = false;
+      if (!c->graphs) FAIL(MSEVB_ERR_HIP, "hipGraph capture of the PME front end failed (set option graphs=0)");
     }
   }
-  int nbc = (int)((K3 + 255) / 256);
-  if (nbc > 2048) nbc = 2048;
-  hipLaunchKernelGGL(k_copy_real, dim3(nbc), dim3(256), 0, st, K3, c->d_grid.p, c->d_Q.p);
-  HIPCHK(hipGetLastError());
-  phase_end(c, PH_SPREAD, st);
-  phase_begin(c, PH_FFT, st);
-  int nbk = 0;
-  CHK(pme_convolve(c, c->d_grid.p, 1, c->d_partials.p + (size_t)slot_recip * MAX_BLOCKS, MAX_BLOCKS, &nbk));
   CHK(reduce_partials(c, slot_recip, nbk));
-  hipLaunchKernelGGL(k_pme_real, dim3(1024), dim3(256), 0, st, K3, c->d_grid.p, c->d_theta.p);
-  phase_end(c, PH_FFT, st);
   c->pme_st = nullptr;
   if (join_aux) { HIPCHK(hipEventRecord(c->ev_join, c->aux)); HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
   if (c->skip_gather_now) return MSEVB_OK;      // EVB fast path: the reciprocal force comes with the gather of the blended potential

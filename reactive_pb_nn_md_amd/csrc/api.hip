@@ -550,6 +550,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
   if (s == "overlap") { c->overlap = v != 0.0; return MSEVB_OK; }
+  if (s == "nbr_tiles") { c->nbr_tiles = v != 0.0; c->list_valid = false; return MSEVB_OK; }
   if (s == "graphs") { c->graphs = v != 0.0; return MSEVB_OK; }
   if (s == "evb_element_stores") { c->evb_element_stores = v != 0.0; return MSEVB_OK; }
   if (s == "shard_principal") { c->shard_principal = v != 0.0; return MSEVB_OK; }

@@ -99,7 +99,9 @@ constexpr unsigned NBR_IDX_MASK = (1u << NBR_IDX_BITS) - 1u;
 // In tile mode (c->pair_tiles) the index is LOCAL: the position of the neighbour inside the concatenation of the neighbour cells
 // of the owning atom's cell (cell_neighbourhood order) - exactly the layout of the LDS tile the pair kernel stages per cell.
 constexpr int PAIR_TILE_LDS_BYTES = 144 * 1024;      // of the 160 KiB per CU; the rest holds the pair-parameter table and reductions
-constexpr int PAIR_TILE_MIN_CELLS = 128;             // fewer cells than this cannot fill the chip with one block per cell
+constexpr int PAIR_TILE_MIN_CELLS = 128;
+constexpr int NBR_TILE_CAP = 5400;                   // atoms of a cell neighbourhood staged in LDS by the list build (28 B each: 148 KB)
+constexpr int NBR_TILE_MIN_CELLS = 64;               // below this many cells the wave-per-atom build fills the chip better             // fewer cells than this cannot fill the chip with one block per cell
 
 // host mirror of a molecule type (as set through the ABI)
 struct MolTypeHost {
@@ -149,6 +151,7 @@ struct msevb_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   hipStream_t pme_st = nullptr;      // non-null while the PME front end is being enqueued on the side stream
   bool overlap = true;
+  bool nbr_tiles = true;         // LDS-staged list build (workgroup per cell) when there are enough cells
   bool graphs = true;            // replay the PME front end as a hipGraph on the side stream
   void* pme_graph_exec = nullptr; char pme_graph_key[128] = {0}; int pme_graph_nbk = 0;
   // multi-rank EVB: the principal diabat's pair loop, per-molecule terms and reciprocal-force accumulation are split over the ranks by

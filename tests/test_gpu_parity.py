@@ -248,6 +248,13 @@ def test_full_size_properties_config_B():
     spec = _synthetic(32, 8, 11, 64)
     h = api.MsEvbHip(spec)
     h.construct_verlet_list()
+    vp1, nl1 = h.get_verlet_list()                    # LDS-staged build (workgroup per cell; only used when there are >= 64 cells)
+    h.set_option("nbr_tiles", 0)
+    h.construct_verlet_list()
+    vp0, nl0 = h.get_verlet_list()                    # wave-per-atom build (the one the small fixtures pin against the reference)
+    assert np.array_equal(vp1, vp0) and np.array_equal(nl1, nl0)
+    h.set_option("nbr_tiles", 1)
+    h.construct_verlet_list()
     h.zero_forces()
     h.real_space_energy_force()
     F = h.get_forces()

@@ -456,18 +456,25 @@ int msevb_intra_molecular_energy_force(msevb_ctx* c, double* e) {
 int total_force_enqueue(msevb_ctx* c) {
   c->timing_now = c->timing && (c->timing_tick++ % c->timing_stride) == 0;
   // Verlet freshness: src/total_energy_forces.f90:30-39 (rebuild when the flag was raised by the previous call)
-  if (c->flag_verlet_list == 1 || !c->list_valid) {
-    CHK(nb_build(c)); c->flag_verlet_list = 0;
+  const bool rebuild = c->flag_verlet_list == 1 || !c->list_valid;
+  if (rebuild) {      // cells + sorted arrays now; the rows are filled below, beside what only needs the cells
+    CHK(nb_build_begin(c)); c->flag_verlet_list = 0;
     HIPCHK(hipMemsetAsync(c->d_force.p, 0, 3 * (size_t)c->N * 8, c->stream));
   } else CHK(nb_step_refresh(c));
-  if (c->overlap) {     // three independent chains, all adding to the force with fp64 atomics; joined at the end
+  if (c->overlap) {     // independent chains, all adding to the force with fp64 atomics
     HIPCHK(aux_fork(c));
-    CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));                    // main: the pair loop (longest)
+    if (!rebuild) CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));      // main: the pair loop (longest) goes out first
     CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux2));      // aux2: per-molecule terms (few, long threads)
-    CHK(pme_forces(c, S_RECIP, true));                               // aux: stencils, spreading, FFTs, convolution; gather on main
+    CHK(pme_front(c, S_RECIP, true));                                // aux: stencils, spreading, FFTs, convolution
+    if (rebuild) {                                                   // main: list rows (one host synchronisation) beside them, then the pair loop
+      CHK(nb_build_finish(c));
+      CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
+    }
+    CHK(pme_tail(c, true));                                          // main: wait for aux, gather (skipped by the EVB fast path)
     HIPCHK(hipEventRecord(c->ev_join2, c->aux2));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
   } else {
+    if (rebuild) CHK(nb_build_finish(c));
     CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
     CHK(molecule_forces(c, S_ELEC_INTRA, true, true));
     CHK(pme_forces(c, S_RECIP, false));

@@ -151,6 +151,7 @@ struct msevb_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   hipStream_t pme_st = nullptr;      // non-null while the PME front end is being enqueued on the side stream
   bool overlap = true;
+  bool cells_valid = false;      // cell_start / perm are current (a list build is in progress or done)
   bool nbr_tiles = true;         // LDS-staged list build (workgroup per cell) when there are enough cells
   bool graphs = true;            // replay the PME front end as a hipGraph on the side stream
   void* pme_graph_exec = nullptr; char pme_graph_key[128] = {0}; int pme_graph_nbk = 0;
@@ -259,6 +260,8 @@ struct msevb_ctx {
 
 // ---- cross-file entry points (all enqueue on c->stream) ----------------------------------------------
 int nb_build(msevb_ctx* c);                        // neighbor.hip
+int nb_build_begin(msevb_ctx* c);     // cells + sorted arrays
+int nb_build_finish(msevb_ctx* c);    // rows (one host synchronisation)
 int nb_refresh_sorted(msevb_ctx* c);               // gather posq/type in sorted order
 extern "C" int msevb_comm_allreduce_forces(msevb_ctx* c);   // comm.hip
 void evb_release(msevb_ctx* c);        // evb.hip: per-context EVB scratch
@@ -267,7 +270,9 @@ int nb_step_refresh(msevb_ctx* c);      // refresh + displacement check + zero f
 int nb_check_displacements(msevb_ctx* c, int initialize, int* flag);
 int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw);              // pair.hip
 int molecule_forces(msevb_ctx* c, int slot0, bool do_nb, bool do_bonded, hipStream_t st = nullptr);  // molecule.hip
-int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux = false);                           // pme.hip
+int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux = false);
+int pme_front(msevb_ctx* c, int slot_recip, bool join_aux);
+int pme_tail(msevb_ctx* c, bool join_aux);                           // pme.hip
 int pme_setup(msevb_ctx* c);
 void pme_teardown(msevb_ctx* c);
 int reduce_partials(msevb_ctx* c, int slot, int nblocks);                // deferred: one fused launch in flush_reductions

@@ -1233,7 +1233,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
       for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gslots[grid_of[d]] = diag_slot(c, D, d);
       if ((double)K3 * ngrid >= 2147483648.0) FAIL(MSEVB_ERR_LIMIT, "EVB gather: K^3 * n_grids exceeds the 32-bit offset range");
       if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));      // the gather folds the real-space deltas in
-      const int* permp = c->list_valid ? c->d_perm.p : nullptr;     // cell-sorted traversal keeps the stencils of co-resident waves in L2
+      const int* permp = c->cells_valid ? c->d_perm.p : nullptr;     // cell-sorted traversal keeps the stencils of co-resident waves in L2
       for (int g0 = 0; g0 < ngrid; g0 += 8) {
         const int ng = std::min(8, ngrid - g0);
         auto kern = ng > 4 ? k_stencil_gather<8> : ng > 2 ? k_stencil_gather<4> : ng > 1 ? k_stencil_gather<2> : k_stencil_gather<1>;

@@ -341,7 +341,12 @@ int nb_step_refresh(msevb_ctx* c) {
   return MSEVB_OK;
 }
 
-int nb_build(msevb_ctx* c) {
+// A (re)build in two halves so that the caller can start everything that only needs the CELL structure (PME spreading, per-molecule
+// terms) on the side streams while the rows are still being filled: nb_build_begin = cell sort + sorted arrays, nb_build_finish = rows
+// (+ the one host synchronisation of a build).  nb_build = both.
+int nb_build(msevb_ctx* c) { CHK(nb_build_begin(c)); return nb_build_finish(c); }
+
+int nb_build_begin(msevb_ctx* c) {
   const int N = c->N;
   if ((unsigned)N > NBR_IDX_MASK || c->nt > 256) FAIL(MSEVB_ERR_LIMIT, "Verlet list entries hold 24-bit atom indices and 8-bit atom types");
   phase_begin(c, PH_VERLET);
@@ -362,6 +367,16 @@ int nb_build(msevb_ctx* c) {
   HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tb, c->d_cell_keys_tmp.p, c->d_cell_of.p, c->d_perm_tmp.p, c->d_perm.p, N, 0, bits, c->stream));
   hipLaunchKernelGGL(k_cell_bounds, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, ncell, c->d_cell_of.p, c->d_cell_start.p);
   CHK(nb_refresh_sorted(c));
+  c->list_valid = false;      // cells are current, rows are not yet
+  c->cells_valid = true;
+  return MSEVB_OK;
+}
+
+int nb_build_finish(msevb_ctx* c) {
+  const int N = c->N;
+  const int3 nc = make_int3(c->ncell[0], c->ncell[1], c->ncell[2]);
+  const int ncell = nc.x * nc.y * nc.z;
+  const BoxDev box = make_box(c);
   const int wpb = 4;
   const dim3 grid((N + wpb - 1) / wpb), block(64 * wpb);
   const double rv2 = c->rv * c->rv;

@@ -286,7 +286,10 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
   return MSEVB_OK;
 }
 
-int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux) {
+int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux) { CHK(pme_front(c, slot_recip, join_aux)); return pme_tail(c, join_aux); }
+
+// front end: stencils, spreading, FFT, convolution (+ energy), inverse FFT, real part - on `aux` when on_aux
+int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
   const int N = c->N, K = c->K;
   const size_t K3 = (size_t)K * K * K;
   // join_aux: the caller has forked the side streams; the front end (stencils, spreading, FFTs, convolution) goes to `aux` beside the
@@ -298,7 +301,7 @@ int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux) {
   // side stream it is captured once into a hipGraph and replayed with one launch (the ~14 launches cost the host ~80 us per step, and
   // the host is what decides when the EVB chains behind them can start).  Steps that sample the phase timers launch directly.
   struct Key { const void* p[8]; int v[8]; } key = {{c->d_grid.p, c->d_Q.p, c->d_theta.p, c->d_w.p, c->d_base.p, c->d_cell_start.p, c->d_perm.p, c->d_chg.p},
-                                               {N, K, c->ncell[0], c->ncell[1], c->ncell[2], c->list_valid ? 1 : 0, c->spread_tiles ? 1 : 0, slot_recip}};
+                                               {N, K, c->ncell[0], c->ncell[1], c->ncell[2], c->cells_valid ? 1 : 0, c->spread_tiles ? 1 : 0, slot_recip}};
   const bool use_graph = join_aux && c->graphs && !c->timing_now;
   bool capturing = false;
   int nbk = 0;
@@ -317,7 +320,7 @@ int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux) {
       int3 T;
       T.x = (int)ceil((double)K / c->ncell[0]) + 8; T.y = (int)ceil((double)K / c->ncell[1]) + 8; T.z = (int)ceil((double)K / c->ncell[2]) + 8;
       const size_t tile_bytes = (size_t)T.x * T.y * T.z * sizeof(double);
-      if (c->list_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= K && T.y <= K && T.z <= K) {
+      if (c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= K && T.y <= K && T.z <= K) {
         const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
         hipLaunchKernelGGL(k_pme_spread_tiles, dim3(ncell), dim3(256), tile_bytes, st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T,
                            c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_base.p, c->d_w.p, c->d_grid.p);
@@ -350,7 +353,13 @@ int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux) {
   }
   CHK(reduce_partials(c, slot_recip, nbk));
   c->pme_st = nullptr;
-  if (join_aux) { HIPCHK(hipEventRecord(c->ev_join, c->aux)); HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
+  if (join_aux) HIPCHK(hipEventRecord(c->ev_join, c->aux));
+  return MSEVB_OK;
+}
+
+// tail on the main stream: wait for the front end, gather (atomic adds when other force kernels may still be running)
+int pme_tail(msevb_ctx* c, bool join_aux) {
+  if (join_aux) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   if (c->skip_gather_now) return MSEVB_OK;      // EVB fast path: the reciprocal force comes with the gather of the blended potential
   phase_begin(c, PH_GATHER);
   CHK(pme_gather(c, c->d_grid.p, c->d_chg.p, c->d_force_recip.p, c->d_force.p, join_aux));

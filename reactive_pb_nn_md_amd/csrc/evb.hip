@@ -701,6 +701,8 @@ struct EvbWork {   // persistent device scratch of one context
   int grids_cap = 0;
   bool tabs_uploaded = false;
   double screen_r = 0.0;
+  // what the last force call left behind, for msevb_evb_partial_blend on the fast path (virtual-rank tests)
+  int last_ngrid = 0, last_nra = 0, last_grid_of[MAX_DIABATS]; const RecipAtom* last_d_ra = nullptr; bool last_fast = false;
   bool counters_dirty = true, dv_dirty = true;
   std::vector<RegionRec> region;
 };
@@ -879,10 +881,41 @@ static double blend_terms(const msevb_ctx* c, int D, const double* ev, BlendTerm
   }
   return (c->rank == 0 || (c->shard_principal && c->n_ranks > 1)) ? 1.0 : 0.0;      // sharded principal: every rank holds a part of F11
 }
+// Fast-path blend of THIS rank's share for the ground-state vector ev: one gather of the blended potential of its grids (+ the principal
+// one on rank 0), the special atoms' corrections into the delta store, then the blend of delta / off-diagonal stores.  c->d_force holds
+// (this rank's part of) F11 on entry and the rank's partial Hellmann-Feynman force on exit.
+static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, const int* grid_of, int ngrid, int nra, const RecipAtom* d_ra);
+
 static inline bool owned(const msevb_ctx* c, int d) { return d == 0 || ((d - 1) % c->n_ranks) == c->rank; }
 
 extern "C" int msevb_comm_allgather_evb(msevb_ctx* c);   // comm.hip
 extern "C" int msevb_comm_allreduce_energies(msevb_ctx* c);
+
+static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, const int* grid_of, int ngrid, int nra, const RecipAtom* d_ra) {
+  const int K = c->K;
+  const size_t K3 = (size_t)K * K * K, n3 = 3 * (size_t)c->N;
+  BlendTerms bt;
+  double w11 = blend_terms(c, D, ev, bt);
+  if (w11 == 0.0) {      // replicated (not sharded) principal diabat on a rank other than 0: F11 counts on rank 0 only, the gather below adds to zero
+    HIPCHK(hipMemsetAsync(c->d_force.p, 0, n3 * 8, c->stream));
+    w11 = 1.0;
+  }
+  // reciprocal space of the blend in ONE gather: blended potential of this rank's diabats (+ the principal one on rank 0) ...
+  GridCoefs gc; gc.n = ngrid; gc.c0 = c->rank == 0 ? ev[0] * ev[0] : 0.0;
+  for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gc.c[grid_of[d]] = ev[d] * ev[d];
+  if (c->overlap && ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // convolved diabat grids (aux)
+  if (w->d_pack.alloc(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended potential)");
+  hipLaunchKernelGGL(k_evb_blend_grids, dim3(1024), dim3(256), 0, c->stream, K3, gc, c->d_theta.p, w->d_grids.p, w->d_pack.p);
+  CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p));
+  // ... the special atoms' own-stencil corrections per diabat go to the delta store, which the blend consumes and re-zeroes
+  if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));
+  if (ngrid) hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
+                                w->d_sw.p, w->d_sdw.p, w->d_grids.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0],
+                                c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3);
+  hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p, 1);
+  HIPCHK(hipGetLastError());
+  return MSEVB_OK;
+}
 
 int evb_force_energy(msevb_ctx* c, double* epot_out) {
   static const bool ht_on = getenv("MSEVB_HOST_TIMING") != nullptr;
@@ -1275,6 +1308,8 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     c->cpl_A[d] = w->h_E[2 * nu + ncp + ngrid + 3 * cp_of[d]];      // geometric factor A: the off-diagonal store holds dV, F_pd = -A dV
   }
   HT(9);
+  w->last_ngrid = ngrid; w->last_nra = nra; w->last_d_ra = d_ra; w->last_fast = fast;
+  for (int d = 0; d < D; ++d) w->last_grid_of[d] = grid_of[d];
   // ---- 10. multi-GPU: Hamiltonian entries of the other ranks' diabats
   if (c->n_ranks > 1 && c->nccl_comm) CHK(msevb_comm_allgather_evb(c));
   // E0 = potential energy of the principal diabat (fetch B); added to the diagonal and to the eigenvalue
@@ -1292,6 +1327,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     CHK(principal_energy(E0));
     for (int d = 0; d < D; ++d) if (d == 0 || owned(c, d)) c->H[d][d] += E0;
     if (epot_out) *epot_out = c->H[0][0];
+    if (fast) w->delta_dirty = true;      // no blend consumed the delta store: msevb_evb_partial_blend may still, the next call re-zeroes it
     rearm.ok = true;
     return MSEVB_OK;
   }
@@ -1302,24 +1338,12 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   int g = 0; double eg = ev[0];
   for (int i = 1; i < D; ++i) if (ev[i] < eg) { eg = ev[i]; g = i; }
   for (int i = 0; i < D; ++i) c->eigvec[i] = v[(size_t)i * D + g];
-  BlendTerms bt;
-  const double w11 = blend_terms(c, D, c->eigvec, bt);
   phase_begin(c, PH_EVB_BLEND);
   if (fast) {
-    // reciprocal space of the blend in ONE gather: blended potential of this rank's diabats (+ the principal one on rank 0) ...
-    GridCoefs gc; gc.n = ngrid; gc.c0 = c->rank == 0 ? c->eigvec[0] * c->eigvec[0] : 0.0;
-    for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gc.c[grid_of[d]] = c->eigvec[d] * c->eigvec[d];
-    if (c->overlap && ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // convolved diabat grids (aux)
-    if (w->d_pack.alloc(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended potential)");
-    hipLaunchKernelGGL(k_evb_blend_grids, dim3(1024), dim3(256), 0, c->stream, K3, gc, c->d_theta.p, w->d_grids.p, w->d_pack.p);
-    CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p));
-    // ... the special atoms' own-stencil corrections per diabat go to the delta store, which the blend consumes and re-zeroes
-    if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));
-    if (ngrid) hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
-                                  w->d_sw.p, w->d_sdw.p, w->d_grids.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0],
-                                  c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3);
-    hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p, 1);
+    CHK(fast_blend_phase(c, w, D, c->eigvec, grid_of.data(), ngrid, nra, d_ra));
   } else {
+    BlendTerms bt;
+    const double w11 = blend_terms(c, D, c->eigvec, bt);
     hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0);
   }
   HIPCHK(hipGetLastError());
@@ -1410,14 +1434,20 @@ int msevb_get_evb_state(msevb_ctx* c, int* nd, int* plog, int* cm, double* H, do
 
 int msevb_evb_partial_blend(msevb_ctx* c, const double* eigvec, double* force) {
   if (!c || c->D <= 0 || !eigvec || !force) { if (c) c->err = "bad argument"; return MSEVB_ERR_ARG; }
-  if (!c->evb_element_stores) FAIL(MSEVB_ERR_STATE, "per-element force stores are off: msevb_set_option(ctx, \"evb_element_stores\", 1) before the EVB force call");
   auto it = g_work.find(c);
-  if (it == g_work.end() || !it->second->d_F11.p) FAIL(MSEVB_ERR_STATE, "no EVB force call yet");
+  if (it == g_work.end()) FAIL(MSEVB_ERR_STATE, "no EVB force call yet");
+  EvbWork* w = it->second;
   const size_t n3 = 3 * (size_t)c->N;
-  BlendTerms bt;
-  const double w11 = blend_terms(c, c->D, eigvec, bt);
-  HIPCHK(hipMemcpyAsync(c->d_force.p, it->second->d_F11.p, n3 * 8, hipMemcpyDeviceToDevice, c->stream));
-  hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0);
+  if (w->last_fast) {      // fast path: consumes the delta store and the force accumulator of the last call - ONE call per force call
+    CHK(fast_blend_phase(c, w, c->D, eigvec, w->last_grid_of, w->last_ngrid, w->last_nra, w->last_d_ra));
+    w->delta_dirty = false;      // the blend re-zeroed every slot it read
+  } else {
+    if (!w->d_F11.p) FAIL(MSEVB_ERR_STATE, "no EVB force call yet");
+    BlendTerms bt;
+    const double w11 = blend_terms(c, c->D, eigvec, bt);
+    HIPCHK(hipMemcpyAsync(c->d_force.p, w->d_F11.p, n3 * 8, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0);
+  }
   HIPCHK(hipMemcpyAsync(force, c->d_force.p, n3 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return MSEVB_OK;

@@ -196,10 +196,26 @@ def test_diabat_sharding_is_a_partition(n_ranks):
         hr.close()
     assert np.allclose(np.diag(Hsum)[1:], np.diag(full["H"])[1:], rtol=1e-13)
     assert np.abs(Fsum - Fblend).max() < 1e-10
+    # the default path (no per-element stores: one gather of the rank's blended potential, self-cleaning delta store), twice per
+    # rank so that a delta store left dirty by the first call would show in the second
+    Fsum = np.zeros_like(Fblend)
+    for r in range(n_ranks):
+        hr = api.MsEvbHip(spec)
+        hr.comm_set_virtual(r, n_ranks)
+        for _rep in range(2):
+            hr.ms_evb_calculate_total_force_energy(want_force=False)
+            Fr = hr.evb_partial_blend(full["eigvec"])
+        hr.ms_evb_calculate_total_force_energy(want_force=False)      # ... and once without the hook consuming it
+        hr.ms_evb_calculate_total_force_energy(want_force=False)
+        assert np.abs(hr.evb_partial_blend(full["eigvec"]) - Fr).max() < 1e-10
+        Fsum += Fr
+        hr.close()
+    assert np.abs(Fsum - Fblend).max() < 1e-10
 
 
+@pytest.mark.parametrize("stores", [0, 1])
 @pytest.mark.parametrize("n_ranks", [2, 3])
-def test_sharded_principal_partial_sums(n_ranks):
+def test_sharded_principal_partial_sums(n_ranks, stores):
     """multi-rank layout with the principal diabat's pair loop / per-molecule terms / reciprocal-force accumulation split over the ranks
     (what msevb_comm_init switches on): the ranks' partial blends and partial H11 add up to the single-rank force and energy"""
     g = golden("evb_n6_d8_s1")
@@ -211,7 +227,7 @@ def test_sharded_principal_partial_sums(n_ranks):
     Fsum, Esum = np.zeros_like(Fblend), 0.0
     for r in range(n_ranks):
         hr = api.MsEvbHip(spec)
-        hr.set_option("evb_element_stores", 1)
+        hr.set_option("evb_element_stores", stores)
         hr.set_option("shard_principal", 1)
         hr.comm_set_virtual(r, n_ranks)
         e_part, _ = hr.ms_evb_calculate_total_force_energy(want_force=False)      # virtual ranks return their share of H11

@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-evb", action="store_true")
     ap.add_argument("--no-phase-timing", action="store_true", help="skip the per-phase HIP events (roofline block becomes null)")
+    ap.add_argument("--rccl-single", action="store_true", help="diagnostic: N=1 with a one-rank RCCL communicator (cost of the two collectives per step)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (msevb_set_option), e.g. pair_tiles=0")
     args = ap.parse_args()
 
@@ -112,6 +113,8 @@ def main():
         dist.broadcast(idbuf, 0)
         raw = (C.c_ubyte * 128)(*idbuf.tolist())
         h._chk(h.L.msevb_comm_init(h.ctx, raw, rank, world))
+    elif args.rccl_single:
+        h.comm_init(api.MsEvbHip.comm_unique_id(h.L), 0, 1)
     vel = synth.maxwell_boltzmann(spec.mass, 300.0, 12345)
     h.set_velocities(vel)
     use_evb = not args.no_evb

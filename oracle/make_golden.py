@@ -80,13 +80,16 @@ def compact(d, keep_store=True):
     return out
 
 
-def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, **simkw):
+def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, proton_shift=0.0, so3h_eref=None, **simkw):
     if ONLY and name not in ONLY:
         return
     ff = forcefield.ch3so3h_water_forcefield()
     if sapt:
         ff = forcefield.with_test_sapt(ff)
-    s = synth.make_system(n_side, n_diabat=n_diabat, seed=seed)
+    if so3h_eref is not None:
+        import dataclasses
+        ff = dataclasses.replace(ff, reference_energy=dict(ff.reference_energy, so3h=so3h_eref))
+    s = synth.make_system(n_side, n_diabat=n_diabat, seed=seed, proton_shift=proton_shift)
     vel = None
     if md_steps:
         p = forcefield.build_params(ff, moltype_order=["h2o", "so3h"])
@@ -98,6 +101,8 @@ def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=Fa
     out["gen_n_side"] = np.array(n_side)
     out["gen_n_diabat"] = np.array(n_diabat)
     out["gen_seed"] = np.array(seed)
+    out["gen_proton_shift"] = np.array(proton_shift)
+    out["gen_so3h_eref"] = np.array(np.nan if so3h_eref is None else so3h_eref)
     out["gen_xyz"] = s.xyz
     out["gen_hydronium"] = np.array(s.hydronium)
     if vel is not None:
@@ -121,6 +126,11 @@ def main():
     case("evb_n6_d4_sapt_s7", 6, 4, 7, evb=True, sapt=True, **small)
     case("md_std_n6_s4", 6, 1, 4, evb=False, md_steps=4, **small)
     case("md_evb_n6_d2_s5", 6, 2, 5, evb=True, md_steps=4, keep_store=False, **small)
+    # principal-diabat switch (src/ms_evb.f90:218-227).  Acid proton started next to its acceptor and the acid's reference energy
+    # raised by 850 kJ/mol (the unrelaxed lattice otherwise keeps the acid diabat ~800 kJ/mol below): the reference's FIRST EVB force
+    # call (during its initialisation) hands the proton to the water, so everything this fixture holds - 'xyz', topology, Hamiltonian,
+    # the MD steps - is the state AFTER the switch, in the reference's re-ordered atom arrays; gen_xyz is the state before it.
+    case("md_evb_n6_d4_switch_s8", 6, 4, 8, evb=True, md_steps=6, keep_store=False, proton_shift=0.55, so3h_eref=-643.65 + 850.0, **small)
 
 
 if __name__ == "__main__":

@@ -162,6 +162,17 @@ class Oracle:
     def kinetic_energy(self, vel):
         return self.L.orc_kinetic_energy(self.h, _p(vel, C.c_double))
 
+    def apply_principal(self):
+        """src/ms_evb.f90:218-227: adopt the topology of the new principal diabat found by the last evb() call"""
+        self.L.orc_evb_apply_principal(self.h)
+
+    def topology(self):
+        M = len(self.spec.mol_natom)
+        at, ch = np.zeros(self.N, dtype=np.int32), np.zeros(self.N)
+        mn, mt, ma = np.zeros(M, dtype=np.int32), np.zeros(M, dtype=np.int32), np.zeros((M, 8), dtype=np.int32)
+        self.L.orc_get_topology(self.h, _p(at, C.c_int), _p(ch, C.c_double), _p(mn, C.c_int), _p(mt, C.c_int), _p(ma, C.c_int))
+        return dict(atom_type_index=at, charge=ch, mol_n_atom=mn, mol_type_index=mt, mol_atom_index=ma)
+
     def evb(self):
         F = np.zeros((self.N, 3))
         e = self.L.orc_evb_force_energy(self.h, _p(F, C.c_double))

@@ -396,6 +396,19 @@ program ref_dump
      call dump_r8('md_velocity', atom_data%velocity, (/3,N/))
      call dump_r8('md_force', atom_data%force, (/3,N/))
      call dump_i4('md_atom_type_index', atom_data%atom_type_index, (/N/))
+     ! topology after the steps: a principal-diabat switch (src/ms_evb.f90:218-227) re-orders the atom arrays
+     call dump_r8('md_charge', atom_data%charge, (/N/))
+     allocate(itmp(M))
+     do i_mole = 1, M
+        itmp(i_mole) = molecule_data(i_mole)%n_atom
+     end do
+     call dump_i4('md_mol_n_atom', itmp, (/M/))
+     do i_mole = 1, M
+        itmp(i_mole) = molecule_data(i_mole)%molecule_type_index
+     end do
+     call dump_i4('md_mol_type_index', itmp, (/M/))
+     deallocate(itmp)
+     if (ms_evb_simulation == "yes") call dump_is('md_hydronium_molecule', hydronium_molecule_index(1))
   end if
 
   call dump_close()

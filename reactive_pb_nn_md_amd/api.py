@@ -287,6 +287,21 @@ class MsEvbHip:
         self._chk(self.L.msevb_calculate_kinetic_energy(self.ctx, C.byref(v)))
         return v.value
 
+    @staticmethod
+    def comm_unique_id(lib=None):
+        """128 opaque bytes (ncclUniqueId) made by rank 0 and handed to every rank's comm_init"""
+        L = lib or load_library()
+        raw = (C.c_ubyte * 128)()
+        rc = L.msevb_comm_unique_id(raw)
+        if rc != 0:
+            raise RuntimeError("msevb_comm_unique_id failed (%d)" % rc)
+        return bytes(raw)
+
+    def comm_init(self, unique_id, rank, n_ranks):
+        """join the RCCL communicator: diabats (and the principal diabat's pair loop) are sharded over n_ranks processes"""
+        raw = (C.c_ubyte * 128)(*unique_id)
+        self._chk(self.L.msevb_comm_init(self.ctx, raw, int(rank), int(n_ranks)))
+
     def comm_set_virtual(self, rank, n_ranks):
         self._chk(self.L.msevb_comm_set_virtual(self.ctx, int(rank), int(n_ranks)))
 

@@ -86,6 +86,7 @@ int msevb_destroy(msevb_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->aux2) (void)hipStreamSynchronize(c->aux2);
   evb_release(c);
+  msevb_comm_release(c);
   if (c->pme_graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)c->pme_graph_exec); c->pme_graph_exec = nullptr; }
   if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); c->aux = nullptr; }
   if (c->aux2) { (void)hipStreamSynchronize(c->aux2); (void)hipStreamDestroy(c->aux2); c->aux2 = nullptr; }
@@ -363,6 +364,8 @@ int msevb_set_positions(msevb_ctx* c, const double* xyz) {
   NEED_FINAL();
   memcpy(c->h_xyz.data(), xyz, 3 * (size_t)c->N * 8);
   HIPCHK(hipMemcpyAsync(c->d_xyz.p, xyz, 3 * (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(c->d_energies.p + S_FAULT, 0, 8, c->stream));      // new coordinates: the sticky bad-coordinate flag starts over
+  c->h_energies[S_FAULT] = 0.0;
   HIPCHK(hipStreamSynchronize(c->stream));
   return MSEVB_OK;
 }
@@ -481,8 +484,10 @@ int total_force_enqueue(msevb_ctx* c) {
   }
   return MSEVB_OK;
 }
-void total_force_collect(msevb_ctx* c, double* en) {
+int total_force_collect(msevb_ctx* c, double* en) {
   const double* h = c->h_energies;
+  // the index arithmetic of the reference (and ours) covers atoms at most one box image away; a blown-up trajectory is reported, not run
+  if (h[S_FAULT] != 0.0) FAIL(MSEVB_ERR_NUMERIC, "atom coordinates are not finite or more than one box length outside the cell (unstable trajectory?)");
   if (c->list_valid) {   // flag for the NEXT call (src/general_routines.f90:1320-1326)
     const double skin = 1.2 * (c->rv - c->rc);
     if ((h[S_MAXD1] + h[S_MAXD2]) > skin) c->flag_verlet_list = 1;
@@ -493,6 +498,7 @@ void total_force_collect(msevb_ctx* c, double* en) {
   en[MSEVB_E_BOND] = h[S_BOND]; en[MSEVB_E_ANGLE] = h[S_ANGLE]; en[MSEVB_E_DIHEDRAL] = h[S_DIH]; en[MSEVB_E_RECIP] = h[S_RECIP];
   en[MSEVB_E_POTENTIAL] = en[MSEVB_E_ELEC] + en[MSEVB_E_VDW] + en[MSEVB_E_BOND] + en[MSEVB_E_ANGLE] + en[MSEVB_E_DIHEDRAL];
   en[7] = 0.0;
+  return MSEVB_OK;
 }
 
 int msevb_calculate_total_force_energy(msevb_ctx* c, double* energies, double* force) {
@@ -501,7 +507,7 @@ int msevb_calculate_total_force_energy(msevb_ctx* c, double* energies, double* f
   if (force) HIPCHK(hipMemcpyAsync(force, c->d_force.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
   CHK(fetch_energies(c));
   double en[MSEVB_N_ENERGY];
-  total_force_collect(c, en);
+  CHK(total_force_collect(c, en));
   if (energies) memcpy(energies, en, sizeof en);
   return MSEVB_OK;
 }

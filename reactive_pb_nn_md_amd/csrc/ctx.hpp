@@ -265,6 +265,7 @@ int nb_build_finish(msevb_ctx* c);    // rows (one host synchronisation)
 int nb_refresh_sorted(msevb_ctx* c);               // gather posq/type in sorted order
 extern "C" int msevb_comm_allreduce_forces(msevb_ctx* c);   // comm.hip
 void evb_release(msevb_ctx* c);        // evb.hip: per-context EVB scratch
+extern "C" void msevb_comm_release(msevb_ctx* c);   // comm.hip: destroys the RCCL communicator, if any
 int flush_one(msevb_ctx* c, int slot, hipStream_t st);      // api.hip
 int nb_step_refresh(msevb_ctx* c);      // refresh + displacement check + zero forces (neighbor.hip)
 int nb_check_displacements(msevb_ctx* c, int initialize, int* flag);
@@ -290,14 +291,16 @@ double volume32(const double box[3]);
 
 // defined inside api.hip's extern "C" block
 extern "C" int total_force_enqueue(msevb_ctx* c);
-extern "C" void total_force_collect(msevb_ctx* c, double* en);
+extern "C" int total_force_collect(msevb_ctx* c, double* en);
 extern "C" int upload_topology(msevb_ctx* c);
 int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part_stride, int* nblocks);
 int pme_prepare_atoms(msevb_ctx* c, bool with_indices);
 int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic = false, const double* theta = nullptr);
 
 constexpr int MAX_BLOCKS = 65536;
-enum Slot { S_ELEC_PAIR = 0, S_VDW_PAIR, S_ELEC_INTRA, S_VDW_INTRA, S_BOND, S_ANGLE, S_DIH, S_RECIP, S_KE, S_PX, S_PY, S_PZ, S_MAXD1, S_MAXD2, S_EVB0, N_SLOTS = 32 };
+enum Slot { S_ELEC_PAIR = 0, S_VDW_PAIR, S_ELEC_INTRA, S_VDW_INTRA, S_BOND, S_ANGLE, S_DIH, S_RECIP, S_KE, S_PX, S_PY, S_PZ, S_VX, S_VY, S_VZ /* sum of velocities: KE after the momentum removal */, S_MAXD1, S_MAXD2, S_EVB0,
+            S_FAULT = 31,      // sticky: a kernel met a coordinate outside what its index arithmetic covers (non-finite, or more than one box away)
+            N_SLOTS = 32 };
 
 inline void phase_begin(msevb_ctx* c, int p, hipStream_t st = nullptr) {
   if (!(c->timing_now || (c->timing && p == PH_VERLET))) return;      // list rebuilds are rare: always timed (and counted)

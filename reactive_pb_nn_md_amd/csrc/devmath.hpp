@@ -16,7 +16,7 @@ __device__ __forceinline__ void pair_interaction(double r2, double qq, const Pai
   const double inv_r2 = 1.0 / r2;
   const double inv_r = r * inv_r2;
   const double x1 = r * inv_dx;
-  const int idx = (int)ceil(x1);
+  const int idx = max((int)ceil(x1), 1);      // r = 0 / NaN (a blown-up trajectory) must not read in front of the table
   const double c2 = (x1 + 1.0) - (double)idx, c1 = 1.0 - c2;
   const double2 t0 = etab[idx - 1], t1 = etab[idx];
   const double ev = c1 * t0.x + c2 * t1.x, sv = c1 * t0.y + c2 * t1.y;
@@ -30,7 +30,7 @@ __device__ __forceinline__ void pair_interaction(double r2, double qq, const Pai
     fs += inv_r2 * (12.0 * pp.p[0] * r12i - 6.0 * pp.p[1] * r6i);
   } else if (SAPT && pp.type == 1 && pp.nonzero) {
     const double A = pp.p[0], B = pp.p[1];
-    const int ti = (int)ceil(B * r / TT_MAX * (double)TT_GRID);
+    const int ti = min(max((int)ceil(B * r / TT_MAX * (double)TT_GRID), 1), TT_GRID);
     const double* t = tt + 4 * (ti - 1);
     const double* dt = dtt + 4 * (ti - 1);
     const double r6i = inv_r2 * inv_r2 * inv_r2, r8i = r6i * inv_r2, r10i = r8i * inv_r2, r12i = r10i * inv_r2;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void pair_interaction_rows(double r2, double qq, cons
     fs += inv_r2 * (12.0 * pp.p[0] * r12i - 6.0 * pp.p[1] * r6i);
   } else if (SAPT && pp.type == 1 && pp.nonzero) {
     const double A = pp.p[0], B = pp.p[1];
-    const int ti = (int)ceil(B * r / TT_MAX * (double)TT_GRID);
+    const int ti = min(max((int)ceil(B * r / TT_MAX * (double)TT_GRID), 1), TT_GRID);
     const double* t = tt + 4 * (ti - 1);
     const double* dt = dtt + 4 * (ti - 1);
     const double r6i = inv_r2 * inv_r2 * inv_r2, r8i = r6i * inv_r2, r10i = r8i * inv_r2, r12i = r10i * inv_r2;
@@ -108,7 +108,7 @@ __device__ __forceinline__ void vdw_interaction(double r2, const PairParam& pp, 
     fs = inv_r2 * (12.0 * pp.p[0] * r12i - 6.0 * pp.p[1] * r6i);
   } else if (pp.type == 1 && pp.nonzero) {
     const double r = sqrt(r2), A = pp.p[0], B = pp.p[1];
-    const int ti = (int)ceil(B * r / TT_MAX * (double)TT_GRID);
+    const int ti = min(max((int)ceil(B * r / TT_MAX * (double)TT_GRID), 1), TT_GRID);
     const double* t = tt + 4 * (ti - 1);
     const double* dt = dtt + 4 * (ti - 1);
     const double r6i = inv_r2 * inv_r2 * inv_r2, r8i = r6i * inv_r2, r10i = r8i * inv_r2, r12i = r10i * inv_r2;
@@ -124,7 +124,7 @@ __device__ __forceinline__ void vdw_interaction(double r2, const PairParam& pp, 
 __device__ __forceinline__ void ewald_interaction(double r2, double qq, const double2* __restrict__ etab, double inv_dx, double& fs, double& e_el) {
   const double r = sqrt(r2), inv_r2 = 1.0 / r2, inv_r = r * inv_r2;
   const double x1 = r * inv_dx;
-  const int idx = (int)ceil(x1);
+  const int idx = max((int)ceil(x1), 1);      // r = 0 / NaN (a blown-up trajectory) must not read in front of the table
   const double c2 = (x1 + 1.0) - (double)idx, c1 = 1.0 - c2;
   const double2 t0 = etab[idx - 1], t1 = etab[idx];
   const double qr = qq * inv_r;

@@ -332,7 +332,7 @@ __global__ void k_evb_grid_init(size_t K3, int ng, const double* __restrict__ Q,
 // stencil of one special atom in its NEW state (one thread per entry): same index arithmetic as k_pme_prep
 __global__ void k_evb_spec_prep(int n, const RecipAtom* __restrict__ ra, int K, int G, double k00, double k01, double k02, double k10, double k11,
                                 double k12, double k20, double k21, double k22, const double* __restrict__ B6, const double* __restrict__ B5,
-                                int* __restrict__ sbase, double* __restrict__ sw, double* __restrict__ sdw) {
+                                int* __restrict__ sbase, double* __restrict__ sw, double* __restrict__ sdw, double* __restrict__ fault) {
 #pragma clang fp contract(off)
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
@@ -341,6 +341,7 @@ __global__ void k_evb_spec_prep(int n, const RecipAtom* __restrict__ ra, int K, 
   for (int l = 0; l < 3; ++l) {
     double u = (double)K * ((kk[l][0] * x + kk[l][1] * y) + kk[l][2] * z);
     if (u < 0.0) u = u + (double)K; else if (u >= (double)K) u = u - (double)K;
+    if (!(u >= 0.0 && u < (double)K)) { *fault = 1.0; u = 0.5; }      // see k_pme_prep
     if (fabs(fmod(u, 1.0)) < 1e-6) u = u + 1e-6;
     const int np = (int)floor(u);
     sbase[3 * e + l] = np;
@@ -888,8 +889,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
 
 static inline bool owned(const msevb_ctx* c, int d) { return d == 0 || ((d - 1) % c->n_ranks) == c->rank; }
 
-extern "C" int msevb_comm_allgather_evb(msevb_ctx* c);   // comm.hip
-extern "C" int msevb_comm_allreduce_energies(msevb_ctx* c);
+extern "C" int msevb_comm_allgather_evb(msevb_ctx* c, int with_energies);   // comm.hip
 
 static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, const int* grid_of, int ngrid, int nra, const RecipAtom* d_ra) {
   const int K = c->K;
@@ -1158,7 +1158,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   if (w->dv_dirty) { HIPCHK(hipMemsetAsync(w->d_dVspec.p, 0, w->d_dVspec.n * 8, ss)); w->dv_dirty = false; }   // afterwards k_evb_coupling_finish leaves it zeroed
   // B-spline stencils of the special atoms in their new states (needs descriptors only)
   if (ngrid) hipLaunchKernelGGL(k_evb_spec_prep, dim3((nra + 63) / 64), dim3(64), 0, ss, nra, d_ra, K, c->spline_grid, c->kk[0][0], c->kk[0][1], c->kk[0][2],
-                                c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p);
+                                c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p, c->d_energies.p + S_FAULT);
   if (c->overlap) {      // descriptors + special stencils are on the device: the main stream and the off-diagonal chain may use them
     HIPCHK(hipEventRecord(w->ev_fork2, ss));
     HIPCHK(hipStreamWaitEvent(c->stream, w->ev_fork2, 0));
@@ -1311,14 +1311,21 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   w->last_ngrid = ngrid; w->last_nra = nra; w->last_d_ra = d_ra; w->last_fast = fast;
   for (int d = 0; d < D; ++d) w->last_grid_of[d] = grid_of[d];
   // ---- 10. multi-GPU: Hamiltonian entries of the other ranks' diabats
-  if (c->n_ranks > 1 && c->nccl_comm) CHK(msevb_comm_allgather_evb(c));
+  bool energies_in = false;
+  if (c->nccl_comm) {
+    if (sharded) {      // the ranks' partial principal energies travel with the Hamiltonian entries
+      if (c->overlap) HIPCHK(hipEventSynchronize(w->ev_fetch)); else HIPCHK(hipStreamSynchronize(c->stream));
+      if (c->rank != 0) c->h_energies[S_RECIP] = 0.0;      // replicated term: counts once
+      energies_in = true;
+    }
+    CHK(msevb_comm_allgather_evb(c, sharded ? 1 : 0));
+  }
   // E0 = potential energy of the principal diabat (fetch B); added to the diagonal and to the eigenvalue
   auto principal_energy = [&](double& E0) -> int {
     if (c->overlap) HIPCHK(hipEventSynchronize(w->ev_fetch)); else HIPCHK(hipStreamSynchronize(c->stream));
-    if (sharded && c->rank != 0) c->h_energies[S_RECIP] = 0.0;      // sharded principal diabat: replicated terms count once (rank 0)
-    if (sharded && c->nccl_comm) CHK(msevb_comm_allreduce_energies(c));      // -> complete and identical on every rank
+    if (sharded && !energies_in && c->rank != 0) c->h_energies[S_RECIP] = 0.0;      // sharded principal diabat: replicated terms count once (rank 0)
     double en[MSEVB_N_ENERGY];
-    total_force_collect(c, en);
+    CHK(total_force_collect(c, en));
     E0 = en[MSEVB_E_POTENTIAL] - (1.0 - once) * c->ewald_self;
     return MSEVB_OK;
   };
@@ -1347,7 +1354,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
     hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0);
   }
   HIPCHK(hipGetLastError());
-  if (c->n_ranks > 1 && c->nccl_comm) CHK(msevb_comm_allreduce_forces(c));
+  if (c->nccl_comm) CHK(msevb_comm_allreduce_forces(c));
   phase_end(c, PH_EVB_BLEND);
   {   // the blend is enqueued: now the principal energy (it shifts the whole diagonal, not the ground-state vector)
     double E0 = 0.0;

@@ -57,9 +57,9 @@ __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt
 // kinetic energy of the kicked velocities (calculate_kinetic_energy, src/total_energy_forces.f90:106)
 __global__ __launch_bounds__(256) void k_step_second_half(int N, double dt, const double* __restrict__ mass, const double* __restrict__ F, double* __restrict__ v,
                                                           int* __restrict__ bad, double* __restrict__ part) {
-  __shared__ double red[4][256];
+  __shared__ double red[7][256];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  double p[4] = {0, 0, 0, 0};
+  double p[7] = {0, 0, 0, 0, 0, 0, 0};
   if (i < N) {
     const double m = mass[i];
     for (int d = 0; d < 3; ++d) {
@@ -67,14 +67,25 @@ __global__ __launch_bounds__(256) void k_step_second_half(int N, double dt, cons
       const double vv = v[3 * i + d] + dt / 2.0 / m * f * 100.0;
       v[3 * i + d] = vv;
       if (fabs(f) > 10e4) atomicExch(bad, i + 1);
-      p[d] = m * vv; p[3] += 0.5 * m * vv * vv / 100.0;
+      p[d] = m * vv; p[3] += 0.5 * m * vv * vv / 100.0; p[4 + d] = vv;
     }
   }
-  for (int s = 0; s < 4; ++s) red[s][threadIdx.x] = p[s];
+  for (int s = 0; s < 7; ++s) red[s][threadIdx.x] = p[s];
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) for (int s = 0; s < 4; ++s) red[s][threadIdx.x] += red[s][threadIdx.x + st]; __syncthreads(); }
-  if (threadIdx.x == 0) { part[(size_t)S_PX * MAX_BLOCKS + blockIdx.x] = red[0][0]; part[(size_t)S_PY * MAX_BLOCKS + blockIdx.x] = red[1][0];
-    part[(size_t)S_PZ * MAX_BLOCKS + blockIdx.x] = red[2][0]; part[(size_t)S_KE * MAX_BLOCKS + blockIdx.x] = red[3][0]; }
+  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) for (int s = 0; s < 7; ++s) red[s][threadIdx.x] += red[s][threadIdx.x + st]; __syncthreads(); }
+  if (threadIdx.x < 7) {
+    const int slot[7] = {S_PX, S_PY, S_PZ, S_KE, S_VX, S_VY, S_VZ};
+    part[(size_t)slot[threadIdx.x] * MAX_BLOCKS + blockIdx.x] = red[threadIdx.x][0];
+  }
+}
+
+// The reference removes the centre-of-mass momentum at the end of the step (every atom gives up P/N, src/md_integration.f90:125-177,:528)
+// and its kinetic energy is taken after that; we remove it inside the next step's first kernel, so the kinetic energy of the kicked
+// velocities is corrected for it: sum m/2 (v - P/(N m))^2 = KE - P.sum(v)/N + P^2/(2 N^2) sum(1/m)
+static double ke_after_removal(const msevb_ctx* c, const double* e /* S_KE.. S_VZ */, double inv_mass_sum) {
+  const double* P = e + (S_PX - S_KE); const double* V = e + (S_VX - S_KE);
+  const double N = (double)c->N;
+  return e[0] - (P[0] * V[0] + P[1] * V[1] + P[2] * V[2]) / N / 100.0 + (P[0] * P[0] + P[1] * P[1] + P[2] * P[2]) / (2.0 * N * N) * inv_mass_sum / 100.0;
 }
 
 }  // namespace
@@ -106,12 +117,15 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
   HIPCHK(hipMemsetAsync(d_bad.p, 0, sizeof(int), c->stream));
   // trajectory energies come back asynchronously: the EVB force call synchronises with the host on its own (Hamiltonian), so the loop
   // itself never waits; without EVB the host needs the Verlet flag of every step and fetches the energies at its end
-  static thread_local double* h_ke = nullptr; static thread_local int h_ke_cap = 0;
+  static thread_local double* h_ke = nullptr; static thread_local int h_ke_cap = 0;      // 7 doubles per step: S_KE, S_P*, S_V*
+  static_assert(S_PX == S_KE + 1 && S_VX == S_KE + 4 && S_VZ == S_KE + 6, "kinetic energy block of the energy slots");
   if (n_steps > h_ke_cap) {
     if (h_ke) HIPCHK(hipHostFree(h_ke));
     h_ke_cap = n_steps + 64;
-    HIPCHK(hipHostMalloc((void**)&h_ke, h_ke_cap * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&h_ke, 7 * (size_t)h_ke_cap * sizeof(double), hipHostMallocDefault));
   }
+  double inv_mass_sum = 0.0;
+  for (int a = 0; a < N; ++a) inv_mass_sum += 1.0 / c->h_mass[a];
   const int nbm = (M + 255) / 256, nba = (N + 255) / 256;
   for (int s = 0; s < n_steps; ++s) {
     phase_begin(c, PH_INTEGRATE);
@@ -124,20 +138,21 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
     hipLaunchKernelGGL(k_step_second_half, dim3(nba), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p, c->d_partials.p);
     HIPCHK(hipGetLastError());
     CHK(reduce_partials(c, S_PX, nba)); CHK(reduce_partials(c, S_PY, nba)); CHK(reduce_partials(c, S_PZ, nba)); CHK(reduce_partials(c, S_KE, nba));
+    CHK(reduce_partials(c, S_VX, nba)); CHK(reduce_partials(c, S_VY, nba)); CHK(reduce_partials(c, S_VZ, nba));
     if (use_evb) {
       CHK(flush_reductions(c));
-      HIPCHK(hipMemcpyAsync(h_ke + s, c->d_energies.p + S_KE, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpyAsync(h_ke + 7 * (size_t)s, c->d_energies.p + S_KE, 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
       if (energies_out) energies_out[2 * s] = epot;
     } else {
       CHK(fetch_energies(c));   // one host synchronisation per step: energies + Verlet flag
-      double en[MSEVB_N_ENERGY]; total_force_collect(c, en);
-      if (energies_out) { energies_out[2 * s] = en[MSEVB_E_POTENTIAL]; energies_out[2 * s + 1] = c->h_energies[S_KE]; }
+      double en[MSEVB_N_ENERGY]; CHK(total_force_collect(c, en));
+      if (energies_out) { energies_out[2 * s] = en[MSEVB_E_POTENTIAL]; energies_out[2 * s + 1] = ke_after_removal(c, c->h_energies + S_KE, inv_mass_sum); }
     }
   }
   if (n_steps > 0) hipLaunchKernelGGL(k_remove_momentum, dim3((n3 + 255) / 256), dim3(256), 0, c->stream, N, c->d_mass.p, c->d_energies.p, c->d_vel.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
-  if (use_evb && energies_out) for (int s = 0; s < n_steps; ++s) energies_out[2 * s + 1] = h_ke[s];
+  if (use_evb && energies_out) for (int s = 0; s < n_steps; ++s) energies_out[2 * s + 1] = ke_after_removal(c, h_ke + 7 * (size_t)s, inv_mass_sum);
   int bad = 0;
   HIPCHK(hipMemcpy(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost));
   if (bad) { char b[96]; snprintf(b, sizeof b, "force on atom %d is too big", bad); FAIL(MSEVB_ERR_NUMERIC, b); }

@@ -18,7 +18,7 @@ namespace {
 __global__ __launch_bounds__(256) void k_pme_prep(int N, int K, int G, const double* __restrict__ xyz, double k00, double k01,
                            double k02, double k10, double k11, double k12, double k20, double k21, double k22,
                            const double* __restrict__ B6, const double* __restrict__ B5, double* __restrict__ uscale, int* __restrict__ base,
-                           int* __restrict__ splindex, double* __restrict__ w, double* __restrict__ dw) {
+                           int* __restrict__ splindex, double* __restrict__ w, double* __restrict__ dw, double* __restrict__ fault) {
 #pragma clang fp contract(off)
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 18 * N) return;
@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256) void k_pme_prep(int N, int K, int G, const dou
   const double ka = l == 0 ? k00 : l == 1 ? k10 : k20, kb = l == 0 ? k01 : l == 1 ? k11 : k21, kc = l == 0 ? k02 : l == 1 ? k12 : k22;
   double u = (double)K * ((ka * x + kb * y) + kc * z);
   if (u < 0.0) u = u + (double)K; else if (u >= (double)K) u = u - (double)K;
+  if (!(u >= 0.0 && u < (double)K)) { *fault = 1.0; u = 0.5; }      // more than one box away, or not a number: flag it, stay inside the grid
   if (fabs(fmod(u, 1.0)) < 1e-6) u = u + 1e-6;
   const int np = (int)floor(u);
   if (k == 0) { uscale[3 * i + l] = u; base[3 * i + l] = np; }
@@ -271,7 +272,7 @@ int pme_prepare_atoms(msevb_ctx* c, bool with_indices) {
   const long nt = 18L * N;
   hipLaunchKernelGGL(k_pme_prep, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, pme_stream(c), N, c->K, c->spline_grid, c->d_xyz.p, c->kk[0][0], c->kk[0][1],
                      c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, c->d_uscale.p,
-                     c->d_base.p, with_indices ? c->d_splindex.p : (int*)nullptr, c->d_w.p, c->d_dw.p);
+                     c->d_base.p, with_indices ? c->d_splindex.p : (int*)nullptr, c->d_w.p, c->d_dw.p, c->d_energies.p + S_FAULT);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
 }

@@ -89,7 +89,8 @@ def _random_rotations(rng, n):
 
 
 def make_system(n_side: int, n_diabat: int = 1, seed: int = 0, max_chain: int = 3,
-                acid_position: str = "middle", quantize_gro: bool = True, liquid_like: bool = False) -> System:
+                acid_position: str = "middle", quantize_gro: bool = True, liquid_like: bool = False,
+                proton_shift: float = 0.0) -> System:
     """n_side^3 lattice sites (box = n_side*3.1 A); n_diabat = 1 + number of planted waters
     (1, 2, 4 -> partial tree, 8 -> full depth-3 binary tree, 16 needs max_chain=4)."""
     rng = np.random.default_rng(seed)
@@ -97,6 +98,9 @@ def make_system(n_side: int, n_diabat: int = 1, seed: int = 0, max_chain: int = 
     centre = np.full(3, 0.5 * L)
     acid = _ACID + centre - _ACID[1]
     tree = _plant_tree(acid, n_diabat - 1, max_chain)
+    if proton_shift:      # acid proton moved along O-H towards its planted acceptor: > ~0.3 A makes the acceptor's diabat the principal one
+        acid = acid.copy()
+        acid[5] += proton_shift * _unit(acid[5] - acid[4])
     special = np.concatenate([acid] + tree) if tree else acid
 
     g = (np.arange(n_side) + 0.5) * SPACING

@@ -29,3 +29,25 @@ def oracle_lib():
     import oracle_py
     oracle_py.build()
     return oracle_py
+
+
+def pre_switch_spec(g):
+    """the state BEFORE the reference's initial principal-diabat switch of a '*_switch_*' fixture: the generating synthetic box
+    (gen_* fields) with the force field of oracle/make_golden.py; the fixture itself holds the state after the switch"""
+    import dataclasses
+    from reactive_pb_nn_md_amd import forcefield, synth, system
+    ff = forcefield.ch3so3h_water_forcefield()
+    if np.isfinite(float(g["gen_so3h_eref"])):
+        ff = dataclasses.replace(ff, reference_energy=dict(ff.reference_energy, so3h=float(g["gen_so3h_eref"])))
+    p = forcefield.build_params(ff, moltype_order=["h2o", "so3h"])
+    s = synth.make_system(int(g["gen_n_side"]), n_diabat=int(g["gen_n_diabat"]), seed=int(g["gen_seed"]), proton_shift=float(g["gen_proton_shift"]))
+    assert np.array_equal(s.xyz, g["gen_xyz"])
+    post = system.from_golden(g)
+    return system.from_synth(s, p, rc=post.rc, rv=post.rv, alpha=post.alpha, pme_grid=post.pme_grid, nslist=post.nslist, max_chain=post.max_chain)
+
+
+def reference_atom_order(topo):
+    """the reference keeps every molecule's atoms contiguous and re-packs its atom arrays after a proton transfer
+    (shift_array_data_donor_acceptor_transfer, src/ms_evb.f90:865); we keep atom indices fixed and edit the molecules' atom lists.
+    Returns perm with reference_array[k] <-> our_array[perm[k]]"""
+    return np.concatenate([topo["mol_atom_index"][m, :topo["mol_n_atom"][m]] for m in range(len(topo["mol_n_atom"]))])

@@ -10,7 +10,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import all_golden, golden
+from conftest import all_golden, golden, pre_switch_spec, reference_atom_order
 from reactive_pb_nn_md_amd import api, forcefield, synth, system
 
 pytestmark = pytest.mark.gpu
@@ -236,6 +236,100 @@ def test_sharded_principal_partial_sums(n_ranks, stores):
         hr.close()
     assert np.abs(Fsum - Fblend).max() < 1e-10
     assert rel(Esum, full["H"][0, 0]) < 1e-13
+
+
+@pytest.mark.parametrize("evb", [False, True])
+def test_blown_up_trajectory_is_an_error_not_a_fault(evb):
+    """velocities 60x thermal: atoms collide, coordinates run away.  The reference's (and our) grid index arithmetic only covers atoms
+    within one box image; the library must notice and return MSEVB_ERR_NUMERIC instead of indexing outside its buffers"""
+    g = golden("evb_n6_d2_s1")
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    h.set_velocities(60.0 * synth.maxwell_boltzmann(spec.mass, 300.0, 9))
+    if evb:
+        h.ms_evb_calculate_total_force_energy(want_force=False)
+    else:
+        h.calculate_total_force_energy(want_force=False)
+    with pytest.raises(RuntimeError, match="not finite|more than one box|too big|diabat|hydronium|too many"):
+        for _ in range(40):
+            h.md_integrate_atomic(25, spec.delta_t, use_evb=evb)
+    # new coordinates clear the condition
+    h.set_positions(spec.xyz)
+    h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 9))
+    h.construct_verlet_list()
+    if evb:
+        e, _ = h.ms_evb_calculate_total_force_energy()
+    else:
+        e = h.calculate_total_force_energy()[0]["potential"]
+    assert np.isfinite(e)
+    h.close()
+
+
+def test_principal_switch_against_reference():
+    """src/ms_evb.f90:218-227.  The fixture's reference run switched the principal diabat in its first EVB force call and holds the
+    state after it (in the reference's re-packed atom arrays).  From the state before the switch the library must arrive at that
+    topology - atom types, charges, molecule records, the transferred proton made whole with its new molecule - and follow the
+    reference's trajectory on it.  All 1-based values are the C-ABI's (Fortran numbering)."""
+    g = golden("md_evb_n6_d4_switch_s8")
+    post = system.from_golden(g)
+    pre = pre_switch_spec(g)
+    h = api.MsEvbHip(pre)
+    h.ms_evb_calculate_total_force_energy(want_force=False)
+    st = h.evb_state()
+    assert st["principle_diabat"] != 1 and st["new_hydronium_molecule"] == post.hydronium + 1
+    t = h.topology()
+    assert t["hydronium_molecule"] == post.hydronium + 1
+    t["mol_atom_index"] = t["mol_atom_index"] - 1
+    perm = reference_atom_order(t)
+    assert sorted(perm) == list(range(pre.n_atom))
+    assert np.array_equal(t["mol_n_atom"], post.mol_natom) and np.array_equal(t["mol_type_index"] - 1, post.mol_type)
+    assert np.array_equal(t["atom_type_index"][perm] - 1, post.atype)
+    assert np.array_equal(t["charge"][perm], post.charge)
+    assert np.abs(h.get_positions()[perm] - post.xyz).max() < 1e-12
+    # the force call on the new topology against the reference's Hamiltonian, adiabatic energy and force
+    e, F = h.ms_evb_calculate_total_force_energy()
+    st = h.evb_state()
+    D = int(g["n_diabat"][0])
+    assert st["D"] == D and st["principle_diabat"] == 1 and st["new_hydronium_molecule"] == post.hydronium + 1
+    assert np.abs(np.triu(st["H"]) - np.triu(g["evb_hamiltonian"])).max() < E_RTOL * np.abs(g["evb_hamiltonian"]).max()
+    assert rel(e, g["E_adiabatic"][0]) < E_RTOL
+    assert np.abs(F[perm] - g["F_adiabatic"]).max() < F_TOL
+    # ... and the steps after it (the reference read its velocities in ITS atom order)
+    vel = np.zeros_like(g["md_velocity0"])
+    vel[perm] = g["md_velocity0"]
+    h.set_velocities(vel)
+    n = int(g["md_nsteps"][0])
+    en = h.md_integrate_atomic(n, post.delta_t, use_evb=True)
+    assert np.abs(en[:, 0] - g["md_energy"][:, 0]).max() < 1e-9 * np.abs(g["md_energy"][:, 0]).max()
+    assert np.abs(en[:, 1] - g["md_energy"][:, 1]).max() < 1e-8 * np.abs(g["md_energy"][:, 1]).max()
+    assert h.topology()["hydronium_molecule"] == int(g["md_hydronium_molecule"][0])
+    assert np.abs(h.get_positions()[perm] - g["md_xyz"]).max() < 1e-10
+    assert np.abs(h.get_velocities()[perm] - g["md_velocity"]).max() < 1e-9
+    assert np.abs(h.get_forces()[perm] - g["md_force"]).max() < 1e-7
+    h.close()
+
+
+def test_rccl_communicator_of_one_rank():
+    """the real collective path (ncclAllGather of the Hamiltonian entries on the side stream, in-place ncclAllReduce of the forces on
+    the main stream) on a communicator of ONE rank: same force call, same trajectory as without a communicator"""
+    g = golden("evb_n6_d8_s1")
+    spec = system.from_golden(g)
+    vel = synth.maxwell_boltzmann(spec.mass, 300.0, 5)
+    out = []
+    for comm in (False, True):
+        h = api.MsEvbHip(spec)
+        if comm:
+            h.comm_init(api.MsEvbHip.comm_unique_id(h.L), 0, 1)
+        e, F = h.ms_evb_calculate_total_force_energy()
+        st = h.evb_state()
+        h.set_velocities(vel)
+        en = h.md_integrate_atomic(20, spec.delta_t, use_evb=True)
+        out.append((e, F, st["H"], en, h.get_positions()))
+        h.close()
+    (e0, F0, H0, en0, x0), (e1, F1, H1, en1, x1) = out
+    assert rel(e1, e0) < 1e-14 and np.abs(H1 - H0).max() < 1e-12 * np.abs(H0).max()
+    assert np.abs(F1 - F0).max() < 1e-10
+    assert np.abs(en1 - en0).max() < 1e-9 * np.abs(en0).max() and np.abs(x1 - x0).max() < 1e-10
 
 
 def _synthetic(n_side, n_diabat, seed, K, rc=9.0, rv=10.5):

@@ -5,7 +5,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import all_golden, golden
+from conftest import all_golden, golden, pre_switch_spec, reference_atom_order
 from reactive_pb_nn_md_amd import system
 
 TABLES = (("B6", "B6_spline"), ("B5", "B5_spline"), ("erfc", "erfc_table"), ("ewaldscale", "ewaldscale_table"),
@@ -113,3 +113,45 @@ def test_md_trajectory(oracle_lib, name, evb):
     assert np.abs(o.get_xyz() - g["md_xyz"]).max() < 1e-10
     assert np.abs(vel - g["md_velocity"]).max() < 1e-9
     assert np.abs(F - g["md_force"]).max() < 1e-7
+
+
+def test_principal_switch(oracle_lib):
+    """src/ms_evb.f90:218-227.  The fixture's reference run switched the principal diabat in its first EVB force call; starting
+    from the state before it, the oracle must arrive at the reference's topology (atom types, charges, molecule records, the
+    transferred proton made whole with its new molecule) and then follow its trajectory on the new topology."""
+    g = golden("md_evb_n6_d4_switch_s8")
+    post = system.from_golden(g)
+    pre = pre_switch_spec(g)
+    assert pre.hydronium != post.hydronium
+    o = oracle_lib.Oracle(pre)
+    o.verlet_build()
+    r = o.evb()
+    assert r["new_hydronium"] == post.hydronium and r["principal"] != 0
+    o.apply_principal()
+    t = o.topology()
+    perm = reference_atom_order(t)
+    assert sorted(perm) == list(range(pre.n_atom))
+    assert np.array_equal(t["mol_n_atom"], post.mol_natom) and np.array_equal(t["mol_type_index"], post.mol_type)
+    assert np.array_equal(t["atom_type_index"][perm], post.atype)
+    assert np.array_equal(t["charge"][perm], post.charge)
+    assert np.abs(o.get_xyz()[perm] - post.xyz).max() < 1e-12
+    # the force call on the new topology: the reference's Hamiltonian, adiabatic energy and force
+    r = o.evb()
+    D = int(g["n_diabat"][0])
+    assert r["D"] == D and r["new_hydronium"] == post.hydronium and r["principal"] == 0
+    assert np.abs(r["H"] - np.triu(g["evb_hamiltonian"])).max() < 1e-9 * np.abs(g["evb_hamiltonian"]).max()
+    assert abs(r["E"] - g["E_adiabatic"][0]) < 1e-10 * abs(r["E"])
+    assert np.abs(r["F"][perm] - g["F_adiabatic"]).max() < 1e-8
+    # ... and the steps after it (the reference read its velocities in ITS atom order)
+    vel = np.zeros_like(g["md_velocity0"])
+    vel[perm] = g["md_velocity0"]
+    F = r["F"].copy()
+    assert np.abs(F[perm] - g["md_F0"]).max() < 1e-8
+    for s in range(int(g["md_nsteps"][0])):
+        pe = o.md_step(vel, F, post.delta_t, True)
+        ke = o.kinetic_energy(vel)
+        assert abs(pe - g["md_energy"][s, 0]) < 1e-8 * abs(pe) and abs(ke - g["md_energy"][s, 1]) < 1e-8 * abs(ke)
+    assert int(g["md_hydronium_molecule"][0]) - 1 == post.hydronium      # no further switch inside the fixture
+    assert np.abs(o.get_xyz()[perm] - g["md_xyz"]).max() < 1e-10
+    assert np.abs(vel[perm] - g["md_velocity"]).max() < 1e-9
+    assert np.abs(F[perm] - g["md_force"]).max() < 1e-7

@@ -76,8 +76,8 @@ def cpu_baseline(spec):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n-side", type=int, default=32)
     ap.add_argument("--diabats", type=int, default=8)
     ap.add_argument("--pme-grid", type=int, default=64)

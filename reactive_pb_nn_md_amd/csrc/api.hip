@@ -106,6 +106,7 @@ int msevb_destroy(msevb_ctx* c) {
   c->d_sort_tmp.release(); c->d_posq.release(); c->d_grid.release(); c->d_fft_work.release();
   for (int p = 0; p < PH_COUNT; ++p) for (hipEvent_t e : c->ph[p].ev) (void)hipEventDestroy(e);
   if (c->h_energies) (void)hipHostFree(c->h_energies);
+  if (c->h_nbr_stats) (void)hipHostFree(c->h_nbr_stats);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return MSEVB_OK;
@@ -390,6 +391,7 @@ int msevb_update_verlet_displacements(msevb_ctx* c, int* flag) {
 
 int msevb_get_verlet_list(msevb_ctx* c, int* vp, int* nl, long* nn) {
   NEED_FINAL();
+  CHK(nb_settle(c));
   if (!c->list_valid) FAIL(MSEVB_ERR_STATE, "no Verlet list");
   const int N = c->N;
   std::vector<unsigned> st(N), cnt(N);
@@ -432,6 +434,7 @@ int msevb_zero_forces(msevb_ctx* c) { NEED_FINAL(); HIPCHK(hipMemsetAsync(c->d_f
 
 int msevb_real_space_energy_force(msevb_ctx* c, double* e) {
   NEED_FINAL();
+  CHK(nb_settle(c));
   if (!c->list_valid) CHK(nb_build(c)); else CHK(nb_refresh_sorted(c));
   CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
   CHK(molecule_forces(c, S_ELEC_INTRA, true, false));
@@ -459,6 +462,7 @@ int msevb_intra_molecular_energy_force(msevb_ctx* c, double* e) {
 int total_force_enqueue(msevb_ctx* c) {
   c->timing_now = c->timing && (c->timing_tick++ % c->timing_stride) == 0;
   // Verlet freshness: src/total_energy_forces.f90:30-39 (rebuild when the flag was raised by the previous call)
+  CHK(nb_settle(c));
   const bool rebuild = c->flag_verlet_list == 1 || !c->list_valid;
   if (rebuild) {      // cells + sorted arrays now; the rows are filled below, beside what only needs the cells
     CHK(nb_build_begin(c)); c->flag_verlet_list = 0;
@@ -470,14 +474,14 @@ int total_force_enqueue(msevb_ctx* c) {
     CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux2));      // aux2: per-molecule terms (few, long threads)
     CHK(pme_front(c, S_RECIP, true));                                // aux: stencils, spreading, FFTs, convolution
     if (rebuild) {                                                   // main: list rows (one host synchronisation) beside them, then the pair loop
-      CHK(nb_build_finish(c));
+      CHK(nb_build_finish(c, true));
       CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
     }
     CHK(pme_tail(c, true));                                          // main: wait for aux, gather (skipped by the EVB fast path)
     HIPCHK(hipEventRecord(c->ev_join2, c->aux2));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
   } else {
-    if (rebuild) CHK(nb_build_finish(c));
+    if (rebuild) CHK(nb_build_finish(c, true));
     CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
     CHK(molecule_forces(c, S_ELEC_INTRA, true, true));
     CHK(pme_forces(c, S_RECIP, false));
@@ -503,9 +507,11 @@ int total_force_collect(msevb_ctx* c, double* en) {
 
 int msevb_calculate_total_force_energy(msevb_ctx* c, double* energies, double* force) {
   NEED_FINAL();
-  CHK(total_force_enqueue(c));
-  if (force) HIPCHK(hipMemcpyAsync(force, c->d_force.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
-  CHK(fetch_energies(c));
+  do {      // repeated only when a list row outgrew its stride in a rebuild (the stride has grown by then)
+    CHK(total_force_enqueue(c));
+    if (force) HIPCHK(hipMemcpyAsync(force, c->d_force.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
+    CHK(fetch_energies(c));
+  } while (nb_check_overflow(c));
   double en[MSEVB_N_ENERGY];
   CHK(total_force_collect(c, en));
   if (energies) memcpy(energies, en, sizeof en);
@@ -563,6 +569,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
   if (s == "overlap") { c->overlap = v != 0.0; return MSEVB_OK; }
+  if (s == "nbr_cap") { if (v < 64.0) return MSEVB_ERR_ARG; c->nbr_cap = ((unsigned)v + 63u) & ~63u; c->list_valid = false; return MSEVB_OK; }      // row stride (tests: force the overflow path)
   if (s == "nbr_tiles") { c->nbr_tiles = v != 0.0; c->list_valid = false; return MSEVB_OK; }
   if (s == "graphs") { c->graphs = v != 0.0; return MSEVB_OK; }
   if (s == "evb_element_stores") { c->evb_element_stores = v != 0.0; return MSEVB_OK; }

@@ -217,6 +217,8 @@ struct msevb_ctx {
   size_t n_nbr = 0;
   unsigned nbr_cap = 0;          // row stride of the Verlet list (0: not sized yet)
   bool list_valid = false;
+  bool nbr_check_pending = false;      // a deferred rebuild's row statistics have not been looked at yet
+  int* h_nbr_stats = nullptr;          // pinned: {tile_max, pad, count_max, pad, count_sum lo, hi}
   int flag_verlet_list = 0;
   DBuf<double4> d_posq;        // sorted {x,y,z,q}
   DBuf<int> d_type_sorted, d_mol_sorted;
@@ -261,7 +263,10 @@ struct msevb_ctx {
 // ---- cross-file entry points (all enqueue on c->stream) ----------------------------------------------
 int nb_build(msevb_ctx* c);                        // neighbor.hip
 int nb_build_begin(msevb_ctx* c);     // cells + sorted arrays
-int nb_build_finish(msevb_ctx* c);    // rows (one host synchronisation)
+int nb_build_finish(msevb_ctx* c, bool defer);    // rows (one host synchronisation unless deferred)
+int nb_check_overflow(msevb_ctx* c);  // after a deferred finish
+int nb_settle(msevb_ctx* c);          // looks at statistics a failed call left behind
+constexpr int MSEVB_RETRY = 1000;     // internal: repeat the force call (never leaves the library)
 int nb_refresh_sorted(msevb_ctx* c);               // gather posq/type in sorted order
 extern "C" int msevb_comm_allreduce_forces(msevb_ctx* c);   // comm.hip
 void evb_release(msevb_ctx* c);        // evb.hip: per-context EVB scratch

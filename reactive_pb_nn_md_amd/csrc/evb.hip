@@ -917,7 +917,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   return MSEVB_OK;
 }
 
-int evb_force_energy(msevb_ctx* c, double* epot_out) {
+static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   static const bool ht_on = getenv("MSEVB_HOST_TIMING") != nullptr;
   double ht_last = ht_on ? now_us() : 0.0;
   auto HT = [&](int k) { if (ht_on) { const double t = now_us(); g_ht.t[k] += t - ht_last; ht_last = t; } };
@@ -1323,6 +1323,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   // E0 = potential energy of the principal diabat (fetch B); added to the diagonal and to the eigenvalue
   auto principal_energy = [&](double& E0) -> int {
     if (c->overlap) HIPCHK(hipEventSynchronize(w->ev_fetch)); else HIPCHK(hipStreamSynchronize(c->stream));
+    if (nb_check_overflow(c)) return MSEVB_RETRY;      // a list row outgrew its stride in this call's rebuild: the whole force call is repeated
     if (sharded && !energies_in && c->rank != 0) c->h_energies[S_RECIP] = 0.0;      // sharded principal diabat: replicated terms count once (rank 0)
     double en[MSEVB_N_ENERGY];
     CHK(total_force_collect(c, en));
@@ -1390,6 +1391,13 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
   rearm.ok = true;
   HT(11); g_ht.n++;
   return MSEVB_OK;
+}
+
+int evb_force_energy(msevb_ctx* c, double* epot_out) {
+  int rc = evb_force_energy_once(c, epot_out);
+  for (int k = 0; k < 3 && rc == MSEVB_RETRY; ++k) rc = evb_force_energy_once(c, epot_out);
+  if (rc == MSEVB_RETRY) FAIL(MSEVB_ERR_LIMIT, "Verlet list rows keep overflowing");
+  return rc;
 }
 
 // frees the per-context EVB scratch (called by msevb_destroy while the context's streams still exist)

@@ -134,7 +134,14 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
     phase_end(c, PH_INTEGRATE);
     double epot = 0.0;
     if (use_evb) { CHK(evb_force_energy(c, &epot)); }
-    else { CHK(total_force_enqueue(c)); }
+    else {
+      CHK(total_force_enqueue(c));
+      while (c->nbr_check_pending) {      // rebuild step: the half kick below must not run on forces from a list with a cut row
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!nb_check_overflow(c)) break;
+        CHK(total_force_enqueue(c));
+      }
+    }
     hipLaunchKernelGGL(k_step_second_half, dim3(nba), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p, c->d_partials.p);
     HIPCHK(hipGetLastError());
     CHK(reduce_partials(c, S_PX, nba)); CHK(reduce_partials(c, S_PY, nba)); CHK(reduce_partials(c, S_PZ, nba)); CHK(reduce_partials(c, S_KE, nba));

@@ -205,9 +205,12 @@ __global__ __launch_bounds__(1024) void k_neighbors_tiles(int3 nc, const int* __
 }
 
 // {max, sum} of the row counts -> out[0] (unsigned), out[1..2] (64-bit sum)
-__global__ void k_count_stats(int N, const unsigned* __restrict__ count, unsigned* __restrict__ out) {
+// row statistics {max, pad, sum (64 bit)}; rows longer than the stride (they were not written past it) are cut to it, so that a pair
+// loop enqueued before the host has seen the statistics stays inside its rows - the host then rebuilds with a larger stride
+__global__ void k_count_stats(int N, unsigned* __restrict__ count, unsigned cap, unsigned* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned v = i < N ? count[i] : 0u;
+  if (cap && v > cap) count[i] = cap;
   unsigned mx = v;
   unsigned long long sm = v;
   for (int o = 32; o > 0; o >>= 1) { mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64)); sm += (unsigned long long)__shfl_xor((long long)sm, o, 64); }
@@ -344,7 +347,7 @@ int nb_step_refresh(msevb_ctx* c) {
 // A (re)build in two halves so that the caller can start everything that only needs the CELL structure (PME spreading, per-molecule
 // terms) on the side streams while the rows are still being filled: nb_build_begin = cell sort + sorted arrays, nb_build_finish = rows
 // (+ the one host synchronisation of a build).  nb_build = both.
-int nb_build(msevb_ctx* c) { CHK(nb_build_begin(c)); return nb_build_finish(c); }
+int nb_build(msevb_ctx* c) { CHK(nb_build_begin(c)); return nb_build_finish(c, false); }
 
 int nb_build_begin(msevb_ctx* c) {
   const int N = c->N;
@@ -372,7 +375,9 @@ int nb_build_begin(msevb_ctx* c) {
   return MSEVB_OK;
 }
 
-int nb_build_finish(msevb_ctx* c) {
+// defer: the row statistics of a REbuild travel to pinned host memory without a synchronisation; the caller looks at them with
+// nb_check_overflow() once it has waited for something later on the stream, and repeats its force call in the (rare) overflow case.
+int nb_build_finish(msevb_ctx* c, bool defer) {
   const int N = c->N;
   const int3 nc = make_int3(c->ncell[0], c->ncell[1], c->ncell[2]);
   const int ncell = nc.x * nc.y * nc.z;
@@ -383,13 +388,15 @@ int nb_build_finish(msevb_ctx* c) {
   // tile size of the LDS-staged pair kernel + row statistics scratch: {tile_max, pad, count_max, pad, count_sum(64-bit)}
   if (c->d_tile_max.alloc(8)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (list statistics)");
   int* d_stats = c->d_tile_max.p;
-  int h_stats[8];
-  auto stats = [&](bool with_tile) -> int {       // one synchronisation per (re)build
+  if (!c->h_nbr_stats) HIPCHK(hipHostMalloc((void**)&c->h_nbr_stats, 8 * sizeof(int), hipHostMallocDefault));
+  int* h_stats = c->h_nbr_stats;
+  c->nbr_check_pending = false;
+  auto stats = [&](bool with_tile, bool sync = true) -> int {       // one synchronisation per (re)build, unless deferred
     HIPCHK(hipMemsetAsync(d_stats, 0, 8 * sizeof(int), c->stream));
     if (with_tile) hipLaunchKernelGGL(k_tile_max, dim3((ncell + 255) / 256), dim3(256), 0, c->stream, ncell, nc, c->d_cell_start.p, d_stats);
-    hipLaunchKernelGGL(k_count_stats, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, c->d_nbr_count.p, (unsigned*)d_stats + 2);
+    hipLaunchKernelGGL(k_count_stats, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, c->d_nbr_count.p, c->nbr_cap, (unsigned*)d_stats + 2);
     HIPCHK(hipMemcpyAsync(h_stats, d_stats, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (sync) HIPCHK(hipStreamSynchronize(c->stream));
     return MSEVB_OK;
   };
   auto fill = [&]() -> int {
@@ -430,16 +437,42 @@ int nb_build_finish(msevb_ctx* c) {
     if (c->pair_tiles_opt != 0) { CHK(stats(true)); decide_tiles(h_stats[0]); }    // the tile size fixes the entry format of this build
     else c->pair_tiles = false;
     CHK(fill());
-    CHK(stats(false));
-    if ((unsigned)h_stats[2] > c->nbr_cap) { set_cap((unsigned)h_stats[2]); CHK(fill()); CHK(stats(false)); }
+    if (defer) { CHK(stats(false, false)); c->nbr_check_pending = true; }
+    else {
+      CHK(stats(false));
+      if ((unsigned)h_stats[2] > c->nbr_cap) { set_cap((unsigned)h_stats[2]); CHK(fill()); CHK(stats(false)); }
+    }
   }
   if ((double)N * c->nbr_cap >= 4294967296.0) FAIL(MSEVB_ERR_LIMIT, "Verlet list exceeds 32-bit row offsets");
-  c->n_nbr = (size_t)(((unsigned long long)(unsigned)h_stats[5] << 32) | (unsigned)h_stats[4]);
+  if (!c->nbr_check_pending) c->n_nbr = (size_t)(((unsigned long long)(unsigned)h_stats[5] << 32) | (unsigned)h_stats[4]);
   HIPCHK(hipGetLastError());
   phase_end(c, PH_VERLET);
   c->list_valid = true;
   int flag;
   CHK(nb_check_displacements(c, 1, &flag));
+  return MSEVB_OK;
+}
+
+// After a deferred rebuild, once the host has waited for work enqueued behind it: 1 = a row overflowed its stride (the stride has been
+// enlarged, the list is marked stale, the caller repeats the force call), 0 = the list is complete.
+int nb_check_overflow(msevb_ctx* c) {
+  if (!c->nbr_check_pending) return 0;
+  c->nbr_check_pending = false;
+  const int* h = c->h_nbr_stats;
+  if ((unsigned)h[2] > c->nbr_cap) {
+    c->nbr_cap = ((unsigned)((unsigned)h[2] * 1.15) + 64u + 63u) & ~63u;
+    c->list_valid = false;
+    return 1;
+  }
+  c->n_nbr = (size_t)(((unsigned long long)(unsigned)h[5] << 32) | (unsigned)h[4]);
+  return 0;
+}
+
+// a deferred rebuild whose statistics nobody looked at (the call that made it failed before its end): look now
+int nb_settle(msevb_ctx* c) {
+  if (!c->nbr_check_pending) return MSEVB_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  (void)nb_check_overflow(c);      // on overflow the list is marked stale and the next use rebuilds it
   return MSEVB_OK;
 }
 

@@ -309,6 +309,35 @@ def test_principal_switch_against_reference():
     h.close()
 
 
+@pytest.mark.parametrize("evb", [False, True])
+def test_list_row_overflow_repeats_the_force_call(evb):
+    """a rebuild inside a force call does not wait for its row statistics; when a row outgrew the stride the call is repeated with
+    a larger one.  Forced here with a stride of 64 entries (rows hold ~240)"""
+    g = golden("evb_n6_d4_s2")
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    call = (lambda: h.ms_evb_calculate_total_force_energy()) if evb else (lambda: h.calculate_total_force_energy())
+    e0, F0 = call()
+    vp0, nl0 = h.get_verlet_list()
+    h.set_option("nbr_cap", 64)          # also marks the list stale: the next force call rebuilds it (deferred statistics)
+    e1, F1 = call()
+    vp1, nl1 = h.get_verlet_list()
+    assert np.array_equal(vp0, vp1) and np.array_equal(nl0, nl1)
+    assert np.abs(F1 - F0).max() < 1e-10
+    assert (rel(e1, e0) if evb else rel(e1["potential"], e0["potential"])) < 1e-13
+    if evb:      # ... and inside the MD loop
+        h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 3))
+        h.set_option("nbr_cap", 64)
+        en1 = h.md_integrate_atomic(5, spec.delta_t, use_evb=True)
+        h2 = api.MsEvbHip(spec)
+        h2.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 3))
+        h2.ms_evb_calculate_total_force_energy(want_force=False)
+        en2 = h2.md_integrate_atomic(5, spec.delta_t, use_evb=True)
+        assert np.abs(en1 - en2).max() < 1e-9 * np.abs(en2).max()
+        h2.close()
+    h.close()
+
+
 def test_rccl_communicator_of_one_rank():
     """the real collective path (ncclAllGather of the Hamiltonian entries on the side stream, in-place ncclAllReduce of the forces on
     the main stream) on a communicator of ONE rank: same force call, same trajectory as without a communicator"""

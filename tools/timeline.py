@@ -12,6 +12,11 @@ def short(n): return n.replace("(anonymous namespace)::", "").replace("void ", "
 # steps are delimited by k_evb_blend launches
 blend = [i for i, r in enumerate(rows) if "k_evb_blend" in r[0]]
 a, b = blend[-3], blend[-2]          # one full step between two blends (skip the last, possibly truncated)
+if len(sys.argv) > 2 and sys.argv[2] == "rebuild":      # the last complete step that rebuilt the Verlet list
+    for k in range(len(blend) - 2, 0, -1):
+        if any("k_neighbors" in r[0] for r in rows[blend[k - 1]:blend[k] + 1]):
+            a, b = blend[k - 1], blend[k]
+            break
 seg = rows[a:b + 1]
 t0 = seg[0][1]
 busy = 0; cur_end = seg[0][1]; gaps = []

@@ -470,13 +470,10 @@ int total_force_enqueue(msevb_ctx* c) {
   } else CHK(nb_step_refresh(c));
   if (c->overlap) {     // independent chains, all adding to the force with fp64 atomics
     HIPCHK(aux_fork(c));
-    if (!rebuild) CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));      // main: the pair loop (longest) goes out first
+    if (rebuild) CHK(nb_build_finish(c, true));                      // main: list rows first (the longest chain of a rebuild step: rows, then the pair loop)
+    CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));                    // main: the pair loop (longest) goes out first
     CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux2));      // aux2: per-molecule terms (few, long threads)
     CHK(pme_front(c, S_RECIP, true));                                // aux: stencils, spreading, FFTs, convolution
-    if (rebuild) {                                                   // main: list rows (one host synchronisation) beside them, then the pair loop
-      CHK(nb_build_finish(c, true));
-      CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
-    }
     CHK(pme_tail(c, true));                                          // main: wait for aux, gather (skipped by the EVB fast path)
     HIPCHK(hipEventRecord(c->ev_join2, c->aux2));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));

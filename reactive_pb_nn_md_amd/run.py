@@ -1,0 +1,129 @@
+"""Command-line mirror of the reference's main program (src/main_ms_evb.f90:16-125) on the MI355X library:
+
+    python -m reactive_pb_nn_md_amd.run  sys.gro  ff.pmt  sys.top  sim.pmt  traj_out.gro  log_out  [hop_out]  [a_out]
+                                         [--evb yes|no] [--seed N] [--velocity-checkpoint FILE --checkpoint-every N] [--device D]
+
+Same eight positional files as the reference (src/general_routines.f90:20-27).  Like the reference it refuses to overwrite
+its outputs (they are opened status='new', :49-50) and, when trajectory + log + velocity checkpoint all exist, continues the
+old trajectory from the checkpoint's last frame.  Differences, deliberately: `--evb` replaces the reference's compile-time
+switch ms_evb_simulation (src/glob_v.f90:45; default: yes when the topology has [ evb_pairs ]); the Maxwell-Boltzmann
+velocities come from a seeded generator (the reference seeds from the clock, src/general_routines.f90:726); only the NVE
+ensemble runs (out of scope: Langevin / MC barostat).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+
+from . import api, io, synth
+
+
+def _mol_atoms(topo):
+    return [list(topo["mol_atom_index"][m, :topo["mol_n_atom"][m]] - 1) for m in range(len(topo["mol_n_atom"]))]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m reactive_pb_nn_md_amd.run", description=__doc__.split("\n\n")[0])
+    for name in ("gro", "ffpmt", "top", "simpmt", "traj_out", "log_out"):
+        ap.add_argument(name)
+    ap.add_argument("hop_out", nargs="?", default=None)
+    ap.add_argument("a_out", nargs="?", default=None)
+    ap.add_argument("--evb", choices=("yes", "no"), default=None)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--velocity-checkpoint", default="velocity_checkpoint")
+    ap.add_argument("--checkpoint-every", type=int, default=0, help="steps between velocity checkpoints (0 = none; the reference: checkpoint_velocity / n_step_velocity)")
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+
+    # restart logic of check_restart_trajectory (src/general_routines.f90:60-140): trajectory, log and velocity checkpoint all present
+    # -> continue from the trajectory's last frame (its molecule membership included: protons may have moved) and the checkpoint
+    have = [os.path.exists(p) for p in (a.traj_out, a.log_out, a.velocity_checkpoint)]
+    restart = all(have)
+    if not restart and (have[0] or have[1]):
+        raise SystemExit("output file exists (the reference opens its outputs with status='new'): %s" % (a.traj_out if have[0] else a.log_out))
+    spec, gro, ff, strings, numbers = io.load_inputs(a.traj_out if restart else a.gro, a.ffpmt, a.top, a.simpmt, frame=-1 if restart else 0)
+    if strings["ensemble"] != "NVE":
+        raise SystemExit("ensemble %s: only NVE is built (md_integrate_atomic's NVE branch, src/md_integration.f90:469-486)" % strings["ensemble"])
+    use_evb = (a.evb == "yes") if a.evb else bool(ff.evb_pairs)
+    n_step, n_output, dt = int(numbers["n_step"]), int(numbers["n_output"]), float(numbers["delta_t"])
+
+    n_old = 0
+    vel = None
+    if restart:
+        n_old = int(gro.title.split()[1])
+        n_ck, vel = io.read_velocity_checkpoint(a.velocity_checkpoint, spec.n_atom, step=n_old)
+
+    h = api.MsEvbHip(spec, device=a.device)
+    atom_names = list(gro.atom_names)
+    mol_type_names = list(spec.params.moltype_names)
+
+    def names_now():
+        t = h.topology()
+        return t, [mol_type_names[k - 1] for k in t["mol_type_index"]], [spec.params.atype_names[k - 1] for k in t["atom_type_index"]]
+
+    traj = open(a.traj_out, "a" if restart else "x")
+    log = open(a.log_out, "a" if restart else "x")
+    hop = open(a.hop_out, "a" if restart else "x") if (a.hop_out and use_evb) else None
+    ckpt = open(a.velocity_checkpoint, "a") if a.checkpoint_every > 0 else None
+
+    def force_call():
+        if use_evb:
+            e, _ = h.ms_evb_calculate_total_force_energy(want_force=False)
+            return e, None
+        en, _ = h.calculate_total_force_energy(want_force=False)
+        return en["potential"], (en["elec"], en["vdw"], en["bond"], en["angle"], en["dihedral"])
+
+    def print_step(i_step, e_pot, e_kin, terms):
+        t, mnames, anames = names_now()
+        io.write_gro_frame(traj, "step  %d time(ps) %r" % (i_step, i_step * dt), mnames, _mol_atoms(t), anames, h.get_positions(), spec.box)
+        io.write_log_step(log, i_step, dt, e_pot, e_kin, terms)
+        traj.flush()
+        log.flush()
+
+    e_pot, terms = force_call()
+    if not restart:
+        log.write(" real_space_cutoff %r verlet_cutoff %r alpha_sqrt %r pme_grid %d delta_t %r n_atom %d\n" % (spec.rc, spec.rv, spec.alpha, spec.pme_grid, dt, spec.n_atom))
+        vel = synth.maxwell_boltzmann(spec.mass, float(numbers["temperature"]), a.seed)
+    h.set_velocities(vel)
+    e_kin = h.calculate_kinetic_energy()
+    if not restart:
+        print_step(0, e_pot, e_kin, terms)
+    hyd = h.topology()["hydronium_molecule"] if use_evb else 0
+    done = 0
+    total = n_step - n_old
+    block = max(1, n_output)
+    if a.checkpoint_every > 0:
+        block = np.gcd(block, a.checkpoint_every)
+    while done < total:
+        nb = int(min(block, total - done))
+        en = h.md_integrate_atomic(nb, dt, use_evb=use_evb)
+        done += nb
+        step = n_old + done
+        if use_evb:
+            new_hyd = h.topology()["hydronium_molecule"]
+            if hop is not None and new_hyd != hyd:
+                hop.write(" step %d  proton transfer: hydronium molecule %d -> %d\n" % (step, hyd, new_hyd))
+                hop.flush()
+            hyd = new_hyd
+        if done % max(1, n_output) == 0:
+            t5 = None
+            if not use_evb:
+                e5 = h.calculate_total_force_energy(want_force=False)[0]
+                t5 = (e5["elec"], e5["vdw"], e5["bond"], e5["angle"], e5["dihedral"])
+            print_step(step, en[-1, 0], h.calculate_kinetic_energy(), t5)
+        if ckpt is not None and done % a.checkpoint_every == 0:
+            t, mnames, anames = names_now()
+            io.write_velocity_checkpoint(ckpt, step, mnames, _mol_atoms(t), anames, h.get_velocities())
+            ckpt.flush()
+    for f in (traj, log, hop, ckpt):
+        if f is not None:
+            f.close()
+    h.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

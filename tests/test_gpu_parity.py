@@ -6,6 +6,7 @@ Tolerances (fp64 path; the GPU sums in a different order and uses reciprocal mul
   integer work (Verlet pair set, PME grid / table indices) bit-exact.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -336,6 +337,50 @@ def test_list_row_overflow_repeats_the_force_call(evb):
         assert np.abs(en1 - en2).max() < 1e-9 * np.abs(en2).max()
         h2.close()
     h.close()
+
+
+def test_command_line_run_and_restart(tmp_path):
+    """python -m reactive_pb_nn_md_amd.run on the reference's four input files: trajectory / log / checkpoint in the reference's
+    formats, the energies of the library call by call, a refused overwrite, and a restart that continues the step numbering"""
+    import ref_inputs
+    from reactive_pb_nn_md_amd import io, run
+    ff = forcefield.ch3so3h_water_forcefield()
+    s = synth.make_system(6, n_diabat=2, seed=5)
+    d = str(tmp_path)
+    ref_inputs.write_gro(d + "/sys.gro", s)
+    ref_inputs.write_ffpmt(d + "/ff.pmt", ff)
+    ref_inputs.write_top(d + "/sys.top", ff)
+    ref_inputs.write_simpmt(d + "/sim.pmt", n_step=8, rc=7.0, rv=8.0, nslist=16, pme_grid=16)
+    txt = open(d + "/sim.pmt").read().replace("n_output 1000000", "n_output 4")
+    open(d + "/sim.pmt", "w").write(txt)
+    args = [d + "/sys.gro", d + "/ff.pmt", d + "/sys.top", d + "/sim.pmt", d + "/traj.gro", d + "/run.log", d + "/hop.out", d + "/a.out",
+            "--seed", "11", "--velocity-checkpoint", d + "/vel", "--checkpoint-every", "4"]
+    assert run.main(args) == 0
+    log = [ln.split() for ln in open(d + "/run.log") if len(ln.split()) == 4 and ln.split()[0].isdigit()]
+    assert [int(r[0]) for r in log] == [0, 4, 8]
+    # the same run through the API
+    spec = io.load_inputs(d + "/sys.gro", d + "/ff.pmt", d + "/sys.top", d + "/sim.pmt")[0]
+    h = api.MsEvbHip(spec)
+    e0, _ = h.ms_evb_calculate_total_force_energy(want_force=False)
+    h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 11))
+    en = h.md_integrate_atomic(8, spec.delta_t, use_evb=True)
+    assert rel(float(log[0][2]), e0) < 1e-6 and rel(float(log[1][2]), en[3, 0]) < 1e-6 and rel(float(log[2][2]), en[7, 0]) < 1e-6
+    assert rel(float(log[2][3]), en[7, 1]) < 1e-6
+    last = io.read_gro(d + "/traj.gro", -1)
+    assert last.title.split()[1] == "8" and np.abs(last.xyz - h.get_positions()).max() < 6e-3      # F8.3 nm
+    st, v = io.read_velocity_checkpoint(d + "/vel", spec.n_atom)
+    assert st == 8 and np.abs(v - h.get_velocities()).max() < 1e-6
+    h.close()
+    # outputs exist and the checkpoint too -> restart: four more steps appended, numbered 12
+    open(d + "/sim.pmt", "w").write(txt.replace("n_step 8", "n_step 12"))
+    assert run.main(args) == 0
+    log = [ln.split() for ln in open(d + "/run.log") if len(ln.split()) == 4 and ln.split()[0].isdigit()]
+    assert [int(r[0]) for r in log] == [0, 4, 8, 12]
+    assert io.read_gro(d + "/traj.gro", -1).title.split()[1] == "12"
+    # without the checkpoint the existing outputs are not overwritten
+    os.remove(d + "/vel")
+    with pytest.raises(SystemExit, match="output file exists"):
+        run.main(args)
 
 
 def test_rccl_communicator_of_one_rank():

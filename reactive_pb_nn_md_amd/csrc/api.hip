@@ -565,6 +565,10 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "phase_timing_stride") { c->timing_stride = v < 1.0 ? 1 : (int)v; return MSEVB_OK; }
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
+  if (s == "ensemble_nvt") { c->nvt = v != 0.0; return MSEVB_OK; }
+  if (s == "friction_coeff") { if (!(v > 0.0)) return MSEVB_ERR_ARG; c->friction = v; return MSEVB_OK; }
+  if (s == "temperature") { if (!(v >= 0.0)) return MSEVB_ERR_ARG; c->temperature = v; return MSEVB_OK; }
+  if (s == "langevin_seed") { c->langevin_seed = (unsigned long long)v; c->langevin_tick = 0; return MSEVB_OK; }
   if (s == "overlap") { c->overlap = v != 0.0; return MSEVB_OK; }
   if (s == "nbr_cap") { if (v < 64.0) return MSEVB_ERR_ARG; c->nbr_cap = ((unsigned)v + 63u) & ~63u; c->list_valid = false; return MSEVB_OK; }      // row stride (tests: force the overflow path)
   if (s == "nbr_tiles") { c->nbr_tiles = v != 0.0; c->list_valid = false; return MSEVB_OK; }

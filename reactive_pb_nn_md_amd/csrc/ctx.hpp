@@ -258,6 +258,8 @@ struct msevb_ctx {
   bool timing = true;
   // phase events are SAMPLED: one force call in timing_stride records them (every record costs ~2 us of host time, 25 per step)
   bool timing_now = false; int timing_stride = 8; long timing_tick = 0;
+  // NVT: Langevin leap-frog kicks (langevin_integrator, src/md_integration.f90:186-228) instead of the plain half kicks
+  bool nvt = false; double friction = 0.1 /* 1/ps, the reference's default */, temperature = 300.0; unsigned long long langevin_seed = 0, langevin_tick = 0;
 };
 
 // ---- cross-file entry points (all enqueue on c->stream) ----------------------------------------------

@@ -2,10 +2,36 @@
 // half kick + drift (:469-486), molecule COM update and wrap into the box (update_r_com src/general_routines.f90:420,
 // shift_molecules_into_box :1145), force call, second half kick with the |F| > 1e5 guard (:508-529), removal of the
 // centre-of-mass momentum (:125-177) and calculate_kinetic_energy (src/total_energy_forces.f90:106).
+// NVT (option ensemble_nvt): both kicks become the reference's Langevin leap-frog update (langevin_integrator, :186-228)
+//     v <- a v + (1 - a)/gamma * F/m * 100 + sqrt(2 kB T gamma 1000) / sqrt(m/1000) / 100 * sqrt((1 - a^2)/(2 gamma)) * N(0,1),   a = exp(-gamma dt/2)
+// with three fresh normal deviates per atom and kick.  The reference draws them with random_number() seeded from the clock
+// (src/general_routines.f90:726), so its stream cannot be reproduced; ours is counter based - Philox4x32-10 keyed by the seed, counter
+// (atom, kick number) - so a trajectory depends on the seed only, not on launch geometry, and the host can restate it (langevin.py).
 #include "ctx.hpp"
 
 
 namespace {
+
+struct Langevin { int on; double a, b, c; unsigned k0, k1; unsigned long long kick; };      // b = (1-a)/gamma*100, c = noise amplitude * sqrt(1000)/100: times 1/sqrt(m)
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// three standard normal deviates for (atom, kick): Box-Muller on 32-bit uniforms in (0,1]
+__device__ __forceinline__ void normal3(const Langevin& L, int atom, double z[3]) {
+  unsigned r[4];
+  philox4x32_10((unsigned)atom, (unsigned)L.kick, (unsigned)(L.kick >> 32), 0u, L.k0, L.k1, r);
+  const double u0 = ((double)r[0] + 1.0) * (1.0 / 4294967296.0), u1 = (double)r[1] * (1.0 / 4294967296.0);
+  const double u2 = ((double)r[2] + 1.0) * (1.0 / 4294967296.0), u3 = (double)r[3] * (1.0 / 4294967296.0);
+  const double ra = sqrt(-2.0 * log(u0)), rb = sqrt(-2.0 * log(u2));
+  z[0] = ra * cos(6.283185307179586 * u1); z[1] = ra * sin(6.283185307179586 * u1); z[2] = rb * cos(6.283185307179586 * u3);
+}
 
 // per-block partial sums of momentum (3) and kinetic energy
 __global__ __launch_bounds__(256) void k_momentum_ke(int N, const double* __restrict__ mass, const double* __restrict__ v, double* __restrict__ part) {
@@ -30,7 +56,7 @@ __global__ void k_remove_momentum(int N, const double* __restrict__ mass, const 
 // half kick + drift of the molecule's atoms (:469-486), then the molecule is shifted back into the box by its centre of mass
 __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt, int remove, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms,
                                                          const double* __restrict__ mass, const double* __restrict__ F, const double* __restrict__ en,
-                                                         double* __restrict__ v, double* __restrict__ x, BoxDev box) {
+                                                         double* __restrict__ v, double* __restrict__ x, BoxDev box, Langevin L) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   const int n = mol_natom[m];
@@ -38,10 +64,13 @@ __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt
   for (int k = 0; k < n; ++k) {
     const int a = mol_atoms[m * MAX_MOL_ATOMS + k];
     const double ma = mass[a];
+    double z[3] = {0, 0, 0};
+    if (L.on) normal3(L, a, z);
     for (int d = 0; d < 3; ++d) {
       double vv = v[3 * a + d];
       if (remove) vv -= en[S_PX + d] / (double)N / ma;
-      vv = vv + dt / 2.0 / ma * F[3 * a + d] * 100.0;
+      if (L.on) vv = L.a * vv + L.b * F[3 * a + d] / ma + L.c / sqrt(ma) * z[d];
+      else vv = vv + dt / 2.0 / ma * F[3 * a + d] * 100.0;
       v[3 * a + d] = vv;
       const double xx = x[3 * a + d] + vv * dt;
       x[3 * a + d] = xx;
@@ -56,15 +85,17 @@ __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt
 // second half: one thread per atom - half kick with the |F| > 1e5 guard (:508-529) and the per-block partial sums of momentum and
 // kinetic energy of the kicked velocities (calculate_kinetic_energy, src/total_energy_forces.f90:106)
 __global__ __launch_bounds__(256) void k_step_second_half(int N, double dt, const double* __restrict__ mass, const double* __restrict__ F, double* __restrict__ v,
-                                                          int* __restrict__ bad, double* __restrict__ part) {
+                                                          int* __restrict__ bad, double* __restrict__ part, Langevin L) {
   __shared__ double red[7][256];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double p[7] = {0, 0, 0, 0, 0, 0, 0};
   if (i < N) {
     const double m = mass[i];
+    double z[3] = {0, 0, 0};
+    if (L.on) normal3(L, i, z);
     for (int d = 0; d < 3; ++d) {
       const double f = F[3 * i + d];
-      const double vv = v[3 * i + d] + dt / 2.0 / m * f * 100.0;
+      const double vv = L.on ? L.a * v[3 * i + d] + L.b * f / m + L.c / sqrt(m) * z[d] : v[3 * i + d] + dt / 2.0 / m * f * 100.0;
       v[3 * i + d] = vv;
       if (fabs(f) > 10e4) atomicExch(bad, i + 1);
       p[d] = m * vv; p[3] += 0.5 * m * vv * vv / 100.0; p[4 + d] = vv;
@@ -127,10 +158,18 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
   double inv_mass_sum = 0.0;
   for (int a = 0; a < N; ++a) inv_mass_sum += 1.0 / c->h_mass[a];
   const int nbm = (M + 255) / 256, nba = (N + 255) / 256;
+  Langevin L{};
+  if (c->nvt) {      // constants of langevin_integrator (src/md_integration.f90:225): the 1/sqrt(m) stays in the kernel
+    const double g = c->friction, a = exp(-g * dt / 2.0);
+    L.on = 1; L.a = a; L.b = (1.0 - a) / g * 100.0;
+    L.c = sqrt(2.0 * 0.008314462 * c->temperature * g * 1000.0) * sqrt(1000.0) / 100.0 * sqrt((1.0 - exp(-g * dt)) / (2.0 * g));
+    L.k0 = (unsigned)c->langevin_seed; L.k1 = (unsigned)(c->langevin_seed >> 32);
+  }
   for (int s = 0; s < n_steps; ++s) {
     phase_begin(c, PH_INTEGRATE);
+    L.kick = c->langevin_tick++;
     hipLaunchKernelGGL(k_step_first_half, dim3(nbm), dim3(256), 0, c->stream, M, N, dt, s > 0 ? 1 : 0, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_mass.p, c->d_force.p,
-                       c->d_energies.p, c->d_vel.p, c->d_xyz.p, box);
+                       c->d_energies.p, c->d_vel.p, c->d_xyz.p, box, L);
     phase_end(c, PH_INTEGRATE);
     double epot = 0.0;
     if (use_evb) { CHK(evb_force_energy(c, &epot)); }
@@ -142,7 +181,8 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
         CHK(total_force_enqueue(c));
       }
     }
-    hipLaunchKernelGGL(k_step_second_half, dim3(nba), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p, c->d_partials.p);
+    L.kick = c->langevin_tick++;
+    hipLaunchKernelGGL(k_step_second_half, dim3(nba), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p, c->d_partials.p, L);
     HIPCHK(hipGetLastError());
     CHK(reduce_partials(c, S_PX, nba)); CHK(reduce_partials(c, S_PY, nba)); CHK(reduce_partials(c, S_PZ, nba)); CHK(reduce_partials(c, S_KE, nba));
     CHK(reduce_partials(c, S_VX, nba)); CHK(reduce_partials(c, S_VY, nba)); CHK(reduce_partials(c, S_VZ, nba));

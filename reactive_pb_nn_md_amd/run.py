@@ -7,8 +7,8 @@ Same eight positional files as the reference (src/general_routines.f90:20-27).  
 its outputs (they are opened status='new', :49-50) and, when trajectory + log + velocity checkpoint all exist, continues the
 old trajectory from the checkpoint's last frame.  Differences, deliberately: `--evb` replaces the reference's compile-time
 switch ms_evb_simulation (src/glob_v.f90:45; default: yes when the topology has [ evb_pairs ]); the Maxwell-Boltzmann
-velocities come from a seeded generator (the reference seeds from the clock, src/general_routines.f90:726); only the NVE
-ensemble runs (out of scope: Langevin / MC barostat).
+velocities and the Langevin noise come from seeded generators (the reference seeds from the clock, src/general_routines.f90:726);
+ensembles NVE and NVT (Langevin leap-frog) run, NPT (Monte-Carlo barostat) does not.
 """
 from __future__ import annotations
 
@@ -45,8 +45,8 @@ def main(argv=None):
     if not restart and (have[0] or have[1]):
         raise SystemExit("output file exists (the reference opens its outputs with status='new'): %s" % (a.traj_out if have[0] else a.log_out))
     spec, gro, ff, strings, numbers = io.load_inputs(a.traj_out if restart else a.gro, a.ffpmt, a.top, a.simpmt, frame=-1 if restart else 0)
-    if strings["ensemble"] != "NVE":
-        raise SystemExit("ensemble %s: only NVE is built (md_integrate_atomic's NVE branch, src/md_integration.f90:469-486)" % strings["ensemble"])
+    if strings["ensemble"] not in ("NVE", "NVT"):
+        raise SystemExit("ensemble %s: NVE and NVT (Langevin) are built; the Monte-Carlo barostat is not" % strings["ensemble"])
     use_evb = (a.evb == "yes") if a.evb else bool(ff.evb_pairs)
     n_step, n_output, dt = int(numbers["n_step"]), int(numbers["n_output"]), float(numbers["delta_t"])
 
@@ -57,6 +57,9 @@ def main(argv=None):
         n_ck, vel = io.read_velocity_checkpoint(a.velocity_checkpoint, spec.n_atom, step=n_old)
 
     h = api.MsEvbHip(spec, device=a.device)
+    if strings["ensemble"] == "NVT":      # Langevin leap-frog kicks (src/md_integration.f90:186-228); friction default of :203-204
+        for k, v in (("ensemble_nvt", 1), ("friction_coeff", numbers.get("friction_coeff", 0.1)), ("temperature", numbers["temperature"]), ("langevin_seed", a.seed)):
+            h.set_option(k, float(v))
     atom_names = list(gro.atom_names)
     mol_type_names = list(spec.params.moltype_names)
 

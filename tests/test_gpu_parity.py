@@ -339,6 +339,62 @@ def test_list_row_overflow_repeats_the_force_call(evb):
     h.close()
 
 
+@pytest.mark.parametrize("evb", [False, True])
+def test_langevin_step_against_host_restatement(evb):
+    """NVT: both kicks of a step follow langevin_integrator (src/md_integration.f90:186-228) with the library's counter-based
+    normal deviates, which reactive_pb_nn_md_amd/langevin.py restates; x1 = x0 + v1 dt, then the centre-of-mass momentum goes"""
+    from reactive_pb_nn_md_amd import langevin
+    g = golden("evb_n6_d2_s1")
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    gam, T, seed, dt = 5.0, 320.0, 12345678901, spec.delta_t
+    for k, v in (("ensemble_nvt", 1), ("friction_coeff", gam), ("temperature", T), ("langevin_seed", seed)):
+        h.set_option(k, v)
+    v0 = synth.maxwell_boltzmann(spec.mass, 300.0, 4)
+    h.set_velocities(v0)
+    F0 = (h.ms_evb_calculate_total_force_energy() if evb else h.calculate_total_force_energy())[1]
+    x0 = h.get_positions()
+    h.md_integrate_atomic(1, dt, use_evb=evb)
+    v1 = langevin.kick(v0, F0, spec.mass, dt, gam, T, langevin.normals(spec.n_atom, 0, seed))
+    x1 = x0 + v1 * dt
+    xg = h.get_positions()
+    d = xg - x1
+    assert np.abs(d - spec.box * np.round(d / spec.box)).max() < 1e-12      # molecules may have been shifted back into the box
+    F1 = h.get_forces()
+    v2 = langevin.kick(v1, F1, spec.mass, dt, gam, T, langevin.normals(spec.n_atom, 1, seed))
+    v2 -= (spec.mass[:, None] * v2).sum(0) / spec.n_atom / spec.mass[:, None]      # every atom gives up P/N (src/md_integration.f90:125-177)
+    assert np.abs(h.get_velocities() - v2).max() < 1e-10
+    # the deviates are standard normal and differ from kick to kick
+    z = np.concatenate([langevin.normals(spec.n_atom, k, seed) for k in range(40)])
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02 and abs((z ** 4).mean() - 3.0) < 0.15
+    h.close()
+
+
+def test_langevin_thermostat_reaches_its_temperature():
+    """strong friction on an (initially much too hot) lattice of water: the kinetic temperature settles at the thermostat's.
+    Water only - the example force field's acid proton carries no repulsion outside the EVB terms and collapses onto a water
+    oxygen after a few hundred steps of plain MD, thermostat or not"""
+    import dataclasses
+    s = synth.make_system(6, n_diabat=1, seed=3)
+    a0, a1 = s.mol_first[s.hydronium], s.mol_first[s.hydronium] + s.mol_natom[s.hydronium]
+    keep = np.r_[0:a0, a1:s.n_atom]
+    natom = np.delete(s.mol_natom, s.hydronium)
+    s = dataclasses.replace(s, xyz=s.xyz[keep], atom_names=[s.atom_names[k] for k in keep], mol_names=[m for i, m in enumerate(s.mol_names) if i != s.hydronium],
+                            mol_natom=natom, mol_first=np.concatenate([[0], np.cumsum(natom)[:-1]]).astype(np.int32), hydronium=-1)
+    p = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"])
+    spec = system.from_synth(s, p, rc=7.0, rv=8.0, pme_grid=16, nslist=16)
+    h = api.MsEvbHip(spec)
+    for k, v in (("ensemble_nvt", 1), ("friction_coeff", 100.0), ("temperature", 300.0), ("langevin_seed", 7)):
+        h.set_option(k, v)
+    h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 4))
+    h.calculate_total_force_energy(want_force=False)
+    h.md_integrate_atomic(400, spec.delta_t)
+    en = h.md_integrate_atomic(2000, spec.delta_t)
+    Tk = 2.0 * en[:, 1] / ((3 * spec.n_atom - 3) * 0.008314462)
+    assert abs(Tk.mean() - 300.0) < 20.0, Tk.mean()
+    h.close()
+
+
 def test_command_line_run_and_restart(tmp_path):
     """python -m reactive_pb_nn_md_amd.run on the reference's four input files: trajectory / log / checkpoint in the reference's
     formats, the energies of the library call by call, a refused overwrite, and a restart that continues the step numbering"""

@@ -100,7 +100,9 @@ constexpr unsigned NBR_IDX_MASK = (1u << NBR_IDX_BITS) - 1u;
 // of the owning atom's cell (cell_neighbourhood order) - exactly the layout of the LDS tile the pair kernel stages per cell.
 constexpr int PAIR_TILE_LDS_BYTES = 144 * 1024;      // of the 160 KiB per CU; the rest holds the pair-parameter table and reductions
 constexpr int PAIR_TILE_MIN_CELLS = 128;
-constexpr int NBR_TILE_CAP = 5400;                   // atoms of a cell neighbourhood staged in LDS by the list build (28 B each: 148 KB)
+constexpr int NBR_TILE_CAP = 8000;                   // most atoms of a cell neighbourhood the list build can stage in LDS
+constexpr int NBR_TILE_CAP2 = 4032;                  // ... while two workgroups still fit a CU (2 x (4032 x 20 B + 0.9 KB static) <= 160 KB)
+constexpr int NBR_TILE_BYTES = 20;                   // per staged atom: float4 {x,y,z,molecule} + the entry word
 constexpr int NBR_TILE_MIN_CELLS = 64;               // below this many cells the wave-per-atom build fills the chip better             // fewer cells than this cannot fill the chip with one block per cell
 
 // host mirror of a molecule type (as set through the ABI)

@@ -106,24 +106,43 @@ __global__ __launch_bounds__(256) void k_neighbors(int N, const double4* __restr
   if (lane == 0) { count[i] = total; if (FILL) start[i] = base; }
 }
 
-// LDS-staged list build: ONE WORKGROUP PER CELL.  {x,y,z} and the molecule index of the cell's whole neighbourhood (its <= 27 neighbour
-// cells) are staged once in LDS; the 16 wavefronts take the cell's atoms round-robin and scan the tile 64 candidates per trip with
-// conflict-free LDS reads instead of global loads, and without the per-candidate minimum-image arithmetic (see the staging loop): the
-// wave-per-atom kernel above spends 0.95 ms per rebuild at 98 k atoms on fp64 floor()s.  Same traversal order and, through the tie-zone
-// re-evaluation below, the same decisions => the same rows.  A neighbourhood that does not fit the LDS tile (tile_cap atoms)
-// is scanned from global memory by the same loop.
+// LDS-staged list build: ONE WORKGROUP PER CELL.  The cell's whole neighbourhood (its <= 27 neighbour cells, ~3 600 atoms at liquid
+// density) is staged once in LDS as {x, y, z (fp32, relative to the cell centre, moved to the periodic image next to this cell), molecule}
+// + the finished list entry word; the 16 wavefronts take the cell's atoms round-robin and scan the tile 64 candidates per trip.
+// The scan is a SINGLE-PRECISION pre-filter: |r2_f32 - rv2| >= 1e-3 rv2 decides (the fp32 error of r2 is < 3e-4 A^2 for coordinates
+// < 20 A); the ~1 candidate per atom inside that band is decided in fp64 exactly as the wave-per-atom kernel does, including the
+// tie-zone re-evaluation with the reference's own arithmetic (coordinates read from a .gro are multiples of 0.01 A: exact ties occur).
+// Same traversal order, same decisions => the same rows.  20 B per tile atom: two workgroups share a CU.  A neighbourhood that does
+// not fit the tile (tile_cap atoms) is scanned from global memory by the same loop.  (The fp64 version of this scan cost 0.83 ms per
+// rebuild at 98 k atoms, the wave-per-atom kernel with its per-candidate floor()s 0.95 ms.)
+__device__ __forceinline__ bool nbr_decide_fp64(const double4& pr, double xi, double yi, double zi, const double4& q, double shx, double shy, double shz,
+                                                const BoxDev& box, double rv2) {
+  const double xj = (q.x - box.L[0] * floor(q.x * box.invL[0])) + shx, yj = (q.y - box.L[1] * floor(q.y * box.invL[1])) + shy, zj = (q.z - box.L[2] * floor(q.z * box.invL[2])) + shz;
+  const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
+  const double r2 = dx * dx + dy * dy + dz * dz;
+  bool hit = r2 < rv2;
+  if (fabs(r2 - rv2) < 1e-9 * rv2) {      // tie zone: decide with the reference's arithmetic on the raw coordinates
+    double ex = pr.x - q.x, ey = pr.y - q.y, ez = pr.z - q.z;
+    ex -= box.L[0] * floor(ex * box.invL[0] + 0.5);
+    ey -= box.L[1] * floor(ey * box.invL[1] + 0.5);
+    ez -= box.L[2] * floor(ez * box.invL[2] + 0.5);
+    hit = (ex * ex + ey * ey + ez * ez) < rv2;
+  }
+  return hit;
+}
+
 template <bool LOCAL>
-__global__ __launch_bounds__(1024) void k_neighbors_tiles(int3 nc, const int* __restrict__ cell_start, const double4* __restrict__ posq, const int* __restrict__ mol_s,
-                                                          const int* __restrict__ type_s, BoxDev box, double rv2, unsigned cap, int tile_cap,      // molecule index < 2^23
+__global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int* __restrict__ cell_start, const double4* __restrict__ posq, const int* __restrict__ mol_s,
+                                                          const int* __restrict__ type_s, BoxDev box, double rv2, unsigned cap, int tile_cap,
                                                           unsigned* __restrict__ count, unsigned* __restrict__ start, int* __restrict__ nbr) {
-  extern __shared__ double tdata[];                       // x[tile_cap], y[tile_cap], z[tile_cap], then int (mol << 8 | type)[tile_cap]
+  extern __shared__ float4 t4[];                          // {x, y, z, molecule (int bits)}[tile_cap], then the entry words int[tile_cap]
   __shared__ int s_lo[27], s_off[28], s_ns;
   __shared__ double s_shift[27][3];
   const int cidx = blockIdx.x;
+  const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
   if (threadIdx.x == 0) {
     int slots[27];
     const int ns = cell_neighbourhood(cidx, nc.x, nc.y, nc.z, slots);
-    const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
     int off = 0;
     for (int s = 0; s < ns; ++s) {
       s_lo[s] = cell_start[slots[s]]; s_off[s] = off; off += cell_start[slots[s] + 1] - s_lo[s];
@@ -136,75 +155,81 @@ __global__ __launch_bounds__(1024) void k_neighbors_tiles(int3 nc, const int* __
   __syncthreads();
   const int ns = s_ns, ntile = s_off[ns];
   const bool in_lds = ntile <= tile_cap;
-  double* tx = tdata; double* ty = tdata + tile_cap; double* tz = tdata + 2 * tile_cap;
-  int* tm = (int*)(tdata + 3 * tile_cap);
-  // Tile coordinates are wrapped into the box and moved to the image next to this cell ONCE, at staging: with cells >= the list radius
-  // and >= 4 cells per axis the plain difference of two tile coordinates is the minimum image, so the scan (3 645 candidates per atom)
-  // needs no floor() - it was bound by exactly those fp64 instructions.
+  int* te = (int*)(t4 + tile_cap);
+  // cell centre: tile coordinates are within +-1.5 cells of it
+  const double ox = (cx + 0.5) * box.L[0] / nc.x, oy = (cy + 0.5) * box.L[1] / nc.y, oz = (cz + 0.5) * box.L[2] / nc.z;
   if (in_lds) {
     for (int s = 0; s < ns; ++s) {
       const int lo = s_lo[s], n = s_off[s + 1] - s_off[s], o = s_off[s];
       for (int k = threadIdx.x; k < n; k += blockDim.x) {
         const double4 p = posq[lo + k];
-        tx[o + k] = (p.x - box.L[0] * floor(p.x * box.invL[0])) + s_shift[s][0];
-        ty[o + k] = (p.y - box.L[1] * floor(p.y * box.invL[1])) + s_shift[s][1];
-        tz[o + k] = (p.z - box.L[2] * floor(p.z * box.invL[2])) + s_shift[s][2];
-        tm[o + k] = (mol_s[lo + k] << 8) | type_s[lo + k];      // molecule and type share a word
+        float4 t;
+        t.x = (float)(((p.x - box.L[0] * floor(p.x * box.invL[0])) + s_shift[s][0]) - ox);
+        t.y = (float)(((p.y - box.L[1] * floor(p.y * box.invL[1])) + s_shift[s][1]) - oy);
+        t.z = (float)(((p.z - box.L[2] * floor(p.z * box.invL[2])) + s_shift[s][2]) - oz);
+        t.w = __int_as_float(mol_s[lo + k]);
+        t4[o + k] = t;
+        te[o + k] = (int)((LOCAL ? (unsigned)(o + k) : (unsigned)(lo + k)) | ((unsigned)type_s[lo + k] << NBR_IDX_BITS));
       }
     }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int i1 = cell_start[cidx + 1];
+  const float rv2f = (float)rv2, band = 1e-3f * (float)rv2;
   for (int i = cell_start[cidx] + wave; i < i1; i += wpb) {
     const double4 pr = posq[i];
     const double xi = pr.x - box.L[0] * floor(pr.x * box.invL[0]), yi = pr.y - box.L[1] * floor(pr.y * box.invL[1]), zi = pr.z - box.L[2] * floor(pr.z * box.invL[2]);
+    const float fx = (float)(xi - ox), fy = (float)(yi - oy), fz = (float)(zi - oz);
     const int mi = mol_s[i];
     unsigned total = 0;
     const unsigned base = (unsigned)i * cap;
-    for (int sl = 0; sl < ns; ++sl) {
-      const int lo = s_lo[sl], o = s_off[sl], n = s_off[sl + 1] - o;
-      const double shx = s_shift[sl][0], shy = s_shift[sl][1], shz = s_shift[sl][2];
-      for (int p0 = 0; p0 < n; p0 += 64) {
-        const int p = p0 + lane, j = lo + p;
-        bool hit = false;
-        int mt = 0;
-        if (p < n && j != i) {
-          double xj, yj, zj;
-          if (in_lds) { xj = tx[o + p]; yj = ty[o + p]; zj = tz[o + p]; mt = tm[o + p]; }
-          else {      // neighbourhood larger than the LDS tile: same coordinates, computed on the fly
-            const double4 q = posq[j];
-            xj = (q.x - box.L[0] * floor(q.x * box.invL[0])) + shx; yj = (q.y - box.L[1] * floor(q.y * box.invL[1])) + shy; zj = (q.z - box.L[2] * floor(q.z * box.invL[2])) + shz;
-            mt = (mol_s[j] << 8) | type_s[j];
-          }
-          if ((mt >> 8) != mi) {
-            const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
-            const double r2 = dx * dx + dy * dy + dz * dz;
-            hit = r2 < rv2;
-            if (fabs(r2 - rv2) < 1e-9 * rv2) {      // tie zone (coordinates read from a .gro are multiples of 0.01 A: exact ties DO occur):
-              const double4 q = posq[j];            // decide with the reference's own arithmetic on the raw coordinates
-              double ex = pr.x - q.x, ey = pr.y - q.y, ez = pr.z - q.z;
-              ex -= box.L[0] * floor(ex * box.invL[0] + 0.5);
-              ey -= box.L[1] * floor(ey * box.invL[1] + 0.5);
-              ez -= box.L[2] * floor(ez * box.invL[2] + 0.5);
-              hit = (ex * ex + ey * ey + ez * ez) < rv2;
-            }
+    if (in_lds) {
+      for (int p0 = 0; p0 < ntile; p0 += 64) {
+        const int p = p0 + lane, pc = min(p, ntile - 1);
+        const float4 t = t4[pc];              // both reads unconditional: one wait per trip, no divergence in the common case
+        const int entry = te[pc];
+        const float dx = fx - t.x, dy = fy - t.y, dz = fz - t.z;
+        const float r2 = dx * dx + dy * dy + dz * dz;
+        const bool cand = p < ntile && __float_as_int(t.w) != mi;
+        bool hit = cand && r2 < rv2f;
+        if (__ballot(cand && fabsf(r2 - rv2f) < band)) {      // rare (about one candidate per atom): too close to call in single precision
+          if (cand && fabsf(r2 - rv2f) < band) {
+            int s2 = 0;
+            while (p >= s_off[s2 + 1]) ++s2;
+            const int j = s_lo[s2] + (p - s_off[s2]);
+            hit = nbr_decide_fp64(pr, xi, yi, zi, posq[j], s_shift[s2][0], s_shift[s2][1], s_shift[s2][2], box, rv2);
           }
         }
         const unsigned long long m = __ballot(hit);
         if (hit) {
           const unsigned slot = total + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-          const unsigned idx = LOCAL ? (unsigned)(o + p) : (unsigned)j;
-          if (slot < cap) nbr[base + slot] = (int)(idx | ((unsigned)(mt & 0xff) << NBR_IDX_BITS));
+          if (slot < cap) nbr[base + slot] = entry;
         }
         total += (unsigned)__popcll(m);
+      }
+    } else {           // neighbourhood larger than the tile: the same decisions from global memory
+      for (int sl = 0; sl < ns; ++sl) {
+        const int lo = s_lo[sl], o = s_off[sl], n = s_off[sl + 1] - o;
+        const double shx = s_shift[sl][0], shy = s_shift[sl][1], shz = s_shift[sl][2];
+        for (int p0 = 0; p0 < n; p0 += 64) {
+          const int p = p0 + lane, j = lo + p;
+          bool hit = false;
+          if (p < n && mol_s[j] != mi) hit = nbr_decide_fp64(pr, xi, yi, zi, posq[j], shx, shy, shz, box, rv2);
+          const unsigned long long m = __ballot(hit);
+          if (hit) {
+            const unsigned slot = total + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            const unsigned idx = LOCAL ? (unsigned)(o + p) : (unsigned)j;
+            if (slot < cap) nbr[base + slot] = (int)(idx | ((unsigned)type_s[j] << NBR_IDX_BITS));
+          }
+          total += (unsigned)__popcll(m);
+        }
       }
     }
     if (lane == 0) { count[i] = total; start[i] = base; }
   }
 }
 
-// {max, sum} of the row counts -> out[0] (unsigned), out[1..2] (64-bit sum)
 // row statistics {max, pad, sum (64 bit)}; rows longer than the stride (they were not written past it) are cut to it, so that a pair
 // loop enqueued before the host has seen the statistics stays inside its rows - the host then rebuilds with a larger stride
 __global__ void k_count_stats(int N, unsigned* __restrict__ count, unsigned cap, unsigned* __restrict__ out) {
@@ -405,11 +430,15 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
       static bool attr_set[2] = {false, false};
       auto kern = c->pair_tiles ? k_neighbors_tiles<true> : k_neighbors_tiles<false>;
       if (!attr_set[c->pair_tiles ? 1 : 0]) {
-        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NBR_TILE_CAP * 28));
+        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NBR_TILE_CAP * NBR_TILE_BYTES));
         attr_set[c->pair_tiles ? 1 : 0] = true;
       }
-      hipLaunchKernelGGL(kern, dim3(ncell), dim3(1024), (size_t)NBR_TILE_CAP * 28, c->stream, nc, c->d_cell_start.p, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, box, rv2,
-                         c->nbr_cap, NBR_TILE_CAP, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p);
+      // tile: sized from the largest neighbourhood the last build saw
+      // (a larger one is scanned from global memory).  Up to NBR_TILE_CAP2 atoms two workgroups share a CU's 160 KB.
+      int tile_cap = NBR_TILE_CAP2;
+      if (c->tile_atoms_max > 0 && c->tile_atoms_max * 1.03 > NBR_TILE_CAP2) tile_cap = std::min(NBR_TILE_CAP, ((int)(c->tile_atoms_max * 1.08) + 63) & ~63);
+      hipLaunchKernelGGL(kern, dim3(ncell), dim3(1024), (size_t)tile_cap * NBR_TILE_BYTES, c->stream, nc, c->d_cell_start.p, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, box, rv2,
+                         c->nbr_cap, tile_cap, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p);
     } else if (c->pair_tiles)
       hipLaunchKernelGGL((k_neighbors<true, true>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
                          c->nbr_cap, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p);
@@ -437,7 +466,7 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
     if (c->pair_tiles_opt != 0) { CHK(stats(true)); decide_tiles(h_stats[0]); }    // the tile size fixes the entry format of this build
     else c->pair_tiles = false;
     CHK(fill());
-    if (defer) { CHK(stats(false, false)); c->nbr_check_pending = true; }
+    if (defer) { CHK(stats(true, false)); c->nbr_check_pending = true; }      // + the largest neighbourhood, for the next build's tile
     else {
       CHK(stats(false));
       if ((unsigned)h_stats[2] > c->nbr_cap) { set_cap((unsigned)h_stats[2]); CHK(fill()); CHK(stats(false)); }
@@ -459,6 +488,7 @@ int nb_check_overflow(msevb_ctx* c) {
   if (!c->nbr_check_pending) return 0;
   c->nbr_check_pending = false;
   const int* h = c->h_nbr_stats;
+  if (h[0] > 0) c->tile_atoms_max = h[0];
   if ((unsigned)h[2] > c->nbr_cap) {
     c->nbr_cap = ((unsigned)((unsigned)h[2] * 1.15) + 64u + 63u) & ~63u;
     c->list_valid = false;

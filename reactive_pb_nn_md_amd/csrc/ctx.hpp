@@ -219,6 +219,10 @@ struct msevb_ctx {
   size_t n_nbr = 0;
   unsigned nbr_cap = 0;          // row stride of the Verlet list (0: not sized yet)
   bool list_valid = false;
+  // rolling pruned pair list (pair.hip): rows of the pairs within rc + prune_delta, rewritten by the pair loop itself whenever the two
+  // largest displacements since the last pruning add up to prune_delta; d_prune_mode[0]: 1 = this step prunes, 2 = this step uses the rows
+  bool prune = true; double prune_delta = 0.6;
+  DBuf<int> d_nbr2, d_prune_mode; DBuf<unsigned> d_nbr2_count; DBuf<double4> d_posq_prune;
   bool nbr_check_pending = false;      // a deferred rebuild's row statistics have not been looked at yet
   int* h_nbr_stats = nullptr;          // pinned: {tile_max, pad, count_max, pad, count_sum lo, hi}
   int flag_verlet_list = 0;
@@ -261,6 +265,7 @@ struct msevb_ctx {
   // phase events are SAMPLED: one force call in timing_stride records them (every record costs ~2 us of host time, 25 per step)
   bool timing_now = false; int timing_stride = 8; long timing_tick = 0;
   // NVT: Langevin leap-frog kicks (langevin_integrator, src/md_integration.f90:186-228) instead of the plain half kicks
+  bool evb_device_solve = false;     // single rank: H' assembly + Jacobi + blend coefficients in a kernel (no host round trip before the blend)
   bool nvt = false; double friction = 0.1 /* 1/ps, the reference's default */, temperature = 300.0; unsigned long long langevin_seed = 0, langevin_tick = 0;
 };
 
@@ -269,6 +274,7 @@ int nb_build(msevb_ctx* c);                        // neighbor.hip
 int nb_build_begin(msevb_ctx* c);     // cells + sorted arrays
 int nb_build_finish(msevb_ctx* c, bool defer);    // rows (one host synchronisation unless deferred)
 int nb_check_overflow(msevb_ctx* c);  // after a deferred finish
+int nb_prune_reset(msevb_ctx* c);     // the next pair loop prunes (list rebuilt / positions replaced)
 int nb_settle(msevb_ctx* c);          // looks at statistics a failed call left behind
 constexpr int MSEVB_RETRY = 1000;     // internal: repeat the force call (never leaves the library)
 int nb_refresh_sorted(msevb_ctx* c);               // gather posq/type in sorted order
@@ -307,7 +313,7 @@ int pme_prepare_atoms(msevb_ctx* c, bool with_indices);
 int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic = false, const double* theta = nullptr);
 
 constexpr int MAX_BLOCKS = 65536;
-enum Slot { S_ELEC_PAIR = 0, S_VDW_PAIR, S_ELEC_INTRA, S_VDW_INTRA, S_BOND, S_ANGLE, S_DIH, S_RECIP, S_KE, S_PX, S_PY, S_PZ, S_VX, S_VY, S_VZ /* sum of velocities: KE after the momentum removal */, S_MAXD1, S_MAXD2, S_EVB0,
+enum Slot { S_ELEC_PAIR = 0, S_VDW_PAIR, S_ELEC_INTRA, S_VDW_INTRA, S_BOND, S_ANGLE, S_DIH, S_RECIP, S_KE, S_PX, S_PY, S_PZ, S_VX, S_VY, S_VZ /* sum of velocities: KE after the momentum removal */, S_MAXD1, S_MAXD2, S_PRD1, S_PRD2 /* two largest displacements since the pair list was last pruned */, S_EVB0,
             S_FAULT = 31,      // sticky: a kernel met a coordinate outside what its index arithmetic covers (non-finite, or more than one box away)
             N_SLOTS = 32 };
 

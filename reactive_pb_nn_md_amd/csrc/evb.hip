@@ -608,10 +608,12 @@ __global__ void k_evb_slot0(size_t n3, const double* __restrict__ F11, double* _
 // Fast path (no per-element force stores): the stencil gather is LINEAR in the potential, so sum_d c_d^2 (recip force of diabat d) is the
 // gather of the BLENDED potential  c_0^2 theta_1 + sum_{d>=1} c_d^2 theta_d  - one gather over one grid instead of one per diabat.
 struct GridCoefs { int n; double c0; double c[MAX_DIABATS]; };
-__global__ void k_evb_blend_grids(size_t K3, GridCoefs gc, const double* __restrict__ theta1, const double2* __restrict__ grids, double* __restrict__ out) {
+// dc != nullptr: the coefficients {c0, c[0..n)} come from device memory (written by k_evb_solve), gc only carries n
+__global__ void k_evb_blend_grids(size_t K3, GridCoefs gc, const double* __restrict__ dc, const double* __restrict__ theta1, const double2* __restrict__ grids, double* __restrict__ out) {
+  const double c0 = dc ? dc[0] : gc.c0;      // (uniform scalar loads either way; writing into the by-value struct would move it to scratch)
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K3; k += (size_t)gridDim.x * blockDim.x) {
-    double s = gc.c0 * theta1[k];
-    for (int g = 0; g < gc.n; ++g) s += gc.c[g] * grids[(size_t)g * K3 + k].x;
+    double s = c0 * theta1[k];
+    for (int g = 0; g < gc.n; ++g) s += (dc ? dc[1 + g] : gc.c[g]) * grids[(size_t)g * K3 + k].x;
     out[k] = s;
   }
 }
@@ -621,15 +623,105 @@ struct BlendTerms { int n; int slot[2 * MAX_DIABATS]; double coef[2 * MAX_DIABAT
 // F = w11 F11 + sum_d c_d^2 store_d + 2 sum c_p c_d F_pd with w11 = 1 (w11 < 1 only for a rank's PARTIAL blend, see evb_partial terms);
 // F holds F11 on entry and the blended force on exit.
 // zero_diag: Fdiag is the self-cleaning delta store itself (fast path): every diagonal slot read is reset for the next step.
-__global__ void k_evb_blend(size_t n3, BlendTerms bt, double w11, double* __restrict__ Fdiag, const double* __restrict__ Foff, size_t fstride, double* __restrict__ F, int zero_diag) {
+__global__ void k_evb_blend(size_t n3, BlendTerms bt, const double* __restrict__ dc, double w11, double* __restrict__ Fdiag, const double* __restrict__ Foff, size_t fstride, double* __restrict__ F, int zero_diag) {
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (size_t)gridDim.x * blockDim.x) {
     double s = w11 * F[k];
     for (int t = 0; t < bt.n; ++t) {
       const int sl = bt.slot[t];
-      if (sl < 0) s += bt.coef[t] * Foff[(size_t)(-sl - 1) * fstride + k];
-      else { double* p = Fdiag + (size_t)sl * fstride + k; s += bt.coef[t] * *p; if (zero_diag) *p = 0.0; }
+      const double cf = dc ? dc[t] : bt.coef[t];      // device-resident coefficients (k_evb_solve) or kernel arguments
+      if (sl < 0) s += cf * Foff[(size_t)(-sl - 1) * fstride + k];
+      else { double* p = Fdiag + (size_t)sl * fstride + k; s += cf * *p; if (zero_diag) *p = 0.0; }
     }
     F[k] = s;
+  }
+}
+
+// ---- Hamiltonian assembly + Jacobi + blend coefficients ON THE DEVICE (single rank, fast path): the blend phase is enqueued behind this
+// kernel without a host round trip (fetch -> host Jacobi -> launch cost ~60 us of the step's critical path).  One wavefront; every
+// scalar decision and every element update is the arithmetic of the host versions (H' assembly in evb_force_energy_once, jacobi_h =
+// jacobi of src/general_routines.f90:2013-2088), lanes only spread independent k-loops, so the result is bit-identical to the host path.
+struct SolveDesc {
+  int D, nu, ncp, ngrid, nterm, unit00;
+  double e_hyd, Hp_norep, once;
+  int parent[MAX_DIABATS], grid_of[MAX_DIABATS], cp_of[MAX_DIABATS], unit_off[MAX_DIABATS + 1];
+  double eref_delta[MAX_DIABATS];
+  int term_i[2 * MAX_DIABATS], term_j[2 * MAX_DIABATS];      // blend terms in blend_terms() order (i == j: diagonal)
+  // followed in memory by: int unit_idx[unit_off[D]]; double unit_sign[unit_off[D]] (8-byte aligned)
+};
+// out_host: {status, lowest eigenvalue of H', eigvec[D], cpl_A[D], H'[D*D] row-major (upper triangle filled)}
+__global__ __launch_bounds__(64) void k_evb_solve(const SolveDesc* __restrict__ sd, const int* __restrict__ unit_idx, const double* __restrict__ unit_sign,
+                                                  const double* __restrict__ E, const double* __restrict__ e_recip1, double* __restrict__ dcoef, double* __restrict__ out_host) {
+#pragma clang fp contract(off)
+  extern __shared__ double sh[];      // A[n*n], V[n*n], d[n], b[n], z[n], cplA[n]
+  const int n = sd->D, lane = threadIdx.x;
+  double* A = sh; double* V = A + n * n; double* dd = V + n * n; double* bb = dd + n; double* zz = bb + n; double* cA = zz + n;
+  const int nu = sd->nu, ncp = sd->ncp, ngrid = sd->ngrid;
+  for (int k = lane; k < n * n; k += 64) { A[k] = 0.0; V[k] = (k / n == k % n) ? 1.0 : 0.0; }
+  for (int k = lane; k < n; k += 64) { zz[k] = 0.0; cA[k] = 0.0; }
+  __syncthreads();
+  const double Er1 = *e_recip1;
+  for (int d = lane; d < n; d += 64) {
+    if (d == 0) { const int iu = sd->unit00; A[0] = sd->Hp_norep + sd->once * (E[iu] + E[nu + iu]); }
+    else {
+      double e = sd->e_hyd + sd->eref_delta[d];
+      for (int q = sd->unit_off[d]; q < sd->unit_off[d + 1]; ++q) { const int iu = unit_idx[q]; e += unit_sign[q] * (E[iu] + E[nu + iu]); }
+      e += E[2 * nu + ncp + sd->grid_of[d]] - Er1;
+      A[d * n + d] = e;
+      const double hpd = E[2 * nu + ncp + ngrid + 3 * sd->cp_of[d] + 2];
+      const int p = sd->parent[d];
+      A[p * n + d] = hpd; A[d * n + p] = hpd;
+      cA[d] = E[2 * nu + ncp + ngrid + 3 * sd->cp_of[d]];
+    }
+  }
+  __syncthreads();
+  for (int k = lane; k < n * n; k += 64) out_host[2 + 2 * n + k] = (k / n <= k % n) ? A[k] : 0.0;      // H' as the host assembles it (upper triangle)
+  for (int k = lane; k < n; k += 64) { bb[k] = A[k * n + k]; dd[k] = bb[k]; }
+  __syncthreads();
+  int status = -1;
+  for (int it = 1; it <= 50; ++it) {
+    double sm = 0.0;      // every lane runs the same serial sum: the threshold must not depend on a reduction order
+    for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) sm += fabs(A[i * n + j]);
+    if (sm == 0.0) { status = 0; break; }
+    const double tresh = it < 4 ? 0.2 * sm / (double)(n * n) : 0.0;
+    for (int ip = 0; ip < n - 1; ++ip) for (int iq = ip + 1; iq < n; ++iq) {
+      const double apq = A[ip * n + iq];
+      const double g = 100.0 * fabs(apq);
+      if (it > 4 && fabs(dd[ip]) + g == fabs(dd[ip]) && fabs(dd[iq]) + g == fabs(dd[iq])) { __syncthreads(); if (lane == 0) A[ip * n + iq] = 0.0; __syncthreads(); }
+      else if (fabs(apq) > tresh) {
+        double h = dd[iq] - dd[ip], t;
+        if (fabs(h) + g == fabs(h)) t = apq / h;
+        else { const double theta = 0.5 * h / apq; t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta)); if (theta < 0.0) t = -t; }
+        const double cs = 1.0 / sqrt(1 + t * t), s = t * cs, tau = s / (1.0 + cs);
+        h = t * apq;
+        __syncthreads();
+        if (lane == 0) { zz[ip] -= h; zz[iq] += h; dd[ip] -= h; dd[iq] += h; A[ip * n + iq] = 0.0; }
+        // the four k-loops of the rotation touch disjoint elements: one lane per k
+        for (int k = lane; k < n; k += 64) {
+          double *x = nullptr, *y = nullptr;
+          if (k < ip) { x = &A[k * n + ip]; y = &A[k * n + iq]; }
+          else if (k > ip && k < iq) { x = &A[ip * n + k]; y = &A[k * n + iq]; }
+          else if (k > iq) { x = &A[ip * n + k]; y = &A[iq * n + k]; }
+          if (x) { const double gg = *x, hh = *y; *x = gg - s * (hh + gg * tau); *y = hh + s * (gg - hh * tau); }
+          double* vx = &V[k * n + ip]; double* vy = &V[k * n + iq];
+          const double gg = *vx, hh = *vy; *vx = gg - s * (hh + gg * tau); *vy = hh + s * (gg - hh * tau);
+        }
+        __syncthreads();
+      }
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) { bb[i] += zz[i]; dd[i] = bb[i]; zz[i] = 0.0; }
+    __syncthreads();
+  }
+  // ground state, blend coefficients
+  int gidx = 0; double eg = dd[0];
+  for (int i = 1; i < n; ++i) if (dd[i] < eg) { eg = dd[i]; gidx = i; }
+  if (lane == 0) { out_host[0] = (double)status; out_host[1] = eg; dcoef[0] = V[gidx] * V[gidx]; }
+  for (int k = lane; k < n; k += 64) { out_host[2 + k] = V[k * n + gidx]; out_host[2 + n + k] = cA[k]; }
+  for (int d = 1 + lane; d < n; d += 64) if (sd->grid_of[d] >= 0) { const double ev = V[d * n + gidx]; dcoef[1 + sd->grid_of[d]] = ev * ev; }
+  for (int t = lane; t < sd->nterm; t += 64) {
+    const int i = sd->term_i[t], j = sd->term_j[t];
+    const double ei = V[i * n + gidx], ej = V[j * n + gidx];
+    dcoef[1 + ngrid + t] = i == j ? ei * ej : 2.0 * ei * ej * -cA[j];
   }
 }
 
@@ -660,9 +752,12 @@ __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ 
 }
 
 // copies two small device arrays into pinned host memory (zero-copy stores): the energy downloads, without copy commands
-__global__ void k_evb_publish(const double* __restrict__ a, int na, double* __restrict__ ha, const double* __restrict__ b, int nb, double* __restrict__ hb) {
+// flag != nullptr: after the data, the sequence number goes to pinned memory - the host spins on it instead of sleeping on an event
+__global__ void k_evb_publish(const double* __restrict__ a, int na, double* __restrict__ ha, const double* __restrict__ b, int nb, double* __restrict__ hb,
+                              volatile long long* flag = nullptr, long long seq = 0) {
   for (int k = threadIdx.x; k < na; k += blockDim.x) ha[k] = a[k];
   for (int k = threadIdx.x; k < nb; k += blockDim.x) hb[k] = b[k];
+  if (flag) { __threadfence_system(); __syncthreads(); if (threadIdx.x == 0) *flag = seq; }
 }
 
 // publishes the record count of k_evb_region to pinned host memory
@@ -697,6 +792,8 @@ struct EvbWork {   // persistent device scratch of one context
   DBuf<double> d_F11, d_pack, d_com_atom;
   hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
   RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
+  long long* h_flag = nullptr; long long seq_A = 0;      // pinned: sequence number of the last published fetch A
+  DBuf<double> d_coef; double* h_solve = nullptr; size_t h_solve_cap = 0; hipEvent_t ev_solve = nullptr;      // device-side Hamiltonian solve (k_evb_solve)
   char* h_desc = nullptr; DBuf<char> d_desc; size_t desc_cap = 0;   // units | couplings | recip atoms, one pinned block -> one upload
   double* h_E = nullptr; size_t hE_cap = 0;                         // pinned
   int grids_cap = 0;
@@ -874,24 +971,28 @@ static inline int off_slot(const msevb_ctx* c, int D, int d) { return ((d - 1) %
 static inline int diag_slot(const msevb_ctx* c, int D, int d) { return d == 0 ? 0 : 1 + off_slot(c, D, d); }
 static inline bool owned(const msevb_ctx* c, int d);
 // terms of this rank's share of the Hellmann-Feynman blend; returns the weight of the principal force F11 in it (rank 0 carries it)
-static double blend_terms(const msevb_ctx* c, int D, const double* ev, BlendTerms& bt) {
-  bt.n = 0;
+static double blend_terms(const msevb_ctx* c, int D, const double* ev, BlendTerms& bt, int* ti = nullptr, int* tj = nullptr) {
+  bt.n = 0;      // ev == nullptr: only the structure (slots, and the (i,j) of every term for k_evb_solve); the coefficients come from the device
   for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) {
-    if (i == j) { if (i == 0 ? c->rank == 0 : owned(c, i)) { bt.coef[bt.n] = ev[i] * ev[j]; bt.slot[bt.n++] = diag_slot(c, D, i); } }
-    else if (c->parent[j] == i && owned(c, j)) { bt.coef[bt.n] = 2.0 * ev[i] * ev[j] * -c->cpl_A[j]; bt.slot[bt.n++] = -off_slot(c, D, j) - 1; }
+    const bool diag = i == j && (i == 0 ? c->rank == 0 : owned(c, i)), off = i != j && c->parent[j] == i && owned(c, j);
+    if (!diag && !off) continue;
+    bt.coef[bt.n] = !ev ? 0.0 : diag ? ev[i] * ev[j] : 2.0 * ev[i] * ev[j] * -c->cpl_A[j];
+    if (ti) { ti[bt.n] = i; tj[bt.n] = j; }
+    bt.slot[bt.n++] = diag ? diag_slot(c, D, i) : -off_slot(c, D, j) - 1;
   }
   return (c->rank == 0 || (c->shard_principal && c->n_ranks > 1)) ? 1.0 : 0.0;      // sharded principal: every rank holds a part of F11
 }
 // Fast-path blend of THIS rank's share for the ground-state vector ev: one gather of the blended potential of its grids (+ the principal
 // one on rank 0), the special atoms' corrections into the delta store, then the blend of delta / off-diagonal stores.  c->d_force holds
 // (this rank's part of) F11 on entry and the rank's partial Hellmann-Feynman force on exit.
-static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, const int* grid_of, int ngrid, int nra, const RecipAtom* d_ra);
+static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, const int* grid_of, int ngrid, int nra, const RecipAtom* d_ra, const double* dcoef = nullptr);
 
 static inline bool owned(const msevb_ctx* c, int d) { return d == 0 || ((d - 1) % c->n_ranks) == c->rank; }
 
 extern "C" int msevb_comm_allgather_evb(msevb_ctx* c, int with_energies);   // comm.hip
 
-static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, const int* grid_of, int ngrid, int nra, const RecipAtom* d_ra) {
+// dcoef: coefficients in device memory {c0, grid coefficients, blend terms} written by k_evb_solve (then ev is not needed)
+static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, const int* grid_of, int ngrid, int nra, const RecipAtom* d_ra, const double* dcoef) {
   const int K = c->K;
   const size_t K3 = (size_t)K * K * K, n3 = 3 * (size_t)c->N;
   BlendTerms bt;
@@ -901,18 +1002,18 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
     w11 = 1.0;
   }
   // reciprocal space of the blend in ONE gather: blended potential of this rank's diabats (+ the principal one on rank 0) ...
-  GridCoefs gc; gc.n = ngrid; gc.c0 = c->rank == 0 ? ev[0] * ev[0] : 0.0;
-  for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gc.c[grid_of[d]] = ev[d] * ev[d];
+  GridCoefs gc; gc.n = ngrid; gc.c0 = 0.0;
+  if (ev) { gc.c0 = c->rank == 0 ? ev[0] * ev[0] : 0.0; for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gc.c[grid_of[d]] = ev[d] * ev[d]; }
   if (c->overlap && ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // convolved diabat grids (aux)
   if (w->d_pack.alloc(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended potential)");
-  hipLaunchKernelGGL(k_evb_blend_grids, dim3(1024), dim3(256), 0, c->stream, K3, gc, c->d_theta.p, w->d_grids.p, w->d_pack.p);
+  hipLaunchKernelGGL(k_evb_blend_grids, dim3(1024), dim3(256), 0, c->stream, K3, gc, dcoef, c->d_theta.p, w->d_grids.p, w->d_pack.p);
   CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p));
   // ... the special atoms' own-stencil corrections per diabat go to the delta store, which the blend consumes and re-zeroes
   if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));
   if (ngrid) hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
                                 w->d_sw.p, w->d_sdw.p, w->d_grids.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0],
                                 c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3);
-  hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p, 1);
+  hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, dcoef ? dcoef + 1 + ngrid : (const double*)nullptr, w11, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p, 1);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
 }
@@ -941,6 +1042,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipEventCreateWithFlags(&w->ev_cpl, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_flush, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_fetchA, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&w->ev_solve, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_E, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_fetch, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&w->h_region, REGION_FAST * sizeof(RegionRec), hipHostMallocDefault));
@@ -1123,7 +1225,13 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     w->tabs_uploaded = true;
   }
   if (nu > MAX_UNITS || ncp > MAX_DIABATS || nra > MAX_DIABATS * MAX_SPEC) FAIL(MSEVB_ERR_LIMIT, "EVB descriptor staging too small");
-  const size_t off_u = 0, off_c = off_u + (size_t)nu * sizeof(UnitDesc), off_r = off_c + (size_t)ncp * sizeof(CouplingDesc), desc_bytes = off_r + (size_t)nra * sizeof(RecipAtom);
+  // single rank, no per-element stores: the Hamiltonian is assembled and diagonalised on the device (k_evb_solve), its descriptor rides along
+  const bool dev_solve = !c->evb_element_stores && c->n_ranks == 1 && !c->nccl_comm && c->evb_device_solve;
+  int n_unit_refs = 0;
+  for (int d = 1; d < D; ++d) n_unit_refs += (int)units_of[d].size();
+  const size_t off_u = 0, off_c = off_u + (size_t)nu * sizeof(UnitDesc), off_r = off_c + (size_t)ncp * sizeof(CouplingDesc);
+  const size_t off_s = (off_r + (size_t)nra * sizeof(RecipAtom) + 7) & ~(size_t)7, off_si = off_s + sizeof(SolveDesc), off_ss = (off_si + (size_t)n_unit_refs * sizeof(int) + 7) & ~(size_t)7;
+  const size_t desc_bytes = dev_solve ? off_ss + (size_t)n_unit_refs * sizeof(double) : off_r + (size_t)nra * sizeof(RecipAtom);
   // "setup" stream: aux2 when overlapping - it already holds this step's neighbourhood fetch and per-molecule kernel; descriptors,
   // zero-fills and everything that needs only positions + descriptors follow there, beside the principal force still running elsewhere
   const hipStream_t ss = c->overlap ? w->stream2 : c->stream;
@@ -1137,6 +1245,24 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   memcpy(w->h_desc + off_u, units.data(), (size_t)nu * sizeof(UnitDesc));
   if (ncp) memcpy(w->h_desc + off_c, cps.data(), (size_t)ncp * sizeof(CouplingDesc));
   if (nra) memcpy(w->h_desc + off_r, ras.data(), (size_t)nra * sizeof(RecipAtom));
+  BlendTerms bt_dev;      // slots of the blend terms (the coefficients will come from the device)
+  if (dev_solve) {
+    SolveDesc* sd = (SolveDesc*)(w->h_desc + off_s);
+    int* ui = (int*)(w->h_desc + off_si); double* us = (double*)(w->h_desc + off_ss);
+    sd->D = D; sd->nu = nu; sd->ncp = ncp; sd->ngrid = ngrid; sd->unit00 = units_of[0][0];
+    sd->e_hyd = c->e_ref[c->h_mol_type[c->hydronium]]; sd->Hp_norep = sd->e_hyd; sd->once = 1.0;
+    int q = 0;
+    sd->unit_off[0] = 0; sd->unit_off[1] = 0;
+    for (int d = 1; d < D; ++d) {
+      sd->parent[d] = c->parent[d]; sd->grid_of[d] = grid_of[d]; sd->cp_of[d] = cp_of[d]; sd->eref_delta[d] = eref_delta[d];
+      sd->unit_off[d] = q;
+      for (int iu : units_of[d]) { ui[q] = iu; us[q] = units[iu].sign; ++q; }
+      sd->unit_off[d + 1] = q;
+    }
+    sd->parent[0] = -1; sd->grid_of[0] = -1; sd->cp_of[0] = -1; sd->eref_delta[0] = 0.0;
+    (void)blend_terms(c, D, nullptr, bt_dev, sd->term_i, sd->term_j);
+    sd->nterm = bt_dev.n;
+  }
   HIPCHK(hipMemcpyAsync(w->d_desc.p, w->h_desc, desc_bytes, hipMemcpyHostToDevice, ss));
   const UnitDesc* d_units = (const UnitDesc*)(w->d_desc.p + off_u);
   const CouplingDesc* d_cps = (const CouplingDesc*)(w->d_desc.p + off_c);
@@ -1228,7 +1354,24 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     CHK(flush_one(c, S_RECIP, sg));                              // principal reciprocal energy: its partial sums are complete on `sg`
     if (c->overlap) { HIPCHK(hipEventRecord(w->ev_E, sg)); HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0)); }
     if (c->overlap && ncp) HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_cpl, 0));      // coupling energies (aux3)
-    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, ss, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE);
+    if (dev_solve) {
+      const size_t need = 2 + 2 * (size_t)D + (size_t)D * D;
+      if (need > w->h_solve_cap) {
+        if (w->h_solve) HIPCHK(hipHostFree(w->h_solve));
+        w->h_solve_cap = 2 * need + 64;
+        HIPCHK(hipHostMalloc((void**)&w->h_solve, w->h_solve_cap * sizeof(double), hipHostMallocDefault));
+      }
+      if (w->d_coef.alloc(1 + MAX_DIABATS + 2 * MAX_DIABATS)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blend coefficients)");
+      static bool attr = false;
+      if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * MAX_DIABATS * MAX_DIABATS + 4 * MAX_DIABATS) * 8)); attr = true; }
+      hipLaunchKernelGGL(k_evb_solve, dim3(1), dim3(64), (size_t)(2 * D * D + 4 * D) * 8, ss, (const SolveDesc*)(w->d_desc.p + off_s), (const int*)(w->d_desc.p + off_si),
+                         (const double*)(w->d_desc.p + off_ss), w->d_E.p, c->d_energies.p + S_RECIP, w->d_coef.p, w->h_solve);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(w->ev_solve, ss));
+      return MSEVB_OK;
+    }
+    if (!w->h_flag) { HIPCHK(hipHostMalloc((void**)&w->h_flag, 64, hipHostMallocDefault)); *w->h_flag = 0; }
+    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, ss, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, ++w->seq_A);
     HIPCHK(hipGetLastError());
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, ss));
     return MSEVB_OK;
@@ -1287,18 +1430,38 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   //         and the diagonal real-space deltas (forked in step 5b, joined here)
   HIPCHK(hipGetLastError());
   if (ncp && c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_cpl, 0));      // off-diagonal force stores complete
+  if (dev_solve) {      // the blend phase goes out NOW, behind the device-side solve: no host round trip between the energies and the blend
+    HIPCHK(hipStreamWaitEvent(c->stream, w->ev_solve, 0));
+    phase_begin(c, PH_EVB_BLEND);
+    CHK(fast_blend_phase(c, w, D, nullptr, grid_of.data(), ngrid, nra, d_ra, w->d_coef.p));
+    phase_end(c, PH_EVB_BLEND);
+  }
   HT(8);
-  // ---- 9. Hamiltonian without the principal diabat's energy (H' = H - E0 I), from fetch A
-  if (c->overlap) HIPCHK(hipEventSynchronize(w->ev_fetchA)); else HIPCHK(hipStreamSynchronize(c->stream));
-  const double E_recip1 = w->h_E[nE];                  // this rank's own (complete) principal reciprocal energy
+  // ---- 9. Hamiltonian without the principal diabat's energy (H' = H - E0 I), from fetch A (or from the device-side solve)
+  if (dev_solve) HIPCHK(hipEventSynchronize(w->ev_solve));
+  else if (c->overlap) {      // spin on the publish kernel's sequence number (an event wait costs the host 10-20 us to wake up); the event is the fallback
+    volatile long long* f = (volatile long long*)w->h_flag;
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (*f != w->seq_A) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;      // a failed kernel never writes: let the event report it
+    }
+    if (*f != w->seq_A) HIPCHK(hipEventSynchronize(w->ev_fetchA));
+  } else HIPCHK(hipStreamSynchronize(c->stream));
+  const double E_recip1 = dev_solve ? 0.0 : w->h_E[nE];                  // this rank's own (complete) principal reciprocal energy
   const bool sharded = c->shard_principal && c->n_ranks > 1;
   const bool partial = sharded && !c->nccl_comm;       // virtual ranks (tests): the caller sums the ranks' shares
   memset(c->H, 0, sizeof c->H);
   auto unitE = [&](int iu) { return w->h_E[iu] + w->h_E[nu + iu]; };
   const double once = (partial && c->rank != 0) ? 0.0 : 1.0;      // replicated terms count once over virtual ranks
   const double Hp_norep = once * c->e_ref[c->h_mol_type[c->hydronium]];
-  c->H[0][0] = Hp_norep + once * unitE(units_of[0][0]);
-  for (int d = 1; d < D; ++d) {
+  if (dev_solve) {
+    const double* hs = w->h_solve;
+    if (hs[0] != 0.0) FAIL(MSEVB_ERR_NUMERIC, "too many iterations in jacobi");
+    for (int i = 0; i < D; ++i) { c->eigvec[i] = hs[2 + i]; c->cpl_A[i] = hs[2 + D + i]; for (int j = i; j < D; ++j) c->H[i][j] = hs[2 + 2 * D + (size_t)i * D + j]; }
+  } else c->H[0][0] = Hp_norep + once * unitE(units_of[0][0]);
+  for (int d = 1; d < D && !dev_solve; ++d) {
     if (!owned(c, d)) continue;
     double e = c->e_ref[c->h_mol_type[c->hydronium]] + eref_delta[d];
     for (int iu : units_of[d]) e += units[iu].sign * unitE(iu);
@@ -1340,23 +1503,28 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     return MSEVB_OK;
   }
   // ---- 11. diagonalise H', blend (diagonalize_evb_hamiltonian, :242)
-  std::vector<double> a((size_t)D * D), ev(D), v((size_t)D * D);
-  for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) { a[(size_t)i * D + j] = c->H[i][j]; a[(size_t)j * D + i] = c->H[i][j]; }
-  if (jacobi_h(D, a, ev, v) != 0) FAIL(MSEVB_ERR_NUMERIC, "too many iterations in jacobi");
-  int g = 0; double eg = ev[0];
-  for (int i = 1; i < D; ++i) if (ev[i] < eg) { eg = ev[i]; g = i; }
-  for (int i = 0; i < D; ++i) c->eigvec[i] = v[(size_t)i * D + g];
-  phase_begin(c, PH_EVB_BLEND);
-  if (fast) {
+  double eg = 0.0;
+  if (dev_solve) eg = w->h_solve[1];
+  else {
+    std::vector<double> a((size_t)D * D), ev(D), v((size_t)D * D);
+    for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) { a[(size_t)i * D + j] = c->H[i][j]; a[(size_t)j * D + i] = c->H[i][j]; }
+    if (jacobi_h(D, a, ev, v) != 0) FAIL(MSEVB_ERR_NUMERIC, "too many iterations in jacobi");
+    int g = 0; eg = ev[0];
+    for (int i = 1; i < D; ++i) if (ev[i] < eg) { eg = ev[i]; g = i; }
+    for (int i = 0; i < D; ++i) c->eigvec[i] = v[(size_t)i * D + g];
+  }
+  if (!dev_solve) phase_begin(c, PH_EVB_BLEND);
+  if (dev_solve) {
+  } else if (fast) {
     CHK(fast_blend_phase(c, w, D, c->eigvec, grid_of.data(), ngrid, nra, d_ra));
   } else {
     BlendTerms bt;
     const double w11 = blend_terms(c, D, c->eigvec, bt);
-    hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0);
+    hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, (const double*)nullptr, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0);
   }
   HIPCHK(hipGetLastError());
   if (c->nccl_comm) CHK(msevb_comm_allreduce_forces(c));
-  phase_end(c, PH_EVB_BLEND);
+  if (!dev_solve) phase_end(c, PH_EVB_BLEND);
   {   // the blend is enqueued: now the principal energy (it shifts the whole diagonal, not the ground-state vector)
     double E0 = 0.0;
     CHK(principal_energy(E0));
@@ -1410,11 +1578,14 @@ void evb_release(msevb_ctx* c) {
     DBuf<double>* db[] = {&w->d_exch, &w->d_part, &w->d_E, &w->d_dVspec, &w->d_sw, &w->d_sdw, &w->d_Fdelta, &w->d_F11, &w->d_pack, &w->d_com_atom};
     for (auto b : db) b->release();
     w->d_tabs.release(); w->d_sbase.release(); w->d_counter.release(); w->d_grids.release(); w->d_region.release(); w->d_cand.release(); w->d_desc.release();
-    hipEvent_t* ev[] = {&w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA};
+    hipEvent_t* ev[] = {&w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA, &w->ev_solve};
     for (auto e : ev) if (*e) (void)hipEventDestroy(*e);
     if (w->h_region) (void)hipHostFree(w->h_region);
     if (w->h_count) (void)hipHostFree(w->h_count);
     if (w->h_desc) (void)hipHostFree(w->h_desc);
+    if (w->h_solve) (void)hipHostFree(w->h_solve);
+    if (w->h_flag) (void)hipHostFree(w->h_flag);
+    w->d_coef.release();
     if (w->h_E) (void)hipHostFree(w->h_E);
     delete w;
   }
@@ -1461,7 +1632,7 @@ int msevb_evb_partial_blend(msevb_ctx* c, const double* eigvec, double* force) {
     BlendTerms bt;
     const double w11 = blend_terms(c, c->D, eigvec, bt);
     HIPCHK(hipMemcpyAsync(c->d_force.p, w->d_F11.p, n3 * 8, hipMemcpyDeviceToDevice, c->stream));
-    hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0);
+    hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, (const double*)nullptr, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0);
   }
   HIPCHK(hipMemcpyAsync(force, c->d_force.p, n3 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));

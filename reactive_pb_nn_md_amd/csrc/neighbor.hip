@@ -284,13 +284,20 @@ __global__ __launch_bounds__(256) void k_displacements(int N, const double* __re
 __global__ __launch_bounds__(256) void k_step_refresh(int N, const int* __restrict__ perm, const double* __restrict__ xyz, const double* __restrict__ chg,
                                                       const int* __restrict__ atype, const int* __restrict__ mol_of, double4* __restrict__ posq, int* __restrict__ type_s,
                                                       int* __restrict__ mol_s, double* __restrict__ store, double* __restrict__ disp, BoxDev box,
-                                                      double* __restrict__ F, double* __restrict__ part1, double* __restrict__ part2) {
+                                                      double* __restrict__ F, double* __restrict__ part1, double* __restrict__ part2,
+                                                      const double4* __restrict__ posq_prune, double* __restrict__ part3, double* __restrict__ part4) {
   __shared__ double s1[256], s2[256];
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  double nrm = 0.0;
+  double nrm = 0.0, nrm_p = 0.0;
   if (k < N) {
     const int i = perm[k];
     const double x[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    if (posq_prune) {      // displacement since the pair list was pruned (snapshot taken by the pair loop, sorted order)
+      const double4 q = posq_prune[k];
+      double e[3] = {x[0] - q.x, x[1] - q.y, x[2] - q.z};
+      for (int d = 0; d < 3; ++d) e[d] -= box.L[d] * floor(e[d] * box.invL[d] + 0.5);
+      nrm_p = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    }
     posq[k] = make_double4(x[0], x[1], x[2], chg[i]);
     type_s[k] = atype[i];
     mol_s[k] = mol_of[i];
@@ -318,10 +325,29 @@ __global__ __launch_bounds__(256) void k_step_refresh(int N, const int* __restri
     __syncthreads();
   }
   if (threadIdx.x == 0) { part1[blockIdx.x] = s1[0]; part2[blockIdx.x] = s2[0]; }
+  if (!posq_prune) return;
+  __syncthreads();
+  s1[threadIdx.x] = nrm_p;
+  s2[threadIdx.x] = 0.0;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+      double a1 = s1[threadIdx.x], a2 = s2[threadIdx.x], b1 = s1[threadIdx.x + st], b2 = s2[threadIdx.x + st];
+      s1[threadIdx.x] = fmax(a1, b1);
+      s2[threadIdx.x] = fmax(fmin(a1, b1), fmax(a2, b2));
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part3[blockIdx.x] = s1[0]; part4[blockIdx.x] = s2[0]; }
 }
 
-__global__ void k_top2_final(int nb, const double* __restrict__ part1, const double* __restrict__ part2, double* __restrict__ out) {
+// blockIdx.x = 0: displacement since the last list build -> out[0..1] (the host's rebuild flag); blockIdx.x = 1: displacement since the
+// last pruning -> out[2..3] and the pair loop's mode for THIS step: two atoms approach by at most d1 + d2, so the pruned rows (all pairs
+// within rc + delta when they were written) still hold every pair within rc while d1 + d2 < delta
+__global__ void k_top2_final(int nb, const double* __restrict__ part1, const double* __restrict__ part2, double* __restrict__ out,
+                             const double* __restrict__ part3, const double* __restrict__ part4, double prune_delta, int* __restrict__ prune_mode) {
   __shared__ double s1[256], s2[256];
+  if (blockIdx.x == 1) { part1 = part3; part2 = part4; out += 2; }
   double m1 = 0, m2 = 0;
   for (int k = threadIdx.x; k < nb; k += 256) {
     double b1 = part1[k], b2 = part2[k];
@@ -338,7 +364,11 @@ __global__ void k_top2_final(int nb, const double* __restrict__ part1, const dou
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { out[0] = s1[0]; out[1] = s2[0]; }
+  if (threadIdx.x == 0) {
+    out[0] = s1[0]; out[1] = s2[0];
+    // prune_mode[2]: pruned rows exist for the CURRENT full rows (cleared by nb_prune_reset, set by a pair loop that wrote them)
+    if (blockIdx.x == 1) { const int use = prune_mode[2] != 0 && (s1[0] + s2[0]) < prune_delta; prune_mode[0] = use ? 2 : 1; prune_mode[1] += use ? 0 : 1; }
+  }
 }
 
 }  // namespace
@@ -354,17 +384,33 @@ int nb_refresh_sorted(msevb_ctx* c) {
   hipLaunchKernelGGL(k_gather_sorted, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, c->d_perm.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p,
                      c->d_mol_of.p, c->d_posq.p, c->d_type_sorted.p, c->d_mol_sorted.p, c->d_inv_perm.p);
   HIPCHK(hipGetLastError());
+  return nb_prune_reset(c);      // positions were replaced wholesale: whatever pruned rows exist are not known to cover them
+}
+
+// the next pair loop runs on the full rows and writes fresh pruned ones
+int nb_prune_reset(msevb_ctx* c) {
+  if (!c->prune) return MSEVB_OK;
+  if (!c->d_prune_mode.p) {
+    if (c->d_prune_mode.alloc(4)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (prune state)");
+    HIPCHK(hipMemsetAsync(c->d_prune_mode.p, 0, 4 * sizeof(int), c->stream));
+  }
+  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->d_prune_mode.p, 1, 1, c->stream));            // mode: prune
+  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(c->d_prune_mode.p + 2), 0, 1, c->stream));      // no pruned rows for these full rows yet
   return MSEVB_OK;
 }
 
 // displacement check + sorted-array refresh + force zeroing of a step that keeps the current list (one kernel + the tiny top-2 finish)
 int nb_step_refresh(msevb_ctx* c) {
   const int N = c->N, nb = (N + 255) / 256;
+  const bool pr = c->prune && c->d_posq_prune.p && c->d_prune_mode.p;
+  static_assert(S_MAXD2 == S_MAXD1 + 1 && S_PRD1 == S_MAXD1 + 2 && S_PRD2 == S_MAXD1 + 3, "displacement slots are contiguous");
   hipLaunchKernelGGL(k_step_refresh, dim3(nb), dim3(256), 0, c->stream, N, c->d_perm.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p, c->d_mol_of.p, c->d_posq.p,
                      c->d_type_sorted.p, c->d_mol_sorted.p, c->d_xyz_store.p, c->d_disp.p, make_box(c), c->d_force.p,
-                     c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS);
-  hipLaunchKernelGGL(k_top2_final, dim3(1), dim3(256), 0, c->stream, nb, c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS,
-                     c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS, c->d_energies.p + S_MAXD1);
+                     c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS,
+                     pr ? c->d_posq_prune.p : (const double4*)nullptr, c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS);
+  hipLaunchKernelGGL(k_top2_final, dim3(pr ? 2 : 1), dim3(256), 0, c->stream, nb, c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS,
+                     c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS, c->d_energies.p + S_MAXD1,
+                     c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS, c->prune_delta, c->d_prune_mode.p);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
 }
@@ -515,7 +561,7 @@ int nb_check_displacements(msevb_ctx* c, int initialize, int* flag) {
   hipLaunchKernelGGL(k_displacements, dim3(nb), dim3(256), 0, c->stream, N, c->d_xyz.p, c->d_xyz_store.p, c->d_disp.p, box, initialize,
                      c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS);
   hipLaunchKernelGGL(k_top2_final, dim3(1), dim3(256), 0, c->stream, nb, c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS,
-                     c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS, c->d_energies.p + S_MAXD1);
+                     c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS, c->d_energies.p + S_MAXD1, (const double*)nullptr, (const double*)nullptr, 0.0, (int*)nullptr);
   HIPCHK(hipGetLastError());
   if (flag) *flag = 0;
   return MSEVB_OK;

@@ -23,11 +23,13 @@ constexpr unsigned NBR_NONE = 0xffffffffu;     // padding entry of a partial tri
 // One atom's list row, 64 lanes x 2 entries per trip; the entries of the NEXT trip are loaded before the current trip is evaluated
 // and the Ewald table rows of both entries of a trip are fetched before either pair is finished.  `src` is the {x,y,z,q} array the
 // entries index: the cell-sorted array in HBM (k_pair) or the cell-neighbourhood tile in LDS (k_pair_tiles).
-template <bool SAPT, class PosPtr>
+// PRUNE: when `out` is set, the entries within sqrt(rp2) are compacted into out[0 .. n_out) on the way (the rolling pruned list).
+template <bool SAPT, bool PRUNE = false, class PosPtr>
 __device__ __forceinline__ void pair_row(PosPtr src, const double4 pi, int ti, unsigned s, unsigned e, int lane, const int* __restrict__ nbr,
                                          const PairParam* sp, int nt, const double2* __restrict__ etab, double inv_dx, int emax,
                                          const double* __restrict__ tt, const double* __restrict__ dtt, const BoxDev& box, double rc2,
-                                         double& fx, double& fy, double& fz, double& e_el, double& e_vdw) {
+                                         double& fx, double& fy, double& fz, double& e_el, double& e_vdw, int* __restrict__ out = nullptr, double rp2 = 0.0,
+                                         unsigned* n_out = nullptr) {
 #pragma clang fp contract(fast)
   unsigned k = s + lane;
   unsigned e0 = k < e ? (unsigned)nbr[k] : NBR_NONE, e1 = k + 64 < e ? (unsigned)nbr[k + 64] : NBR_NONE;
@@ -42,6 +44,15 @@ __device__ __forceinline__ void pair_row(PosPtr src, const double4 pi, int ti, u
     dxb -= box.L[0] * floor(dxb * box.invL[0] + 0.5); dyb -= box.L[1] * floor(dyb * box.invL[1] + 0.5); dzb -= box.L[2] * floor(dzb * box.invL[2] + 0.5);
     const double r2a = dxa * dxa + dya * dya + dza * dza, r2b = dxb * dxb + dyb * dyb + dzb * dzb;
     const bool ina = va && r2a < rc2, inb = vb && r2b < rc2;
+    if (PRUNE && out) {      // wave-uniform branch
+      const bool ka = va && r2a < rp2, kb = vb && r2b < rp2;
+      const unsigned long long ma = __ballot(ka), mb = __ballot(kb);
+      unsigned tot = *n_out;
+      if (ka) out[tot + __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0u))] = (int)e0;
+      tot += (unsigned)__popcll(ma);
+      if (kb) out[tot + __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u))] = (int)e1;
+      *n_out = tot + (unsigned)__popcll(mb);
+    }
     EwaldRows wa, wb;
     ewald_fetch(ina ? r2a : rc2, inv_dx, emax, etab, wa);
     ewald_fetch(inb ? r2b : rc2, inv_dx, emax, etab, wb);
@@ -59,13 +70,18 @@ __device__ __forceinline__ void pair_row(PosPtr src, const double4 pi, int ti, u
   }
 }
 
-template <bool SAPT>
+// PRUNE: the rolling pruned list.  prune_state[0] (written on this stream by k_top2_final / nb_prune_reset just before) selects for the whole
+// launch: 2 = run on the pruned rows nbr2 / count2 (pairs within rc + delta when they were written); 1 = run on the full rows and, on the
+// way, rewrite the pruned rows and the position snapshot the displacement check refers to.  The set of pairs inside rc is the same
+// either way; ~25 % of the entries of a full row lie outside rc + delta and cost a gather each.
+template <bool SAPT, bool PRUNE>
 __global__ __launch_bounds__(256) void k_pair(int i_lo, int N, const double4* __restrict__ posq, const int* __restrict__ type_s,
                                               const unsigned* __restrict__ nbr_start, const unsigned* __restrict__ nbr_count, const int* __restrict__ nbr,
                                               const PairParam* __restrict__ pairpar, int nt, const double2* __restrict__ etab, double inv_dx, int emax,
                                               const double* __restrict__ tt, const double* __restrict__ dtt, BoxDev box, double rc2,
                                               const int* __restrict__ perm, double* __restrict__ F, double* __restrict__ part_el,
-                                              double* __restrict__ part_vdw) {
+                                              double* __restrict__ part_vdw, int* __restrict__ prune_state, int* __restrict__ nbr2,
+                                              unsigned* __restrict__ count2, double4* __restrict__ posq_prune, double rp2, int N_all) {
   extern __shared__ PairParam sp[];
   for (int k = threadIdx.x; k < nt * nt; k += blockDim.x) sp[k] = pairpar[k];
   __shared__ double red[2][4];
@@ -75,12 +91,26 @@ __global__ __launch_bounds__(256) void k_pair(int i_lo, int N, const double4* __
   // contiguous chunk of sorted atoms per block, blocks in XCD-aware order (neighbourhoods of one slab stay in one L2)
   const int per_block = (N - i_lo + gridDim.x - 1) / gridDim.x;      // [i_lo, N): this rank's share of the sorted atoms
   const int i0 = i_lo + xcd_block(blockIdx.x, gridDim.x) * per_block, i1 = min(N, i0 + per_block);
+  const int mode = PRUNE ? __builtin_amdgcn_readfirstlane(prune_state[0]) : 0;
+  if (PRUNE && mode != 2) {      // snapshot of ALL positions (the displacement check runs over every atom, also when the rows are sharded over ranks)
+    const int all = N_all, chunk = (all + gridDim.x - 1) / gridDim.x, k0 = blockIdx.x * chunk, k1 = min(all, k0 + chunk);
+    for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x) posq_prune[k] = posq[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0) prune_state[2] = 1;      // seen by the NEXT step's k_top2_final: pruned rows exist for these full rows
+  }
   for (int i = i0 + wave; i < i1; i += wpb) {
     const double4 pi = posq[i];
     const int ti = type_s[i];
-    const unsigned s = nbr_start[i], e = s + nbr_count[i];
+    const unsigned s = nbr_start[i];
     double fx = 0.0, fy = 0.0, fz = 0.0;
-    pair_row<SAPT>(posq, pi, ti, s, e, lane, nbr, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, fx, fy, fz, e_el, e_vdw);
+    if (PRUNE && mode == 2) {
+      pair_row<SAPT>(posq, pi, ti, s, s + count2[i], lane, nbr2, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, fx, fy, fz, e_el, e_vdw);
+    } else if (PRUNE) {
+      unsigned n2 = 0;
+      pair_row<SAPT, true>(posq, pi, ti, s, s + nbr_count[i], lane, nbr, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, fx, fy, fz, e_el, e_vdw, nbr2 + s, rp2, &n2);
+      if (lane == 0) count2[i] = n2;
+    } else {
+      pair_row<SAPT>(posq, pi, ti, s, s + nbr_count[i], lane, nbr, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, fx, fy, fz, e_el, e_vdw);
+    }
     fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
     if (lane == 0) {
       const int o = perm[i];
@@ -188,11 +218,17 @@ int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw) {
     nblocks = round_up8((i_hi - i_lo + 7) / 8);      // 8 atoms per block, two per wave
     if (nblocks > 16384) nblocks = 16384;
     // force fields without a live SAPT term (every Buckingham coefficient zero, as in the CH3SO3H/H2O example) run the lean instantiation
-    auto kern = c->has_sapt ? k_pair<true> : k_pair<false>;
+    bool pr = c->prune && c->rc + c->prune_delta < c->rv;      // rolling pruned rows (a delta that reaches the list radius prunes nothing)
+    if (pr) {
+      if (c->d_nbr2.alloc(c->d_nbr.n) || c->d_nbr2_count.alloc(N) || c->d_posq_prune.alloc(N)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (pruned pair list)");
+      if (!c->d_prune_mode.p) CHK(nb_prune_reset(c));
+    }
+    auto kern = c->has_sapt ? (pr ? k_pair<true, true> : k_pair<true, false>) : (pr ? k_pair<false, true> : k_pair<false, false>);
+    const double rp = c->rc + c->prune_delta;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), c->nt * c->nt * sizeof(PairParam), c->stream, i_lo, i_hi, c->d_posq.p, c->d_type_sorted.p,
                        c->d_nbr_start.p, c->d_nbr_count.p, c->d_nbr.p, c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->erfc_grid, c->d_tt.p, c->d_dtt.p, box,
                        c->rc * c->rc, c->d_perm.p, c->d_force.p, c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS,
-                       c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS);
+                       c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS, c->d_prune_mode.p, c->d_nbr2.p, c->d_nbr2_count.p, c->d_posq_prune.p, rp * rp, N);
   }
   HIPCHK(hipGetLastError());
   phase_end(c, PH_PAIR);

@@ -439,6 +439,31 @@ def test_command_line_run_and_restart(tmp_path):
         run.main(args)
 
 
+@pytest.mark.parametrize("evb", [False, True])
+def test_rolling_pruned_pair_list_is_exact(evb):
+    """the pair loop runs on rows pruned to rc + delta and rewrites them whenever the two largest displacements since the last pruning
+    add up to delta: the set of pairs inside rc is always complete, so trajectories with and without pruning agree to rounding - also
+    with a tiny delta (re-pruned almost every step) and a delta beyond the list radius (never pruned)"""
+    g = golden("evb_n6_d4_s2")
+    spec = system.from_golden(g)
+    out = []
+    for prune, delta in ((0, 0.6), (1, 0.6), (1, 0.05), (1, 5.0)):
+        h = api.MsEvbHip(spec)
+        h.set_option("pair_prune", prune)
+        h.set_option("prune_delta", delta)
+        h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 21))
+        if evb:
+            h.ms_evb_calculate_total_force_energy(want_force=False)
+        else:
+            h.calculate_total_force_energy(want_force=False)
+        en = h.md_integrate_atomic(60, spec.delta_t, use_evb=evb)
+        out.append((en, h.get_positions(), h.get_forces()))
+        h.close()
+    for en, x, F in out[1:]:
+        assert np.abs(en - out[0][0]).max() < 1e-8 * np.abs(out[0][0]).max()
+        assert np.abs(x - out[0][1]).max() < 1e-9 and np.abs(F - out[0][2]).max() < 1e-6
+
+
 def test_rccl_communicator_of_one_rank():
     """the real collective path (ncclAllGather of the Hamiltonian entries on the side stream, in-place ncclAllReduce of the forces on
     the main stream) on a communicator of ONE rank: same force call, same trajectory as without a communicator"""

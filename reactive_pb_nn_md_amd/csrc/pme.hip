@@ -63,6 +63,9 @@ __global__ __launch_bounds__(256) void k_pme_spread(int N, int K, const double* 
 }
 
 
+__host__ __device__ inline int spread_plane_stride(int3 T) { const int rows = (T.x | 1) * T.y; return rows + (6 - rows % 16 + 16) % 16; }
+constexpr int SPREAD_CHUNK = 64;      // atoms of a cell staged in LDS at a time (10.5 KB)
+
 // LDS-tiled spread: one workgroup per neighbour cell (atoms are cell-sorted).  The cell's atoms scatter
 // their 216-point stencils into an LDS tile with ds_add_f64, the tile is flushed once with global fp64 atomics
 // (non-zero points only): ~20x fewer HBM atomics than one per stencil point.  Atoms that drifted out of the tile since the
@@ -75,38 +78,58 @@ __global__ __launch_bounds__(256) void k_pme_spread_tiles(int K, int3 nc, int3 T
   const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
   // tile origin: first grid point that can receive charge from an atom inside the cell, minus one point of drift margin
   const int ox = (int)floor((double)cx * K / nc.x) - 6, oy = (int)floor((double)cy * K / nc.y) - 6, oz = (int)floor((double)cz * K / nc.z) - 6;
-  const int ntile = T.x * T.y * T.z;
+  // row stride padded to an odd number of doubles: with T.x = 16 a row is exactly the 32 LDS banks wide and the 36 taps (k2,k3) of an
+  // atom, which differ only in their row, all hit the same two banks (111 us stand-alone, bank-conflict bound)
+  // ... and the plane stride to 6 (mod 16) doubles, which spreads the 6 x 6 taps of an atom evenly over the 16 double-wide bank pairs
+  const int P = T.x | 1, P2 = spread_plane_stride(T);
+  const int ntile = P2 * T.z;
   for (int k = threadIdx.x; k < ntile; k += blockDim.x) tile[k] = 0.0;
-  __syncthreads();
+  // per-atom inputs of a chunk of the cell's atoms are staged in LDS first: the scatter loop then has no global loads (it used to wait
+  // for six dependent weight loads per item at < 3 waves per SIMD - latency bound, 90 us)
+  double* sw = tile + ntile;                         // [SPREAD_CHUNK][18] weights (3 axes x 6 taps)
+  double* sq = sw + SPREAD_CHUNK * 18;               // [SPREAD_CHUNK] charges
+  int* sb = (int*)(sq + SPREAD_CHUNK);               // [SPREAD_CHUNK][3] base grid points
   const int s = cell_start[cidx], e = cell_start[cidx + 1];
-  for (int t = threadIdx.x; t < (e - s) * 36; t += blockDim.x) {
-    const int i = perm[s + t / 36], r = t % 36, k3 = r / 6, k2 = r % 6;
-    const double q = chg[i];
-    if (q == 0.0) continue;
-    const int b1 = base[3 * i], b2 = base[3 * i + 1], b3 = base[3 * i + 2];
-    int l3 = (b3 - k3 - oz) % K; if (l3 < 0) l3 += K;
-    int l2 = (b2 - k2 - oy) % K; if (l2 < 0) l2 += K;
-    const double w23 = q * w[(3 * i + 1) * 6 + k2] * w[(3 * i + 2) * 6 + k3];
-    for (int k1 = 0; k1 < 6; ++k1) {
-      int l1 = (b1 - k1 - ox) % K; if (l1 < 0) l1 += K;
-      const double v = q * w[(3 * i) * 6 + k1] * w[(3 * i + 1) * 6 + k2] * w[(3 * i + 2) * 6 + k3];
-      if (l1 < T.x && l2 < T.y && l3 < T.z) atomicAdd(&tile[l1 + T.x * (l2 + T.y * l3)], v);
-      else {
-        int n1 = b1 - k1; if (n1 < 0) n1 += K;
-        int n2 = b2 - k2; if (n2 < 0) n2 += K;
-        int n3 = b3 - k3; if (n3 < 0) n3 += K;
-        atomicAdd(&grid[n1 + (size_t)K * (n2 + (size_t)K * n3)].x, v);
+  for (int c0 = s; c0 < e; c0 += SPREAD_CHUNK) {
+    const int n = min(SPREAD_CHUNK, e - c0);
+    __syncthreads();      // tile zeroed / previous chunk consumed
+    for (int k = threadIdx.x; k < n * 18; k += blockDim.x) { const int a = k / 18, r = k - 18 * a; sw[k] = w[(size_t)perm[c0 + a] * 18 + r]; }
+    for (int k = threadIdx.x; k < n * 3; k += blockDim.x) { const int a = k / 3, r = k - 3 * a; sb[k] = base[3 * perm[c0 + a] + r]; }
+    for (int a = threadIdx.x; a < n; a += blockDim.x) sq[a] = chg[perm[c0 + a]];
+    __syncthreads();
+    for (int t = threadIdx.x; t < n * 36; t += blockDim.x) {
+      const int a = t / 36, r = t % 36, k3 = r / 6, k2 = r % 6;
+      const double q = sq[a];
+      if (q == 0.0) continue;
+      const int b1 = sb[3 * a], b2 = sb[3 * a + 1], b3 = sb[3 * a + 2];
+      // tile-local coordinates: base - tap - origin lies in (-K, K + 12): one conditional add and one conditional subtract wrap it
+      int l3 = b3 - k3 - oz; l3 += l3 < 0 ? K : 0; l3 -= l3 >= K ? K : 0;
+      int l2 = b2 - k2 - oy; l2 += l2 < 0 ? K : 0; l2 -= l2 >= K ? K : 0;
+      const bool in23 = l2 < T.y && l3 < T.z;
+      double* trow = tile + P * l2 + P2 * l3;
+      const double w2 = sw[18 * a + 6 + k2], w3 = sw[18 * a + 12 + k3];
+      int l1 = b1 - ox; l1 += l1 < 0 ? K : 0; l1 -= l1 >= K ? K : 0;      // tap 0; the taps walk down with wrap-around
+      for (int k1 = 0; k1 < 6; ++k1) {
+        const double v = q * sw[18 * a + k1] * w2 * w3;
+        if (in23 && l1 < T.x) atomicAdd(&trow[l1], v);
+        else {      // the atom drifted out of the tile since the last list build: straight to the grid
+          int n1 = b1 - k1; if (n1 < 0) n1 += K;
+          int n2 = b2 - k2; if (n2 < 0) n2 += K;
+          int n3 = b3 - k3; if (n3 < 0) n3 += K;
+          atomicAdd(&grid[n1 + (size_t)K * (n2 + (size_t)K * n3)].x, v);
+        }
+        l1 = l1 == 0 ? K - 1 : l1 - 1;
       }
     }
-    (void)w23;
   }
   __syncthreads();
   for (int k = threadIdx.x; k < ntile; k += blockDim.x) {
     const double v = tile[k];
-    if (v != 0.0) {
-      int n1 = (ox + k % T.x) % K; if (n1 < 0) n1 += K;
-      int n2 = (oy + (k / T.x) % T.y) % K; if (n2 < 0) n2 += K;
-      int n3 = (oz + k / (T.x * T.y)) % K; if (n3 < 0) n3 += K;
+    if (v != 0.0) {      // padding points stay zero
+      const int r = k % P2;
+      int n1 = (ox + r % P) % K; if (n1 < 0) n1 += K;
+      int n2 = (oy + r / P) % K; if (n2 < 0) n2 += K;
+      int n3 = (oz + k / P2) % K; if (n3 < 0) n3 += K;
       atomicAdd(&grid[n1 + (size_t)K * (n2 + (size_t)K * n3)].x, v);
     }
   }
@@ -320,7 +343,7 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
     {
       int3 T;
       T.x = (int)ceil((double)K / c->ncell[0]) + 8; T.y = (int)ceil((double)K / c->ncell[1]) + 8; T.z = (int)ceil((double)K / c->ncell[2]) + 8;
-      const size_t tile_bytes = (size_t)T.x * T.y * T.z * sizeof(double);
+      const size_t tile_bytes = (size_t)spread_plane_stride(T) * T.z * sizeof(double) + (size_t)SPREAD_CHUNK * (18 * 8 + 8 + 12);      // tile + staged atom inputs
       if (c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= K && T.y <= K && T.z <= K) {
         const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
         hipLaunchKernelGGL(k_pme_spread_tiles, dim3(ncell), dim3(256), tile_bytes, st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T,

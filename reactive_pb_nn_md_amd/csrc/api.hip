@@ -472,10 +472,11 @@ int total_force_enqueue(msevb_ctx* c) {
     HIPCHK(aux_fork(c));
     if (rebuild) CHK(nb_build_finish(c, true));                      // main: list rows first (the longest chain of a rebuild step: rows, then the pair loop)
     CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));                    // main: the pair loop (longest) goes out first
-    CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux2));      // aux2: per-molecule terms (few, long threads)
+    CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux3));      // aux3: per-molecule terms (few, long threads); aux2 stays free for the
+                                                                     // EVB descriptors + environment chain, which the host enqueues next
     CHK(pme_front(c, S_RECIP, true));                                // aux: stencils, spreading, FFTs, convolution
     CHK(pme_tail(c, true));                                          // main: wait for aux, gather (skipped by the EVB fast path)
-    HIPCHK(hipEventRecord(c->ev_join2, c->aux2));
+    HIPCHK(hipEventRecord(c->ev_join2, c->aux3));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
   } else {
     if (rebuild) CHK(nb_build_finish(c, true));

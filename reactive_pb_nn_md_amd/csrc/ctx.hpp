@@ -343,6 +343,7 @@ inline hipError_t aux_fork(msevb_ctx* c) {     // both side streams continue fro
   hipError_t e = hipEventRecord(c->ev_fork, c->stream);
   if (e == hipSuccess) e = hipStreamWaitEvent(c->aux, c->ev_fork, 0);
   if (e == hipSuccess) e = hipStreamWaitEvent(c->aux2, c->ev_fork, 0);
+  if (e == hipSuccess) e = hipStreamWaitEvent(c->aux3, c->ev_fork, 0);
   return e;
 }
 inline hipError_t aux_join(msevb_ctx* c) {     // the main stream waits for what both side streams hold so far

@@ -761,7 +761,11 @@ __global__ void k_evb_publish(const double* __restrict__ a, int na, double* __re
 }
 
 // publishes the record count of k_evb_region to pinned host memory
-__global__ void k_evb_publish_count(const int* __restrict__ counter, int* __restrict__ host_count) { *host_count = *counter; }
+__global__ void k_evb_publish_count(const int* __restrict__ counter, int* __restrict__ host_count, volatile long long* flag, long long seq) {
+  *host_count = *counter;
+  __threadfence_system();      // the records k_evb_region wrote to pinned memory on this stream are visible before the flag
+  *flag = seq;
+}
 
 __global__ void k_sum_rows(int nrow, int ncol, int stride, const double* __restrict__ part, double* __restrict__ out) {
   const int r = blockIdx.x;
@@ -792,7 +796,7 @@ struct EvbWork {   // persistent device scratch of one context
   DBuf<double> d_F11, d_pack, d_com_atom;
   hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
   RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
-  long long* h_flag = nullptr; long long seq_A = 0;      // pinned: sequence number of the last published fetch A
+  long long* h_flag = nullptr; long long seq_A = 0, seq_R = 0, seq_B = 0;      // pinned: sequence number of the last published fetch A
   DBuf<double> d_coef; double* h_solve = nullptr; size_t h_solve_cap = 0; hipEvent_t ev_solve = nullptr;      // device-side Hamiltonian solve (k_evb_solve)
   char* h_desc = nullptr; DBuf<char> d_desc; size_t desc_cap = 0;   // units | couplings | recip atoms, one pinned block -> one upload
   double* h_E = nullptr; size_t hE_cap = 0;                         // pinned
@@ -982,6 +986,20 @@ static double blend_terms(const msevb_ctx* c, int D, const double* ev, BlendTerm
   }
   return (c->rank == 0 || (c->shard_principal && c->n_ranks > 1)) ? 1.0 : 0.0;      // sharded principal: every rank holds a part of F11
 }
+// The host waits for small results (neighbourhood record, energies) by spinning on a sequence number the producing kernel writes to
+// pinned memory behind its data: hipEventSynchronize sleeps on an interrupt and needs 50-100 us to wake up, a spin sees the store in
+// ~2 us.  The event stays the fallback (a kernel that failed never writes; the event reports the error).
+static int spin_wait(volatile long long* flag, long long seq, hipEvent_t ev) {
+  const auto t0 = std::chrono::steady_clock::now();
+  long spins = 0;
+  while (*flag != seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+  }
+  if (*flag != seq && hipEventSynchronize(ev) != hipSuccess) return -1;
+  return 0;
+}
+
 // Fast-path blend of THIS rank's share for the ground-state vector ev: one gather of the blended potential of its grids (+ the principal
 // one on rank 0), the special atoms' corrections into the delta store, then the blend of delta / off-diagonal stores.  c->d_force holds
 // (this rank's part of) F11 on entry and the rank's partial Hellmann-Feynman force on exit.
@@ -1059,7 +1077,8 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_in, 0));
   hipLaunchKernelGGL(k_evb_region, dim3((M + 255) / 256), dim3(256), 0, w->stream2, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
                      c->d_mass.p, box, w->d_counter.p, w->d_region.p, REGION_CAP, w->d_counter.p + 1, w->h_region, REGION_FAST);
-  hipLaunchKernelGGL(k_evb_publish_count, dim3(1), dim3(1), 0, w->stream2, w->d_counter.p, w->h_count);
+  if (!w->h_flag) { HIPCHK(hipHostMalloc((void**)&w->h_flag, 64, hipHostMallocDefault)); memset(w->h_flag, 0, 64); }
+  hipLaunchKernelGGL(k_evb_publish_count, dim3(1), dim3(1), 0, w->stream2, w->d_counter.p, w->h_count, (volatile long long*)(w->h_flag + 1), ++w->seq_R);
   HIPCHK(hipEventRecord(w->ev_region, w->stream2));
   HT(1);
   // ---- 2. principal diabat (calculate_total_force_energy, src/ms_evb.f90:411) - enqueued, not waited for
@@ -1070,7 +1089,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   c->shard_now = false; c->skip_gather_now = false;
   CHK(rc_tfe);
   HT(2);
-  HIPCHK(hipEventSynchronize(w->ev_region));
+  if (spin_wait((volatile long long*)(w->h_flag + 1), w->seq_R, w->ev_region)) HIPCHK(hipErrorUnknown);
   const int nreg = *w->h_count;
   if (nreg > REGION_CAP) FAIL(MSEVB_ERR_LIMIT, "EVB neighbourhood buffer too small");
   w->region.resize(nreg);
@@ -1370,7 +1389,6 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
       HIPCHK(hipEventRecord(w->ev_solve, ss));
       return MSEVB_OK;
     }
-    if (!w->h_flag) { HIPCHK(hipHostMalloc((void**)&w->h_flag, 64, hipHostMallocDefault)); *w->h_flag = 0; }
     hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, ss, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, ++w->seq_A);
     HIPCHK(hipGetLastError());
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, ss));
@@ -1379,7 +1397,8 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   auto fetch_B = [&]() -> int {      // principal energy slots + Verlet displacement flag (main stream, behind the pair loop)
     CHK(flush_reductions(c));
     if (c->overlap) { HIPCHK(hipEventRecord(w->ev_flush, c->stream)); HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_flush, 0)); }
-    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, ss, c->d_energies.p, (int)N_SLOTS, c->h_energies, (const double*)nullptr, 0, (double*)nullptr);
+    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, ss, c->d_energies.p, (int)N_SLOTS, c->h_energies, (const double*)nullptr, 0, (double*)nullptr,
+                       (volatile long long*)(w->h_flag + 2), ++w->seq_B);
     HIPCHK(hipGetLastError());
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetch, ss));
     return MSEVB_OK;
@@ -1439,15 +1458,8 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   HT(8);
   // ---- 9. Hamiltonian without the principal diabat's energy (H' = H - E0 I), from fetch A (or from the device-side solve)
   if (dev_solve) HIPCHK(hipEventSynchronize(w->ev_solve));
-  else if (c->overlap) {      // spin on the publish kernel's sequence number (an event wait costs the host 10-20 us to wake up); the event is the fallback
-    volatile long long* f = (volatile long long*)w->h_flag;
-    const auto t0 = std::chrono::steady_clock::now();
-    long spins = 0;
-    while (*f != w->seq_A) {
-      __builtin_ia32_pause();
-      if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;      // a failed kernel never writes: let the event report it
-    }
-    if (*f != w->seq_A) HIPCHK(hipEventSynchronize(w->ev_fetchA));
+  else if (c->overlap) {
+    if (spin_wait((volatile long long*)w->h_flag, w->seq_A, w->ev_fetchA)) HIPCHK(hipErrorUnknown);
   } else HIPCHK(hipStreamSynchronize(c->stream));
   const double E_recip1 = dev_solve ? 0.0 : w->h_E[nE];                  // this rank's own (complete) principal reciprocal energy
   const bool sharded = c->shard_principal && c->n_ranks > 1;
@@ -1477,7 +1489,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   bool energies_in = false;
   if (c->nccl_comm) {
     if (sharded) {      // the ranks' partial principal energies travel with the Hamiltonian entries
-      if (c->overlap) HIPCHK(hipEventSynchronize(w->ev_fetch)); else HIPCHK(hipStreamSynchronize(c->stream));
+      if (c->overlap) { if (spin_wait((volatile long long*)(w->h_flag + 2), w->seq_B, w->ev_fetch)) HIPCHK(hipErrorUnknown); } else HIPCHK(hipStreamSynchronize(c->stream));
       if (c->rank != 0) c->h_energies[S_RECIP] = 0.0;      // replicated term: counts once
       energies_in = true;
     }
@@ -1485,7 +1497,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   }
   // E0 = potential energy of the principal diabat (fetch B); added to the diagonal and to the eigenvalue
   auto principal_energy = [&](double& E0) -> int {
-    if (c->overlap) HIPCHK(hipEventSynchronize(w->ev_fetch)); else HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->overlap) { if (spin_wait((volatile long long*)(w->h_flag + 2), w->seq_B, w->ev_fetch)) HIPCHK(hipErrorUnknown); } else HIPCHK(hipStreamSynchronize(c->stream));
     if (nb_check_overflow(c)) return MSEVB_RETRY;      // a list row outgrew its stride in this call's rebuild: the whole force call is repeated
     if (sharded && !energies_in && c->rank != 0) c->h_energies[S_RECIP] = 0.0;      // sharded principal diabat: replicated terms count once (rank 0)
     double en[MSEVB_N_ENERGY];

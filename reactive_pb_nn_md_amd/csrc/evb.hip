@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void k_evb_recip_special(int n, const RecipAto
     const double s = q * conv, Kd = (double)K;
     tot[0] += -Kd * (k00 * f1 + k10 * f2 + k20 * f3) * s; tot[1] += -Kd * (k01 * f1 + k11 * f2 + k21 * f3) * s; tot[2] += -Kd * (k02 * f1 + k12 * f2 + k22 * f3) * s;
   }
-  if (lane == 0) { double* F = Fstore + (size_t)r.slot * fstride; for (int d = 0; d < 3; ++d) F[3 * r.idx + d] += tot[d]; }
+  if (lane == 0) { double* F = Fstore + (size_t)r.slot * fstride; for (int d = 0; d < 3; ++d) atomicAdd(&F[3 * r.idx + d], tot[d]); }      // beside k_evb_env / k_evb_special
 }
 
 // centre of mass of every molecule, stored per ATOM (coalesced reads in k_evb_coupling, which takes the minimum image per molecule)
@@ -792,7 +792,7 @@ struct EvbWork {   // persistent device scratch of one context
   DBuf<double> d_part, d_E, d_dVspec; DBuf<int> d_sbase, d_counter; DBuf<double> d_sw, d_sdw;
   DBuf<double2> d_grids; DBuf<RegionRec> d_region; DBuf<int> d_cand;
   DBuf<double> d_Fdelta;      // [n_diag][3N] real-space deltas of the diabats, accumulated on stream2 beside the reciprocal space
-  hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_E = nullptr, ev_fetch = nullptr, ev_cpl = nullptr, ev_flush = nullptr, ev_fetchA = nullptr; bool delta_dirty = true;
+  hipEvent_t ev_rs = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_E = nullptr, ev_fetch = nullptr, ev_cpl = nullptr, ev_flush = nullptr, ev_fetchA = nullptr; bool delta_dirty = true;
   DBuf<double> d_F11, d_pack, d_com_atom;
   hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
   RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
@@ -1026,11 +1026,10 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   if (w->d_pack.alloc(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended potential)");
   hipLaunchKernelGGL(k_evb_blend_grids, dim3(1024), dim3(256), 0, c->stream, K3, gc, dcoef, c->d_theta.p, w->d_grids.p, w->d_pack.p);
   CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p));
-  // ... the special atoms' own-stencil corrections per diabat go to the delta store, which the blend consumes and re-zeroes
-  if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0));
-  if (ngrid) hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, c->stream, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
-                                w->d_sw.p, w->d_sdw.p, w->d_grids.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0],
-                                c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3);
+  // ... the special atoms' own-stencil corrections per diabat are in the delta store already (k_evb_recip_special ran at the end of the
+  // diabat grid chain, before the host's turn); the blend consumes the store and re-zeroes it
+  if (c->overlap) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0)); if (ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_rs, 0)); }
+  (void)nra; (void)d_ra;
   hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, dcoef ? dcoef + 1 + ngrid : (const double*)nullptr, w11, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p, 1);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
@@ -1062,6 +1061,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipEventCreateWithFlags(&w->ev_fetchA, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_solve, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_E, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&w->ev_rs, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w->ev_fetch, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&w->h_region, REGION_FAST * sizeof(RegionRec), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&w->h_count, 64, hipHostMallocDefault));
@@ -1419,6 +1419,12 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   }
   phase_end(c, PH_EVB_RECIP, sg);
   CHK(fetch_A());
+  if (fast && ngrid) {      // own-stencil corrections of the special atoms -> delta store; behind the energy fetch on this stream: the host's turn does not wait for it
+    hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, sg, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
+                       w->d_sw.p, w->d_sdw.p, w->d_grids.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0],
+                       c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3);
+    if (c->overlap) HIPCHK(hipEventRecord(w->ev_rs, sg));
+  }
   CHK(fetch_B());
   if (!fast) {      // per-element force stores (msevb_get_evb_element_force, sharding tests)
     if (ngrid) {
@@ -1590,7 +1596,7 @@ void evb_release(msevb_ctx* c) {
     DBuf<double>* db[] = {&w->d_exch, &w->d_part, &w->d_E, &w->d_dVspec, &w->d_sw, &w->d_sdw, &w->d_Fdelta, &w->d_F11, &w->d_pack, &w->d_com_atom};
     for (auto b : db) b->release();
     w->d_tabs.release(); w->d_sbase.release(); w->d_counter.release(); w->d_grids.release(); w->d_region.release(); w->d_cand.release(); w->d_desc.release();
-    hipEvent_t* ev[] = {&w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA, &w->ev_solve};
+    hipEvent_t* ev[] = {&w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA, &w->ev_solve, &w->ev_rs};
     for (auto e : ev) if (*e) (void)hipEventDestroy(*e);
     if (w->h_region) (void)hipHostFree(w->h_region);
     if (w->h_count) (void)hipHostFree(w->h_count);

@@ -143,6 +143,7 @@ def main():
         h.set_option(k, float(v))
     h.set_option("phase_timing", 0.0 if args.no_phase_timing else 1.0)      # HIP events on the library's stream around every phase (live roofline input)
     h.L.msevb_reset_phase_times(h.ctx)
+    D_start = int(h.evb_state()["D"]) if use_evb else 1      # diabats when the timed region starts (the planted tree of the hot lattice box dissolves over time)
     barrier()
     t0 = time.perf_counter()
     en = h.md_integrate_atomic(args.steps, spec.delta_t, use_evb=use_evb)
@@ -155,7 +156,8 @@ def main():
         dt = float(t[0])
     phases = h.phase_times()
     st = h.evb_state() if use_evb else {"D": 1}
-    D = int(st["D"])
+    D_end = int(st["D"])
+    D = D_start
     vp_n = C.c_long()
     h._chk(h.L.msevb_get_verlet_list(h.ctx, None, None, C.byref(vp_n)))
     D_local = 1 + sum(1 for d in range(1, D) if (d - 1) % world == rank)
@@ -190,7 +192,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "CH3SO3H/H2O box %d atoms, %d diabats, %d^3 PME grid, r_c 9.0 / r_v 10.5 A, dt 0.5 fs, NVE, %s force call"
                                    % (spec.n_atom, D, spec.pme_grid, "MS-EVB" if use_evb else "non-EVB"),
-                       "n_atoms": spec.n_atom, "n_diabats": D, "pme_grid": spec.pme_grid, "parallelism": "diabats sharded over %d GPU(s)" % world},
+                       "n_atoms": spec.n_atom, "n_diabats": D, "n_diabats_at_end": D_end, "pme_grid": spec.pme_grid, "parallelism": "diabats sharded over %d GPU(s)" % world},
             "roofline": roofline,
             "step_roofline": {"algorithmic_bytes_per_step": int(b_step), "achieved_GBs": round(b_step / (dt / args.steps) / 1e9, 2),
                               "frac_of_hbm_peak": round(b_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},

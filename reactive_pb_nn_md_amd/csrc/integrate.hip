@@ -54,9 +54,34 @@ __global__ void k_remove_momentum(int N, const double* __restrict__ mass, const 
 // Fused step kernels of the device-resident MD loop -----------------------------------------------------------------------------
 // first half: one thread per molecule - removal of the centre-of-mass momentum measured at the end of the previous step (:125-177),
 // half kick + drift of the molecule's atoms (:469-486), then the molecule is shifted back into the box by its centre of mass
+// remove == 2: the momentum is summed HERE from the per-block partial sums the previous step's second kernel left (every block sums them
+// again - 3 x nb numbers - which takes the reduction kernel and the 56-byte download out of the chain in front of the pair loop); block 0
+// also finishes the kinetic-energy / velocity sums of that step and posts all seven to `post` (pinned host memory) and to the energy slots.
 __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt, int remove, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms,
-                                                         const double* __restrict__ mass, const double* __restrict__ F, const double* __restrict__ en,
-                                                         double* __restrict__ v, double* __restrict__ x, BoxDev box, Langevin L) {
+                                                         const double* __restrict__ mass, const double* __restrict__ F, double* __restrict__ en,
+                                                         double* __restrict__ v, double* __restrict__ x, BoxDev box, Langevin L,
+                                                         const double* __restrict__ part, int nb, double* __restrict__ post) {
+  __shared__ double red[256];
+  __shared__ double tot[7];
+  double P[3] = {0.0, 0.0, 0.0};
+  if (remove == 2) {
+    const int slot[7] = {S_PX, S_PY, S_PZ, S_KE, S_VX, S_VY, S_VZ};
+    const int nq = blockIdx.x == 0 ? 7 : 3;
+    for (int q = 0; q < nq; ++q) {
+      double s = 0.0;
+      for (int k = threadIdx.x; k < nb; k += 256) s += part[(size_t)slot[q] * MAX_BLOCKS + k];
+      red[threadIdx.x] = s;
+      __syncthreads();
+      for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+      if (threadIdx.x == 0) tot[q] = red[0];
+      __syncthreads();
+    }
+    for (int d = 0; d < 3; ++d) P[d] = tot[d];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      en[S_PX] = tot[0]; en[S_PY] = tot[1]; en[S_PZ] = tot[2]; en[S_KE] = tot[3]; en[S_VX] = tot[4]; en[S_VY] = tot[5]; en[S_VZ] = tot[6];
+      if (post) { post[0] = tot[3]; post[1] = tot[0]; post[2] = tot[1]; post[3] = tot[2]; post[4] = tot[4]; post[5] = tot[5]; post[6] = tot[6]; }      // order of the slots S_KE..S_VZ
+    }
+  } else if (remove == 1) { P[0] = en[S_PX]; P[1] = en[S_PY]; P[2] = en[S_PZ]; }
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   const int n = mol_natom[m];
@@ -68,7 +93,7 @@ __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt
     if (L.on) normal3(L, a, z);
     for (int d = 0; d < 3; ++d) {
       double vv = v[3 * a + d];
-      if (remove) vv -= en[S_PX + d] / (double)N / ma;
+      if (remove) vv -= P[d] / (double)N / ma;
       if (L.on) vv = L.a * vv + L.b * F[3 * a + d] / ma + L.c / sqrt(ma) * z[d];
       else vv = vv + dt / 2.0 / ma * F[3 * a + d] * 100.0;
       v[3 * a + d] = vv;
@@ -168,8 +193,10 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
   for (int s = 0; s < n_steps; ++s) {
     phase_begin(c, PH_INTEGRATE);
     L.kick = c->langevin_tick++;
-    hipLaunchKernelGGL(k_step_first_half, dim3(nbm), dim3(256), 0, c->stream, M, N, dt, s > 0 ? 1 : 0, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_mass.p, c->d_force.p,
-                       c->d_energies.p, c->d_vel.p, c->d_xyz.p, box, L);
+    // EVB loop (no host synchronisation of its own): from the second step on the kernel reduces the previous step's partial sums itself
+    const bool self_reduce = use_evb && s > 0;
+    hipLaunchKernelGGL(k_step_first_half, dim3(nbm), dim3(256), 0, c->stream, M, N, dt, self_reduce ? 2 : (s > 0 ? 1 : 0), c->d_mol_natom.p, c->d_mol_atoms.p, c->d_mass.p,
+                       c->d_force.p, c->d_energies.p, c->d_vel.p, c->d_xyz.p, box, L, c->d_partials.p, nba, self_reduce ? h_ke + 7 * (size_t)(s - 1) : (double*)nullptr);
     phase_end(c, PH_INTEGRATE);
     double epot = 0.0;
     if (use_evb) { CHK(evb_force_energy(c, &epot)); }
@@ -184,11 +211,15 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
     L.kick = c->langevin_tick++;
     hipLaunchKernelGGL(k_step_second_half, dim3(nba), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p, c->d_partials.p, L);
     HIPCHK(hipGetLastError());
-    CHK(reduce_partials(c, S_PX, nba)); CHK(reduce_partials(c, S_PY, nba)); CHK(reduce_partials(c, S_PZ, nba)); CHK(reduce_partials(c, S_KE, nba));
-    CHK(reduce_partials(c, S_VX, nba)); CHK(reduce_partials(c, S_VY, nba)); CHK(reduce_partials(c, S_VZ, nba));
+    if (!use_evb || s == n_steps - 1) {      // (inside the EVB loop the next step's first kernel does this)
+      CHK(reduce_partials(c, S_PX, nba)); CHK(reduce_partials(c, S_PY, nba)); CHK(reduce_partials(c, S_PZ, nba)); CHK(reduce_partials(c, S_KE, nba));
+      CHK(reduce_partials(c, S_VX, nba)); CHK(reduce_partials(c, S_VY, nba)); CHK(reduce_partials(c, S_VZ, nba));
+    }
     if (use_evb) {
-      CHK(flush_reductions(c));
-      HIPCHK(hipMemcpyAsync(h_ke + 7 * (size_t)s, c->d_energies.p + S_KE, 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      if (s == n_steps - 1) {
+        CHK(flush_reductions(c));
+        HIPCHK(hipMemcpyAsync(h_ke + 7 * (size_t)s, c->d_energies.p + S_KE, 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      }
       if (energies_out) energies_out[2 * s] = epot;
     } else {
       CHK(fetch_energies(c));   // one host synchronisation per step: energies + Verlet flag

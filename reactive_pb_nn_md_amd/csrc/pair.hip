@@ -221,7 +221,8 @@ int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw) {
     bool pr = c->prune && c->rc + c->prune_delta < c->rv;      // rolling pruned rows (a delta that reaches the list radius prunes nothing)
     if (pr) {
       if (c->d_nbr2.alloc(c->d_nbr.n) || c->d_nbr2_count.alloc(N) || c->d_posq_prune.alloc(N)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (pruned pair list)");
-      if (!c->d_prune_mode.p) CHK(nb_prune_reset(c));
+      // the pruned rows cover the atom range of the launch that wrote them: another range (sharded EVB call <-> full call) starts over
+      if (!c->d_prune_mode.p || c->prune_lo != i_lo || c->prune_hi != i_hi) { CHK(nb_prune_reset(c)); c->prune_lo = i_lo; c->prune_hi = i_hi; }
     }
     auto kern = c->has_sapt ? (pr ? k_pair<true, true> : k_pair<true, false>) : (pr ? k_pair<false, true> : k_pair<false, false>);
     const double rp = c->rc + c->prune_delta;

@@ -224,6 +224,7 @@ def test_sharded_principal_partial_sums(n_ranks, stores):
     h = api.MsEvbHip(spec)
     _e, Fblend = h.ms_evb_calculate_total_force_energy()
     full = h.evb_state()
+    en_full, F_full = h.calculate_total_force_energy()
     h.close()
     Fsum, Esum = np.zeros_like(Fblend), 0.0
     for r in range(n_ranks):
@@ -234,6 +235,9 @@ def test_sharded_principal_partial_sums(n_ranks, stores):
         e_part, _ = hr.ms_evb_calculate_total_force_energy(want_force=False)      # virtual ranks return their share of H11
         Esum += e_part
         Fsum += hr.evb_partial_blend(full["eigvec"])
+        # a full (unsharded) force call on the same context afterwards: the pruned pair rows of the rank's atom range must not be reused
+        en_r, F_r = hr.calculate_total_force_energy()
+        assert rel(en_r["potential"], en_full["potential"]) < 1e-13 and np.abs(F_r - F_full).max() < 1e-10
         hr.close()
     assert np.abs(Fsum - Fblend).max() < 1e-10
     assert rel(Esum, full["H"][0, 0]) < 1e-13

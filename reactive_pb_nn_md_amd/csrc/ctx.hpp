@@ -238,8 +238,8 @@ struct msevb_ctx {
   int plan_batch = 0;
   bool spread_tiles = true;
   bool has_sapt = false;     // some (type_i,type_j) entry has non-zero SAPT coefficients
-  rocfft_execution_info fft_info = nullptr;
-  DBuf<char> d_fft_work;
+  rocfft_execution_info fft_info = nullptr, fft_info_b = nullptr;      // single-grid plans (their work buffer is baked into the captured PME graph) / batched plans
+  DBuf<char> d_fft_work, d_fft_work_b;
   int fft_batch = 1;
   // reductions
   DBuf<double> d_partials;     // [n_slots][MAX_BLOCKS]

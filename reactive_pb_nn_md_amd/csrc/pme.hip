@@ -251,6 +251,7 @@ void pme_teardown(msevb_ctx* c) {
   if (c->plan_bwd_b) { rocfft_plan_destroy(c->plan_bwd_b); c->plan_bwd_b = nullptr; }
   c->plan_batch = 0;
   if (c->fft_info) { rocfft_execution_info_destroy(c->fft_info); c->fft_info = nullptr; }
+  if (c->fft_info_b) { rocfft_execution_info_destroy(c->fft_info_b); c->fft_info_b = nullptr; }
 }
 
 // theta_g = IFFT(CB * FFT(grid_g)) in place for `batch` contiguous grids; the energy partials of grid g go to
@@ -269,22 +270,26 @@ int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part
       FFTCHK(rocfft_plan_get_work_buffer_size(c->plan_fwd_b, &wf));
       FFTCHK(rocfft_plan_get_work_buffer_size(c->plan_bwd_b, &wb));
       if (wb > wf) wf = wb;
-      if (wf > c->d_fft_work.n) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (c->d_fft_work.alloc(wf)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (FFT work buffer)");
+      // the batched plans have their OWN work buffer and execution info: growing a shared buffer would free the one whose address the
+      // captured graph of the single-grid front end replays with (K = 128 needs work buffers; K = 64 does not - config C faulted here)
+      if (!c->fft_info_b) FFTCHK(rocfft_execution_info_create(&c->fft_info_b));
+      if (wf > c->d_fft_work_b.n) {
+        HIPCHK(hipDeviceSynchronize());
+        if (c->d_fft_work_b.alloc(wf)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (FFT work buffer)");
       }
-      if (c->d_fft_work.n) FFTCHK(rocfft_execution_info_set_work_buffer(c->fft_info, c->d_fft_work.p, c->d_fft_work.n));
+      if (c->d_fft_work_b.n) FFTCHK(rocfft_execution_info_set_work_buffer(c->fft_info_b, c->d_fft_work_b.p, c->d_fft_work_b.n));
       c->plan_batch = batch;
     }
     pf = c->plan_fwd_b; pb = c->plan_bwd_b;
   }
   void* buf[1] = {grids};
-  FFTCHK(rocfft_execution_info_set_stream(c->fft_info, pme_stream(c)));
-  FFTCHK(rocfft_execute(pf, buf, nullptr, c->fft_info));
+  rocfft_execution_info info = batch > 1 ? c->fft_info_b : c->fft_info;
+  FFTCHK(rocfft_execution_info_set_stream(info, pme_stream(c)));
+  FFTCHK(rocfft_execute(pf, buf, nullptr, info));
   int nb = (int)((K3 + 255) / 256);
   if (nb > 512) nb = 512;
   hipLaunchKernelGGL(k_pme_conv, dim3(nb, batch), dim3(256), 0, pme_stream(c), K3, c->d_CB.p, grids, part_stride, part, 0.5 * c->conv);
-  FFTCHK(rocfft_execute(pb, buf, nullptr, c->fft_info));
+  FFTCHK(rocfft_execute(pb, buf, nullptr, info));
   HIPCHK(hipGetLastError());
   if (nblocks) *nblocks = nb;
   return MSEVB_OK;
@@ -324,7 +329,7 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
   // The front end is the same ~14 launches with the same arguments every step (all its inputs live at fixed device addresses): on the
   // side stream it is captured once into a hipGraph and replayed with one launch (the ~14 launches cost the host ~80 us per step, and
   // the host is what decides when the EVB chains behind them can start).  Steps that sample the phase timers launch directly.
-  struct Key { const void* p[8]; int v[8]; } key = {{c->d_grid.p, c->d_Q.p, c->d_theta.p, c->d_w.p, c->d_base.p, c->d_cell_start.p, c->d_perm.p, c->d_chg.p},
+  struct Key { const void* p[9]; int v[8]; } key = {{c->d_grid.p, c->d_Q.p, c->d_theta.p, c->d_w.p, c->d_base.p, c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_fft_work.p},
                                                {N, K, c->ncell[0], c->ncell[1], c->ncell[2], c->cells_valid ? 1 : 0, c->spread_tiles ? 1 : 0, slot_recip}};
   const bool use_graph = join_aux && c->graphs && !c->timing_now;
   bool capturing = false;

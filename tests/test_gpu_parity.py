@@ -468,6 +468,24 @@ def test_rolling_pruned_pair_list_is_exact(evb):
         assert np.abs(x - out[0][1]).max() < 1e-9 and np.abs(F - out[0][2]).max() < 1e-6
 
 
+def test_large_pme_grid_graph_replay_with_batched_diabat_ffts():
+    """128^3 grid: rocFFT needs work buffers.  The single-grid front end is replayed from a captured hipGraph (its work buffer address
+    is baked in) while the diabat grids use batched plans with a larger work buffer of their own - sharing one buffer freed the
+    captured one when the batched plans grew it (SURVEY config C faulted on its second force call)"""
+    spec = _synthetic(10, 4, 3, 128, rc=7.0, rv=8.0)
+    out = []
+    for graphs in (1, 0):
+        h = api.MsEvbHip(spec)
+        h.set_option("graphs", graphs)
+        h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 2))
+        e, F = h.ms_evb_calculate_total_force_energy()
+        en = h.md_integrate_atomic(6, spec.delta_t, use_evb=True)
+        out.append((e, F, en, h.get_positions()))
+        h.close()
+    assert rel(out[0][0], out[1][0]) < 1e-13 and np.abs(out[0][1] - out[1][1]).max() < 1e-10
+    assert np.abs(out[0][2] - out[1][2]).max() < 1e-9 * np.abs(out[1][2]).max() and np.abs(out[0][3] - out[1][3]).max() < 1e-10
+
+
 def test_rccl_communicator_of_one_rank():
     """the real collective path (ncclAllGather of the Hamiltonian entries on the side stream, in-place ncclAllReduce of the forces on
     the main stream) on a communicator of ONE rank: same force call, same trajectory as without a communicator"""

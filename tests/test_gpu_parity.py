@@ -468,6 +468,40 @@ def test_rolling_pruned_pair_list_is_exact(evb):
         assert np.abs(x - out[0][1]).max() < 1e-9 and np.abs(F - out[0][2]).max() < 1e-6
 
 
+def test_orthorhombic_box_against_oracle(oracle_lib):
+    """box lengths 1 : 1.12 : 1.31 (molecules kept rigid, centres of mass scaled): different cell counts, tile shapes and reciprocal
+    vectors per axis.  No reference run for this shape (the fixtures are cubic) - GPU against the CPU oracle, EVB force call + MD steps"""
+    import dataclasses
+    s = synth.make_system(8, n_diabat=4, seed=4)
+    scale = np.array([1.0, 1.12, 1.31])
+    xyz = s.xyz.copy()
+    for f, n in zip(s.mol_first, s.mol_natom):
+        com = xyz[f:f + n].mean(0)
+        xyz[f:f + n] += com * (scale - 1.0)
+    s = dataclasses.replace(s, xyz=xyz, box=s.box * scale)
+    p = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"])
+    spec = system.from_synth(s, p, rc=7.0, rv=8.0, pme_grid=24)
+    o = oracle_lib.Oracle(spec, threads=8)
+    o.verlet_build()
+    r = o.evb()
+    h = api.MsEvbHip(spec)
+    e, F = h.ms_evb_calculate_total_force_energy()
+    st = h.evb_state()
+    assert st["D"] == r["D"] and r["D"] >= 2
+    assert np.abs(st["H"] - r["H"]).max() < E_RTOL * np.abs(r["H"]).max()
+    assert rel(e, r["E"]) < E_RTOL and np.abs(F - r["F"]).max() < 1e-8
+    vel = synth.maxwell_boltzmann(spec.mass, 300.0, 6)
+    h.set_velocities(vel)
+    en = h.md_integrate_atomic(5, spec.delta_t, use_evb=True)
+    v, Fo = vel.copy(), r["F"].copy()
+    o.apply_principal()
+    for k in range(5):
+        pe = o.md_step(v, Fo, spec.delta_t, True)
+        assert abs(pe - en[k, 0]) < 1e-8 * abs(pe)
+    assert np.abs(h.get_positions() - o.get_xyz()).max() < 1e-9
+    h.close()
+
+
 def test_large_pme_grid_graph_replay_with_batched_diabat_ffts():
     """128^3 grid: rocFFT needs work buffers.  The single-grid front end is replayed from a captured hipGraph (its work buffer address
     is baked in) while the diabat grids use batched plans with a larger work buffer of their own - sharing one buffer freed the

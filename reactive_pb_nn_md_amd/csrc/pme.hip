@@ -210,6 +210,94 @@ __global__ __launch_bounds__(256) void k_pme_gather(int N, int K, const double* 
   }
 }
 
+// LDS-tiled gather, the counterpart of k_pme_spread_tiles: one workgroup per neighbour cell stages the potential of the cell's tile
+// (same origin, size and bank-conflict padding) once, the 8-lane groups then take the cell's atoms round-robin and read their 216 taps
+// from LDS instead of gathering them from L2.  Same loops and summation order per atom as k_pme_gather (bit-identical forces); an atom
+// whose stencil left the tile since the last list build is done from global memory by the same code.
+__global__ __launch_bounds__(256) void k_pme_gather_tiles(int K, int3 nc, int3 T, const int* __restrict__ cell_start, const int* __restrict__ perm,
+                                                          const double* __restrict__ chg, const int* __restrict__ base, const double* __restrict__ w,
+                                                          const double* __restrict__ dw, const double* __restrict__ theta, double conv, double k00, double k01,
+                                                          double k02, double k10, double k11, double k12, double k20, double k21, double k22,
+                                                          double* __restrict__ F_recip, double* __restrict__ F, int atomic, int add_lo, int add_hi) {
+  extern __shared__ double tile[];
+  const int cidx = blockIdx.x;
+  const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
+  const int ox = (int)floor((double)cx * K / nc.x) - 6, oy = (int)floor((double)cy * K / nc.y) - 6, oz = (int)floor((double)cz * K / nc.z) - 6;
+  const int P = T.x | 1, P2 = spread_plane_stride(T);
+  for (int r = threadIdx.x; r < T.x * T.y * T.z; r += blockDim.x) {      // stage: x fastest (coalesced rows of T.x points)
+    const int a = r % T.x, b = (r / T.x) % T.y, cc = r / (T.x * T.y);
+    int n1 = ox + a; n1 += n1 < 0 ? K : 0; n1 -= n1 >= K ? K : 0;
+    int n2 = oy + b; n2 += n2 < 0 ? K : 0; n2 -= n2 >= K ? K : 0;
+    int n3 = oz + cc; n3 += n3 < 0 ? K : 0; n3 -= n3 >= K ? K : 0;
+    tile[a + P * b + P2 * cc] = theta[n1 + (size_t)K * (n2 + (size_t)K * n3)];
+  }
+  __syncthreads();
+  const int s = cell_start[cidx], e = cell_start[cidx + 1];
+  const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3, ngrp = blockDim.x >> 3;
+  for (int a0 = s; a0 < e; a0 += ngrp) {      // uniform trip count per wave (shuffles below)
+    const int ia = a0 + grp;
+    const bool live = ia < e;
+    const int i = live ? perm[ia] : 0;
+    double f1 = 0.0, f2 = 0.0, f3 = 0.0;
+    if (live && sub < 6) {
+      const int b1 = base[3 * i], b2 = base[3 * i + 1], b3 = base[3 * i + 2];
+      // tile-local coordinate of tap 0 per axis; the 6 taps walk down: all inside the tile <=> 5 <= l < T
+      int l1 = b1 - ox; l1 += l1 < 0 ? K : 0; l1 -= l1 >= K ? K : 0;
+      int l2 = b2 - oy; l2 += l2 < 0 ? K : 0; l2 -= l2 >= K ? K : 0;
+      int l3 = b3 - oz; l3 += l3 < 0 ? K : 0; l3 -= l3 >= K ? K : 0;
+      const bool in_tile = l1 >= 5 && l1 < T.x && l2 >= 5 && l2 < T.y && l3 >= 5 && l3 < T.z;
+      const double* wi = w + (size_t)i * 18;
+      const double* dwi = dw + (size_t)i * 18;
+      double w1[6], d1[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { w1[k] = wi[k]; d1[k] = dwi[k]; }
+      const double w3 = wi[12 + sub], d3 = dwi[12 + sub];
+      if (in_tile) {
+        const double* plane = tile + P2 * (l3 - sub) + l1;
+#pragma unroll
+        for (int k2 = 0; k2 < 6; ++k2) {
+          const double* row = plane + P * (l2 - k2);
+          const double w2 = wi[6 + k2], d2 = dwi[6 + k2];
+          double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { const double th = row[-k]; s0 += w1[k] * th; s1 += d1[k] * th; }
+          f1 += s1 * w2 * w3; f2 += s0 * d2 * w3; f3 += s0 * w2 * d3;
+        }
+      } else {
+        int n3 = b3 - sub; if (n3 < 0) n3 += K;
+        int n1[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { int n = b1 - k; if (n < 0) n += K; n1[k] = n; }
+#pragma unroll
+        for (int k2 = 0; k2 < 6; ++k2) {
+          int n2 = b2 - k2; if (n2 < 0) n2 += K;
+          const double* row = theta + (size_t)K * (n2 + (size_t)K * n3);
+          const double w2 = wi[6 + k2], d2 = dwi[6 + k2];
+          double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { const double th = row[n1[k]]; s0 += w1[k] * th; s1 += d1[k] * th; }
+          f1 += s1 * w2 * w3; f2 += s0 * d2 * w3; f3 += s0 * w2 * d3;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); f3 += __shfl_xor(f3, o, 64); }
+    if (live && sub == 0) {
+      const double sc = chg[i] * conv;
+      f1 *= sc; f2 *= sc; f3 *= sc;
+      const double Kd = (double)K;
+      const double fx = -Kd * (k00 * f1 + k10 * f2 + k20 * f3);
+      const double fy = -Kd * (k01 * f1 + k11 * f2 + k21 * f3);
+      const double fz = -Kd * (k02 * f1 + k12 * f2 + k22 * f3);
+      F_recip[3 * i] = fx; F_recip[3 * i + 1] = fy; F_recip[3 * i + 2] = fz;
+      if (F && i >= add_lo && i < add_hi) {
+        if (atomic) { atomicAdd(&F[3 * i], fx); atomicAdd(&F[3 * i + 1], fy); atomicAdd(&F[3 * i + 2], fz); }
+        else { F[3 * i] += fx; F[3 * i + 1] += fy; F[3 * i + 2] += fz; }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // stream of the PME front end (prep ... inverse FFT): the side stream while the principal pair loop runs on the main one
@@ -309,6 +397,19 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
   const int N = c->N;
   int add_lo, add_hi;
   shard_range(c, N, add_lo, add_hi);
+  {
+    int3 T;
+    T.x = (int)ceil((double)c->K / c->ncell[0]) + 8; T.y = (int)ceil((double)c->K / c->ncell[1]) + 8; T.z = (int)ceil((double)c->K / c->ncell[2]) + 8;
+    const size_t tile_bytes = (size_t)spread_plane_stride(T) * T.z * sizeof(double);
+    if (c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= c->K && T.y <= c->K && T.z <= c->K) {      // workgroup per cell, potential staged in LDS
+      const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
+      hipLaunchKernelGGL(k_pme_gather_tiles, dim3(ncell), dim3(256), tile_bytes, c->stream, c->K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T, c->d_cell_start.p, c->d_perm.p,
+                         chg, c->d_base.p, c->d_w.p, c->d_dw.p, theta ? theta : c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2],
+                         c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, atomic ? 1 : 0, add_lo, add_hi);
+      HIPCHK(hipGetLastError());
+      return MSEVB_OK;
+    }
+  }
   hipLaunchKernelGGL(k_pme_gather, dim3((N * 8 + 255) / 256), dim3(256), 0, c->stream, N, c->K, chg, c->d_base.p, c->d_w.p, c->d_dw.p, theta ? theta : c->d_theta.p, c->conv, c->kk[0][0],
                      c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, atomic ? 1 : 0, add_lo, add_hi);
   HIPCHK(hipGetLastError());

@@ -64,9 +64,15 @@ int msevb_create(msevb_ctx** out, int device_id) {
   HIPCHK(hipSetDevice(device_id));
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));      // equal priorities: a favoured main stream starves the side chains
   c->own_stream = true;
-  HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&c->aux3, hipStreamNonBlocking));
+  {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    // the side chains feed the host's turn (Hamiltonian, blend coefficients), the pair loop only has to be done when the blend starts:
+    // side streams above the main one (+1 % measured; the opposite order lost 10 %)
+    HIPCHK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi));
+    HIPCHK(hipStreamCreateWithPriority(&c->aux2, hipStreamNonBlocking, hi));
+    HIPCHK(hipStreamCreateWithPriority(&c->aux3, hipStreamNonBlocking, hi));
+  }
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
@@ -85,6 +91,7 @@ int msevb_destroy(msevb_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->aux2) (void)hipStreamSynchronize(c->aux2);
+  stamps_report(c);
   evb_release(c);
   msevb_comm_release(c);
   if (c->pme_graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)c->pme_graph_exec); c->pme_graph_exec = nullptr; }
@@ -458,11 +465,36 @@ int msevb_intra_molecular_energy_force(msevb_ctx* c, double* e) {
   return MSEVB_OK;
 }
 
+__global__ void k_stamp(unsigned long long* out) { *out = wall_clock64(); }
+void stamp(msevb_ctx* c, int idx, hipStream_t st) {
+  if (c->stamps_on < 0) c->stamps_on = getenv("MSEVB_STAMPS") ? 1 : 0;
+  if (!c->stamps_on) return;
+  if (!c->h_stamps) { if (hipHostMalloc((void**)&c->h_stamps, 4 * 16 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { c->stamps_on = 0; return; } memset(c->h_stamps, 0, 512); }
+  if (idx == 0) {      // a ring of four stamp sets: the set written two steps ago is complete by now
+    c->stamp_step++;
+    unsigned long long* old = c->h_stamps + 16 * ((c->stamp_step + 2) & 3);
+    if (c->stamp_step > 4 && old[0] && old[9] > old[0] && old[2] > old[1] && old[1] - old[0] < 12000ull) {      // steps that rebuild the list (pair start > 120 us) are left out
+      for (int k = 1; k < 16; ++k) if (old[k] >= old[0]) c->stamp_sum[k] += (double)(old[k] - old[0]) * 0.01;
+      c->stamp_n++;
+    }
+    memset(c->h_stamps + 16 * (c->stamp_step & 3), 0, 128);
+  }
+  hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, st, c->h_stamps + 16 * (c->stamp_step & 3) + idx);
+}
+void stamps_report(msevb_ctx* c) {
+  if (c->stamps_on != 1 || !c->stamp_n) return;
+  const char* nm[16] = {"step start", "pair start", "pair end", "spec_prep start", "env chain end", "grid chain start", "grid chain end", "coupling chain end", "blend phase start", "blend end", "fetch A published", "", "", "", "", ""};
+  fprintf(stderr, "[msevb gpu stamps, us after stamp 0, %ld steps]", c->stamp_n);
+  for (int k = 1; k < 11; ++k) fprintf(stderr, " %s %.0f |", nm[k], c->stamp_sum[k] / c->stamp_n);
+  fprintf(stderr, "\n");
+}
+
 // the principal-diabat force call, everything enqueued on the stream; energies land in c->h_energies after fetch_energies()
 int total_force_enqueue(msevb_ctx* c) {
   c->timing_now = c->timing && (c->timing_tick++ % c->timing_stride) == 0;
   // Verlet freshness: src/total_energy_forces.f90:30-39 (rebuild when the flag was raised by the previous call)
   CHK(nb_settle(c));
+  stamp(c, 0, c->stream);
   const bool rebuild = c->flag_verlet_list == 1 || !c->list_valid;
   if (rebuild) {      // cells + sorted arrays now; the rows are filled below, beside what only needs the cells
     CHK(nb_build_begin(c)); c->flag_verlet_list = 0;
@@ -471,7 +503,9 @@ int total_force_enqueue(msevb_ctx* c) {
   if (c->overlap) {     // independent chains, all adding to the force with fp64 atomics
     HIPCHK(aux_fork(c));
     if (rebuild) CHK(nb_build_finish(c, true));                      // main: list rows first (the longest chain of a rebuild step: rows, then the pair loop)
+    stamp(c, 1, c->stream);
     CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));                    // main: the pair loop (longest) goes out first
+    stamp(c, 2, c->stream);
     CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux3));      // aux3: per-molecule terms (few, long threads); aux2 stays free for the
                                                                      // EVB descriptors + environment chain, which the host enqueues next
     CHK(pme_front(c, S_RECIP, true));                                // aux: stencils, spreading, FFTs, convolution

@@ -265,6 +265,7 @@ struct msevb_ctx {
   // phase events are SAMPLED: one force call in timing_stride records them (every record costs ~2 us of host time, 25 per step)
   bool timing_now = false; int timing_stride = 8; long timing_tick = 0;
   // NVT: Langevin leap-frog kicks (langevin_integrator, src/md_integration.f90:186-228) instead of the plain half kicks
+  int stamps_on = -1; unsigned long long* h_stamps = nullptr; double stamp_sum[16] = {0}; long stamp_n = 0, stamp_step = 0;
   bool evb_device_solve = false;     // single rank: H' assembly + Jacobi + blend coefficients in a kernel (no host round trip before the blend)
   bool nvt = false; double friction = 0.1 /* 1/ps, the reference's default */, temperature = 300.0; unsigned long long langevin_seed = 0, langevin_tick = 0;
 };
@@ -276,6 +277,11 @@ int nb_build_finish(msevb_ctx* c, bool defer);    // rows (one host synchronisat
 int nb_check_overflow(msevb_ctx* c);  // after a deferred finish
 int nb_prune_reset(msevb_ctx* c);     // the next pair loop prunes (list rebuilt / positions replaced)
 int nb_settle(msevb_ctx* c);          // looks at statistics a failed call left behind
+// GPU-side timestamps of a step (MSEVB_STAMPS=1): tiny kernels write the 100 MHz wall clock at points of interest of each stream; the
+// averages, relative to stamp 0, are printed when the context is destroyed.  The profiler's per-call host overhead distorts exactly the
+// thing this shows: WHEN the host gets the side chains out.
+extern "C" void stamp(msevb_ctx* c, int idx, hipStream_t st);
+extern "C" void stamps_report(msevb_ctx* c);
 constexpr int MSEVB_RETRY = 1000;     // internal: repeat the force call (never leaves the library)
 int nb_refresh_sorted(msevb_ctx* c);               // gather posq/type in sorted order
 extern "C" int msevb_comm_allreduce_forces(msevb_ctx* c);   // comm.hip

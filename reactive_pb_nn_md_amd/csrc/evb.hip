@@ -1023,6 +1023,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   GridCoefs gc; gc.n = ngrid; gc.c0 = 0.0;
   if (ev) { gc.c0 = c->rank == 0 ? ev[0] * ev[0] : 0.0; for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gc.c[grid_of[d]] = ev[d] * ev[d]; }
   if (c->overlap && ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // convolved diabat grids (aux)
+  stamp(c, 8, c->stream);
   if (w->d_pack.alloc(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended potential)");
   hipLaunchKernelGGL(k_evb_blend_grids, dim3(1024), dim3(256), 0, c->stream, K3, gc, dcoef, c->d_theta.p, w->d_grids.p, w->d_pack.p);
   CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p));
@@ -1031,6 +1032,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   if (c->overlap) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0)); if (ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_rs, 0)); }
   (void)nra; (void)d_ra;
   hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, dcoef ? dcoef + 1 + ngrid : (const double*)nullptr, w11, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p, 1);
+  stamp(c, 9, c->stream);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
 }
@@ -1302,6 +1304,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   // every element of an owned slot is written by its kernels; slots of other ranks' diabats are never read (partial blend + all-reduce)
   if (w->dv_dirty) { HIPCHK(hipMemsetAsync(w->d_dVspec.p, 0, w->d_dVspec.n * 8, ss)); w->dv_dirty = false; }   // afterwards k_evb_coupling_finish leaves it zeroed
   // B-spline stencils of the special atoms in their new states (needs descriptors only)
+  stamp(c, 3, ss);
   if (ngrid) hipLaunchKernelGGL(k_evb_spec_prep, dim3((nra + 63) / 64), dim3(64), 0, ss, nra, d_ra, K, c->spline_grid, c->kk[0][0], c->kk[0][1], c->kk[0][2],
                                 c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p, c->d_energies.p + S_FAULT);
   if (c->overlap) {      // descriptors + special stencils are on the device: the main stream and the off-diagonal chain may use them
@@ -1334,6 +1337,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
                      w->d_Fdelta.p, n3, E_units_spec);
   HIPCHK(hipGetLastError());
   phase_end(c, PH_EVB_REAL, sr);
+  stamp(c, 4, sr);
   if (c->overlap) HIPCHK(hipEventRecord(w->ev_join2, w->stream2));
   // ---- 6a'. off-diagonal elements (evb_diabatic_coupling, :1021): few, latency-bound kernels writing only d_Foff; on aux2 behind the
   //           diagonal deltas (the all-atom gather waits for those, only the blend for these)
@@ -1353,6 +1357,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     hipLaunchKernelGGL(k_evb_coupling_finish, dim3(ncp), dim3(64), 0, so, ncp, d_cps, w->d_exch.p, c->d_mass.p, box, c->conv, E_cp_env,
                        w->d_dVspec.p, c->d_Foff.p, n3, d_cpout);
     HIPCHK(hipGetLastError());
+    stamp(c, 7, so);
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_cpl, so));
   }
   // The Hamiltonian needs energies only, and all of them exist before the all-atom gather (the longest kernel of the EVB phase)
@@ -1371,9 +1376,9 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   // write into pinned host memory (no copy commands).
   auto fetch_A = [&]() -> int {      // call after everything that produces a unit / coupling / grid energy has been enqueued
     CHK(flush_one(c, S_RECIP, sg));                              // principal reciprocal energy: its partial sums are complete on `sg`
-    if (c->overlap) { HIPCHK(hipEventRecord(w->ev_E, sg)); HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0)); }
-    if (c->overlap && ncp) HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_cpl, 0));      // coupling energies (aux3)
+    if (c->overlap) HIPCHK(hipEventRecord(w->ev_E, sg));
     if (dev_solve) {
+      if (c->overlap) { HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0)); if (ncp) HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_cpl, 0)); }
       const size_t need = 2 + 2 * (size_t)D + (size_t)D * D;
       if (need > w->h_solve_cap) {
         if (w->h_solve) HIPCHK(hipHostFree(w->h_solve));
@@ -1389,14 +1394,21 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
       HIPCHK(hipEventRecord(w->ev_solve, ss));
       return MSEVB_OK;
     }
-    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, ss, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, ++w->seq_A);
+    // published from the diabat grid stream, normally the last chain to finish: the waits for the other two chains' events are then
+    // already satisfied and the publish kernel starts right behind the last energy kernel (a publish on another stream starts an event hop later)
+    if (c->overlap) { HIPCHK(hipStreamWaitEvent(sg, w->ev_join2, 0)); if (ncp) HIPCHK(hipStreamWaitEvent(sg, w->ev_cpl, 0)); }
+    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, ++w->seq_A);
     HIPCHK(hipGetLastError());
-    if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, ss));
+    stamp(c, 10, sg);
+    if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, sg));
     return MSEVB_OK;
   };
   auto fetch_B = [&]() -> int {      // principal energy slots + Verlet displacement flag (main stream, behind the pair loop)
     CHK(flush_reductions(c));
-    if (c->overlap) { HIPCHK(hipEventRecord(w->ev_flush, c->stream)); HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_flush, 0)); }
+    if (c->overlap) {
+      HIPCHK(hipEventRecord(w->ev_flush, c->stream)); HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_flush, 0));
+      HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0));      // the principal reciprocal energy slot is reduced on the diabat grid stream (fetch A)
+    }
     hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, ss, c->d_energies.p, (int)N_SLOTS, c->h_energies, (const double*)nullptr, 0, (double*)nullptr,
                        (volatile long long*)(w->h_flag + 2), ++w->seq_B);
     HIPCHK(hipGetLastError());
@@ -1405,6 +1417,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   };
   // ---- 6b. reciprocal space of the owned diabats (calculate_reciprocal_space_pme, :1962)
   phase_begin(c, PH_EVB_RECIP, sg);
+  stamp(c, 5, sg);
   if (ngrid) {
     hipLaunchKernelGGL(k_evb_grid_init, dim3(2048), dim3(256), 0, sg, K3, ngrid, c->d_Q.p, w->d_grids.p);
     hipLaunchKernelGGL(k_evb_patch, dim3((nra + 3) / 4), dim3(256), 0, sg, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, w->d_sbase.p, w->d_sw.p, w->d_grids.p);
@@ -1418,6 +1431,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     if (!fast) hipLaunchKernelGGL(k_evb_pack, dim3(2048), dim3(256), 0, sg, K3, ngrid, w->d_grids.p, w->d_pack.p);
   }
   phase_end(c, PH_EVB_RECIP, sg);
+  stamp(c, 6, sg);
   CHK(fetch_A());
   if (fast && ngrid) {      // own-stencil corrections of the special atoms -> delta store; behind the energy fetch on this stream: the host's turn does not wait for it
     hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, sg, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,

@@ -502,6 +502,26 @@ def test_orthorhombic_box_against_oracle(oracle_lib):
     h.close()
 
 
+def test_device_side_hamiltonian_solve():
+    """option evb_device_solve: H' assembly, the reference's cyclic Jacobi and the blend coefficients in one kernel (kept as an option:
+    slower than the host round trip it replaces) - same algorithm and operation order: identical Hamiltonian and energy, ground-state
+    vector to the last bits (device division / square root), same trajectory"""
+    g = golden("evb_n6_d8_s1")
+    spec = system.from_golden(g)
+    out = []
+    for dev in (0, 1):
+        h = api.MsEvbHip(spec)
+        h.set_option("evb_device_solve", dev)
+        e, F = h.ms_evb_calculate_total_force_energy()
+        st = h.evb_state()
+        h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 8))
+        en = h.md_integrate_atomic(10, spec.delta_t, use_evb=True)
+        out.append((e, F, st["H"], st["eigvec"], en))
+        h.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][2], out[1][2]) and np.abs(out[0][3] - out[1][3]).max() < 1e-14
+    assert np.abs(out[0][1] - out[1][1]).max() < 1e-10 and np.abs(out[0][4] - out[1][4]).max() < 1e-9 * np.abs(out[0][4]).max()
+
+
 def test_large_pme_grid_graph_replay_with_batched_diabat_ffts():
     """128^3 grid: rocFFT needs work buffers.  The single-grid front end is replayed from a captured hipGraph (its work buffer address
     is baked in) while the diabat grids use batched plans with a larger work buffer of their own - sharing one buffer freed the

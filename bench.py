@@ -166,7 +166,11 @@ def main():
     # every phase runs once per step; the library records its HIP events on one force call in eight (sampling keeps the ~25 event
     # records per step off the host's critical path), so the averages are over the timed region, the counts are not per-step counts
     per_step = {k: v[0] for k, v in kern.items()}
-    dom = max(per_step, key=per_step.get) if per_step else None
+    # the roofline block is about the dominant KERNEL: phases that are one kernel launch (the EVB phases are chains of kernels on side
+    # streams, their event brackets include waits for other chains)
+    single = ("real space (pair loop)", "Q_grid (spread)", "Q grid derivatives (gather)", "intra-molecular (non-bonded + bonded)")
+    cand = {k: v for k, v in per_step.items() if k in single}
+    dom = max(cand, key=cand.get) if cand else None
     roofline = None
     if dom:
         launches_per_step = 1.0

@@ -504,8 +504,8 @@ def test_orthorhombic_box_against_oracle(oracle_lib):
 
 def test_device_side_hamiltonian_solve():
     """option evb_device_solve: H' assembly, the reference's cyclic Jacobi and the blend coefficients in one kernel (kept as an option:
-    slower than the host round trip it replaces) - same algorithm and operation order: identical Hamiltonian and energy, ground-state
-    vector to the last bits (device division / square root), same trajectory"""
+    slower than the host round trip it replaces) - same algorithm and operation order as the host path: Hamiltonian, energy and
+    ground-state vector agree to the last bits, same trajectory"""
     g = golden("evb_n6_d8_s1")
     spec = system.from_golden(g)
     out = []
@@ -518,7 +518,9 @@ def test_device_side_hamiltonian_solve():
         en = h.md_integrate_atomic(10, spec.delta_t, use_evb=True)
         out.append((e, F, st["H"], st["eigvec"], en))
         h.close()
-    assert out[0][0] == out[1][0] and np.array_equal(out[0][2], out[1][2]) and np.abs(out[0][3] - out[1][3]).max() < 1e-14
+    # (two runs of the same call differ in the last bits anyway: the candidate list is compacted with an atomic counter, so the order
+    # of the energy partial sums is not fixed)
+    assert rel(out[0][0], out[1][0]) < 1e-14 and np.abs(out[0][2] - out[1][2]).max() < 1e-13 * np.abs(out[0][2]).max() and np.abs(out[0][3] - out[1][3]).max() < 1e-13
     assert np.abs(out[0][1] - out[1][1]).max() < 1e-10 and np.abs(out[0][4] - out[1][4]).max() < 1e-9 * np.abs(out[0][4]).max()
 
 

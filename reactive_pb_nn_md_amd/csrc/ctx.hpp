@@ -223,6 +223,7 @@ struct msevb_ctx {
   // largest displacements since the last pruning add up to prune_delta; d_prune_mode[0]: 1 = this step prunes, 2 = this step uses the rows
   bool prune = true; double prune_delta = 0.6; int prune_lo = -1, prune_hi = -1;
   DBuf<int> d_nbr2, d_prune_mode; DBuf<unsigned> d_nbr2_count; DBuf<double4> d_posq_prune;
+  bool nbr_stats_copy_pending = false;      // in-kernel row statistics of a deferred rebuild still have to be downloaded
   bool nbr_check_pending = false;      // a deferred rebuild's row statistics have not been looked at yet
   int* h_nbr_stats = nullptr;          // pinned: {tile_max, pad, count_max, pad, count_sum lo, hi}
   int flag_verlet_list = 0;

@@ -134,7 +134,7 @@ __device__ __forceinline__ bool nbr_decide_fp64(const double4& pr, double xi, do
 template <bool LOCAL>
 __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int* __restrict__ cell_start, const double4* __restrict__ posq, const int* __restrict__ mol_s,
                                                           const int* __restrict__ type_s, BoxDev box, double rv2, unsigned cap, int tile_cap,
-                                                          unsigned* __restrict__ count, unsigned* __restrict__ start, int* __restrict__ nbr) {
+                                                          unsigned* __restrict__ count, unsigned* __restrict__ start, int* __restrict__ nbr, int* __restrict__ stats) {
   extern __shared__ float4 t4[];                          // {x, y, z, molecule (int bits)}[tile_cap], then the entry words int[tile_cap]
   __shared__ int s_lo[27], s_off[28], s_ns;
   __shared__ double s_shift[27][3];
@@ -177,6 +177,7 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int i1 = cell_start[cidx + 1];
   const float rv2f = (float)rv2, band = 1e-3f * (float)rv2;
+  unsigned wmax = 0; unsigned long long wsum = 0;
   for (int i = cell_start[cidx] + wave; i < i1; i += wpb) {
     const double4 pr = posq[i];
     const double xi = pr.x - box.L[0] * floor(pr.x * box.invL[0]), yi = pr.y - box.L[1] * floor(pr.y * box.invL[1]), zi = pr.z - box.L[2] * floor(pr.z * box.invL[2]);
@@ -226,7 +227,19 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
         }
       }
     }
-    if (lane == 0) { count[i] = total; start[i] = base; }
+    if (lane == 0) { count[i] = stats ? min(total, cap) : total; start[i] = base; }      // with in-kernel statistics the row is cut here (see k_count_stats)
+    wmax = max(wmax, total); wsum += total;
+  }
+  if (stats) {      // {largest neighbourhood, -, longest row (uncut), -, sum of the row lengths (64 bit)}: one atomic each per workgroup
+    __shared__ unsigned s_max[16];
+    __shared__ unsigned long long s_sum[16];
+    if (lane == 0) { s_max[wave] = wmax; s_sum[wave] = wsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned m = 0; unsigned long long sm = 0;
+      for (int k = 0; k < wpb; ++k) { m = max(m, s_max[k]); sm += s_sum[k]; }
+      atomicMax((unsigned*)stats + 2, m); atomicAdd((unsigned long long*)(stats + 4), sm); atomicMax(stats, ntile);
+    }
   }
 }
 
@@ -470,8 +483,10 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
     if (sync) HIPCHK(hipStreamSynchronize(c->stream));
     return MSEVB_OK;
   };
-  auto fill = [&]() -> int {
+  bool inline_stats = false;      // the fill kernel left {tile max, row max, row sum} in d_stats and cut overlong rows itself
+  auto fill = [&](bool want_inline = false) -> int {
     if (c->d_nbr.alloc((size_t)N * c->nbr_cap)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (neighbour list)");
+    inline_stats = false;
     if (ncell >= NBR_TILE_MIN_CELLS && c->nbr_tiles && nc.x >= 4 && nc.y >= 4 && nc.z >= 4) {      // workgroup per cell, neighbourhood staged in LDS
       static bool attr_set[2] = {false, false};
       auto kern = c->pair_tiles ? k_neighbors_tiles<true> : k_neighbors_tiles<false>;
@@ -483,8 +498,9 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
       // (a larger one is scanned from global memory).  Up to NBR_TILE_CAP2 atoms two workgroups share a CU's 160 KB.
       int tile_cap = NBR_TILE_CAP2;
       if (c->tile_atoms_max > 0 && c->tile_atoms_max * 1.03 > NBR_TILE_CAP2) tile_cap = std::min(NBR_TILE_CAP, ((int)(c->tile_atoms_max * 1.08) + 63) & ~63);
+      if (want_inline) { HIPCHK(hipMemsetAsync(d_stats, 0, 8 * sizeof(int), c->stream)); inline_stats = true; }
       hipLaunchKernelGGL(kern, dim3(ncell), dim3(1024), (size_t)tile_cap * NBR_TILE_BYTES, c->stream, nc, c->d_cell_start.p, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, box, rv2,
-                         c->nbr_cap, tile_cap, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p);
+                         c->nbr_cap, tile_cap, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p, want_inline ? d_stats : (int*)nullptr);
     } else if (c->pair_tiles)
       hipLaunchKernelGGL((k_neighbors<true, true>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
                          c->nbr_cap, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p);
@@ -511,9 +527,12 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
   } else {                    // rebuild: one pass; the stride only grows when a row overflowed
     if (c->pair_tiles_opt != 0) { CHK(stats(true)); decide_tiles(h_stats[0]); }    // the tile size fixes the entry format of this build
     else c->pair_tiles = false;
-    CHK(fill());
-    if (defer) { CHK(stats(true, false)); c->nbr_check_pending = true; }      // + the largest neighbourhood, for the next build's tile
-    else {
+    CHK(fill(defer));
+    if (defer) {      // statistics without a synchronisation: by the fill kernel itself when it is the tile kernel (nothing between it and the pair loop)
+      if (inline_stats) c->nbr_stats_copy_pending = true;      // downloaded behind the pair loop (pair_forces): the host only looks at its next wait
+      else CHK(stats(true, false));      // + the largest neighbourhood, for the next build's tile
+      c->nbr_check_pending = true;
+    } else {
       CHK(stats(false));
       if ((unsigned)h_stats[2] > c->nbr_cap) { set_cap((unsigned)h_stats[2]); CHK(fill()); CHK(stats(false)); }
     }

@@ -233,6 +233,10 @@ int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw) {
   }
   HIPCHK(hipGetLastError());
   phase_end(c, PH_PAIR);
+  if (c->nbr_stats_copy_pending) {      // row statistics of this call's list rebuild (nb_build_finish), out of the way of the pair loop
+    HIPCHK(hipMemcpyAsync(c->h_nbr_stats, c->d_tile_max.p, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->nbr_stats_copy_pending = false;
+  }
   CHK(reduce_partials(c, slot_elec, nblocks));
   CHK(reduce_partials(c, slot_vdw, nblocks));
   return MSEVB_OK;

@@ -75,6 +75,8 @@ int msevb_get_ewald_self(msevb_ctx* ctx, double* ewald_self);
 
 /* ---- per-step data ---------------------------------------------------------------------------- */
 int msevb_set_positions(msevb_ctx* ctx, const double* xyz /*(3,N) host*/);
+/* periodic_box_change (src/pme.f90:634-664): new orthorhombic box lengths; CB, the reciprocal lattice and the Verlet list are rebuilt for them */
+int msevb_set_box(msevb_ctx* ctx, const double* box3);
 int msevb_get_positions(msevb_ctx* ctx, double* xyz);
 int msevb_set_velocities(msevb_ctx* ctx, const double* velocity /*(3,N) host*/);
 int msevb_get_velocities(msevb_ctx* ctx, double* velocity);

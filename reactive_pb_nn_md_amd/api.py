@@ -154,6 +154,13 @@ class MsEvbHip:
         a = np.ascontiguousarray(xyz, dtype=np.float64)
         self._chk(self.L.msevb_set_positions(self.ctx, _dp(a)))
 
+    def set_box(self, box):
+        """periodic_box_change (src/pme.f90:634): new orthorhombic box lengths; CB, reciprocal lattice and Verlet list follow"""
+        b = np.ascontiguousarray(box, dtype=np.float64)
+        self._chk(self.L.msevb_set_box(self.ctx, _dp(b)))
+        import dataclasses
+        self.spec = dataclasses.replace(self.spec, box=b.copy())      # the caller's spec object is left alone
+
     def get_positions(self):
         out = np.zeros((self.N, 3))
         self._chk(self.L.msevb_get_positions(self.ctx, _dp(out)))

@@ -377,6 +377,23 @@ int msevb_set_positions(msevb_ctx* c, const double* xyz) {
   HIPCHK(hipStreamSynchronize(c->stream));
   return MSEVB_OK;
 }
+// periodic_box_change (src/pme.f90:634-664): new box lengths -> CB array, reciprocal lattice, stale cells / list / captured PME graph
+int msevb_set_box(msevb_ctx* c, const double* box3) {
+  NEED_FINAL();
+  if (!box3) { c->err = "bad argument"; return MSEVB_ERR_ARG; }
+  double L = box3[0];
+  for (int d = 0; d < 3; ++d) { if (!(box3[d] > 0.0)) FAIL(MSEVB_ERR_ARG, "box lengths must be positive"); L = box3[d] < L ? box3[d] : L; }
+  if (!(c->rc < c->rv && c->rv < 0.5 * L)) FAIL(MSEVB_ERR_ARG, "need real_space_cutoff < verlet_cutoff < L/2 (src/general_routines.f90:1115-1130)");
+  HIPCHK(hipDeviceSynchronize());
+  for (int d = 0; d < 3; ++d) c->box[d] = box3[d];
+  CHK(build_box_tables(c));
+  HIPCHK(hipMemcpy(c->d_CB.p, c->t_CB.data(), c->t_CB.size() * 8, hipMemcpyHostToDevice));
+  if (c->pme_graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)c->pme_graph_exec); c->pme_graph_exec = nullptr; }      // box and lattice are baked into its kernel arguments
+  memset(c->pme_graph_key, 0, sizeof c->pme_graph_key);
+  c->list_valid = false; c->cells_valid = false; c->flag_verlet_list = 1;
+  return MSEVB_OK;
+}
+
 int msevb_get_positions(msevb_ctx* c, double* xyz) { NEED_FINAL(); HIPCHK(hipMemcpyAsync(xyz, c->d_xyz.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
 int msevb_set_velocities(msevb_ctx* c, const double* v) { NEED_FINAL(); HIPCHK(hipMemcpyAsync(c->d_vel.p, v, 3 * (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
 int msevb_get_velocities(msevb_ctx* c, double* v) { NEED_FINAL(); HIPCHK(hipMemcpyAsync(v, c->d_vel.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }

@@ -276,6 +276,7 @@ int nb_build(msevb_ctx* c);                        // neighbor.hip
 int nb_build_begin(msevb_ctx* c);     // cells + sorted arrays
 int nb_build_finish(msevb_ctx* c, bool defer);    // rows (one host synchronisation unless deferred)
 int nb_check_overflow(msevb_ctx* c);  // after a deferred finish
+int build_box_tables(msevb_ctx* c);    // tables.cpp: CB array + reciprocal lattice for the current box
 int nb_prune_reset(msevb_ctx* c);     // the next pair loop prunes (list rebuilt / positions replaced)
 int nb_settle(msevb_ctx* c);          // looks at statistics a failed call left behind
 // GPU-side timestamps of a step (MSEVB_STAMPS=1): tiny kernels write the 100 MHz wall clock at points of interest of each stream; the

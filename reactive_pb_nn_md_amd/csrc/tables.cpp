@@ -70,8 +70,40 @@ void recip_lattice(const double box[3], double vol, double kk[3][3]) {  // src/g
   for (int i = 0; i < 3; ++i) { kk[0][i] = ka[i] / vol; kk[1][i] = kb[i] / vol; kk[2][i] = kc[i] / vol; }
 }
 
+// everything that depends on the box: CB(K,K,K) and the reciprocal lattice of the scaled coordinates.  Called at set-up and by
+// msevb_set_box (periodic_box_change, src/pme.f90:634-664)
+int build_box_tables(msevb_ctx* c) {
+  const int K = c->K, n = c->order;
+  // CB(i,j,l): periodic_box_change uses volume = box(1,1)**3 (cubic assumption of the reference, src/pme.f90:646)
+  const double vol = c->box[0] * c->box[0] * c->box[0];
+  double kk[3][3];
+  recip_lattice(c->box, vol, kk);
+  const double pi32 = double(3.14159265f);  // `real*8, parameter :: pi=3.14159265` (src/pme.f90:542)
+  std::vector<double> bm(K);
+  for (int m = 0; m < K; ++m) bm[m] = b_mod_sq(c->pi, m, n, K);
+  c->t_CB.resize(size_t(K) * K * K);
+  for (int i = 0; i < K; ++i) {
+    const int m1 = i > K / 2 ? i - K : i;
+    for (int j = 0; j < K; ++j) {
+      const int m2 = j > K / 2 ? j - K : j;
+      for (int l = 0; l < K; ++l) {
+        const int m3 = l > K / 2 ? l - K : l;
+        double mm[3];
+        for (int d = 0; d < 3; ++d) mm[d] = double(m1) * kk[0][d] + double(m2) * kk[1][d] + double(m3) * kk[2][d];
+        const double mag = (mm[0] * mm[0] + mm[1] * mm[1]) + mm[2] * mm[2];
+        c->t_CB[i + size_t(K) * (j + size_t(K) * l)] =
+            1.0 / (vol * pi32) * std::exp(-(pi32 * pi32) * mag / (c->alpha * c->alpha)) / mag * bm[i] * bm[j] * bm[l];
+      }
+    }
+  }
+  c->t_CB[0] = 0.0;
+  // reciprocal lattice used for the scaled coordinates: fp32-rounded volume (src/general_routines.f90:484)
+  recip_lattice(c->box, volume32(c->box), c->kk);
+  return MSEVB_OK;
+}
+
 int build_tables(msevb_ctx* c) {
-  const int G = c->spline_grid, E = c->erfc_grid, K = c->K, n = c->order;
+  const int G = c->spline_grid, E = c->erfc_grid, n = c->order;
   if (n != 6) FAIL(MSEVB_ERR_ARG, "only spline_order = 6 is self-consistent in the reference (src/pme.f90:247 divides by 6)");
   c->t_B6.resize(G);
   c->t_B5.resize(G);
@@ -102,35 +134,11 @@ int build_tables(msevb_ctx* c) {
       c->t_dtt[(i - 1) * 4 + q] = std::exp(-x) * ipow(x, nn) / fact[nn];
     }
   }
-  // CB(i,j,l): periodic_box_change uses volume = box(1,1)**3 (cubic assumption of the reference, src/pme.f90:646)
-  const double vol = c->box[0] * c->box[0] * c->box[0];
-  double kk[3][3];
-  recip_lattice(c->box, vol, kk);
-  const double pi32 = double(3.14159265f);  // `real*8, parameter :: pi=3.14159265` (src/pme.f90:542)
-  std::vector<double> bm(K);
-  for (int m = 0; m < K; ++m) bm[m] = b_mod_sq(c->pi, m, n, K);
-  c->t_CB.resize(size_t(K) * K * K);
-  for (int i = 0; i < K; ++i) {
-    const int m1 = i > K / 2 ? i - K : i;
-    for (int j = 0; j < K; ++j) {
-      const int m2 = j > K / 2 ? j - K : j;
-      for (int l = 0; l < K; ++l) {
-        const int m3 = l > K / 2 ? l - K : l;
-        double mm[3];
-        for (int d = 0; d < 3; ++d) mm[d] = double(m1) * kk[0][d] + double(m2) * kk[1][d] + double(m3) * kk[2][d];
-        const double mag = (mm[0] * mm[0] + mm[1] * mm[1]) + mm[2] * mm[2];
-        c->t_CB[i + size_t(K) * (j + size_t(K) * l)] =
-            1.0 / (vol * pi32) * std::exp(-(pi32 * pi32) * mag / (c->alpha * c->alpha)) / mag * bm[i] * bm[j] * bm[l];
-      }
-    }
-  }
-  c->t_CB[0] = 0.0;
+  CHK(build_box_tables(c));
   // update_Ewald_self (src/pme.f90:608-625)
   double es = 0.0;
   for (int i = 0; i < c->N; ++i) es = es - c->h_chg[i] * c->h_chg[i];
   es = es * c->alpha / c->pi_sqrt;
   c->ewald_self = es * c->conv;
-  // reciprocal lattice used for the scaled coordinates: fp32-rounded volume (src/general_routines.f90:484)
-  recip_lattice(c->box, volume32(c->box), c->kk);
   return MSEVB_OK;
 }

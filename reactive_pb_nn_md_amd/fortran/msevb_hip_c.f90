@@ -74,6 +74,11 @@ module msevb_hip_c
        import :: c_ptr, c_int
        type(c_ptr), value :: ctx
      end function
+     integer(c_int) function msevb_set_box(ctx, box3) bind(C, name="msevb_set_box")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: box3(3)
+     end function
      integer(c_int) function msevb_set_positions(ctx, xyz) bind(C, name="msevb_set_positions")
        import :: c_ptr, c_int, c_double
        type(c_ptr), value :: ctx

@@ -383,7 +383,7 @@ def locate_hydronium(gro: GroSystem, ff: ForceField) -> int:
     return hits[0]
 
 
-def load_inputs(gro_path, ffpmt_path, top_path, simpmt_path, frame=0):
+def load_inputs(gro_path, ffpmt_path, top_path, simpmt_path, frame=0, evb=True):
     """the four input files of the reference's command line -> (SystemSpec, GroSystem, ForceField, strings, numbers)"""
     from . import system as sysmod
     gro = read_gro(gro_path, frame)
@@ -391,7 +391,7 @@ def load_inputs(gro_path, ffpmt_path, top_path, simpmt_path, frame=0):
     strings, numbers = read_simpmt(simpmt_path)
     if strings["lj_comb_rule"] != "opls":
         raise NotImplementedError("lj_comb_rule '%s' (only 'opls' is built)" % strings["lj_comb_rule"])
-    gro.hydronium = locate_hydronium(gro, ff)
+    gro.hydronium = locate_hydronium(gro, ff) if evb else -1      # (a build of the reference without MS-EVB never looks for one)
     order = []
     for nm in gro.mol_names:      # molecule types in order of first appearance in the .gro, the .top's extra ones after them
         if nm not in order:

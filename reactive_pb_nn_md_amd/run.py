@@ -8,7 +8,7 @@ its outputs (they are opened status='new', :49-50) and, when trajectory + log + 
 old trajectory from the checkpoint's last frame.  Differences, deliberately: `--evb` replaces the reference's compile-time
 switch ms_evb_simulation (src/glob_v.f90:45; default: yes when the topology has [ evb_pairs ]); the Maxwell-Boltzmann
 velocities and the Langevin noise come from seeded generators (the reference seeds from the clock, src/general_routines.f90:726);
-ensembles NVE and NVT (Langevin leap-frog) run, NPT (Monte-Carlo barostat) does not.
+ensembles NVE, NVT (Langevin leap-frog) and NPT (Langevin + the Monte-Carlo barostat every `barofreq` steps) run.
 """
 from __future__ import annotations
 
@@ -44,9 +44,9 @@ def main(argv=None):
     restart = all(have)
     if not restart and (have[0] or have[1]):
         raise SystemExit("output file exists (the reference opens its outputs with status='new'): %s" % (a.traj_out if have[0] else a.log_out))
-    spec, gro, ff, strings, numbers = io.load_inputs(a.traj_out if restart else a.gro, a.ffpmt, a.top, a.simpmt, frame=-1 if restart else 0)
-    if strings["ensemble"] not in ("NVE", "NVT"):
-        raise SystemExit("ensemble %s: NVE and NVT (Langevin) are built; the Monte-Carlo barostat is not" % strings["ensemble"])
+    spec, gro, ff, strings, numbers = io.load_inputs(a.traj_out if restart else a.gro, a.ffpmt, a.top, a.simpmt, frame=-1 if restart else 0, evb=a.evb != "no")
+    if strings["ensemble"] not in ("NVE", "NVT", "NPT"):
+        raise SystemExit("ensemble %s: NVE, NVT (Langevin) and NPT (Langevin + Monte-Carlo barostat) are built" % strings["ensemble"])
     use_evb = (a.evb == "yes") if a.evb else bool(ff.evb_pairs)
     n_step, n_output, dt = int(numbers["n_step"]), int(numbers["n_output"]), float(numbers["delta_t"])
 
@@ -57,7 +57,13 @@ def main(argv=None):
         n_ck, vel = io.read_velocity_checkpoint(a.velocity_checkpoint, spec.n_atom, step=n_old)
 
     h = api.MsEvbHip(spec, device=a.device)
-    if strings["ensemble"] == "NVT":      # Langevin leap-frog kicks (src/md_integration.f90:186-228); friction default of :203-204
+    baro = None
+    if strings["ensemble"] == "NPT":      # mc_sample (src/md_integration.f90:17-60): Langevin steps + a volume move every barofreq steps
+        from . import barostat
+        if "pressure" not in numbers:
+            raise SystemExit("variable pressure has not been given a value AND ensemble is set to NPT")
+        baro = barostat.MCBarostat(numbers["pressure"], numbers["temperature"], numbers.get("baroscale", 0.01), a.seed + 1)
+    if strings["ensemble"] in ("NVT", "NPT"):      # Langevin leap-frog kicks (src/md_integration.f90:186-228); friction default of :203-204
         for k, v in (("ensemble_nvt", 1), ("friction_coeff", numbers.get("friction_coeff", 0.1)), ("temperature", numbers["temperature"]), ("langevin_seed", a.seed)):
             h.set_option(k, float(v))
     atom_names = list(gro.atom_names)
@@ -100,11 +106,19 @@ def main(argv=None):
     block = max(1, n_output)
     if a.checkpoint_every > 0:
         block = np.gcd(block, a.checkpoint_every)
+    barofreq = int(numbers.get("barofreq", 25))
+    if baro is not None:
+        block = np.gcd(block, barofreq)
     while done < total:
         nb = int(min(block, total - done))
         en = h.md_integrate_atomic(nb, dt, use_evb=use_evb)
         done += nb
         step = n_old + done
+        if baro is not None and step % barofreq == 0:
+            t = h.topology()
+            acc, e_now = baro.move(h, en[-1, 0], use_evb, _mol_atoms(t), spec.mass, spec.n_mole)
+            en[-1, 0] = e_now
+            spec = h.spec
         if use_evb:
             new_hyd = h.topology()["hydronium_molecule"]
             if hop is not None and new_hyd != hyd:

@@ -399,6 +399,71 @@ def test_langevin_thermostat_reaches_its_temperature():
     h.close()
 
 
+def _water_box(n_side, seed):
+    """the synthetic lattice without its acid molecule (plain water; hydronium = -1)"""
+    import dataclasses
+    s = synth.make_system(n_side, n_diabat=1, seed=seed)
+    a0, a1 = s.mol_first[s.hydronium], s.mol_first[s.hydronium] + s.mol_natom[s.hydronium]
+    keep = np.r_[0:a0, a1:s.n_atom]
+    natom = np.delete(s.mol_natom, s.hydronium)
+    return dataclasses.replace(s, xyz=s.xyz[keep], atom_names=[s.atom_names[k] for k in keep], mol_names=[m for i, m in enumerate(s.mol_names) if i != s.hydronium],
+                               mol_natom=natom, mol_first=np.concatenate([[0], np.cumsum(natom)[:-1]]).astype(np.int32), hydronium=-1)
+
+
+@pytest.mark.parametrize("evb", [False, True])
+def test_box_change_equals_a_fresh_context(evb):
+    """msevb_set_box = periodic_box_change (src/pme.f90:634): CB array, reciprocal lattice, cells, list and the captured PME graph follow
+    the new box - the force call after it equals the one of a context created with that box and those coordinates"""
+    from reactive_pb_nn_md_amd import barostat
+    import dataclasses
+    g = golden("evb_n6_d4_s2")
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    call = (lambda hh: hh.ms_evb_calculate_total_force_energy()) if evb else (lambda hh: (lambda r: (r[0]["potential"], r[1]))(hh.calculate_total_force_energy()))
+    e0, F0 = call(h)
+    h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 1))
+    h.md_integrate_atomic(3, spec.delta_t, use_evb=evb)      # a replayed PME graph exists now
+    scale = 1.03
+    t = h.topology()
+    mol_atoms = [list(t["mol_atom_index"][m, :t["mol_n_atom"][m]] - 1) for m in range(spec.n_mole)]
+    x_new = barostat.MCBarostat.scaled_positions(h.get_positions(), spec.mass, mol_atoms, scale)
+    h.set_box(spec.box * scale)
+    h.set_positions(x_new)
+    e1, F1 = call(h)
+    h2 = api.MsEvbHip(dataclasses.replace(spec, box=spec.box * scale, xyz=x_new))
+    e2, F2 = call(h2)
+    assert rel(e1, e2) < 1e-13 and np.abs(F1 - F2).max() < 1e-10 and rel(e1, e0) > 1e-6
+    # ... and back
+    h.set_box(spec.box)
+    h.set_positions(spec.xyz)
+    e3, F3 = call(h)
+    assert rel(e3, e0) < 1e-13 and np.abs(F3 - F0).max() < 1e-10
+    with pytest.raises(RuntimeError, match="verlet_cutoff < L/2"):
+        h.set_box(np.full(3, 15.0))
+    h.close(); h2.close()
+
+
+def test_npt_run_through_the_command_line(tmp_path):
+    """ensemble NPT in the simulation-parameter file: Langevin steps + a Monte-Carlo volume move every barofreq steps (mc_sample,
+    src/md_integration.f90:17-60).  Water box at a pressure that squeezes it: the box shrinks, the run stays finite"""
+    import ref_inputs
+    from reactive_pb_nn_md_amd import io, run
+    ff = forcefield.ch3so3h_water_forcefield()
+    s = _water_box(6, 3)
+    d = str(tmp_path)
+    ref_inputs.write_gro(d + "/sys.gro", s)
+    ref_inputs.write_ffpmt(d + "/ff.pmt", ff)
+    ref_inputs.write_top(d + "/sys.top", ff)
+    ref_inputs.write_simpmt(d + "/sim.pmt", n_step=60, rc=7.0, rv=8.0, nslist=16, pme_grid=16)
+    txt = open(d + "/sim.pmt").read().replace("ensemble NVE", "ensemble NPT").replace("n_output 1000000", "n_output 20")
+    open(d + "/sim.pmt", "w").write(txt + "pressure 20000.0\nbarofreq 5\nbaroscale 0.004\nfriction_coeff 50.0\n")
+    assert run.main([d + "/sys.gro", d + "/ff.pmt", d + "/sys.top", d + "/sim.pmt", d + "/traj.gro", d + "/run.log", "--evb", "no", "--seed", "2"]) == 0
+    first, last = io.read_gro(d + "/traj.gro", 0), io.read_gro(d + "/traj.gro", -1)
+    assert last.title.split()[1] == "60" and last.box[0] < first.box[0] and last.box[0] > 0.9 * first.box[0]
+    log = [ln.split() for ln in open(d + "/run.log") if len(ln.split()) == 4 and ln.split()[0].isdigit()]
+    assert [int(r[0]) for r in log] == [0, 20, 40, 60] and all(np.isfinite(float(r[2])) for r in log)
+
+
 def test_command_line_run_and_restart(tmp_path):
     """python -m reactive_pb_nn_md_amd.run on the reference's four input files: trajectory / log / checkpoint in the reference's
     formats, the energies of the library call by call, a refused overwrite, and a restart that continues the step numbering"""

@@ -186,3 +186,70 @@ def test_trajectory_frame_and_velocity_checkpoint_round_trip(tmp_path):
     assert st == 10 and np.abs(v2 - 2 * v).max() < 1e-6
     st, v1 = io.read_velocity_checkpoint(vp, s.n_atom, step=5)
     assert np.abs(v1 - v).max() < 1e-6
+
+
+def test_monte_carlo_barostat_logic():
+    """monte_carlo_barostat (src/md_integration.f90:229-386) on a stub handle with a known E(L): acceptance weight, rigid scaling of
+    the molecules' centres of mass, forced acceptance when the excess proton moved, step-size adaptation"""
+    from reactive_pb_nn_md_amd import barostat
+
+    class Stub:
+        def __init__(self, xyz, L, k):
+            self.spec = type("S", (), {})()
+            self.spec.box = np.full(3, float(L))
+            self.x, self.k, self.hyd, self.hop_on_next = xyz.copy(), k, 7, False
+        def get_positions(self): return self.x.copy()
+        def set_positions(self, x): self.x = np.array(x, dtype=float)
+        def set_box(self, b): self.spec.box = np.array(b, dtype=float)
+        def topology(self): return {"hydronium_molecule": self.hyd}
+        def calculate_total_force_energy(self, want_force=True): return {"potential": self.k * (self.spec.box[0] - 20.0) ** 2}, None
+        def ms_evb_calculate_total_force_energy(self, want_force=True):
+            if self.hop_on_next:
+                self.hyd += 1
+                self.hop_on_next = False
+            return self.k * (self.spec.box[0] - 20.0) ** 2, None
+
+    rng = np.random.default_rng(1)
+    mol_atoms = [[0, 1, 2], [3, 4, 5], [6, 7, 8, 9]]
+    mass = np.array([16.0, 1.0, 1.0] * 2 + [16.0, 1.0, 1.0, 1.0])
+    xyz = rng.uniform(0, 20, size=(10, 3))
+    xs = barostat.MCBarostat.scaled_positions(xyz, mass, mol_atoms, 1.05)
+    for a in mol_atoms:
+        com0 = (xyz[a] * mass[a, None]).sum(0) / mass[a].sum()
+        com1 = (xs[a] * mass[a, None]).sum(0) / mass[a].sum()
+        assert np.allclose(com1, 1.05 * com0) and np.allclose(xs[a] - com1, xyz[a] - com0)      # rigid molecules, scaled centres
+    # a steep well around L = 20: moves away from it are rejected and undone, moves towards it accepted (w < 0)
+    h = Stub(xyz, 21.0, 1.0e4)
+    b = barostat.MCBarostat(1.0, 300.0, baroscale=0.01, seed=3)
+    e = h.calculate_total_force_energy()[0]["potential"]
+    n_acc = 0
+    for _ in range(40):
+        L0, x0 = h.spec.box[0], h.get_positions()
+        acc, e1 = b.move(h, e, False, mol_atoms, mass, 3)
+        kT = barostat.BOLTZMANN * 300.0
+        w = 1.0e4 * (b.last["new_len"] - 20.0) ** 2 - e + barostat.BAR_TO_KJMOL_A3 * 1.0 * (b.last["new_len"] ** 3 - L0 ** 3) - 3 * kT * 3.0 * np.log(b.last["new_len"] / L0)
+        assert abs(w - b.last["w"]) < 1e-9 * max(1.0, abs(w))
+        if acc:
+            assert h.spec.box[0] == b.last["new_len"] and abs(e1 - 1.0e4 * (h.spec.box[0] - 20.0) ** 2) < 1e-9
+            n_acc += 1
+        else:
+            assert h.spec.box[0] == L0 and np.array_equal(h.get_positions(), x0) and e1 == e
+        e = e1
+    assert 0 < n_acc < 40 and abs(h.spec.box[0] - 20.0) < abs(21.0 - 20.0)
+    # at the bottom of a much steeper well nearly every move is rejected: after more than 10 trials below 25 % the step shrinks by 1.1
+    h3 = Stub(xyz, 20.0, 1.0e9)
+    b3 = barostat.MCBarostat(1.0, 300.0, baroscale=0.01, seed=5)
+    e3 = 0.0
+    for _ in range(11):
+        _acc, e3 = b3.move(h3, e3, False, mol_atoms, mass, 3)
+    assert abs(b3.baroscale - 0.01 / 1.1) < 1e-15 and b3.n_trials == 0
+    # a trial call that moves the excess proton is accepted whatever its weight
+    h2 = Stub(xyz, 20.0, 1.0e6)
+    h2.hop_on_next = True
+    b2 = barostat.MCBarostat(1.0, 300.0, baroscale=0.05, seed=4)
+    acc, _ = b2.move(h2, 0.0, True, mol_atoms, mass, 3)
+    assert acc and b2.last["w"] == -1.0
+    # non-cubic boxes are refused, as in the reference
+    h2.spec.box = np.array([20.0, 20.0, 21.0])
+    with pytest.raises(ValueError, match="non-cubic"):
+        b2.move(h2, 0.0, True, mol_atoms, mass, 3)

@@ -161,7 +161,7 @@ def test_md_trajectory_against_reference(name, evb):
     h.close()
 
 
-@pytest.mark.parametrize("n_ranks", [2, 3])
+@pytest.mark.parametrize("n_ranks", [2, 3, 8])
 def test_diabat_sharding_is_a_partition(n_ranks):
     """virtual ranks: every Hamiltonian element is produced by exactly one rank and equals the single-rank result, and the ranks'
     partial Hellmann-Feynman forces (what msevb_comm_allreduce_forces sums) add up to the single-rank force"""
@@ -215,7 +215,7 @@ def test_diabat_sharding_is_a_partition(n_ranks):
 
 
 @pytest.mark.parametrize("stores", [0, 1])
-@pytest.mark.parametrize("n_ranks", [2, 3])
+@pytest.mark.parametrize("n_ranks", [2, 3, 8])
 def test_sharded_principal_partial_sums(n_ranks, stores):
     """multi-rank layout with the principal diabat's pair loop / per-molecule terms / reciprocal-force accumulation split over the ranks
     (what msevb_comm_init switches on): the ranks' partial blends and partial H11 add up to the single-rank force and energy"""

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
   __syncthreads();
   const int ns = s_ns, ntile = s_off[ns];
   const bool in_lds = ntile <= tile_cap;
-  int* te = (int*)(t4 + tile_cap);
+  int* te = (int*)(t4 + tile_cap + 2);      // (+ 2 spare float4: the last pair of an odd-sized tile reads one entry past it)
   // cell centre: tile coordinates are within +-1.5 cells of it
   const double ox = (cx + 0.5) * box.L[0] / nc.x, oy = (cy + 0.5) * box.L[1] / nc.y, oz = (cz + 0.5) * box.L[2] / nc.z;
   if (in_lds) {
@@ -186,28 +186,37 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
     unsigned total = 0;
     const unsigned base = (unsigned)i * cap;
     if (in_lds) {
-      for (int p0 = 0; p0 < ntile; p0 += 64) {
-        const int p = p0 + lane, pc = min(p, ntile - 1);
-        const float4 t = t4[pc];              // both reads unconditional: one wait per trip, no divergence in the common case
-        const int entry = te[pc];
-        const float dx = fx - t.x, dy = fy - t.y, dz = fz - t.z;
-        const float r2 = dx * dx + dy * dy + dz * dz;
-        const bool cand = p < ntile && __float_as_int(t.w) != mi;
-        bool hit = cand && r2 < rv2f;
-        if (__ballot(cand && fabsf(r2 - rv2f) < band)) {      // rare (about one candidate per atom): too close to call in single precision
-          if (cand && fabsf(r2 - rv2f) < band) {
-            int s2 = 0;
-            while (p >= s_off[s2 + 1]) ++s2;
-            const int j = s_lo[s2] + (p - s_off[s2]);
-            hit = nbr_decide_fp64(pr, xi, yi, zi, posq[j], s_shift[s2][0], s_shift[s2][1], s_shift[s2][2], box, rv2);
+      // two ADJACENT candidates per lane and trip (128 per trip): one 32-byte and one 8-byte LDS read per lane, the fp32 arithmetic of
+      // the pair packs into v_pk_* instructions; the compaction keeps the candidates' order (slot = hits before this lane's pair, then A, then B)
+      for (int p0 = 0; p0 < ntile; p0 += 128) {
+        const int pA = p0 + 2 * lane, pB = pA + 1;
+        const int pr_ = pA < ntile ? pA : 0;      // even index; entry pr_ + 1 <= ntile exists (the tile has one spare entry)
+        const float4 tA = t4[pr_], tB = t4[pr_ + 1];
+        const int2 en = *(const int2*)(te + pr_);
+        const float dxA = fx - tA.x, dyA = fy - tA.y, dzA = fz - tA.z, dxB = fx - tB.x, dyB = fy - tB.y, dzB = fz - tB.z;
+        const float r2A = dxA * dxA + dyA * dyA + dzA * dzA, r2B = dxB * dxB + dyB * dyB + dzB * dzB;
+        const bool cA = pA < ntile && __float_as_int(tA.w) != mi, cB = pB < ntile && __float_as_int(tB.w) != mi;
+        bool hA = cA && r2A < rv2f, hB = cB && r2B < rv2f;
+        const bool bA = cA && fabsf(r2A - rv2f) < band, bB = cB && fabsf(r2B - rv2f) < band;
+        if (__ballot(bA || bB)) {      // rare (about one candidate per atom): too close to call in single precision
+          for (int q = 0; q < 2; ++q) {
+            if (q == 0 ? bA : bB) {
+              const int p = q == 0 ? pA : pB;
+              int s2 = 0;
+              while (p >= s_off[s2 + 1]) ++s2;
+              const int j = s_lo[s2] + (p - s_off[s2]);
+              const bool hit = nbr_decide_fp64(pr, xi, yi, zi, posq[j], s_shift[s2][0], s_shift[s2][1], s_shift[s2][2], box, rv2);
+              if (q == 0) hA = hit; else hB = hit;
+            }
           }
         }
-        const unsigned long long m = __ballot(hit);
-        if (hit) {
-          const unsigned slot = total + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-          if (slot < cap) nbr[base + slot] = entry;
-        }
-        total += (unsigned)__popcll(m);
+        const unsigned long long mA = __ballot(hA), mB = __ballot(hB);
+        const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u)) +
+                                __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
+        const unsigned slotA = total + before, slotB = slotA + (hA ? 1u : 0u);
+        if (hA && slotA < cap) nbr[base + slotA] = en.x;
+        if (hB && slotB < cap) nbr[base + slotB] = en.y;
+        total += (unsigned)(__popcll(mA) + __popcll(mB));
       }
     } else {           // neighbourhood larger than the tile: the same decisions from global memory
       for (int sl = 0; sl < ns; ++sl) {
@@ -491,7 +500,7 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
       static bool attr_set[2] = {false, false};
       auto kern = c->pair_tiles ? k_neighbors_tiles<true> : k_neighbors_tiles<false>;
       if (!attr_set[c->pair_tiles ? 1 : 0]) {
-        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NBR_TILE_CAP * NBR_TILE_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NBR_TILE_CAP * NBR_TILE_BYTES + 64));
         attr_set[c->pair_tiles ? 1 : 0] = true;
       }
       // tile: sized from the largest neighbourhood the last build saw
@@ -499,7 +508,7 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
       int tile_cap = NBR_TILE_CAP2;
       if (c->tile_atoms_max > 0 && c->tile_atoms_max * 1.03 > NBR_TILE_CAP2) tile_cap = std::min(NBR_TILE_CAP, ((int)(c->tile_atoms_max * 1.08) + 63) & ~63);
       if (want_inline) { HIPCHK(hipMemsetAsync(d_stats, 0, 8 * sizeof(int), c->stream)); inline_stats = true; }
-      hipLaunchKernelGGL(kern, dim3(ncell), dim3(1024), (size_t)tile_cap * NBR_TILE_BYTES, c->stream, nc, c->d_cell_start.p, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, box, rv2,
+      hipLaunchKernelGGL(kern, dim3(ncell), dim3(1024), (size_t)tile_cap * NBR_TILE_BYTES + 64, c->stream, nc, c->d_cell_start.p, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, box, rv2,
                          c->nbr_cap, tile_cap, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p, want_inline ? d_stats : (int*)nullptr);
     } else if (c->pair_tiles)
       hipLaunchKernelGGL((k_neighbors<true, true>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,

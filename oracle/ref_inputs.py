@@ -114,9 +114,9 @@ def write_top(path, ff):
 
 
 def write_simpmt(path, *, n_step=1, rc=8.0, rv=9.5, nslist=10, alpha=0.3, pme_grid=32, n_exclusions=2,
-                 delta_t=0.0005, temperature=300.0):
+                 delta_t=0.0005, temperature=300.0, lj_comb_rule="opls"):
     with open(path, "w") as f:
-        f.write("Simulation Methodology\nensemble NVE\nlj_comb_rule opls\ngrid_Tang_Toennies yes\n")
+        f.write("Simulation Methodology\nensemble NVE\nlj_comb_rule %s\ngrid_Tang_Toennies yes\n" % lj_comb_rule)
         f.write("Simulation Parameters\n")
         for k, v in (("n_step", n_step), ("n_output", 1000000), ("n_exclusions", n_exclusions),
                      ("temperature", temperature), ("delta_t", delta_t), ("real_space_cutoff", rc),

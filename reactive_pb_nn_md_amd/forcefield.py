@@ -74,6 +74,13 @@ class ForceField:
     sapt: list = field(default_factory=list)   # optional [(name, A_ex, A_el, A_ind, A_dhf, B, C6, C8, C10, C12)] 'custom_sapt_parameters'
 
 
+def with_standard_cross_terms(ff: ForceField) -> ForceField:
+    """the force field for `lj_comb_rule standard` runs: the explicit cross terms become (epsilon, sigma) pairs (test values); the atomic
+    parameters already are epsilon / sigma"""
+    import dataclasses
+    return dataclasses.replace(ff, cross_terms=[(i, j, 0.55 + 0.1 * k, 2.9 + 0.2 * k) for k, (i, j, _a, _b) in enumerate(ff.cross_terms)])
+
+
 def with_test_sapt(ff: ForceField) -> ForceField:
     """adds a synthetic 'custom_sapt_parameters' block (test values, not a fitted force field) so that the SAPT/Tang-Toennies
     branch of the pair kernel is exercised with non-zero coefficients: every pair involving a zero-epsilon (hydrogen) type
@@ -222,8 +229,9 @@ def build_params(ff: ForceField, moltype_order=None, lj_comb_rule="opls", n_excl
     """moltype_order: molecule-type names in the reference's index order (first appearance in the
     coordinate file, then the remaining ``[ moleculetype ]`` blocks in file order,
     src/initialize_routines.f90:699, src/intra_bonded_interactions.f90:1109-1121)."""
-    if lj_comb_rule != "opls":
-        raise NotImplementedError("only lj_comb_rule=opls is mirrored (the configuration of SURVEY.md 8d)")
+    if lj_comb_rule not in ("opls", "standard"):      # src/initialize_routines.f90:611
+        raise ValueError("lj_comb_rule parameter isn't recognized: 'standard' (Lorentz-Berthelot) or 'opls'")
+    opls = lj_comb_rule == "opls"
     names = [a[0] for a in ff.atypes]
     nt = len(names)
     idx = {n: i for i, n in enumerate(names)}
@@ -239,19 +247,23 @@ def build_params(ff: ForceField, moltype_order=None, lj_comb_rule="opls", n_excl
     for i, a in enumerate(ff.atypes):
         vdw[i, i, 0] = a[2]
         vdw[i, i, 1] = a[3]
-    for (i, j, c6, c12) in ff.cross_terms:
+    for (i, j, p1, p2) in ff.cross_terms:      # opls: (C6, C12), stored C12 first; standard: (epsilon, sigma) as read (:389-405)
         i -= 1
         j -= 1
-        vdw[i, j, 0] = c12
-        vdw[i, j, 1] = c6
-        vdw[j, i, 0] = c12
-        vdw[j, i, 1] = c6
+        if not opls and (p1 > 1000.0 or p2 > 1000.0):
+            raise ValueError("looks like combination rule should be opls: cross term parameters look like C6 and C12")
+        vdw[i, j, 0] = vdw[j, i, 0] = p2 if opls else p1
+        vdw[i, j, 1] = vdw[j, i, 1] = p1 if opls else p2
         gen_cross[i, j] = gen_cross[j, i] = 1
-    # opls: atomic C12/C6 first (gen_C12_C6_epsilon_sigma, :620-634)
-    for i in range(nt):
-        eps, sig = vdw[i, i, 0], vdw[i, i, 1]
-        vdw[i, i, 0] = 4.0 * eps * sig ** 12
-        vdw[i, i, 1] = 4.0 * eps * sig ** 6
+
+    def to_c12_c6(i, j):      # gen_C12_C6_epsilon_sigma (:620-634)
+        eps, sig = vdw[i, j, 0], vdw[i, j, 1]
+        vdw[i, j, 0] = 4.0 * eps * sig ** 12
+        vdw[i, j, 1] = 4.0 * eps * sig ** 6
+
+    if opls:      # atomic C12 / C6 first, geometric means of those afterwards (:446-451)
+        for i in range(nt):
+            to_c12_c6(i, i)
 
     def combine(i, j):
         if vtype[i, j] == 1:
@@ -264,9 +276,13 @@ def build_params(ff: ForceField, moltype_order=None, lj_comb_rule="opls", n_excl
             vdw[i, j, 1] = (t[i, i, 4] + t[j, j, 4]) * t[i, i, 4] * t[j, j, 4] / (t[i, i, 4] ** 2 + t[j, j, 4] ** 2)
             for k in range(4):
                 vdw[i, j, 2 + k] = math.sqrt(t[i, i, 5 + k] * t[j, j, 5 + k])
-        else:
+        elif opls:
             vdw[i, j, 0] = math.sqrt(vdw[i, i, 0] * vdw[j, j, 0])
             vdw[i, j, 1] = math.sqrt(vdw[i, i, 1] * vdw[j, j, 1])
+        else:      # Lorentz-Berthelot on (epsilon, sigma) (:603-605)
+            e = math.sqrt(vdw[i, i, 0] * vdw[j, j, 0])
+            sg = (vdw[i, i, 1] + vdw[j, j, 1]) / 2.0
+            vdw[i, j, 0], vdw[i, j, 1] = e, sg
 
     for i in range(nt):
         for j in range(nt):
@@ -293,6 +309,11 @@ def build_params(ff: ForceField, moltype_order=None, lj_comb_rule="opls", n_excl
             combine(i, i)
         else:
             vtype[i, i] = 0
+    if not opls:      # standard: every Lennard-Jones entry (explicit cross terms included) goes from (epsilon, sigma) to (C12, C6) last (:518-528)
+        for i in range(nt):
+            for j in range(nt):
+                if vtype[i, j] == 0:
+                    to_c12_c6(i, j)
     vdw14 = vdw.copy()
     for (n1, n2, c6, c12) in ff.pairtypes:
         i, j = idx[n1], idx[n2]

@@ -389,14 +389,12 @@ def load_inputs(gro_path, ffpmt_path, top_path, simpmt_path, frame=0, evb=True):
     gro = read_gro(gro_path, frame)
     ff = read_forcefield(ffpmt_path, top_path)
     strings, numbers = read_simpmt(simpmt_path)
-    if strings["lj_comb_rule"] != "opls":
-        raise NotImplementedError("lj_comb_rule '%s' (only 'opls' is built)" % strings["lj_comb_rule"])
     gro.hydronium = locate_hydronium(gro, ff) if evb else -1      # (a build of the reference without MS-EVB never looks for one)
     order = []
     for nm in gro.mol_names:      # molecule types in order of first appearance in the .gro, the .top's extra ones after them
         if nm not in order:
             order.append(nm)
-    params = ffmod.build_params(ff, moltype_order=order)
+    params = ffmod.build_params(ff, moltype_order=order, lj_comb_rule=strings["lj_comb_rule"], n_exclusions=int(numbers["n_exclusions"]))
     rc, rv = numbers["real_space_cutoff"], numbers["verlet_cutoff"]
     L = float(gro.box.min())
     if not (rc < rv < L / 2.0):      # src/general_routines.f90:1115-1130

@@ -49,6 +49,23 @@ def test_forcefield_tables_match_reference_init():
         assert tuple(a[0]) == tuple(b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
 
 
+def test_lorentz_berthelot_tables_match_reference_init():
+    """lj_comb_rule standard (src/initialize_routines.f90:446-528, :603-605): epsilon/sigma combined by Lorentz-Berthelot, explicit
+    cross terms read as (epsilon, sigma), everything converted to C12/C6 last - against the tables of a reference run with that rule"""
+    g = golden("std_n6_lb_s9")
+    ref = system.from_golden(g).params
+    ff = forcefield.with_standard_cross_terms(forcefield.ch3so3h_water_forcefield())
+    mine = forcefield.build_params(ff, moltype_order=["h2o", "so3h"], lj_comb_rule="standard")
+    opls = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"])
+    assert np.array_equal(mine.vdw_type, ref.vdw_type)
+    assert np.allclose(mine.vdw_param, ref.vdw_param, rtol=1e-14, atol=0) and np.allclose(mine.vdw_param14, ref.vdw_param14, rtol=1e-14, atol=0)
+    assert not np.allclose(mine.vdw_param, opls.vdw_param, rtol=1e-6)      # a different rule, different cross terms
+    with pytest.raises(ValueError, match="isn't recognized"):
+        forcefield.build_params(ff, moltype_order=["h2o", "so3h"], lj_comb_rule="geometric")
+    with pytest.raises(ValueError, match="should be opls"):      # C6/C12-sized cross terms under the standard rule (:399-404)
+        forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"], lj_comb_rule="standard")
+
+
 def test_spec_from_synth_equals_spec_from_reference_dump():
     g = golden("evb_n6_d2_s1")
     ref = system.from_golden(g)

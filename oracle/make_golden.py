@@ -80,12 +80,14 @@ def compact(d, keep_store=True):
     return out
 
 
-def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, proton_shift=0.0, so3h_eref=None, standard=False, **simkw):
+def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, proton_shift=0.0, so3h_eref=None, standard=False, rb=False, **simkw):
     if ONLY and name not in ONLY:
         return
     ff = forcefield.ch3so3h_water_forcefield()
     if sapt:
         ff = forcefield.with_test_sapt(ff)
+    if rb:
+        ff = forcefield.with_rb_dihedral(ff)
     if standard:      # Lorentz-Berthelot combination rule (lj_comb_rule standard): cross terms are (epsilon, sigma)
         ff = forcefield.with_standard_cross_terms(ff)
         simkw["lj_comb_rule"] = "standard"
@@ -128,6 +130,7 @@ def main():
     case("std_n6_sapt_s6", 6, 1, 6, evb=False, sapt=True, **small)
     case("evb_n6_d4_sapt_s7", 6, 4, 7, evb=True, sapt=True, **small)
     case("std_n6_lb_s9", 6, 1, 9, evb=False, standard=True, **small)
+    case("std_n6_rb_s10", 6, 1, 10, evb=False, rb=True, **small)
     case("md_std_n6_s4", 6, 1, 4, evb=False, md_steps=4, **small)
     case("md_evb_n6_d2_s5", 6, 2, 5, evb=True, md_steps=4, keep_store=False, **small)
     # principal-diabat switch (src/ms_evb.f90:218-227).  Acid proton started next to its acceptor and the acid's reference energy

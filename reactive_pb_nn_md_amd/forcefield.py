@@ -81,6 +81,14 @@ def with_standard_cross_terms(ff: ForceField) -> ForceField:
     return dataclasses.replace(ff, cross_terms=[(i, j, 0.55 + 0.1 * k, 2.9 + 0.2 * k) for k, (i, j, _a, _b) in enumerate(ff.cross_terms)])
 
 
+def with_rb_dihedral(ff: ForceField) -> ForceField:
+    """the acid's proper dihedral C-S-O-H as a Ryckaert-Bellemans polynomial (function type 3, test coefficients): exercises the third
+    dihedral form of quartet_dihedral_energy_force (src/intra_bonded_interactions.f90:529)"""
+    import dataclasses
+    dt = [(("C_a", "S_a", "O_ah", "H_a", 3, 9.28, 12.16, -13.12, -3.06, 26.24, -31.5) if d[:4] == ("C_a", "S_a", "O_ah", "H_a") else d) for d in ff.dihedraltypes]
+    return dataclasses.replace(ff, dihedraltypes=dt)
+
+
 def with_test_sapt(ff: ForceField) -> ForceField:
     """adds a synthetic 'custom_sapt_parameters' block (test values, not a fitted force field) so that the SAPT/Tang-Toennies
     branch of the pair kernel is exercised with non-zero coefficients: every pair involving a zero-epsilon (hydrogen) type

@@ -41,7 +41,7 @@ def test_verlet_list_identical(oracle_lib, name):
     assert h.hexdigest() == str(g["neighbor_pairs_sha256"])
 
 
-@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3", "std_n6_sapt_s6", "std_n6_lb_s9"])
+@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3", "std_n6_sapt_s6", "std_n6_lb_s9", "std_n6_rb_s10"])
 def test_stages(oracle_lib, name):
     g = golden(name)
     o = oracle_lib.Oracle(system.from_golden(g))
@@ -57,7 +57,10 @@ def test_stages(oracle_lib, name):
     assert np.abs(th - g["theta_conv_Q"]).max() < 1e-14                              # FFT: own radix-2 vs MKL
     assert np.abs(F - g["F_recip"]).max() < 1e-11 and abs(E[0] - g["E_recip"][0]) < 1e-10
     E, F = o.bonded()
-    assert np.array_equal(F, g["F_bonded"])
+    if "_rb_" in name:      # Ryckaert-Bellemans: cosine**n is a libm/compiler power in the reference build, a product here (1 ulp)
+        assert np.abs(F - g["F_bonded"]).max() < 1e-12
+    else:
+        assert np.array_equal(F, g["F_bonded"])
     assert (E[2], E[3], E[4]) == (g["E_bond"][0], g["E_angle"][0], g["E_dihedral"][0])
     e, E, F = o.total()
     assert np.abs(F - g["F_total"]).max() < 1e-11 and abs(e - g["E_total"][0]) < 1e-9 * abs(e)

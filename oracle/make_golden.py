@@ -80,7 +80,7 @@ def compact(d, keep_store=True):
     return out
 
 
-def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, proton_shift=0.0, so3h_eref=None, standard=False, rb=False, **simkw):
+def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, proton_shift=0.0, so3h_eref=None, standard=False, rb=False, cf2=False, **simkw):
     if ONLY and name not in ONLY:
         return
     ff = forcefield.ch3so3h_water_forcefield()
@@ -88,6 +88,8 @@ def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=Fa
         ff = forcefield.with_test_sapt(ff)
     if rb:
         ff = forcefield.with_rb_dihedral(ff)
+    if cf2:
+        ff = forcefield.with_gaussian_coupling(ff)
     if standard:      # Lorentz-Berthelot combination rule (lj_comb_rule standard): cross terms are (epsilon, sigma)
         ff = forcefield.with_standard_cross_terms(ff)
         simkw["lj_comb_rule"] = "standard"
@@ -127,6 +129,7 @@ def main():
     case("evb_n6_d4_s2", 6, 4, 2, evb=True, **small)
     case("evb_n6_d8_s1", 6, 8, 1, evb=True, **small)
     case("evb_n8_d8_s1", 8, 8, 1, evb=True, keep_store=False)
+    case("evb_n6_d4_cf2_s11", 6, 4, 11, evb=True, cf2=True, **small)
     case("std_n6_sapt_s6", 6, 1, 6, evb=False, sapt=True, **small)
     case("evb_n6_d4_sapt_s7", 6, 4, 7, evb=True, sapt=True, **small)
     case("std_n6_lb_s9", 6, 1, 9, evb=False, standard=True, **small)

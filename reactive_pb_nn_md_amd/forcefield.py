@@ -89,6 +89,14 @@ def with_rb_dihedral(ff: ForceField) -> ForceField:
     return dataclasses.replace(ff, dihedraltypes=dt)
 
 
+def with_gaussian_coupling(ff: ForceField) -> ForceField:
+    """the acid-water coupling with the reference's second geometric form, A = exp(-gamma q^2) exp(-k (R_OO - D)^2)
+    (evb_diabatic_coupling_function case 2, src/ms_evb.f90:1241-1250; test parameters {Vconst, gamma, k, D})"""
+    import dataclasses
+    gf = [((r[0], r[1], r[2], 2, [-92.5, 1.75, 9.1, 2.55]) if r[:3] == ("OW", "O_ah", "H_a") else r) for r in ff.geometry_factor]
+    return dataclasses.replace(ff, geometry_factor=gf)
+
+
 def with_test_sapt(ff: ForceField) -> ForceField:
     """adds a synthetic 'custom_sapt_parameters' block (test values, not a fitted force field) so that the SAPT/Tang-Toennies
     branch of the pair kernel is exercised with non-zero coefficients: every pair involving a zero-epsilon (hydrogen) type

@@ -66,6 +66,20 @@ def test_lorentz_berthelot_tables_match_reference_init():
         forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"], lj_comb_rule="standard")
 
 
+def test_exclusion_matrices_for_n_exclusions_3():
+    """n_exclusions = 3: atoms three bonds apart are excluded outright instead of interacting with the 1-4 parameters
+    (src/intra_bonded_interactions.f90:574-660) - against the matrices of a reference run with that setting"""
+    g = golden("std_n6_ex3_s12")
+    ref = system.from_golden(g).params
+    mine3 = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"], n_exclusions=3)
+    mine2 = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"], n_exclusions=2)
+    differs = False
+    for a, b, c2 in zip(mine3.moltypes, ref.moltypes, mine2.moltypes):
+        assert np.array_equal(a["excl"], b["excl"]), a["name"]
+        differs |= not np.array_equal(a["excl"], c2["excl"])
+    assert differs
+
+
 def test_spec_from_synth_equals_spec_from_reference_dump():
     g = golden("evb_n6_d2_s1")
     ref = system.from_golden(g)

@@ -134,6 +134,7 @@ def main():
     case("evb_n6_d4_sapt_s7", 6, 4, 7, evb=True, sapt=True, **small)
     case("std_n6_lb_s9", 6, 1, 9, evb=False, standard=True, **small)
     case("std_n6_rb_s10", 6, 1, 10, evb=False, rb=True, **small)
+    case("std_n6_k20_s13", 6, 1, 13, evb=False, rc=7.0, rv=8.0, nslist=16, pme_grid=20, alpha=0.33)      # grid size that is no power of two, another Ewald parameter
     case("std_n6_ex3_s12", 6, 1, 12, evb=False, n_exclusions=3, **small)      # 1-4 pairs excluded instead of taking the pairtypes parameters
     case("md_std_n6_s4", 6, 1, 4, evb=False, md_steps=4, **small)
     case("md_evb_n6_d2_s5", 6, 2, 5, evb=True, md_steps=4, keep_store=False, **small)

@@ -54,7 +54,7 @@ def test_verlet_pair_set_identical(name):
     h.close()
 
 
-@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3", "std_n6_sapt_s6", "std_n6_lb_s9", "std_n6_rb_s10", "std_n6_ex3_s12"])
+@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3", "std_n6_sapt_s6", "std_n6_lb_s9", "std_n6_rb_s10", "std_n6_ex3_s12", "std_n6_k20_s13"])
 def test_stages_against_reference(name):
     g = golden(name)
     h = api.MsEvbHip(system.from_golden(g))

@@ -92,6 +92,7 @@ int msevb_destroy(msevb_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->aux2) (void)hipStreamSynchronize(c->aux2);
   stamps_report(c);
+  for (auto& e : c->pinned_user) if (e.registered) { (void)hipHostUnregister(const_cast<void*>(e.p)); e.registered = false; }
   evb_release(c);
   msevb_comm_release(c);
   if (c->pme_graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)c->pme_graph_exec); c->pme_graph_exec = nullptr; }
@@ -347,7 +348,6 @@ int msevb_finalize(msevb_ctx* c) {
   HIPCHK(hipMemset(c->d_force.p, 0, 3 * (size_t)N * 8));
   HIPCHK(hipMemset(c->d_energies.p, 0, N_SLOTS * 8));
   CHK(pme_setup(c));
-  c->h_xyz.assign(3 * (size_t)N, 0.0);
   c->list_valid = false;
   c->flag_verlet_list = 1;
   c->finalized = true;
@@ -368,9 +368,27 @@ int msevb_get_ewald_self(msevb_ctx* c, double* e) { *e = c->ewald_self; return M
 
 #define NEED_FINAL() do { if (!c || !c->finalized) { if (c) c->err = "context not finalized (msevb_finalize)"; return MSEVB_ERR_STATE; } (void)hipSetDevice(c->device); } while (0)
 
+void pin_user_buffer(msevb_ctx* c, const void* p, size_t bytes) {
+  if (!c->pin_host_arrays || !p || bytes < (1u << 16)) return;
+  int free_slot = -1, coldest = 0;
+  for (int k = 0; k < 8; ++k) {
+    auto& e = c->pinned_user[k];
+    if (e.p == p && e.bytes == bytes) {
+      if (!e.registered && ++e.hits >= 2) e.registered = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess;      // a failure just leaves it pageable
+      if (!e.registered) (void)hipGetLastError();
+      return;
+    }
+    if (!e.p && free_slot < 0) free_slot = k;
+    if (c->pinned_user[k].hits < c->pinned_user[coldest].hits) coldest = k;
+  }
+  const int k = free_slot >= 0 ? free_slot : coldest;      // temporaries (a new address every call) only ever pass through here
+  if (c->pinned_user[k].registered) (void)hipHostUnregister(const_cast<void*>(c->pinned_user[k].p));
+  c->pinned_user[k] = {p, bytes, 1, false};
+}
+
 int msevb_set_positions(msevb_ctx* c, const double* xyz) {
   NEED_FINAL();
-  memcpy(c->h_xyz.data(), xyz, 3 * (size_t)c->N * 8);
+  pin_user_buffer(c, xyz, 3 * (size_t)c->N * 8);
   HIPCHK(hipMemcpyAsync(c->d_xyz.p, xyz, 3 * (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemsetAsync(c->d_energies.p + S_FAULT, 0, 8, c->stream));      // new coordinates: the sticky bad-coordinate flag starts over
   c->h_energies[S_FAULT] = 0.0;
@@ -558,7 +576,7 @@ int msevb_calculate_total_force_energy(msevb_ctx* c, double* energies, double* f
   NEED_FINAL();
   do {      // repeated only when a list row outgrew its stride in a rebuild (the stride has grown by then)
     CHK(total_force_enqueue(c));
-    if (force) HIPCHK(hipMemcpyAsync(force, c->d_force.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
+    if (force) { pin_user_buffer(c, force, 3 * (size_t)c->N * 8); HIPCHK(hipMemcpyAsync(force, c->d_force.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream)); }
     CHK(fetch_energies(c));
   } while (nb_check_overflow(c));
   double en[MSEVB_N_ENERGY];
@@ -625,6 +643,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "overlap") { c->overlap = v != 0.0; return MSEVB_OK; }
   if (s == "pair_prune") { c->prune = v != 0.0; if (c->prune && c->finalized) (void)nb_prune_reset(c); return MSEVB_OK; }
   if (s == "prune_delta") { if (!(v > 0.0)) return MSEVB_ERR_ARG; c->prune_delta = v; if (c->prune && c->finalized) (void)nb_prune_reset(c); return MSEVB_OK; }
+  if (s == "pin_host_arrays") { c->pin_host_arrays = v != 0.0; return MSEVB_OK; }
   if (s == "nbr_cap") { if (v < 64.0) return MSEVB_ERR_ARG; c->nbr_cap = ((unsigned)v + 63u) & ~63u; c->list_valid = false; return MSEVB_OK; }      // row stride (tests: force the overflow path)
   if (s == "nbr_tiles") { c->nbr_tiles = v != 0.0; c->list_valid = false; return MSEVB_OK; }
   if (s == "graphs") { c->graphs = v != 0.0; return MSEVB_OK; }

@@ -184,7 +184,11 @@ struct msevb_ctx {
   std::vector<int> h_ang_idx, h_dih_idx;
   std::vector<double> h_ang_par, h_dih_par;
   MolTypeHost h_mt[MAX_MOLTYPES];
-  std::vector<double> h_xyz;
+  // caller-owned host arrays that keep coming back (a Fortran host's atom_data%xyz / %force) can be page-locked on their second use, so
+  // that the copies go by DMA instead of through a staging buffer.  Opt-in: an array that is freed and whose address is
+  // handed out again (numpy temporaries) would keep a stale registration.
+  bool pin_host_arrays = false;      // opt-in (option pin_host_arrays): only safe when the caller's arrays live as long as the context uses them
+  struct PinnedUser { const void* p; size_t bytes; int hits; bool registered; } pinned_user[8] = {};
   // tables
   std::vector<double> t_B6, t_B5, t_erfc, t_scale, t_tt, t_dtt, t_CB;
   double erfc_dx = 0, ewald_self = 0, kk[3][3];
@@ -277,6 +281,7 @@ int nb_build_begin(msevb_ctx* c);     // cells + sorted arrays
 int nb_build_finish(msevb_ctx* c, bool defer);    // rows (one host synchronisation unless deferred)
 int nb_check_overflow(msevb_ctx* c);  // after a deferred finish
 int build_box_tables(msevb_ctx* c);    // tables.cpp: CB array + reciprocal lattice for the current box
+extern "C" void pin_user_buffer(msevb_ctx* c, const void* p, size_t bytes);      // api.hip
 int nb_prune_reset(msevb_ctx* c);     // the next pair loop prunes (list rebuilt / positions replaced)
 int nb_settle(msevb_ctx* c);          // looks at statistics a failed call left behind
 // GPU-side timestamps of a step (MSEVB_STAMPS=1): tiny kernels write the 100 MHz wall clock at points of interest of each stream; the

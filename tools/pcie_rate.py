@@ -11,15 +11,20 @@ spec = system.from_synth(s, p, rc=9.0, rv=10.5, alpha=0.3, pme_grid=64)
 h = api.MsEvbHip(spec)
 x = spec.xyz.copy()
 h.ms_evb_calculate_total_force_energy()
-for mode in ("device-resident", "host arrays"):
+import ctypes as C
+F = np.zeros((spec.n_atom, 3)); e = C.c_double()
+dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+for mode in ("device-resident", "host arrays", "host arrays, page-locked by the library"):
     n = 200
+    if mode.endswith("library"):
+        h.set_option("pin_host_arrays", 1)
     h.synchronize(); t0 = time.perf_counter()
     for k in range(n):
-        if mode == "host arrays":
-            h.set_positions(x)
-            h.ms_evb_calculate_total_force_energy(want_force=True)
+        if mode != "device-resident":      # the same two caller arrays every call, as a Fortran host has them
+            h._chk(h.L.msevb_set_positions(h.ctx, dp(x)))
+            h._chk(h.L.msevb_ms_evb_calculate_total_force_energy(h.ctx, C.byref(e), dp(F)))
         else:
             h.ms_evb_calculate_total_force_energy(want_force=False)
     h.synchronize(); dt = time.perf_counter() - t0
-    print("%-16s %.3f ms per force call  (%.0f calls/s)" % (mode, dt / n * 1e3, n / dt), flush=True)
+    print("%-42s %.3f ms per force call  (%.0f calls/s)" % (mode, dt / n * 1e3, n / dt), flush=True)
 h.close()

@@ -89,6 +89,13 @@ def main(argv=None):
         t, mnames, anames = names_now()
         io.write_gro_frame(traj, "step  %d time(ps) %r" % (i_step, i_step * dt), mnames, _mol_atoms(t), anames, h.get_positions(), spec.box)
         io.write_log_step(log, i_step, dt, e_pot, e_kin, terms)
+        if use_evb:      # print_evb_trajectory_data (src/ms_evb.f90:3128-3162): the diabats of the last force call
+            st = h.evb_state()
+            log.write(" number of diabat states :  %d\n diabat state    hydronium molecule   evb coefficient  solvation shell\n" % st["D"])
+            for d in range(st["D"]):
+                hops = [hp for hp in st["proton_log"][d] if hp[0] >= 0]
+                mol = hops[-1][3] if hops else t["hydronium_molecule"]
+                log.write("%5d%10d%14.6f%5d\n" % (d + 1, mol, st["eigvec"][d] ** 2, len(hops)))
         traj.flush()
         log.flush()
 
@@ -122,7 +129,8 @@ def main(argv=None):
         if use_evb:
             new_hyd = h.topology()["hydronium_molecule"]
             if hop is not None and new_hyd != hyd:
-                hop.write(" step %d  proton transfer: hydronium molecule %d -> %d\n" % (step, hyd, new_hyd))
+                # the reference's two lines (src/ms_evb.f90:334-335); the step is the end of the integration block the hop happened in
+                hop.write(" step  %d\n proton hop from  %d  to  %d\n" % (step, hyd, new_hyd))
                 hop.flush()
             hyd = new_hyd
         if done % max(1, n_output) == 0:

@@ -460,7 +460,7 @@ def test_npt_run_through_the_command_line(tmp_path):
     assert run.main([d + "/sys.gro", d + "/ff.pmt", d + "/sys.top", d + "/sim.pmt", d + "/traj.gro", d + "/run.log", "--evb", "no", "--seed", "2"]) == 0
     first, last = io.read_gro(d + "/traj.gro", 0), io.read_gro(d + "/traj.gro", -1)
     assert last.title.split()[1] == "60" and last.box[0] < first.box[0] and last.box[0] > 0.9 * first.box[0]
-    log = [ln.split() for ln in open(d + "/run.log") if len(ln.split()) == 4 and ln.split()[0].isdigit()]
+    log = [ln.split() for ln in open(d + "/run.log") if len(ln.split()) == 4 and ln.split()[0].isdigit() and "E" in ln.split()[2]]
     assert [int(r[0]) for r in log] == [0, 20, 40, 60] and all(np.isfinite(float(r[2])) for r in log)
 
 
@@ -481,7 +481,7 @@ def test_command_line_run_and_restart(tmp_path):
     args = [d + "/sys.gro", d + "/ff.pmt", d + "/sys.top", d + "/sim.pmt", d + "/traj.gro", d + "/run.log", d + "/hop.out", d + "/a.out",
             "--seed", "11", "--velocity-checkpoint", d + "/vel", "--checkpoint-every", "4"]
     assert run.main(args) == 0
-    log = [ln.split() for ln in open(d + "/run.log") if len(ln.split()) == 4 and ln.split()[0].isdigit()]
+    log = [ln.split() for ln in open(d + "/run.log") if len(ln.split()) == 4 and ln.split()[0].isdigit() and "E" in ln.split()[2]]
     assert [int(r[0]) for r in log] == [0, 4, 8]
     # the same run through the API
     spec = io.load_inputs(d + "/sys.gro", d + "/ff.pmt", d + "/sys.top", d + "/sim.pmt")[0]
@@ -491,6 +491,13 @@ def test_command_line_run_and_restart(tmp_path):
     en = h.md_integrate_atomic(8, spec.delta_t, use_evb=True)
     assert rel(float(log[0][2]), e0) < 1e-6 and rel(float(log[1][2]), en[3, 0]) < 1e-6 and rel(float(log[2][2]), en[7, 0]) < 1e-6
     assert rel(float(log[2][3]), en[7, 1]) < 1e-6
+    # the diabat table of print_evb_trajectory_data: one block per printed step, coefficients of the last one = c_d^2 of the API run
+    txt_log = open(d + "/run.log").read()
+    assert txt_log.count("number of diabat states") == 3
+    tab = [ln.split() for ln in txt_log.split("number of diabat states")[-1].split("\n")[2:] if len(ln.split()) == 4]
+    st = h.evb_state()
+    assert len(tab) == st["D"] and all(abs(float(r[2]) - st["eigvec"][k] ** 2) < 2e-6 for k, r in enumerate(tab))
+    assert int(tab[0][1]) == h.topology()["hydronium_molecule"] and int(tab[0][3]) == 0 and int(tab[1][3]) >= 1
     last = io.read_gro(d + "/traj.gro", -1)
     assert last.title.split()[1] == "8" and np.abs(last.xyz - h.get_positions()).max() < 6e-3      # F8.3 nm
     st, v = io.read_velocity_checkpoint(d + "/vel", spec.n_atom)
@@ -499,7 +506,7 @@ def test_command_line_run_and_restart(tmp_path):
     # outputs exist and the checkpoint too -> restart: four more steps appended, numbered 12
     open(d + "/sim.pmt", "w").write(txt.replace("n_step 8", "n_step 12"))
     assert run.main(args) == 0
-    log = [ln.split() for ln in open(d + "/run.log") if len(ln.split()) == 4 and ln.split()[0].isdigit()]
+    log = [ln.split() for ln in open(d + "/run.log") if len(ln.split()) == 4 and ln.split()[0].isdigit() and "E" in ln.split()[2]]
     assert [int(r[0]) for r in log] == [0, 4, 8, 12]
     assert io.read_gro(d + "/traj.gro", -1).title.split()[1] == "12"
     # without the checkpoint the existing outputs are not overwritten

@@ -75,6 +75,8 @@ int msevb_get_ewald_self(msevb_ctx* ctx, double* ewald_self);
 
 /* ---- per-step data ---------------------------------------------------------------------------- */
 int msevb_set_positions(msevb_ctx* ctx, const double* xyz /*(3,N) host*/);
+/* atype_freeze (src/glob_v.f90, used at src/md_integration.f90:89-169,:473,:512): 1 = atoms of this type are not integrated */
+int msevb_set_frozen_types(msevb_ctx* ctx, const int* atype_freeze /*(n_atom_type)*/, int n_atom_type);
 /* periodic_box_change (src/pme.f90:634-664): new orthorhombic box lengths; CB, the reciprocal lattice and the Verlet list are rebuilt for them */
 int msevb_set_box(msevb_ctx* ctx, const double* box3);
 int msevb_get_positions(msevb_ctx* ctx, double* xyz);

@@ -80,7 +80,7 @@ def compact(d, keep_store=True):
     return out
 
 
-def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, proton_shift=0.0, so3h_eref=None, standard=False, rb=False, cf2=False, **simkw):
+def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, proton_shift=0.0, so3h_eref=None, standard=False, rb=False, cf2=False, freeze=(), **simkw):
     if ONLY and name not in ONLY:
         return
     ff = forcefield.ch3so3h_water_forcefield()
@@ -90,6 +90,9 @@ def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=Fa
         ff = forcefield.with_rb_dihedral(ff)
     if cf2:
         ff = forcefield.with_gaussian_coupling(ff)
+    if freeze:
+        import dataclasses
+        ff = dataclasses.replace(ff, freeze=list(freeze))
     if standard:      # Lorentz-Berthelot combination rule (lj_comb_rule standard): cross terms are (epsilon, sigma)
         ff = forcefield.with_standard_cross_terms(ff)
         simkw["lj_comb_rule"] = "standard"
@@ -138,6 +141,7 @@ def main():
     case("std_n6_ex3_s12", 6, 1, 12, evb=False, n_exclusions=3, **small)      # 1-4 pairs excluded instead of taking the pairtypes parameters
     case("md_std_n6_s4", 6, 1, 4, evb=False, md_steps=4, **small)
     case("md_evb_n6_d2_s5", 6, 2, 5, evb=True, md_steps=4, keep_store=False, **small)
+    case("md_std_n6_frz_s14", 6, 1, 14, evb=False, md_steps=4, freeze=("OW", "S_a"), **small)      # frozen atom types (atype_freeze)
     # principal-diabat switch (src/ms_evb.f90:218-227).  Acid proton started next to its acceptor and the acid's reference energy
     # raised by 850 kJ/mol (the unrelaxed lattice otherwise keeps the acid diabat ~800 kJ/mol below): the reference's FIRST EVB force
     # call (during its initialisation) hands the proton to the water, so everything this fixture holds - 'xyz', topology, Hamiltonian,

@@ -751,12 +751,14 @@ static void shift_into_box(OrcSys* s) { /* shift_molecules_into_box: src/general
     for (int k = 0; k < s->mol_natom[m]; ++k) for (int d = 0; d < 3; ++d) s->xyz[3 * at[k] + d] = s->xyz[3 * at[k] + d] + sh[d];
   }
 }
-static void remove_com_momentum(OrcSys* s, double* vel) { /* src/md_integration.f90:125-177 */
+static int frozen_atom(const OrcSys* s, int a) { return s->atype_freeze[s->atype[a]] == 1; }
+void orc_set_atype_freeze(OrcSys* s, const int* f) { for (int t = 0; t < s->nt; ++t) s->atype_freeze[t] = f[t]; }
+static void remove_com_momentum(OrcSys* s, double* vel) { /* src/md_integration.f90:125-177; frozen atom types carry no momentum and are not counted */
   double rho[3] = {0, 0, 0}; int n = 0;
   for (int m = 0; m < s->M; ++m) { const int* at = &s->mol_atoms[m * ORC_MAX_MOL_ATOMS];
-    for (int k = 0; k < s->mol_natom[m]; ++k) { int a = at[k]; n++; for (int d = 0; d < 3; ++d) rho[d] = rho[d] + s->mass[a] * vel[3 * a + d]; } }
+    for (int k = 0; k < s->mol_natom[m]; ++k) { int a = at[k]; if (frozen_atom(s, a)) continue; n++; for (int d = 0; d < 3; ++d) rho[d] = rho[d] + s->mass[a] * vel[3 * a + d]; } }
   for (int d = 0; d < 3; ++d) rho[d] = rho[d] / (double)n;
-  for (int a = 0; a < s->N; ++a) for (int d = 0; d < 3; ++d) vel[3 * a + d] = vel[3 * a + d] - rho[d] / s->mass[a];
+  for (int a = 0; a < s->N; ++a) { if (frozen_atom(s, a)) continue; for (int d = 0; d < 3; ++d) vel[3 * a + d] = vel[3 * a + d] - rho[d] / s->mass[a]; }
 }
 double orc_kinetic_energy(OrcSys* s, const double* vel) { /* src/total_energy_forces.f90:106-121 */
   double ke = 0; for (int a = 0; a < s->N; ++a) ke = ke + 0.5 * s->mass[a] * dot3(&vel[3 * a], &vel[3 * a]) / 100.0; return ke;
@@ -764,15 +766,17 @@ double orc_kinetic_energy(OrcSys* s, const double* vel) { /* src/total_energy_fo
 /* md_integrate_atomic, NVE: src/md_integration.f90:438-541 */
 double orc_md_step(OrcSys* s, double* vel, double* F, double dt, int evb) {
   int N = s->N; double E[5], epot;
-  for (int a = 0; a < N; ++a) for (int d = 0; d < 3; ++d) {
-    vel[3 * a + d] = vel[3 * a + d] + dt / 2.0 / s->mass[a] * F[3 * a + d] * 100.0;
-    s->xyz[3 * a + d] = s->xyz[3 * a + d] + vel[3 * a + d] * dt;
-  }
+  for (int a = 0; a < N; ++a) { if (frozen_atom(s, a)) continue;      /* :473 */
+    for (int d = 0; d < 3; ++d) {
+      vel[3 * a + d] = vel[3 * a + d] + dt / 2.0 / s->mass[a] * F[3 * a + d] * 100.0;
+      s->xyz[3 * a + d] = s->xyz[3 * a + d] + vel[3 * a + d] * dt;
+    } }
   orc_update_com(s); shift_into_box(s);
   if (s->verlet_flag == 1) { orc_verlet_build(s, s->nslist); orc_verlet_check(s, 1); s->verlet_flag = 0; }
   else s->verlet_flag = orc_verlet_check(s, 0);
   if (evb) { epot = orc_evb_force_energy_noverlet(s, F); orc_evb_apply_principal(s); } else epot = orc_total(s, E, F);
-  for (int a = 0; a < N; ++a) for (int d = 0; d < 3; ++d) vel[3 * a + d] = vel[3 * a + d] + dt / 2.0 / s->mass[a] * F[3 * a + d] * 100.0;
+  for (int a = 0; a < N; ++a) { if (frozen_atom(s, a)) continue;      /* :512 */
+    for (int d = 0; d < 3; ++d) vel[3 * a + d] = vel[3 * a + d] + dt / 2.0 / s->mass[a] * F[3 * a + d] * 100.0; }
   remove_com_momentum(s, vel);
   return epot;
 }

@@ -45,6 +45,7 @@ struct OrcSys {
   int *verlet_point, *neighbor_list, n_neighbors, nslist, verlet_flag; double *vstore, *vdisp;
   /* EVB tables */
   double atype_chg[ORC_MAX_TYPES];
+  int atype_freeze[ORC_MAX_TYPES];   /* src/glob_v.f90:323 */
   int acid[ORC_MAX_MOLTYPES], base[ORC_MAX_MOLTYPES], conj_mol[ORC_MAX_MOLTYPES], proton_type[ORC_MAX_MOLTYPES], heavy_type[ORC_MAX_MOLTYPES];
   int conj_atype[ORC_MAX_TYPES]; double ref_energy[ORC_MAX_MOLTYPES], exch_atomic[ORC_MAX_TYPES], exch_proton[ORC_MAX_MOLTYPES][ORC_MAX_MOLTYPES];
   int n_da, da_types[ORC_MAX_INTERACTION][3]; double da_par[ORC_MAX_INTERACTION][6];
@@ -83,4 +84,5 @@ double orc_total_topo(OrcSys* s, const OrcTopo* tp, const int* vp, const int* nl
 void orc_update_com(OrcSys* s);
 double orc_evb_force_energy_noverlet(OrcSys* s, double* F);
 void orc_set_atype_chg(OrcSys* s, const double* atype_chg);
+void orc_set_atype_freeze(OrcSys* s, const int* atype_freeze);
 #endif

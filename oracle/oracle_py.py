@@ -69,6 +69,10 @@ class Oracle:
                               len(mt["dihedrals"]), k[3][1], k[4][1], k[5][1], k[6][1])
         c, pc = _d(p.atype_chg)
         L.orc_set_atype_chg(self.h, pc)
+        fz = getattr(p, "atype_freeze", None)
+        if fz is not None:
+            k = _i(np.asarray(fz)[:nt])
+            L.orc_set_atype_freeze(self.h, k[1])
         if p.evb:
             e = p.evb
             da_t = np.array([r[0] for r in e["donor_acceptor"]], dtype=np.int32).reshape(-1, 3)

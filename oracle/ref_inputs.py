@@ -37,7 +37,7 @@ def write_ffpmt(path, ff):
     with open(path, "w") as f:
         f.write("solute_species\natom_type_parameters\n%d\n" % len(ff.atypes))
         for a in ff.atypes:
-            f.write("%s %r %r %r 0\n" % (a[0], a[1], a[2], a[3]))
+            f.write("%s %r %r %r %d\n" % (a[0], a[1], a[2], a[3], 1 if a[0] in set(getattr(ff, "freeze", [])) else 0))
         if ff.sapt:
             f.write("\ncustom_sapt_parameters\nname Aex Ael Aind Adhf B C6 C8 C10 C12\n")
             for row in ff.sapt:

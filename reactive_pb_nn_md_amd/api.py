@@ -110,6 +110,8 @@ class MsEvbHip:
             self._set_evb(p.evb, nt, nmt, spec)
         if finalize:
             self._chk(self.L.msevb_finalize(self.ctx))
+            if getattr(p, "atype_freeze", None) is not None and np.any(p.atype_freeze):
+                self.set_frozen_types(p.atype_freeze)
             self.set_positions(spec.xyz)
 
     def _set_evb(self, e, nt, nmt, spec):
@@ -153,6 +155,11 @@ class MsEvbHip:
     def set_positions(self, xyz):
         a = np.ascontiguousarray(xyz, dtype=np.float64)
         self._chk(self.L.msevb_set_positions(self.ctx, _dp(a)))
+
+    def set_frozen_types(self, atype_freeze):
+        """atype_freeze (src/md_integration.f90:473, :512): atoms of these types keep position and velocity"""
+        a = np.ascontiguousarray(atype_freeze, dtype=np.int32)
+        self._chk(self.L.msevb_set_frozen_types(self.ctx, _ip(a), len(a)))
 
     def set_box(self, box):
         """periodic_box_change (src/pme.f90:634): new orthorhombic box lengths; CB, reciprocal lattice and Verlet list follow"""

@@ -104,7 +104,7 @@ int msevb_destroy(msevb_ctx* c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   pme_teardown(c);
   DBuf<int>* ib[] = {&c->d_atype, &c->d_mol_type, &c->d_mol_natom, &c->d_mol_atoms, &c->d_mol_of, &c->d_cell_of, &c->d_perm, &c->d_cell_keys_tmp,
-                     &c->d_perm_tmp, &c->d_cell_start, &c->d_inv_perm, &c->d_tile_max, &c->d_nbr, &c->d_nbr2, &c->d_prune_mode, &c->d_type_sorted, &c->d_mol_sorted, &c->d_base, &c->d_splindex};
+                     &c->d_perm_tmp, &c->d_cell_start, &c->d_inv_perm, &c->d_tile_max, &c->d_nbr, &c->d_nbr2, &c->d_prune_mode, &c->d_frozen, &c->d_type_sorted, &c->d_mol_sorted, &c->d_base, &c->d_splindex};
   for (auto b : ib) b->release();
   DBuf<double>* db[] = {&c->d_chg, &c->d_mass, &c->d_B6, &c->d_B5, &c->d_tt, &c->d_dtt, &c->d_CB, &c->d_xyz, &c->d_vel, &c->d_force, &c->d_force_recip,
                         &c->d_xyz_store, &c->d_disp, &c->d_maxdisp, &c->d_Q, &c->d_theta, &c->d_w, &c->d_dw, &c->d_uscale, &c->d_partials, &c->d_energies,
@@ -298,8 +298,33 @@ int upload_topology(msevb_ctx* c) {   // atom types / charges / molecule members
   HIPCHK(hipMemcpyAsync(c->d_mol_natom.p, c->h_mol_natom.data(), M * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->d_mol_atoms.p, c->h_mol_atoms.data(), (size_t)M * MAX_MOL_ATOMS * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->d_mol_of.p, c->h_mol_of.data(), N * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  // frozen atoms follow the atom types (which follow the topology)
+  c->n_free = (double)N; c->inv_mass_sum_free = 0.0; c->any_frozen = false;
+  std::vector<int> fr;
+  if (!c->freeze_type.empty()) {
+    fr.assign(N, 0);
+    int nfr = 0;
+    for (int a = 0; a < N; ++a) { const int t = c->h_atype[a]; if (t >= 0 && t < (int)c->freeze_type.size() && c->freeze_type[t] == 1) { fr[a] = 1; ++nfr; } }
+    c->any_frozen = nfr > 0;
+    c->n_free = (double)(N - nfr);
+  }
+  for (int a = 0; a < N; ++a) if (fr.empty() || !fr[a]) c->inv_mass_sum_free += 1.0 / c->h_mass[a];
+  if (c->any_frozen) {
+    if (c->d_frozen.alloc(N)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (frozen flags)");
+    HIPCHK(hipMemcpyAsync(c->d_frozen.p, fr.data(), N * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   return MSEVB_OK;
+}
+
+// atype_freeze(i_type) == 1 (src/md_integration.f90:473, :512, :89-169): atoms of such types are neither kicked nor moved, do not
+// count in the centre-of-mass momentum and do not give any of it up
+int msevb_set_frozen_types(msevb_ctx* c, const int* atype_freeze, int n_types) {
+  if (!c || !c->finalized) { if (c) c->err = "context not finalized"; return MSEVB_ERR_STATE; }
+  (void)hipSetDevice(c->device);
+  if (!atype_freeze || n_types < 0) { c->err = "bad argument"; return MSEVB_ERR_ARG; }
+  c->freeze_type.assign(atype_freeze, atype_freeze + n_types);
+  return upload_topology(c);
 }
 
 int msevb_finalize(msevb_ctx* c) {

@@ -187,6 +187,8 @@ struct msevb_ctx {
   // caller-owned host arrays that keep coming back (a Fortran host's atom_data%xyz / %force) can be page-locked on their second use, so
   // that the copies go by DMA instead of through a staging buffer.  Opt-in: an array that is freed and whose address is
   // handed out again (numpy temporaries) would keep a stale registration.
+  // frozen atom types (atype_freeze): d_frozen = per-atom flags (nullptr when nothing is frozen), n_free = atoms that are integrated
+  std::vector<int> freeze_type; DBuf<int> d_frozen; bool any_frozen = false; double n_free = 0.0, inv_mass_sum_free = 0.0;
   bool pin_host_arrays = false;      // opt-in (option pin_host_arrays): only safe when the caller's arrays live as long as the context uses them
   struct PinnedUser { const void* p; size_t bytes; int hits; bool registered; } pinned_user[8] = {};
   // tables

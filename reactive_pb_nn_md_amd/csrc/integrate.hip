@@ -34,21 +34,22 @@ __device__ __forceinline__ void normal3(const Langevin& L, int atom, double z[3]
 }
 
 // per-block partial sums of momentum (3) and kinetic energy
-__global__ __launch_bounds__(256) void k_momentum_ke(int N, const double* __restrict__ mass, const double* __restrict__ v, double* __restrict__ part) {
+// (frozen atoms - atype_freeze - count in the kinetic energy, not in the momentum: src/md_integration.f90:125-177, total_energy_forces.f90:106)
+__global__ __launch_bounds__(256) void k_momentum_ke(int N, const double* __restrict__ mass, const double* __restrict__ v, double* __restrict__ part, const int* __restrict__ frozen) {
   __shared__ double red[4][256];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double p[4] = {0, 0, 0, 0};
-  if (i < N) { const double m = mass[i]; for (int d = 0; d < 3; ++d) { p[d] = m * v[3 * i + d]; p[3] += 0.5 * m * v[3 * i + d] * v[3 * i + d] / 100.0; } }
+  if (i < N) { const double m = mass[i]; const bool fr = frozen && frozen[i]; for (int d = 0; d < 3; ++d) { p[d] = fr ? 0.0 : m * v[3 * i + d]; p[3] += 0.5 * m * v[3 * i + d] * v[3 * i + d] / 100.0; } }
   for (int s = 0; s < 4; ++s) red[s][threadIdx.x] = p[s];
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) for (int s = 0; s < 4; ++s) red[s][threadIdx.x] += red[s][threadIdx.x + st]; __syncthreads(); }
   if (threadIdx.x == 0) { part[(size_t)S_PX * MAX_BLOCKS + blockIdx.x] = red[0][0]; part[(size_t)S_PY * MAX_BLOCKS + blockIdx.x] = red[1][0];
     part[(size_t)S_PZ * MAX_BLOCKS + blockIdx.x] = red[2][0]; part[(size_t)S_KE * MAX_BLOCKS + blockIdx.x] = red[3][0]; }
 }
-__global__ void k_remove_momentum(int N, const double* __restrict__ mass, const double* __restrict__ en, double* __restrict__ v) {
+__global__ void k_remove_momentum(int N, double n_free, const double* __restrict__ mass, const double* __restrict__ en, double* __restrict__ v, const int* __restrict__ frozen) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 3 * N) return;
-  v[i] -= en[S_PX + i % 3] / (double)N / mass[i / 3];
+  if (i >= 3 * N || (frozen && frozen[i / 3])) return;
+  v[i] -= en[S_PX + i % 3] / n_free / mass[i / 3];
 }
 
 // Fused step kernels of the device-resident MD loop -----------------------------------------------------------------------------
@@ -60,7 +61,7 @@ __global__ void k_remove_momentum(int N, const double* __restrict__ mass, const 
 __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt, int remove, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms,
                                                          const double* __restrict__ mass, const double* __restrict__ F, double* __restrict__ en,
                                                          double* __restrict__ v, double* __restrict__ x, BoxDev box, Langevin L,
-                                                         const double* __restrict__ part, int nb, double* __restrict__ post) {
+                                                         const double* __restrict__ part, int nb, double* __restrict__ post, const int* __restrict__ frozen, double n_free) {
   __shared__ double red[256];
   __shared__ double tot[7];
   double P[3] = {0.0, 0.0, 0.0};
@@ -89,11 +90,12 @@ __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt
   for (int k = 0; k < n; ++k) {
     const int a = mol_atoms[m * MAX_MOL_ATOMS + k];
     const double ma = mass[a];
+    if (frozen && frozen[a]) { for (int d = 0; d < 3; ++d) com[d] += x[3 * a + d] * ma; mt += ma; continue; }      // neither kicked nor moved
     double z[3] = {0, 0, 0};
     if (L.on) normal3(L, a, z);
     for (int d = 0; d < 3; ++d) {
       double vv = v[3 * a + d];
-      if (remove) vv -= P[d] / (double)N / ma;
+      if (remove) vv -= P[d] / n_free / ma;
       if (L.on) vv = L.a * vv + L.b * F[3 * a + d] / ma + L.c / sqrt(ma) * z[d];
       else vv = vv + dt / 2.0 / ma * F[3 * a + d] * 100.0;
       v[3 * a + d] = vv;
@@ -110,11 +112,14 @@ __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt
 // second half: one thread per atom - half kick with the |F| > 1e5 guard (:508-529) and the per-block partial sums of momentum and
 // kinetic energy of the kicked velocities (calculate_kinetic_energy, src/total_energy_forces.f90:106)
 __global__ __launch_bounds__(256) void k_step_second_half(int N, double dt, const double* __restrict__ mass, const double* __restrict__ F, double* __restrict__ v,
-                                                          int* __restrict__ bad, double* __restrict__ part, Langevin L) {
+                                                          int* __restrict__ bad, double* __restrict__ part, Langevin L, const int* __restrict__ frozen) {
   __shared__ double red[7][256];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double p[7] = {0, 0, 0, 0, 0, 0, 0};
-  if (i < N) {
+  if (i < N && frozen && frozen[i]) {      // frozen: velocity untouched, kinetic energy counted, no momentum
+    const double m = mass[i];
+    for (int d = 0; d < 3; ++d) p[3] += 0.5 * m * v[3 * i + d] * v[3 * i + d] / 100.0;
+  } else if (i < N) {
     const double m = mass[i];
     double z[3] = {0, 0, 0};
     if (L.on) normal3(L, i, z);
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void k_step_second_half(int N, double dt, cons
 // velocities is corrected for it: sum m/2 (v - P/(N m))^2 = KE - P.sum(v)/N + P^2/(2 N^2) sum(1/m)
 static double ke_after_removal(const msevb_ctx* c, const double* e /* S_KE.. S_VZ */, double inv_mass_sum) {
   const double* P = e + (S_PX - S_KE); const double* V = e + (S_VX - S_KE);
-  const double N = (double)c->N;
+  const double N = c->n_free;      // the atoms that are integrated (all of them unless atom types are frozen)
   return e[0] - (P[0] * V[0] + P[1] * V[1] + P[2] * V[2]) / N / 100.0 + (P[0] * P[0] + P[1] * P[1] + P[2] * P[2]) / (2.0 * N * N) * inv_mass_sum / 100.0;
 }
 
@@ -148,7 +153,7 @@ static double ke_after_removal(const msevb_ctx* c, const double* e /* S_KE.. S_V
 
 static int momentum_ke(msevb_ctx* c) {
   const int nb = (c->N + 255) / 256;
-  hipLaunchKernelGGL(k_momentum_ke, dim3(nb), dim3(256), 0, c->stream, c->N, c->d_mass.p, c->d_vel.p, c->d_partials.p);
+  hipLaunchKernelGGL(k_momentum_ke, dim3(nb), dim3(256), 0, c->stream, c->N, c->d_mass.p, c->d_vel.p, c->d_partials.p, c->any_frozen ? c->d_frozen.p : (const int*)nullptr);
   HIPCHK(hipGetLastError());
   CHK(reduce_partials(c, S_PX, nb)); CHK(reduce_partials(c, S_PY, nb)); CHK(reduce_partials(c, S_PZ, nb)); CHK(reduce_partials(c, S_KE, nb));
   return flush_reductions(c);   // the momentum is consumed on the device right away
@@ -180,8 +185,8 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
     h_ke_cap = n_steps + 64;
     HIPCHK(hipHostMalloc((void**)&h_ke, 7 * (size_t)h_ke_cap * sizeof(double), hipHostMallocDefault));
   }
-  double inv_mass_sum = 0.0;
-  for (int a = 0; a < N; ++a) inv_mass_sum += 1.0 / c->h_mass[a];
+  const double inv_mass_sum = c->inv_mass_sum_free;
+  const int* frz = c->any_frozen ? c->d_frozen.p : (const int*)nullptr;
   const int nbm = (M + 255) / 256, nba = (N + 255) / 256;
   Langevin L{};
   if (c->nvt) {      // constants of langevin_integrator (src/md_integration.f90:225): the 1/sqrt(m) stays in the kernel
@@ -196,7 +201,7 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
     // EVB loop (no host synchronisation of its own): from the second step on the kernel reduces the previous step's partial sums itself
     const bool self_reduce = use_evb && s > 0;
     hipLaunchKernelGGL(k_step_first_half, dim3(nbm), dim3(256), 0, c->stream, M, N, dt, self_reduce ? 2 : (s > 0 ? 1 : 0), c->d_mol_natom.p, c->d_mol_atoms.p, c->d_mass.p,
-                       c->d_force.p, c->d_energies.p, c->d_vel.p, c->d_xyz.p, box, L, c->d_partials.p, nba, self_reduce ? h_ke + 7 * (size_t)(s - 1) : (double*)nullptr);
+                       c->d_force.p, c->d_energies.p, c->d_vel.p, c->d_xyz.p, box, L, c->d_partials.p, nba, self_reduce ? h_ke + 7 * (size_t)(s - 1) : (double*)nullptr, frz, c->n_free);
     phase_end(c, PH_INTEGRATE);
     double epot = 0.0;
     if (use_evb) { CHK(evb_force_energy(c, &epot)); }
@@ -209,7 +214,7 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
       }
     }
     L.kick = c->langevin_tick++;
-    hipLaunchKernelGGL(k_step_second_half, dim3(nba), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p, c->d_partials.p, L);
+    hipLaunchKernelGGL(k_step_second_half, dim3(nba), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p, c->d_partials.p, L, frz);
     HIPCHK(hipGetLastError());
     if (!use_evb || s == n_steps - 1) {      // (inside the EVB loop the next step's first kernel does this)
       CHK(reduce_partials(c, S_PX, nba)); CHK(reduce_partials(c, S_PY, nba)); CHK(reduce_partials(c, S_PZ, nba)); CHK(reduce_partials(c, S_KE, nba));
@@ -227,7 +232,7 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
       if (energies_out) { energies_out[2 * s] = en[MSEVB_E_POTENTIAL]; energies_out[2 * s + 1] = ke_after_removal(c, c->h_energies + S_KE, inv_mass_sum); }
     }
   }
-  if (n_steps > 0) hipLaunchKernelGGL(k_remove_momentum, dim3((n3 + 255) / 256), dim3(256), 0, c->stream, N, c->d_mass.p, c->d_energies.p, c->d_vel.p);
+  if (n_steps > 0) hipLaunchKernelGGL(k_remove_momentum, dim3((n3 + 255) / 256), dim3(256), 0, c->stream, N, c->n_free, c->d_mass.p, c->d_energies.p, c->d_vel.p, frz);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   if (use_evb && energies_out) for (int s = 0; s < n_steps; ++s) energies_out[2 * s + 1] = ke_after_removal(c, h_ke + 7 * (size_t)s, inv_mass_sum);

@@ -71,6 +71,7 @@ class ForceField:
     exchange_charge_atomic: dict
     exchange_charge_proton: list      # [(mol1,mol2,q)]
     evb_pairs: list                   # [EvbPair]
+    freeze: list = field(default_factory=list)  # names of frozen atom types (5th column of the force-field file = 1, src/md_integration.f90:473)
     sapt: list = field(default_factory=list)   # optional [(name, A_ex, A_el, A_ind, A_dhf, B, C6, C8, C10, C12)] 'custom_sapt_parameters'
 
 
@@ -203,6 +204,7 @@ class Params:
     moltype_names: list
     moltypes: list                   # per molecule type: dict(n_atom, atype[], bonds[nb,2], angles[na,3], dihedrals[nd,4], excl[n,n])
     evb: dict
+    atype_freeze: np.ndarray = None  # [nt] int32: 1 = atoms of this type are not integrated (atype_freeze, src/glob_v.f90)
 
     @property
     def n_atom_type(self):
@@ -425,4 +427,5 @@ def build_params(ff: ForceField, moltype_order=None, lj_comb_rule="opls", n_excl
     evb["coupling"] = [((idx[r[0]], idx[r[1]], idx[r[2]]), int(r[3]), np.array(list(r[4]) + [0.0] * (10 - len(r[4])))) for r in ff.geometry_factor]
     return Params(atype_names=names, atype_chg=chg, atype_mass=mass, vdw_type=vtype, vdw_param=vdw,
                   vdw_param14=vdw14, bond_type=btype, bond_param=bpar, angle_type=atype_ang,
-                  dihedral_type=atype_dih, moltype_names=order, moltypes=mts, evb=evb)
+                  dihedral_type=atype_dih, moltype_names=order, moltypes=mts, evb=evb,
+                  atype_freeze=np.array([1 if n in set(ff.freeze) else 0 for n in names], dtype=np.int32))

@@ -74,6 +74,12 @@ module msevb_hip_c
        import :: c_ptr, c_int
        type(c_ptr), value :: ctx
      end function
+     integer(c_int) function msevb_set_frozen_types(ctx, atype_freeze, n_atom_type) bind(C, name="msevb_set_frozen_types")
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+       integer(c_int), intent(in) :: atype_freeze(*)
+       integer(c_int), value :: n_atom_type
+     end function
      integer(c_int) function msevb_set_box(ctx, box3) bind(C, name="msevb_set_box")
        import :: c_ptr, c_int, c_double
        type(c_ptr), value :: ctx

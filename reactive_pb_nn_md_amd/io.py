@@ -318,13 +318,12 @@ def read_top(path):
 
 def read_forcefield(ffpmt_path, top_path) -> ForceField:
     p, t = read_ffpmt(ffpmt_path), read_top(top_path)
-    if any(p["freeze"]):
-        raise NotImplementedError("frozen atom types (freeze = 1) are not supported")
     return ForceField(atypes=p["atypes"], cross_terms=p["cross_terms"], pairtypes=p["pairtypes"], bondtypes=t["bondtypes"],
                       angletypes=t["angletypes"], dihedraltypes=t["dihedraltypes"], moltypes=t["moltypes"],
                       reference_energy=t["reference_energy"], donor_acceptor=t["donor_acceptor"], proton_acceptor=t["proton_acceptor"],
                       geometry_factor=t["geometry_factor"], exchange_charge_atomic=t["exchange_charge_atomic"],
-                      exchange_charge_proton=t["exchange_charge_proton"], evb_pairs=t["evb_pairs"], sapt=p["sapt"])
+                      exchange_charge_proton=t["exchange_charge_proton"], evb_pairs=t["evb_pairs"], sapt=p["sapt"],
+                      freeze=[a[0] for a, f in zip(p["atypes"], p["freeze"]) if f == 1])
 
 
 # --------------------------------------------------------------------------------------------------- simulation parameters

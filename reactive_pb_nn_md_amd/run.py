@@ -102,7 +102,8 @@ def main(argv=None):
     e_pot, terms = force_call()
     if not restart:
         log.write(" real_space_cutoff %r verlet_cutoff %r alpha_sqrt %r pme_grid %d delta_t %r n_atom %d\n" % (spec.rc, spec.rv, spec.alpha, spec.pme_grid, dt, spec.n_atom))
-        vel = synth.maxwell_boltzmann(spec.mass, float(numbers["temperature"]), a.seed)
+        frozen = np.asarray(spec.params.atype_freeze)[h.topology()["atom_type_index"] - 1] == 1
+        vel = synth.maxwell_boltzmann(spec.mass, float(numbers["temperature"]), a.seed, frozen)
     h.set_velocities(vel)
     e_kin = h.calculate_kinetic_energy()
     if not restart:

@@ -165,16 +165,21 @@ def make_system(n_side: int, n_diabat: int = 1, seed: int = 0, max_chain: int = 
                   mol_first=first, mol_natom=natom, hydronium=hyd, n_diabat_planted=n_diabat)
 
 
-def maxwell_boltzmann(mass: np.ndarray, temperature: float, seed: int) -> np.ndarray:
+def maxwell_boltzmann(mass: np.ndarray, temperature: float, seed: int, frozen: np.ndarray | None = None) -> np.ndarray:
     """Seeded velocities (A/ps), zero total momentum, rescaled to the target temperature
     (same post-processing as src/md_integration.f90:100-114; the reference seeds its own
-    generator from the clock, src/general_routines.f90:726, so the draw itself is ours)."""
+    generator from the clock, src/general_routines.f90:726, so the draw itself is ours).
+    `frozen` (bool per atom, from atype_freeze): those atoms get no velocity and are left out of the momentum
+    removal and of the temperature count (src/md_integration.f90:89, :107, :151, :169)."""
     rng = np.random.default_rng(seed)
     n = len(mass)
+    free = np.ones(n, dtype=bool) if frozen is None else ~np.asarray(frozen, dtype=bool)
+    nf = int(free.sum())
     sd = np.sqrt(BOLTZMANN * 1000.0 * temperature / (mass / 1000.0)) / 100.0
     v = rng.standard_normal((n, 3)) * sd[:, None]
-    p = (mass[:, None] * v).sum(0) / n
-    v -= p[None, :] / mass[:, None]
+    v[~free] = 0.0
+    p = (mass[:, None] * v).sum(0) / nf
+    v[free] -= p[None, :] / mass[free, None]
     ke = 0.5 * (mass[:, None] * v * v).sum() / CONV_KJMOL_ANG2PS2GMOL
-    v *= np.sqrt(1.5 * BOLTZMANN * temperature * n / ke)
+    v *= np.sqrt(1.5 * BOLTZMANN * temperature * nf / ke)
     return v

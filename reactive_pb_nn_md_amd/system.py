@@ -139,7 +139,7 @@ def from_golden(g) -> SystemSpec:
         )
         hyd = int(g["hydronium_molecule"][0]) - 1
     params = ffmod.Params(atype_names=["t%d" % i for i in range(nt)], atype_chg=g["atype_chg"][:nt].astype(np.float64),
-                          atype_mass=g["atype_mass"][:nt].astype(np.float64), vdw_type=vdw_type, vdw_param=vdw,
+                          atype_mass=g["atype_mass"][:nt].astype(np.float64), atype_freeze=g["atype_freeze"][:nt].astype(np.int32), vdw_type=vdw_type, vdw_param=vdw,
                           vdw_param14=vdw14, bond_type=btype, bond_param=bpar, angle_type=ang, dihedral_type=dih,
                           moltype_names=[m["name"] for m in mts], moltypes=mts, evb=evb)
     box = _f(g["box"])

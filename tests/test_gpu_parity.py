@@ -140,7 +140,7 @@ def test_lds_tiled_pair_kernel(name):
     h.close()
 
 
-@pytest.mark.parametrize("name,evb", [("md_std_n6_s4", False), ("md_evb_n6_d2_s5", True)])
+@pytest.mark.parametrize("name,evb", [("md_std_n6_s4", False), ("md_evb_n6_d2_s5", True), ("md_std_n6_frz_s14", False)])
 def test_md_trajectory_against_reference(name, evb):
     g = golden(name)
     spec = system.from_golden(g)

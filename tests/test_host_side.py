@@ -284,3 +284,20 @@ def test_monte_carlo_barostat_logic():
     h2.spec.box = np.array([20.0, 20.0, 21.0])
     with pytest.raises(ValueError, match="non-cubic"):
         b2.move(h2, 0.0, True, mol_atoms, mass, 3)
+
+
+def test_velocity_sampling_with_frozen_atoms():
+    """src/md_integration.f90:89-114, :151-169: frozen atom types get no velocity, carry no momentum, and the temperature count is the free atoms"""
+    from reactive_pb_nn_md_amd import synth
+    from reactive_pb_nn_md_amd.forcefield import BOLTZMANN, CONV_KJMOL_ANG2PS2GMOL
+    rng = np.random.default_rng(0)
+    mass = rng.uniform(1.0, 32.0, 300)
+    frozen = np.zeros(300, dtype=bool)
+    frozen[::3] = True
+    v = synth.maxwell_boltzmann(mass, 300.0, 7, frozen)
+    assert np.all(v[frozen] == 0.0)
+    assert np.abs((mass[:, None] * v).sum(0)).max() < 1e-10
+    ke = 0.5 * (mass[:, None] * v * v).sum() / CONV_KJMOL_ANG2PS2GMOL
+    assert abs(ke - 1.5 * BOLTZMANN * 300.0 * (~frozen).sum()) < 1e-9 * ke
+    v0 = synth.maxwell_boltzmann(mass, 300.0, 7)
+    assert np.all(v0 != 0.0) and np.abs((mass[:, None] * v0).sum(0)).max() < 1e-10

@@ -95,7 +95,7 @@ def test_evb_from_scratch_equals_reference_delta(oracle_lib, name):
     assert abs(np.linalg.norm(r["eigvec"]) - 1.0) < 1e-12
 
 
-@pytest.mark.parametrize("name,evb", [("md_std_n6_s4", False), ("md_evb_n6_d2_s5", True)])
+@pytest.mark.parametrize("name,evb", [("md_std_n6_s4", False), ("md_evb_n6_d2_s5", True), ("md_std_n6_frz_s14", False)])
 def test_md_trajectory(oracle_lib, name, evb):
     g = golden(name)
     spec = system.from_golden(g)

@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 from reactive_pb_nn_md_amd import api, forcefield, synth, system  # noqa: E402
 
+FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X fp64 vector: 256 CUs x 64 lanes x 2 x 2.4 GHz
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
 
 
@@ -217,6 +218,13 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(ab[dom] / launches_per_step)}
+        if dom == "real space (pair loop)":
+            # the pair arithmetic is fp64 VALU, report that fraction beside the HBM one.  Algorithmic flops =
+            # 50 per pair inside r_c, pairs counted once (P_rc = N * 4/3 pi r_c^3 rho / 2); peak = 256 CUs x 64 lanes x 2 (FMA) x 2.4 GHz.
+            p_rc = spec.n_atom * (4.0 / 3.0 * np.pi * spec.rc ** 3 * spec.n_atom / float(np.prod(spec.box))) / 2.0
+            tf = 50.0 * p_rc / (avg_ms * 1e-3) / 1e12
+            roofline["fp64_valu"] = {"algorithmic_flops_per_launch": int(50.0 * p_rc), "achieved": round(tf, 3), "peak": FP64_VALU_PEAK_TFLOPS,
+                                     "unit": "TFLOP/s", "frac": round(tf / FP64_VALU_PEAK_TFLOPS, 5)}
     out = None
     if rank == 0:
         b_step = sum(ab.values())

@@ -343,30 +343,40 @@ def test_list_row_overflow_repeats_the_force_call(evb):
     h.close()
 
 
-@pytest.mark.parametrize("evb", [False, True])
-def test_langevin_step_against_host_restatement(evb):
+@pytest.mark.parametrize("evb,frozen", [(False, False), (True, False), (True, True)])
+def test_langevin_step_against_host_restatement(evb, frozen):
     """NVT: both kicks of a step follow langevin_integrator (src/md_integration.f90:186-228) with the library's counter-based
     normal deviates, which reactive_pb_nn_md_amd/langevin.py restates; x1 = x0 + v1 dt, then the centre-of-mass momentum goes"""
     from reactive_pb_nn_md_amd import langevin
     g = golden("evb_n6_d2_s1")
     spec = system.from_golden(g)
     h = api.MsEvbHip(spec)
+    free = np.ones(spec.n_atom, dtype=bool)
+    if frozen:      # atype_freeze (src/md_integration.f90:473, :512, :151-169): water oxygens neither kicked nor moved nor counted in P/N
+        ti = h.topology()["atom_type_index"]
+        fz = np.zeros(spec.params.n_atom_type, dtype=np.int32)
+        fz[np.bincount(ti[spec.mass > 10.0]).argmax() - 1] = 1      # the most common heavy type: water oxygen
+        h.set_frozen_types(fz)
+        free = fz[ti - 1] == 0
+        assert 0 < (~free).sum() < spec.n_atom
     gam, T, seed, dt = 5.0, 320.0, 12345678901, spec.delta_t
     for k, v in (("ensemble_nvt", 1), ("friction_coeff", gam), ("temperature", T), ("langevin_seed", seed)):
         h.set_option(k, v)
-    v0 = synth.maxwell_boltzmann(spec.mass, 300.0, 4)
+    v0 = synth.maxwell_boltzmann(spec.mass, 300.0, 4, ~free)
     h.set_velocities(v0)
     F0 = (h.ms_evb_calculate_total_force_energy() if evb else h.calculate_total_force_energy())[1]
     x0 = h.get_positions()
     h.md_integrate_atomic(1, dt, use_evb=evb)
-    v1 = langevin.kick(v0, F0, spec.mass, dt, gam, T, langevin.normals(spec.n_atom, 0, seed))
+    v1 = np.where(free[:, None], langevin.kick(v0, F0, spec.mass, dt, gam, T, langevin.normals(spec.n_atom, 0, seed)), v0)
     x1 = x0 + v1 * dt
     xg = h.get_positions()
     d = xg - x1
     assert np.abs(d - spec.box * np.round(d / spec.box)).max() < 1e-12      # molecules may have been shifted back into the box
     F1 = h.get_forces()
-    v2 = langevin.kick(v1, F1, spec.mass, dt, gam, T, langevin.normals(spec.n_atom, 1, seed))
-    v2 -= (spec.mass[:, None] * v2).sum(0) / spec.n_atom / spec.mass[:, None]      # every atom gives up P/N (src/md_integration.f90:125-177)
+    v2 = np.where(free[:, None], langevin.kick(v1, F1, spec.mass, dt, gam, T, langevin.normals(spec.n_atom, 1, seed)), v1)
+    v2[free] -= (spec.mass[free, None] * v2[free]).sum(0) / free.sum() / spec.mass[free, None]      # every free atom gives up P/N_free (src/md_integration.f90:125-177)
+    if frozen:
+        assert np.abs(d[~free] - spec.box * np.round(d[~free] / spec.box)).max() < 1e-13 and np.all(h.get_velocities()[~free] == 0.0)
     assert np.abs(h.get_velocities() - v2).max() < 1e-10
     # the deviates are standard normal and differ from kick to kick
     z = np.concatenate([langevin.normals(spec.n_atom, k, seed) for k in range(40)])

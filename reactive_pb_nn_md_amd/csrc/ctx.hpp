@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/msevb_hip.h"
@@ -241,8 +242,10 @@ struct msevb_ctx {
   DBuf<double> d_theta;        // real part of the convolved grid (theta_conv_Q)
   DBuf<double> d_w, d_dw, d_uscale;   // per atom: B6 weights [N][3][6], derivative weights, scaled coords
   DBuf<int> d_base, d_splindex;       // nearpt [N][3], B6 rows [N][3][6]
-  rocfft_plan plan_fwd = nullptr, plan_bwd = nullptr, plan_fwd_b = nullptr, plan_bwd_b = nullptr;
-  int plan_batch = 0;
+  rocfft_plan plan_fwd = nullptr, plan_bwd = nullptr;
+  // batched plans by batch size (= number of non-principal diabat grids): kept for the life of the context, because the diabat count moves
+  // up and down during a run and creating a plan pair costs milliseconds (a step costs 0.6 ms)
+  std::map<int, std::pair<rocfft_plan, rocfft_plan>> plans_b;
   bool spread_tiles = true;
   bool has_sapt = false;     // some (type_i,type_j) entry has non-zero SAPT coefficients
   rocfft_execution_info fft_info = nullptr, fft_info_b = nullptr;      // single-grid plans (their work buffer is baked into the captured PME graph) / batched plans

@@ -335,11 +335,47 @@ int pme_setup(msevb_ctx* c) {
 void pme_teardown(msevb_ctx* c) {
   if (c->plan_fwd) { rocfft_plan_destroy(c->plan_fwd); c->plan_fwd = nullptr; }
   if (c->plan_bwd) { rocfft_plan_destroy(c->plan_bwd); c->plan_bwd = nullptr; }
-  if (c->plan_fwd_b) { rocfft_plan_destroy(c->plan_fwd_b); c->plan_fwd_b = nullptr; }
-  if (c->plan_bwd_b) { rocfft_plan_destroy(c->plan_bwd_b); c->plan_bwd_b = nullptr; }
-  c->plan_batch = 0;
+  for (auto& kv : c->plans_b) { if (kv.second.first) rocfft_plan_destroy(kv.second.first); if (kv.second.second) rocfft_plan_destroy(kv.second.second); }
+  c->plans_b.clear();
   if (c->fft_info) { rocfft_execution_info_destroy(c->fft_info); c->fft_info = nullptr; }
   if (c->fft_info_b) { rocfft_execution_info_destroy(c->fft_info_b); c->fft_info_b = nullptr; }
+}
+
+// The plan pair for `batch` grids, created on first use and kept (c->plans_b).  The first batched call also creates the pairs for the batch
+// sizes around it: a proton-transfer tree gains and loses a diabat every few dozen steps, and a plan pair costs milliseconds to make.
+static int pme_batched_plan_make(msevb_ctx* c, int batch) {
+  if (c->plans_b.count(batch)) return MSEVB_OK;
+  size_t len[3] = {(size_t)c->K, (size_t)c->K, (size_t)c->K};
+  rocfft_plan f = nullptr, b = nullptr;
+  FFTCHK(rocfft_plan_create(&f, rocfft_placement_inplace, rocfft_transform_type_complex_forward, rocfft_precision_double, 3, len, batch, nullptr));
+  FFTCHK(rocfft_plan_create(&b, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, rocfft_precision_double, 3, len, batch, nullptr));
+  c->plans_b[batch] = std::make_pair(f, b);
+  size_t wf = 0, wb = 0;
+  FFTCHK(rocfft_plan_get_work_buffer_size(f, &wf));
+  FFTCHK(rocfft_plan_get_work_buffer_size(b, &wb));
+  if (wb > wf) wf = wb;
+  // the batched plans have their OWN work buffer and execution info: growing a shared buffer would free the one whose address the
+  // captured graph of the single-grid front end replays with (K = 128 needs work buffers; K = 64 does not - config C faulted here)
+  if (!c->fft_info_b) FFTCHK(rocfft_execution_info_create(&c->fft_info_b));
+  if (wf > c->d_fft_work_b.n) {
+    HIPCHK(hipDeviceSynchronize());
+    if (c->d_fft_work_b.alloc(wf)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (FFT work buffer)");
+    FFTCHK(rocfft_execution_info_set_work_buffer(c->fft_info_b, c->d_fft_work_b.p, c->d_fft_work_b.n));
+  }
+  return MSEVB_OK;
+}
+
+static int pme_batched_plans(msevb_ctx* c, int batch, rocfft_plan* pf, rocfft_plan* pb) {
+  if (!c->plans_b.count(batch)) {
+    const bool first = c->plans_b.empty();
+    if (int rc = pme_batched_plan_make(c, batch)) return rc;
+    if (first && c->K <= 64) {      // small grids only: at K = 128 a work buffer per size would be 100s of MB and the step is 8 ms anyway
+      const int hi = batch + 3 > 10 ? batch + 3 : 10;
+      for (int b = 2; b <= hi; ++b) if (int rc = pme_batched_plan_make(c, b)) return rc;
+    }
+  }
+  *pf = c->plans_b[batch].first; *pb = c->plans_b[batch].second;
+  return MSEVB_OK;
 }
 
 // theta_g = IFFT(CB * FFT(grid_g)) in place for `batch` contiguous grids; the energy partials of grid g go to
@@ -348,27 +384,7 @@ int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part
   const size_t K3 = (size_t)c->K * c->K * c->K;
   rocfft_plan pf = c->plan_fwd, pb = c->plan_bwd;
   if (batch > 1) {
-    if (c->plan_batch != batch) {
-      if (c->plan_fwd_b) { rocfft_plan_destroy(c->plan_fwd_b); c->plan_fwd_b = nullptr; }
-      if (c->plan_bwd_b) { rocfft_plan_destroy(c->plan_bwd_b); c->plan_bwd_b = nullptr; }
-      size_t len[3] = {(size_t)c->K, (size_t)c->K, (size_t)c->K};
-      FFTCHK(rocfft_plan_create(&c->plan_fwd_b, rocfft_placement_inplace, rocfft_transform_type_complex_forward, rocfft_precision_double, 3, len, batch, nullptr));
-      FFTCHK(rocfft_plan_create(&c->plan_bwd_b, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, rocfft_precision_double, 3, len, batch, nullptr));
-      size_t wf = 0, wb = 0;
-      FFTCHK(rocfft_plan_get_work_buffer_size(c->plan_fwd_b, &wf));
-      FFTCHK(rocfft_plan_get_work_buffer_size(c->plan_bwd_b, &wb));
-      if (wb > wf) wf = wb;
-      // the batched plans have their OWN work buffer and execution info: growing a shared buffer would free the one whose address the
-      // captured graph of the single-grid front end replays with (K = 128 needs work buffers; K = 64 does not - config C faulted here)
-      if (!c->fft_info_b) FFTCHK(rocfft_execution_info_create(&c->fft_info_b));
-      if (wf > c->d_fft_work_b.n) {
-        HIPCHK(hipDeviceSynchronize());
-        if (c->d_fft_work_b.alloc(wf)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (FFT work buffer)");
-      }
-      if (c->d_fft_work_b.n) FFTCHK(rocfft_execution_info_set_work_buffer(c->fft_info_b, c->d_fft_work_b.p, c->d_fft_work_b.n));
-      c->plan_batch = batch;
-    }
-    pf = c->plan_fwd_b; pb = c->plan_bwd_b;
+    if (int rc = pme_batched_plans(c, batch, &pf, &pb)) return rc;
   }
   void* buf[1] = {grids};
   rocfft_execution_info info = batch > 1 ? c->fft_info_b : c->fft_info;

@@ -135,6 +135,9 @@ struct DBuf {  // device buffer
     n = count;
     return 0;
   }
+  // for buffers whose size follows the diabat count: grow with half as much again, so that a tree gaining a diabat or two during a run
+  // does not free + allocate (a device synchronisation and milliseconds) every time
+  int alloc_room(size_t count) { return (count <= n && p) ? 0 : alloc(count + count / 2); }
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 

@@ -1223,11 +1223,11 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   const int envb = std::min(16, (N + 255) / 256), cpb = 1024 /* partial-sum row stride; the coupling launches use up to this many blocks per element */;
   const int part_stride = 1024;
   const int n_rows = nu + ncp + ngrid + 8;
-  if (c->d_Fdiag.alloc((size_t)n_diag * n3) || c->d_Foff.alloc((size_t)std::max(n_off, 1) * n3) || 
-      w->d_tabs.alloc(1) || w->d_exch.alloc(MAX_TYPES) || w->d_part.alloc((size_t)n_rows * part_stride) ||
-      w->d_E.alloc(2 * n_rows + 3 * std::max(ncp, 1) + 8) || w->d_dVspec.alloc((size_t)MAX_DIABATS * MAX_SPEC * 3) ||
-      w->d_sbase.alloc(3 * std::max(nra, 1)) || w->d_sw.alloc(18 * (size_t)std::max(nra, 1)) || w->d_sdw.alloc(18 * (size_t)std::max(nra, 1)) ||
-      w->d_grids.alloc(K3 * std::max(ngrid, 1)) || w->d_pack.alloc(K3 * std::max(ngrid, 1)) || w->d_F11.alloc(n3) || w->d_com_atom.alloc(n3))
+  if (c->d_Fdiag.alloc_room((size_t)n_diag * n3) || c->d_Foff.alloc_room((size_t)std::max(n_off, 1) * n3) || 
+      w->d_tabs.alloc(1) || w->d_exch.alloc(MAX_TYPES) || w->d_part.alloc_room((size_t)n_rows * part_stride) ||
+      w->d_E.alloc_room(2 * n_rows + 3 * std::max(ncp, 1) + 8) || w->d_dVspec.alloc((size_t)MAX_DIABATS * MAX_SPEC * 3) ||
+      w->d_sbase.alloc_room(3 * std::max(nra, 1)) || w->d_sw.alloc_room(18 * (size_t)std::max(nra, 1)) || w->d_sdw.alloc_room(18 * (size_t)std::max(nra, 1)) ||
+      w->d_grids.alloc_room(K3 * std::max(ngrid, 1)) || w->d_pack.alloc_room(K3 * std::max(ngrid, 1)) || w->d_F11.alloc(n3) || w->d_com_atom.alloc(n3))
     FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB work buffers)");
   c->evb_cap = D;
   if (!w->tabs_uploaded) {
@@ -1298,7 +1298,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   double* d_cpout = w->d_E.p + 2 * nu + ncp + ngrid;   // [ncp][3]: one download fetches everything
   {   // delta store of the diagonal real-space terms: zero on first use / after a resize / after a failed call, then self-cleaning
     const size_t need = (size_t)n_diag * n3;
-    if (w->d_Fdelta.n < need) { if (w->d_Fdelta.alloc(need)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB delta store)"); w->delta_dirty = true; }
+    if (w->d_Fdelta.n < need) { if (w->d_Fdelta.alloc_room(need)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB delta store)"); w->delta_dirty = true; }
     if (w->delta_dirty) { HIPCHK(hipMemsetAsync(w->d_Fdelta.p, 0, w->d_Fdelta.n * 8, ss)); w->delta_dirty = false; }
   }
   // every element of an owned slot is written by its kernels; slots of other ranks' diabats are never read (partial blend + all-reduce)

@@ -99,6 +99,9 @@ def main():
         import torch
         import torch.distributed as dist
         dist.init_process_group("gloo")      # rendezvous / barriers / timing reduction only; data path is RCCL inside the library
+        ndev = torch.cuda.device_count()      # does not initialise the GPU
+        if ndev > 0:
+            local_rank %= ndev                # a launcher that shows each rank one device only
 
     s = synth.make_system(args.n_side, n_diabat=args.diabats, seed=0, max_chain=3 if args.diabats <= 8 else 4)
     p = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"])
@@ -128,6 +131,7 @@ def main():
         try:
             import torch
             if torch.cuda.is_available():
+                torch.cuda.set_device(local_rank)      # never torch's default device 0 from every rank
                 torch.cuda.synchronize()
         except Exception:
             pass

@@ -93,6 +93,9 @@ void* msevb_device_positions(msevb_ctx* ctx);
 int msevb_construct_verlet_list(msevb_ctx* ctx);
 /* update_verlet_displacements (src/general_routines.f90:1259): flag=1 when the two largest displacements exceed the skin */
 int msevb_update_verlet_displacements(msevb_ctx* ctx, int* flag_verlet_list);
+/* verlet_list_data%flag_verlet_list (src/glob_v.f90:236-250) as the last force call left it: 1 = the NEXT force call rebuilds the
+   list (src/total_energy_forces.f90:30-41).  Read-only. */
+int msevb_get_verlet_flag(msevb_ctx* ctx, int* flag_verlet_list);
 /* optional read-back of the half list in the reference's layout (verlet_point(N+1), neighbor_list, 1-based); order within
    an atom's list is ascending j.  Pass NULL to query sizes only. */
 int msevb_get_verlet_list(msevb_ctx* ctx, int* verlet_point, int* neighbor_list, long* n_neighbors);

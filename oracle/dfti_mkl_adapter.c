@@ -36,7 +36,8 @@ enum { DFTI_COMPLEX_ = 32, DFTI_DOUBLE_ = 36 };
 int dfti_create_descriptor_highd_(f_ptr_desc* d, int* precision, int* domain, int* dim, int* length) {
   long len[8];
   if (*precision != DFTI_DOUBLE_ || *dim > 8) return -1;
-  for (int i = 0; i < *dim; ++i) len[i] = length[i];
+  /* the Fortran array X(n1,n2,n3) is the row-major array [n3][n2][n1] of MKL's C interface */
+  for (int i = 0; i < *dim; ++i) len[i] = length[*dim - 1 - i];
   DFTI_HANDLE h = NULL;
   long st = DftiCreateDescriptor_d_md(&h, *domain, (long)*dim, len);
   d->base_addr = h;

@@ -80,7 +80,7 @@ def compact(d, keep_store=True):
     return out
 
 
-def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, proton_shift=0.0, so3h_eref=None, standard=False, rb=False, cf2=False, freeze=(), **simkw):
+def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, proton_shift=0.0, so3h_eref=None, standard=False, rb=False, cf2=False, freeze=(), md_temp=300.0, **simkw):
     if ONLY and name not in ONLY:
         return
     ff = forcefield.ch3so3h_water_forcefield()
@@ -105,7 +105,7 @@ def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=Fa
         p = forcefield.build_params(ff, moltype_order=["h2o", "so3h"])
         idx = {n: i for i, n in enumerate(p.atype_names)}
         mass = np.array([p.atype_mass[idx[a]] for a in s.atom_names])
-        vel = synth.maxwell_boltzmann(mass, 300.0, seed + 100)
+        vel = synth.maxwell_boltzmann(mass, md_temp, seed + 100)
     d = ref_inputs.run_reference(s, ff, evb=evb, velocities=vel, nsteps=md_steps, **simkw)
     out = compact(d, keep_store=keep_store)
     out["gen_n_side"] = np.array(n_side)
@@ -142,6 +142,12 @@ def main():
     case("md_std_n6_s4", 6, 1, 4, evb=False, md_steps=4, **small)
     case("md_evb_n6_d2_s5", 6, 2, 5, evb=True, md_steps=4, keep_store=False, **small)
     case("md_std_n6_frz_s14", 6, 1, 14, evb=False, md_steps=4, freeze=("OW", "S_a"), **small)      # frozen atom types (atype_freeze)
+    # trajectories that cross Verlet-list rebuilds (update_verlet_displacements, src/general_routines.f90:1259-1337: the flag raised in
+    # one force call makes the NEXT one rebuild, src/total_energy_forces.f90:30-41) and changes of the diabat count: 60 steps at 600 K.
+    # md_verlet_flag / md_n_diabat hold flag_verlet_list and diabat_index after every step.
+    case("md_std_n6_rebuild_s21", 6, 1, 21, evb=False, md_steps=60, md_temp=600.0, **small)
+    case("md_evb_n6_d4_rebuild_s24", 6, 4, 24, evb=True, md_steps=60, md_temp=600.0, keep_store=False, **small)      # 7 rebuilds, D = 4 -> 5 -> 6
+    case("md_evb_n6_d4_drop_s22", 6, 4, 22, evb=True, md_steps=60, md_temp=600.0, keep_store=False, **small)         # 6 rebuilds, D = 4 -> 1
     # principal-diabat switch (src/ms_evb.f90:218-227).  Acid proton started next to its acceptor and the acid's reference energy
     # raised by 850 kJ/mol (the unrelaxed lattice otherwise keeps the acid diabat ~800 kJ/mol below): the reference's FIRST EVB force
     # call (during its initialisation) hands the proton to the water, so everything this fixture holds - 'xyz', topology, Hamiltonian,

@@ -763,6 +763,7 @@ static void remove_com_momentum(OrcSys* s, double* vel) { /* src/md_integration.
 double orc_kinetic_energy(OrcSys* s, const double* vel) { /* src/total_energy_forces.f90:106-121 */
   double ke = 0; for (int a = 0; a < s->N; ++a) ke = ke + 0.5 * s->mass[a] * dot3(&vel[3 * a], &vel[3 * a]) / 100.0; return ke;
 }
+int orc_verlet_flag(OrcSys* s) { return s->verlet_flag; }   /* flag_verlet_list as the last force call left it (src/total_energy_forces.f90:30-41) */
 /* md_integrate_atomic, NVE: src/md_integration.f90:438-541 */
 double orc_md_step(OrcSys* s, double* vel, double* F, double dt, int evb) {
   int N = s->N; double E[5], epot;

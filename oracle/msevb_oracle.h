@@ -54,6 +54,7 @@ double orc_ewald_self(OrcSys*);
 int  orc_verlet_build(OrcSys*, int nslist);   /* returns number of half-list entries */
 void orc_verlet_get(OrcSys*, int* verlet_point /*[N+1] 0-based offsets*/, int* neighbor_list);
 int  orc_verlet_check(OrcSys*, int initialize); /* src/general_routines.f90:1259, returns flag */
+int  orc_verlet_flag(OrcSys*);                  /* flag_verlet_list after the last force call of orc_md_step */
 
 /* stage routines; F is ACCUMULATED into (caller zeroes); E = {E_elec, E_vdw, E_bond, E_angle, E_dihedral} */
 void orc_pair_real_space(OrcSys*, double* E, double* F);   /* src/pair_int_real_space.f90:135 */

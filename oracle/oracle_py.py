@@ -118,6 +118,12 @@ class Oracle:
         self.L.orc_verlet_check(self.h, 1)
         return n
 
+    def verlet_flag(self):
+        return int(self.L.orc_verlet_flag(self.h))
+
+    def n_diabat(self):
+        return int(self.L.orc_evb_n_diabat(self.h))
+
     def verlet_get(self):
         vp = np.zeros(self.N + 1, dtype=np.int32)
         self.L.orc_verlet_get(self.h, _p(vp, C.c_int), None)

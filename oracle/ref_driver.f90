@@ -106,6 +106,7 @@ program ref_dump
   integer :: principle_diabat, new_h, i_step
   integer, allocatable :: itmp(:), itmp2(:,:)
   real*8, allocatable :: rtmp(:,:), vel(:,:), etraj(:,:)
+  integer, allocatable :: vflag(:), ndia(:)
   real*8 :: Epot
 
   nargs_cli = command_argument_count()
@@ -371,7 +372,7 @@ program ref_dump
 
   !----- optional: NSTEPS of velocity Verlet from a seeded velocity file (src/md_integration.f90:438)
   if (nsteps > 0) then
-     allocate(vel(3,N), etraj(2,nsteps))
+     allocate(vel(3,N), etraj(2,nsteps), vflag(nsteps), ndia(nsteps))
      open(unit=78, file=trim(velfile), access='stream', form='unformatted', status='old')
      read(78) vel
      close(78)
@@ -389,7 +390,14 @@ program ref_dump
         call calculate_kinetic_energy( system_data%kinetic_energy, N, atom_data%mass, atom_data%velocity, constants%conv_kJmol_ang2ps2gmol )
         etraj(1,i_step) = system_data%potential_energy
         etraj(2,i_step) = system_data%kinetic_energy
+        ! flag_verlet_list as the force call of this step left it (1 = the NEXT force call rebuilds the list,
+        ! src/total_energy_forces.f90:30-41) and the diabat count of this step's EVB call (src/ms_evb.f90:451)
+        vflag(i_step) = verlet_list_data%flag_verlet_list
+        ndia(i_step) = 1
+        if (ms_evb_simulation == "yes") ndia(i_step) = diabat_index
      end do
+     call dump_i4('md_verlet_flag', vflag, (/nsteps/))
+     call dump_i4('md_n_diabat', ndia, (/nsteps/))
      call dump_is('md_nsteps', nsteps)
      call dump_r8('md_energy', etraj, (/2,nsteps/))
      call dump_r8('md_xyz', atom_data%xyz, (/3,N/))

@@ -209,6 +209,12 @@ class MsEvbHip:
         self._chk(self.L.msevb_update_verlet_displacements(self.ctx, C.byref(f)))
         return f.value
 
+    def verlet_flag(self):
+        """flag_verlet_list as the last force call left it (1 = the next force call rebuilds the list)"""
+        f = C.c_int()
+        self._chk(self.L.msevb_get_verlet_flag(self.ctx, C.byref(f)))
+        return f.value
+
     def get_verlet_list(self):
         n = C.c_long()
         self._chk(self.L.msevb_get_verlet_list(self.ctx, None, None, C.byref(n)))

@@ -456,6 +456,8 @@ int msevb_update_verlet_displacements(msevb_ctx* c, int* flag) {
   return MSEVB_OK;
 }
 
+int msevb_get_verlet_flag(msevb_ctx* c, int* flag) { if (!c || !flag) return MSEVB_ERR_ARG; *flag = c->flag_verlet_list; return MSEVB_OK; }
+
 int msevb_get_verlet_list(msevb_ctx* c, int* vp, int* nl, long* nn) {
   NEED_FINAL();
   CHK(nb_settle(c));

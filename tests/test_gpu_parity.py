@@ -161,6 +161,44 @@ def test_md_trajectory_against_reference(name, evb):
     h.close()
 
 
+@pytest.mark.parametrize("name,evb", [("md_std_n6_rebuild_s21", False), ("md_evb_n6_d4_rebuild_s24", True), ("md_evb_n6_d4_drop_s22", True)])
+def test_md_trajectory_across_rebuilds_against_reference(name, evb):
+    """60 reference steps at 600 K that cross 6-7 Verlet-list rebuilds (update_verlet_displacements, src/general_routines.f90:1259-1337;
+    the flag raised by one force call makes the NEXT one rebuild, src/total_energy_forces.f90:30-41) and changes of the diabat count
+    (4 -> 5 -> 6 and 4 -> 1).  Step by step: energies, flag_verlet_list and the diabat count of the real reference; then the end state."""
+    g = golden(name)
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    h.set_velocities(g["md_velocity0"])
+    if evb:
+        h.ms_evb_calculate_total_force_energy(want_force=False)
+    else:
+        h.calculate_total_force_energy(want_force=False)
+    assert np.abs(h.get_forces() - g["md_F0"]).max() < F_TOL
+    n = int(g["md_nsteps"][0])
+    flags, nd = g["md_verlet_flag"], g["md_n_diabat"]
+    assert flags.sum() >= 6 and (not evb or len(set(nd)) > 1)      # the fixture does cross the events
+    for s in range(n):
+        en = h.md_integrate_atomic(1, spec.delta_t, use_evb=evb)
+        assert abs(en[0, 0] - g["md_energy"][s, 0]) < 1e-9 * abs(g["md_energy"][s, 0]), s
+        assert abs(en[0, 1] - g["md_energy"][s, 1]) < 1e-8 * abs(g["md_energy"][s, 1]), s
+        assert h.verlet_flag() == flags[s], s
+        if evb:
+            assert h.evb_state()["D"] == nd[s], s
+    assert np.abs(h.get_positions() - g["md_xyz"]).max() < 1e-10
+    assert np.abs(h.get_velocities() - g["md_velocity"]).max() < 1e-9
+    assert np.abs(h.get_forces() - g["md_force"]).max() < 1e-7
+    h.close()
+    # the same trajectory in ONE call (device-resident loop, no host look at the flag between steps)
+    h = api.MsEvbHip(spec)
+    h.set_velocities(g["md_velocity0"])
+    (h.ms_evb_calculate_total_force_energy if evb else h.calculate_total_force_energy)(want_force=False)
+    en = h.md_integrate_atomic(n, spec.delta_t, use_evb=evb)
+    assert np.abs(en[:, 0] - g["md_energy"][:, 0]).max() < 1e-9 * np.abs(g["md_energy"][:, 0]).max()
+    assert np.abs(h.get_positions() - g["md_xyz"]).max() < 1e-10 and np.abs(h.get_forces() - g["md_force"]).max() < 1e-7
+    h.close()
+
+
 @pytest.mark.parametrize("n_ranks", [2, 3, 8])
 def test_diabat_sharding_is_a_partition(n_ranks):
     """virtual ranks: every Hamiltonian element is produced by exactly one rank and equals the single-rank result, and the ranks'
@@ -717,6 +755,72 @@ def test_full_size_properties_config_B():
     h.ms_evb_calculate_total_force_energy(want_force=False)           # velocity Verlet starts from the forces at the current positions
     tr2 = h.md_integrate_atomic(40, spec.delta_t, use_evb=True)
     assert np.abs(tr1 - tr2).max() < 1e-6 * np.abs(tr1).max()
+    h.close()
+
+
+@pytest.mark.parametrize("stores", [0, 1])
+def test_config_4_workload_eight_virtual_ranks(stores):
+    """BASELINE.json configs[3] at its own size: 98 220 atoms, 8 diabats, 64^3, sharded one diabat per rank over EIGHT (virtual) ranks
+    with the principal diabat's pair loop / per-molecule terms / reciprocal forces split as msevb_comm_init does: the ranks' partial
+    blends add up to the single-rank force, the partial H11 to H11, every Hamiltonian entry is produced by exactly one rank."""
+    spec = _synthetic(32, 8, 11, 64)
+    h = api.MsEvbHip(spec)
+    _e, Fblend = h.ms_evb_calculate_total_force_energy()
+    full = h.evb_state()
+    assert full["D"] == 8
+    h.close()
+    R = 8
+    Fsum, Esum, Hsum = np.zeros_like(Fblend), 0.0, np.zeros((8, 8))
+    for r in range(R):
+        hr = api.MsEvbHip(spec)
+        hr.set_option("evb_element_stores", stores)
+        hr.set_option("shard_principal", 1)
+        hr.comm_set_virtual(r, R)
+        e_part, _ = hr.ms_evb_calculate_total_force_energy(want_force=False)
+        st = hr.evb_state()
+        for d in range(2, 9):
+            p = full["coupling_matrix"][d - 1]
+            if (d - 2) % R == r:
+                Hsum[p - 1, d - 1] += st["H"][p - 1, d - 1]
+            else:
+                assert st["H"][p - 1, d - 1] == 0.0 and st["H"][d - 1, d - 1] == 0.0      # produced by exactly one rank
+        Esum += e_part
+        Fsum += hr.evb_partial_blend(full["eigvec"])
+        hr.close()
+    assert rel(Esum, full["H"][0, 0]) < 1e-13
+    for d in range(2, 9):
+        p = full["coupling_matrix"][d - 1]
+        assert rel(Hsum[p - 1, d - 1], full["H"][p - 1, d - 1]) < 1e-11, d
+    assert np.abs(Fsum - Fblend).max() < F_TOL
+
+
+def test_config_C_against_oracle(oracle_lib):
+    """BASELINE.json configs[4] on one GPU: 985 362 atoms, 128^3 grid, 16 planted diabats (chains of 4 hops).  Principal-diabat force call
+    against the CPU oracle at full size (one call), schedule independence, Jacobi ground state == LAPACK, third law."""
+    s = synth.make_system(69, n_diabat=16, seed=0, max_chain=4)
+    p = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"])
+    spec = system.from_synth(s, p, rc=9.0, rv=10.5, alpha=0.3, pme_grid=128, max_chain=4)
+    assert spec.n_atom > 980000
+    h = api.MsEvbHip(spec)
+    en, F = h.calculate_total_force_energy()
+    o = oracle_lib.Oracle(spec, threads=min(64, os.cpu_count() or 8))
+    o.verlet_build()
+    e_o, E_o, F_o = o.total()
+    assert rel(en["potential"], e_o) < E_RTOL and np.abs(F - F_o).max() < 1e-8
+    del o
+    e1, F1 = h.ms_evb_calculate_total_force_energy()
+    st = h.evb_state()
+    assert st["D"] == 16 and abs(np.linalg.norm(st["eigvec"]) - 1.0) < 1e-12
+    w = np.linalg.eigvalsh(np.triu(st["H"]) + np.triu(st["H"], 1).T)
+    assert rel(e1, w[0]) < 1e-12
+    assert rel(st["H"][0, 0], en["potential"] + (st["H"][0, 0] - en["potential"])) < 1e-15
+    h.set_option("overlap", 0); h.set_option("graphs", 0); h.set_option("pair_prune", 0)
+    e0, F0 = h.ms_evb_calculate_total_force_energy()
+    assert rel(e0, e1) < 1e-13 and np.abs(F0 - F1).max() < F_TOL
+    h.set_option("overlap", 1); h.set_option("graphs", 1); h.set_option("pair_prune", 1)
+    h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 1))
+    tr = h.md_integrate_atomic(10, spec.delta_t, use_evb=True)
+    assert np.all(np.isfinite(tr)) and abs(tr[-1].sum() - tr[0].sum()) < 2e-3 * abs(tr[0].sum())
     h.close()
 
 

@@ -2,6 +2,8 @@
 (oracle/make_golden.py).  This is what pins the oracle; the GPU tests then compare against it."""
 import hashlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -95,8 +97,11 @@ def test_evb_from_scratch_equals_reference_delta(oracle_lib, name):
     assert abs(np.linalg.norm(r["eigvec"]) - 1.0) < 1e-12
 
 
-@pytest.mark.parametrize("name,evb", [("md_std_n6_s4", False), ("md_evb_n6_d2_s5", True), ("md_std_n6_frz_s14", False)])
+@pytest.mark.parametrize("name,evb", [("md_std_n6_s4", False), ("md_evb_n6_d2_s5", True), ("md_std_n6_frz_s14", False),
+                                      ("md_std_n6_rebuild_s21", False), ("md_evb_n6_d4_rebuild_s24", True), ("md_evb_n6_d4_drop_s22", True)])
 def test_md_trajectory(oracle_lib, name, evb):
+    """the *_rebuild_* / *_drop_* fixtures are 60 reference steps at 600 K that cross 6-7 Verlet-list rebuilds
+    (update_verlet_displacements, src/general_routines.f90:1259-1337) and changes of the diabat count (4 -> 5 -> 6, 4 -> 1)"""
     g = golden(name)
     spec = system.from_golden(g)
     o = oracle_lib.Oracle(spec)
@@ -113,6 +118,11 @@ def test_md_trajectory(oracle_lib, name, evb):
         ke = o.kinetic_energy(vel)
         assert abs(pe - g["md_energy"][s, 0]) < 1e-8 * abs(pe)
         assert abs(ke - g["md_energy"][s, 1]) < 1e-8 * abs(ke)
+        if "md_verlet_flag" in g:
+            assert o.verlet_flag() == g["md_verlet_flag"][s], s
+            assert (o.n_diabat() if evb else 1) == g["md_n_diabat"][s], s
+    if "md_verlet_flag" in g:
+        assert g["md_verlet_flag"].sum() >= 6 and (not evb or len(set(g["md_n_diabat"])) > 1)      # the fixture does cross the events
     assert np.abs(o.get_xyz() - g["md_xyz"]).max() < 1e-10
     assert np.abs(vel - g["md_velocity"]).max() < 1e-9
     assert np.abs(F - g["md_force"]).max() < 1e-7
@@ -158,3 +168,36 @@ def test_principal_switch(oracle_lib):
     assert np.abs(o.get_xyz()[perm] - g["md_xyz"]).max() < 1e-10
     assert np.abs(vel[perm] - g["md_velocity"]).max() < 1e-9
     assert np.abs(F[perm] - g["md_force"]).max() < 1e-7
+
+
+def test_dfti_adapter_against_numpy_fft(tmp_path):
+    """oracle/dfti_mkl_adapter.c is the calling-convention layer between the reference's Fortran DFTI interface and the real Intel MKL
+    DFTI inside libtorch_cpu.so (it contains no arithmetic).  Driven here exactly as flang-compiled reference code drives it - a Fortran
+    pointer descriptor whose first word is the handle, every argument by reference - on random 20^3 (the size of fixture std_n6_k20_s13)
+    and non-cubic grids: forward and backward transforms, unnormalised, in place, against numpy.fft."""
+    import ctypes as C
+    import importlib.util
+    import subprocess
+    spec = importlib.util.find_spec("torch")
+    if spec is None:
+        pytest.skip("no torch (MKL DFTI provider)")
+    tlib = os.path.join(os.path.dirname(spec.origin), "lib")
+    so = str(tmp_path / "libdfti_adapter.so")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "dfti_mkl_adapter.c")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", src, "-o", so, "-L" + tlib, "-ltorch_cpu", "-lc10", "-Wl,-rpath," + tlib])
+    L = C.CDLL(so)
+    rng = np.random.default_rng(5)
+    for dims in ((20, 20, 20), (16, 16, 16), (12, 20, 8)):
+        desc = (C.c_void_p * 8)()                       # stands for the Fortran pointer descriptor (first word = base address)
+        lens = (C.c_int * 3)(*dims)                     # Fortran extents n1 (fastest), n2, n3
+        assert L.dfti_create_descriptor_highd_(desc, C.byref(C.c_int(36)), C.byref(C.c_int(32)), C.byref(C.c_int(3)), lens) == 0
+        assert L.dfti_set_value_intval_(desc, C.byref(C.c_int(26)), C.byref(C.c_int(1))) == 0      # DFTI_NUMBER_OF_USER_THREADS
+        assert L.dfti_commit_descriptor_external_(desc) == 0
+        a = rng.standard_normal(dims[::-1]) + 1j * rng.standard_normal(dims[::-1])                 # C view [n3][n2][n1] of X(n1,n2,n3)
+        x = a.copy()
+        assert L.dfti_compute_forward_z_(desc, x.ctypes.data_as(C.c_void_p)) == 0
+        ref = np.fft.fftn(a)
+        assert np.abs(x - ref).max() < 1e-12 * np.abs(ref).max()
+        assert L.dfti_compute_backward_z_(desc, x.ctypes.data_as(C.c_void_p)) == 0
+        assert np.abs(x - a * a.size).max() < 1e-12 * a.size                                     # unnormalised both ways
+        assert L.dfti_free_descriptor_external_(desc) == 0 and not desc[0]

@@ -83,6 +83,9 @@ int msevb_get_positions(msevb_ctx* ctx, double* xyz);
 int msevb_set_velocities(msevb_ctx* ctx, const double* velocity /*(3,N) host*/);
 int msevb_get_velocities(msevb_ctx* ctx, double* velocity);
 int msevb_get_forces(msevb_ctx* ctx, double* force /*(3,N) host*/);
+/* atom_data%force as the host holds it (a host that changed its arrays between two steps of msevb_md_integrate_atomic: the first
+   half-kick of velocity Verlet, src/md_integration.f90:478, uses the forces of the previous force call) */
+int msevb_set_forces(msevb_ctx* ctx, const double* force /*(3,N) host*/);
 void* msevb_device_forces(msevb_ctx* ctx);      /* device pointer to force(3,N), valid until destroy */
 void* msevb_device_positions(msevb_ctx* ctx);
 
@@ -118,6 +121,18 @@ int msevb_calculate_total_force_energy(msevb_ctx* ctx, double* energies /*[MSEVB
 int msevb_get_pme_state(msevb_ctx* ctx, double* Q_grid, double* theta_conv_Q, double* xyz_scale, double* force_recip);
 /* grid indices of the spread (bit-exact contract): nearpt(3,N) = floor(xyz_scale), splindex(3,6,N) = B6 table rows (1-based) */
 int msevb_get_pme_indices(msevb_ctx* ctx, int* nearpt, int* splindex);
+
+/* The PME stages at the reference's own granularity, for a host that switches one procedure at a time.  They take what the reference
+   procedures take: SCALED coordinates (create_scaled_direct_coordinates, src/general_routines.f90:497), charges and HOST grids; the
+   force path above never uses them (it keeps its grids on the device).
+   grid_Q (src/pme.f90:184): Q(K,K,K) = sum of the n_atom B-spline stencils */
+int msevb_grid_Q(msevb_ctx* ctx, double* Q /*(K,K,K) out*/, const double* chg /*(n_atom)*/, const double* xyz_scale /*(3,n_atom)*/, int n_atom);
+/* modify_Q_grid (src/pme.f90:275): Q += (operation > 0) or -= (operation < 0) the stencils of n_atom atoms; charges with |q| <= 1e-6 skipped (:296) */
+int msevb_modify_Q_grid(msevb_ctx* ctx, double* Q /*(K,K,K) inout*/, const double* chg, const double* xyz_scale, int n_atom, int operation);
+/* derivative_grid_Q (src/pme.f90:346) for n_atom atoms in one call: force(3,n_atom) = -K kk^T sum fac * FQ * conv, FQ = theta_conv_Q(K,K,K),
+   kk(3,3) column-major as construct_reciprocal_lattice_vector (src/general_routines.f90:473) returns it */
+int msevb_derivative_grid_Q(msevb_ctx* ctx, double* force /*(3,n_atom) out*/, const double* FQ, const double* chg, const double* xyz_scale,
+                            int n_atom, const double* kk, double conv_e2A_kJmol);
 
 /* ms_evb_calculate_total_force_energy (src/ms_evb.f90:181): principal diabat, diabat enumeration, per-diabat delta
    updates, EVB Hamiltonian, Jacobi diagonalisation, Hellmann-Feynman forces, principal-diabat switch. */

@@ -441,6 +441,7 @@ int msevb_get_positions(msevb_ctx* c, double* xyz) { NEED_FINAL(); HIPCHK(hipMem
 int msevb_set_velocities(msevb_ctx* c, const double* v) { NEED_FINAL(); HIPCHK(hipMemcpyAsync(c->d_vel.p, v, 3 * (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
 int msevb_get_velocities(msevb_ctx* c, double* v) { NEED_FINAL(); HIPCHK(hipMemcpyAsync(v, c->d_vel.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
 int msevb_get_forces(msevb_ctx* c, double* f) { NEED_FINAL(); HIPCHK(hipMemcpyAsync(f, c->d_force.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
+int msevb_set_forces(msevb_ctx* c, const double* f) { NEED_FINAL(); if (!f) return MSEVB_ERR_ARG; HIPCHK(hipMemcpyAsync(c->d_force.p, f, 3 * (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
 void* msevb_device_forces(msevb_ctx* c) { return c ? c->d_force.p : nullptr; }
 void* msevb_device_positions(msevb_ctx* c) { return c ? c->d_xyz.p : nullptr; }
 

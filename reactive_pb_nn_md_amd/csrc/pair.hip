@@ -20,6 +20,17 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 constexpr unsigned NBR_NONE = 0xffffffffu;     // padding entry of a partial trip
 
+// Minimum-image separation and r^2 with the reference's own operation order and NO FMA contraction (src/pair_int_real_space.f90:222-226:
+// dr - box*floor(dr/box + 0.5), dot_product): the cutoff decision r2 < rc2 is a discrete one - coordinates read from a .gro are
+// multiples of 0.01 A, so pairs sit EXACTLY on the cutoff (about 30 of them at 98 k atoms, 280 at 985 k) and the last bit of r2 decides
+// whether such a pair contributes its 3e-3 kJ/mol.  Everything after the decision may round differently (tolerances of DESIGN.md 5).
+__device__ __forceinline__ double min_image_r2(const double4& pi, const double4& pj, const BoxDev& box, double& dx, double& dy, double& dz) {
+#pragma clang fp contract(off)
+  dx = pi.x - pj.x; dy = pi.y - pj.y; dz = pi.z - pj.z;
+  dx = dx - box.L[0] * floor(dx * box.invL[0] + 0.5); dy = dy - box.L[1] * floor(dy * box.invL[1] + 0.5); dz = dz - box.L[2] * floor(dz * box.invL[2] + 0.5);
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
 // One atom's list row, 64 lanes x 2 entries per trip; the entries of the NEXT trip are loaded before the current trip is evaluated
 // and the Ewald table rows of both entries of a trip are fetched before either pair is finished.  `src` is the {x,y,z,q} array the
 // entries index: the cell-sorted array in HBM (k_pair) or the cell-neighbourhood tile in LDS (k_pair_tiles).
@@ -38,11 +49,8 @@ __device__ __forceinline__ void pair_row(PosPtr src, const double4 pi, int ti, u
     const unsigned n0 = kn < e ? (unsigned)nbr[kn] : NBR_NONE, n1 = kn + 64 < e ? (unsigned)nbr[kn + 64] : NBR_NONE;
     const bool va = e0 != NBR_NONE, vb = e1 != NBR_NONE;
     const double4 pa = src[va ? (e0 & NBR_IDX_MASK) : 0u], pb = src[vb ? (e1 & NBR_IDX_MASK) : 0u];
-    double dxa = pi.x - pa.x, dya = pi.y - pa.y, dza = pi.z - pa.z;
-    double dxb = pi.x - pb.x, dyb = pi.y - pb.y, dzb = pi.z - pb.z;
-    dxa -= box.L[0] * floor(dxa * box.invL[0] + 0.5); dya -= box.L[1] * floor(dya * box.invL[1] + 0.5); dza -= box.L[2] * floor(dza * box.invL[2] + 0.5);
-    dxb -= box.L[0] * floor(dxb * box.invL[0] + 0.5); dyb -= box.L[1] * floor(dyb * box.invL[1] + 0.5); dzb -= box.L[2] * floor(dzb * box.invL[2] + 0.5);
-    const double r2a = dxa * dxa + dya * dya + dza * dza, r2b = dxb * dxb + dyb * dyb + dzb * dzb;
+    double dxa, dya, dza, dxb, dyb, dzb;
+    const double r2a = min_image_r2(pi, pa, box, dxa, dya, dza), r2b = min_image_r2(pi, pb, box, dxb, dyb, dzb);
     const bool ina = va && r2a < rc2, inb = vb && r2b < rc2;
     if (PRUNE && out) {      // wave-uniform branch
       const bool ka = va && r2a < rp2, kb = vb && r2b < rp2;

@@ -1,6 +1,6 @@
 !==============================================================================
 ! msevb_hip_c : iso_c_binding interfaces of libmsevb_hip.so (include/msevb_hip.h).
-! One interface per C entry point; arrays are passed exactly as the reference
+! One interface per C entry point (checked by tests/test_host_side.py against the header); arrays are passed exactly as the reference
 ! stores them (1-based index values, column-major), so no copies are needed.
 !==============================================================================
 module msevb_hip_c
@@ -110,6 +110,11 @@ module msevb_hip_c
        type(c_ptr), value :: ctx
        real(c_double), intent(out) :: f(3,*)
      end function
+     integer(c_int) function msevb_set_forces(ctx, f) bind(C, name="msevb_set_forces")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: f(3,*)
+     end function
      integer(c_int) function msevb_construct_verlet_list(ctx) bind(C, name="msevb_construct_verlet_list")
        import :: c_ptr, c_int
        type(c_ptr), value :: ctx
@@ -171,6 +176,134 @@ module msevb_hip_c
        type(c_ptr), value :: ctx
        character(kind=c_char), intent(in) :: name(*)      ! NUL-terminated, e.g. "overlap"//c_null_char
        real(c_double), value :: value
+     end function
+     ! ---- the remaining entry points of include/msevb_hip.h ----
+     integer(c_int) function msevb_set_stream(ctx, hip_stream) bind(C, name="msevb_set_stream")
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx, hip_stream
+     end function
+     integer(c_int) function msevb_synchronize(ctx) bind(C, name="msevb_synchronize")
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function msevb_get_table(ctx, name, out, n) bind(C, name="msevb_get_table")
+       import :: c_ptr, c_int, c_double, c_char
+       type(c_ptr), value :: ctx
+       character(kind=c_char), intent(in) :: name(*)
+       real(c_double), intent(out) :: out(*)
+       integer(c_int), value :: n
+     end function
+     integer(c_int) function msevb_get_ewald_self(ctx, ewald_self) bind(C, name="msevb_get_ewald_self")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: ewald_self
+     end function
+     type(c_ptr) function msevb_device_forces(ctx) bind(C, name="msevb_device_forces")
+       import :: c_ptr
+       type(c_ptr), value :: ctx
+     end function
+     type(c_ptr) function msevb_device_positions(ctx) bind(C, name="msevb_device_positions")
+       import :: c_ptr
+       type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function msevb_get_verlet_flag(ctx, flag) bind(C, name="msevb_get_verlet_flag")
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+       integer(c_int), intent(out) :: flag
+     end function
+     integer(c_int) function msevb_get_verlet_list(ctx, verlet_point, neighbor_list, n_neighbors) bind(C, name="msevb_get_verlet_list")
+       import :: c_ptr, c_int, c_long
+       type(c_ptr), value :: ctx
+       type(c_ptr), value :: verlet_point, neighbor_list      ! c_loc of integer arrays, or c_null_ptr to query the size
+       integer(c_long), intent(out) :: n_neighbors
+     end function
+     integer(c_int) function msevb_zero_forces(ctx) bind(C, name="msevb_zero_forces")
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function msevb_real_space_energy_force(ctx, e) bind(C, name="msevb_real_space_energy_force")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: e(4)
+     end function
+     integer(c_int) function msevb_pme_reciprocal_space_energy_force(ctx, E_recip) bind(C, name="msevb_pme_reciprocal_space_energy_force")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: E_recip
+     end function
+     integer(c_int) function msevb_intra_molecular_energy_force(ctx, e) bind(C, name="msevb_intra_molecular_energy_force")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: e(3)
+     end function
+     integer(c_int) function msevb_get_pme_state(ctx, Q_grid, theta_conv_Q, xyz_scale, force_recip) bind(C, name="msevb_get_pme_state")
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+       type(c_ptr), value :: Q_grid, theta_conv_Q, xyz_scale, force_recip      ! c_loc of the host arrays, or c_null_ptr
+     end function
+     integer(c_int) function msevb_get_pme_indices(ctx, nearpt, splindex) bind(C, name="msevb_get_pme_indices")
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+       integer(c_int), intent(out) :: nearpt(3,*), splindex(3,6,*)
+     end function
+     integer(c_int) function msevb_grid_Q(ctx, Q, chg, xyz_scale, n_atom) bind(C, name="msevb_grid_Q")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: Q(*)
+       real(c_double), intent(in) :: chg(*), xyz_scale(3,*)
+       integer(c_int), value :: n_atom
+     end function
+     integer(c_int) function msevb_modify_Q_grid(ctx, Q, chg, xyz_scale, n_atom, operation) bind(C, name="msevb_modify_Q_grid")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(inout) :: Q(*)
+       real(c_double), intent(in) :: chg(*), xyz_scale(3,*)
+       integer(c_int), value :: n_atom, operation
+     end function
+     integer(c_int) function msevb_derivative_grid_Q(ctx, force, FQ, chg, xyz_scale, n_atom, kk, conv) bind(C, name="msevb_derivative_grid_Q")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: force(3,*)
+       real(c_double), intent(in) :: FQ(*), chg(*), xyz_scale(3,*), kk(3,3)
+       integer(c_int), value :: n_atom
+       real(c_double), value :: conv
+     end function
+     integer(c_int) function msevb_get_evb_element_force(ctx, i, j, force) bind(C, name="msevb_get_evb_element_force")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: i, j
+       real(c_double), intent(out) :: force(3,*)
+     end function
+     integer(c_int) function msevb_evb_partial_blend(ctx, eigvec, force) bind(C, name="msevb_evb_partial_blend")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: eigvec(*)
+       real(c_double), intent(out) :: force(3,*)
+     end function
+     integer(c_int) function msevb_comm_set_virtual(ctx, rank, n_ranks) bind(C, name="msevb_comm_set_virtual")
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: rank, n_ranks
+     end function
+     integer(c_int) function msevb_comm_allreduce_energies(ctx) bind(C, name="msevb_comm_allreduce_energies")
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function msevb_comm_allreduce_forces(ctx) bind(C, name="msevb_comm_allreduce_forces")
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function msevb_get_phase_times(ctx, n, names, ms, calls) bind(C, name="msevb_get_phase_times")
+       import :: c_ptr, c_int, c_double, c_long
+       type(c_ptr), value :: ctx
+       integer(c_int), intent(out) :: n
+       type(c_ptr), intent(out) :: names(16)      ! NUL-terminated C strings owned by the library
+       real(c_double), intent(out) :: ms(16)
+       integer(c_long), intent(out) :: calls(16)
+     end function
+     integer(c_int) function msevb_reset_phase_times(ctx) bind(C, name="msevb_reset_phase_times")
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
      end function
   end interface
 contains

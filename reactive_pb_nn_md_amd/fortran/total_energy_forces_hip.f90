@@ -1,28 +1,100 @@
 !==============================================================================
 ! Drop-in replacement of the reference's module `total_energy_forces`
-! (src/total_energy_forces.f90) and of the hot entry point of module `ms_evb`
-! (ms_evb_calculate_total_force_energy, src/ms_evb.f90:181) that runs the force
-! call on an MI355X through libmsevb_hip.so.
+! (src/total_energy_forces.f90): the force call runs on an MI355X through
+! libmsevb_hip.so.
 !
 ! It is compiled AGAINST THE REFERENCE'S OWN, UNCHANGED glob_v.f90 /
-! general_routines.f90 (module global_variables, routines): the derived types,
-! force-field tables and EVB tables are read from there, so main_ms_evb.f90,
-! md_integration.f90 and initialize_routines.f90 stay untouched - see
-! INTEGRATION.md for the build line.  Same procedure names, same argument lists:
+! general_routines.f90 / pair_int_real_space.f90 / pme.f90 /
+! intra_bonded_interactions.f90: the derived types, force-field tables and EVB
+! tables are read from there, and - like the reference's module
+! (src/total_energy_forces.f90:5-10) - it re-exports pair_int_real_space,
+! pme_routines and bonded_interactions, through which md_integration.f90 reaches
+! periodic_box_change (src/md_integration.f90:231-233,294,334).  main_ms_evb.f90,
+! md_integration.f90 and initialize_routines.f90 stay untouched; see
+! INTEGRATION.md and `make -C reactive_pb_nn_md_amd/fortran link_check`.
+! Same procedure names, same argument lists:
 !   calculate_total_force_energy(system_data, molecule_data, atom_data, verlet_list_data, PME_data)
 !   calculate_kinetic_energy(KE, n_atom, mass, vel_atom, conv_fac)
-!   msevb_hip_ms_evb_force_energy(...)   body for ms_evb_calculate_total_force_energy
+! plus the body of ms_evb_calculate_total_force_energy (module ms_evb in ms_evb_hip.f90):
+!   msevb_hip_ms_evb_force_energy(...)
+!
+! Environment (one process per GPU):
+!   MSEVB_DEVICE     HIP device ordinal of this process (default: LOCAL_RANK, else 0)
+!   MSEVB_RANK / MSEVB_NRANKS / MSEVB_COMM_FILE   join an RCCL communicator of MSEVB_NRANKS processes: rank 0 writes the
+!                    128-byte unique id to MSEVB_COMM_FILE, the others wait for that file (the reference has no MPI to broadcast it)
 !==============================================================================
 module total_energy_forces
   use global_variables
   use routines
+  use pair_int_real_space
+  use pme_routines
+  use bonded_interactions
   use msevb_hip_c
   use iso_c_binding
   implicit none
   type(c_ptr), save, private :: ctx = c_null_ptr
-  logical, save, private :: uploaded = .false.
+  logical, save, private :: uploaded = .false., uploaded_evb = .false.
+  real*8, save, private :: box_uploaded(3,3) = 0d0
 
 contains
+
+  !-- the library context of this process (for callers that want the C entry points directly, e.g. msevb_hip_stages)
+  function msevb_hip_context() result(p)
+    type(c_ptr) :: p
+    p = ctx
+  end function msevb_hip_context
+
+  !-- host arrays were re-ordered (principal-diabat switch): the next force call uploads everything again
+  subroutine msevb_hip_invalidate()
+    if (c_associated(ctx)) call msevb_check(ctx, msevb_destroy(ctx), "msevb_destroy")
+    ctx = c_null_ptr
+    uploaded = .false.
+  end subroutine msevb_hip_invalidate
+
+  integer function env_int(name, default)
+    character(*), intent(in) :: name
+    integer, intent(in) :: default
+    character(64) :: v
+    integer :: l, st, ios
+    env_int = default
+    call get_environment_variable(name, v, l, st)
+    if (st == 0 .and. l > 0) then
+       read(v(1:l), *, iostat=ios) env_int
+       if (ios /= 0) env_int = default
+    end if
+  end function env_int
+
+  !-- MSEVB_RANK / MSEVB_NRANKS / MSEVB_COMM_FILE: one process per GPU, RCCL communicator over xGMI
+  subroutine msevb_hip_join_communicator()
+    integer :: rank, nranks, l, st, ios, tries
+    character(512) :: fname
+    integer(c_signed_char) :: id(128)
+    logical :: there
+    nranks = env_int("MSEVB_NRANKS", 1)
+    if (nranks < 2) return
+    rank = env_int("MSEVB_RANK", env_int("RANK", 0))
+    call get_environment_variable("MSEVB_COMM_FILE", fname, l, st)
+    if (st /= 0 .or. l == 0) stop "MSEVB_NRANKS > 1 needs MSEVB_COMM_FILE (a path all ranks can read)"
+    if (rank == 0) then
+       call msevb_check(ctx, msevb_comm_unique_id(id), "msevb_comm_unique_id")
+       open(unit=97, file=fname(1:l)//".tmp", access='stream', form='unformatted', status='replace')
+       write(97) id
+       close(97)
+       call rename(fname(1:l)//".tmp", fname(1:l))      ! the id appears under its name only when complete
+    else
+       do tries = 1, 6000
+          inquire(file=fname(1:l), exist=there)
+          if (there) exit
+          call sleep(1)
+       end do
+       if (.not. there) stop "MSEVB_COMM_FILE did not appear"
+       open(unit=97, file=fname(1:l), access='stream', form='unformatted', status='old')
+       read(97, iostat=ios) id
+       close(97)
+       if (ios /= 0) stop "MSEVB_COMM_FILE unreadable"
+    end if
+    call msevb_check(ctx, msevb_comm_init(ctx, id, rank, nranks), "msevb_comm_init")
+  end subroutine msevb_hip_join_communicator
 
   !-- push every table the hot path reads to the GPU library (once; again after a box change)
   subroutine msevb_hip_upload(system_data, molecule_data, atom_data, verlet_list_data, PME_data, use_evb)
@@ -37,7 +109,7 @@ contains
     integer :: i, j, k, l, n, it, na, nb, nang, nd, dev
 
     if (.not. c_associated(ctx)) then
-       dev = 0
+       dev = env_int("MSEVB_DEVICE", env_int("LOCAL_RANK", 0))
        call msevb_check(ctx, msevb_create(ctx, dev), "msevb_create")
     end if
     call msevb_check(ctx, msevb_set_system(ctx, system_data%total_atoms, system_data%n_mole, system_data%box, real_space_cutoff, &
@@ -92,8 +164,32 @@ contains
             hydronium_molecule_index(1), evb_max_chain), "msevb_set_evb")
     end if
     call msevb_check(ctx, msevb_finalize(ctx), "msevb_finalize")
+    call msevb_check(ctx, msevb_set_frozen_types(ctx, atype_freeze, n_atom_type), "msevb_set_frozen_types")
+    call msevb_hip_join_communicator()
     uploaded = .true.
+    uploaded_evb = use_evb
+    box_uploaded = system_data%box
   end subroutine msevb_hip_upload
+
+  !-- everything a force call needs before it starts: tables uploaded (again after msevb_hip_invalidate), and the box the host holds NOW.
+  !   The Monte-Carlo barostat changes system_data%box and calls periodic_box_change (src/pme.f90:634) of the reference's own pme.f90 for
+  !   the host-side CB array; the GPU side follows here: a changed box goes to msevb_set_box (CB, reciprocal lattice, Verlet list)
+  subroutine msevb_hip_prepare(system_data, molecule_data, atom_data, verlet_list_data, PME_data, use_evb)
+    type(system_data_type), intent(in) :: system_data
+    type(molecule_data_type), dimension(:), intent(in) :: molecule_data
+    type(atom_data_type), intent(in) :: atom_data
+    type(verlet_list_data_type), intent(in) :: verlet_list_data
+    type(PME_data_type), intent(in) :: PME_data
+    logical, intent(in) :: use_evb
+    real(c_double) :: b3(3)
+    if (uploaded .and. (use_evb .neqv. uploaded_evb)) call msevb_hip_invalidate()
+    if (.not. uploaded) call msevb_hip_upload(system_data, molecule_data, atom_data, verlet_list_data, PME_data, use_evb)
+    if (any(system_data%box /= box_uploaded)) then
+       b3 = (/ system_data%box(1,1), system_data%box(2,2), system_data%box(3,3) /)
+       call msevb_check(ctx, msevb_set_box(ctx, b3), "msevb_set_box")
+       box_uploaded = system_data%box
+    end if
+  end subroutine msevb_hip_prepare
 
   !***********************************************************
   ! same interface as the reference (src/total_energy_forces.f90:19)
@@ -106,7 +202,7 @@ contains
     Type(PME_data_type), intent(inout)                  :: PME_data
     real(c_double) :: e(MSEVB_N_ENERGY)
 
-    if (.not. uploaded) call msevb_hip_upload(system_data, molecule_data, atom_data, verlet_list_data, PME_data, .false.)
+    call msevb_hip_prepare(system_data, molecule_data, atom_data, verlet_list_data, PME_data, .false.)
     call msevb_check(ctx, msevb_set_positions(ctx, atom_data%xyz), "msevb_set_positions")
     ! the Verlet list (and its freshness logic, :30-39) lives on the device
     call msevb_check(ctx, msevb_calculate_total_force_energy(ctx, e, atom_data%force), "msevb_calculate_total_force_energy")
@@ -117,23 +213,46 @@ contains
   end subroutine calculate_total_force_energy
 
   !***********************************************************
-  ! body for ms_evb_calculate_total_force_energy (src/ms_evb.f90:181); the proton-hop re-topologisation of the host
-  ! arrays is read back from the library (msevb_get_topology) when the principal diabat changed
+  ! body of ms_evb_calculate_total_force_energy (src/ms_evb.f90:181-235): the whole EVB force call on the GPU.  Returns what the
+  ! reference's diagonalize_evb_hamiltonian leaves behind for the host (src/ms_evb.f90:242-344): the number of diabats, the proton log
+  ! and coupling matrix, the Hamiltonian, the ground-state vector, the principal diabat and the hydronium molecule it implies.
+  ! proton_log is (n_diabat, max_chain, 5) as the reference's evb_diabat_proton_log(evb_max_states, evb_max_chain, 5).
   !***********************************************************
-  subroutine msevb_hip_ms_evb_force_energy(system_data, molecule_data, atom_data, verlet_list_data, PME_data, new_hydronium)
+  subroutine msevb_hip_ms_evb_force_energy(system_data, molecule_data, atom_data, verlet_list_data, PME_data, n_diabat, proton_log, coupling_matrix, &
+       hamiltonian, eigenvector, principle_diabat, new_hydronium)
     Type(system_data_type),intent(inout)                :: system_data
-    Type(molecule_data_type),dimension(:),intent(inout) :: molecule_data
+    Type(molecule_data_type),dimension(:),intent(in)    :: molecule_data
     Type(atom_data_type),intent(inout)                  :: atom_data
     Type(verlet_list_data_type),intent(inout)           :: verlet_list_data
     Type(PME_data_type), intent(inout)                  :: PME_data
-    integer, intent(out) :: new_hydronium
+    integer, intent(out) :: n_diabat, principle_diabat, new_hydronium
+    integer, intent(inout) :: proton_log(:,:,:), coupling_matrix(:)
+    real*8, intent(inout) :: hamiltonian(:,:), eigenvector(:)
     integer(c_int) :: nd, pr, nh
+    integer(c_int), allocatable, target :: plog(:,:,:), par(:)
+    real(c_double), allocatable, target :: hh(:,:), ev(:)
+    integer :: d, h, q, mc
 
-    if (.not. uploaded) call msevb_hip_upload(system_data, molecule_data, atom_data, verlet_list_data, PME_data, .true.)
+    call msevb_hip_prepare(system_data, molecule_data, atom_data, verlet_list_data, PME_data, .true.)
     call msevb_check(ctx, msevb_set_positions(ctx, atom_data%xyz), "msevb_set_positions")
     call msevb_check(ctx, msevb_ms_evb_calculate_total_force_energy(ctx, system_data%potential_energy, atom_data%force), "msevb_ms_evb_calculate_total_force_energy")
     call msevb_check(ctx, msevb_get_evb_state(ctx, nd, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, pr, nh), "msevb_get_evb_state")
-    new_hydronium = nh
+    mc = evb_max_chain
+    allocate(plog(5, mc, nd), par(nd), hh(nd, nd), ev(nd))      ! the library writes C order [d][hop][5], [i][j]
+    call msevb_check(ctx, msevb_get_evb_state(ctx, nd, c_loc(plog), c_loc(par), c_loc(hh), c_loc(ev), pr, nh), "msevb_get_evb_state")
+    n_diabat = nd; principle_diabat = pr; new_hydronium = nh
+    if (nd > size(proton_log,1) .or. nd > size(hamiltonian,1)) stop "more diabats than evb_max_states"
+    proton_log = -1
+    do d = 1, nd; do h = 1, min(mc, size(proton_log,2)); do q = 1, 5
+       proton_log(d, h, q) = plog(q, h, d)
+    end do; end do; end do
+    coupling_matrix(1:nd) = par(1:nd)
+    hamiltonian = 0d0
+    do d = 1, nd; do h = 1, nd
+       hamiltonian(d, h) = hh(h, d)      ! C [i][j] -> Fortran (i,j)
+    end do; end do
+    eigenvector(1:nd) = ev(1:nd)
+    verlet_list_data%flag_verlet_list = 0
   end subroutine msevb_hip_ms_evb_force_energy
 
   !**************************************

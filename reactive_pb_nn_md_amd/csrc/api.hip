@@ -472,7 +472,7 @@ int msevb_get_verlet_list(msevb_ctx* c, int* vp, int* nl, long* nn) {
   HIPCHK(hipMemcpy(perm.data(), c->d_perm.p, N * sizeof(int), hipMemcpyDeviceToHost));
   std::vector<std::vector<int>> half(N);
   std::vector<int> cstart, keys;
-  if (c->pair_tiles) {     // local (tile) indices: decode with the cell structure
+  if (c->pair_tiles) {     // half list with tile-local indices: decode with the cell structure
     const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
     cstart.resize(ncell + 1); keys.resize(N);
     HIPCHK(hipMemcpy(cstart.data(), c->d_cell_start.p, (ncell + 1) * sizeof(int), hipMemcpyDeviceToHost));
@@ -480,17 +480,23 @@ int msevb_get_verlet_list(msevb_ctx* c, int* vp, int* nl, long* nn) {
   }
   for (int k = 0; k < N; ++k) {
     const int i = perm[k];
-    int slots[27], off[28], ns = 0;
+    int slots[HALF_SLOTS], off[HALF_SLOTS + 1];
     if (c->pair_tiles) {
-      ns = cell_neighbourhood(keys[k], c->ncell[0], c->ncell[1], c->ncell[2], slots);
+      cell_half_neighbourhood(keys[k], c->ncell[0], c->ncell[1], c->ncell[2], slots);
       off[0] = 0;
-      for (int s = 0; s < ns; ++s) off[s + 1] = off[s] + cstart[slots[s] + 1] - cstart[slots[s]];
+      for (int s = 0; s < HALF_SLOTS; ++s) off[s + 1] = off[s] + cstart[slots[s] + 1] - cstart[slots[s]];
     }
     for (unsigned q = st[k]; q < st[k] + cnt[k]; ++q) {
       int js = (int)((unsigned)nb[q] & NBR_IDX_MASK);
-      if (c->pair_tiles) { int s = 0; while (s + 1 < ns && js >= off[s + 1]) ++s; js = cstart[slots[s]] + (js - off[s]); }
-      const int j = perm[js];
-      if (j > i) half[i].push_back(j);
+      if (c->pair_tiles) {      // every pair is stored once, with the atom that comes first in its cell's half neighbourhood
+        int s = 0; while (s + 1 < HALF_SLOTS && js >= off[s + 1]) ++s;
+        js = cstart[slots[s]] + (js - off[s]);
+        const int j = perm[js];
+        half[std::min(i, j)].push_back(std::max(i, j));
+      } else {                  // full list: every pair twice
+        const int j = perm[js];
+        if (j > i) half[i].push_back(j);
+      }
     }
   }
   long tot = 0;

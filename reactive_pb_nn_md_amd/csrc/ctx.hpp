@@ -93,14 +93,35 @@ inline int cell_neighbourhood(int cidx, int ncx, int ncy, int ncz, int* slots) {
   return n;
 }
 
+// The HALF neighbourhood of cell cidx: slot 0 = the cell itself, slots 1..13 = its 13 "forward" neighbours (offset (ox,oy,oz) with
+// oz > 0, or oz == 0 and oy > 0, or oz == oy == 0 and ox > 0), so that every unordered pair of neighbouring cells appears in exactly one
+// half neighbourhood.  Needs >= 3 cells per axis (the +1 and -1 neighbours must be different cells); the users ask for >= 4.
+// Layout of the LDS tile of the half-list pair kernel and of its tile-local list entries (pair.hip, neighbor.hip, api.hip decoder).
+constexpr int HALF_SLOTS = 14;
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline void cell_half_neighbourhood(int cidx, int ncx, int ncy, int ncz, int* slots) {
+  const int cx = cidx % ncx, cy = (cidx / ncx) % ncy, cz = cidx / (ncx * ncy);
+  int n = 0;
+  slots[n++] = cidx;
+  for (int oz = 0; oz <= 1; ++oz)
+    for (int oy = (oz ? -1 : 0); oy <= 1; ++oy)
+      for (int ox = ((oz || oy) ? -1 : 1); ox <= 1; ++ox) {
+        const int xx = (cx + ox + ncx) % ncx, yy = (cy + oy + ncy) % ncy, zz = (cz + oz + ncz) % ncz;
+        slots[n++] = xx + ncx * (yy + ncy * zz);
+      }
+}
+
 // Verlet-list entry: sorted index of the neighbour in the low 24 bits, its atom type in the high 8 (the pair kernel then needs
 // no per-neighbour type gather).  Limits: N < 2^24 atoms, MAX_TYPES <= 256; the list is rebuilt whenever the topology changes.
 constexpr int NBR_IDX_BITS = 24;
 constexpr unsigned NBR_IDX_MASK = (1u << NBR_IDX_BITS) - 1u;
-// In tile mode (c->pair_tiles) the index is LOCAL: the position of the neighbour inside the concatenation of the neighbour cells
-// of the owning atom's cell (cell_neighbourhood order) - exactly the layout of the LDS tile the pair kernel stages per cell.
-constexpr int PAIR_TILE_LDS_BYTES = 144 * 1024;      // of the 160 KiB per CU; the rest holds the pair-parameter table and reductions
-constexpr int PAIR_TILE_MIN_CELLS = 128;
+// In tile mode (c->pair_tiles) the list is a HALF list and the index is LOCAL: the position of the neighbour inside the concatenation
+// of the cells of the owning atom's half neighbourhood (cell_half_neighbourhood order) - exactly the layout of the LDS tile the pair
+// kernel stages per cell (positions 32 B + force accumulators 24 B per tile atom).
+constexpr int PAIR_TILE_LDS_BYTES = 156 * 1024;      // of the 160 KiB per CU; the rest holds the static reductions
+constexpr int PAIR_TILE_ATOM_BYTES = 56;
 constexpr int NBR_TILE_CAP = 8000;                   // most atoms of a cell neighbourhood the list build can stage in LDS
 constexpr int NBR_TILE_CAP2 = 4032;                  // ... while two workgroups still fit a CU (2 x (4032 x 20 B + 0.9 KB static) <= 160 KB)
 constexpr int NBR_TILE_BYTES = 20;                   // per staged atom: float4 {x,y,z,molecule} + the entry word
@@ -169,10 +190,12 @@ struct msevb_ctx {
   bool skip_gather_now = false;      // EVB fast path: the principal reciprocal force comes with the blended gather
   bool shard_principal = false;
   bool shard_now = false;        // true while the EVB force call enqueues the principal diabat
-  int pair_tiles_opt = 0;        // 0 off (default: measured slower than the global-gather kernel once the PME front end overlaps it), 1 on when it fits, -1 auto
+  int pair_tiles_opt = -1;       // half-list LDS pair kernel: -1 / 1 = whenever the box has >= 4 cells per axis and the tile fits in LDS (default), 0 = never
   bool pair_tiles = false;       // format of the current list
-  int tile_atoms_max = 0;
+  int tile_atoms_max = 0;        // largest 27-cell neighbourhood (atoms) the last build saw
+  int half_tile_max = 0, half_tile_cap = 0;      // largest half neighbourhood the last build saw / tile size (atoms) the current half list was built for
   bool finalized = false;
+  bool attr_pair_half[4] = {false, false, false, false};      // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
 
   // ---- configuration
   int N = 0, M = 0, K = 0, order = 6, spline_grid = 100000, erfc_grid = 100000;
@@ -238,6 +261,7 @@ struct msevb_ctx {
   int* h_nbr_stats = nullptr;          // pinned: {tile_max, pad, count_max, pad, count_sum lo, hi}
   int flag_verlet_list = 0;
   DBuf<double4> d_posq;        // sorted {x,y,z,q}
+  DBuf<double> d_fsorted;      // [N][3] force accumulator of the half-list pair kernel in SORTED order (coalesced atomics), folded into d_force and re-zeroed by k_pair_fold
   DBuf<int> d_type_sorted, d_mol_sorted;
   // PME
   DBuf<double2> d_grid;        // complex K^3 (x fastest), in place FFT

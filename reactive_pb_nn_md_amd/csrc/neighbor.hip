@@ -50,7 +50,8 @@ __global__ void k_gather_sorted(int N, const int* __restrict__ perm, const doubl
   if (inv_perm) inv_perm[i] = k;
 }
 
-// largest number of atoms in the neighbourhood (distinct neighbour cells) of any cell = LDS tile size of the tiled pair kernel
+// out[0]: largest number of atoms in the neighbourhood (distinct neighbour cells) of any cell = LDS tile of the full-list build;
+// out[1]: the same for the HALF neighbourhood (cell + 13 forward cells) = LDS tile of the half-list build and of the half-list pair kernel
 __global__ void k_tile_max(int ncell, int3 nc, const int* __restrict__ cell_start, int* __restrict__ out) {
   const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
   if (cidx >= ncell) return;
@@ -59,13 +60,18 @@ __global__ void k_tile_max(int ncell, int3 nc, const int* __restrict__ cell_star
   int tot = 0;
   for (int s = 0; s < ns; ++s) tot += cell_start[slots[s] + 1] - cell_start[slots[s]];
   atomicMax(out, tot);
+  if (nc.x >= 3 && nc.y >= 3 && nc.z >= 3) {
+    cell_half_neighbourhood(cidx, nc.x, nc.y, nc.z, slots);
+    tot = 0;
+    for (int s = 0; s < HALF_SLOTS; ++s) tot += cell_start[slots[s] + 1] - cell_start[slots[s]];
+    atomicMax(out + 1, tot);
+  }
 }
 
 // One wavefront per sorted atom.  Rows have a fixed stride `cap` (row i starts at i * cap), so a rebuild is ONE pass: hits are
 // written compactly (ballot + mbcnt) while they fit, the true count goes to count[i], and the host re-runs with a larger stride only
 // when max(count) > cap.  FILL = false only counts (first build: sizes cap).
-// LOCAL: entries hold the neighbour's position inside the cell-neighbourhood tile instead of its sorted index.
-template <bool FILL, bool LOCAL>
+template <bool FILL>
 __global__ __launch_bounds__(256) void k_neighbors(int N, const double4* __restrict__ posq, const int* __restrict__ mol_s, const int* __restrict__ type_s,
                                                    const int* __restrict__ keys, const int* __restrict__ cell_start, BoxDev box, int3 nc,
                                                    double rv2, unsigned cap, unsigned* __restrict__ count, unsigned* __restrict__ start,
@@ -79,7 +85,6 @@ __global__ __launch_bounds__(256) void k_neighbors(int N, const double4* __restr
   const int ns = cell_neighbourhood(keys[i], nc.x, nc.y, nc.z, slots);
   unsigned total = 0;
   const unsigned base = (unsigned)i * cap;
-  int off = 0;     // running offset of the current cell inside the tile
   for (int sl = 0; sl < ns; ++sl) {
     const int s = cell_start[slots[sl]], e = cell_start[slots[sl] + 1];
     for (int j0 = s; j0 < e; j0 += 64) {
@@ -96,12 +101,10 @@ __global__ __launch_bounds__(256) void k_neighbors(int N, const double4* __restr
       const unsigned long long m = __ballot(hit);
       if (FILL && hit) {
         const unsigned slot = total + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        const unsigned idx = LOCAL ? (unsigned)(off + (j - s)) : (unsigned)j;
-        if (slot < cap) nbr[base + slot] = (int)(idx | ((unsigned)type_s[j] << NBR_IDX_BITS));
+        if (slot < cap) nbr[base + slot] = (int)((unsigned)j | ((unsigned)type_s[j] << NBR_IDX_BITS));
       }
       total += (unsigned)__popcll(m);
     }
-    off += e - s;
   }
   if (lane == 0) { count[i] = total; if (FILL) start[i] = base; }
 }
@@ -131,7 +134,10 @@ __device__ __forceinline__ bool nbr_decide_fp64(const double4& pr, double xi, do
   return hit;
 }
 
-template <bool LOCAL>
+// HALF: the tile is the HALF neighbourhood (the cell + its 13 forward cells, cell_half_neighbourhood order), an atom keeps the partners
+// that come AFTER it in the tile (same cell: larger sorted index; forward cells: all) - every pair once - and the entries hold the
+// partner's position in the tile: the list of the half-list LDS pair kernel (pair.hip).  The set of unordered pairs is the same.
+template <bool HALF>
 __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int* __restrict__ cell_start, const double4* __restrict__ posq, const int* __restrict__ mol_s,
                                                           const int* __restrict__ type_s, BoxDev box, double rv2, unsigned cap, int tile_cap,
                                                           unsigned* __restrict__ count, unsigned* __restrict__ start, int* __restrict__ nbr, int* __restrict__ stats) {
@@ -142,7 +148,9 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
   const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
   if (threadIdx.x == 0) {
     int slots[27];
-    const int ns = cell_neighbourhood(cidx, nc.x, nc.y, nc.z, slots);
+    int ns;
+    if (HALF) { cell_half_neighbourhood(cidx, nc.x, nc.y, nc.z, slots); ns = HALF_SLOTS; }
+    else ns = cell_neighbourhood(cidx, nc.x, nc.y, nc.z, slots);
     int off = 0;
     for (int s = 0; s < ns; ++s) {
       s_lo[s] = cell_start[slots[s]]; s_off[s] = off; off += cell_start[slots[s] + 1] - s_lo[s];
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
         t.z = (float)(((p.z - box.L[2] * floor(p.z * box.invL[2])) + s_shift[s][2]) - oz);
         t.w = __int_as_float(mol_s[lo + k]);
         t4[o + k] = t;
-        te[o + k] = (int)((LOCAL ? (unsigned)(o + k) : (unsigned)(lo + k)) | ((unsigned)type_s[lo + k] << NBR_IDX_BITS));
+        te[o + k] = (int)((HALF ? (unsigned)(o + k) : (unsigned)(lo + k)) | ((unsigned)type_s[lo + k] << NBR_IDX_BITS));
       }
     }
   }
@@ -185,17 +193,18 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
     const int mi = mol_s[i];
     unsigned total = 0;
     const unsigned base = (unsigned)i * cap;
+    const int pfirst = HALF ? i - cell_start[cidx] + 1 : 0;      // half list: first tile position that counts as a partner of this atom
     if (in_lds) {
       // two ADJACENT candidates per lane and trip (128 per trip): one 32-byte and one 8-byte LDS read per lane, the fp32 arithmetic of
       // the pair packs into v_pk_* instructions; the compaction keeps the candidates' order (slot = hits before this lane's pair, then A, then B)
-      for (int p0 = 0; p0 < ntile; p0 += 128) {
+      for (int p0 = HALF ? (pfirst & ~127) : 0; p0 < ntile; p0 += 128) {
         const int pA = p0 + 2 * lane, pB = pA + 1;
         const int pr_ = pA < ntile ? pA : 0;      // even index; entry pr_ + 1 <= ntile exists (the tile has one spare entry)
         const float4 tA = t4[pr_], tB = t4[pr_ + 1];
         const int2 en = *(const int2*)(te + pr_);
         const float dxA = fx - tA.x, dyA = fy - tA.y, dzA = fz - tA.z, dxB = fx - tB.x, dyB = fy - tB.y, dzB = fz - tB.z;
         const float r2A = dxA * dxA + dyA * dyA + dzA * dzA, r2B = dxB * dxB + dyB * dyB + dzB * dzB;
-        const bool cA = pA < ntile && __float_as_int(tA.w) != mi, cB = pB < ntile && __float_as_int(tB.w) != mi;
+        const bool cA = pA < ntile && pA >= pfirst && __float_as_int(tA.w) != mi, cB = pB < ntile && pB >= pfirst && __float_as_int(tB.w) != mi;
         bool hA = cA && r2A < rv2f, hB = cB && r2B < rv2f;
         const bool bA = cA && fabsf(r2A - rv2f) < band, bB = cB && fabsf(r2B - rv2f) < band;
         if (__ballot(bA || bB)) {      // rare (about one candidate per atom): too close to call in single precision
@@ -225,11 +234,11 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
         for (int p0 = 0; p0 < n; p0 += 64) {
           const int p = p0 + lane, j = lo + p;
           bool hit = false;
-          if (p < n && mol_s[j] != mi) hit = nbr_decide_fp64(pr, xi, yi, zi, posq[j], shx, shy, shz, box, rv2);
+          if (p < n && o + p >= pfirst && mol_s[j] != mi) hit = nbr_decide_fp64(pr, xi, yi, zi, posq[j], shx, shy, shz, box, rv2);
           const unsigned long long m = __ballot(hit);
           if (hit) {
             const unsigned slot = total + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            const unsigned idx = LOCAL ? (unsigned)(o + p) : (unsigned)j;
+            const unsigned idx = HALF ? (unsigned)(o + p) : (unsigned)j;
             if (slot < cap) nbr[base + slot] = (int)(idx | ((unsigned)type_s[j] << NBR_IDX_BITS));
           }
           total += (unsigned)__popcll(m);
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
     if (threadIdx.x == 0) {
       unsigned m = 0; unsigned long long sm = 0;
       for (int k = 0; k < wpb; ++k) { m = max(m, s_max[k]); sm += s_sum[k]; }
-      atomicMax((unsigned*)stats + 2, m); atomicAdd((unsigned long long*)(stats + 4), sm); atomicMax(stats, ntile);
+      atomicMax((unsigned*)stats + 2, m); atomicAdd((unsigned long long*)(stats + 4), sm); atomicMax(stats + (HALF ? 1 : 0), ntile);
     }
   }
 }
@@ -492,58 +501,64 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
     if (sync) HIPCHK(hipStreamSynchronize(c->stream));
     return MSEVB_OK;
   };
-  bool inline_stats = false;      // the fill kernel left {tile max, row max, row sum} in d_stats and cut overlong rows itself
+  bool inline_stats = false;      // the fill kernel left {tile max, half tile max, row max, row sum} in d_stats and cut overlong rows itself
+  const bool tile_build_ok = ncell >= NBR_TILE_MIN_CELLS && c->nbr_tiles && nc.x >= 4 && nc.y >= 4 && nc.z >= 4;      // workgroup per cell, neighbourhood staged in LDS
+  // Format of THIS build: half list with tile-local entries (the LDS pair kernel, pair.hip) when the largest half neighbourhood the
+  // previous build saw (+ 8 %) fits the pair kernel's LDS tile; a build that meets a larger one is repeated (nb_check_overflow).
+  auto decide_format = [&]() {
+    const int cap = ((int)(c->half_tile_max * 1.08) + 63) & ~63;
+    const size_t bytes = (size_t)cap * PAIR_TILE_ATOM_BYTES + (size_t)c->nt * c->nt * sizeof(PairParam) + 2048;
+    c->pair_tiles = tile_build_ok && c->pair_tiles_opt != 0 && c->half_tile_max > 0 && bytes <= (size_t)PAIR_TILE_LDS_BYTES;
+    c->half_tile_cap = c->pair_tiles ? cap : 0;
+  };
   auto fill = [&](bool want_inline = false) -> int {
     if (c->d_nbr.alloc((size_t)N * c->nbr_cap)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (neighbour list)");
     inline_stats = false;
-    if (ncell >= NBR_TILE_MIN_CELLS && c->nbr_tiles && nc.x >= 4 && nc.y >= 4 && nc.z >= 4) {      // workgroup per cell, neighbourhood staged in LDS
-      static bool attr_set[2] = {false, false};
+    if (tile_build_ok) {
       auto kern = c->pair_tiles ? k_neighbors_tiles<true> : k_neighbors_tiles<false>;
-      if (!attr_set[c->pair_tiles ? 1 : 0]) {
-        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NBR_TILE_CAP * NBR_TILE_BYTES + 64));
-        attr_set[c->pair_tiles ? 1 : 0] = true;
-      }
+      HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NBR_TILE_CAP * NBR_TILE_BYTES + 64));      // per device: cheap, every launch
       // tile: sized from the largest neighbourhood the last build saw
       // (a larger one is scanned from global memory).  Up to NBR_TILE_CAP2 atoms two workgroups share a CU's 160 KB.
       int tile_cap = NBR_TILE_CAP2;
-      if (c->tile_atoms_max > 0 && c->tile_atoms_max * 1.03 > NBR_TILE_CAP2) tile_cap = std::min(NBR_TILE_CAP, ((int)(c->tile_atoms_max * 1.08) + 63) & ~63);
+      const int seen = c->pair_tiles ? c->half_tile_max : c->tile_atoms_max;
+      if (seen > 0 && seen * 1.03 > NBR_TILE_CAP2) tile_cap = std::min(NBR_TILE_CAP, ((int)(seen * 1.08) + 63) & ~63);
       if (want_inline) { HIPCHK(hipMemsetAsync(d_stats, 0, 8 * sizeof(int), c->stream)); inline_stats = true; }
       hipLaunchKernelGGL(kern, dim3(ncell), dim3(1024), (size_t)tile_cap * NBR_TILE_BYTES + 64, c->stream, nc, c->d_cell_start.p, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, box, rv2,
                          c->nbr_cap, tile_cap, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p, want_inline ? d_stats : (int*)nullptr);
-    } else if (c->pair_tiles)
-      hipLaunchKernelGGL((k_neighbors<true, true>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
-                         c->nbr_cap, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p);
-    else
-      hipLaunchKernelGGL((k_neighbors<true, false>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
+    } else
+      hipLaunchKernelGGL((k_neighbors<true>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
                          c->nbr_cap, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p);
     HIPCHK(hipGetLastError());
     return MSEVB_OK;
   };
   auto set_cap = [&](unsigned maxcount) { c->nbr_cap = ((unsigned)(maxcount * 1.15) + 64u + 63u) & ~63u; };
-  auto decide_tiles = [&](int tile_max) {
-    c->tile_atoms_max = tile_max;
-    const size_t tile_bytes = (size_t)tile_max * sizeof(double4) + (size_t)c->nt * c->nt * sizeof(PairParam) + 1024;
-    const bool fits = tile_bytes <= (size_t)PAIR_TILE_LDS_BYTES;
-    c->pair_tiles = fits && (c->pair_tiles_opt == 1 || (c->pair_tiles_opt == -1 && ncell >= PAIR_TILE_MIN_CELLS));
-  };
-  if (c->nbr_cap == 0) {      // first build: a counting pass sizes the row stride
-    hipLaunchKernelGGL((k_neighbors<false, false>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
+  if (c->nbr_cap == 0 || (c->pair_tiles_opt != 0 && tile_build_ok && c->half_tile_max == 0)) {      // first build: a counting pass sizes the row stride (full rows: an upper bound of the half rows) and the tiles
+    hipLaunchKernelGGL((k_neighbors<false>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
                        0u, c->d_nbr_count.p, (unsigned*)nullptr, (int*)nullptr);
+    const unsigned cap_before = c->nbr_cap;
+    c->nbr_cap = 0;      // k_count_stats must not cut the counted rows
     CHK(stats(true));
-    set_cap((unsigned)h_stats[2]);
-    decide_tiles(h_stats[0]);
+    if (cap_before == 0 || (unsigned)h_stats[2] > cap_before) set_cap((unsigned)h_stats[2]); else c->nbr_cap = cap_before;
+    c->tile_atoms_max = h_stats[0]; c->half_tile_max = h_stats[1];
+    decide_format();
     CHK(fill());
+    CHK(stats(false));
   } else {                    // rebuild: one pass; the stride only grows when a row overflowed
-    if (c->pair_tiles_opt != 0) { CHK(stats(true)); decide_tiles(h_stats[0]); }    // the tile size fixes the entry format of this build
-    else c->pair_tiles = false;
+    decide_format();
     CHK(fill(defer));
     if (defer) {      // statistics without a synchronisation: by the fill kernel itself when it is the tile kernel (nothing between it and the pair loop)
       if (inline_stats) c->nbr_stats_copy_pending = true;      // downloaded behind the pair loop (pair_forces): the host only looks at its next wait
       else CHK(stats(true, false));      // + the largest neighbourhood, for the next build's tile
       c->nbr_check_pending = true;
     } else {
-      CHK(stats(false));
-      if ((unsigned)h_stats[2] > c->nbr_cap) { set_cap((unsigned)h_stats[2]); CHK(fill()); CHK(stats(false)); }
+      CHK(stats(true));
+      c->tile_atoms_max = h_stats[0];
+      const bool tile_grew = c->pair_tiles && h_stats[1] > c->half_tile_cap;      // a half neighbourhood outgrew the pair kernel's LDS tile
+      if (h_stats[1] > 0) c->half_tile_max = h_stats[1];
+      if ((unsigned)h_stats[2] > c->nbr_cap || tile_grew) {
+        if ((unsigned)h_stats[2] > c->nbr_cap) set_cap((unsigned)h_stats[2]);
+        decide_format(); CHK(fill()); CHK(stats(false));
+      }
     }
   }
   if ((double)N * c->nbr_cap >= 4294967296.0) FAIL(MSEVB_ERR_LIMIT, "Verlet list exceeds 32-bit row offsets");
@@ -563,8 +578,10 @@ int nb_check_overflow(msevb_ctx* c) {
   c->nbr_check_pending = false;
   const int* h = c->h_nbr_stats;
   if (h[0] > 0) c->tile_atoms_max = h[0];
-  if ((unsigned)h[2] > c->nbr_cap) {
-    c->nbr_cap = ((unsigned)((unsigned)h[2] * 1.15) + 64u + 63u) & ~63u;
+  const bool tile_grew = c->pair_tiles && h[1] > c->half_tile_cap;      // a half neighbourhood outgrew the LDS tile of the pair kernel (which skipped that cell)
+  if (h[1] > 0) c->half_tile_max = h[1];
+  if ((unsigned)h[2] > c->nbr_cap || tile_grew) {
+    if ((unsigned)h[2] > c->nbr_cap) c->nbr_cap = ((unsigned)((unsigned)h[2] * 1.15) + 64u + 63u) & ~63u;
     c->list_valid = false;
     return 1;
   }

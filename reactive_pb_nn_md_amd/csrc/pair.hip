@@ -6,6 +6,8 @@
 // cell-sorted array (L2-resident neighbourhoods), the (type_i,type_j) parameter table lives in LDS, and the
 // per-atom force is reduced across the 64 lanes with shuffles - the list is a full list, so no fp64 atomics.
 // Algorithmic bytes per step: 4 B per list entry + 36 B per atom read, 24 B per atom written.
+// Two kernels: k_pair (full list, partner records gathered from L2; small boxes) and k_pair_half (half list, LDS tiles; see below).
+#include <algorithm>
 #include "ctx.hpp"
 #include "devmath.hpp"
 
@@ -138,62 +140,193 @@ __global__ __launch_bounds__(256) void k_pair(int i_lo, int N, const double4* __
 }
 
 
-// LDS-staged variant: ONE WORKGROUP PER CELL.  The {x,y,z,q} records of the cell's whole neighbourhood (its <= 27 neighbour
-// cells, contiguous ranges of the cell-sorted array) are staged once into an LDS tile with coalesced 32-B loads; the list
-// entries of the cell's atoms are LOCAL indices into that tile, so the per-pair neighbour gather is two ds_read_b128 instead
-// of two divergent global loads (the global-gather kernel above is bound by the L1 tag rate: one 64-B line per lane and load).
-// Waves of the block take the cell's atoms round-robin; everything else is as in k_pair.
-template <bool SAPT, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_pair_tiles(int3 nc, const int* __restrict__ cell_start, const double4* __restrict__ posq, const int* __restrict__ type_s,
-                                                     const unsigned* __restrict__ nbr_start, const unsigned* __restrict__ nbr_count, const int* __restrict__ nbr, const PairParam* __restrict__ pairpar, int nt,
-                                                     const double2* __restrict__ etab, double inv_dx, int emax, const double* __restrict__ tt, const double* __restrict__ dtt,
-                                                     BoxDev box, double rc2, const int* __restrict__ perm, double* __restrict__ F, double* __restrict__ part_el,
-                                                     double* __restrict__ part_vdw) {
-  extern __shared__ double4 tile[];                     // [tile atoms] then the pair-parameter table
-  __shared__ int s_lo[27], s_off[28], s_ns;
+// ---------------------------------------------------------------------------------------------------------------------------------
+// HALF-LIST LDS PAIR KERNEL: one workgroup per cell of the neighbour grid.
+//   * The list is a HALF list (every pair once, Newton's third law): atom i of cell c keeps the partners that come after it in the
+//     HALF NEIGHBOURHOOD of c (the cell itself + its 13 forward cells, ctx.hpp), entries = position in that tile (neighbor.hip).
+//   * The tile - {x,y,z relative to the cell centre at the periodic image next to it, q} of its ~1 900 atoms, 32 B each - is staged
+//     once per workgroup with coalesced loads; the per-pair partner gather is then two ds_read_b128 instead of a divergent 64-B line
+//     per lane through L1 (what bounds the global-gather kernel above: 146 M L1 lines per launch at 98 k atoms), no per-pair
+//     minimum-image arithmetic is left (the tile IS the minimum image for every pair of the list when there are >= 4 cells per axis),
+//     and the Ewald-table rows - the two gathers parity forces on us - are the only per-lane global loads.
+//   * -f_ij goes to a force tile in LDS with ds_add_f64 (partners of one row are distinct atoms: no same-address serialisation); the
+//     row owner's force is reduced across the wave as before and added to the same tile; the tile is flushed ONCE per workgroup with
+//     coalesced fp64 atomics into a force array in SORTED order (Fs, SoA), which k_pair_fold adds to the caller-order force array.
+//   * Waves take the cell's atoms from an LDS counter (rows of a half list differ a lot in length).
+//   * The cutoff decision is the reference's to the last bit: pairs within 1e-9 relative of r_c^2 are re-decided from the raw coordinates
+//     with min_image_r2 (coordinates from a .gro put pairs EXACTLY on the cutoff).
+// Half the pair evaluations of the full-list kernel, ~5x fewer L1 line accesses.  Needs >= 4 cells per axis and a half neighbourhood that
+// fits the tile (56 B per atom: 2 700 atoms); otherwise the list is built in the full format and k_pair runs.
+__device__ __forceinline__ int tile_to_sorted(int p, const int* s_lo, const int* s_off) {
+  int s = 0;
+  while (s + 1 < HALF_SLOTS && p >= s_off[s + 1]) ++s;
+  return s_lo[s] + (p - s_off[s]);
+}
+
+template <bool SAPT, bool PRUNE>
+__device__ __forceinline__ void pair_row_half(const double4* tile, double* tfx, double* tfy, double* tfz, const double4 pi, int ti, int i_sorted, unsigned s, unsigned e,
+                                              int lane, const int* __restrict__ nbr, const PairParam* sp, int nt, const double2* __restrict__ etab, double inv_dx, int emax,
+                                              const double* __restrict__ tt, const double* __restrict__ dtt, const BoxDev& box, double rc2, const double4* __restrict__ posq,
+                                              const int* s_lo, const int* s_off, double& fx, double& fy, double& fz, double& e_el, double& e_vdw,
+                                              int* __restrict__ out, double rp2, unsigned& n_out) {
+#pragma clang fp contract(fast)
+  const double tie = 1e-9 * rc2;
+  unsigned k = s + lane;
+  unsigned e0 = k < e ? (unsigned)nbr[k] : NBR_NONE, e1 = k + 64 < e ? (unsigned)nbr[k + 64] : NBR_NONE;
+  for (unsigned k0 = s; k0 < e; k0 += 128) {      // wave-uniform trip count
+    const unsigned kn = k + 128;
+    const unsigned n0 = kn < e ? (unsigned)nbr[kn] : NBR_NONE, n1 = kn + 64 < e ? (unsigned)nbr[kn + 64] : NBR_NONE;
+    const bool va = e0 != NBR_NONE, vb = e1 != NBR_NONE;
+    const unsigned ja = va ? (e0 & NBR_IDX_MASK) : 0u, jb = vb ? (e1 & NBR_IDX_MASK) : 0u;
+    const double4 pa = tile[ja], pb = tile[jb];
+    const double dxa = pi.x - pa.x, dya = pi.y - pa.y, dza = pi.z - pa.z;
+    const double dxb = pi.x - pb.x, dyb = pi.y - pb.y, dzb = pi.z - pb.z;
+    const double r2a = dxa * dxa + dya * dya + dza * dza, r2b = dxb * dxb + dyb * dyb + dzb * dzb;
+    bool ina = va && r2a < rc2, inb = vb && r2b < rc2;
+    const bool ta = va && fabs(r2a - rc2) < tie, tb = vb && fabs(r2b - rc2) < tie;
+    if (__ballot(ta || tb)) {      // rare: on the cutoff to within rounding - the reference's arithmetic on the raw coordinates decides
+      double ux, uy, uz;
+      if (ta) ina = min_image_r2(posq[i_sorted], posq[tile_to_sorted((int)ja, s_lo, s_off)], box, ux, uy, uz) < rc2;
+      if (tb) inb = min_image_r2(posq[i_sorted], posq[tile_to_sorted((int)jb, s_lo, s_off)], box, ux, uy, uz) < rc2;
+    }
+    if (PRUNE && out) {      // wave-uniform branch: compact the entries within rc + delta into the pruned row
+      const bool ka = va && r2a < rp2, kb = vb && r2b < rp2;
+      const unsigned long long ma = __ballot(ka), mb = __ballot(kb);
+      unsigned tot = n_out;
+      if (ka) out[tot + __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0u))] = (int)e0;
+      tot += (unsigned)__popcll(ma);
+      if (kb) out[tot + __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u))] = (int)e1;
+      n_out = tot + (unsigned)__popcll(mb);
+    }
+    EwaldRows wa, wb;      // lanes outside the cutoff all fetch the row of r_c: one line for the lot
+    ewald_fetch(ina ? r2a : rc2, inv_dx, emax, etab, wa);
+    ewald_fetch(inb ? r2b : rc2, inv_dx, emax, etab, wb);
+    if (ina) {
+      double fs, ee, ev;
+      pair_interaction_rows<SAPT>(r2a, pi.w * pa.w, sp[ti * nt + (int)(e0 >> NBR_IDX_BITS)], wa, tt, dtt, fs, ee, ev);
+      const double gx = fs * dxa, gy = fs * dya, gz = fs * dza;
+      fx += gx; fy += gy; fz += gz; e_el += ee; e_vdw += ev;
+      atomicAdd(&tfx[ja], -gx); atomicAdd(&tfy[ja], -gy); atomicAdd(&tfz[ja], -gz);
+    }
+    if (inb) {
+      double fs, ee, ev;
+      pair_interaction_rows<SAPT>(r2b, pi.w * pb.w, sp[ti * nt + (int)(e1 >> NBR_IDX_BITS)], wb, tt, dtt, fs, ee, ev);
+      const double gx = fs * dxb, gy = fs * dyb, gz = fs * dzb;
+      fx += gx; fy += gy; fz += gz; e_el += ee; e_vdw += ev;
+      atomicAdd(&tfx[jb], -gx); atomicAdd(&tfy[jb], -gy); atomicAdd(&tfz[jb], -gz);
+    }
+    e0 = n0; e1 = n1; k = kn;
+  }
+}
+
+template <bool SAPT, bool PRUNE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_pair_half(int c_lo, int c_hi, int3 nc, int tile_cap, const int* __restrict__ cell_start, const double4* __restrict__ posq,
+                                                    const int* __restrict__ type_s, const unsigned* __restrict__ nbr_start, const unsigned* __restrict__ nbr_count,
+                                                    const int* __restrict__ nbr, const PairParam* __restrict__ pairpar, int nt, const double2* __restrict__ etab, double inv_dx,
+                                                    int emax, const double* __restrict__ tt, const double* __restrict__ dtt, BoxDev box, double rc2, double* __restrict__ Fs,
+                                                    double* __restrict__ part_el, double* __restrict__ part_vdw, int* __restrict__ prune_state, int* __restrict__ nbr2,
+                                                    unsigned* __restrict__ count2, double4* __restrict__ posq_prune, double rp2, int N_all) {
+  extern __shared__ double4 tile[];                     // [tile_cap] positions, then the force tile (3 x [tile_cap]), then the pair-parameter table
+  __shared__ int s_lo[HALF_SLOTS], s_off[HALF_SLOTS + 1], s_next;
   __shared__ double red[2][16];
-  const int cidx = blockIdx.x;
+  double* tfx = (double*)(tile + tile_cap);
+  double* tfy = tfx + tile_cap;
+  double* tfz = tfy + tile_cap;
+  PairParam* sp = (PairParam*)(tfz + tile_cap);
+  const int mode = PRUNE ? __builtin_amdgcn_readfirstlane(prune_state[0]) : 0;
+  if (PRUNE && mode != 2) {      // snapshot of ALL positions (the displacement check runs over every atom, also when the cells are sharded over ranks)
+    const int chunk = (N_all + gridDim.x - 1) / gridDim.x, k0 = blockIdx.x * chunk, k1 = min(N_all, k0 + chunk);
+    for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x) posq_prune[k] = posq[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0) prune_state[2] = 1;      // seen by the NEXT step's k_top2_final: pruned rows exist for these full rows
+  }
+  const int cidx = c_lo + xcd_block(blockIdx.x, gridDim.x);      // one XCD works on one contiguous eighth of the cells (a slab): its L2 holds that slab's rows
+  if (cidx >= c_hi) { if (threadIdx.x == 0) { part_el[blockIdx.x] = 0.0; part_vdw[blockIdx.x] = 0.0; } return; }
   if (threadIdx.x == 0) {
-    int slots[27];
-    const int ns = cell_neighbourhood(cidx, nc.x, nc.y, nc.z, slots);
+    int slots[HALF_SLOTS];
+    cell_half_neighbourhood(cidx, nc.x, nc.y, nc.z, slots);
     int off = 0;
-    for (int s = 0; s < ns; ++s) { s_lo[s] = cell_start[slots[s]]; s_off[s] = off; off += cell_start[slots[s] + 1] - s_lo[s]; }
-    s_off[ns] = off; s_ns = ns;
+    for (int s = 0; s < HALF_SLOTS; ++s) { s_lo[s] = cell_start[slots[s]]; s_off[s] = off; off += cell_start[slots[s] + 1] - s_lo[s]; }
+    s_off[HALF_SLOTS] = off; s_next = 0;
   }
   __syncthreads();
-  const int ns = s_ns, ntile = s_off[ns];
-  PairParam* sp = (PairParam*)(tile + ntile);
+  const int ntile = s_off[HALF_SLOTS], na = s_off[1];
+  if (ntile > tile_cap) {      // a half neighbourhood larger than the tile this list was built for: the host sees it in the build statistics and repeats the call
+    if (threadIdx.x == 0) { part_el[blockIdx.x] = 0.0; part_vdw[blockIdx.x] = 0.0; }
+    return;
+  }
   for (int k = threadIdx.x; k < nt * nt; k += blockDim.x) sp[k] = pairpar[k];
-  for (int s = 0; s < ns; ++s) {
-    const int lo = s_lo[s], n = s_off[s + 1] - s_off[s], o = s_off[s];
-    for (int k = threadIdx.x; k < n; k += blockDim.x) tile[o + k] = posq[lo + k];
+  {      // stage: coordinates relative to the cell centre, at the periodic image nearest to it (>= 4 cells per axis: within 2 cells of it)
+    const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
+    const double ox = (cx + 0.5) * box.L[0] / nc.x, oy = (cy + 0.5) * box.L[1] / nc.y, oz = (cz + 0.5) * box.L[2] / nc.z;
+    for (int s = 0; s < HALF_SLOTS; ++s) {
+      const int lo = s_lo[s], n = s_off[s + 1] - s_off[s], o = s_off[s];
+      for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const double4 p = posq[lo + k];
+        double4 t;
+        t.x = p.x - ox; t.x = t.x - box.L[0] * floor(t.x * box.invL[0] + 0.5);
+        t.y = p.y - oy; t.y = t.y - box.L[1] * floor(t.y * box.invL[1] + 0.5);
+        t.z = p.z - oz; t.z = t.z - box.L[2] * floor(t.z * box.invL[2] + 0.5);
+        t.w = p.w;
+        tile[o + k] = t;
+        tfx[o + k] = 0.0; tfy[o + k] = 0.0; tfz[o + k] = 0.0;
+      }
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   double e_el = 0.0, e_vdw = 0.0;
-  const int i1 = cell_start[cidx + 1];
-  for (int i = cell_start[cidx] + wave; i < i1; i += wpb) {
-    const double4 pi = posq[i];
+  const int cs = s_lo[0];
+  for (;;) {
+    int a = 0;
+    if (lane == 0) a = atomicAdd(&s_next, 1);
+    a = __builtin_amdgcn_readfirstlane(a);
+    if (a >= na) break;
+    const int i = cs + a;
+    const double4 pi = tile[a];
     const int ti = type_s[i];
-    const unsigned s = nbr_start[i], e = s + nbr_count[i];
+    const unsigned s = nbr_start[i];
     double fx = 0.0, fy = 0.0, fz = 0.0;
-    pair_row<SAPT>(tile, pi, ti, s, e, lane, nbr, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, fx, fy, fz, e_el, e_vdw);
+    unsigned n2 = 0;
+    if (PRUNE && mode == 2)
+      pair_row_half<SAPT, false>(tile, tfx, tfy, tfz, pi, ti, i, s, s + count2[i], lane, nbr2, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, posq, s_lo, s_off, fx, fy, fz, e_el, e_vdw, nullptr, 0.0, n2);
+    else if (PRUNE) {
+      pair_row_half<SAPT, true>(tile, tfx, tfy, tfz, pi, ti, i, s, s + nbr_count[i], lane, nbr, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, posq, s_lo, s_off, fx, fy, fz, e_el, e_vdw, nbr2 + s, rp2, n2);
+      if (lane == 0) count2[i] = n2;
+    } else
+      pair_row_half<SAPT, false>(tile, tfx, tfy, tfz, pi, ti, i, s, s + nbr_count[i], lane, nbr, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, posq, s_lo, s_off, fx, fy, fz, e_el, e_vdw, nullptr, 0.0, n2);
     fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
-    if (lane == 0) {
-      const int o = perm[i];
-      atomicAdd(&F[3 * o], fx); atomicAdd(&F[3 * o + 1], fy); atomicAdd(&F[3 * o + 2], fz);
-    }
+    if (lane == 0) { atomicAdd(&tfx[a], fx); atomicAdd(&tfy[a], fy); atomicAdd(&tfz[a], fz); }
   }
   e_el = wave_sum(e_el);
   e_vdw = wave_sum(e_vdw);
   if (lane == 0) { red[0][wave] = e_el; red[1][wave] = e_vdw; }
-  __syncthreads();
+  __syncthreads();      // ... and every wave's LDS force adds are done
   if (threadIdx.x == 0) {
     double a = 0, b = 0;
     for (int w = 0; w < wpb; ++w) { a += red[0][w]; b += red[1][w]; }
-    part_el[blockIdx.x] = 0.5 * a;
-    part_vdw[blockIdx.x] = 0.5 * b;
+    part_el[blockIdx.x] = a;      // half list: every pair once
+    part_vdw[blockIdx.x] = b;
   }
+  // flush the force tile: runs of consecutive sorted atoms per cell, one coalesced fp64 atomic per component (partners no row reached stay out)
+  for (int s = 0; s < HALF_SLOTS; ++s) {
+    const int lo = s_lo[s], n = s_off[s + 1] - s_off[s], o = s_off[s];
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+      const double vx = tfx[o + k], vy = tfy[o + k], vz = tfz[o + k];
+      if (vx != 0.0 || vy != 0.0 || vz != 0.0) {
+        atomicAdd(&Fs[lo + k], vx); atomicAdd(&Fs[(size_t)N_all + lo + k], vy); atomicAdd(&Fs[2 * (size_t)N_all + lo + k], vz);
+      }
+    }
+  }
+}
+
+// caller-order force += sorted-order accumulator of k_pair_half (atomic: the per-molecule kernel and the reciprocal gather may be running), accumulator re-zeroed
+__global__ __launch_bounds__(256) void k_pair_fold(int N, const int* __restrict__ perm, double* __restrict__ Fs, double* __restrict__ F) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  const double vx = Fs[k], vy = Fs[(size_t)N + k], vz = Fs[2 * (size_t)N + k];
+  Fs[k] = 0.0; Fs[(size_t)N + k] = 0.0; Fs[2 * (size_t)N + k] = 0.0;
+  const int o = perm[k];
+  atomicAdd(&F[3 * o], vx); atomicAdd(&F[3 * o + 1], vy); atomicAdd(&F[3 * o + 2], vz);
 }
 
 }  // namespace
@@ -205,21 +338,37 @@ int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw) {
   for (int d = 0; d < 3; ++d) { box.L[d] = c->box[d]; box.invL[d] = 1.0 / c->box[d]; }
   int nblocks;
   phase_begin(c, PH_PAIR);
-  if (c->pair_tiles && !(c->shard_now && c->n_ranks > 1)) {
+  if (c->pair_tiles) {      // half list, tile-local entries: the LDS kernel, one workgroup per cell
     const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
-    if (ncell > MAX_BLOCKS) FAIL(MSEVB_ERR_LIMIT, "pair_forces: too many cells");
-    nblocks = ncell;
-    const size_t lds = (size_t)c->tile_atoms_max * sizeof(double4) + (size_t)c->nt * c->nt * sizeof(PairParam);
-    // the SAPT instantiation needs > 128 VGPRs: 512 threads (8 waves) per cell instead of 1024
-    auto kern = c->has_sapt ? k_pair_tiles<true, 512> : k_pair_tiles<false, 1024>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[c->has_sapt ? 1 : 0]) {
-      HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_TILE_LDS_BYTES));
-      attr_set[c->has_sapt ? 1 : 0] = true;
+    int c_lo = 0, c_hi = ncell;
+    if (c->shard_now && c->n_ranks > 1) { c_lo = (int)((long)ncell * c->rank / c->n_ranks); c_hi = (int)((long)ncell * (c->rank + 1) / c->n_ranks); }      // this rank's slab of cells
+    nblocks = round_up8(std::max(c_hi - c_lo, 1));
+    if (nblocks > MAX_BLOCKS) FAIL(MSEVB_ERR_LIMIT, "pair_forces: too many cells");
+    const size_t lds = (size_t)c->half_tile_cap * PAIR_TILE_ATOM_BYTES + (size_t)c->nt * c->nt * sizeof(PairParam);
+    const bool pr = c->prune && c->rc + c->prune_delta < c->rv;
+    if (pr) {
+      if (c->d_nbr2.alloc(c->d_nbr.n) || c->d_nbr2_count.alloc(N) || c->d_posq_prune.alloc(N)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (pruned pair list)");
+      if (!c->d_prune_mode.p || c->prune_lo != -2 - c_lo || c->prune_hi != c_hi) { CHK(nb_prune_reset(c)); c->prune_lo = -2 - c_lo; c->prune_hi = c_hi; }      // (cell ranges are kept apart from the atom ranges of k_pair)
     }
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(c->has_sapt ? 512 : 1024), lds, c->stream, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), c->d_cell_start.p, c->d_posq.p, c->d_type_sorted.p,
-                       c->d_nbr_start.p, c->d_nbr_count.p, c->d_nbr.p, c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->erfc_grid, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->d_perm.p,
-                       c->d_force.p, c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS, c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS);
+    if (!c->d_fsorted.p) {
+      if (c->d_fsorted.alloc(3 * (size_t)N)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (sorted force accumulator)");
+      HIPCHK(hipMemsetAsync(c->d_fsorted.p, 0, 3 * (size_t)N * 8, c->stream));
+    }
+    // the SAPT instantiation needs > 128 VGPRs: 512 threads (8 waves) per cell instead of 1024
+    void (*kern)(int, int, int3, int, const int*, const double4*, const int*, const unsigned*, const unsigned*, const int*, const PairParam*, int, const double2*, double, int,
+                 const double*, const double*, BoxDev, double, double*, double*, double*, int*, int*, unsigned*, double4*, double, int) =
+        c->has_sapt ? (pr ? k_pair_half<true, true, 512> : k_pair_half<true, false, 512>) : (pr ? k_pair_half<false, true, 1024> : k_pair_half<false, false, 1024>);
+    const int which = (c->has_sapt ? 2 : 0) + (pr ? 1 : 0);
+    if (!c->attr_pair_half[which]) {
+      HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_TILE_LDS_BYTES));
+      c->attr_pair_half[which] = true;
+    }
+    const double rp = c->rc + c->prune_delta;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(c->has_sapt ? 512 : 1024), lds, c->stream, c_lo, c_hi, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), c->half_tile_cap,
+                       c->d_cell_start.p, c->d_posq.p, c->d_type_sorted.p, c->d_nbr_start.p, c->d_nbr_count.p, c->d_nbr.p, c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx,
+                       c->erfc_grid, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->d_fsorted.p, c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS,
+                       c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS, c->d_prune_mode.p, c->d_nbr2.p, c->d_nbr2_count.p, c->d_posq_prune.p, rp * rp, N);
+    hipLaunchKernelGGL(k_pair_fold, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, c->d_perm.p, c->d_fsorted.p, c->d_force.p);
   } else {
     int i_lo, i_hi;
     shard_range(c, N, i_lo, i_hi);

@@ -108,7 +108,7 @@ def test_unchanged_reference_main_program_on_the_gpu_library(tmp_path, name, evb
     log = _parse_log(str(tmp_path / "out.log"))
     assert sorted(log) == list(range(7)), (sorted(log), r.stdout[-2000:])
     pe0, ke0, comps = log[0]
-    close = lambda a, b: abs(a - b) <= 2e-6 * max(abs(b), 1.0)      # E16.6
+    close = lambda a, b: abs(a - b) <= 1e-5 * max(abs(b), 1.0)      # print_step writes E16.6: six significant digits
     if evb:
         assert close(pe0, g["E_adiabatic"][0]), (pe0, g["E_adiabatic"][0])
     else:

@@ -115,29 +115,46 @@ def test_evb_against_reference(name, stores):
     h.close()
 
 
-@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_sapt_s6"])
-def test_lds_tiled_pair_kernel(name):
-    """The optional LDS-staged pair kernel (one workgroup per cell, list entries local to the cell-neighbourhood tile; off by
-    default) against the reference, including the decode of its list back to the reference's half list."""
-    g = golden(name)
-    spec = system.from_golden(g)
-    h = api.MsEvbHip(spec)
-    h.set_option("pair_tiles", 1)
-    h.construct_verlet_list()
-    vp, nl = h.get_verlet_list()
-    assert len(nl) == int(g["neighbor_count"]) and np.array_equal(vp, g["verlet_point"])
-    hh = hashlib.sha256()
-    for i in range(spec.n_atom):
-        hh.update(np.int32(i + 1).tobytes())
-        hh.update(np.sort(nl[vp[i] - 1:vp[i + 1] - 1]).astype("<i4").tobytes())
-    assert hh.hexdigest() == str(g["neighbor_pairs_sha256"])
-    h.zero_forces()
-    e = h.real_space_energy_force()
-    assert np.abs(h.get_forces() - (g["F_pair"] + g["F_intra_nb"])).max() < F_TOL
-    assert rel(e[0], g["E_elec_pair"][0]) < E_RTOL and rel(e[1], g["E_vdw_pair"][0]) < E_RTOL
-    en, F = h.calculate_total_force_energy()
-    assert np.abs(F - g["F_total"]).max() < F_TOL and rel(en["potential"], g["E_total"][0]) < E_RTOL
-    h.close()
+@pytest.mark.parametrize("sapt", [False, True])
+def test_half_list_lds_pair_kernel_against_oracle(oracle_lib, sapt):
+    """The half-list LDS pair kernel (one workgroup per cell, tile-local list entries; the default whenever the box has >= 4 cells per
+    axis - the small reference fixtures do not, they run the full-list kernel) at the size of BASELINE.json configs[1]: its list decodes
+    to the oracle's pair set, forces / energies equal the oracle's AND the full-list kernel's, with and without the rolling pruned rows,
+    also with a live SAPT (Buckingham + Tang-Toennies) term."""
+    s = synth.make_system(15, n_diabat=2, seed=7)
+    ff = forcefield.ch3so3h_water_forcefield()
+    if sapt:
+        ff = forcefield.with_test_sapt(ff)
+    p = forcefield.build_params(ff, moltype_order=["h2o", "so3h"])
+    spec = system.from_synth(s, p, rc=9.0, rv=10.5, pme_grid=32)
+    o = oracle_lib.Oracle(spec, threads=8)
+    o.verlet_build()
+    vpo, nlo = o.verlet_get()
+    rows_o = [np.sort(nlo[vpo[i] - 1:vpo[i + 1] - 1]) for i in range(spec.n_atom)]
+    Eo, Fo = o.pair()
+    Ei, Fi = o.intra_nonbonded()
+    e_tot, _E, F_tot = o.total()
+    Fk = {}
+    for tiles in (1, 0):
+        h = api.MsEvbHip(spec)
+        h.set_option("pair_tiles", tiles)
+        h.construct_verlet_list()
+        vp, nl = h.get_verlet_list()
+        assert np.array_equal(vp, vpo)
+        assert all(np.array_equal(nl[vp[i] - 1:vp[i + 1] - 1], rows_o[i]) for i in range(spec.n_atom))      # the same set of pairs
+        for prune in (0, 1):
+            h.set_option("pair_prune", prune)
+            h.zero_forces()
+            e = h.real_space_energy_force()
+            assert np.abs(h.get_forces() - (Fo + Fi)).max() < F_TOL, (tiles, prune)
+            assert rel(e[0], Eo[0]) < E_RTOL and abs(e[1] - Eo[1]) < E_RTOL * max(abs(Eo[1]), 1.0), (tiles, prune, e, Eo)
+        # the full force call three times at the same positions: the first writes the rolling pruned rows, the others run on them
+        for rep in range(3):
+            en, F = h.calculate_total_force_energy()
+            assert rel(en["potential"], e_tot) < E_RTOL and np.abs(F - F_tot).max() < F_TOL, (tiles, rep)
+        Fk[tiles] = F
+        h.close()
+    assert np.abs(Fk[1] - Fk[0]).max() < F_TOL
 
 
 @pytest.mark.parametrize("name,evb", [("md_std_n6_s4", False), ("md_evb_n6_d2_s5", True), ("md_std_n6_frz_s14", False)])

@@ -51,7 +51,7 @@ def exported_symbols():
     """names declared in include/msevb_hip.h"""
     import re
     hdr = open(os.path.join(os.path.dirname(_HERE), "include", "msevb_hip.h")).read()
-    return sorted(set(re.findall(r"\b(msevb_[a-z_0-9]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(msevb_[A-Za-z_0-9]+)\s*\(", hdr)))
 
 
 def _ip(a):
@@ -252,6 +252,29 @@ class MsEvbHip:
         Q, th, u, fr = np.zeros((K, K, K)), np.zeros((K, K, K)), np.zeros((self.N, 3)), np.zeros((self.N, 3))
         self._chk(self.L.msevb_get_pme_state(self.ctx, _dp(Q), _dp(th), _dp(u), _dp(fr)))
         return Q, th, u, fr
+
+    def grid_Q(self, chg, xyz_scale):
+        """grid_Q (src/pme.f90:184) at the reference's granularity: scaled coordinates and charges in, Q(K,K,K) out (host arrays)"""
+        K = self.K
+        Q = np.zeros((K, K, K))
+        chg, u = np.ascontiguousarray(chg, dtype=np.float64), np.ascontiguousarray(xyz_scale, dtype=np.float64)
+        self._chk(self.L.msevb_grid_Q(self.ctx, _dp(Q), _dp(chg), _dp(u), len(chg)))
+        return Q
+
+    def modify_Q_grid(self, Q, chg, xyz_scale, operation):
+        """modify_Q_grid (src/pme.f90:275): Q +/-= the stencils of a few atoms, in place"""
+        chg, u = np.ascontiguousarray(chg, dtype=np.float64), np.ascontiguousarray(xyz_scale, dtype=np.float64)
+        assert Q.flags.c_contiguous and Q.dtype == np.float64
+        self._chk(self.L.msevb_modify_Q_grid(self.ctx, _dp(Q), _dp(chg), _dp(u), len(chg), int(operation)))
+        return Q
+
+    def derivative_grid_Q(self, FQ, chg, xyz_scale, kk, conv):
+        """derivative_grid_Q (src/pme.f90:346) for all the atoms handed in: reciprocal forces (n,3) from theta_conv_Q"""
+        chg, u = np.ascontiguousarray(chg, dtype=np.float64), np.ascontiguousarray(xyz_scale, dtype=np.float64)
+        FQ, kk = np.ascontiguousarray(FQ, dtype=np.float64), np.ascontiguousarray(kk, dtype=np.float64)      # kk: the memory of the Fortran array kk(3,3)
+        F = np.zeros((len(chg), 3))
+        self._chk(self.L.msevb_derivative_grid_Q(self.ctx, _dp(F), _dp(FQ), _dp(chg), _dp(u), len(chg), kk.ctypes.data_as(C.POINTER(C.c_double)), C.c_double(conv)))
+        return F
 
     def pme_indices(self):
         near = np.zeros((self.N, 3), dtype=np.int32)

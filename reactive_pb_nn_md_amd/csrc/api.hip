@@ -111,6 +111,8 @@ int msevb_destroy(msevb_ctx* c) {
                         &c->d_Fdiag, &c->d_Foff};
   for (auto b : db) b->release();
   c->d_pair_par.release(); c->d_moltypes.release(); c->d_ewald_tab.release(); c->d_nbr_count.release(); c->d_nbr2_count.release(); c->d_posq_prune.release(); c->d_nbr_start.release();
+  c->d_comm_h.release(); c->d_comm_e.release(); c->d_bad.release(); c->d_fsorted.release();
+  if (c->h_ke) (void)hipHostFree(c->h_ke);
   c->d_sort_tmp.release(); c->d_posq.release(); c->d_grid.release(); c->d_fft_work.release(); c->d_fft_work_b.release();
   for (int p = 0; p < PH_COUNT; ++p) for (hipEvent_t e : c->ph[p].ev) (void)hipEventDestroy(e);
   if (c->h_energies) (void)hipHostFree(c->h_energies);

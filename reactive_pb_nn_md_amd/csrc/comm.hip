@@ -38,7 +38,7 @@ int msevb_comm_init(msevb_ctx* c, const void* id128, int rank, int n_ranks) {
 int msevb_comm_allgather_evb(msevb_ctx* c, int with_energies) {
   const int D = c->D, S = slots_per_rank(c, D), R = c->n_ranks, P = 2 * S + 1 + 8;
   ncclComm_t comm = (ncclComm_t)c->nccl_comm;
-  static thread_local DBuf<double> d_h;
+  DBuf<double>& d_h = c->d_comm_h;
   if (d_h.alloc((size_t)R * P)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (comm)");
   std::vector<double> h((size_t)R * P, 0.0);
   double* mine = h.data() + (size_t)c->rank * P;
@@ -58,7 +58,7 @@ int msevb_comm_allgather_evb(msevb_ctx* c, int with_energies) {
 // Stand-alone sum of the eight principal energy slots over the ranks (the EVB force call itself carries them in its all-gather).
 int msevb_comm_allreduce_energies(msevb_ctx* c) {
   if (!c || !c->nccl_comm) return MSEVB_OK;
-  static thread_local DBuf<double> d_e;
+  DBuf<double>& d_e = c->d_comm_e;
   if (d_e.alloc(8)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (comm)");
   HIPCHK(hipMemcpyAsync(d_e.p, c->h_energies + S_ELEC_PAIR, 8 * sizeof(double), hipMemcpyHostToDevice, c->aux2));
   if (ncclAllReduce(d_e.p, d_e.p, 8, ncclDouble, ncclSum, (ncclComm_t)c->nccl_comm, c->aux2) != ncclSuccess) FAIL(MSEVB_ERR_COMM, "ncclAllReduce failed");

@@ -296,6 +296,12 @@ struct msevb_ctx {
   int evb_cap = 0;
   int rank = 0, n_ranks = 1;
   void* nccl_comm = nullptr;
+  // per-context scratch that used to be process-wide (two contexts on different GPUs / host threads must not share it)
+  void* evb_work = nullptr;            // EvbWork of evb.hip (created by the first EVB force call, freed by evb_release)
+  DBuf<double> d_comm_h, d_comm_e;     // staging of the Hamiltonian all-gather / the energy all-reduce (comm.hip)
+  DBuf<int> d_bad;                     // 'force too large' flag of the integrator (integrate.hip)
+  double* h_ke = nullptr; int h_ke_cap = 0;      // pinned kinetic-energy records of msevb_md_integrate_atomic
+  bool attr_evb_solve = false;         // hipFuncSetAttribute done on this context's device
 
   PhaseTimer ph[PH_COUNT];
   bool timing = true;

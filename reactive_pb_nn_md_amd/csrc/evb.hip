@@ -808,7 +808,6 @@ struct EvbWork {   // persistent device scratch of one context
   bool counters_dirty = true, dv_dirty = true;
   std::vector<RegionRec> region;
 };
-std::map<msevb_ctx*, EvbWork*> g_work;
 // host-side section timing (MSEVB_HOST_TIMING=1): where the CPU thread spends the step
 struct HostTimes { double t[12] = {0}; long n = 0; };
 HostTimes g_ht;
@@ -1043,9 +1042,8 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   auto HT = [&](int k) { if (ht_on) { const double t = now_us(); g_ht.t[k] += t - ht_last; ht_last = t; } };
 
   if (!c->evb_set) FAIL(MSEVB_ERR_STATE, "EVB tables not set (msevb_set_evb)");
-  EvbWork*& wp = g_work[c];
-  if (!wp) wp = new EvbWork();
-  EvbWork* w = wp;
+  if (!c->evb_work) c->evb_work = new EvbWork();
+  EvbWork* w = (EvbWork*)c->evb_work;
   const int N = c->N, M = c->M, K = c->K;
   const size_t K3 = (size_t)K * K * K, n3 = 3 * (size_t)N;
   const BoxDev box = mkbox(c);
@@ -1386,8 +1384,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
         HIPCHK(hipHostMalloc((void**)&w->h_solve, w->h_solve_cap * sizeof(double), hipHostMallocDefault));
       }
       if (w->d_coef.alloc(1 + MAX_DIABATS + 2 * MAX_DIABATS)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blend coefficients)");
-      static bool attr = false;
-      if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * MAX_DIABATS * MAX_DIABATS + 4 * MAX_DIABATS) * 8)); attr = true; }
+      if (!c->attr_evb_solve) { HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * MAX_DIABATS * MAX_DIABATS + 4 * MAX_DIABATS) * 8)); c->attr_evb_solve = true; }
       hipLaunchKernelGGL(k_evb_solve, dim3(1), dim3(64), (size_t)(2 * D * D + 4 * D) * 8, ss, (const SolveDesc*)(w->d_desc.p + off_s), (const int*)(w->d_desc.p + off_si),
                          (const double*)(w->d_desc.p + off_ss), w->d_E.p, c->d_energies.p + S_RECIP, w->d_coef.p, w->h_solve);
       HIPCHK(hipGetLastError());
@@ -1603,9 +1600,7 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
 // frees the per-context EVB scratch (called by msevb_destroy while the context's streams still exist)
 void evb_release(msevb_ctx* c) {
   if (getenv("MSEVB_HOST_TIMING") && g_ht.n) { fprintf(stderr, "[msevb host us/step]"); for (int k = 0; k < 12; ++k) fprintf(stderr, " %d:%.1f", k, g_ht.t[k] / g_ht.n); fprintf(stderr, "\n"); }
-  auto it = g_work.find(c);
-  if (it == g_work.end()) return;
-  EvbWork* w = it->second;
+  EvbWork* w = (EvbWork*)c->evb_work;
   if (w) {
     DBuf<double>* db[] = {&w->d_exch, &w->d_part, &w->d_E, &w->d_dVspec, &w->d_sw, &w->d_sdw, &w->d_Fdelta, &w->d_F11, &w->d_pack, &w->d_com_atom};
     for (auto b : db) b->release();
@@ -1621,7 +1616,7 @@ void evb_release(msevb_ctx* c) {
     if (w->h_E) (void)hipHostFree(w->h_E);
     delete w;
   }
-  g_work.erase(it);
+  c->evb_work = nullptr;
 }
 
 extern "C" {
@@ -1652,9 +1647,8 @@ int msevb_get_evb_state(msevb_ctx* c, int* nd, int* plog, int* cm, double* H, do
 
 int msevb_evb_partial_blend(msevb_ctx* c, const double* eigvec, double* force) {
   if (!c || c->D <= 0 || !eigvec || !force) { if (c) c->err = "bad argument"; return MSEVB_ERR_ARG; }
-  auto it = g_work.find(c);
-  if (it == g_work.end()) FAIL(MSEVB_ERR_STATE, "no EVB force call yet");
-  EvbWork* w = it->second;
+  EvbWork* w = (EvbWork*)c->evb_work;
+  if (!w) FAIL(MSEVB_ERR_STATE, "no EVB force call yet");
   const size_t n3 = 3 * (size_t)c->N;
   if (w->last_fast) {      // fast path: consumes the delta store and the force accumulator of the last call - ONE call per force call
     CHK(fast_blend_phase(c, w, c->D, eigvec, w->last_grid_of, w->last_ngrid, w->last_nra, w->last_d_ra));
@@ -1676,11 +1670,11 @@ int msevb_get_evb_element_force(msevb_ctx* c, int i, int j, double* force) {
   if (!c->evb_element_stores) FAIL(MSEVB_ERR_STATE, "per-element force stores are off: msevb_set_option(ctx, \"evb_element_stores\", 1) before the EVB force call");
   const size_t n3 = 3 * (size_t)c->N;
   if (i == j) {      // diagonal: principal force (copy kept by k_evb_slot0) + the stored difference; zero on ranks that do not own the diabat
-    auto it = g_work.find(c);
-    if (it == g_work.end() || !it->second->d_F11.p) FAIL(MSEVB_ERR_STATE, "no EVB force call yet");
+    EvbWork* w11 = (EvbWork*)c->evb_work;
+    if (!w11 || !w11->d_F11.p) FAIL(MSEVB_ERR_STATE, "no EVB force call yet");
     if (i > 1 && !owned(c, i - 1)) { memset(force, 0, n3 * 8); return MSEVB_OK; }
     std::vector<double> d(n3);
-    HIPCHK(hipMemcpyAsync(force, it->second->d_F11.p, n3 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(force, w11->d_F11.p, n3 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(d.data(), c->d_Fdiag.p + (size_t)diag_slot(c, c->D, i - 1) * n3, n3 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     for (size_t k = 0; k < n3; ++k) force[k] = force[k] + d[k];

@@ -173,12 +173,12 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
   const int N = c->N, M = c->M, n3 = 3 * N;
   BoxDev box;
   for (int d = 0; d < 3; ++d) { box.L[d] = c->box[d]; box.invL[d] = 1.0 / c->box[d]; }
-  static thread_local DBuf<int> d_bad;
+  DBuf<int>& d_bad = c->d_bad;
   if (d_bad.alloc(1)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed");
   HIPCHK(hipMemsetAsync(d_bad.p, 0, sizeof(int), c->stream));
   // trajectory energies come back asynchronously: the EVB force call synchronises with the host on its own (Hamiltonian), so the loop
   // itself never waits; without EVB the host needs the Verlet flag of every step and fetches the energies at its end
-  static thread_local double* h_ke = nullptr; static thread_local int h_ke_cap = 0;      // 7 doubles per step: S_KE, S_P*, S_V*
+  double*& h_ke = c->h_ke; int& h_ke_cap = c->h_ke_cap;      // 7 doubles per step: S_KE, S_P*, S_V*
   static_assert(S_PX == S_KE + 1 && S_VX == S_KE + 4 && S_VZ == S_KE + 6, "kinetic energy block of the energy slots");
   if (n_steps > h_ke_cap) {
     if (h_ke) HIPCHK(hipHostFree(h_ke));

@@ -83,6 +83,31 @@ def test_stages_against_reference(name):
     h.close()
 
 
+@pytest.mark.parametrize("name", ["std_n6_s3", "std_n6_k20_s13"])
+def test_pme_stage_entry_points_against_reference(name):
+    """grid_Q / modify_Q_grid / derivative_grid_Q (src/pme.f90:184, :275, :346) at the reference's own granularity (host arrays and SCALED
+    coordinates in and out - what reactive_pb_nn_md_amd/fortran/msevb_hip_stages.f90 binds) against the real reference's grids and forces"""
+    g = golden(name)
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    u, q = g["xyz_scale"], spec.charge
+    Q = h.grid_Q(q, u)
+    assert np.abs(Q - g["Q_grid"]).max() < 1e-14
+    # take five atoms off the grid and put them back with twice their charge: equals the full spread of the modified charges
+    idx = np.array([0, 7, 100, 311, spec.n_atom - 1])
+    Q2 = h.modify_Q_grid(Q.copy(), q[idx], u[idx], -1)
+    Q2 = h.modify_Q_grid(Q2, 2.0 * q[idx], u[idx], +1)
+    q2 = q.copy(); q2[idx] *= 2.0
+    assert np.abs(Q2 - h.grid_Q(q2, u)).max() < 1e-13
+    small = np.where(np.abs(q) > 1e-6, q, 0.0)      # modify_Q_grid skips |q| <= 1e-6 (src/pme.f90:296), grid_Q does not
+    assert np.abs(h.modify_Q_grid(np.zeros_like(Q), q, u, +1) - h.grid_Q(small, u)).max() < 1e-14
+    F = h.derivative_grid_Q(g["theta_conv_Q"], q, u, g["kk"], float(g["conv_e2A_kJmol"][0]))
+    assert np.abs(F - g["F_recip"]).max() < F_TOL
+    F1 = h.derivative_grid_Q(g["theta_conv_Q"], q[5:6], u[5:6], g["kk"], float(g["conv_e2A_kJmol"][0]))      # one atom per call, as the reference calls it
+    assert np.abs(F1[0] - g["F_recip"][5]).max() < F_TOL
+    h.close()
+
+
 @pytest.mark.parametrize("stores", [0, 1])
 @pytest.mark.parametrize("name", all_golden("evb_"))
 def test_evb_against_reference(name, stores):
@@ -130,7 +155,7 @@ def test_half_list_lds_pair_kernel_against_oracle(oracle_lib, sapt):
     o = oracle_lib.Oracle(spec, threads=8)
     o.verlet_build()
     vpo, nlo = o.verlet_get()
-    rows_o = [np.sort(nlo[vpo[i] - 1:vpo[i + 1] - 1]) for i in range(spec.n_atom)]
+    rows_o = [np.sort(nlo[vpo[i]:vpo[i + 1]]) + 1 for i in range(spec.n_atom)]      # the oracle's arrays are 0-based
     Eo, Fo = o.pair()
     Ei, Fi = o.intra_nonbonded()
     e_tot, _E, F_tot = o.total()
@@ -140,7 +165,7 @@ def test_half_list_lds_pair_kernel_against_oracle(oracle_lib, sapt):
         h.set_option("pair_tiles", tiles)
         h.construct_verlet_list()
         vp, nl = h.get_verlet_list()
-        assert np.array_equal(vp, vpo)
+        assert np.array_equal(vp, vpo + 1)
         assert all(np.array_equal(nl[vp[i] - 1:vp[i + 1] - 1], rows_o[i]) for i in range(spec.n_atom))      # the same set of pairs
         for prune in (0, 1):
             h.set_option("pair_prune", prune)

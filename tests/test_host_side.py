@@ -91,6 +91,14 @@ def test_spec_from_synth_equals_spec_from_reference_dump():
     assert mine.hydronium == ref.hydronium
 
 
+def test_fortran_bindings_cover_the_header():
+    """reactive_pb_nn_md_amd/fortran/msevb_hip_c.f90 binds every entry point include/msevb_hip.h declares, and nothing else"""
+    import re
+    src = open(os.path.join(os.path.dirname(api.LIB_PATH), "fortran", "msevb_hip_c.f90")).read()
+    bound = sorted(set(re.findall(r'bind\(C,\s*name="(msevb_[A-Za-z_0-9]+)"\)', src)))
+    assert bound == api.exported_symbols()
+
+
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(api.LIB_PATH), "libmsevb_hip.so must be built (python -c 'import __graft_entry__ as g; g.build()')"
     lib = ctypes.CDLL(api.LIB_PATH)

@@ -122,6 +122,7 @@ constexpr unsigned NBR_IDX_MASK = (1u << NBR_IDX_BITS) - 1u;
 // kernel stages per cell (positions 32 B + force accumulators 24 B per tile atom).
 constexpr int PAIR_TILE_LDS_BYTES = 156 * 1024;      // of the 160 KiB per CU; the rest holds the static reductions
 constexpr int PAIR_TILE_ATOM_BYTES = 56;
+constexpr int PAIR_CELL_MAX = 512;                   // most atoms of ONE cell the half-list pair kernel keeps row metadata for (a cell of edge r_v holds ~135 at liquid density)
 constexpr int NBR_TILE_CAP = 8000;                   // most atoms of a cell neighbourhood the list build can stage in LDS
 constexpr int NBR_TILE_CAP2 = 4032;                  // ... while two workgroups still fit a CU (2 x (4032 x 20 B + 0.9 KB static) <= 160 KB)
 constexpr int NBR_TILE_BYTES = 20;                   // per staged atom: float4 {x,y,z,molecule} + the entry word
@@ -274,6 +275,8 @@ struct msevb_ctx {
   // up and down during a run and creating a plan pair costs milliseconds (a step costs 0.6 ms)
   std::map<int, std::pair<rocfft_plan, rocfft_plan>> plans_b;
   bool spread_tiles = true;
+  bool spread_mfma = false;      // charge spreading as a per-cell contraction on the matrix cores (v_mfma_f64_16x16x4_f64), option spread_mfma
+  bool attr_spread_mfma = false;
   bool has_sapt = false;     // some (type_i,type_j) entry has non-zero SAPT coefficients
   rocfft_execution_info fft_info = nullptr, fft_info_b = nullptr;      // single-grid plans (their work buffer is baked into the captured PME graph) / batched plans
   DBuf<char> d_fft_work, d_fft_work_b;

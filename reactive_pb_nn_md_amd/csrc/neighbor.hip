@@ -166,19 +166,19 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
   int* te = (int*)(t4 + tile_cap + 2);      // (+ 2 spare float4: the last pair of an odd-sized tile reads one entry past it)
   // cell centre: tile coordinates are within +-1.5 cells of it
   const double ox = (cx + 0.5) * box.L[0] / nc.x, oy = (cy + 0.5) * box.L[1] / nc.y, oz = (cz + 0.5) * box.L[2] / nc.z;
-  if (in_lds) {
-    for (int s = 0; s < ns; ++s) {
-      const int lo = s_lo[s], n = s_off[s + 1] - s_off[s], o = s_off[s];
-      for (int k = threadIdx.x; k < n; k += blockDim.x) {
-        const double4 p = posq[lo + k];
-        float4 t;
-        t.x = (float)(((p.x - box.L[0] * floor(p.x * box.invL[0])) + s_shift[s][0]) - ox);
-        t.y = (float)(((p.y - box.L[1] * floor(p.y * box.invL[1])) + s_shift[s][1]) - oy);
-        t.z = (float)(((p.z - box.L[2] * floor(p.z * box.invL[2])) + s_shift[s][2]) - oz);
-        t.w = __int_as_float(mol_s[lo + k]);
-        t4[o + k] = t;
-        te[o + k] = (int)((HALF ? (unsigned)(o + k) : (unsigned)(lo + k)) | ((unsigned)type_s[lo + k] << NBR_IDX_BITS));
-      }
+  if (in_lds) {      // ONE pass over the tile: every thread has its loads in flight together (a loop over the slots waits for memory once per slot)
+    for (int q = threadIdx.x; q < ntile; q += blockDim.x) {
+      int s = 0;
+      while (s + 1 < ns && q >= s_off[s + 1]) ++s;
+      const int j = s_lo[s] + (q - s_off[s]);
+      const double4 p = posq[j];
+      float4 t;
+      t.x = (float)(((p.x - box.L[0] * floor(p.x * box.invL[0])) + s_shift[s][0]) - ox);
+      t.y = (float)(((p.y - box.L[1] * floor(p.y * box.invL[1])) + s_shift[s][1]) - oy);
+      t.z = (float)(((p.z - box.L[2] * floor(p.z * box.invL[2])) + s_shift[s][2]) - oz);
+      t.w = __int_as_float(mol_s[j]);
+      t4[q] = t;
+      te[q] = (int)((HALF ? (unsigned)q : (unsigned)j) | ((unsigned)type_s[j] << NBR_IDX_BITS));
     }
   }
   __syncthreads();

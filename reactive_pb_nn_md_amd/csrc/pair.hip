@@ -20,6 +20,23 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 
+// sum over the 16 lanes of each DPP row (lanes 16 r .. 16 r + 15), left in every lane of the row: four cross-lane moves inside the VALU
+// (quad swaps, half-row mirror, row mirror), no LDS traffic - __shfl_xor goes through the LDS pipe (ds_bpermute), which the half-list
+// pair kernel needs for its tile reads and force adds.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum16(double v) {
+  v += dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);      // row_half_mirror: quad q <-> quad 1 - q of each half row
+  v += dpp_mov<0x140>(v);      // row_mirror: half row <-> half row
+  return v;
+}
+
 constexpr unsigned NBR_NONE = 0xffffffffu;     // padding entry of a partial trip
 
 // Minimum-image separation and r^2 with the reference's own operation order and NO FMA contraction (src/pair_int_real_space.f90:222-226:
@@ -168,11 +185,10 @@ __device__ __forceinline__ void pair_row_half(const double4* tile, double* tfx, 
                                               int lane, const int* __restrict__ nbr, const PairParam* sp, int nt, const double2* __restrict__ etab, double inv_dx, int emax,
                                               const double* __restrict__ tt, const double* __restrict__ dtt, const BoxDev& box, double rc2, const double4* __restrict__ posq,
                                               const int* s_lo, const int* s_off, double& fx, double& fy, double& fz, double& e_el, double& e_vdw,
-                                              int* __restrict__ out, double rp2, unsigned& n_out) {
+                                              int* __restrict__ out, double rp2, unsigned& n_out, unsigned e0, unsigned e1) {
 #pragma clang fp contract(fast)
   const double tie = 1e-9 * rc2;
-  unsigned k = s + lane;
-  unsigned e0 = k < e ? (unsigned)nbr[k] : NBR_NONE, e1 = k + 64 < e ? (unsigned)nbr[k + 64] : NBR_NONE;
+  unsigned k = s + lane;      // e0 / e1 = entries k and k + 64 of the row (NBR_NONE past its end), loaded by the caller while the previous row was evaluated
   for (unsigned k0 = s; k0 < e; k0 += 128) {      // wave-uniform trip count
     const unsigned kn = k + 128;
     const unsigned n0 = kn < e ? (unsigned)nbr[kn] : NBR_NONE, n1 = kn + 64 < e ? (unsigned)nbr[kn + 64] : NBR_NONE;
@@ -229,6 +245,8 @@ __global__ __launch_bounds__(THREADS) void k_pair_half(int c_lo, int c_hi, int3 
   extern __shared__ double4 tile[];                     // [tile_cap] positions, then the force tile (3 x [tile_cap]), then the pair-parameter table
   __shared__ int s_lo[HALF_SLOTS], s_off[HALF_SLOTS + 1], s_next;
   __shared__ double red[2][16];
+  __shared__ unsigned s_cnt[PAIR_CELL_MAX];      // row lengths of the cell's atoms (the rows this launch runs on)
+  __shared__ unsigned char s_typ[PAIR_CELL_MAX];
   double* tfx = (double*)(tile + tile_cap);
   double* tfy = tfx + tile_cap;
   double* tfz = tfy + tile_cap;
@@ -241,80 +259,92 @@ __global__ __launch_bounds__(THREADS) void k_pair_half(int c_lo, int c_hi, int3 
   }
   const int cidx = c_lo + xcd_block(blockIdx.x, gridDim.x);      // one XCD works on one contiguous eighth of the cells (a slab): its L2 holds that slab's rows
   if (cidx >= c_hi) { if (threadIdx.x == 0) { part_el[blockIdx.x] = 0.0; part_vdw[blockIdx.x] = 0.0; } return; }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < HALF_SLOTS + 1) {      // 14 lanes look up their cell, lane 14 waits for the prefix sum below
     int slots[HALF_SLOTS];
     cell_half_neighbourhood(cidx, nc.x, nc.y, nc.z, slots);
-    int off = 0;
-    for (int s = 0; s < HALF_SLOTS; ++s) { s_lo[s] = cell_start[slots[s]]; s_off[s] = off; off += cell_start[slots[s] + 1] - s_lo[s]; }
-    s_off[HALF_SLOTS] = off; s_next = 0;
+    if (threadIdx.x < HALF_SLOTS) { s_lo[threadIdx.x] = cell_start[slots[threadIdx.x]]; s_off[threadIdx.x + 1] = cell_start[slots[threadIdx.x] + 1] - cell_start[slots[threadIdx.x]]; }
   }
   __syncthreads();
+  if (threadIdx.x == 0) { int off = 0; for (int s = 0; s < HALF_SLOTS; ++s) { const int n = s_off[s + 1]; s_off[s] = off; off += n; } s_off[HALF_SLOTS] = off; s_next = 0; }
+  __syncthreads();
   const int ntile = s_off[HALF_SLOTS], na = s_off[1];
-  if (ntile > tile_cap) {      // a half neighbourhood larger than the tile this list was built for: the host sees it in the build statistics and repeats the call
+  if (ntile > tile_cap || na > PAIR_CELL_MAX) {      // a half neighbourhood larger than the tile this list was built for: the host sees it in the build statistics and repeats the call
     if (threadIdx.x == 0) { part_el[blockIdx.x] = 0.0; part_vdw[blockIdx.x] = 0.0; }
     return;
   }
   for (int k = threadIdx.x; k < nt * nt; k += blockDim.x) sp[k] = pairpar[k];
-  {      // stage: coordinates relative to the cell centre, at the periodic image nearest to it (>= 4 cells per axis: within 2 cells of it)
+  const int cs = s_lo[0];
+  {      // stage, ONE pass over the tile (every thread has its loads in flight together): coordinates relative to the cell centre, at the
+         // periodic image nearest to it (>= 4 cells per axis: every tile atom is within 2 cells of it)
     const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
     const double ox = (cx + 0.5) * box.L[0] / nc.x, oy = (cy + 0.5) * box.L[1] / nc.y, oz = (cz + 0.5) * box.L[2] / nc.z;
-    for (int s = 0; s < HALF_SLOTS; ++s) {
-      const int lo = s_lo[s], n = s_off[s + 1] - s_off[s], o = s_off[s];
-      for (int k = threadIdx.x; k < n; k += blockDim.x) {
-        const double4 p = posq[lo + k];
-        double4 t;
-        t.x = p.x - ox; t.x = t.x - box.L[0] * floor(t.x * box.invL[0] + 0.5);
-        t.y = p.y - oy; t.y = t.y - box.L[1] * floor(t.y * box.invL[1] + 0.5);
-        t.z = p.z - oz; t.z = t.z - box.L[2] * floor(t.z * box.invL[2] + 0.5);
-        t.w = p.w;
-        tile[o + k] = t;
-        tfx[o + k] = 0.0; tfy[o + k] = 0.0; tfz[o + k] = 0.0;
-      }
+    for (int p = threadIdx.x; p < ntile; p += blockDim.x) {
+      const double4 q = posq[tile_to_sorted(p, s_lo, s_off)];
+      double4 t;
+      t.x = q.x - ox; t.x = t.x - box.L[0] * floor(t.x * box.invL[0] + 0.5);
+      t.y = q.y - oy; t.y = t.y - box.L[1] * floor(t.y * box.invL[1] + 0.5);
+      t.z = q.z - oz; t.z = t.z - box.L[2] * floor(t.z * box.invL[2] + 0.5);
+      t.w = q.w;
+      tile[p] = t;
+      tfx[p] = 0.0; tfy[p] = 0.0; tfz[p] = 0.0;
     }
+    const unsigned* cnt = (PRUNE && mode == 2) ? count2 : nbr_count;
+    for (int a = threadIdx.x; a < na; a += blockDim.x) { s_cnt[a] = cnt[cs + a]; s_typ[a] = (unsigned char)type_s[cs + a]; }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+  const int* rows = (PRUNE && mode == 2) ? nbr2 : nbr;
   double e_el = 0.0, e_vdw = 0.0;
-  const int cs = s_lo[0];
-  for (;;) {
-    int a = 0;
-    if (lane == 0) a = atomicAdd(&s_next, 1);
-    a = __builtin_amdgcn_readfirstlane(a);
-    if (a >= na) break;
+  // Rows are handed out by an LDS counter (half-list rows differ a lot in length); a wave draws its NEXT row and loads that row's first 128
+  // entries before it evaluates the current one, so the list latency of a row hides behind the arithmetic of its predecessor.
+  int a = 0;
+  if (lane == 0) a = atomicAdd(&s_next, 1);
+  a = __builtin_amdgcn_readfirstlane(a);
+  unsigned e0 = NBR_NONE, e1 = NBR_NONE;
+  if (a < na) {
+    const unsigned s = nbr_start[cs + a], n = s_cnt[a];
+    e0 = (unsigned)lane < n ? (unsigned)rows[s + lane] : NBR_NONE; e1 = (unsigned)lane + 64 < n ? (unsigned)rows[s + lane + 64] : NBR_NONE;
+  }
+  while (a < na) {
+    int an = 0;
+    if (lane == 0) an = atomicAdd(&s_next, 1);
+    an = __builtin_amdgcn_readfirstlane(an);
+    unsigned f0 = NBR_NONE, f1 = NBR_NONE;
+    if (an < na) {
+      const unsigned s = nbr_start[cs + an], n = s_cnt[an];
+      f0 = (unsigned)lane < n ? (unsigned)rows[s + lane] : NBR_NONE; f1 = (unsigned)lane + 64 < n ? (unsigned)rows[s + lane + 64] : NBR_NONE;
+    }
     const int i = cs + a;
     const double4 pi = tile[a];
-    const int ti = type_s[i];
+    const int ti = s_typ[a];
     const unsigned s = nbr_start[i];
     double fx = 0.0, fy = 0.0, fz = 0.0;
     unsigned n2 = 0;
-    if (PRUNE && mode == 2)
-      pair_row_half<SAPT, false>(tile, tfx, tfy, tfz, pi, ti, i, s, s + count2[i], lane, nbr2, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, posq, s_lo, s_off, fx, fy, fz, e_el, e_vdw, nullptr, 0.0, n2);
-    else if (PRUNE) {
-      pair_row_half<SAPT, true>(tile, tfx, tfy, tfz, pi, ti, i, s, s + nbr_count[i], lane, nbr, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, posq, s_lo, s_off, fx, fy, fz, e_el, e_vdw, nbr2 + s, rp2, n2);
+    if (PRUNE && mode != 2) {
+      pair_row_half<SAPT, true>(tile, tfx, tfy, tfz, pi, ti, i, s, s + s_cnt[a], lane, rows, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, posq, s_lo, s_off, fx, fy, fz, e_el, e_vdw, nbr2 + s, rp2, n2, e0, e1);
       if (lane == 0) count2[i] = n2;
     } else
-      pair_row_half<SAPT, false>(tile, tfx, tfy, tfz, pi, ti, i, s, s + nbr_count[i], lane, nbr, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, posq, s_lo, s_off, fx, fy, fz, e_el, e_vdw, nullptr, 0.0, n2);
-    fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
-    if (lane == 0) { atomicAdd(&tfx[a], fx); atomicAdd(&tfy[a], fy); atomicAdd(&tfz[a], fz); }
+      pair_row_half<SAPT, false>(tile, tfx, tfy, tfz, pi, ti, i, s, s + s_cnt[a], lane, rows, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, posq, s_lo, s_off, fx, fy, fz, e_el, e_vdw, nullptr, 0.0, n2, e0, e1);
+    fx = row_sum16(fx); fy = row_sum16(fy); fz = row_sum16(fz);      // the four row sums meet in the LDS add
+    if ((lane & 15) == 0) { atomicAdd(&tfx[a], fx); atomicAdd(&tfy[a], fy); atomicAdd(&tfz[a], fz); }
+    a = an; e0 = f0; e1 = f1;
   }
   e_el = wave_sum(e_el);
   e_vdw = wave_sum(e_vdw);
   if (lane == 0) { red[0][wave] = e_el; red[1][wave] = e_vdw; }
   __syncthreads();      // ... and every wave's LDS force adds are done
   if (threadIdx.x == 0) {
-    double a = 0, b = 0;
-    for (int w = 0; w < wpb; ++w) { a += red[0][w]; b += red[1][w]; }
-    part_el[blockIdx.x] = a;      // half list: every pair once
-    part_vdw[blockIdx.x] = b;
+    double a_ = 0, b_ = 0;
+    for (int w = 0; w < wpb; ++w) { a_ += red[0][w]; b_ += red[1][w]; }
+    part_el[blockIdx.x] = a_;      // half list: every pair once
+    part_vdw[blockIdx.x] = b_;
   }
   // flush the force tile: runs of consecutive sorted atoms per cell, one coalesced fp64 atomic per component (partners no row reached stay out)
-  for (int s = 0; s < HALF_SLOTS; ++s) {
-    const int lo = s_lo[s], n = s_off[s + 1] - s_off[s], o = s_off[s];
-    for (int k = threadIdx.x; k < n; k += blockDim.x) {
-      const double vx = tfx[o + k], vy = tfy[o + k], vz = tfz[o + k];
-      if (vx != 0.0 || vy != 0.0 || vz != 0.0) {
-        atomicAdd(&Fs[lo + k], vx); atomicAdd(&Fs[(size_t)N_all + lo + k], vy); atomicAdd(&Fs[2 * (size_t)N_all + lo + k], vz);
-      }
+  for (int p = threadIdx.x; p < ntile; p += blockDim.x) {
+    const double vx = tfx[p], vy = tfy[p], vz = tfz[p];
+    if (vx != 0.0 || vy != 0.0 || vz != 0.0) {
+      const int j = tile_to_sorted(p, s_lo, s_off);
+      atomicAdd(&Fs[j], vx); atomicAdd(&Fs[(size_t)N_all + j], vy); atomicAdd(&Fs[2 * (size_t)N_all + j], vz);
     }
   }
 }

@@ -135,6 +135,92 @@ __global__ __launch_bounds__(256) void k_pme_spread_tiles(int K, int3 nc, int3 T
   }
 }
 
+// MFMA spread (north_star: "MFMA used only for the B-spline -> charge-grid spreading/gathering contraction").  One workgroup (4 waves) per
+// neighbour cell; the cell's tile is 16 x 16 x 16 grid points (needs ceil(K / cells) + 8 <= 16 on every axis).  The charge of the tile is
+// the contraction over the cell's atoms of three DENSE 16-entry weight vectors (6 non-zero B-spline taps each, placed at the atom's
+// position inside the tile):
+//     tile[z][y][x] = sum_a (q_a Wz_a[z] Wy_a[y]) * Wx_a[x]
+// i.e. for every plane z a GEMM  D_z[y][x] = sum_a A_z[y][a] B[a][x]  with A_z[y][a] = q_a Wz_a[z] Wy_a[y], B[a][x] = Wx_a[x]:
+// M = N = 16, K = atoms of the cell -> v_mfma_f64_16x16x4_f64, 4 atoms per instruction.  Operand maps (cdna_hip_programming.md):
+// A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15], D[row = (lane >> 4) + 4 r][col = lane & 15], r = 0..3.
+// Wave w owns the planes z = 4 w .. 4 w + 3 (16 accumulator doubles per lane); per 4 atoms a lane reads Wy, Wx once and q Wz four times
+// from LDS, multiplies four times and issues four MFMAs.  The accumulators go straight to the grid with fp64 atomics, x fastest
+// (16 consecutive doubles per quarter wave), zeros skipped.  Atoms whose stencil left the tile since the last list build are spread
+// point by point as in k_pme_spread_tiles.  ~19x the multiply-adds of the direct stencil loop, but no LDS atomics and no bank conflicts.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+constexpr int SPREAD_MFMA_CHUNK = 192;      // atoms of a cell staged at a time (3 x 16 doubles each: 72 KB)
+__global__ __launch_bounds__(256) void k_pme_spread_mfma(int K, int3 nc, const int* __restrict__ cell_start, const int* __restrict__ perm,
+                                                         const double* __restrict__ chg, const int* __restrict__ base, const double* __restrict__ w,
+                                                         double2* __restrict__ grid) {
+  extern __shared__ double sm[];
+  double* Wx = sm;                                   // [CHUNK][16]
+  double* Wy = Wx + SPREAD_MFMA_CHUNK * 16;          // [CHUNK][16]
+  double* Wz = Wy + SPREAD_MFMA_CHUNK * 16;          // [CHUNK][16], times the charge
+  __shared__ int s_out[SPREAD_MFMA_CHUNK], s_nout;
+  const int cidx = blockIdx.x;
+  const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
+  const int ox = (int)floor((double)cx * K / nc.x) - 6, oy = (int)floor((double)cy * K / nc.y) - 6, oz = (int)floor((double)cz * K / nc.z) - 6;
+  const int s = cell_start[cidx], e = cell_start[cidx + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  mfma_d4 acc[4];
+  for (int r = 0; r < 4; ++r) acc[r] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+  for (int c0 = s; c0 < e; c0 += SPREAD_MFMA_CHUNK) {
+    const int n = min(SPREAD_MFMA_CHUNK, e - c0), n4 = (n + 3) & ~3;
+    __syncthreads();      // previous chunk consumed
+    if (threadIdx.x == 0) s_nout = 0;
+    for (int k = threadIdx.x; k < n4 * 48; k += blockDim.x) sm[(k / (n4 * 16)) * SPREAD_MFMA_CHUNK * 16 + k % (n4 * 16)] = 0.0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < n * 3; t += blockDim.x) {      // one thread per (atom, axis): six taps into the dense vector
+      const int a = t / 3, d = t - 3 * a, i = perm[c0 + a];
+      const int b1 = base[3 * i], b2 = base[3 * i + 1], b3 = base[3 * i + 2];
+      int l1 = b1 - ox; l1 += l1 < 0 ? K : 0; l1 -= l1 >= K ? K : 0;
+      int l2 = b2 - oy; l2 += l2 < 0 ? K : 0; l2 -= l2 >= K ? K : 0;
+      int l3 = b3 - oz; l3 += l3 < 0 ? K : 0; l3 -= l3 >= K ? K : 0;
+      const double q = chg[i];
+      const bool inside = l1 >= 5 && l1 < 16 && l2 >= 5 && l2 < 16 && l3 >= 5 && l3 < 16;
+      if (!inside) { if (d == 0 && q != 0.0) s_out[atomicAdd(&s_nout, 1)] = i; continue; }      // its dense vectors stay zero
+      const int l = d == 0 ? l1 : d == 1 ? l2 : l3;
+      double* W = (d == 0 ? Wx : d == 1 ? Wy : Wz) + a * 16;
+      const double sc = d == 2 ? q : 1.0;
+      for (int k = 0; k < 6; ++k) W[l - k] = sc * w[(size_t)i * 18 + d * 6 + k];
+    }
+    __syncthreads();
+    const int col = lane & 15, kq = lane >> 4;
+    for (int a0 = 0; a0 < n4; a0 += 4) {
+      const int a = a0 + kq;
+      const double bx = Wx[a * 16 + col], ay = Wy[a * 16 + col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Wz[a * 16 + 4 * wave + r] * ay, bx, acc[r], 0, 0, 0);
+    }
+    __syncthreads();
+    for (int o = 0; o < s_nout; ++o) {      // atoms that drifted out of the tile: straight to the grid, 216 taps over the block
+      const int i = s_out[o];
+      const double q = chg[i];
+      for (int t = threadIdx.x; t < 216; t += blockDim.x) {
+        const int k1 = t % 6, k2 = (t / 6) % 6, k3 = t / 36;
+        int n1 = base[3 * i] - k1; if (n1 < 0) n1 += K;
+        int n2 = base[3 * i + 1] - k2; if (n2 < 0) n2 += K;
+        int n3 = base[3 * i + 2] - k3; if (n3 < 0) n3 += K;
+        atomicAdd(&grid[n1 + (size_t)K * (n2 + (size_t)K * n3)].x, q * w[(size_t)i * 18 + k1] * w[(size_t)i * 18 + 6 + k2] * w[(size_t)i * 18 + 12 + k3]);
+      }
+    }
+  }
+  // D[row = y = (lane >> 4) + 4 v][col = x = lane & 15] of plane z = 4 wave + r
+  int n1 = ox + (lane & 15); n1 += n1 < 0 ? K : 0; n1 -= n1 >= K ? K : 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int n3 = oz + 4 * wave + r; n3 += n3 < 0 ? K : 0; n3 -= n3 >= K ? K : 0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const double val = acc[r][v];
+      if (val != 0.0) {
+        int n2 = oy + (lane >> 4) + 4 * v; n2 += n2 < 0 ? K : 0; n2 -= n2 >= K ? K : 0;
+        atomicAdd(&grid[n1 + (size_t)K * (n2 + (size_t)K * n3)].x, val);
+      }
+    }
+  }
+}
+
 // blockIdx.y = grid (batch) index; energy partials of grid g go to part[g*part_stride + blockIdx.x]
 __global__ __launch_bounds__(256) void k_pme_conv(size_t K3, const double* __restrict__ CB, double2* __restrict__ grids, int part_stride,
                                                   double* __restrict__ part, double half_conv) {
@@ -447,7 +533,7 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
   // side stream it is captured once into a hipGraph and replayed with one launch (the ~14 launches cost the host ~80 us per step, and
   // the host is what decides when the EVB chains behind them can start).  Steps that sample the phase timers launch directly.
   struct Key { const void* p[9]; int v[8]; } key = {{c->d_grid.p, c->d_Q.p, c->d_theta.p, c->d_w.p, c->d_base.p, c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_fft_work.p},
-                                               {N, K, c->ncell[0], c->ncell[1], c->ncell[2], c->cells_valid ? 1 : 0, c->spread_tiles ? 1 : 0, slot_recip}};
+                                               {N, K, c->ncell[0], c->ncell[1], c->ncell[2], c->cells_valid ? 1 : 0, (c->spread_tiles ? 1 : 0) + (c->spread_mfma ? 2 : 0), slot_recip}};
   const bool use_graph = join_aux && c->graphs && !c->timing_now;
   bool capturing = false;
   int nbk = 0;
@@ -466,7 +552,12 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
       int3 T;
       T.x = (int)ceil((double)K / c->ncell[0]) + 8; T.y = (int)ceil((double)K / c->ncell[1]) + 8; T.z = (int)ceil((double)K / c->ncell[2]) + 8;
       const size_t tile_bytes = (size_t)spread_plane_stride(T) * T.z * sizeof(double) + (size_t)SPREAD_CHUNK * (18 * 8 + 8 + 12);      // tile + staged atom inputs
-      if (c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= K && T.y <= K && T.z <= K) {
+      if (c->cells_valid && c->spread_mfma && T.x <= 16 && T.y <= 16 && T.z <= 16 && K >= 16) {      // 16^3 tile per cell: the contraction over the cell's atoms on the matrix cores
+        const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
+        if (!c->attr_spread_mfma) { HIPCHK(hipFuncSetAttribute((const void*)k_pme_spread_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, SPREAD_MFMA_CHUNK * 48 * 8)); c->attr_spread_mfma = true; }
+        hipLaunchKernelGGL(k_pme_spread_mfma, dim3(ncell), dim3(256), (size_t)SPREAD_MFMA_CHUNK * 48 * 8, st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]),
+                           c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_base.p, c->d_w.p, c->d_grid.p);
+      } else if (c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= K && T.y <= K && T.z <= K) {
         const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
         hipLaunchKernelGGL(k_pme_spread_tiles, dim3(ncell), dim3(256), tile_bytes, st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T,
                            c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_base.p, c->d_w.p, c->d_grid.p);

@@ -83,6 +83,47 @@ def test_stages_against_reference(name):
     h.close()
 
 
+@pytest.mark.parametrize("name", ["std_n6_s3", "std_n6_sapt_s6", "evb_n6_d4_s2"])
+def test_mfma_charge_spreading_against_reference(name):
+    """option spread_mfma: grid_Q (src/pme.f90:184-262) as a per-cell contraction on the matrix cores (v_mfma_f64_16x16x4_f64, 16^3 tile per
+    cell) - the real reference's Q_grid, theta and reciprocal forces; then the EVB force call on top of it"""
+    g = golden(name)
+    h = api.MsEvbHip(system.from_golden(g))
+    h.set_option("spread_mfma", 1)
+    h.construct_verlet_list()
+    h.zero_forces()
+    er = h.pme_reciprocal_space_energy_force()
+    Q, th, u, fr = h.pme_state()
+    assert np.abs(Q - g["Q_grid"]).max() < 1e-14 and np.abs(th - g["theta_conv_Q"]).max() < 1e-13
+    assert np.abs(h.get_forces() - g["F_recip"]).max() < F_TOL and rel(er, g["E_recip"][0]) < E_RTOL
+    if name.startswith("evb"):
+        e, F = h.ms_evb_calculate_total_force_energy()
+        assert rel(e, g["E_adiabatic"][0]) < E_RTOL and np.abs(F - g["F_adiabatic"]).max() < F_TOL
+    h.close()
+
+
+def test_mfma_charge_spreading_config_B():
+    """... and at BASELINE.json configs[2] (98 220 atoms, 64^3: 729 cells, 16^3 tiles) against the LDS-atomic kernel: same grid, same forces,
+    also along a trajectory on which atoms drift out of their cell's tile (those are spread point by point)"""
+    spec = _synthetic(32, 8, 11, 64)
+    out = []
+    for mfma in (0, 1):
+        h = api.MsEvbHip(spec)
+        h.set_option("spread_mfma", mfma)
+        h.construct_verlet_list()
+        h.zero_forces()
+        er = h.pme_reciprocal_space_energy_force()
+        Q = h.pme_state()[0]
+        F = h.get_forces()
+        h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 99))
+        h.ms_evb_calculate_total_force_energy(want_force=False)
+        tr = h.md_integrate_atomic(25, spec.delta_t, use_evb=True)
+        out.append((er, Q, F, tr, h.get_positions()))
+        h.close()
+    assert rel(out[1][0], out[0][0]) < 1e-13 and np.abs(out[1][1] - out[0][1]).max() < 1e-13 and np.abs(out[1][2] - out[0][2]).max() < F_TOL
+    assert np.abs(out[1][3] - out[0][3]).max() < 1e-8 * np.abs(out[0][3]).max() and np.abs(out[1][4] - out[0][4]).max() < 1e-8
+
+
 @pytest.mark.parametrize("name", ["std_n6_s3", "std_n6_k20_s13"])
 def test_pme_stage_entry_points_against_reference(name):
     """grid_Q / modify_Q_grid / derivative_grid_Q (src/pme.f90:184, :275, :346) at the reference's own granularity (host arrays and SCALED

@@ -107,7 +107,7 @@ int msevb_destroy(msevb_ctx* c) {
                      &c->d_perm_tmp, &c->d_cell_start, &c->d_inv_perm, &c->d_tile_max, &c->d_nbr, &c->d_nbr2, &c->d_prune_mode, &c->d_frozen, &c->d_type_sorted, &c->d_mol_sorted, &c->d_base, &c->d_splindex};
   for (auto b : ib) b->release();
   DBuf<double>* db[] = {&c->d_chg, &c->d_mass, &c->d_B6, &c->d_B5, &c->d_tt, &c->d_dtt, &c->d_CB, &c->d_xyz, &c->d_vel, &c->d_force, &c->d_force_recip,
-                        &c->d_xyz_store, &c->d_disp, &c->d_maxdisp, &c->d_Q, &c->d_theta, &c->d_w, &c->d_dw, &c->d_uscale, &c->d_partials, &c->d_energies,
+                        &c->d_xyz_store, &c->d_disp, &c->d_maxdisp, &c->d_Q, &c->d_theta, &c->d_green, &c->d_w, &c->d_dw, &c->d_uscale, &c->d_partials, &c->d_energies,
                         &c->d_Fdiag, &c->d_Foff};
   for (auto b : db) b->release();
   c->d_pair_par.release(); c->d_moltypes.release(); c->d_ewald_tab.release(); c->d_nbr_count.release(); c->d_nbr2_count.release(); c->d_posq_prune.release(); c->d_nbr_start.release();
@@ -433,6 +433,7 @@ int msevb_set_box(msevb_ctx* c, const double* box3) {
   for (int d = 0; d < 3; ++d) c->box[d] = box3[d];
   CHK(build_box_tables(c));
   HIPCHK(hipMemcpy(c->d_CB.p, c->t_CB.data(), c->t_CB.size() * 8, hipMemcpyHostToDevice));
+  CHK(pme_build_green(c));
   if (c->pme_graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)c->pme_graph_exec); c->pme_graph_exec = nullptr; }      // box and lattice are baked into its kernel arguments
   memset(c->pme_graph_key, 0, sizeof c->pme_graph_key);
   c->list_valid = false; c->cells_valid = false; c->flag_verlet_list = 1;
@@ -673,6 +674,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
   if (s == "spread_mfma") { c->spread_mfma = v != 0.0; return MSEVB_OK; }
   if (s == "evb_device_solve") { c->evb_device_solve = v != 0.0; return MSEVB_OK; }
+  if (s == "evb_recip_linear") { c->evb_recip_linear = v != 0.0; return MSEVB_OK; }
   if (s == "ensemble_nvt") { c->nvt = v != 0.0; return MSEVB_OK; }
   if (s == "friction_coeff") { if (!(v > 0.0)) return MSEVB_ERR_ARG; c->friction = v; return MSEVB_OK; }
   if (s == "temperature") { if (!(v >= 0.0)) return MSEVB_ERR_ARG; c->temperature = v; return MSEVB_OK; }

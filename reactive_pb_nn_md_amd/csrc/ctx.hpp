@@ -268,6 +268,7 @@ struct msevb_ctx {
   DBuf<double2> d_grid;        // complex K^3 (x fastest), in place FFT
   DBuf<double> d_Q;            // real copy of the spread grid (kept for the EVB delta path)
   DBuf<double> d_theta;        // real part of the convolved grid (theta_conv_Q)
+  DBuf<double> d_green;        // G = IFFT(CB): real-space kernel of the reciprocal sum (theta = G * Q), K^3
   DBuf<double> d_w, d_dw, d_uscale;   // per atom: B6 weights [N][3][6], derivative weights, scaled coords
   DBuf<int> d_base, d_splindex;       // nearpt [N][3], B6 rows [N][3][6]
   rocfft_plan plan_fwd = nullptr, plan_bwd = nullptr;
@@ -312,6 +313,7 @@ struct msevb_ctx {
   bool timing_now = false; int timing_stride = 8; long timing_tick = 0;
   // NVT: Langevin leap-frog kicks (langevin_integrator, src/md_integration.f90:186-228) instead of the plain half kicks
   int stamps_on = -1; unsigned long long* h_stamps = nullptr; double stamp_sum[16] = {0}; long stamp_n = 0, stamp_step = 0;
+  bool evb_recip_linear = true;      // diabats' reciprocal space through the linear response of theta to the charge differences (evb.hip): no transform per diabat
   bool evb_device_solve = false;     // single rank: H' assembly + Jacobi + blend coefficients in a kernel (no host round trip before the blend)
   bool nvt = false; double friction = 0.1 /* 1/ps, the reference's default */, temperature = 300.0; unsigned long long langevin_seed = 0, langevin_tick = 0;
 };
@@ -344,6 +346,7 @@ int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux = false);
 int pme_front(msevb_ctx* c, int slot_recip, bool join_aux);
 int pme_tail(msevb_ctx* c, bool join_aux);                           // pme.hip
 int pme_setup(msevb_ctx* c);
+int pme_build_green(msevb_ctx* c);   // after the CB array changed (box change)
 void pme_teardown(msevb_ctx* c);
 int reduce_partials(msevb_ctx* c, int slot, int nblocks);                // deferred: one fused launch in flush_reductions
 int flush_reductions(msevb_ctx* c);

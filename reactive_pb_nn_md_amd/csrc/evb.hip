@@ -618,6 +618,147 @@ __global__ void k_evb_blend_grids(size_t K3, GridCoefs gc, const double* __restr
   }
 }
 
+// ---- reciprocal space of the non-principal diabats WITHOUT a Fourier transform per diabat (default fast path) -----------------------
+// The reference transforms every diabat's charge grid (calculate_reciprocal_space_pme, src/ms_evb.f90:1962-2090).  Q_d differs from the
+// principal grid Q_1 by the stencils of a few dozen atoms (DQ_d = -q_old S_old + q_new S_new over the atoms of the molecules a hop touched),
+// and theta = IFFT(CB FFT(Q)) is LINEAR in Q:  theta_d = theta_1 + G * DQ_d  with the real-space kernel G = IFFT(CB) (K^3 table, built
+// with the box).  Hence
+//   E_recip,d - E_recip,1 = conv (DQ_d . theta_1 + 1/2 DQ_d . G * DQ_d)        linear term: stencil dots with theta_1 (k_evb_recip_linear)
+//                                                                             quadratic term: stencil-pair sums over G (k_evb_recip_pairs)
+//   blended potential     = theta_1 + sum_d c_d^2 G * DQ_d = IFFT(CB FFT(Q_1 + sum_d c_d^2 DQ_d))      ONE transform pair, after the Jacobi
+//   special atoms' forces in diabat d: their stencils against theta_1 + G * DQ_d               the same two kernels
+// instead of D - 1 transform pairs of dense grids (7 x 4 MB x 4 passes per step at 98 k atoms).  A stencil pair (T, S) interacts through
+//   sum_{i in T, j in S} wT_i wS_j G(x_T,i - x_S,j) = sum_{o in [-5,5]^3} W(o) G(b_T - b_S - o),  W = separable cross-correlation of the
+// two stencils' tap weights (11 values per axis): 1331 table reads per pair.
+struct Stencil { int base[3]; int grid, slot, idx; double q; double w[18], dw[18]; };
+
+// two stencils per recip entry: 2 e = the atom as the principal diabat has it (charge -q_old), 2 e + 1 = its new state (charge +q_new).
+// Charges modify_Q_grid would skip (|q| <= 1e-6, src/pme.f90:296) and entries whose two states are identical get q = 0.
+__global__ void k_evb_stencils(int n, const RecipAtom* __restrict__ ra, const int* __restrict__ base, const double* __restrict__ w, const double* __restrict__ dw,
+                               const int* __restrict__ sbase, const double* __restrict__ sw, const double* __restrict__ sdw, Stencil* __restrict__ st) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const RecipAtom r = ra[e];
+  Stencil a, b;
+  a.grid = b.grid = r.grid; a.slot = b.slot = r.slot; a.idx = b.idx = r.idx;
+  bool same = r.q_old == r.q_new;
+  for (int d = 0; d < 3; ++d) { a.base[d] = base[3 * r.idx + d]; b.base[d] = sbase[3 * e + d]; same = same && a.base[d] == b.base[d]; }
+  for (int k = 0; k < 18; ++k) {
+    a.w[k] = w[18 * (size_t)r.idx + k]; a.dw[k] = dw[18 * (size_t)r.idx + k]; b.w[k] = sw[18 * (size_t)e + k]; b.dw[k] = sdw[18 * (size_t)e + k];
+    same = same && a.w[k] == b.w[k];
+  }
+  a.q = (same || fabs(r.q_old) <= 1e-6) ? 0.0 : -r.q_old;
+  b.q = (same || fabs(r.q_new) <= 1e-6) ? 0.0 : r.q_new;
+  st[2 * e] = a; st[2 * e + 1] = b;
+}
+
+// one wavefront per stencil: its dot with theta_1 (energy, linear term) and the force theta_1 exerts on it -> the diabat's slot of the delta store
+__global__ __launch_bounds__(256) void k_evb_recip_linear(int nst, const Stencil* __restrict__ st, int K, const double* __restrict__ theta, double conv, double k00, double k01,
+                                                          double k02, double k10, double k11, double k12, double k20, double k21, double k22, double* __restrict__ Fstore,
+                                                          size_t fstride, double* __restrict__ E_lin) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (e >= nst) return;
+  const Stencil& t = st[e];
+  const double q = t.q;
+  if (q == 0.0) return;
+  double f1 = 0, f2 = 0, f3 = 0, en = 0;
+  for (int p = lane; p < 216; p += 64) {
+    const int k1 = p % 6, k2 = (p / 6) % 6, k3 = p / 36;
+    int n1 = t.base[0] - k1; if (n1 < 0) n1 += K;
+    int n2 = t.base[1] - k2; if (n2 < 0) n2 += K;
+    int n3 = t.base[2] - k3; if (n3 < 0) n3 += K;
+    const double th = theta[n1 + (size_t)K * (n2 + (size_t)K * n3)];
+    en += t.w[k1] * t.w[6 + k2] * t.w[12 + k3] * th;
+    f1 += t.dw[k1] * t.w[6 + k2] * t.w[12 + k3] * th; f2 += t.dw[6 + k2] * t.w[k1] * t.w[12 + k3] * th; f3 += t.dw[12 + k3] * t.w[k1] * t.w[6 + k2] * th;
+  }
+  for (int o = 32; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); f3 += __shfl_xor(f3, o, 64); en += __shfl_xor(en, o, 64); }
+  if (lane == 0) {
+    const double s = q * conv, Kd = (double)K;
+    double* F = Fstore + (size_t)t.slot * fstride;
+    atomicAdd(&F[3 * t.idx], -Kd * (k00 * f1 + k10 * f2 + k20 * f3) * s);
+    atomicAdd(&F[3 * t.idx + 1], -Kd * (k01 * f1 + k11 * f2 + k21 * f3) * s);
+    atomicAdd(&F[3 * t.idx + 2], -Kd * (k02 * f1 + k12 * f2 + k22 * f3) * s);
+    atomicAdd(&E_lin[t.grid], q * en);
+  }
+}
+
+// one wavefront per ORDERED pair (T, S) of stencils of the same diabat: the potential S raises at T's taps, through the real-space kernel
+// G = IFFT(CB): energy q_T q_S sum W G (halved when the grids' energies are finished: every unordered pair appears twice, T = S once with
+// its own factor 1/2) and the force on T's atom.  blockIdx.y = diabat grid, pairs of that grid = blockIdx.x * 4 + wave.
+struct GridRanges { int start[MAX_DIABATS + 1]; };
+__global__ __launch_bounds__(256) void k_evb_recip_pairs(GridRanges gr, const Stencil* __restrict__ st, int K, const double* __restrict__ green, double conv, double k00,
+                                                         double k01, double k02, double k10, double k11, double k12, double k20, double k21, double k22,
+                                                         double* __restrict__ Fstore, size_t fstride, double* __restrict__ E_quad) {
+  __shared__ double sW[4][3][2][11];      // per wave: [axis][W, dW][o + 5]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int g = blockIdx.y, s0 = gr.start[g], ns = gr.start[g + 1] - s0;
+  const int pr = blockIdx.x * 4 + wv;
+  if (pr >= ns * ns) return;
+  const Stencil& T = st[s0 + pr / ns];
+  const Stencil& S = st[s0 + pr % ns];
+  const double qq = T.q * S.q;
+  if (qq == 0.0) return;
+  if (lane < 33) {      // cross-correlations of the tap weights: W(o) = sum_{i - j = o} wT[i] wS[j], dW with T's derivative weights
+    const int ax = lane / 11, o = lane % 11 - 5;
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < 6; ++i) { const int j = i - o; if (j >= 0 && j < 6) { a += T.w[6 * ax + i] * S.w[6 * ax + j]; b += T.dw[6 * ax + i] * S.w[6 * ax + j]; } }
+    sW[wv][ax][0][o + 5] = a; sW[wv][ax][1][o + 5] = b;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // tap i of T sits at b_T - i, tap j of S at b_S - j: separation (b_T - b_S) - (i - j)
+  int d1 = T.base[0] - S.base[0], d2 = T.base[1] - S.base[1], d3 = T.base[2] - S.base[2];
+  double en = 0, f1 = 0, f2 = 0, f3 = 0;
+  for (int p = lane; p < 1331; p += 64) {
+    const int o1 = p % 11, o2 = (p / 11) % 11, o3 = p / 121;
+    int n1 = (d1 - (o1 - 5)) % K; if (n1 < 0) n1 += K;
+    int n2 = (d2 - (o2 - 5)) % K; if (n2 < 0) n2 += K;
+    int n3 = (d3 - (o3 - 5)) % K; if (n3 < 0) n3 += K;
+    const double G = green[n1 + (size_t)K * (n2 + (size_t)K * n3)];
+    const double w1 = sW[wv][0][0][o1], w2 = sW[wv][1][0][o2], w3 = sW[wv][2][0][o3];
+    en += w1 * w2 * w3 * G;
+    f1 += sW[wv][0][1][o1] * w2 * w3 * G; f2 += w1 * sW[wv][1][1][o2] * w3 * G; f3 += w1 * w2 * sW[wv][2][1][o3] * G;
+  }
+  for (int o = 32; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); f3 += __shfl_xor(f3, o, 64); en += __shfl_xor(en, o, 64); }
+  if (lane == 0) {
+    const double s = qq * conv, Kd = (double)K;
+    double* F = Fstore + (size_t)T.slot * fstride;
+    atomicAdd(&F[3 * T.idx], -Kd * (k00 * f1 + k10 * f2 + k20 * f3) * s);
+    atomicAdd(&F[3 * T.idx + 1], -Kd * (k01 * f1 + k11 * f2 + k21 * f3) * s);
+    atomicAdd(&F[3 * T.idx + 2], -Kd * (k02 * f1 + k12 * f2 + k22 * f3) * s);
+    atomicAdd(&E_quad[g], qq * en);
+  }
+}
+
+// E_grid[g] = conv (linear + 1/2 quadratic): the diabat's reciprocal energy RELATIVE to the principal one; accumulators re-zeroed
+__global__ void k_evb_grid_energy(int ng, double* __restrict__ E_lin, double* __restrict__ E_quad, double conv, double* __restrict__ E_grid) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  E_grid[g] = conv * (E_lin[g] + 0.5 * E_quad[g]);
+  E_lin[g] = 0.0; E_quad[g] = 0.0;
+}
+
+// blended charge grid: grid += sum over the stencils of c_d^2 q S (the grid holds Q_1 on rank 0, zero on the others); coefficients as kernel
+// arguments, or from device memory behind k_evb_solve
+__global__ __launch_bounds__(256) void k_evb_blend_patch(int nst, const Stencil* __restrict__ st, GridCoefs gc, const double* __restrict__ dc, int K, double2* __restrict__ grid) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (e >= nst) return;
+  const Stencil& t = st[e];
+  const double q = t.q * (dc ? dc[1 + t.grid] : gc.c[t.grid]);
+  if (q == 0.0) return;
+  for (int p = lane; p < 216; p += 64) {
+    const int k1 = p % 6, k2 = (p / 6) % 6, k3 = p / 36;
+    int n1 = t.base[0] - k1; if (n1 < 0) n1 += K;
+    int n2 = t.base[1] - k2; if (n2 < 0) n2 += K;
+    int n3 = t.base[2] - k3; if (n3 < 0) n3 += K;
+    atomicAdd(&grid[n1 + (size_t)K * (n2 + (size_t)K * n3)].x, q * t.w[k1] * t.w[6 + k2] * t.w[12 + k3]);
+  }
+}
+__global__ void k_grid_real(size_t K3, const double2* __restrict__ grid, double* __restrict__ out) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K3; k += (size_t)gridDim.x * blockDim.x) out[k] = grid[k].x;
+}
+
 struct BlendTerms { int n; int slot[2 * MAX_DIABATS]; double coef[2 * MAX_DIABATS]; };   // slot < 0: off-diagonal store, index -slot-1 (kernel argument, no upload)
 // The diagonal store holds differences to the principal force F11 (F_dd = F11 + store_d) and sum_d c_d^2 = 1, so
 // F = w11 F11 + sum_d c_d^2 store_d + 2 sum c_p c_d F_pd with w11 = 1 (w11 < 1 only for a rank's PARTIAL blend, see evb_partial terms);
@@ -794,6 +935,8 @@ struct EvbWork {   // persistent device scratch of one context
   DBuf<double> d_Fdelta;      // [n_diag][3N] real-space deltas of the diabats, accumulated on stream2 beside the reciprocal space
   hipEvent_t ev_rs = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_E = nullptr, ev_fetch = nullptr, ev_cpl = nullptr, ev_flush = nullptr, ev_fetchA = nullptr; bool delta_dirty = true;
   DBuf<double> d_F11, d_pack, d_com_atom;
+  DBuf<Stencil> d_stencils; DBuf<double> d_Elq;      // linear-response reciprocal path: stencil records, {E_lin[MAX_DIABATS], E_quad[MAX_DIABATS], 0}
+  int last_nst = 0; bool last_linear = false, elq_zeroed = false;
   hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
   RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
   long long* h_flag = nullptr; long long seq_A = 0, seq_R = 0, seq_B = 0;      // pinned: sequence number of the last published fetch A
@@ -1021,11 +1164,32 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   // reciprocal space of the blend in ONE gather: blended potential of this rank's diabats (+ the principal one on rank 0) ...
   GridCoefs gc; gc.n = ngrid; gc.c0 = 0.0;
   if (ev) { gc.c0 = c->rank == 0 ? ev[0] * ev[0] : 0.0; for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gc.c[grid_of[d]] = ev[d] * ev[d]; }
-  if (c->overlap && ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // convolved diabat grids (aux)
+  if (c->overlap && ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // convolved diabat grids / grid energies (aux)
   stamp(c, 8, c->stream);
   if (w->d_pack.alloc(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended potential)");
-  hipLaunchKernelGGL(k_evb_blend_grids, dim3(1024), dim3(256), 0, c->stream, K3, gc, dcoef, c->d_theta.p, w->d_grids.p, w->d_pack.p);
-  CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p));
+  if (w->last_linear) {
+    // blended CHARGE grid Q_1 (rank 0) + sum_d c_d^2 DQ_d -> one transform pair -> blended potential theta_1 + sum_d c_d^2 G * DQ_d
+    // (sum_d c_d^2 = 1 over all ranks, so the principal potential enters once, on rank 0)
+    if (!ngrid) {
+      if (c->rank == 0) CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, c->d_theta.p));
+    } else {
+      if (w->d_grids.alloc_room(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended charge grid)");
+      if (c->rank == 0) hipLaunchKernelGGL(k_evb_grid_init, dim3(2048), dim3(256), 0, c->stream, K3, 1, c->d_Q.p, w->d_grids.p);
+      else HIPCHK(hipMemsetAsync(w->d_grids.p, 0, K3 * sizeof(double2), c->stream));
+      hipLaunchKernelGGL(k_evb_blend_patch, dim3((w->last_nst + 3) / 4), dim3(256), 0, c->stream, w->last_nst, w->d_stencils.p, gc, dcoef, K, w->d_grids.p);
+      HIPCHK(hipGetLastError());
+      int nbk = 0;
+      hipStream_t keep = c->pme_st; c->pme_st = nullptr;      // on the main stream
+      const int rc_conv = pme_convolve(c, w->d_grids.p, 1, w->d_part.p, 1024, &nbk);      // (the energy partials of this transform are not used)
+      c->pme_st = keep;
+      CHK(rc_conv);
+      hipLaunchKernelGGL(k_grid_real, dim3(1024), dim3(256), 0, c->stream, K3, w->d_grids.p, w->d_pack.p);
+      CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p));
+    }
+  } else {
+    hipLaunchKernelGGL(k_evb_blend_grids, dim3(1024), dim3(256), 0, c->stream, K3, gc, dcoef, c->d_theta.p, w->d_grids.p, w->d_pack.p);
+    CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p));
+  }
   // ... the special atoms' own-stencil corrections per diabat are in the delta store already (k_evb_recip_special ran at the end of the
   // diabat grid chain, before the host's turn); the blend consumes the store and re-zeroes it
   if (c->overlap) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0)); if (ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_rs, 0)); }
@@ -1367,6 +1531,12 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipHostMalloc((void**)&w->h_E, w->hE_cap * sizeof(double), hipHostMallocDefault));
   }
   const hipStream_t sg = c->overlap ? c->aux : c->stream;      // diabat grids: `aux` is free once the principal convolution is done
+  const bool linear = fast && c->evb_recip_linear && c->d_green.p;      // no transform per diabat: linear response of theta to the charge differences (E_grid holds energy DIFFERENCES)
+  if (linear) {
+    if (w->d_Elq.alloc(2 * MAX_DIABATS + 1)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB grid energies)");
+    if (!w->elq_zeroed) { HIPCHK(hipMemsetAsync(w->d_Elq.p, 0, (2 * MAX_DIABATS + 1) * 8, ss)); w->elq_zeroed = true; }      // (ss: ahead of every stream that forks from it)
+  }
+  w->last_linear = linear; w->last_nst = 2 * nra;
   // The ground-state VECTOR does not depend on the principal diabat's energy E0: it sits on the whole diagonal (H = H' + E0 I).  So the
   // host diagonalises H' from the energies that exist long before the pair loop ends (unit, coupling and grid energies, fetch A) and
   // the blend kernels queue up directly behind the pair loop; E0 (fetch B: the principal energy slots, complete only after the pair
@@ -1386,7 +1556,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
       if (w->d_coef.alloc(1 + MAX_DIABATS + 2 * MAX_DIABATS)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blend coefficients)");
       if (!c->attr_evb_solve) { HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * MAX_DIABATS * MAX_DIABATS + 4 * MAX_DIABATS) * 8)); c->attr_evb_solve = true; }
       hipLaunchKernelGGL(k_evb_solve, dim3(1), dim3(64), (size_t)(2 * D * D + 4 * D) * 8, ss, (const SolveDesc*)(w->d_desc.p + off_s), (const int*)(w->d_desc.p + off_si),
-                         (const double*)(w->d_desc.p + off_ss), w->d_E.p, c->d_energies.p + S_RECIP, w->d_coef.p, w->h_solve);
+                         (const double*)(w->d_desc.p + off_ss), w->d_E.p, linear ? w->d_Elq.p + 2 * MAX_DIABATS /* zero: the grid energies are differences already */ : c->d_energies.p + S_RECIP, w->d_coef.p, w->h_solve);
       HIPCHK(hipGetLastError());
       HIPCHK(hipEventRecord(w->ev_solve, ss));
       return MSEVB_OK;
@@ -1415,7 +1585,24 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   // ---- 6b. reciprocal space of the owned diabats (calculate_reciprocal_space_pme, :1962)
   phase_begin(c, PH_EVB_RECIP, sg);
   stamp(c, 5, sg);
-  if (ngrid) {
+  const int nst = 2 * nra;
+  GridRanges granges;
+  if (ngrid && linear) {
+    // stencil records of the special atoms (old and new state), their dots with theta_1 and their mutual interaction through G = IFFT(CB):
+    // energies relative to the principal diabat -> E_grid, forces on the special atoms -> the diabats' slots of the delta store
+    if (w->d_stencils.alloc_room((size_t)std::max(nst, 1))) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB stencils)");
+    { int g = 0; granges.start[0] = 0; for (int e = 0; e < nra; ++e) { while (g < ras[e].grid) granges.start[++g] = 2 * e; } while (g < ngrid) granges.start[++g] = nst; }
+    int max_ns = 0;
+    for (int g = 0; g < ngrid; ++g) max_ns = std::max(max_ns, granges.start[g + 1] - granges.start[g]);
+    hipLaunchKernelGGL(k_evb_stencils, dim3((nra + 63) / 64), dim3(64), 0, sg, nra, d_ra, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p, w->d_stencils.p);
+    hipLaunchKernelGGL(k_evb_recip_linear, dim3((nst + 3) / 4), dim3(256), 0, sg, nst, w->d_stencils.p, K, c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
+                       c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p);
+    hipLaunchKernelGGL(k_evb_recip_pairs, dim3((max_ns * max_ns + 3) / 4, ngrid), dim3(256), 0, sg, granges, w->d_stencils.p, K, c->d_green.p, c->conv, c->kk[0][0], c->kk[0][1],
+                       c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p + MAX_DIABATS);
+    hipLaunchKernelGGL(k_evb_grid_energy, dim3(1), dim3(128), 0, sg, ngrid, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid);
+    HIPCHK(hipGetLastError());
+    if (c->overlap) HIPCHK(hipEventRecord(w->ev_rs, sg));      // the special atoms' forces are in the delta store
+  } else if (ngrid) {
     hipLaunchKernelGGL(k_evb_grid_init, dim3(2048), dim3(256), 0, sg, K3, ngrid, c->d_Q.p, w->d_grids.p);
     hipLaunchKernelGGL(k_evb_patch, dim3((nra + 3) / 4), dim3(256), 0, sg, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, w->d_sbase.p, w->d_sw.p, w->d_grids.p);
     HIPCHK(hipGetLastError());
@@ -1430,7 +1617,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   phase_end(c, PH_EVB_RECIP, sg);
   stamp(c, 6, sg);
   CHK(fetch_A());
-  if (fast && ngrid) {      // own-stencil corrections of the special atoms -> delta store; behind the energy fetch on this stream: the host's turn does not wait for it
+  if (fast && ngrid && !linear) {      // own-stencil corrections of the special atoms -> delta store; behind the energy fetch on this stream: the host's turn does not wait for it
     hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, sg, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
                        w->d_sw.p, w->d_sdw.p, w->d_grids.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0],
                        c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3);
@@ -1494,7 +1681,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     if (!owned(c, d)) continue;
     double e = c->e_ref[c->h_mol_type[c->hydronium]] + eref_delta[d];
     for (int iu : units_of[d]) e += units[iu].sign * unitE(iu);
-    e += w->h_E[2 * nu + ncp + grid_of[d]] - E_recip1;
+    e += w->h_E[2 * nu + ncp + grid_of[d]] - (linear ? 0.0 : E_recip1);
     c->H[d][d] = e;
     c->H[c->parent[d]][d] = w->h_E[2 * nu + ncp + ngrid + 3 * cp_of[d] + 2];
     c->cpl_A[d] = w->h_E[2 * nu + ncp + ngrid + 3 * cp_of[d]];      // geometric factor A: the off-diagonal store holds dV, F_pd = -A dV
@@ -1604,7 +1791,7 @@ void evb_release(msevb_ctx* c) {
   if (w) {
     DBuf<double>* db[] = {&w->d_exch, &w->d_part, &w->d_E, &w->d_dVspec, &w->d_sw, &w->d_sdw, &w->d_Fdelta, &w->d_F11, &w->d_pack, &w->d_com_atom};
     for (auto b : db) b->release();
-    w->d_tabs.release(); w->d_sbase.release(); w->d_counter.release(); w->d_grids.release(); w->d_region.release(); w->d_cand.release(); w->d_desc.release();
+    w->d_stencils.release(); w->d_Elq.release(); w->d_tabs.release(); w->d_sbase.release(); w->d_counter.release(); w->d_grids.release(); w->d_region.release(); w->d_cand.release(); w->d_desc.release();
     hipEvent_t* ev[] = {&w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA, &w->ev_solve, &w->ev_rs};
     for (auto e : ev) if (*e) (void)hipEventDestroy(*e);
     if (w->h_region) (void)hipHostFree(w->h_region);

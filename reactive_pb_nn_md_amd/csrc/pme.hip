@@ -245,6 +245,10 @@ __global__ void k_copy_real(size_t K3, const double2* __restrict__ grid, double*
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K3; k += (size_t)gridDim.x * blockDim.x) Q[k] = grid[k].x;
 }
 
+__global__ void k_real_to_complex(size_t K3, const double* __restrict__ in, double2* __restrict__ out) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K3; k += (size_t)gridDim.x * blockDim.x) out[k] = make_double2(in[k], 0.0);
+}
+
 // real part of the convolved grid, contiguous (the gathers read 6 consecutive doubles per stencil row)
 __global__ void k_pme_real(size_t K3, const double2* __restrict__ grid, double* __restrict__ theta) {
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K3; k += (size_t)gridDim.x * blockDim.x) theta[k] = grid[k].x;
@@ -415,6 +419,22 @@ int pme_setup(msevb_ctx* c) {
     FFTCHK(rocfft_execution_info_set_work_buffer(c->fft_info, c->d_fft_work.p, wf));
   }
   FFTCHK(rocfft_execution_info_set_stream(c->fft_info, c->stream));
+  return pme_build_green(c);
+}
+
+// Real-space kernel of the reciprocal sum, G = IFFT(CB) (unnormalised backward transform, as theta = IFFT(CB FFT(Q)) is): theta = G * Q as a
+// periodic convolution.  The MS-EVB path evaluates the diabats' charge DIFFERENCES through it (evb.hip).  Rebuilt with the box (CB).
+int pme_build_green(msevb_ctx* c) {
+  const size_t K3 = (size_t)c->K * c->K * c->K;
+  if (!c->plan_bwd || !c->d_CB.p) return MSEVB_OK;
+  if (c->d_green.alloc(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (PME real-space kernel)");
+  hipLaunchKernelGGL(k_real_to_complex, dim3(1024), dim3(256), 0, c->stream, K3, c->d_CB.p, c->d_grid.p);
+  void* buf[1] = {c->d_grid.p};
+  FFTCHK(rocfft_execution_info_set_stream(c->fft_info, c->stream));
+  FFTCHK(rocfft_execute(c->plan_bwd, buf, nullptr, c->fft_info));
+  hipLaunchKernelGGL(k_copy_real, dim3(1024), dim3(256), 0, c->stream, K3, c->d_grid.p, c->d_green.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
   return MSEVB_OK;
 }
 

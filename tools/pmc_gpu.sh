@@ -11,5 +11,6 @@ for grp in "$@"; do
   n=$((n+1))
   timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace -d $OUT/g$n -o p -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline $BENCH_ARGS > $OUT/g$n.log 2>&1
 done
-python3 $R/tools/summarize_pmc.py $OUT > $OUT/summary.txt 2>&1 || true
+python3 $R/tools/summarize_pmc.py $OUT $PMC_ONLY > $OUT/summary.txt 2>&1 || true
+find $OUT -name "*.db" -delete || true      # gpurun merges at most 64 MiB back: keep the summary, drop the databases
 tail -60 $OUT/summary.txt

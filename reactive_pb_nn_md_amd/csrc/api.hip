@@ -674,6 +674,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
   if (s == "spread_mfma") { c->spread_mfma = v != 0.0; return MSEVB_OK; }
   if (s == "evb_device_solve") { c->evb_device_solve = v != 0.0; return MSEVB_OK; }
+  if (s == "pair_threads") { c->pair_threads = v == 512.0 ? 512 : 1024; return MSEVB_OK; }
   if (s == "evb_recip_linear") { c->evb_recip_linear = v != 0.0; return MSEVB_OK; }
   if (s == "ensemble_nvt") { c->nvt = v != 0.0; return MSEVB_OK; }
   if (s == "friction_coeff") { if (!(v > 0.0)) return MSEVB_ERR_ARG; c->friction = v; return MSEVB_OK; }

@@ -196,7 +196,8 @@ struct msevb_ctx {
   int tile_atoms_max = 0;        // largest 27-cell neighbourhood (atoms) the last build saw
   int half_tile_max = 0, half_tile_cap = 0;      // largest half neighbourhood the last build saw / tile size (atoms) the current half list was built for
   bool finalized = false;
-  bool attr_pair_half[4] = {false, false, false, false};      // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
+  bool attr_pair_half[8] = {false, false, false, false, false, false, false, false};
+  int pair_threads = 1024;       // workgroup size of the half-list pair kernel (option pair_threads: 512 leaves room on the CU for the side chains)      // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
 
   // ---- configuration
   int N = 0, M = 0, K = 0, order = 6, spline_grid = 100000, erfc_grid = 100000;

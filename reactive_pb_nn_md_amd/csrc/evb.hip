@@ -31,6 +31,8 @@
 namespace {
 
 constexpr int MAX_SPEC = (MAX_CHAIN + 1) * MAX_MOL_ATOMS;
+constexpr int CPL_BINS = 32;      // the workgroups of a coupling add their Zundel-force sums into one of 32 copies (blockIdx.x % 32): up to 1024 workgroups adding to ONE
+                                  // set of addresses serialised in the L2 (same-address atomics cost ~30 ns each: 30 us per launch); k_evb_coupling_finish sums the copies
 constexpr int REGION_CAP = 8192;
 constexpr int REGION_FAST = 2048;     // records fetched speculatively together with the count (one synchronisation)
 constexpr int MAX_UNITS = 2 * MAX_CHAIN * MAX_DIABATS + 1;
@@ -329,31 +331,35 @@ __global__ void k_evb_grid_init(size_t K3, int ng, const double* __restrict__ Q,
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K3 * ng; k += (size_t)gridDim.x * blockDim.x) grids[k] = make_double2(Q[k % K3], 0.0);
 }
 
-// stencil of one special atom in its NEW state (one thread per entry): same index arithmetic as k_pme_prep
+// stencil of one special atom in its NEW state: same index arithmetic as k_pme_prep, one thread per (entry, axis, tap) - a thread per entry
+// walked 54 dependent table reads (12 us for a hundred atoms).
+// xyz != nullptr: entries n .. 2n - 1 are the same atoms as the PRINCIPAL diabat has them (current positions) - the values k_pme_prep writes
+// for those atoms, recomputed here so that the linear-response path does not have to wait for the principal front end (outputs obase / ow / odw)
 __global__ void k_evb_spec_prep(int n, const RecipAtom* __restrict__ ra, int K, int G, double k00, double k01, double k02, double k10, double k11,
                                 double k12, double k20, double k21, double k22, const double* __restrict__ B6, const double* __restrict__ B5,
-                                int* __restrict__ sbase, double* __restrict__ sw, double* __restrict__ sdw, double* __restrict__ fault) {
+                                int* __restrict__ sbase, double* __restrict__ sw, double* __restrict__ sdw, double* __restrict__ fault, const double* __restrict__ xyz = nullptr,
+                                int* __restrict__ obase = nullptr, double* __restrict__ ow = nullptr, double* __restrict__ odw = nullptr) {
 #pragma clang fp contract(off)
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  const double x = ra[e].x_new[0], y = ra[e].x_new[1], z = ra[e].x_new[2];
-  const double kk[3][3] = {{k00, k01, k02}, {k10, k11, k12}, {k20, k21, k22}};
-  for (int l = 0; l < 3; ++l) {
-    double u = (double)K * ((kk[l][0] * x + kk[l][1] * y) + kk[l][2] * z);
-    if (u < 0.0) u = u + (double)K; else if (u >= (double)K) u = u - (double)K;
-    if (!(u >= 0.0 && u < (double)K)) { *fault = 1.0; u = 0.5; }      // see k_pme_prep
-    if (fabs(fmod(u, 1.0)) < 1e-6) u = u + 1e-6;
-    const int np = (int)floor(u);
-    sbase[3 * e + l] = np;
-    for (int k = 0; k < 6; ++k) {
-      const double a1 = u - (double)(np - k), a2 = a1 - 1.0;
-      sw[(3 * e + l) * 6 + k] = B6[(int)ceil(a1 / 6.0 * (double)G) - 1];
-      double d = 0.0;
-      if (a1 < 5.0) d = B5[(int)ceil(a1 / 5.0 * (double)G) - 1];
-      if (0.0 < a2) d = d - B5[(int)ceil(a2 / 5.0 * (double)G) - 1];
-      sdw[(3 * e + l) * 6 + k] = d;
-    }
-  }
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 18 * n * (xyz ? 2 : 1)) return;
+  const bool old_state = t >= 18 * n;
+  const int tt = old_state ? t - 18 * n : t;
+  const int e = tt / 18, r = tt - 18 * e, l = r / 6, k = r - 6 * l;
+  const double x = old_state ? xyz[3 * ra[e].idx] : ra[e].x_new[0], y = old_state ? xyz[3 * ra[e].idx + 1] : ra[e].x_new[1], z = old_state ? xyz[3 * ra[e].idx + 2] : ra[e].x_new[2];
+  const double ka = l == 0 ? k00 : l == 1 ? k10 : k20, kb = l == 0 ? k01 : l == 1 ? k11 : k21, kc = l == 0 ? k02 : l == 1 ? k12 : k22;
+  double u = (double)K * ((ka * x + kb * y) + kc * z);
+  if (u < 0.0) u = u + (double)K; else if (u >= (double)K) u = u - (double)K;
+  if (!(u >= 0.0 && u < (double)K)) { *fault = 1.0; u = 0.5; }      // see k_pme_prep
+  if (fabs(fmod(u, 1.0)) < 1e-6) u = u + 1e-6;
+  const int np = (int)floor(u);
+  int* ob = old_state ? obase : sbase; double* w_ = old_state ? ow : sw; double* dw_ = old_state ? odw : sdw;
+  if (k == 0) ob[3 * e + l] = np;
+  const double a1 = u - (double)(np - k), a2 = a1 - 1.0;
+  w_[(3 * e + l) * 6 + k] = B6[(int)ceil(a1 / 6.0 * (double)G) - 1];
+  double d = 0.0;
+  if (a1 < 5.0) d = B5[(int)ceil(a1 / 5.0 * (double)G) - 1];
+  if (0.0 < a2) d = d - B5[(int)ceil(a2 / 5.0 * (double)G) - 1];
+  dw_[(3 * e + l) * 6 + k] = d;
 }
 
 // one wavefront per entry: remove the atom's principal stencil, add its new stencil (modify_Q_grid, src/pme.f90:275)
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(256) void k_evb_coupling(int N, int n_cp, const Cou
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
   if (threadIdx.x == 0) part[(size_t)ic * part_stride + blockIdx.x] = red[0];
-  for (int k = threadIdx.x; k < cp.n_spec * 3; k += blockDim.x) { const double v = sF[k / 3][k % 3]; if (v != 0.0) atomicAdd(&dVspec[(size_t)ic * MAX_SPEC * 3 + k], v); }
+  for (int k = threadIdx.x; k < cp.n_spec * 3; k += blockDim.x) { const double v = sF[k / 3][k % 3]; if (v != 0.0) atomicAdd(&dVspec[((size_t)ic * CPL_BINS + (blockIdx.x % CPL_BINS)) * MAX_SPEC * 3 + k], v); }
 }
 
 // evb_diabatic_coupling_function (src/ms_evb.f90:1180-1266)
@@ -545,12 +551,28 @@ __global__ void k_evb_coupling_finish(int n_cp, const CouplingDesc* __restrict__
                                       BoxDev box, double conv, const double* __restrict__ Vex_env, double* __restrict__ dVspec,
                                       double* __restrict__ Foff, size_t fstride, double* __restrict__ out /*[n_cp][3]*/) {
   const int ic = blockIdx.x;
-  if (ic >= n_cp || threadIdx.x != 0) return;
-  const CouplingDesc& cp = cps[ic];
-  double vex = Vex_env[ic];
+  if (ic >= n_cp) return;
+  __shared__ CouplingDesc cp;      // staged once: the serial part below walks the descriptor with dependent reads (global memory: 34 us per launch)
+  {
+    const int* src = (const int*)&cps[ic]; int* dst = (int*)&cp;
+    for (int k = threadIdx.x; k < (int)(sizeof(CouplingDesc) / 4); k += blockDim.x) dst[k] = src[k];
+  }
   __shared__ double dV[MAX_SPEC][3];
   __shared__ bool inDA[MAX_SPEC];
-  for (int k = 0; k < cp.n_spec; ++k) for (int d = 0; d < 3; ++d) { dV[k][d] = dVspec[(size_t)ic * MAX_SPEC * 3 + 3 * k + d]; dVspec[(size_t)ic * MAX_SPEC * 3 + 3 * k + d] = 0.0; }
+  __syncthreads();
+  for (int k = threadIdx.x; k < cp.n_spec * 3; k += blockDim.x) {      // sum of the CPL_BINS copies the coupling kernels added into, which are left zeroed
+    double* p = dVspec + (size_t)ic * CPL_BINS * MAX_SPEC * 3 + k;
+    double v[CPL_BINS];
+#pragma unroll
+    for (int b = 0; b < CPL_BINS; ++b) { v[b] = p[(size_t)b * MAX_SPEC * 3]; p[(size_t)b * MAX_SPEC * 3] = 0.0; }
+    double sum = 0.0;
+#pragma unroll
+    for (int b = 0; b < CPL_BINS; ++b) sum += v[b];
+    (&dV[0][0])[k] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double vex = Vex_env[ic];
   for (int k = 0; k < cp.n_spec; ++k) inDA[k] = false;
   for (int k = 0; k < cp.nD; ++k) inDA[cp.D_at[k]] = true;
   for (int k = 0; k < cp.nA; ++k) inDA[cp.A_at[k]] = true;
@@ -634,7 +656,7 @@ struct Stencil { int base[3]; int grid, slot, idx; double q; double w[18], dw[18
 
 // two stencils per recip entry: 2 e = the atom as the principal diabat has it (charge -q_old), 2 e + 1 = its new state (charge +q_new).
 // Charges modify_Q_grid would skip (|q| <= 1e-6, src/pme.f90:296) and entries whose two states are identical get q = 0.
-__global__ void k_evb_stencils(int n, const RecipAtom* __restrict__ ra, const int* __restrict__ base, const double* __restrict__ w, const double* __restrict__ dw,
+__global__ void k_evb_stencils(int n, const RecipAtom* __restrict__ ra, const int* __restrict__ obase, const double* __restrict__ ow, const double* __restrict__ odw,
                                const int* __restrict__ sbase, const double* __restrict__ sw, const double* __restrict__ sdw, Stencil* __restrict__ st) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
@@ -642,9 +664,9 @@ __global__ void k_evb_stencils(int n, const RecipAtom* __restrict__ ra, const in
   Stencil a, b;
   a.grid = b.grid = r.grid; a.slot = b.slot = r.slot; a.idx = b.idx = r.idx;
   bool same = r.q_old == r.q_new;
-  for (int d = 0; d < 3; ++d) { a.base[d] = base[3 * r.idx + d]; b.base[d] = sbase[3 * e + d]; same = same && a.base[d] == b.base[d]; }
+  for (int d = 0; d < 3; ++d) { a.base[d] = obase[3 * e + d]; b.base[d] = sbase[3 * e + d]; same = same && a.base[d] == b.base[d]; }
   for (int k = 0; k < 18; ++k) {
-    a.w[k] = w[18 * (size_t)r.idx + k]; a.dw[k] = dw[18 * (size_t)r.idx + k]; b.w[k] = sw[18 * (size_t)e + k]; b.dw[k] = sdw[18 * (size_t)e + k];
+    a.w[k] = ow[18 * (size_t)e + k]; a.dw[k] = odw[18 * (size_t)e + k]; b.w[k] = sw[18 * (size_t)e + k]; b.dw[k] = sdw[18 * (size_t)e + k];
     same = same && a.w[k] == b.w[k];
   }
   a.q = (same || fabs(r.q_old) <= 1e-6) ? 0.0 : -r.q_old;
@@ -683,50 +705,80 @@ __global__ __launch_bounds__(256) void k_evb_recip_linear(int nst, const Stencil
   }
 }
 
-// one wavefront per ORDERED pair (T, S) of stencils of the same diabat: the potential S raises at T's taps, through the real-space kernel
-// G = IFFT(CB): energy q_T q_S sum W G (halved when the grids' energies are finished: every unordered pair appears twice, T = S once with
-// its own factor 1/2) and the force on T's atom.  blockIdx.y = diabat grid, pairs of that grid = blockIdx.x * 4 + wave.
+// One WORKGROUP per target stencil T (blockIdx.x) of a diabat (blockIdx.y); its four waves take the source stencils S of the same diabat in
+// turn: the potential S raises at T's taps through the real-space kernel G = IFFT(CB) -> energy q_T q_S sum W G (halved when the grids'
+// energies are finished: every unordered pair appears twice, T = S once with its own factor 1/2) and the force on T's atom, summed over S
+// in registers and added ONCE per target (one atomic set per pair serialised in the L2 on a handful of addresses: 40 us for 6 300 pairs).
 struct GridRanges { int start[MAX_DIABATS + 1]; };
 __global__ __launch_bounds__(256) void k_evb_recip_pairs(GridRanges gr, const Stencil* __restrict__ st, int K, const double* __restrict__ green, double conv, double k00,
                                                          double k01, double k02, double k10, double k11, double k12, double k20, double k21, double k22,
                                                          double* __restrict__ Fstore, size_t fstride, double* __restrict__ E_quad) {
   __shared__ double sW[4][3][2][11];      // per wave: [axis][W, dW][o + 5]
+  __shared__ double sT[36];               // T.w[18], T.dw[18]
+  __shared__ double sS[4][18];            // per wave: S.w[18]
+  __shared__ double red[4][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = blockIdx.y, s0 = gr.start[g], ns = gr.start[g + 1] - s0;
-  const int pr = blockIdx.x * 4 + wv;
-  if (pr >= ns * ns) return;
-  const Stencil& T = st[s0 + pr / ns];
-  const Stencil& S = st[s0 + pr % ns];
-  const double qq = T.q * S.q;
-  if (qq == 0.0) return;
-  if (lane < 33) {      // cross-correlations of the tap weights: W(o) = sum_{i - j = o} wT[i] wS[j], dW with T's derivative weights
-    const int ax = lane / 11, o = lane % 11 - 5;
-    double a = 0.0, b = 0.0;
-    for (int i = 0; i < 6; ++i) { const int j = i - o; if (j >= 0 && j < 6) { a += T.w[6 * ax + i] * S.w[6 * ax + j]; b += T.dw[6 * ax + i] * S.w[6 * ax + j]; } }
-    sW[wv][ax][0][o + 5] = a; sW[wv][ax][1][o + 5] = b;
-  }
-  __builtin_amdgcn_wave_barrier();
-  // tap i of T sits at b_T - i, tap j of S at b_S - j: separation (b_T - b_S) - (i - j)
-  int d1 = T.base[0] - S.base[0], d2 = T.base[1] - S.base[1], d3 = T.base[2] - S.base[2];
+  if ((int)blockIdx.x >= ns) return;
+  const Stencil& T = st[s0 + blockIdx.x];
+  const double qT = T.q;
+  if (qT == 0.0) return;      // (block-uniform)
+  if (threadIdx.x < 36) sT[threadIdx.x] = threadIdx.x < 18 ? T.w[threadIdx.x] : T.dw[threadIdx.x - 18];
+  __syncthreads();
   double en = 0, f1 = 0, f2 = 0, f3 = 0;
-  for (int p = lane; p < 1331; p += 64) {
-    const int o1 = p % 11, o2 = (p / 11) % 11, o3 = p / 121;
-    int n1 = (d1 - (o1 - 5)) % K; if (n1 < 0) n1 += K;
-    int n2 = (d2 - (o2 - 5)) % K; if (n2 < 0) n2 += K;
-    int n3 = (d3 - (o3 - 5)) % K; if (n3 < 0) n3 += K;
-    const double G = green[n1 + (size_t)K * (n2 + (size_t)K * n3)];
-    const double w1 = sW[wv][0][0][o1], w2 = sW[wv][1][0][o2], w3 = sW[wv][2][0][o3];
-    en += w1 * w2 * w3 * G;
-    f1 += sW[wv][0][1][o1] * w2 * w3 * G; f2 += w1 * sW[wv][1][1][o2] * w3 * G; f3 += w1 * w2 * sW[wv][2][1][o3] * G;
+  for (int is = wv; is < ns; is += 4) {
+    const Stencil& S = st[s0 + is];
+    const double qS = S.q;
+    if (qS == 0.0) continue;      // (wave-uniform)
+    if (lane < 18) sS[wv][lane] = S.w[lane];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 33) {      // cross-correlations of the tap weights: W(o) = sum_{i - j = o} wT[i] wS[j], dW with T's derivative weights
+      const int ax = lane / 11, o = lane % 11 - 5;
+      double a = 0.0, b = 0.0;
+      for (int i = 0; i < 6; ++i) { const int j = i - o; if (j >= 0 && j < 6) { const double ws = sS[wv][6 * ax + j]; a += sT[6 * ax + i] * ws; b += sT[18 + 6 * ax + i] * ws; } }
+      sW[wv][ax][0][o + 5] = a; sW[wv][ax][1][o + 5] = b;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // tap i of T sits at b_T - i, tap j of S at b_S - j: separation (b_T - b_S) - (i - j)
+    const int d1 = T.base[0] - S.base[0], d2 = T.base[1] - S.base[1], d3 = T.base[2] - S.base[2];
+    // offsets (o1, o2) on the lanes (121 = 64 + 57: two chunks), o3 in the loop: the lane-dependent index arithmetic is done once per chunk,
+    // the plane offset is wave-uniform, and the 11 table reads of a chunk are independent (issued together)
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const int idx = lane + 64 * ch;
+      const bool live = idx < 121;
+      const int o1 = live ? idx % 11 : 0, o2 = live ? idx / 11 : 0;
+      int n1 = d1 - (o1 - 5); n1 += n1 < 0 ? K : 0; n1 -= n1 >= K ? K : 0;      // |d| < K, |o| <= 5 < K: one wrap either way (no integer division)
+      int n2 = d2 - (o2 - 5); n2 += n2 < 0 ? K : 0; n2 -= n2 >= K ? K : 0;
+      const double* row = green + n1 + (size_t)K * n2;
+      const double w1 = sW[wv][0][0][o1], w2 = sW[wv][1][0][o2];
+      const double cc = live ? qS * w1 * w2 : 0.0, ca = live ? qS * sW[wv][0][1][o1] * w2 : 0.0, cb = live ? qS * w1 * sW[wv][1][1][o2] : 0.0;
+      double Gv[11];
+#pragma unroll
+      for (int o3 = 0; o3 < 11; ++o3) {
+        int n3 = d3 - (o3 - 5); n3 += n3 < 0 ? K : 0; n3 -= n3 >= K ? K : 0;
+        Gv[o3] = row[(size_t)K * K * n3];
+      }
+#pragma unroll
+      for (int o3 = 0; o3 < 11; ++o3) {
+        const double g3 = Gv[o3] * sW[wv][2][0][o3], gd = Gv[o3] * sW[wv][2][1][o3];
+        en += cc * g3; f1 += ca * g3; f2 += cb * g3; f3 += cc * gd;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();      // sW / sS are rewritten by the next source stencil
   }
   for (int o = 32; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); f3 += __shfl_xor(f3, o, 64); en += __shfl_xor(en, o, 64); }
-  if (lane == 0) {
-    const double s = qq * conv, Kd = (double)K;
+  if (lane == 0) { red[wv][0] = en; red[wv][1] = f1; red[wv][2] = f2; red[wv][3] = f3; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    en = red[0][0] + red[1][0] + red[2][0] + red[3][0]; f1 = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    f2 = red[0][2] + red[1][2] + red[2][2] + red[3][2]; f3 = red[0][3] + red[1][3] + red[2][3] + red[3][3];
+    const double s = qT * conv, Kd = (double)K;
     double* F = Fstore + (size_t)T.slot * fstride;
     atomicAdd(&F[3 * T.idx], -Kd * (k00 * f1 + k10 * f2 + k20 * f3) * s);
     atomicAdd(&F[3 * T.idx + 1], -Kd * (k01 * f1 + k11 * f2 + k21 * f3) * s);
     atomicAdd(&F[3 * T.idx + 2], -Kd * (k02 * f1 + k12 * f2 + k22 * f3) * s);
-    atomicAdd(&E_quad[g], qq * en);
+    atomicAdd(&E_quad[g], qT * en);
   }
 }
 
@@ -933,9 +985,9 @@ struct EvbWork {   // persistent device scratch of one context
   DBuf<double> d_part, d_E, d_dVspec; DBuf<int> d_sbase, d_counter; DBuf<double> d_sw, d_sdw;
   DBuf<double2> d_grids; DBuf<RegionRec> d_region; DBuf<int> d_cand;
   DBuf<double> d_Fdelta;      // [n_diag][3N] real-space deltas of the diabats, accumulated on stream2 beside the reciprocal space
-  hipEvent_t ev_rs = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_E = nullptr, ev_fetch = nullptr, ev_cpl = nullptr, ev_flush = nullptr, ev_fetchA = nullptr; bool delta_dirty = true;
+  hipEvent_t ev_pairs = nullptr, ev_rs = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_E = nullptr, ev_fetch = nullptr, ev_cpl = nullptr, ev_flush = nullptr, ev_fetchA = nullptr; bool delta_dirty = true;
   DBuf<double> d_F11, d_pack, d_com_atom;
-  DBuf<Stencil> d_stencils; DBuf<double> d_Elq;      // linear-response reciprocal path: stencil records, {E_lin[MAX_DIABATS], E_quad[MAX_DIABATS], 0}
+  DBuf<Stencil> d_stencils; DBuf<double> d_Elq, d_ow, d_odw; DBuf<int> d_obase;      // linear-response reciprocal path: stencil records, {E_lin[MAX_DIABATS], E_quad[MAX_DIABATS], 0}
   int last_nst = 0; bool last_linear = false, elq_zeroed = false;
   hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
   RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
@@ -1387,7 +1439,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   const int n_rows = nu + ncp + ngrid + 8;
   if (c->d_Fdiag.alloc_room((size_t)n_diag * n3) || c->d_Foff.alloc_room((size_t)std::max(n_off, 1) * n3) || 
       w->d_tabs.alloc(1) || w->d_exch.alloc(MAX_TYPES) || w->d_part.alloc_room((size_t)n_rows * part_stride) ||
-      w->d_E.alloc_room(2 * n_rows + 3 * std::max(ncp, 1) + 8) || w->d_dVspec.alloc((size_t)MAX_DIABATS * MAX_SPEC * 3) ||
+      w->d_E.alloc_room(2 * n_rows + 3 * std::max(ncp, 1) + 8) || w->d_dVspec.alloc((size_t)MAX_DIABATS * CPL_BINS * MAX_SPEC * 3) ||
       w->d_sbase.alloc_room(3 * std::max(nra, 1)) || w->d_sw.alloc_room(18 * (size_t)std::max(nra, 1)) || w->d_sdw.alloc_room(18 * (size_t)std::max(nra, 1)) ||
       w->d_grids.alloc_room(K3 * std::max(ngrid, 1)) || w->d_pack.alloc_room(K3 * std::max(ngrid, 1)) || w->d_F11.alloc(n3) || w->d_com_atom.alloc(n3))
     FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB work buffers)");
@@ -1467,8 +1519,20 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   if (w->dv_dirty) { HIPCHK(hipMemsetAsync(w->d_dVspec.p, 0, w->d_dVspec.n * 8, ss)); w->dv_dirty = false; }   // afterwards k_evb_coupling_finish leaves it zeroed
   // B-spline stencils of the special atoms in their new states (needs descriptors only)
   stamp(c, 3, ss);
-  if (ngrid) hipLaunchKernelGGL(k_evb_spec_prep, dim3((nra + 63) / 64), dim3(64), 0, ss, nra, d_ra, K, c->spline_grid, c->kk[0][0], c->kk[0][1], c->kk[0][2],
-                                c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p, c->d_energies.p + S_FAULT);
+  const bool linear = !c->evb_element_stores && c->evb_recip_linear && c->d_green.p;      // no transform per diabat: linear response of theta to the charge differences (E_grid holds energy DIFFERENCES)
+  if (ngrid) {
+    if (linear && (w->d_obase.alloc_room(3 * (size_t)nra) || w->d_ow.alloc_room(18 * (size_t)nra) || w->d_odw.alloc_room(18 * (size_t)nra))) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB stencils)");
+    const int nthr = 18 * nra * (linear ? 2 : 1);
+    hipLaunchKernelGGL(k_evb_spec_prep, dim3((nthr + 255) / 256), dim3(256), 0, ss, nra, d_ra, K, c->spline_grid, c->kk[0][0], c->kk[0][1], c->kk[0][2],
+                       c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p, c->d_energies.p + S_FAULT,
+                       linear ? (const double*)c->d_xyz.p : (const double*)nullptr, w->d_obase.p, w->d_ow.p, w->d_odw.p);
+  }
+  if (linear) {
+    if (w->d_Elq.alloc(2 * MAX_DIABATS + 1) || w->d_stencils.alloc_room((size_t)std::max(2 * nra, 1))) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB stencils)");
+    if (!w->elq_zeroed) { HIPCHK(hipMemsetAsync(w->d_Elq.p, 0, (2 * MAX_DIABATS + 1) * 8, ss)); w->elq_zeroed = true; }      // k_evb_grid_energy re-zeroes it every step
+    if (!w->ev_pairs) HIPCHK(hipEventCreateWithFlags(&w->ev_pairs, hipEventDisableTiming));
+  }
+  w->last_linear = linear; w->last_nst = 2 * nra;
   if (c->overlap) {      // descriptors + special stencils are on the device: the main stream and the off-diagonal chain may use them
     HIPCHK(hipEventRecord(w->ev_fork2, ss));
     HIPCHK(hipStreamWaitEvent(c->stream, w->ev_fork2, 0));
@@ -1500,6 +1564,21 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   HIPCHK(hipGetLastError());
   phase_end(c, PH_EVB_REAL, sr);
   stamp(c, 4, sr);
+  if (linear) {      // behind the real-space deltas on the descriptor stream: done long before the principal convolution, whose tail (k_evb_recip_linear) waits for it
+    if (ngrid) {      // stencil records of the special atoms (old and new state) and their mutual interaction through G = IFFT(CB)
+      const int nst = 2 * nra;
+      GridRanges granges;
+      { int g = 0; granges.start[0] = 0; for (int e = 0; e < nra; ++e) { while (g < ras[e].grid) granges.start[++g] = 2 * e; } while (g < ngrid) granges.start[++g] = nst; }
+      int max_ns = 0;
+      for (int g = 0; g < ngrid; ++g) max_ns = std::max(max_ns, granges.start[g + 1] - granges.start[g]);
+      if (ht_on && g_ht.n == 3) fprintf(stderr, "[msevb] recip entries %d, grids %d, most stencils per grid %d\n", nra, ngrid, max_ns);
+      hipLaunchKernelGGL(k_evb_stencils, dim3((nra + 63) / 64), dim3(64), 0, ss, nra, d_ra, w->d_obase.p, w->d_ow.p, w->d_odw.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p, w->d_stencils.p);
+      hipLaunchKernelGGL(k_evb_recip_pairs, dim3(max_ns, ngrid), dim3(256), 0, ss, granges, w->d_stencils.p, K, c->d_green.p, c->conv, c->kk[0][0], c->kk[0][1],
+                         c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p + MAX_DIABATS);
+      HIPCHK(hipGetLastError());
+    }
+    if (c->overlap) HIPCHK(hipEventRecord(w->ev_pairs, ss));
+  }
   if (c->overlap) HIPCHK(hipEventRecord(w->ev_join2, w->stream2));
   // ---- 6a'. off-diagonal elements (evb_diabatic_coupling, :1021): few, latency-bound kernels writing only d_Foff; on aux2 behind the
   //           diagonal deltas (the all-atom gather waits for those, only the blend for these)
@@ -1509,7 +1588,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     if (c->overlap) HIPCHK(hipStreamWaitEvent(so, w->ev_fork2, 0));
     hipLaunchKernelGGL(k_mol_com, dim3((M + 255) / 256), dim3(256), 0, so, M, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_mass.p, w->d_com_atom.p);
     // ~1000 workgroups per launch in all: every block pays a descriptor copy, two barriers and the Zundel reductions
-    const int cpb_big = std::min(cpb, std::max(64, 1024 / std::max(ncp_big, 1))), cpb_small = std::min(cpb, std::max(64, 1024 / std::max(ncp - ncp_big, 1)));
+    const int cpb_big = cpb, cpb_small = std::min(cpb, std::max(256, 6144 / std::max(ncp - ncp_big, 1)));      // few trips per wave: the kernels are latency-bound
     if (ncp_big) hipLaunchKernelGGL(k_evb_coupling<16>, dim3(cpb_big, ncp_big), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, w->d_com_atom.p, c->d_xyz.p, c->d_chg.p,
                                     w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p, 0);
     if (ncp > ncp_big) hipLaunchKernelGGL(k_evb_coupling<8>, dim3(cpb_small, ncp - ncp_big), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, w->d_com_atom.p, c->d_xyz.p, c->d_chg.p,
@@ -1531,12 +1610,6 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipHostMalloc((void**)&w->h_E, w->hE_cap * sizeof(double), hipHostMallocDefault));
   }
   const hipStream_t sg = c->overlap ? c->aux : c->stream;      // diabat grids: `aux` is free once the principal convolution is done
-  const bool linear = fast && c->evb_recip_linear && c->d_green.p;      // no transform per diabat: linear response of theta to the charge differences (E_grid holds energy DIFFERENCES)
-  if (linear) {
-    if (w->d_Elq.alloc(2 * MAX_DIABATS + 1)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB grid energies)");
-    if (!w->elq_zeroed) { HIPCHK(hipMemsetAsync(w->d_Elq.p, 0, (2 * MAX_DIABATS + 1) * 8, ss)); w->elq_zeroed = true; }      // (ss: ahead of every stream that forks from it)
-  }
-  w->last_linear = linear; w->last_nst = 2 * nra;
   // The ground-state VECTOR does not depend on the principal diabat's energy E0: it sits on the whole diagonal (H = H' + E0 I).  So the
   // host diagonalises H' from the energies that exist long before the pair loop ends (unit, coupling and grid energies, fetch A) and
   // the blend kernels queue up directly behind the pair loop; E0 (fetch B: the principal energy slots, complete only after the pair
@@ -1586,19 +1659,14 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   phase_begin(c, PH_EVB_RECIP, sg);
   stamp(c, 5, sg);
   const int nst = 2 * nra;
-  GridRanges granges;
   if (ngrid && linear) {
     // stencil records of the special atoms (old and new state), their dots with theta_1 and their mutual interaction through G = IFFT(CB):
     // energies relative to the principal diabat -> E_grid, forces on the special atoms -> the diabats' slots of the delta store
-    if (w->d_stencils.alloc_room((size_t)std::max(nst, 1))) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB stencils)");
-    { int g = 0; granges.start[0] = 0; for (int e = 0; e < nra; ++e) { while (g < ras[e].grid) granges.start[++g] = 2 * e; } while (g < ngrid) granges.start[++g] = nst; }
-    int max_ns = 0;
-    for (int g = 0; g < ngrid; ++g) max_ns = std::max(max_ns, granges.start[g + 1] - granges.start[g]);
-    hipLaunchKernelGGL(k_evb_stencils, dim3((nra + 63) / 64), dim3(64), 0, sg, nra, d_ra, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p, w->d_stencils.p);
+    // (the stencil records and the stencil-pair sums need no potential: they went out on the descriptor stream right behind the special
+    //  atoms' stencils, step 5; here, behind the principal convolution, only the dots with theta_1 are left)
+    if (c->overlap) HIPCHK(hipStreamWaitEvent(sg, w->ev_pairs, 0));
     hipLaunchKernelGGL(k_evb_recip_linear, dim3((nst + 3) / 4), dim3(256), 0, sg, nst, w->d_stencils.p, K, c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
                        c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p);
-    hipLaunchKernelGGL(k_evb_recip_pairs, dim3((max_ns * max_ns + 3) / 4, ngrid), dim3(256), 0, sg, granges, w->d_stencils.p, K, c->d_green.p, c->conv, c->kk[0][0], c->kk[0][1],
-                       c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p + MAX_DIABATS);
     hipLaunchKernelGGL(k_evb_grid_energy, dim3(1), dim3(128), 0, sg, ngrid, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid);
     HIPCHK(hipGetLastError());
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_rs, sg));      // the special atoms' forces are in the delta store
@@ -1791,8 +1859,8 @@ void evb_release(msevb_ctx* c) {
   if (w) {
     DBuf<double>* db[] = {&w->d_exch, &w->d_part, &w->d_E, &w->d_dVspec, &w->d_sw, &w->d_sdw, &w->d_Fdelta, &w->d_F11, &w->d_pack, &w->d_com_atom};
     for (auto b : db) b->release();
-    w->d_stencils.release(); w->d_Elq.release(); w->d_tabs.release(); w->d_sbase.release(); w->d_counter.release(); w->d_grids.release(); w->d_region.release(); w->d_cand.release(); w->d_desc.release();
-    hipEvent_t* ev[] = {&w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA, &w->ev_solve, &w->ev_rs};
+    w->d_stencils.release(); w->d_Elq.release(); w->d_ow.release(); w->d_odw.release(); w->d_obase.release(); w->d_tabs.release(); w->d_sbase.release(); w->d_counter.release(); w->d_grids.release(); w->d_region.release(); w->d_cand.release(); w->d_desc.release();
+    hipEvent_t* ev[] = {&w->ev_pairs, &w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA, &w->ev_solve, &w->ev_rs};
     for (auto e : ev) if (*e) (void)hipEventDestroy(*e);
     if (w->h_region) (void)hipHostFree(w->h_region);
     if (w->h_count) (void)hipHostFree(w->h_count);

@@ -387,14 +387,16 @@ int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw) {
     // the SAPT instantiation needs > 128 VGPRs: 512 threads (8 waves) per cell instead of 1024
     void (*kern)(int, int, int3, int, const int*, const double4*, const int*, const unsigned*, const unsigned*, const int*, const PairParam*, int, const double2*, double, int,
                  const double*, const double*, BoxDev, double, double*, double*, double*, int*, int*, unsigned*, double4*, double, int) =
-        c->has_sapt ? (pr ? k_pair_half<true, true, 512> : k_pair_half<true, false, 512>) : (pr ? k_pair_half<false, true, 1024> : k_pair_half<false, false, 1024>);
-    const int which = (c->has_sapt ? 2 : 0) + (pr ? 1 : 0);
+        c->has_sapt ? (pr ? k_pair_half<true, true, 512> : k_pair_half<true, false, 512>)
+                    : (c->pair_threads == 512 ? (pr ? k_pair_half<false, true, 512> : k_pair_half<false, false, 512>) : (pr ? k_pair_half<false, true, 1024> : k_pair_half<false, false, 1024>));
+    const int nthr = (c->has_sapt || c->pair_threads == 512) ? 512 : 1024;
+    const int which = (c->has_sapt ? 2 : 0) + (pr ? 1 : 0) + (nthr == 512 && !c->has_sapt ? 4 : 0);
     if (!c->attr_pair_half[which]) {
       HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_TILE_LDS_BYTES));
       c->attr_pair_half[which] = true;
     }
     const double rp = c->rc + c->prune_delta;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(c->has_sapt ? 512 : 1024), lds, c->stream, c_lo, c_hi, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), c->half_tile_cap,
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nthr), lds, c->stream, c_lo, c_hi, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), c->half_tile_cap,
                        c->d_cell_start.p, c->d_posq.p, c->d_type_sorted.p, c->d_nbr_start.p, c->d_nbr_count.p, c->d_nbr.p, c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx,
                        c->erfc_grid, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->d_fsorted.p, c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS,
                        c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS, c->d_prune_mode.p, c->d_nbr2.p, c->d_nbr2_count.p, c->d_posq_prune.p, rp * rp, N);

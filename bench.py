@@ -97,6 +97,48 @@ def cpu_baseline(spec, steps_per_rebuild):
             "principal_only_steps_per_s": 1.0 / best[1]}
 
 
+def thermalised_line(args, device):
+    """Second measurement on a thermalised box (rank 0, N = 1 only): the same composition built with liquid_like=True (rigid molecules at the
+    force field's equilibrium geometry, random orientations) and relaxed on the GPU, outside the timed region, by 8 blocks of 20 NVE steps
+    with a velocity rescale to 300 K in between (tools/make_thermal_start.py measured this protocol: T 315-360 K afterwards, the planted
+    8-diabat tree lives ~230 more steps, Verlet rebuilds at a liquid's pace); then the warm-up and min(steps, 200) timed steps."""
+    KB = 0.0083144626
+    s = synth.make_system(args.n_side, n_diabat=args.diabats, seed=0, max_chain=3 if args.diabats <= 8 else 4, liquid_like=True)
+    p = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"])
+    spec = system.from_synth(s, p, rc=9.0, rv=10.5, alpha=0.3, pme_grid=args.pme_grid, max_chain=3 if args.diabats <= 8 else 4)
+    h = api.MsEvbHip(spec, device=device)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        h.set_option(k, float(v))
+    h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 12345))
+    h.ms_evb_calculate_total_force_energy(want_force=False)
+    ndf = 3 * spec.n_atom - 3
+    for _b in range(8):
+        en = h.md_integrate_atomic(20, spec.delta_t, use_evb=True)
+        T = 2 * en[-1, 1] / (ndf * KB)
+        h.set_velocities(h.get_velocities() * np.sqrt(300.0 / max(T, 1.0)))
+    h.ms_evb_calculate_total_force_energy(want_force=False)
+    if args.warmup > 0:
+        h.md_integrate_atomic(args.warmup, spec.delta_t, use_evb=True)
+    h.set_option("phase_timing", 1.0)      # counts the list rebuilds
+    h.L.msevb_reset_phase_times(h.ctx)
+    D0 = int(h.evb_state()["D"])
+    steps = min(args.steps, 200)
+    h.synchronize()
+    t0 = time.perf_counter()
+    en = h.md_integrate_atomic(steps, spec.delta_t, use_evb=True)
+    h.synchronize()
+    dt = time.perf_counter() - t0
+    reb = int(h.phase_times().get("verlet list construction", (0, 0))[1])
+    out = {"value": round(steps / dt, 3), "unit": "steps/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+           "workload": "same composition (%d atoms, %d^3 grid), liquid_like start relaxed by 8 x 20 steps with velocity rescaling to 300 K before the warm-up" % (spec.n_atom, spec.pme_grid),
+           "n_diabats_start_end": [D0, int(h.evb_state()["D"])], "verlet_rebuilds": reb,
+           "temperature_first_last_K": [round(2 * en[0, 1] / (ndf * KB), 1), round(2 * en[-1, 1] / (ndf * KB), 1)],
+           "energy_first_last": [float(en[0].sum()), float(en[-1].sum())]}
+    h.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +149,7 @@ def main():
     ap.add_argument("--pme-grid", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-evb", action="store_true")
+    ap.add_argument("--no-thermal", action="store_true", help="skip the second (thermalised box) measurement")
     ap.add_argument("--no-phase-timing", action="store_true", help="skip the per-phase HIP events (roofline block becomes null)")
     ap.add_argument("--rccl-single", action="store_true", help="diagnostic: N=1 with a one-rank RCCL communicator (cost of the two collectives per step)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (msevb_set_option), e.g. pair_tiles=0")
@@ -259,7 +302,7 @@ def main():
             "metric": "MD timesteps/sec", "value": round(args.steps / dt, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "CH3SO3H/H2O box %d atoms, %d diabats, %d^3 PME grid, r_c 9.0 / r_v 10.5 A, dt 0.5 fs, NVE, %s force call"
+            "config": {"workload": "BASELINE.json configs[2] as SURVEY 8d prescribes it (jittered lattice, hot): CH3SO3H/H2O box %d atoms, %d diabats, %d^3 PME grid, r_c 9.0 / r_v 10.5 A, dt 0.5 fs, NVE, %s force call"
                                    % (spec.n_atom, D, spec.pme_grid, "MS-EVB" if use_evb else "non-EVB"),
                        "n_atoms": spec.n_atom, "n_diabats": D, "n_diabats_at_end": D_end, "restarts_from_initial_state_in_timed_region": state["resets"], "pme_grid": spec.pme_grid, "parallelism": "diabats sharded over %d GPU(s)" % world},
             "roofline": roofline,
@@ -274,6 +317,8 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     h.close()
+    if rank == 0 and world == 1 and use_evb and not args.no_thermal and args.n_side >= 16:
+        out["thermalised_box"] = thermalised_line(args, local_rank)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -145,6 +145,10 @@ int msevb_get_evb_state(msevb_ctx* ctx, int* n_diabat, int* proton_log, int* cou
 /* stored force of Hamiltonian element (i,j), 1-based, i<=j (evb_forces_store(:,:,evb_forces_lookup_index(i,j)),
    src/ms_evb.f90:2523), principal atom order */
 int msevb_get_evb_element_force(msevb_ctx* ctx, int i, int j, double* force);
+/* principal-diabat switches (proton hops) since the log was last cleared: log(3, n_hops) = {number of the EVB force call in which the hop
+   happened (1-based over the context's life; *evb_calls = the current count), old hydronium molecule, new hydronium molecule}.  The reference
+   writes each hop with its own step (src/ms_evb.f90:331-335); a caller that integrates blocks of steps on the device reads them here. */
+int msevb_get_hop_log(msevb_ctx* ctx, int* n_hops, int* log /*(3,capacity) or NULL*/, int capacity, long* evb_calls /*or NULL*/, int clear);
 /* current topology (changes when the principal diabat changes, src/ms_evb.f90:218-227) */
 int msevb_get_topology(msevb_ctx* ctx, int* atom_type_index, double* charge, int* mol_n_atom, int* mol_type_index,
                        int* mol_atom_index /*(8,n_mole) 1-based, 0 padded*/, int* hydronium_molecule);
@@ -160,6 +164,12 @@ int msevb_calculate_kinetic_energy(msevb_ctx* ctx, double* kinetic_energy);   /*
 int msevb_comm_unique_id(void* id_bytes_128);                                       /* ncclGetUniqueId */
 int msevb_comm_init(msevb_ctx* ctx, const void* id_bytes_128, int rank, int n_ranks); /* ncclCommInitRank (RCCL) */
 int msevb_comm_set_virtual(msevb_ctx* ctx, int rank, int n_ranks);   /* shard without a communicator (tests) */
+/* payload of the per-step all-gather as context-free functions (no GPU): P = msevb_evb_payload_size doubles per rank = {H_dd, H_pd} of the
+   rank's diabats, H'_11, eight principal energy slots; hamiltonian is D x D row-major (upper triangle), parent[d] 0-based.  Used by the
+   library's own RCCL exchange and by the CPU (gloo) test of the protocol */
+int msevb_evb_payload_size(int n_diabat, int n_ranks);
+int msevb_evb_payload_pack(int n_diabat, int n_ranks, int rank, const double* hamiltonian, const int* parent, const double* energies8 /*or NULL*/, double* out);
+int msevb_evb_payload_unpack(int n_diabat, int n_ranks, const double* all_payloads, const int* parent, double* hamiltonian, double* energies8 /*or NULL*/);
 int msevb_comm_allreduce_energies(msevb_ctx* ctx); /* principal energy slots when the principal real space is sharded (internal) */
 int msevb_comm_allreduce_forces(msevb_ctx* ctx);   /* sum of the ranks' partial Hellmann-Feynman forces (called by the EVB force call itself) */
 int msevb_evb_partial_blend(msevb_ctx* ctx, const double* eigvec, double* force);   /* this rank's share of the blend for a given eigenvector (src/ms_evb.f90:293-309; tests of the sharding) */

@@ -312,6 +312,14 @@ class MsEvbHip:
         self._chk(self.L.msevb_evb_partial_blend(self.ctx, _dp(ev), _dp(f)))
         return f
 
+    def hop_log(self, clear=True):
+        """principal-diabat switches since the last clearing call: (array of {EVB force call number, old, new hydronium molecule}, calls so far)"""
+        n, calls = C.c_int(), C.c_long()
+        self._chk(self.L.msevb_get_hop_log(self.ctx, C.byref(n), None, 0, C.byref(calls), 0))
+        log = np.zeros((max(n.value, 1), 3), dtype=np.int32)
+        self._chk(self.L.msevb_get_hop_log(self.ctx, C.byref(n), _ip(log), max(n.value, 1), C.byref(calls), 1 if clear else 0))
+        return log[:n.value], calls.value
+
     def topology(self):
         at, ch = np.zeros(self.N, dtype=np.int32), np.zeros(self.N)
         mn, mt, ma = np.zeros(self.M, dtype=np.int32), np.zeros(self.M, dtype=np.int32), np.zeros((self.M, 8), dtype=np.int32)

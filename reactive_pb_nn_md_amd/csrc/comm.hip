@@ -35,23 +35,47 @@ int msevb_comm_init(msevb_ctx* c, const void* id128, int rank, int n_ranks) {
 // diabat is sharded, replicated slots zeroed on ranks != 0 by the caller).  Every rank then holds the same bytes, assembles the same
 // Hamiltonian and sums the energy slots in rank order: identical eigenvectors and identical topology decisions on all ranks.
 // The force stores stay where they were computed: every rank blends ITS diabats and the partial forces are summed (msevb_comm_allreduce_forces).
+// The payload of that all-gather, as plain functions (no context, no GPU): what a rank contributes and how the gathered bytes turn back
+// into the Hamiltonian.  msevb_comm_allgather_evb uses them; tests/test_sharding_gloo.py drives them over a gloo all-gather on the CPU.
+// Layout per rank, P = 2 S + 1 + 8 doubles with S = ceil((D - 1) / R): {H_dd, H_pd} of its diabats d = 1 + rank + R s (0-based d, slot s),
+// the principal H'_11 as the rank has it, its eight principal energy slots.  hamiltonian: D x D row-major, upper triangle.
+int msevb_evb_payload_size(int n_diabat, int n_ranks) { return n_diabat <= 1 ? 9 : 2 * ((n_diabat - 1 + n_ranks - 1) / n_ranks) + 9; }
+int msevb_evb_payload_pack(int n_diabat, int n_ranks, int rank, const double* hamiltonian, const int* parent, const double* energies8, double* out) {
+  if (n_diabat < 1 || n_ranks < 1 || rank < 0 || rank >= n_ranks || !hamiltonian || !parent || !out) return MSEVB_ERR_ARG;
+  const int D = n_diabat, R = n_ranks, P = msevb_evb_payload_size(D, R), S = (P - 9) / 2;
+  for (int k = 0; k < P; ++k) out[k] = 0.0;
+  for (int d = 1; d < D; ++d) if ((d - 1) % R == rank) { const int s = (d - 1) / R; out[2 * s] = hamiltonian[(size_t)d * D + d]; out[2 * s + 1] = hamiltonian[(size_t)parent[d] * D + d]; }
+  out[2 * S] = hamiltonian[0];
+  if (energies8) for (int k = 0; k < 8; ++k) out[2 * S + 1 + k] = energies8[k];
+  return MSEVB_OK;
+}
+// all: the R payloads in rank order.  Fills the entries of every diabat, H'_11 from rank 0, and (energies8 != NULL) the rank-ordered sums
+// of the energy slots - the same bytes, the same order of additions on every rank: identical eigenvectors and topology decisions everywhere.
+int msevb_evb_payload_unpack(int n_diabat, int n_ranks, const double* all, const int* parent, double* hamiltonian, double* energies8) {
+  if (n_diabat < 1 || n_ranks < 1 || !all || !parent || !hamiltonian) return MSEVB_ERR_ARG;
+  const int D = n_diabat, R = n_ranks, P = msevb_evb_payload_size(D, R), S = (P - 9) / 2;
+  for (int d = 1; d < D; ++d) { const int r = (d - 1) % R, s = (d - 1) / R; hamiltonian[(size_t)d * D + d] = all[(size_t)r * P + 2 * s]; hamiltonian[(size_t)parent[d] * D + d] = all[(size_t)r * P + 2 * s + 1]; }
+  hamiltonian[0] = all[2 * S];
+  if (energies8) for (int k = 0; k < 8; ++k) { double e = 0.0; for (int r = 0; r < R; ++r) e += all[(size_t)r * P + 2 * S + 1 + k]; energies8[k] = e; }
+  return MSEVB_OK;
+}
+
 int msevb_comm_allgather_evb(msevb_ctx* c, int with_energies) {
-  const int D = c->D, S = slots_per_rank(c, D), R = c->n_ranks, P = 2 * S + 1 + 8;
+  const int D = c->D, R = c->n_ranks, P = msevb_evb_payload_size(D, R);
   ncclComm_t comm = (ncclComm_t)c->nccl_comm;
   DBuf<double>& d_h = c->d_comm_h;
   if (d_h.alloc((size_t)R * P)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (comm)");
-  std::vector<double> h((size_t)R * P, 0.0);
+  std::vector<double> h((size_t)R * P, 0.0), Hm((size_t)D * D, 0.0);
+  for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) Hm[(size_t)i * D + j] = c->H[i][j];
   double* mine = h.data() + (size_t)c->rank * P;
-  for (int d = 1; d < D; ++d) if ((d - 1) % R == c->rank) { const int s = (d - 1) / R; mine[2 * s] = c->H[d][d]; mine[2 * s + 1] = c->H[c->parent[d]][d]; }
-  mine[2 * S] = c->H[0][0];
-  if (with_energies) for (int k = 0; k < 8; ++k) mine[2 * S + 1 + k] = c->h_energies[S_ELEC_PAIR + k];      // S_ELEC_PAIR .. S_RECIP are contiguous
+  if (msevb_evb_payload_pack(D, R, c->rank, Hm.data(), c->parent, with_energies ? c->h_energies + S_ELEC_PAIR : nullptr, mine) != MSEVB_OK) FAIL(MSEVB_ERR_ARG, "EVB payload");      // S_ELEC_PAIR .. S_RECIP are contiguous
   HIPCHK(hipMemcpyAsync(d_h.p + (size_t)c->rank * P, mine, (size_t)P * 8, hipMemcpyHostToDevice, c->aux2));
   if (ncclAllGather(d_h.p + (size_t)c->rank * P, d_h.p, (size_t)P, ncclDouble, comm, c->aux2) != ncclSuccess) FAIL(MSEVB_ERR_COMM, "ncclAllGather failed");
   HIPCHK(hipMemcpyAsync(h.data(), d_h.p, h.size() * 8, hipMemcpyDeviceToHost, c->aux2));
   HIPCHK(hipStreamSynchronize(c->aux2));      // aux2 already holds the energy downloads: the main stream keeps running
-  for (int d = 1; d < D; ++d) { const int r = (d - 1) % R, s = (d - 1) / R; c->H[d][d] = h[(size_t)r * P + 2 * s]; c->H[c->parent[d]][d] = h[(size_t)r * P + 2 * s + 1]; }
-  c->H[0][0] = h[2 * S];
-  if (with_energies) for (int k = 0; k < 8; ++k) { double e = 0.0; for (int r = 0; r < R; ++r) e += h[(size_t)r * P + 2 * S + 1 + k]; c->h_energies[S_ELEC_PAIR + k] = e; }
+  if (msevb_evb_payload_unpack(D, R, h.data(), c->parent, Hm.data(), with_energies ? c->h_energies + S_ELEC_PAIR : nullptr) != MSEVB_OK) FAIL(MSEVB_ERR_ARG, "EVB payload");
+  for (int d = 1; d < D; ++d) { c->H[d][d] = Hm[(size_t)d * D + d]; c->H[c->parent[d]][d] = Hm[(size_t)c->parent[d] * D + d]; }
+  c->H[0][0] = Hm[0];
   return MSEVB_OK;
 }
 

@@ -302,6 +302,9 @@ struct msevb_ctx {
   int rank = 0, n_ranks = 1;
   void* nccl_comm = nullptr;
   // per-context scratch that used to be process-wide (two contexts on different GPUs / host threads must not share it)
+  // principal-diabat switches since the log was last read: {EVB force call number (1-based, counted over the context's life), old hydronium, new hydronium}
+  // (1-based molecules) - the reference writes every hop at its own step (src/ms_evb.f90:331-335)
+  std::vector<int> hop_log; long evb_calls = 0;
   void* evb_work = nullptr;            // EvbWork of evb.hip (created by the first EVB force call, freed by evb_release)
   DBuf<double> d_comm_h, d_comm_e;     // staging of the Hamiltonian all-gather / the energy all-reduce (comm.hip)
   DBuf<int> d_bad;                     // 'force too large' flag of the integrator (integrate.hip)

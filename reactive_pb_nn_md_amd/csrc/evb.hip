@@ -1823,6 +1823,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   HT(10);
   // ---- 12. principal-diabat switch (src/ms_evb.f90:218-227): adopt the new topology, rebuild the Verlet list
   if (c->new_hydronium != c->hydronium) {
+    c->hop_log.push_back((int)c->evb_calls); c->hop_log.push_back(c->hydronium + 1); c->hop_log.push_back(c->new_hydronium + 1);
     HTopo T = P;
     for (int h = 0; h < c->max_chain; ++h) { if (c->plog[pr][h][0] < 0) break; CHK(apply_hop_h(c, w, T, T.hydronium, c->plog[pr][h][1], c->plog[pr][h][3], c->plog[pr][h][4])); }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1846,6 +1847,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
 }
 
 int evb_force_energy(msevb_ctx* c, double* epot_out) {
+  c->evb_calls++;
   int rc = evb_force_energy_once(c, epot_out);
   for (int k = 0; k < 3 && rc == MSEVB_RETRY; ++k) rc = evb_force_energy_once(c, epot_out);
   if (rc == MSEVB_RETRY) FAIL(MSEVB_ERR_LIMIT, "Verlet list rows keep overflowing");
@@ -1943,6 +1945,16 @@ int msevb_get_evb_element_force(msevb_ctx* c, int i, int j, double* force) {
   return MSEVB_OK;
 }
 
+// principal-diabat switches since the last call with clear != 0: log(3, n) = {EVB force call number, old, new hydronium molecule}
+int msevb_get_hop_log(msevb_ctx* c, int* n_hops, int* log, int capacity, long* evb_calls, int clear) {
+  if (!c) return MSEVB_ERR_ARG;
+  const int n = (int)(c->hop_log.size() / 3);
+  if (n_hops) *n_hops = n;
+  if (evb_calls) *evb_calls = c->evb_calls;
+  if (log) for (int k = 0; k < 3 * std::min(n, capacity); ++k) log[k] = c->hop_log[k];
+  if (clear) c->hop_log.clear();
+  return MSEVB_OK;
+}
 int msevb_comm_set_virtual(msevb_ctx* c, int r, int n) { if (!c || n < 1 || r < 0 || r >= n) return MSEVB_ERR_ARG; c->rank = r; c->n_ranks = n; return MSEVB_OK; }
 
 }  // extern "C"

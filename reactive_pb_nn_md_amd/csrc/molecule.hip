@@ -53,6 +53,7 @@ int molecule_forces(msevb_ctx* c, int slot0, bool do_nb, bool do_bonded, hipStre
   shard_range(c, c->M, m_lo, m_hi);
   const int nb = (m_hi - m_lo + MOL_TPB - 1) / MOL_TPB;
   if (!st) st = c->stream;
+  if (nb <= 0) { for (int s = 0; s < 5; ++s) CHK(reduce_partials(c, slot0 + s, 0)); return MSEVB_OK; }      // more ranks than molecules: this rank's share is empty (a launch with no blocks is an error)
   phase_begin(c, PH_MOLECULE, st);
   hipLaunchKernelGGL(k_molecules, dim3(nb), dim3(MOL_TPB), 0, st, m_lo, m_hi, c->d_mol_type.p, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_moltypes.p,
                      c->d_xyz.p, c->d_chg.p, c->d_force.p, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, c->rc * c->rc, c->alpha,

@@ -404,7 +404,7 @@ int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw) {
   } else {
     int i_lo, i_hi;
     shard_range(c, N, i_lo, i_hi);
-    nblocks = round_up8((i_hi - i_lo + 7) / 8);      // 8 atoms per block, two per wave
+    nblocks = round_up8(std::max((i_hi - i_lo + 7) / 8, 1));      // 8 atoms per block, two per wave (an empty share still launches: its blocks write zero partial sums)
     if (nblocks > 16384) nblocks = 16384;
     // force fields without a live SAPT term (every Buckingham coefficient zero, as in the CH3SO3H/H2O example) run the lean instantiation
     bool pr = c->prune && c->rc + c->prune_delta < c->rv;      // rolling pruned rows (a delta that reaches the list radius prunes nothing)

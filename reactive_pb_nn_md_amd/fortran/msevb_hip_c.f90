@@ -142,6 +142,14 @@ module msevb_hip_c
        integer(c_int), intent(out) :: n_diabat, principle_diabat, new_hydronium
        type(c_ptr), value :: proton_log, coupling_matrix, hamiltonian, eigenvector
      end function
+     integer(c_int) function msevb_get_hop_log(ctx, n_hops, log, capacity, evb_calls, clear) bind(C, name="msevb_get_hop_log")
+       import :: c_ptr, c_int, c_long
+       type(c_ptr), value :: ctx
+       integer(c_int), intent(out) :: n_hops
+       integer(c_int), intent(out) :: log(3,*)
+       integer(c_int), value :: capacity, clear
+       integer(c_long), intent(out) :: evb_calls
+     end function
      integer(c_int) function msevb_get_topology(ctx, atom_type_index, charge, mol_n_atom, mol_type_index, mol_atom_index, hydronium_molecule) bind(C, name="msevb_get_topology")
        import :: c_ptr, c_int, c_double
        type(c_ptr), value :: ctx
@@ -284,6 +292,26 @@ module msevb_hip_c
        import :: c_ptr, c_int
        type(c_ptr), value :: ctx
        integer(c_int), value :: rank, n_ranks
+     end function
+     integer(c_int) function msevb_evb_payload_size(n_diabat, n_ranks) bind(C, name="msevb_evb_payload_size")
+       import :: c_int
+       integer(c_int), value :: n_diabat, n_ranks
+     end function
+     integer(c_int) function msevb_evb_payload_pack(n_diabat, n_ranks, rank, hamiltonian, parent, energies8, out) bind(C, name="msevb_evb_payload_pack")
+       import :: c_int, c_double, c_ptr
+       integer(c_int), value :: n_diabat, n_ranks, rank
+       real(c_double), intent(in) :: hamiltonian(*)
+       integer(c_int), intent(in) :: parent(*)
+       type(c_ptr), value :: energies8
+       real(c_double), intent(out) :: out(*)
+     end function
+     integer(c_int) function msevb_evb_payload_unpack(n_diabat, n_ranks, all_payloads, parent, hamiltonian, energies8) bind(C, name="msevb_evb_payload_unpack")
+       import :: c_int, c_double, c_ptr
+       integer(c_int), value :: n_diabat, n_ranks
+       real(c_double), intent(in) :: all_payloads(*)
+       integer(c_int), intent(in) :: parent(*)
+       real(c_double), intent(inout) :: hamiltonian(*)
+       type(c_ptr), value :: energies8
      end function
      integer(c_int) function msevb_comm_allreduce_energies(ctx) bind(C, name="msevb_comm_allreduce_energies")
        import :: c_ptr, c_int

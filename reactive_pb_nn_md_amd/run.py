@@ -128,12 +128,14 @@ def main(argv=None):
             en[-1, 0] = e_now
             spec = h.spec
         if use_evb:
-            new_hyd = h.topology()["hydronium_molecule"]
-            if hop is not None and new_hyd != hyd:
-                # the reference's two lines (src/ms_evb.f90:334-335); the step is the end of the integration block the hop happened in
-                hop.write(" step  %d\n proton hop from  %d  to  %d\n" % (step, hyd, new_hyd))
+            # every hop of the block with its OWN step, as the reference writes them (src/ms_evb.f90:331-335): the library logs the number
+            # of the EVB force call a switch happened in; the block's calls are the last nb of them (a there-and-back pair shows both)
+            hops, calls = h.hop_log()
+            if hop is not None:
+                for call, h_from, h_to in hops:
+                    hop.write(" step  %d\n proton hop from  %d  to  %d\n" % (step - (calls - int(call)), h_from, h_to))
                 hop.flush()
-            hyd = new_hyd
+            hyd = h.topology()["hydronium_molecule"]
         if done % max(1, n_output) == 0:
             t5 = None
             if not use_evb:

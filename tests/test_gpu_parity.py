@@ -403,6 +403,8 @@ def test_principal_switch_against_reference():
     h.ms_evb_calculate_total_force_energy(want_force=False)
     st = h.evb_state()
     assert st["principle_diabat"] != 1 and st["new_hydronium_molecule"] == post.hydronium + 1
+    hops, calls = h.hop_log()      # the hop is logged with the force call it happened in (src/ms_evb.f90:331-335 writes it with its step)
+    assert calls == 1 and hops.tolist() == [[1, pre.hydronium + 1, post.hydronium + 1]] and len(h.hop_log()[0]) == 0
     t = h.topology()
     assert t["hydronium_molecule"] == post.hydronium + 1
     t["mol_atom_index"] = t["mol_atom_index"] - 1

@@ -1,7 +1,7 @@
 """world_size-2 `gloo` test of the diabat sharding used on N>1 GPUs: rank r owns diabats d>=2 with
 (d-2) mod R == r; the Hamiltonian entries are all-gathered (2 doubles per slot), every rank diagonalises the same matrix, blends ITS
 diabats and the partial forces are all-reduced.  The per-element numbers come from the CPU oracle here (no GPU in this container);
-the protocol under test is comm.hip's / evb.hip's (blend_terms)."""
+the payload packing under test is the library's own (csrc/comm.hip, host functions), the blend layout evb.hip's (blend_terms)."""
 import os
 import socket
 import sys
@@ -26,18 +26,31 @@ def _worker(rank, world, port, name, q):
     o.verlet_build()
     r = o.evb()                     # every rank could compute everything; keep only what this rank owns
     D, N = r["D"], spec.n_atom
-    S = sharding.slots_per_rank(D, world)
-    Hloc = np.zeros((S, 2))
+    # the library's OWN payload code (csrc/comm.hip: msevb_evb_payload_pack / _unpack, what msevb_comm_allgather_evb wraps around its
+    # ncclAllGather) - host functions of libmsevb_hip.so, no GPU needed; gloo carries the bytes here
+    import ctypes as C
+    from reactive_pb_nn_md_amd import api
+    L = api.load_library()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    P = L.msevb_evb_payload_size(D, world)
+    assert P == 2 * sharding.slots_per_rank(D, world) + 9
+    parent = np.ascontiguousarray(r["parent"], dtype=np.int32)
+    Hmine = np.zeros((D, D))                                           # what THIS rank computed: its own diabats' entries, H'_11
+    Hmine[0, 0] = r["H"][0, 0]
     for d in range(1, D):
         if sharding.owner(d, world) == rank:
-            Hloc[sharding.local_slot(d, world)] = (r["H"][d, d], r["H"][r["parent"][d], d])
-    Hall = [torch.zeros(S, 2, dtype=torch.float64) for _ in range(world)]
-    dist.all_gather(Hall, torch.from_numpy(Hloc))                    # msevb_comm_allgather_evb
+            Hmine[d, d], Hmine[parent[d], d] = r["H"][d, d], r["H"][parent[d], d]
+    e8 = np.arange(8, dtype=np.float64) * (rank + 1)                   # stand-ins for the principal energy slots: summed over the ranks
+    mine = np.zeros(P)
+    assert L.msevb_evb_payload_pack(D, world, rank, dp(Hmine), ip(parent), dp(e8), dp(mine)) == 0
+    Hall = [torch.zeros(P, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(Hall, torch.from_numpy(mine))                    # msevb_comm_allgather_evb
+    allp = np.ascontiguousarray(np.concatenate([t.numpy() for t in Hall]))
     H = np.zeros((D, D))
-    H[0, 0] = r["H"][0, 0]
-    for d in range(1, D):
-        ow, s = sharding.owner(d, world), sharding.local_slot(d, world)
-        H[d, d], H[r["parent"][d], d] = Hall[ow][s].numpy()
+    esum = np.zeros(8)
+    assert L.msevb_evb_payload_unpack(D, world, dp(allp), ip(parent), dp(H), dp(esum)) == 0
+    assert np.array_equal(esum, np.arange(8) * sum(range(1, world + 1)))
     E, c = sharding.ground_state(H)
     # this rank only has ITS stores: zero the others to prove they are not needed
     Fd, Fo = np.zeros((D, N, 3)), np.zeros((D, N, 3))

@@ -104,14 +104,14 @@ int msevb_destroy(msevb_ctx* c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   pme_teardown(c);
   DBuf<int>* ib[] = {&c->d_atype, &c->d_mol_type, &c->d_mol_natom, &c->d_mol_atoms, &c->d_mol_of, &c->d_cell_of, &c->d_perm, &c->d_cell_keys_tmp,
-                     &c->d_perm_tmp, &c->d_cell_start, &c->d_inv_perm, &c->d_tile_max, &c->d_nbr, &c->d_nbr2, &c->d_prune_mode, &c->d_frozen, &c->d_type_sorted, &c->d_mol_sorted, &c->d_base, &c->d_splindex};
+                     &c->d_perm_tmp, &c->d_cell_start, &c->d_inv_perm, &c->d_tile_max, &c->d_nbr, &c->d_nbr2, &c->d_prune_mode, &c->d_frozen, &c->d_type_sorted, &c->d_mol_sorted, &c->d_base, &c->d_splindex, &c->d_base_s};
   for (auto b : ib) b->release();
   DBuf<double>* db[] = {&c->d_chg, &c->d_mass, &c->d_B6, &c->d_B5, &c->d_tt, &c->d_dtt, &c->d_CB, &c->d_xyz, &c->d_vel, &c->d_force, &c->d_force_recip,
                         &c->d_xyz_store, &c->d_disp, &c->d_maxdisp, &c->d_Q, &c->d_theta, &c->d_green, &c->d_w, &c->d_dw, &c->d_uscale, &c->d_partials, &c->d_energies,
                         &c->d_Fdiag, &c->d_Foff};
   for (auto b : db) b->release();
   c->d_pair_par.release(); c->d_moltypes.release(); c->d_ewald_tab.release(); c->d_nbr_count.release(); c->d_nbr2_count.release(); c->d_posq_prune.release(); c->d_nbr_start.release();
-  c->d_comm_h.release(); c->d_comm_e.release(); c->d_bad.release(); c->d_fsorted.release();
+  c->d_w_s.release(); c->d_comm_h.release(); c->d_comm_e.release(); c->d_bad.release(); c->d_fsorted.release();
   if (c->h_ke) (void)hipHostFree(c->h_ke);
   c->d_sort_tmp.release(); c->d_posq.release(); c->d_grid.release(); c->d_fft_work.release(); c->d_fft_work_b.release();
   for (int p = 0; p < PH_COUNT; ++p) for (hipEvent_t e : c->ph[p].ev) (void)hipEventDestroy(e);
@@ -673,6 +673,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
   if (s == "spread_mfma") { c->spread_mfma = v != 0.0; return MSEVB_OK; }
+  if (s == "spread_bricks") { c->spread_bricks = v != 0.0; return MSEVB_OK; }
   if (s == "evb_device_solve") { c->evb_device_solve = v != 0.0; return MSEVB_OK; }
   if (s == "pair_threads") { c->pair_threads = v == 512.0 ? 512 : 1024; return MSEVB_OK; }
   if (s == "evb_recip_linear") { c->evb_recip_linear = v != 0.0; return MSEVB_OK; }

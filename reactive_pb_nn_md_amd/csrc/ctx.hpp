@@ -272,11 +272,14 @@ struct msevb_ctx {
   DBuf<double> d_green;        // G = IFFT(CB): real-space kernel of the reciprocal sum (theta = G * Q), K^3
   DBuf<double> d_w, d_dw, d_uscale;   // per atom: B6 weights [N][3][6], derivative weights, scaled coords
   DBuf<int> d_base, d_splindex;       // nearpt [N][3], B6 rows [N][3][6]
+  DBuf<int> d_base_s, d_brick_flag; DBuf<double> d_w_s;      // cell-sorted copies of nearpt / B6 weights for the brick spread; its overflow flag
   rocfft_plan plan_fwd = nullptr, plan_bwd = nullptr;
   // batched plans by batch size (= number of non-principal diabat grids): kept for the life of the context, because the diabat count moves
   // up and down during a run and creating a plan pair costs milliseconds (a step costs 0.6 ms)
   std::map<int, std::pair<rocfft_plan, rocfft_plan>> plans_b;
   bool spread_tiles = true;
+  bool spread_bricks = false;    // option: owner-computes charge spreading on the matrix cores (k_pme_spread_bricks): every cell's workgroup writes ITS brick of the grid, no atomics, no zero-fill
+                                 // (needs bricks of <= 8 points per axis, K >= 16).  Measured 63 us alone against 55 + 4 + 5 for the LDS-atomic tiles with fill and copy, 2-3 % slower in the overlapped step: off
   bool spread_mfma = false;      // charge spreading as a per-cell contraction on the matrix cores (v_mfma_f64_16x16x4_f64), option spread_mfma
   bool attr_spread_mfma = false;
   bool has_sapt = false;     // some (type_i,type_j) entry has non-zero SAPT coefficients
@@ -375,6 +378,7 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
 
 constexpr int MAX_BLOCKS = 65536;
 enum Slot { S_ELEC_PAIR = 0, S_VDW_PAIR, S_ELEC_INTRA, S_VDW_INTRA, S_BOND, S_ANGLE, S_DIH, S_RECIP, S_KE, S_PX, S_PY, S_PZ, S_VX, S_VY, S_VZ /* sum of velocities: KE after the momentum removal */, S_MAXD1, S_MAXD2, S_PRD1, S_PRD2 /* two largest displacements since the pair list was last pruned */, S_EVB0,
+            S_BRICK = 30,      // sticky: a brick of the owner-computes spread met more atoms than it can take (nb_check_overflow switches to the tile kernel and has the force call repeated)
             S_FAULT = 31,      // sticky: a kernel met a coordinate outside what its index arithmetic covers (non-finite, or more than one box away)
             N_SLOTS = 32 };
 

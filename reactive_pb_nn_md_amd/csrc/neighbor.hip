@@ -574,6 +574,11 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
 // After a deferred rebuild, once the host has waited for work enqueued behind it: 1 = a row overflowed its stride (the stride has been
 // enlarged, the list is marked stale, the caller repeats the force call), 0 = the list is complete.
 int nb_check_overflow(msevb_ctx* c) {
+  if (c->h_energies[S_BRICK] != 0.0) {      // the brick spread overflowed (denser than any liquid): tile kernel from now on, this force call again
+    c->spread_bricks = false; c->h_energies[S_BRICK] = 0.0;
+    (void)hipMemsetAsync(c->d_energies.p + S_BRICK, 0, sizeof(double), c->stream);
+    return 1;
+  }
   if (!c->nbr_check_pending) return 0;
   c->nbr_check_pending = false;
   const int* h = c->h_nbr_stats;

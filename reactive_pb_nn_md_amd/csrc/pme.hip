@@ -18,7 +18,8 @@ namespace {
 __global__ __launch_bounds__(256) void k_pme_prep(int N, int K, int G, const double* __restrict__ xyz, double k00, double k01,
                            double k02, double k10, double k11, double k12, double k20, double k21, double k22,
                            const double* __restrict__ B6, const double* __restrict__ B5, double* __restrict__ uscale, int* __restrict__ base,
-                           int* __restrict__ splindex, double* __restrict__ w, double* __restrict__ dw, double* __restrict__ fault) {
+                           int* __restrict__ splindex, double* __restrict__ w, double* __restrict__ dw, double* __restrict__ fault,
+                           const int* __restrict__ inv_perm, int* __restrict__ base_s, double* __restrict__ w_s) {
 #pragma clang fp contract(off)
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 18 * N) return;
@@ -35,7 +36,13 @@ __global__ __launch_bounds__(256) void k_pme_prep(int N, int K, int G, const dou
   const double a1 = u - (double)n, a2 = a1 - 1.0;
   const int g6 = (int)ceil(a1 / 6.0 * (double)G);
   if (splindex) splindex[t] = g6;
-  w[t] = B6[g6 - 1];
+  const double wv = B6[g6 - 1];
+  w[t] = wv;
+  if (inv_perm) {      // the same values in CELL-SORTED atom order: the brick spread scans its neighbourhood with coalesced reads
+    const int ks = inv_perm[i];
+    w_s[18 * (size_t)ks + r] = wv;
+    if (k == 0) base_s[3 * ks + l] = np;
+  }
   double d = 0.0;
   if (a1 < 5.0) d = B5[(int)ceil(a1 / 5.0 * (double)G) - 1];
   if (0.0 < a2) d = d - B5[(int)ceil(a2 / 5.0 * (double)G) - 1];
@@ -217,6 +224,122 @@ __global__ __launch_bounds__(256) void k_pme_spread_mfma(int K, int3 nc, const i
         int n2 = oy + (lane >> 4) + 4 * v; n2 += n2 < 0 ? K : 0; n2 -= n2 >= K ? K : 0;
         atomicAdd(&grid[n1 + (size_t)K * (n2 + (size_t)K * n3)].x, val);
       }
+    }
+  }
+}
+
+// OWNER-COMPUTES spread on the matrix cores: one workgroup per neighbour cell, which owns the BRICK of grid points
+// [floor(c K / n), floor((c + 1) K / n)) per axis (<= 8 points) - the bricks partition the grid, so every grid point is WRITTEN once
+// (plain stores of {Q, 0} into the complex grid and of Q into the real copy): no global atomics (the halo flush of the per-cell tiles
+// was ~0.4 M atomic L2 requests per launch, the whole duration of both tile kernels), no zero-fill, no copy pass.
+//   1. scan the cell's neighbourhood (<= 27 cells, cell-sorted base points: coalesced) and keep the atoms whose 6-tap stencil reaches
+//      into the brick on every axis (~5 x the cell's own atoms);
+//   2. per chunk of kept atoms, three dense 8-entry weight vectors per atom (its taps inside the brick, zeros elsewhere), then
+//      brick[z][y][x] = sum_a (q_a Wz_a[z] Wy_a[y]) Wx_a[x] as v_mfma_f64_16x16x4_f64: rows = 2 planes x 8 y, columns = x (8 of 16 used),
+//      4 atoms per instruction; wave w owns the planes 2 w, 2 w + 1.
+constexpr int BRICK_SEL = 2048;       // most atoms a brick can take (a liquid gives ~700)
+constexpr int BRICK_CHUNK = 192;
+__global__ __launch_bounds__(256) void k_pme_spread_bricks(int K, int3 nc, const int* __restrict__ cell_start, const int* __restrict__ base_s, const double* __restrict__ w_s,
+                                                           const double4* __restrict__ posq, double2* __restrict__ grid, double* __restrict__ Q, double* __restrict__ overflow) {
+  __shared__ int s_lo[27], s_n[27], s_ns, s_cnt[4];
+  __shared__ int sel_k[BRICK_SEL];      // four wave-private lists of BRICK_SEL / 4 entries (no shared counter: a wave counts in a register)
+  __shared__ unsigned sel_l[BRICK_SEL];
+  extern __shared__ double Wd[];      // [3][BRICK_CHUNK][8]
+  double* Wx = Wd; double* Wy = Wx + BRICK_CHUNK * 8; double* Wz = Wy + BRICK_CHUNK * 8;
+  const int cidx = blockIdx.x;
+  const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
+  const int p0x = (int)floor((double)cx * K / nc.x), p0y = (int)floor((double)cy * K / nc.y), p0z = (int)floor((double)cz * K / nc.z);
+  const int nbx = (cx + 1 == nc.x ? K : (int)floor((double)(cx + 1) * K / nc.x)) - p0x, nby = (cy + 1 == nc.y ? K : (int)floor((double)(cy + 1) * K / nc.y)) - p0y,
+            nbz = (cz + 1 == nc.z ? K : (int)floor((double)(cz + 1) * K / nc.z)) - p0z;
+  if (threadIdx.x < 27) {      // one lane per neighbour cell (a single thread walked 54 dependent loads)
+    int slots[27];
+    const int ns = cell_neighbourhood(cidx, nc.x, nc.y, nc.z, slots);
+    if ((int)threadIdx.x < ns) { const int lo = cell_start[slots[threadIdx.x]]; s_lo[threadIdx.x] = lo; s_n[threadIdx.x] = cell_start[slots[threadIdx.x] + 1] - lo; }
+    if (threadIdx.x == 0) s_ns = ns;
+  }
+  __syncthreads();
+  const int ns = s_ns;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // 1. selection: every wave takes whole neighbour cells (no search for the cell of a candidate); the base points of a cell's atoms are
+  //    consecutive int triples, and the next trip's are loaded before the current trip is compacted
+  int wcount = 0;      // wave-uniform
+  const int wlist = wave * (BRICK_SEL / 4);
+  for (int sl = wave; sl < ns; sl += 4) {
+    const int lo = s_lo[sl], n = s_n[sl];
+    int ks = lo + min(lane, n - 1);
+    int b1 = base_s[3 * ks], b2 = base_s[3 * ks + 1], b3 = base_s[3 * ks + 2];
+    for (int q0 = 0; q0 < n; q0 += 64) {
+      const int q = q0 + lane, ksn = lo + min(q + 64, n - 1);
+      const int c1 = base_s[3 * ksn], c2 = base_s[3 * ksn + 1], c3 = base_s[3 * ksn + 2];      // next trip (the last one reloads the cell's last atom)
+      int l1 = b1 - p0x; l1 += l1 < 0 ? K : 0;
+      int l2 = b2 - p0y; l2 += l2 < 0 ? K : 0;
+      int l3 = b3 - p0z; l3 += l3 < 0 ? K : 0;
+      const bool keep = q < n && l1 < nbx + 5 && l2 < nby + 5 && l3 < nbz + 5;      // a tap of every axis lands inside the brick
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int slot = wcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (slot < BRICK_SEL / 4) { sel_k[wlist + slot] = ks; sel_l[wlist + slot] = (unsigned)l1 | ((unsigned)l2 << 8) | ((unsigned)l3 << 16); }
+      }
+      wcount += (int)__popcll(m);
+      ks = ksn; b1 = c1; b2 = c2; b3 = c3;
+    }
+  }
+  if (lane == 0) s_cnt[wave] = wcount;
+  __syncthreads();
+  const int n0 = s_cnt[0], n1 = s_cnt[1], n2 = s_cnt[2], n3 = s_cnt[3];
+  if (max(max(n0, n1), max(n2, n3)) > BRICK_SEL / 4) { if (threadIdx.x == 0) *overflow = 1.0; return; }      // sticky energy slot S_BRICK: the host switches to the tile kernel and repeats the force call
+  const int nsel = n0 + n1 + n2 + n3;
+  // position g of the concatenated lists -> entry of a wave's list
+  auto sel_at = [&](int g) { return g < n0 ? g : g < n0 + n1 ? BRICK_SEL / 4 + (g - n0) : g < n0 + n1 + n2 ? 2 * (BRICK_SEL / 4) + (g - n0 - n1) : 3 * (BRICK_SEL / 4) + (g - n0 - n1 - n2); };
+  mfma_d4 acc = (mfma_d4){0.0, 0.0, 0.0, 0.0}, acc2 = (mfma_d4){0.0, 0.0, 0.0, 0.0};      // two accumulation chains: back-to-back MFMAs into one accumulator wait for each other
+  for (int c0 = 0; c0 < nsel; c0 += BRICK_CHUNK) {      // 2. contraction, BRICK_CHUNK atoms at a time
+    const int n = min(BRICK_CHUNK, nsel - c0), n4 = (n + 7) & ~7;
+    __syncthreads();      // previous chunk consumed
+    for (int t = threadIdx.x; t < n4 * 3; t += blockDim.x) {      // one thread per (atom, axis): the taps inside the brick, zeros elsewhere
+      const int a = t / 3, d = t - 3 * a;
+      double* W = (d == 0 ? Wx : d == 1 ? Wy : Wz) + a * 8;
+      if (a < n) {
+        const int se = sel_at(c0 + a);
+        const int ks = sel_k[se];
+        const int l = (int)((sel_l[se] >> (8 * d)) & 255u);
+        const double sc = d == 2 ? posq[ks].w : 1.0;
+        const double* wp = w_s + 18 * (size_t)ks + 6 * d;
+        double w6[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w6[k] = wp[k];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {      // brick point q holds tap k = l - q (static register indexing: a select chain, no scratch)
+          const int k = l - q;
+          double v = 0.0;
+#pragma unroll
+          for (int kk = 0; kk < 6; ++kk) v = k == kk ? w6[kk] : v;
+          W[q] = sc * v;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) W[q] = 0.0;
+      }
+    }
+    __syncthreads();
+    const int row = lane & 15, kq = lane >> 4, zp = row >> 3, y = row & 7;
+    for (int a0 = 0; a0 < n4; a0 += 8) {
+      const int a = a0 + kq, b = a + 4;
+      const double av = Wz[a * 8 + 2 * wave + zp] * Wy[a * 8 + y], av2 = Wz[b * 8 + 2 * wave + zp] * Wy[b * 8 + y];
+      const double bv = row < 8 ? Wx[a * 8 + row] : 0.0, bv2 = row < 8 ? Wx[b * 8 + row] : 0.0;      // (row doubles as the column index of the B operand: lane & 15)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av2, bv2, acc2, 0, 0, 0);
+    }
+  }
+  acc += acc2;
+  // D[row = (lane >> 4) + 4 v][col = lane & 15]: row = plane (row >> 3) of this wave, y = row & 7; col = x
+  const int x = lane & 15;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int r = (lane >> 4) + 4 * v, z = 2 * wave + (r >> 3), y = r & 7;
+    if (x < nbx && y < nby && z < nbz) {
+      const size_t idx = (size_t)(p0x + x) + (size_t)K * ((size_t)(p0y + y) + (size_t)K * (size_t)(p0z + z));
+      grid[idx] = make_double2(acc[v], 0.0);
+      Q[idx] = acc[v];
     }
   }
 }
@@ -403,7 +526,7 @@ int pme_setup(msevb_ctx* c) {
   if (!g_rocfft_ready) { if (rocfft_setup() != rocfft_status_success) FAIL(MSEVB_ERR_FFT, "rocfft_setup failed"); g_rocfft_ready = true; }
   const int batch = c->fft_batch < 1 ? 1 : c->fft_batch;
   if (c->d_grid.alloc(K3 * batch) || c->d_Q.alloc(K3) || c->d_theta.alloc(K3) || c->d_w.alloc(18 * (size_t)N) || c->d_dw.alloc(18 * (size_t)N) || c->d_uscale.alloc(3 * (size_t)N) ||
-      c->d_base.alloc(3 * (size_t)N) || c->d_splindex.alloc(18 * (size_t)N) || c->d_force_recip.alloc(3 * (size_t)N))
+      c->d_base.alloc(3 * (size_t)N) || c->d_base_s.alloc(3 * (size_t)N) || c->d_w_s.alloc(18 * (size_t)N) || c->d_splindex.alloc(18 * (size_t)N) || c->d_force_recip.alloc(3 * (size_t)N))
     FAIL(MSEVB_ERR_HIP, "hipMalloc failed (PME)");
   size_t len[3] = {(size_t)K, (size_t)K, (size_t)K};
   pme_teardown(c);
@@ -510,7 +633,8 @@ int pme_prepare_atoms(msevb_ctx* c, bool with_indices) {
   const long nt = 18L * N;
   hipLaunchKernelGGL(k_pme_prep, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, pme_stream(c), N, c->K, c->spline_grid, c->d_xyz.p, c->kk[0][0], c->kk[0][1],
                      c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, c->d_uscale.p,
-                     c->d_base.p, with_indices ? c->d_splindex.p : (int*)nullptr, c->d_w.p, c->d_dw.p, c->d_energies.p + S_FAULT);
+                     c->d_base.p, with_indices ? c->d_splindex.p : (int*)nullptr, c->d_w.p, c->d_dw.p, c->d_energies.p + S_FAULT,
+                     (c->cells_valid && c->spread_bricks) ? c->d_inv_perm.p : (const int*)nullptr, c->d_base_s.p, c->d_w_s.p);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
 }
@@ -553,7 +677,7 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
   // side stream it is captured once into a hipGraph and replayed with one launch (the ~14 launches cost the host ~80 us per step, and
   // the host is what decides when the EVB chains behind them can start).  Steps that sample the phase timers launch directly.
   struct Key { const void* p[9]; int v[8]; } key = {{c->d_grid.p, c->d_Q.p, c->d_theta.p, c->d_w.p, c->d_base.p, c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_fft_work.p},
-                                               {N, K, c->ncell[0], c->ncell[1], c->ncell[2], c->cells_valid ? 1 : 0, (c->spread_tiles ? 1 : 0) + (c->spread_mfma ? 2 : 0), slot_recip}};
+                                               {N, K, c->ncell[0], c->ncell[1], c->ncell[2], c->cells_valid ? 1 : 0, (c->spread_tiles ? 1 : 0) + (c->spread_mfma ? 2 : 0) + (c->spread_bricks ? 4 : 0), slot_recip}};
   const bool use_graph = join_aux && c->graphs && !c->timing_now;
   bool capturing = false;
   int nbk = 0;
@@ -567,12 +691,18 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
     }
     phase_begin(c, PH_SPREAD, st);
     CHK(pme_prepare_atoms(c, false));
-    HIPCHK(hipMemsetAsync(c->d_grid.p, 0, K3 * sizeof(double2), st));
+    bool bricks = false;
     {
       int3 T;
       T.x = (int)ceil((double)K / c->ncell[0]) + 8; T.y = (int)ceil((double)K / c->ncell[1]) + 8; T.z = (int)ceil((double)K / c->ncell[2]) + 8;
       const size_t tile_bytes = (size_t)spread_plane_stride(T) * T.z * sizeof(double) + (size_t)SPREAD_CHUNK * (18 * 8 + 8 + 12);      // tile + staged atom inputs
-      if (c->cells_valid && c->spread_mfma && T.x <= 16 && T.y <= 16 && T.z <= 16 && K >= 16) {      // 16^3 tile per cell: the contraction over the cell's atoms on the matrix cores
+      bricks = c->cells_valid && c->spread_bricks && K >= 16 && T.x <= 16 && T.y <= 16 && T.z <= 16 && c->d_inv_perm.p;      // bricks of <= 8 points per axis
+      if (!bricks) HIPCHK(hipMemsetAsync(c->d_grid.p, 0, K3 * sizeof(double2), st));
+      if (bricks) {      // owner computes: no zero-fill (below), no atomics, no real-copy pass
+        const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
+        hipLaunchKernelGGL(k_pme_spread_bricks, dim3(ncell), dim3(256), (size_t)3 * BRICK_CHUNK * 8 * sizeof(double), st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]),
+                           c->d_cell_start.p, c->d_base_s.p, c->d_w_s.p, c->d_posq.p, c->d_grid.p, c->d_Q.p, c->d_energies.p + S_BRICK);
+      } else if (c->cells_valid && c->spread_mfma && T.x <= 16 && T.y <= 16 && T.z <= 16 && K >= 16) {      // 16^3 tile per cell: the contraction over the cell's atoms on the matrix cores
         const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
         if (!c->attr_spread_mfma) { HIPCHK(hipFuncSetAttribute((const void*)k_pme_spread_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, SPREAD_MFMA_CHUNK * 48 * 8)); c->attr_spread_mfma = true; }
         hipLaunchKernelGGL(k_pme_spread_mfma, dim3(ncell), dim3(256), (size_t)SPREAD_MFMA_CHUNK * 48 * 8, st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]),
@@ -588,7 +718,7 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
     }
     int nbc = (int)((K3 + 255) / 256);
     if (nbc > 2048) nbc = 2048;
-    hipLaunchKernelGGL(k_copy_real, dim3(nbc), dim3(256), 0, st, K3, c->d_grid.p, c->d_Q.p);
+    if (!bricks) hipLaunchKernelGGL(k_copy_real, dim3(nbc), dim3(256), 0, st, K3, c->d_grid.p, c->d_Q.p);      // (the brick kernel writes Q itself)
     HIPCHK(hipGetLastError());
     phase_end(c, PH_SPREAD, st);
     phase_begin(c, PH_FFT, st);

@@ -88,18 +88,20 @@ def test_mfma_charge_spreading_against_reference(name):
     """option spread_mfma: grid_Q (src/pme.f90:184-262) as a per-cell contraction on the matrix cores (v_mfma_f64_16x16x4_f64, 16^3 tile per
     cell) - the real reference's Q_grid, theta and reciprocal forces; then the EVB force call on top of it"""
     g = golden(name)
-    h = api.MsEvbHip(system.from_golden(g))
-    h.set_option("spread_mfma", 1)
-    h.construct_verlet_list()
-    h.zero_forces()
-    er = h.pme_reciprocal_space_energy_force()
-    Q, th, u, fr = h.pme_state()
-    assert np.abs(Q - g["Q_grid"]).max() < 1e-14 and np.abs(th - g["theta_conv_Q"]).max() < 1e-13
-    assert np.abs(h.get_forces() - g["F_recip"]).max() < F_TOL and rel(er, g["E_recip"][0]) < E_RTOL
-    if name.startswith("evb"):
-        e, F = h.ms_evb_calculate_total_force_energy()
-        assert rel(e, g["E_adiabatic"][0]) < E_RTOL and np.abs(F - g["F_adiabatic"]).max() < F_TOL
-    h.close()
+    for bricks in (1, 0):      # 1: owner-computes MFMA bricks (a cell's workgroup writes its <= 8^3 brick of the grid, no atomics); 0: the 16^3-tile MFMA kernel
+        h = api.MsEvbHip(system.from_golden(g))
+        h.set_option("spread_bricks", bricks)
+        h.set_option("spread_mfma", 1)
+        h.construct_verlet_list()
+        h.zero_forces()
+        er = h.pme_reciprocal_space_energy_force()
+        Q, th, u, fr = h.pme_state()
+        assert np.abs(Q - g["Q_grid"]).max() < 1e-14 and np.abs(th - g["theta_conv_Q"]).max() < 1e-13
+        assert np.abs(h.get_forces() - g["F_recip"]).max() < F_TOL and rel(er, g["E_recip"][0]) < E_RTOL
+        if name.startswith("evb"):
+            e, F = h.ms_evb_calculate_total_force_energy()
+            assert rel(e, g["E_adiabatic"][0]) < E_RTOL and np.abs(F - g["F_adiabatic"]).max() < F_TOL
+        h.close()
 
 
 def test_mfma_charge_spreading_config_B():
@@ -107,8 +109,9 @@ def test_mfma_charge_spreading_config_B():
     also along a trajectory on which atoms drift out of their cell's tile (those are spread point by point)"""
     spec = _synthetic(32, 8, 11, 64)
     out = []
-    for mfma in (0, 1):
+    for bricks, mfma in ((0, 0), (0, 1), (1, 0)):      # LDS-atomic tiles (the default), MFMA tiles, owner-computes MFMA bricks
         h = api.MsEvbHip(spec)
+        h.set_option("spread_bricks", bricks)
         h.set_option("spread_mfma", mfma)
         h.construct_verlet_list()
         h.zero_forces()
@@ -120,8 +123,9 @@ def test_mfma_charge_spreading_config_B():
         tr = h.md_integrate_atomic(25, spec.delta_t, use_evb=True)
         out.append((er, Q, F, tr, h.get_positions()))
         h.close()
-    assert rel(out[1][0], out[0][0]) < 1e-13 and np.abs(out[1][1] - out[0][1]).max() < 1e-13 and np.abs(out[1][2] - out[0][2]).max() < F_TOL
-    assert np.abs(out[1][3] - out[0][3]).max() < 1e-8 * np.abs(out[0][3]).max() and np.abs(out[1][4] - out[0][4]).max() < 1e-8
+    for k in (1, 2):
+        assert rel(out[k][0], out[0][0]) < 1e-13 and np.abs(out[k][1] - out[0][1]).max() < 1e-13 and np.abs(out[k][2] - out[0][2]).max() < F_TOL, k
+        assert np.abs(out[k][3] - out[0][3]).max() < 1e-8 * np.abs(out[0][3]).max() and np.abs(out[k][4] - out[0][4]).max() < 1e-8, k
 
 
 @pytest.mark.parametrize("name", ["std_n6_s3", "std_n6_k20_s13"])

@@ -235,6 +235,109 @@ __device__ __forceinline__ void pair_row_half(const double4* tile, double* tfx, 
   }
 }
 
+// ---- software-pipelined row loop of k_pair_half (launches that run on fixed rows: the pruned rows, or the full rows without pruning) ----
+// A wave works through a STREAM of trips (64 list entries each) that crosses row boundaries; three trips are in flight:
+//     trip t + 2: its 64 entries are being loaded (global),
+//     trip t + 1: stage A done - partner positions read from the tile, r^2, cutoff decision, the two Ewald-table rows REQUESTED,
+//     trip t    : stage B - interaction arithmetic with table rows that were requested one trip ago, LDS force adds.
+// The wave-per-row loop above waits once per trip for the entries of a new row and once for the table rows; with four waves per SIMD
+// (the tile pins one workgroup to a CU) the SIMDs idled 55 % of the time (SQ_WAIT_ANY).  Here the table rows of trip t + 1 and the entries
+// of trip t + 2 are under way while trip t computes.
+struct TripCtx { int a; int last; };      // wave-uniform: row (atom of the cell) of the trip, 1 = last trip of that row
+struct TripState { double dx, dy, dz, r2, qq; EwaldRows w; unsigned e; bool in; };
+
+template <bool SAPT>
+__device__ __forceinline__ void trip_stage_a(const double4* tile, unsigned e, int a, int cs, const double4* __restrict__ posq, const int* s_lo, const int* s_off, const BoxDev& box,
+                                             double rc2, double inv_dx, int emax, const double2* __restrict__ etab, TripState& st) {
+#pragma clang fp contract(fast)
+  const bool v = e != NBR_NONE;
+  const unsigned j = v ? (e & NBR_IDX_MASK) : 0u;
+  const double4 pi = tile[a], pj = tile[j];
+  st.dx = pi.x - pj.x; st.dy = pi.y - pj.y; st.dz = pi.z - pj.z;
+  st.r2 = st.dx * st.dx + st.dy * st.dy + st.dz * st.dz;
+  st.qq = pi.w * pj.w;
+  st.e = e;
+  bool in = v && st.r2 < rc2;
+  const bool tie = v && fabs(st.r2 - rc2) < 1e-9 * rc2;
+  if (__ballot(tie)) {      // rare: on the cutoff to within rounding - the reference's arithmetic on the raw coordinates decides
+    double ux, uy, uz;
+    if (tie) in = min_image_r2(posq[cs + a], posq[tile_to_sorted((int)j, s_lo, s_off)], box, ux, uy, uz) < rc2;
+  }
+  st.in = in;
+  ewald_fetch(in ? st.r2 : rc2, inv_dx, emax, etab, st.w);      // lanes outside the cutoff all fetch the row of r_c: one line for the lot
+}
+
+template <bool SAPT>
+__device__ __forceinline__ void trip_stage_b(const TripState& st, int ti, const PairParam* sp, int nt, const double* __restrict__ tt, const double* __restrict__ dtt,
+                                             double* tfx, double* tfy, double* tfz, double& fx, double& fy, double& fz, double& e_el, double& e_vdw) {
+#pragma clang fp contract(fast)
+  if (st.in) {
+    double fs, ee, ev;
+    pair_interaction_rows<SAPT>(st.r2, st.qq, sp[ti * nt + (int)(st.e >> NBR_IDX_BITS)], st.w, tt, dtt, fs, ee, ev);
+    const double gx = fs * st.dx, gy = fs * st.dy, gz = fs * st.dz;
+    fx += gx; fy += gy; fz += gz; e_el += ee; e_vdw += ev;
+    const unsigned j = st.e & NBR_IDX_MASK;
+    atomicAdd(&tfx[j], -gx); atomicAdd(&tfy[j], -gy); atomicAdd(&tfz[j], -gz);
+  }
+}
+
+// the stream of trips of one wave: rows drawn from the workgroup's LDS counter, 64 entries per trip
+struct TripCursor {
+  int a, na; unsigned s, n, k;      // current row (>= na: no more rows), its first entry, length, next entry offset
+};
+__device__ __forceinline__ void cursor_draw(TripCursor& cu, int* s_next, const unsigned* s_cnt, const unsigned* __restrict__ nbr_start, int cs, int lane) {
+  for (;;) {      // rows without entries are skipped
+    int a = 0;
+    if (lane == 0) a = atomicAdd(s_next, 1);
+    cu.a = __builtin_amdgcn_readfirstlane(a);
+    if (cu.a >= cu.na) return;
+    cu.n = s_cnt[cu.a];
+    if (cu.n == 0) continue;
+    cu.s = nbr_start[cs + cu.a]; cu.k = 0;
+    return;
+  }
+}
+// next trip of the stream: its context and its entries (a load); ctx.a = -1 when the stream has ended
+__device__ __forceinline__ unsigned cursor_next(TripCursor& cu, TripCtx& ctx, const int* __restrict__ rows, int* s_next, const unsigned* s_cnt,
+                                                const unsigned* __restrict__ nbr_start, int cs, int lane) {
+  if (cu.a >= cu.na) { ctx.a = -1; ctx.last = 0; return NBR_NONE; }
+  const unsigned kk = cu.k + (unsigned)lane;
+  const unsigned e = kk < cu.n ? (unsigned)rows[cu.s + kk] : NBR_NONE;
+  ctx.a = cu.a;
+  cu.k += 64;
+  ctx.last = cu.k >= cu.n ? 1 : 0;
+  if (ctx.last) cursor_draw(cu, s_next, s_cnt, nbr_start, cs, lane);
+  return e;
+}
+
+template <bool SAPT>
+__device__ __forceinline__ void pair_rows_pipelined(const double4* tile, double* tfx, double* tfy, double* tfz, int na, int cs, int lane, int* s_next, const unsigned* s_cnt,
+                                                    const unsigned char* s_typ, const unsigned* __restrict__ nbr_start, const int* __restrict__ rows, const PairParam* sp, int nt,
+                                                    const double2* __restrict__ etab, double inv_dx, int emax, const double* __restrict__ tt, const double* __restrict__ dtt,
+                                                    const BoxDev& box, double rc2, const double4* __restrict__ posq, const int* s_lo, const int* s_off, double& e_el, double& e_vdw) {
+  TripCursor cu; cu.na = na; cu.a = 0; cu.s = 0; cu.n = 0; cu.k = 0;
+  cursor_draw(cu, s_next, s_cnt, nbr_start, cs, lane);
+  TripCtx c0, c1, c2;
+  unsigned e1, e2;
+  TripState s0, s1;
+  const unsigned e0 = cursor_next(cu, c0, rows, s_next, s_cnt, nbr_start, cs, lane);
+  e1 = cursor_next(cu, c1, rows, s_next, s_cnt, nbr_start, cs, lane);
+  if (c0.a < 0) return;
+  trip_stage_a<SAPT>(tile, e0, c0.a, cs, posq, s_lo, s_off, box, rc2, inv_dx, emax, etab, s0);
+  double fx = 0.0, fy = 0.0, fz = 0.0;
+  while (c0.a >= 0) {
+    e2 = cursor_next(cu, c2, rows, s_next, s_cnt, nbr_start, cs, lane);                                     // entries of trip t + 2: load issued
+    if (c1.a >= 0) trip_stage_a<SAPT>(tile, e1, c1.a, cs, posq, s_lo, s_off, box, rc2, inv_dx, emax, etab, s1);      // trip t + 1: table rows requested
+    trip_stage_b<SAPT>(s0, s_typ[c0.a], sp, nt, tt, dtt, tfx, tfy, tfz, fx, fy, fz, e_el, e_vdw);             // trip t: arithmetic
+    if (c0.last) {      // (wave-uniform) the row is complete: its owner's force, reduced over the 16-lane rows, joins the tile
+      fx = row_sum16(fx); fy = row_sum16(fy); fz = row_sum16(fz);
+      if ((lane & 15) == 0) { atomicAdd(&tfx[c0.a], fx); atomicAdd(&tfy[c0.a], fy); atomicAdd(&tfz[c0.a], fz); }
+      fx = 0.0; fy = 0.0; fz = 0.0;
+    }
+    c0 = c1; s0 = s1; c1 = c2; e1 = e2;
+  }
+}
+
 template <bool SAPT, bool PRUNE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_pair_half(int c_lo, int c_hi, int3 nc, int tile_cap, const int* __restrict__ cell_start, const double4* __restrict__ posq,
                                                     const int* __restrict__ type_s, const unsigned* __restrict__ nbr_start, const unsigned* __restrict__ nbr_count,
@@ -295,6 +398,11 @@ __global__ __launch_bounds__(THREADS) void k_pair_half(int c_lo, int c_hi, int3 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int* rows = (PRUNE && mode == 2) ? nbr2 : nbr;
   double e_el = 0.0, e_vdw = 0.0;
+  if (!(PRUNE && mode != 2)) {
+    // fixed rows (pruned rows in use, or no pruning): the software-pipelined stream of 64-entry trips
+    pair_rows_pipelined<SAPT>(tile, tfx, tfy, tfz, na, cs, lane, &s_next, s_cnt, s_typ, nbr_start, rows, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, posq, s_lo, s_off, e_el, e_vdw);
+  } else {
+  // A launch that REWRITES the pruned rows (every few steps): wave per row, 128 entries per trip.
   // Rows are handed out by an LDS counter (half-list rows differ a lot in length); a wave draws its NEXT row and loads that row's first 128
   // entries before it evaluates the current one, so the list latency of a row hides behind the arithmetic of its predecessor.
   int a = 0;
@@ -320,14 +428,12 @@ __global__ __launch_bounds__(THREADS) void k_pair_half(int c_lo, int c_hi, int3 
     const unsigned s = nbr_start[i];
     double fx = 0.0, fy = 0.0, fz = 0.0;
     unsigned n2 = 0;
-    if (PRUNE && mode != 2) {
-      pair_row_half<SAPT, true>(tile, tfx, tfy, tfz, pi, ti, i, s, s + s_cnt[a], lane, rows, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, posq, s_lo, s_off, fx, fy, fz, e_el, e_vdw, nbr2 + s, rp2, n2, e0, e1);
-      if (lane == 0) count2[i] = n2;
-    } else
-      pair_row_half<SAPT, false>(tile, tfx, tfy, tfz, pi, ti, i, s, s + s_cnt[a], lane, rows, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, posq, s_lo, s_off, fx, fy, fz, e_el, e_vdw, nullptr, 0.0, n2, e0, e1);
+    pair_row_half<SAPT, true>(tile, tfx, tfy, tfz, pi, ti, i, s, s + s_cnt[a], lane, rows, sp, nt, etab, inv_dx, emax, tt, dtt, box, rc2, posq, s_lo, s_off, fx, fy, fz, e_el, e_vdw, nbr2 + s, rp2, n2, e0, e1);
+    if (lane == 0) count2[i] = n2;
     fx = row_sum16(fx); fy = row_sum16(fy); fz = row_sum16(fz);      // the four row sums meet in the LDS add
     if ((lane & 15) == 0) { atomicAdd(&tfx[a], fx); atomicAdd(&tfy[a], fy); atomicAdd(&tfz[a], fz); }
     a = an; e0 = f0; e1 = f1;
+  }
   }
   e_el = wave_sum(e_el);
   e_vdw = wave_sum(e_vdw);

@@ -80,7 +80,7 @@ def compact(d, keep_store=True):
     return out
 
 
-def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, proton_shift=0.0, so3h_eref=None, standard=False, rb=False, cf2=False, freeze=(), md_temp=300.0, **simkw):
+def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, proton_shift=0.0, so3h_eref=None, standard=False, rb=False, cf2=False, freeze=(), md_temp=300.0, nbaro=0, **simkw):
     if ONLY and name not in ONLY:
         return
     ff = forcefield.ch3so3h_water_forcefield()
@@ -106,7 +106,7 @@ def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=Fa
         idx = {n: i for i, n in enumerate(p.atype_names)}
         mass = np.array([p.atype_mass[idx[a]] for a in s.atom_names])
         vel = synth.maxwell_boltzmann(mass, md_temp, seed + 100)
-    d = ref_inputs.run_reference(s, ff, evb=evb, velocities=vel, nsteps=md_steps, **simkw)
+    d = ref_inputs.run_reference(s, ff, evb=evb, velocities=vel, nsteps=md_steps, nbaro=nbaro, **simkw)
     out = compact(d, keep_store=keep_store)
     out["gen_n_side"] = np.array(n_side)
     out["gen_n_diabat"] = np.array(n_diabat)
@@ -148,6 +148,12 @@ def main():
     case("md_std_n6_rebuild_s21", 6, 1, 21, evb=False, md_steps=60, md_temp=600.0, **small)
     case("md_evb_n6_d4_rebuild_s24", 6, 4, 24, evb=True, md_steps=60, md_temp=600.0, keep_store=False, **small)      # 7 rebuilds, D = 4 -> 5 -> 6
     case("md_evb_n6_d4_drop_s22", 6, 4, 22, evb=True, md_steps=60, md_temp=600.0, keep_store=False, **small)         # 6 rebuilds, D = 4 -> 1
+    # Langevin leap-frog kicks (langevin_integrator, src/md_integration.f90:186-228) at temperature 0: the noise term vanishes, what is left
+    # (friction + force kick) is deterministic
+    case("md_std_n6_nvt0_s16", 6, 1, 16, evb=False, md_steps=4, ensemble="NVT", temperature=0.0, friction_coeff=5.0, **small)
+    # Monte-Carlo barostat (monte_carlo_barostat, :231-386): 2 MD steps, then 6 x (move, MD step) at 2 000 bar with a 0.4 % trial step;
+    # baro_rand holds the two random numbers each move drew (trial length, Metropolis test)
+    case("npt_std_n6_s15", 6, 1, 15, evb=False, md_steps=2, nbaro=6, pressure=2000.0, baroscale=0.004, **small)
     # principal-diabat switch (src/ms_evb.f90:218-227).  Acid proton started next to its acceptor and the acid's reference energy
     # raised by 850 kJ/mol (the unrelaxed lattice otherwise keeps the acid diabat ~800 kJ/mol below): the reference's FIRST EVB force
     # call (during its initialisation) hands the proton to the water, so everything this fixture holds - 'xyz', topology, Hamiltonian,

@@ -19,7 +19,9 @@
 ! out), hence this driver.  Output: a flat tagged binary stream read by
 ! oracle/refdump.py.
 !
-! usage: ref_dump gro ffpmt top simpmt traj_out log_out hop_out a_out DUMP [VELFILE NSTEPS]
+! usage: ref_dump gro ffpmt top simpmt traj_out log_out hop_out a_out DUMP [VELFILE NSTEPS [NBARO]]
+!        NBARO > 0: after the NSTEPS steps, NBARO x (monte_carlo_barostat move, md_integrate_atomic step) as mc_sample orders them
+!        (src/md_integration.f90:28-37), with the random numbers each move draws recorded next to its outcome
 !==============================================================================
 module dumpio
   implicit none
@@ -107,12 +109,21 @@ program ref_dump
   integer, allocatable :: itmp(:), itmp2(:,:)
   real*8, allocatable :: rtmp(:,:), vel(:,:), etraj(:,:)
   integer, allocatable :: vflag(:), ndia(:)
+  integer :: nbaro, i_baro, nseed
+  integer, allocatable :: rstate(:)
+  real*8 :: r12(2)
+  real*8, allocatable :: baro_rand(:,:), baro_box(:), baro_epot(:), baro_scale(:), baro_xyz(:,:,:), baro_epot_md(:)
   real*8 :: Epot
 
   nargs_cli = command_argument_count()
   if (nargs_cli < 9) stop "usage: ref_dump <8 reference args> DUMP [VELFILE NSTEPS]"
   call get_command_argument(9, dumpfile)
   nsteps = 0
+  nbaro = 0
+  if (nargs_cli >= 12) then
+     call get_command_argument(12, arg)
+     read(arg,*) nbaro
+  end if
   if (nargs_cli >= 11) then
      call get_command_argument(10, velfile)
      call get_command_argument(11, arg)
@@ -400,6 +411,7 @@ program ref_dump
      call dump_i4('md_n_diabat', ndia, (/nsteps/))
      call dump_is('md_nsteps', nsteps)
      call dump_r8('md_energy', etraj, (/2,nsteps/))
+     call dump_r8('md_E_terms', (/ system_data%E_elec, system_data%E_vdw, system_data%E_bond, system_data%E_angle, system_data%E_dihedral /), (/5/))
      call dump_r8('md_xyz', atom_data%xyz, (/3,N/))
      call dump_r8('md_velocity', atom_data%velocity, (/3,N/))
      call dump_r8('md_force', atom_data%force, (/3,N/))
@@ -417,6 +429,51 @@ program ref_dump
      call dump_i4('md_mol_type_index', itmp, (/M/))
      deallocate(itmp)
      if (ms_evb_simulation == "yes") call dump_is('md_hydronium_molecule', hydronium_molecule_index(1))
+     !----- the reference's own writers on the end state: trajectory frame + log block (print_step, src/general_routines.f90:870) and the
+     !      velocity checkpoint (print_velocities_checkpoint, :997); read back as text by oracle/ref_inputs.py
+     call print_step( file_io_data%ofile_traj_file_h, file_io_data%ofile_log_file_h, nsteps, system_data, integrator_data, molecule_data, atom_data )
+     open(unit=file_io_data%ifile_velocity_file_h, file='vel_checkpoint.out', status='replace')
+     call print_velocities_checkpoint( file_io_data%ifile_velocity_file_h, nsteps, integrator_data%delta_t, system_data, molecule_data, atom_data )
+     close(file_io_data%ifile_velocity_file_h)
+     flush(file_io_data%ofile_traj_file_h)
+     flush(file_io_data%ofile_log_file_h)
+  end if
+
+  !----- optional: Monte-Carlo barostat moves (src/md_integration.f90:231-386), each followed by one MD step as in mc_sample (:28-37)
+  if (nbaro > 0) then
+     call random_seed(size=nseed)
+     allocate(rstate(nseed), baro_rand(2,nbaro), baro_box(nbaro), baro_epot(nbaro), baro_scale(nbaro), baro_xyz(3,N,nbaro), baro_epot_md(nbaro))
+     rstate = 20240901
+     call random_seed(put=rstate)
+     call dump_s('baro_pressure', system_data%pressure)
+     call dump_s('baro_temperature', system_data%temperature)
+     call dump_s('baro_scale0', system_data%baroscale)
+     call dump_s('baro_box0', system_data%box(1,1))
+     call dump_s('baro_epot0', system_data%potential_energy)
+     do i_baro = 1, nbaro
+        ! the two numbers the move will draw (trial length, Metropolis test): peek at the generator, put its state back
+        call random_seed(get=rstate)
+        call random_number(r12)
+        call random_seed(put=rstate)
+        baro_rand(:,i_baro) = r12
+        call monte_carlo_barostat( system_data, molecule_data, atom_data, integrator_data, verlet_list_data, PME_data, file_io_data )
+        baro_box(i_baro) = system_data%box(1,1)
+        baro_epot(i_baro) = system_data%potential_energy
+        baro_scale(i_baro) = system_data%baroscale
+        baro_xyz(:,:,i_baro) = atom_data%xyz
+        trajectory_step = nsteps + i_baro
+        call md_integrate_atomic( system_data, molecule_data, atom_data, integrator_data, verlet_list_data, PME_data, file_io_data )
+        baro_epot_md(i_baro) = system_data%potential_energy
+     end do
+     call dump_is('baro_n', nbaro)
+     call dump_r8('baro_rand', baro_rand, (/2,nbaro/))
+     call dump_r8('baro_box', baro_box, (/nbaro/))
+     call dump_r8('baro_epot', baro_epot, (/nbaro/))
+     call dump_r8('baro_scale', baro_scale, (/nbaro/))
+     call dump_r8('baro_xyz', baro_xyz, (/3,N,nbaro/))
+     call dump_r8('baro_epot_md', baro_epot_md, (/nbaro/))
+     call dump_r8('baro_end_xyz', atom_data%xyz, (/3,N/))
+     call dump_r8('baro_end_velocity', atom_data%velocity, (/3,N/))
   end if
 
   call dump_close()

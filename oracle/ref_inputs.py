@@ -114,15 +114,16 @@ def write_top(path, ff):
 
 
 def write_simpmt(path, *, n_step=1, rc=8.0, rv=9.5, nslist=10, alpha=0.3, pme_grid=32, n_exclusions=2,
-                 delta_t=0.0005, temperature=300.0, lj_comb_rule="opls"):
+                 delta_t=0.0005, temperature=300.0, lj_comb_rule="opls", ensemble="NVE", friction_coeff=None, pressure=None, baroscale=None):
     with open(path, "w") as f:
-        f.write("Simulation Methodology\nensemble NVE\nlj_comb_rule %s\ngrid_Tang_Toennies yes\n" % lj_comb_rule)
+        f.write("Simulation Methodology\nensemble %s\nlj_comb_rule %s\ngrid_Tang_Toennies yes\n" % (ensemble, lj_comb_rule))
         f.write("Simulation Parameters\n")
-        for k, v in (("n_step", n_step), ("n_output", 1000000), ("n_exclusions", n_exclusions),
+        extra = [(k, v) for k, v in (("friction_coeff", friction_coeff), ("pressure", pressure), ("baroscale", baroscale)) if v is not None]
+        for k, v in [("n_step", n_step), ("n_output", 1000000), ("n_exclusions", n_exclusions)] + extra + list((
                      ("temperature", temperature), ("delta_t", delta_t), ("real_space_cutoff", rc),
                      ("na_nslist", nslist), ("nb_nslist", nslist), ("nc_nslist", nslist),
                      ("verlet_cutoff", rv), ("alpha_sqrt", alpha), ("pme_grid", pme_grid),
-                     ("spline_order", 6), ("n_threads", 1), ("debug", 0)):
+                     ("spline_order", 6), ("n_threads", 1), ("debug", 0))):
             f.write("%s %r\n" % (k, v))
 
 
@@ -151,7 +152,7 @@ def read_dump(path):
     return out
 
 
-def run_reference(system, ff, *, evb, workdir=None, velocities=None, nsteps=0, keep=False, **simkw):
+def run_reference(system, ff, *, evb, workdir=None, velocities=None, nsteps=0, keep=False, nbaro=0, **simkw):
     """Runs the real reference (oracle/_ref/ref_dump_*) on ``system`` and returns its dump."""
     exe = os.path.join(HERE, "_ref", "ref_dump_evb" if evb else "ref_dump_std")
     if not os.path.exists(exe):
@@ -169,13 +170,17 @@ def run_reference(system, ff, *, evb, workdir=None, velocities=None, nsteps=0, k
             os.remove(p)
     if nsteps > 0:
         np.ascontiguousarray(velocities, dtype="<f8").tofile(os.path.join(tmp, "vel.bin"))
-        args += ["vel.bin", str(nsteps)]
+        args += ["vel.bin", str(nsteps)] + ([str(nbaro)] if nbaro else [])
     env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
     r = subprocess.run("ulimit -s unlimited; exec " + " ".join(args), shell=True, cwd=tmp, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0 or "ref_dump finished OK" not in r.stdout:
         raise RuntimeError("reference run failed in %s:\n%s" % (tmp, r.stdout[-3000:]))
     d = read_dump(os.path.join(tmp, "dump.bin"))
+    if nsteps > 0:      # what the reference's own writers left behind (text, as bytes)
+        for key, fn in (("file_traj", "traj.gro"), ("file_log", "out.log"), ("file_vel", "vel_checkpoint.out")):
+            with open(os.path.join(tmp, fn), "rb") as fh:
+                d[key] = np.frombuffer(fh.read(), dtype=np.uint8).copy()
     if not keep and workdir is None:
         import shutil
         shutil.rmtree(tmp, ignore_errors=True)

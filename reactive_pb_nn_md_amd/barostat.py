@@ -18,6 +18,10 @@ class MCBarostat:
         self.rng = np.random.default_rng(seed)
         self.n_trials = self.n_accept = 0
         self.last = None
+        self.uniforms = None      # optional iterator of uniform deviates used INSTEAD of the generator (replaying a reference run's draws)
+
+    def _uniform(self):
+        return float(next(self.uniforms)) if self.uniforms is not None else self.rng.random()
 
     @staticmethod
     def scaled_positions(xyz, mass, mol_atoms, scale):
@@ -39,7 +43,7 @@ class MCBarostat:
         old_len, v_old = box[0], box[0] ** 3
         x_old = h.get_positions()
         hyd_old = h.topology()["hydronium_molecule"] if use_evb else 0
-        new_len = old_len + old_len * self.baroscale * (self.rng.random() * 2.0 - 1.0)
+        new_len = old_len + old_len * self.baroscale * (self._uniform() * 2.0 - 1.0)
         h.set_box(np.full(3, new_len))
         h.set_positions(self.scaled_positions(x_old, mass, mol_atoms, new_len / old_len))
         e_new = self._energy(h, use_evb)
@@ -47,7 +51,7 @@ class MCBarostat:
         if use_evb and h.topology()["hydronium_molecule"] != hyd_old:
             w = -1.0
         accepted = True
-        if w >= 0.0 and self.rng.random() > np.exp(-w / kT):
+        if w >= 0.0 and self._uniform() > np.exp(-w / kT):
             accepted = False
             h.set_box(np.full(3, old_len))
             h.set_positions(x_old)

@@ -246,9 +246,12 @@ __device__ __forceinline__ void pair_row_half(const double4* tile, double* tfx, 
 struct TripCtx { int a; int last; };      // wave-uniform: row (atom of the cell) of the trip, 1 = last trip of that row
 struct TripState { double dx, dy, dz, r2, qq; EwaldRows w; unsigned e; bool in; };
 
+// Stage A and the arithmetic of stage B are BRANCH-FREE (one basic block): with four waves per SIMD the kernel is bound by the issue
+// latency of each wave's dependent fp64 chain, and the compiler interleaves the two independent chains (trip t + 1's geometry, trip t's
+// interaction) only inside a block.  Lanes without a pair, or outside the cutoff, compute on r = r_c and their results are discarded;
+// the exact cutoff decision for a pair within rounding of r_c (min_image_r2, rare) is made after the arithmetic.
 template <bool SAPT>
-__device__ __forceinline__ void trip_stage_a(const double4* tile, unsigned e, int a, int cs, const double4* __restrict__ posq, const int* s_lo, const int* s_off, const BoxDev& box,
-                                             double rc2, double inv_dx, int emax, const double2* __restrict__ etab, TripState& st) {
+__device__ __forceinline__ void trip_stage_a(const double4* tile, unsigned e, int a, double rc2, double inv_dx, int emax, const double2* __restrict__ etab, TripState& st) {
 #pragma clang fp contract(fast)
   const bool v = e != NBR_NONE;
   const unsigned j = v ? (e & NBR_IDX_MASK) : 0u;
@@ -257,26 +260,40 @@ __device__ __forceinline__ void trip_stage_a(const double4* tile, unsigned e, in
   st.r2 = st.dx * st.dx + st.dy * st.dy + st.dz * st.dz;
   st.qq = pi.w * pj.w;
   st.e = e;
-  bool in = v && st.r2 < rc2;
-  const bool tie = v && fabs(st.r2 - rc2) < 1e-9 * rc2;
+  st.in = v;
+  ewald_fetch(v ? fmin(st.r2, rc2) : rc2, inv_dx, emax, etab, st.w);      // lanes outside the cutoff all fetch the row of r_c: one line for the lot
+}
+
+template <bool SAPT>
+__device__ __forceinline__ void trip_stage_b(const TripState& st, int a, int cs, int ti, const PairParam* sp, int nt, const double* __restrict__ tt, const double* __restrict__ dtt,
+                                             const double4* __restrict__ posq, const int* s_lo, const int* s_off, const BoxDev& box, double rc2,
+                                             double* tfx, double* tfy, double* tfz, double& fx, double& fy, double& fz, double& e_el, double& e_vdw) {
+#pragma clang fp contract(fast)
+  const unsigned j = st.e & NBR_IDX_MASK;
+  const PairParam& pp = sp[ti * nt + (st.in ? (int)(st.e >> NBR_IDX_BITS) : 0)];
+  double fs, ee, ev;
+  if (SAPT) pair_interaction_rows<true>(fmin(st.r2, rc2), st.qq, pp, st.w, tt, dtt, fs, ee, ev);
+  else {      // Ewald + LJ without a branch (pair_interaction_rows' arithmetic; a pair type without LJ gets the factor 0)
+    const double inv_r = st.w.inv_r, inv_r2 = inv_r * inv_r;
+    const double c2 = (st.w.x1 + 1.0) - (double)st.w.idx, c1 = 1.0 - c2;
+    const double evv = c1 * st.w.t0.x + c2 * st.w.t1.x, sv = c1 * st.w.t0.y + c2 * st.w.t1.y;
+    const double qr = st.qq * inv_r;
+    ee = qr * evv;
+    fs = qr * inv_r2 * sv;
+    const double lj = pp.type == 0 ? 1.0 : 0.0;
+    const double r6i = inv_r2 * inv_r2 * inv_r2, r12i = r6i * r6i;
+    ev = lj * (pp.p[0] * r12i - pp.p[1] * r6i);
+    fs += lj * inv_r2 * (12.0 * pp.p[0] * r12i - 6.0 * pp.p[1] * r6i);
+  }
+  bool in = st.in && st.r2 < rc2;
+  const bool tie = st.in && fabs(st.r2 - rc2) < 1e-9 * rc2;
   if (__ballot(tie)) {      // rare: on the cutoff to within rounding - the reference's arithmetic on the raw coordinates decides
     double ux, uy, uz;
     if (tie) in = min_image_r2(posq[cs + a], posq[tile_to_sorted((int)j, s_lo, s_off)], box, ux, uy, uz) < rc2;
   }
-  st.in = in;
-  ewald_fetch(in ? st.r2 : rc2, inv_dx, emax, etab, st.w);      // lanes outside the cutoff all fetch the row of r_c: one line for the lot
-}
-
-template <bool SAPT>
-__device__ __forceinline__ void trip_stage_b(const TripState& st, int ti, const PairParam* sp, int nt, const double* __restrict__ tt, const double* __restrict__ dtt,
-                                             double* tfx, double* tfy, double* tfz, double& fx, double& fy, double& fz, double& e_el, double& e_vdw) {
-#pragma clang fp contract(fast)
-  if (st.in) {
-    double fs, ee, ev;
-    pair_interaction_rows<SAPT>(st.r2, st.qq, sp[ti * nt + (int)(st.e >> NBR_IDX_BITS)], st.w, tt, dtt, fs, ee, ev);
+  if (in) {
     const double gx = fs * st.dx, gy = fs * st.dy, gz = fs * st.dz;
     fx += gx; fy += gy; fz += gz; e_el += ee; e_vdw += ev;
-    const unsigned j = st.e & NBR_IDX_MASK;
     atomicAdd(&tfx[j], -gx); atomicAdd(&tfy[j], -gy); atomicAdd(&tfz[j], -gz);
   }
 }
@@ -323,12 +340,12 @@ __device__ __forceinline__ void pair_rows_pipelined(const double4* tile, double*
   const unsigned e0 = cursor_next(cu, c0, rows, s_next, s_cnt, nbr_start, cs, lane);
   e1 = cursor_next(cu, c1, rows, s_next, s_cnt, nbr_start, cs, lane);
   if (c0.a < 0) return;
-  trip_stage_a<SAPT>(tile, e0, c0.a, cs, posq, s_lo, s_off, box, rc2, inv_dx, emax, etab, s0);
+  trip_stage_a<SAPT>(tile, e0, c0.a, rc2, inv_dx, emax, etab, s0);
   double fx = 0.0, fy = 0.0, fz = 0.0;
   while (c0.a >= 0) {
     e2 = cursor_next(cu, c2, rows, s_next, s_cnt, nbr_start, cs, lane);                                     // entries of trip t + 2: load issued
-    if (c1.a >= 0) trip_stage_a<SAPT>(tile, e1, c1.a, cs, posq, s_lo, s_off, box, rc2, inv_dx, emax, etab, s1);      // trip t + 1: table rows requested
-    trip_stage_b<SAPT>(s0, s_typ[c0.a], sp, nt, tt, dtt, tfx, tfy, tfz, fx, fy, fz, e_el, e_vdw);             // trip t: arithmetic
+    trip_stage_a<SAPT>(tile, c1.a >= 0 ? e1 : NBR_NONE, max(c1.a, 0), rc2, inv_dx, emax, etab, s1);      // trip t + 1: table rows requested (a stream that has ended runs an empty trip)
+    trip_stage_b<SAPT>(s0, c0.a, cs, s_typ[c0.a], sp, nt, tt, dtt, posq, s_lo, s_off, box, rc2, tfx, tfy, tfz, fx, fy, fz, e_el, e_vdw);      // trip t: arithmetic
     if (c0.last) {      // (wave-uniform) the row is complete: its owner's force, reduced over the 16-lane rows, joins the tile
       fx = row_sum16(fx); fy = row_sum16(fy); fz = row_sum16(fz);
       if ((lane & 15) == 0) { atomicAdd(&tfx[c0.a], fx); atomicAdd(&tfy[c0.a], fy); atomicAdd(&tfz[c0.a], fz); }

@@ -118,19 +118,37 @@ def write_gro_frame(f, title, mol_names, mol_atoms, atom_names, xyz, box):
     for im, atoms in enumerate(mol_atoms):
         for a in atoms:
             x = xyz[a] / 10.0
-            f.write("%5d%-5s%5s%5d%8.3f%8.3f%8.3f\n" % ((im + 1) % 100000, mol_names[im][:5], atom_names[a][:5], count % 100000, x[0], x[1], x[2]))
+            f.write("%5d%5s%5s%5d%8.3f%8.3f%8.3f\n" % ((im + 1) % 100000, mol_names[im][:5], atom_names[a][:5], count % 100000, x[0], x[1], x[2]))      # both names right-justified: the reference keeps them that way (trim_end, src/general_routines.f90:767)
             count += 1
     b = np.asarray(box) / 10.0
     f.write("%7.4f%7.4f%7.4f%7.4f%7.4f%7.4f%7.4f%7.4f%7.4f\n" % (b[0], b[1], b[2], 0, 0, 0, 0, 0, 0))
 
 
+def fortran_e(x, w=16, d=6):
+    """Fortran Ew.d editing as the reference's compilers print it: 0.dddddd E+ee (mantissa in [0.1, 1)), right-justified in w columns"""
+    from decimal import Decimal, ROUND_HALF_EVEN
+    x = float(x)
+    if x != x or x in (float("inf"), float("-inf")):
+        return ("NaN" if x != x else ("Infinity" if x > 0 else "-Infinity")).rjust(w)
+    if x == 0.0:
+        body = "0." + "0" * d + "E+00"
+    else:
+        dx = Decimal(abs(x))
+        e = dx.adjusted() + 1                                     # |x| = m 10^e with m in [0.1, 1)
+        m = (dx.scaleb(-e)).quantize(Decimal(1).scaleb(-d), rounding=ROUND_HALF_EVEN)
+        if m >= 1:                                                # 0.9999996 rounds up to 1.000000
+            m = (m / 10).quantize(Decimal(1).scaleb(-d)); e += 1
+        body = "0." + str(m).split(".")[1] + ("E%+03d" % e if abs(e) < 100 else "%+04d" % e)
+    return (("-" if x < 0 else "") + body).rjust(w)
+
+
 def write_log_step(f, i_step, delta_t, e_pot, e_kin, terms=None):
     """print_step (src/general_routines.f90:870): terms = (E_elec, E_vdw, E_bond, E_angle, E_dihedral) outside EVB runs"""
     f.write(" i_step , time(ps), potential energy (kJ/mol), kinetic energy (kJ/mol)\n")
-    f.write("%9d%10.3f%16.6E%16.6E\n" % (i_step, i_step * delta_t, e_pot, e_kin))
+    f.write("%9d%10.3f%s%s\n" % (i_step, i_step * delta_t, fortran_e(e_pot), fortran_e(e_kin)))      # '(I9,F10.3,2E16.6)'
     if terms is not None:
         f.write(" Electrostatic ,   VDWs ,   Bond   ,   Angle  ,  Dihedral\n")
-        f.write("".join("%16.6E" % t for t in terms) + "\n")
+        f.write("".join(fortran_e(t) for t in terms) + "\n")                                         # '(5E16.6)'
     f.write(" ------------------------------\n")
 
 
@@ -138,7 +156,7 @@ def write_velocity_checkpoint(f, i_step, mol_names, mol_atoms, atom_names, vel):
     f.write(" step  %d\n" % i_step)
     for im, atoms in enumerate(mol_atoms):
         for k, a in enumerate(atoms):
-            f.write("%5d%-5s%5s%5d%14.6f%14.6f%14.6f\n" % ((im + 1) % 100000, mol_names[im][:5], atom_names[a][:5], k + 1, vel[a, 0], vel[a, 1], vel[a, 2]))
+            f.write("%5d%5s%5s%5d%14.6f%14.6f%14.6f\n" % ((im + 1) % 100000, mol_names[im][:5], atom_names[a][:5], k + 1, vel[a, 0], vel[a, 1], vel[a, 2]))
 
 
 def read_velocity_checkpoint(path, n_atom, step=None):

@@ -511,6 +511,69 @@ def test_langevin_step_against_host_restatement(evb, frozen):
     h.close()
 
 
+def test_langevin_kicks_against_reference_at_zero_temperature():
+    """langevin_integrator (src/md_integration.f90:186-228) in the REAL reference with temperature 0 (the noise term vanishes): four steps of
+    the friction + force kick, leap-frog positions, momentum removal - energies, positions, velocities and forces of the reference's run"""
+    g = golden("md_std_n6_nvt0_s16")
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    for k, v in (("ensemble_nvt", 1), ("friction_coeff", 5.0), ("temperature", 0.0)):
+        h.set_option(k, v)
+    h.set_velocities(g["md_velocity0"])
+    h.calculate_total_force_energy(want_force=False)
+    assert np.abs(h.get_forces() - g["md_F0"]).max() < F_TOL
+    n = int(g["md_nsteps"][0])
+    en = h.md_integrate_atomic(n, spec.delta_t, use_evb=False)
+    assert np.abs(en[:, 0] - g["md_energy"][:, 0]).max() < 1e-9 * np.abs(g["md_energy"][:, 0]).max()
+    assert np.abs(en[:, 1] - g["md_energy"][:, 1]).max() < 1e-8 * np.abs(g["md_energy"][:, 1]).max()
+    assert np.abs(h.get_positions() - g["md_xyz"]).max() < 1e-10 and np.abs(h.get_velocities() - g["md_velocity"]).max() < 1e-9
+    assert np.abs(h.get_forces() - g["md_force"]).max() < 1e-7
+    # the friction is really on: the same steps without it end elsewhere
+    h2 = api.MsEvbHip(spec)
+    h2.set_velocities(g["md_velocity0"])
+    h2.calculate_total_force_energy(want_force=False)
+    h2.md_integrate_atomic(n, spec.delta_t, use_evb=False)
+    assert np.abs(h2.get_velocities() - g["md_velocity"]).max() > 1e-3
+    h.close(); h2.close()
+
+
+def test_monte_carlo_barostat_against_reference():
+    """monte_carlo_barostat (src/md_integration.f90:231-386) of the REAL reference: two MD steps, then six (trial move, MD step) pairs as
+    mc_sample orders them (:28-37), at 2 000 bar with a 0.4 % trial step.  The fixture holds the random numbers every move drew; replayed
+    through barostat.MCBarostat on the GPU library they must give the reference's decisions (2 accepted, 4 rejected), box lengths,
+    coordinates after every move and energies, and the same trajectory in between (msevb_set_box = periodic_box_change, src/pme.f90:634)."""
+    from reactive_pb_nn_md_amd import barostat
+    g = golden("npt_std_n6_s15")
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    h.set_velocities(g["md_velocity0"])
+    h.calculate_total_force_energy(want_force=False)
+    en = h.md_integrate_atomic(int(g["md_nsteps"][0]), spec.delta_t, use_evb=False)
+    assert np.abs(en[:, 0] - g["md_energy"][:, 0]).max() < 1e-9 * np.abs(g["md_energy"][:, 0]).max()
+    mol_atoms = [list(range(f, f + n)) for f, n in zip(spec.mol_first, spec.mol_natom)]
+    b = barostat.MCBarostat(float(g["baro_pressure"][0]), float(g["baro_temperature"][0]), baroscale=float(g["baro_scale0"][0]))
+    e_now = en[-1, 0]
+    assert rel(e_now, g["baro_epot0"][0]) < E_RTOL
+    box = float(g["baro_box0"][0])
+    n_acc = 0
+    for k in range(int(g["baro_n"][0])):
+        b.uniforms = iter(g["baro_rand"][k])      # (trial length, Metropolis test); a move that is accepted with w < 0 leaves the second one to the next move
+        acc, e_now = b.move(h, e_now, False, mol_atoms, spec.mass, spec.n_mole)
+        new_box = float(g["baro_box"][k])
+        assert acc == (abs(new_box - box) > 1e-12), k
+        n_acc += acc
+        box = new_box
+        assert abs(float(np.asarray(h.spec.box)[0]) - box) < 1e-12 and rel(e_now, g["baro_epot"][k]) < 1e-10, k
+        assert np.abs(h.get_positions() - g["baro_xyz"][k]).max() < 1e-10, k
+        assert abs(b.baroscale - g["baro_scale"][k]) < 1e-15
+        e_md = h.md_integrate_atomic(1, spec.delta_t, use_evb=False)
+        assert rel(e_md[0, 0], g["baro_epot_md"][k]) < 1e-9, k
+        e_now = e_md[0, 0]
+    assert 0 < n_acc < int(g["baro_n"][0])      # the fixture holds accepted AND rejected moves
+    assert np.abs(h.get_positions() - g["baro_end_xyz"]).max() < 1e-9 and np.abs(h.get_velocities() - g["baro_end_velocity"]).max() < 1e-8
+    h.close()
+
+
 def test_langevin_thermostat_reaches_its_temperature():
     """strong friction on an (initially much too hot) lattice of water: the kinetic temperature settles at the thermostat's.
     Water only - the example force field's acid proton carries no repulsion outside the EVB terms and collapses onto a water

@@ -227,6 +227,46 @@ def test_trajectory_frame_and_velocity_checkpoint_round_trip(tmp_path):
     assert np.abs(v1 - v).max() < 1e-6
 
 
+@pytest.mark.parametrize("name", ["md_std_n6_s4", "md_evb_n6_d2_s5"])
+def test_output_writers_against_files_the_reference_wrote(name):
+    """io.py's writers against the trajectory frame, log block and velocity checkpoint the REAL reference wrote for the end state of a
+    fixture's MD steps (print_gro_file / print_step / print_velocities_checkpoint, src/general_routines.f90:906, :870, :997; kept by
+    oracle/ref_driver.f90).  Formatted records must agree byte for byte; list-directed records (the reference writes the frame title, the
+    atom count and the captions with `write(*,*)`, whose spacing is the compiler's) token by token."""
+    import io as _io
+    from conftest import golden
+    from reactive_pb_nn_md_amd import io
+    g = golden(name)
+    s = synth.make_system(int(g["gen_n_side"]), n_diabat=int(g["gen_n_diabat"]), seed=int(g["gen_seed"]))
+    mol_atoms = [list(range(f, f + n)) for f, n in zip(s.mol_first, s.mol_natom)]
+    n = int(g["md_nsteps"][0])
+    dt = float(g["delta_t"][0])
+
+    def compare(mine, ref, formatted_from=0):
+        a, b = mine.splitlines(), ref.splitlines()
+        assert len(a) == len(b)
+        for k, (x, y) in enumerate(zip(a, b)):
+            if k < formatted_from:
+                tx, ty = x.split(), y.split()
+                assert len(tx) == len(ty) and all(p == q or float(p) == float(q) for p, q in zip(tx, ty)), (k, x, y)
+            else:
+                assert x == y, (k, x, y)
+
+    f = _io.StringIO()
+    io.write_gro_frame(f, "step  %d time(ps) %r" % (n, n * dt), s.mol_names, mol_atoms, s.atom_names, g["md_xyz"], s.box)
+    compare(f.getvalue(), bytes(g["file_traj"]).decode(), formatted_from=2)
+    f = _io.StringIO()
+    io.write_velocity_checkpoint(f, n, s.mol_names, mol_atoms, s.atom_names, g["md_velocity"])
+    compare(f.getvalue(), bytes(g["file_vel"]).decode(), formatted_from=1)
+    f = _io.StringIO()
+    evb = name.startswith("md_evb")
+    io.write_log_step(f, n, dt, g["md_energy"][-1, 0], g["md_energy"][-1, 1], None if evb else g["md_E_terms"])
+    mine, ref = f.getvalue().splitlines(), bytes(g["file_log"]).decode().splitlines()
+    ref = ref[-len(mine):]      # the log also holds what initialisation printed
+    for x, y in zip(mine, ref):
+        assert x == y if x[:1] == " " and x.strip()[:1] in "0123456789-" or x.strip().startswith("-") and "E" in x else x.split() == y.split(), (x, y)
+
+
 def test_monte_carlo_barostat_logic():
     """monte_carlo_barostat (src/md_integration.f90:229-386) on a stub handle with a known E(L): acceptance weight, rigid scaling of
     the molecules' centres of mass, forced acceptance when the excess proton moved, step-size adaptation"""

@@ -689,7 +689,7 @@ def test_command_line_run_and_restart(tmp_path):
     e0, _ = h.ms_evb_calculate_total_force_energy(want_force=False)
     h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 11))
     en = h.md_integrate_atomic(8, spec.delta_t, use_evb=True)
-    assert rel(float(log[0][2]), e0) < 1e-6 and rel(float(log[1][2]), en[3, 0]) < 1e-6 and rel(float(log[2][2]), en[7, 0]) < 1e-6
+    assert rel(float(log[0][2]), e0) < 1e-5 and rel(float(log[1][2]), en[3, 0]) < 1e-5 and rel(float(log[2][2]), en[7, 0]) < 1e-5      # E16.6 as the reference prints it: six significant digits
     assert rel(float(log[2][3]), en[7, 1]) < 1e-6
     # the diabat table of print_evb_trajectory_data: one block per printed step, coefficients of the last one = c_d^2 of the API run
     txt_log = open(d + "/run.log").read()

@@ -281,7 +281,13 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             wl = tj.get("_workload", {})
-            if dom in tj and world == 1 and wl.get("n_atoms") == spec.n_atom and wl.get("pme_grid") == spec.pme_grid and use_evb:
+            import glob
+            import hashlib
+            hh = hashlib.sha256()
+            for fsrc in sorted(glob.glob(os.path.join(ROOT, "reactive_pb_nn_md_amd", "csrc", "*.h*"))):
+                hh.update(open(fsrc, "rb").read())
+            # the PMC passes are a separate (committed) measurement: only quoted when they were taken on THESE kernel sources, this workload, default options
+            if dom in tj and world == 1 and wl.get("n_atoms") == spec.n_atom and wl.get("pme_grid") == spec.pme_grid and use_evb and not args.opt and tj.get("_build") == hh.hexdigest():
                 traffic = int(tj[dom]["hbm_bytes_per_launch"])
         except (OSError, ValueError, KeyError):
             pass

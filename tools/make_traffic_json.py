@@ -1,11 +1,24 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from a tools/profile_gpu.sh output directory: per-launch HBM traffic of the kernels bench.py may report as
-dominant (FETCH_SIZE and WRITE_SIZE from their own --pmc passes, KiB -> bytes, NO gfx950 x2 correction applied: the pair loop's loads
-are 4-B coalesced and 32-B gathers, not the 16-B/lane streaming pattern that correction is calibrated for - MI355X_MICROARCH.md)."""
-import glob, json, os, sqlite3, sys
+"""traffic.json from a tools/profile_round.sh output directory: per-launch HBM traffic of the kernels bench.py may report as dominant
+(FETCH_SIZE and WRITE_SIZE from their own --pmc passes, KiB -> bytes, NO gfx950 x2 correction applied: the pair loop's loads are 4-B coalesced
+list reads and LDS-tile staging, not the 16-B/lane streaming pattern that correction is calibrated for - MI355X_MICROARCH.md).
+'_build' is the sha256 of the kernel sources the numbers were measured on: bench.py reports traffic = null when its own sources differ.
+    python tools/make_traffic_json.py PROF_DIR [OUT.json]"""
+import glob, hashlib, json, os, sqlite3, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = sys.argv[1]
-phase_of = {"k_pair": "real space (pair loop)", "k_stencil_gather": "ms-evb reciprocal space", "k_pme_spread_tiles": "Q_grid (spread)",
-            "k_pme_gather": "Q grid derivatives (gather)", "k_molecules": "intra-molecular (non-bonded + bonded)"}
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "traffic.json")
+phase_of = {"k_pair_half": "real space (pair loop)", "k_pair": "real space (pair loop)", "k_pme_spread_tiles": "Q_grid (spread)",
+            "k_pme_gather_tiles": "Q grid derivatives (gather)", "k_molecules": "intra-molecular (non-bonded + bonded)"}
+
+
+def build_id():
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "reactive_pb_nn_md_amd", "csrc", "*.h*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 out = {}
 for sub, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     f = glob.glob(os.path.join(d, sub, "**", "*results.db"), recursive=True)[0]
@@ -14,9 +27,12 @@ for sub, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
         if short in phase_of:
             e = out.setdefault(phase_of[short], {"kernel": short, "source": os.path.basename(d.rstrip("/"))})
-            e[key.lower() + "_bytes_per_launch"] = v / n * 1024.0
+            if e["kernel"] != short:
+                continue
+            e[key.lower() + "_bytes_per_launch"] = e.get(key.lower() + "_bytes_per_launch", 0.0) + v / n * 1024.0
 for e in out.values():
     e["hbm_bytes_per_launch"] = e.get("fetch_size_bytes_per_launch", 0.0) + e.get("write_size_bytes_per_launch", 0.0)
 out["_workload"] = {"n_atoms": 98220, "n_diabats": 8, "pme_grid": 64, "note": "bench.py default workload (configs[2])"}
-json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"), "w"), indent=1)
+out["_build"] = build_id()
+json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -74,6 +74,7 @@ int msevb_create(msevb_ctx** out, int device_id) {
     HIPCHK(hipStreamCreateWithPriority(&c->aux3, hipStreamNonBlocking, hi));
   }
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_fork0, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
   HIPCHK(hipHostMalloc((void**)&c->h_energies, N_SLOTS * sizeof(double), hipHostMallocDefault));
@@ -101,6 +102,7 @@ int msevb_destroy(msevb_ctx* c) {
   if (c->aux3) { (void)hipStreamSynchronize(c->aux3); (void)hipStreamDestroy(c->aux3); c->aux3 = nullptr; }
   if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_fork0) (void)hipEventDestroy(c->ev_fork0);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   pme_teardown(c);
   DBuf<int>* ib[] = {&c->d_atype, &c->d_mol_type, &c->d_mol_natom, &c->d_mol_atoms, &c->d_mol_of, &c->d_cell_of, &c->d_perm, &c->d_cell_keys_tmp,
@@ -568,6 +570,14 @@ int total_force_enqueue(msevb_ctx* c) {
   CHK(nb_settle(c));
   stamp(c, 0, c->stream);
   const bool rebuild = c->flag_verlet_list == 1 || !c->list_valid;
+  // A step that keeps its list: the PME front end (stencils, spreading, FFTs) needs the NEW POSITIONS only - not the refreshed sorted arrays,
+  // not the zeroed force array - and is the longest chain beside the pair loop: it leaves for the side stream before the refresh kernels
+  const bool early_pme = c->overlap && !rebuild && c->cells_valid;
+  if (early_pme) {
+    HIPCHK(hipEventRecord(c->ev_fork0, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->aux, c->ev_fork0, 0));
+    CHK(pme_front(c, S_RECIP, true));
+  }
   if (rebuild) {      // cells + sorted arrays now; the rows are filled below, beside what only needs the cells
     CHK(nb_build_begin(c)); c->flag_verlet_list = 0;
     HIPCHK(hipMemsetAsync(c->d_force.p, 0, 3 * (size_t)c->N * 8, c->stream));
@@ -580,7 +590,7 @@ int total_force_enqueue(msevb_ctx* c) {
     stamp(c, 2, c->stream);
     CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux3));      // aux3: per-molecule terms (few, long threads); aux2 stays free for the
                                                                      // EVB descriptors + environment chain, which the host enqueues next
-    CHK(pme_front(c, S_RECIP, true));                                // aux: stencils, spreading, FFTs, convolution
+    if (!early_pme) CHK(pme_front(c, S_RECIP, true));                // aux: stencils, spreading, FFTs, convolution
     CHK(pme_tail(c, true));                                          // main: wait for aux, gather (skipped by the EVB fast path)
     HIPCHK(hipEventRecord(c->ev_join2, c->aux3));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));

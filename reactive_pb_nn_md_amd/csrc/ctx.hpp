@@ -176,7 +176,7 @@ struct msevb_ctx {
   // aux2: per-molecule terms, and for EVB the neighbourhood fetch, descriptor upload, diagonal real-space deltas, energy download
   // (three streams in all: with more, ROCm's 4 hardware queues alias and the intended overlap is lost)
   hipStream_t aux = nullptr, aux2 = nullptr, aux3 = nullptr;      // aux3: off-diagonal EVB chain (4 streams = ROCm's 4 hardware queues)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_fork0 = nullptr /* PME front end leaves before the refresh kernels */, ev_join = nullptr, ev_join2 = nullptr;
   hipStream_t pme_st = nullptr;      // non-null while the PME front end is being enqueued on the side stream
   bool overlap = true;
   bool cells_valid = false;      // cell_start / perm are current (a list build is in progress or done)

@@ -53,6 +53,10 @@ def compact(d, keep_store=True):
             out[k + "_sample_idx"] = np.arange(0, flat.size, 997, dtype=np.int64)
             out[k + "_sample"] = flat[::997].copy()
             out[k + "_shape"] = np.array(v.shape)
+        elif k in ("Q_grid", "theta_conv_Q") and v.size > 100000:      # a 64^3 grid: every 61st point (61 is coprime to 64: all planes, rows and columns are visited)
+            out[k + "_sample"] = v.ravel()[::61].copy()
+            out[k + "_sample_stride"] = np.array(61)
+            out[k + "_sum"] = np.array(v.sum())
         elif k == "neighbor_list":
             out["neighbor_pairs_sha256"] = np.array(pairs_hash(d["verlet_point"], v))
             out["neighbor_count"] = np.array(v.size)
@@ -138,6 +142,9 @@ def main():
     case("std_n6_lb_s9", 6, 1, 9, evb=False, standard=True, **small)
     case("std_n6_rb_s10", 6, 1, 10, evb=False, rb=True, **small)
     case("std_n6_k20_s13", 6, 1, 13, evb=False, rc=7.0, rv=8.0, nslist=16, pme_grid=20, alpha=0.33)      # grid size that is no power of two, another Ewald parameter
+    # 64^3 grid (the size of BASELINE.json configs[2], where the library runs its own LDS transform instead of rocFFT): grids kept as samples
+    case("std_n6_k64_s17", 6, 1, 17, evb=False, rc=7.0, rv=8.0, nslist=16, pme_grid=64)
+    case("evb_n6_d4_k64_s18", 6, 4, 18, evb=True, keep_store=False, rc=7.0, rv=8.0, nslist=16, pme_grid=64)
     case("std_n6_ex3_s12", 6, 1, 12, evb=False, n_exclusions=3, **small)      # 1-4 pairs excluded instead of taking the pairtypes parameters
     case("md_std_n6_s4", 6, 1, 4, evb=False, md_steps=4, **small)
     case("md_evb_n6_d2_s5", 6, 2, 5, evb=True, md_steps=4, keep_store=False, **small)

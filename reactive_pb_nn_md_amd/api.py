@@ -305,9 +305,13 @@ class MsEvbHip:
         self._chk(self.L.msevb_get_evb_element_force(self.ctx, int(i), int(j), _dp(f)))
         return f
 
-    def evb_partial_blend(self, eigvec):
-        """this rank's share of the Hellmann-Feynman force for a given ground-state vector (sharding tests)"""
+    def evb_partial_blend(self, eigvec, download=True):
+        """this rank's share of the Hellmann-Feynman force for a given ground-state vector (sharding tests); download=False leaves it on
+        the device (timing of a virtual rank's step, tools/virtual_rank_times.py)"""
         ev = np.ascontiguousarray(eigvec, dtype=np.float64)
+        if not download:
+            self._chk(self.L.msevb_evb_partial_blend(self.ctx, _dp(ev), None))
+            return None
         f = np.zeros((self.N, 3))
         self._chk(self.L.msevb_evb_partial_blend(self.ctx, _dp(ev), _dp(f)))
         return f

@@ -45,6 +45,17 @@ int flush_one(msevb_ctx* c, int slot, hipStream_t st) {
   return MSEVB_OK;
 }
 
+// ... and the pending slots s0..s1 in one launch on the given stream
+int flush_range(msevb_ctx* c, int s0, int s1, hipStream_t st) {
+  SlotCounts sc; bool any = false;
+  for (int s = 0; s < N_SLOTS; ++s) sc.n[s] = 0;
+  for (int s = s0; s <= s1; ++s) { sc.n[s] = c->slot_count[s]; any |= sc.n[s] > 0; c->slot_count[s] = 0; }
+  if (!any) return MSEVB_OK;
+  hipLaunchKernelGGL(k_reduce_slots, dim3(N_SLOTS), dim3(1024), 0, st, sc, c->d_partials.p, c->d_energies.p);
+  HIPCHK(hipGetLastError());
+  return MSEVB_OK;
+}
+
 int fetch_energies(msevb_ctx* c) {
   CHK(flush_reductions(c));
   HIPCHK(hipMemcpyAsync(c->h_energies, c->d_energies.p, N_SLOTS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -574,8 +585,8 @@ int total_force_enqueue(msevb_ctx* c) {
   // not the zeroed force array - and is the longest chain beside the pair loop: it leaves for the side stream before the refresh kernels
   const bool early_pme = c->overlap && !rebuild && c->cells_valid;
   if (early_pme) {
-    HIPCHK(hipEventRecord(c->ev_fork0, c->stream));
-    HIPCHK(hipStreamWaitEvent(c->aux, c->ev_fork0, 0));
+    if (c->ev_pos_ready) HIPCHK(hipStreamWaitEvent(c->aux, c->ev_pos_ready, 0));      // (the MS-EVB call recorded it right behind the integrator's kernel)
+    else { HIPCHK(hipEventRecord(c->ev_fork0, c->stream)); HIPCHK(hipStreamWaitEvent(c->aux, c->ev_fork0, 0)); }
     CHK(pme_front(c, S_RECIP, true));
   }
   if (rebuild) {      // cells + sorted arrays now; the rows are filled below, beside what only needs the cells
@@ -588,12 +599,15 @@ int total_force_enqueue(msevb_ctx* c) {
     stamp(c, 1, c->stream);
     CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));                    // main: the pair loop (longest) goes out first
     stamp(c, 2, c->stream);
-    CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux3));      // aux3: per-molecule terms (few, long threads); aux2 stays free for the
+    if (!c->defer_molecules_now)                                     // (the MS-EVB call sends them out itself, behind its coupling chain on the same stream)
+      CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux3));    // aux3: per-molecule terms (few, long threads); aux2 stays free for the
                                                                      // EVB descriptors + environment chain, which the host enqueues next
     if (!early_pme) CHK(pme_front(c, S_RECIP, true));                // aux: stencils, spreading, FFTs, convolution
     CHK(pme_tail(c, true));                                          // main: wait for aux, gather (skipped by the EVB fast path)
-    HIPCHK(hipEventRecord(c->ev_join2, c->aux3));
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
+    if (!c->defer_molecules_now) {
+      HIPCHK(hipEventRecord(c->ev_join2, c->aux3));
+      HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
+    }
   } else {
     if (rebuild) CHK(nb_build_finish(c, true));
     CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));
@@ -683,6 +697,9 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
   if (s == "spread_mfma") { c->spread_mfma = v != 0.0; return MSEVB_OK; }
+  if (s == "evb_region_main") { c->evb_region_main = v != 0.0; return MSEVB_OK; }
+  if (s == "evb_defer_molecules") { c->evb_defer_molecules = v != 0.0; return MSEVB_OK; }
+  if (s == "fft_own") { c->fft_own = v != 0.0; return MSEVB_OK; }
   if (s == "spread_bricks") { c->spread_bricks = v != 0.0; return MSEVB_OK; }
   if (s == "evb_device_solve") { c->evb_device_solve = v != 0.0; return MSEVB_OK; }
   if (s == "pair_threads") { c->pair_threads = v == 512.0 ? 512 : 1024; return MSEVB_OK; }

@@ -190,6 +190,10 @@ struct msevb_ctx {
   bool evb_element_stores = false;   // keep F_dd / F_pd of every Hamiltonian element (needed by msevb_get_evb_element_force); default: blended-potential path
   bool skip_gather_now = false;      // EVB fast path: the principal reciprocal force comes with the blended gather
   bool shard_principal = false;
+  hipEvent_t ev_pos_ready = nullptr;      // set by the MS-EVB call around total_force_enqueue: positions of this step are final
+  bool evb_region_main = false;           // option: the neighbourhood kernel on the main stream (see evb.hip, step 1)
+  bool defer_molecules_now = false, evb_defer_molecules = false;      // MS-EVB call: the per-molecule kernel goes out BEHIND the coupling chain on aux3 (the host's
+                                                                     // turn waits for that chain, only the blend for the per-molecule terms)
   bool shard_now = false;        // true while the EVB force call enqueues the principal diabat
   int pair_tiles_opt = -1;       // half-list LDS pair kernel: -1 / 1 = whenever the box has >= 4 cells per axis and the tile fits in LDS (default), 0 = never
   bool pair_tiles = false;       // format of the current list
@@ -286,6 +290,7 @@ struct msevb_ctx {
   rocfft_execution_info fft_info = nullptr, fft_info_b = nullptr;      // single-grid plans (their work buffer is baked into the captured PME graph) / batched plans
   DBuf<char> d_fft_work, d_fft_work_b;
   int fft_batch = 1;
+  bool fft_own = true;           // 64^3 grids: the library's own three-kernel LDS transform + convolution (fft_lds.hip) instead of rocFFT, option fft_own
   // reductions
   DBuf<double> d_partials;     // [n_slots][MAX_BLOCKS]
   DBuf<double> d_energies;     // [32]
@@ -357,6 +362,7 @@ int pme_build_green(msevb_ctx* c);   // after the CB array changed (box change)
 void pme_teardown(msevb_ctx* c);
 int reduce_partials(msevb_ctx* c, int slot, int nblocks);                // deferred: one fused launch in flush_reductions
 int flush_reductions(msevb_ctx* c);
+int flush_range(msevb_ctx* c, int s0, int s1, hipStream_t st);
 int fetch_energies(msevb_ctx* c);
 int integrate_half_kick_drift(msevb_ctx* c, double dt);                  // integrate.hip
 int integrate_half_kick(msevb_ctx* c, double dt);
@@ -374,6 +380,9 @@ extern "C" int total_force_collect(msevb_ctx* c, double* en);
 extern "C" int upload_topology(msevb_ctx* c);
 int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part_stride, int* nblocks);
 int pme_prepare_atoms(msevb_ctx* c, bool with_indices);
+bool fft_lds_usable(const msevb_ctx* c);                              // fft_lds.hip
+int fft_lds_setup(msevb_ctx* c);
+int fft_lds_solve(msevb_ctx* c, const double* Q, double2* work, double* theta, double* part, int* nblocks, hipStream_t st);
 int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic = false, const double* theta = nullptr);
 
 constexpr int MAX_BLOCKS = 65536;

@@ -792,7 +792,7 @@ __global__ void k_evb_grid_energy(int ng, double* __restrict__ E_lin, double* __
 
 // blended charge grid: grid += sum over the stencils of c_d^2 q S (the grid holds Q_1 on rank 0, zero on the others); coefficients as kernel
 // arguments, or from device memory behind k_evb_solve
-__global__ __launch_bounds__(256) void k_evb_blend_patch(int nst, const Stencil* __restrict__ st, GridCoefs gc, const double* __restrict__ dc, int K, double2* __restrict__ grid) {
+__global__ __launch_bounds__(256) void k_evb_blend_patch(int nst, const Stencil* __restrict__ st, GridCoefs gc, const double* __restrict__ dc, int K, double* __restrict__ grid, int gs) {
   const int lane = threadIdx.x & 63;
   const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (e >= nst) return;
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void k_evb_blend_patch(int nst, const Stencil*
     int n1 = t.base[0] - k1; if (n1 < 0) n1 += K;
     int n2 = t.base[1] - k2; if (n2 < 0) n2 += K;
     int n3 = t.base[2] - k3; if (n3 < 0) n3 += K;
-    atomicAdd(&grid[n1 + (size_t)K * (n2 + (size_t)K * n3)].x, q * t.w[k1] * t.w[6 + k2] * t.w[12 + k3]);
+    atomicAdd(&grid[gs * (n1 + (size_t)K * (n2 + (size_t)K * n3))], q * t.w[k1] * t.w[6 + k2] * t.w[12 + k3]);      // gs = 2: real parts of a complex grid
   }
 }
 __global__ void k_grid_real(size_t K3, const double2* __restrict__ grid, double* __restrict__ out) {
@@ -974,11 +974,30 @@ __global__ void k_sum_rows(int nrow, int ncol, int stride, const double* __restr
 // ---------------------------------------------------------------------------------------------------------------- host side
 struct HMol { int id, type, natom; int atoms[MAX_MOL_ATOMS]; double com[3]; };
 struct HAtom { int type; double q; double x[3]; int mol; };
+// Small flat containers with the few std::map / std::vector operations the host side of a force call uses: a hop chain touches at most
+// MAX_CHAIN + 1 molecules (MAX_SPEC atoms), and the topologies are copied once per diabat - node-based maps and heap vectors made the
+// descriptor construction 25 us of the host's turn, which is on the step's critical path (the side chains start behind it).
+template <class V, int CAP> struct FlatMap {
+  int n = 0; int key[CAP]; V val[CAP];
+  V* find(int k) { for (int i = 0; i < n; ++i) if (key[i] == k) return &val[i]; return nullptr; }
+  V& operator[](int k) { if (V* v = find(k)) return *v; if (n >= CAP) throw std::length_error("EVB: more special atoms than MAX_SPEC"); key[n] = k; val[n] = V(); return val[n++]; }
+  const V& at(int k) const { for (int i = 0; i < n; ++i) if (key[i] == k) return val[i]; throw std::out_of_range("EVB: atom not in the hop-chain topology"); }
+};
+template <class V, int CAP> struct FlatVec {
+  int n = 0; V v[CAP];
+  size_t size() const { return (size_t)n; }
+  V& operator[](size_t k) { return v[k]; }
+  const V& operator[](size_t k) const { return v[k]; }
+  void push_back(const V& x) { if (n >= CAP) throw std::length_error("EVB: more molecules in a hop chain than MAX_CHAIN + 1"); v[n++] = x; }
+  V* begin() { return v; } V* end() { return v + n; }
+  const V* begin() const { return v; } const V* end() const { return v + n; }
+};
 struct HTopo {   // the molecules touched so far by a hop chain, in the topology reached so far
-  std::vector<HMol> mols;
-  std::map<int, HAtom> atoms;
+  FlatVec<HMol, MAX_CHAIN + 1> mols;
+  FlatMap<HAtom, MAX_SPEC> atoms;
   int hydronium;
 };
+typedef FlatMap<int, MAX_SPEC> WhereMap;
 
 struct EvbWork {   // persistent device scratch of one context
   DBuf<EvbTablesDev> d_tabs; DBuf<double> d_exch;
@@ -1000,8 +1019,9 @@ struct EvbWork {   // persistent device scratch of one context
   double screen_r = 0.0;
   // what the last force call left behind, for msevb_evb_partial_blend on the fast path (virtual-rank tests)
   int last_ngrid = 0, last_nra = 0, last_grid_of[MAX_DIABATS]; const RecipAtom* last_d_ra = nullptr; bool last_fast = false;
-  bool counters_dirty = true, dv_dirty = true;
-  std::vector<RegionRec> region;
+  bool counters_dirty = true, dv_dirty = true, mol_deferred = false;
+  std::vector<RegionRec> region, region_raw; std::vector<long long> region_key;
+  std::vector<UnitDesc> units; std::vector<CouplingDesc> cps, cps_sorted; std::vector<RecipAtom> ras;      // descriptors of the current force call
 };
 // host-side section timing (MSEVB_HOST_TIMING=1): where the CPU thread spends the step
 struct HostTimes { double t[12] = {0}; long n = 0; };
@@ -1090,7 +1110,7 @@ int heavy_local_acid(const msevb_ctx* c, int acid_type) {   // get_heavy_atom_tr
   return -1;
 }
 
-int fill_spec(const HTopo& t, SpecAtom* spec, int* mols, int& n_spec, int& n_mols, std::map<int, int>& where) {
+int fill_spec(const HTopo& t, SpecAtom* spec, int* mols, int& n_spec, int& n_mols, WhereMap& where) {
   n_spec = 0; n_mols = 0;
   for (const HMol& m : t.mols) {
     mols[n_mols++] = m.id;
@@ -1108,7 +1128,7 @@ int fill_spec(const HTopo& t, SpecAtom* spec, int* mols, int& n_spec, int& n_mol
 int make_unit(msevb_ctx* c, const HTopo& t, int donor, int acceptor, double sign, int slot, int do_rs, int do_rep, UnitDesc& u) {
   memset(&u, 0, sizeof(u));
   u.sign = sign; u.slot = slot; u.do_rs = do_rs; u.do_rep = do_rep; u.donor = donor; u.acceptor = acceptor; u.hyd = t.hydronium;
-  std::map<int, int> where;
+  WhereMap where;
   fill_spec(t, u.spec, u.mols, u.n_spec, u.n_mols, where);
   for (const HMol& m : t.mols) {
     if (do_rs && m.id == donor) { u.nD = m.natom; u.mt_D = m.type; for (int k = 0; k < m.natom; ++k) u.D_at[k] = where[m.atoms[k]]; }
@@ -1210,6 +1230,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   BlendTerms bt;
   double w11 = blend_terms(c, D, ev, bt);
   if (w11 == 0.0) {      // replicated (not sharded) principal diabat on a rank other than 0: F11 counts on rank 0 only, the gather below adds to zero
+    if (c->overlap && w->mol_deferred) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // (the per-molecule kernel still adds to it)
     HIPCHK(hipMemsetAsync(c->d_force.p, 0, n3 * 8, c->stream));
     w11 = 1.0;
   }
@@ -1226,16 +1247,24 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
       if (c->rank == 0) CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, c->d_theta.p));
     } else {
       if (w->d_grids.alloc_room(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended charge grid)");
-      if (c->rank == 0) hipLaunchKernelGGL(k_evb_grid_init, dim3(2048), dim3(256), 0, c->stream, K3, 1, c->d_Q.p, w->d_grids.p);
-      else HIPCHK(hipMemsetAsync(w->d_grids.p, 0, K3 * sizeof(double2), c->stream));
-      hipLaunchKernelGGL(k_evb_blend_patch, dim3((w->last_nst + 3) / 4), dim3(256), 0, c->stream, w->last_nst, w->d_stencils.p, gc, dcoef, K, w->d_grids.p);
-      HIPCHK(hipGetLastError());
-      int nbk = 0;
-      hipStream_t keep = c->pme_st; c->pme_st = nullptr;      // on the main stream
-      const int rc_conv = pme_convolve(c, w->d_grids.p, 1, w->d_part.p, 1024, &nbk);      // (the energy partials of this transform are not used)
-      c->pme_st = keep;
-      CHK(rc_conv);
-      hipLaunchKernelGGL(k_grid_real, dim3(1024), dim3(256), 0, c->stream, K3, w->d_grids.p, w->d_pack.p);
+      if (fft_lds_usable(c)) {      // real grid in, real potential out, in place in d_pack (d_grids is the transform's complex work space)
+        if (c->rank == 0) HIPCHK(hipMemcpyAsync(w->d_pack.p, c->d_Q.p, K3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        else HIPCHK(hipMemsetAsync(w->d_pack.p, 0, K3 * sizeof(double), c->stream));
+        hipLaunchKernelGGL(k_evb_blend_patch, dim3((w->last_nst + 3) / 4), dim3(256), 0, c->stream, w->last_nst, w->d_stencils.p, gc, dcoef, K, w->d_pack.p, 1);
+        HIPCHK(hipGetLastError());
+        CHK(fft_lds_solve(c, w->d_pack.p, w->d_grids.p, w->d_pack.p, nullptr, nullptr, c->stream));
+      } else {
+        if (c->rank == 0) hipLaunchKernelGGL(k_evb_grid_init, dim3(2048), dim3(256), 0, c->stream, K3, 1, c->d_Q.p, w->d_grids.p);
+        else HIPCHK(hipMemsetAsync(w->d_grids.p, 0, K3 * sizeof(double2), c->stream));
+        hipLaunchKernelGGL(k_evb_blend_patch, dim3((w->last_nst + 3) / 4), dim3(256), 0, c->stream, w->last_nst, w->d_stencils.p, gc, dcoef, K, (double*)w->d_grids.p, 2);
+        HIPCHK(hipGetLastError());
+        int nbk = 0;
+        hipStream_t keep = c->pme_st; c->pme_st = nullptr;      // on the main stream
+        const int rc_conv = pme_convolve(c, w->d_grids.p, 1, w->d_part.p, 1024, &nbk);      // (the energy partials of this transform are not used)
+        c->pme_st = keep;
+        CHK(rc_conv);
+        hipLaunchKernelGGL(k_grid_real, dim3(1024), dim3(256), 0, c->stream, K3, w->d_grids.p, w->d_pack.p);
+      }
       CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p));
     }
   } else {
@@ -1245,6 +1274,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   // ... the special atoms' own-stencil corrections per diabat are in the delta store already (k_evb_recip_special ran at the end of the
   // diabat grid chain, before the host's turn); the blend consumes the store and re-zeroes it
   if (c->overlap) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0)); if (ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_rs, 0)); }
+  if (c->overlap && w->mol_deferred) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // the principal diabat's per-molecule forces (aux3, behind the coupling chain)
   (void)nra; (void)d_ra;
   hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, dcoef ? dcoef + 1 + ngrid : (const double*)nullptr, w11, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p, 1);
   stamp(c, 9, c->stream);
@@ -1252,7 +1282,12 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   return MSEVB_OK;
 }
 
+static int evb_force_energy_body(msevb_ctx* c, double* epot_out);
 static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
+  try { return evb_force_energy_body(c, epot_out); }
+  catch (const std::exception& e) { FAIL(MSEVB_ERR_LIMIT, std::string("EVB host side: ") + e.what()); }      // a flat container ran out of room (never across the C ABI)
+}
+static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   static const bool ht_on = getenv("MSEVB_HOST_TIMING") != nullptr;
   double ht_last = ht_on ? now_us() : 0.0;
   auto HT = [&](int k) { if (ht_on) { const double t = now_us(); g_ht.t[k] += t - ht_last; ht_last = t; } };
@@ -1288,30 +1323,48 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   struct Rearm { EvbWork* w; bool ok; ~Rearm() { w->counters_dirty = !ok; if (!ok) { w->dv_dirty = true; w->delta_dirty = true; } } } rearm{w, false};
-  const double Rreg = 5.0 * c->max_chain + 5.0;
+  // a hop goes to a molecule whose centre of mass is within 5 A of the donor's (evb_first_solvation_cutoff): a chain of max_chain hops
+  // stays inside 5 max_chain of the hydronium's
+  const double Rreg = 5.0 * c->max_chain + 0.25;
   HIPCHK(hipEventRecord(w->ev_in, c->stream));
   HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_in, 0));
-  hipLaunchKernelGGL(k_evb_region, dim3((M + 255) / 256), dim3(256), 0, w->stream2, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
+  // The neighbourhood record is the first thing the host's turn needs, and everything the side chains do starts behind that turn: it goes
+  // out on the MAIN stream, directly behind the integrator's first kernel (on a side stream it started one cross-queue event hop,
+  // ~15 us, later; the pair loop, which it now precedes, has that much slack before the blend needs it)
+  const hipStream_t s_reg = c->overlap && c->evb_region_main ? c->stream : w->stream2;
+  hipLaunchKernelGGL(k_evb_region, dim3((M + 255) / 256), dim3(256), 0, s_reg, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
                      c->d_mass.p, box, w->d_counter.p, w->d_region.p, REGION_CAP, w->d_counter.p + 1, w->h_region, REGION_FAST);
   if (!w->h_flag) { HIPCHK(hipHostMalloc((void**)&w->h_flag, 64, hipHostMallocDefault)); memset(w->h_flag, 0, 64); }
-  hipLaunchKernelGGL(k_evb_publish_count, dim3(1), dim3(1), 0, w->stream2, w->d_counter.p, w->h_count, (volatile long long*)(w->h_flag + 1), ++w->seq_R);
-  HIPCHK(hipEventRecord(w->ev_region, w->stream2));
+  hipLaunchKernelGGL(k_evb_publish_count, dim3(1), dim3(1), 0, s_reg, w->d_counter.p, w->h_count, (volatile long long*)(w->h_flag + 1), ++w->seq_R);
+  HIPCHK(hipEventRecord(w->ev_region, s_reg));
   HT(1);
   // ---- 2. principal diabat (calculate_total_force_energy, src/ms_evb.f90:411) - enqueued, not waited for
   const bool fast = !c->evb_element_stores;      // no per-element force stores: one gather of the blended potential (k_evb_blend_grids)
   c->shard_now = c->shard_principal && c->n_ranks > 1;
   c->skip_gather_now = fast;
+  const bool defer_mol = c->overlap && c->evb_defer_molecules;
+  c->defer_molecules_now = defer_mol;
+  c->ev_pos_ready = w->ev_in;      // new positions: what the PME front end waits for (not for the neighbourhood kernels behind them)
   const int rc_tfe = total_force_enqueue(c);
-  c->shard_now = false; c->skip_gather_now = false;
+  c->shard_now = false; c->skip_gather_now = false; c->defer_molecules_now = false; c->ev_pos_ready = nullptr;
   CHK(rc_tfe);
   HT(2);
   if (spin_wait((volatile long long*)(w->h_flag + 1), w->seq_R, w->ev_region)) HIPCHK(hipErrorUnknown);
   const int nreg = *w->h_count;
   if (nreg > REGION_CAP) FAIL(MSEVB_ERR_LIMIT, "EVB neighbourhood buffer too small");
   w->region.resize(nreg);
-  if (nreg <= REGION_FAST) memcpy(w->region.data(), w->h_region, (size_t)nreg * sizeof(RegionRec));
-  else { HIPCHK(hipMemcpyAsync(w->region.data(), w->d_region.p, (size_t)nreg * sizeof(RegionRec), hipMemcpyDeviceToHost, w->stream2)); HIPCHK(hipStreamSynchronize(w->stream2)); }
-  std::sort(w->region.begin(), w->region.end(), [](const RegionRec& a, const RegionRec& b) { return a.mol < b.mol; });
+  {      // records in ascending molecule order (the reference's j_mole loops): sort 8-byte keys, then move each 224-byte record once
+    const RegionRec* src = w->h_region;
+    if (nreg > REGION_FAST) {
+      w->region_raw.resize(nreg);
+      HIPCHK(hipMemcpyAsync(w->region_raw.data(), w->d_region.p, (size_t)nreg * sizeof(RegionRec), hipMemcpyDeviceToHost, w->stream2)); HIPCHK(hipStreamSynchronize(w->stream2));
+      src = w->region_raw.data();
+    }
+    w->region_key.resize(nreg);
+    for (int k = 0; k < nreg; ++k) w->region_key[k] = ((long long)src[k].mol << 32) | (unsigned)k;
+    std::sort(w->region_key.begin(), w->region_key.end());
+    for (int k = 0; k < nreg; ++k) w->region[k] = src[(int)(w->region_key[k] & 0xffffffff)];
+  }
   HT(3);
   // ---- 3. diabat enumeration on the principal topology (evb_conduct_proton_transfer_recursive, :498)
   for (int d = 0; d < MAX_DIABATS; ++d) { c->parent[d] = -1; for (int h = 0; h < MAX_CHAIN; ++h) for (int q = 0; q < 5; ++q) c->plog[d][h][q] = -1; }
@@ -1326,13 +1379,24 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
       const RegionRec* ri = find_region(w, im_donor);
       if (!ri) FAIL(MSEVB_ERR_LIMIT, "EVB: donor outside the gathered neighbourhood");
       const MolTypeHost& mt = c->h_mt[c->h_mol_type[im_donor]];
+      // molecules of the donor's first solvation shell, once per donor (not once per proton), in ascending molecule index
+      struct Near { int k; double sh[3]; };
+      Near near[64]; int n_near = 0;
+      for (int k = 0; k < (int)w->region.size(); ++k) {
+        const RegionRec& rj = w->region[k];
+        if (rj.mol == im_donor) continue;
+        double sh[3], dc[3]; pbc_shift_h(c, ri->com, rj.com, sh);
+        for (int d = 0; d < 3; ++d) dc[d] = rj.com[d] - ri->com[d] - sh[d];
+        if (dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2] >= 25.0) continue;       // evb_first_solvation_cutoff = 5 (src/glob_v.f90:54)
+        if (n_near >= 64) FAIL(MSEVB_ERR_LIMIT, "EVB: more than 64 molecules in a first solvation shell");
+        near[n_near].k = k; for (int d = 0; d < 3; ++d) near[n_near].sh[d] = sh[d];
+        ++n_near;
+      }
       for (int ia = 0; ia < c->h_mol_natom[im_donor]; ++ia) {
         if (mt.reactive_protons[ia] != 1) continue;
-        for (const RegionRec& rj : w->region) {      // ascending molecule index == the reference's j_mole loop
-          if (rj.mol == im_donor) continue;
-          double sh[3], dc[3]; pbc_shift_h(c, ri->com, rj.com, sh);
-          for (int d = 0; d < 3; ++d) dc[d] = rj.com[d] - ri->com[d] - sh[d];
-          if (dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2] >= 25.0) continue;       // evb_first_solvation_cutoff = 5 (src/glob_v.f90:54)
+        for (int q = 0; q < n_near; ++q) {      // ascending molecule index == the reference's j_mole loop
+          const RegionRec& rj = w->region[near[q].k];
+          const double* sh = near[q].sh;
           const MolTypeHost& mj = c->h_mt[c->h_mol_type[rj.mol]];
           for (int ja = 0; ja < rj.natom; ++ja) {
             if (mj.reactive_basic[ja] != 1) continue;
@@ -1341,7 +1405,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
             if (c->D >= MAX_DIABATS) FAIL(MSEVB_ERR_LIMIT, "Found more diabat states than evb_max_states");
             const int d = c->D++;
             c->parent[d] = d_donor;
-            for (int h = 0; h < count; ++h) for (int q = 0; q < 5; ++q) c->plog[d][h][q] = c->plog[d_donor][h][q];
+            for (int h = 0; h < count; ++h) for (int q5 = 0; q5 < 5; ++q5) c->plog[d][h][q5] = c->plog[d_donor][h][q5];
             int heavy = -1;
             for (size_t b = 0; b < mt.bonds.size() / 2; ++b) { if (mt.bonds[2 * b] == ia) heavy = mt.bonds[2 * b + 1]; else if (mt.bonds[2 * b + 1] == ia) heavy = mt.bonds[2 * b]; }
             c->plog[d][count][0] = im_donor; c->plog[d][count][1] = ia; c->plog[d][count][2] = heavy; c->plog[d][count][3] = rj.mol; c->plog[d][count][4] = ja;
@@ -1356,9 +1420,9 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   const int D = c->D, S = slots_per_rank(c, D), n_off = c->n_ranks * S, n_diag = 1 + n_off;
   HT(4);
   // ---- 4. evaluation units / couplings / recip patches of the diabats owned by this rank
-  std::vector<UnitDesc> units;
-  std::vector<CouplingDesc> cps;
-  std::vector<RecipAtom> ras;
+  std::vector<UnitDesc>& units = w->units; units.clear();      // (kept in the work area: the 2.4 kB descriptors are not re-allocated every step)
+  std::vector<CouplingDesc>& cps = w->cps; cps.clear();
+  std::vector<RecipAtom>& ras = w->ras; ras.clear();
   std::vector<int> grid_of(D, -1), cp_of(D, -1);
   std::vector<double> eref_delta(D, 0.0);
   std::vector<std::vector<int>> units_of(D);
@@ -1394,7 +1458,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     // off-diagonal element with the parent diabat, in this (acceptor) topology (evb_diabatic_coupling, :1021)
     CouplingDesc cp; memset(&cp, 0, sizeof(cp));
     cp.slot = off_slot(c, D, d);
-    std::map<int, int> where;
+    WhereMap where;
     fill_spec(T, cp.spec, cp.mols, cp.n_spec, cp.n_mols, where);
     const HMol *Dm = nullptr, *Am = nullptr;
     for (size_t k = 0; k < T.mols.size(); ++k) { if (T.mols[k].id == md) Dm = &T.mols[k]; if (T.mols[k].id == ma) Am = &T.mols[k]; for (int q = 0; q < 3; ++q) cp.mol_com[k][q] = T.mols[k].com[q]; }
@@ -1425,7 +1489,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     std::vector<int> order(cps.size());
     for (size_t k = 0; k < order.size(); ++k) order[k] = (int)k;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return (cps[a].nD + cps[a].nA > 8) > (cps[b].nD + cps[b].nA > 8); });
-    std::vector<CouplingDesc> sorted(cps.size());
+    std::vector<CouplingDesc>& sorted = w->cps_sorted; sorted.resize(cps.size());
     std::vector<int> newpos(cps.size());
     for (size_t k = 0; k < order.size(); ++k) { sorted[k] = cps[order[k]]; newpos[order[k]] = (int)k; if (sorted[k].nD + sorted[k].nA > 8) ncp_big++; }
     cps.swap(sorted);
@@ -1585,8 +1649,8 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   if (ncp) {
     // own stream (aux3): beside the diagonal deltas on aux2 - both chains feed fetch A, which the blend waits for
     hipStream_t so = c->overlap ? c->aux3 : c->stream;
+    hipLaunchKernelGGL(k_mol_com, dim3((M + 255) / 256), dim3(256), 0, so, M, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_mass.p, w->d_com_atom.p);      // positions only
     if (c->overlap) HIPCHK(hipStreamWaitEvent(so, w->ev_fork2, 0));
-    hipLaunchKernelGGL(k_mol_com, dim3((M + 255) / 256), dim3(256), 0, so, M, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_mass.p, w->d_com_atom.p);
     // ~1000 workgroups per launch in all: every block pays a descriptor copy, two barriers and the Zundel reductions
     const int cpb_big = cpb, cpb_small = std::min(cpb, std::max(256, 6144 / std::max(ncp - ncp_big, 1)));      // few trips per wave: the kernels are latency-bound
     if (ncp_big) hipLaunchKernelGGL(k_evb_coupling<16>, dim3(cpb_big, ncp_big), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, w->d_com_atom.p, c->d_xyz.p, c->d_chg.p,
@@ -1601,6 +1665,18 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     stamp(c, 7, so);
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_cpl, so));
   }
+  if (defer_mol) {      // the principal diabat's per-molecule terms: behind the coupling chain on aux3 (they ran in front of it and held it up by ~80 us)
+    c->shard_now = c->shard_principal && c->n_ranks > 1;
+    const int rc_mol = molecule_forces(c, S_ELEC_INTRA, true, true, c->aux3);
+    c->shard_now = false;
+    CHK(rc_mol);
+    CHK(flush_range(c, S_ELEC_INTRA, S_DIH, c->aux3));      // its energy sums on its own stream (fetch B waits for the event, not the main stream)
+    HIPCHK(hipEventRecord(c->ev_join2, c->aux3));
+    // who waits: fetch B (energies), and in the blend phase only the last kernel - the transforms and the gather of the blended potential
+    // ADD to the force array like the per-molecule kernel does, k_evb_blend is the first to read it
+    if (!fast) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // per-element stores: k_evb_slot0 copies F11
+  }
+  w->mol_deferred = defer_mol;
   // The Hamiltonian needs energies only, and all of them exist before the all-atom gather (the longest kernel of the EVB phase)
   // starts: fetch them now on stream2 and let the host diagonalise while the gather runs.
   const size_t nE = (size_t)2 * nu + ncp + ngrid + 3 * (size_t)ncp;
@@ -1648,6 +1724,7 @@ static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
     if (c->overlap) {
       HIPCHK(hipEventRecord(w->ev_flush, c->stream)); HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_flush, 0));
       HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0));      // the principal reciprocal energy slot is reduced on the diabat grid stream (fetch A)
+      if (defer_mol) HIPCHK(hipStreamWaitEvent(w->stream2, c->ev_join2, 0));      // per-molecule energies (aux3)
     }
     hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, ss, c->d_energies.p, (int)N_SLOTS, c->h_energies, (const double*)nullptr, 0, (double*)nullptr,
                        (volatile long long*)(w->h_flag + 2), ++w->seq_B);
@@ -1903,7 +1980,7 @@ int msevb_get_evb_state(msevb_ctx* c, int* nd, int* plog, int* cm, double* H, do
 }
 
 int msevb_evb_partial_blend(msevb_ctx* c, const double* eigvec, double* force) {
-  if (!c || c->D <= 0 || !eigvec || !force) { if (c) c->err = "bad argument"; return MSEVB_ERR_ARG; }
+  if (!c || c->D <= 0 || !eigvec) { if (c) c->err = "bad argument"; return MSEVB_ERR_ARG; }      // force == NULL: the blend stays on the device
   EvbWork* w = (EvbWork*)c->evb_work;
   if (!w) FAIL(MSEVB_ERR_STATE, "no EVB force call yet");
   const size_t n3 = 3 * (size_t)c->N;
@@ -1917,7 +1994,7 @@ int msevb_evb_partial_blend(msevb_ctx* c, const double* eigvec, double* force) {
     HIPCHK(hipMemcpyAsync(c->d_force.p, w->d_F11.p, n3 * 8, hipMemcpyDeviceToDevice, c->stream));
     hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, (const double*)nullptr, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0);
   }
-  HIPCHK(hipMemcpyAsync(force, c->d_force.p, n3 * 8, hipMemcpyDeviceToHost, c->stream));
+  if (force) HIPCHK(hipMemcpyAsync(force, c->d_force.p, n3 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return MSEVB_OK;
 }

@@ -1,0 +1,238 @@
+// fft_lds.hip - the reciprocal-space solve of one 64^3 grid, theta = IFFT( CB . FFT(Q) ), in THREE kernels
+// (reference: src/pme.f90:73-125 - DftiComputeForward, FQ = FQ*CB with E = 1/2 sum CB |FQ|^2, DftiComputeBackward, both unnormalised).
+//
+// rocFFT runs a 64^3 double-complex transform as three kernels of 7-34 us each: at 4 MB the transform is latency bound, not bandwidth
+// bound, and the pair of them + the convolution + the real<->complex passes were ~105 us alone, twice per MS-EVB step (principal charge
+// grid; blended charge grid of the Hellmann-Feynman force - the second one sits on the critical path).  Here:
+//   k_fft_xy_fwd : one workgroup per z plane.  Reads the REAL charge plane (32 KB), 64 x-lines then 64 y-lines through LDS, writes the
+//                  complex plane (x fastest, coalesced).
+//   k_fft_z_conv : one workgroup per (16 x, y) bundle of z-lines: forward along z, times CB (+ the energy partial), backward along z,
+//                  in place - a z-line never leaves its registers between the two transforms.
+//   k_fft_xy_inv : one workgroup per z plane, y-lines then x-lines backward, writes the REAL part (the potential is real: Q is real and
+//                  CB is even) - no complex->real pass behind it.
+// A 64-point line is 8 x 8 (Cooley-Tukey): a thread holds x[j + 8 m], m = 0..7, does a radix-8 butterfly in registers, twiddles by
+// W64^(j k2), the 8 threads of a line exchange through LDS, second radix-8 butterfly: the thread then holds X[j + 8 k1], the layout it
+// started with - so the convolution and the backward transform need no further exchange.
+// Rounding differs from rocFFT / MKL in the last bits only (tested against the rocFFT path).
+#include "ctx.hpp"
+
+namespace {
+
+constexpr int FK = 64;
+constexpr int LS = 72;      // LDS row stride in doubles: 64 + 8 (rows 8 banks apart; 8 x 9 exchange layout fits)
+constexpr double RH = 0.70710678118654752440;
+
+__device__ double2 g_tw64[64];      // W64^m = (cos, sin)(2 pi m / 64), host-computed
+
+// radix-4 / radix-8 butterflies, natural order in and out; S = -1 forward (e^{-i...}), +1 backward
+template <int S> __device__ __forceinline__ void dft4(double& r0, double& i0, double& r1, double& i1, double& r2, double& i2, double& r3, double& i3) {
+  const double t0r = r0 + r2, t0i = i0 + i2, t1r = r0 - r2, t1i = i0 - i2;
+  const double t2r = r1 + r3, t2i = i1 + i3, t3r = r1 - r3, t3i = i1 - i3;
+  r0 = t0r + t2r; i0 = t0i + t2i;
+  r2 = t0r - t2r; i2 = t0i - t2i;
+  // b1 = t1 + i S t3, b3 = t1 - i S t3
+  r1 = t1r - S * t3i; i1 = t1i + S * t3r;
+  r3 = t1r + S * t3i; i3 = t1i - S * t3r;
+}
+
+template <int S> __device__ __forceinline__ void dft8(double (&re)[8], double (&im)[8]) {
+  double er0 = re[0], ei0 = im[0], er1 = re[2], ei1 = im[2], er2 = re[4], ei2 = im[4], er3 = re[6], ei3 = im[6];
+  double or0 = re[1], oi0 = im[1], or1 = re[3], oi1 = im[3], or2 = re[5], oi2 = im[5], or3 = re[7], oi3 = im[7];
+  dft4<S>(er0, ei0, er1, ei1, er2, ei2, er3, ei3);
+  dft4<S>(or0, oi0, or1, oi1, or2, oi2, or3, oi3);
+  // O[k] *= W8^k: W8^1 = (c, S c), W8^2 = (0, S), W8^3 = (-c, S c)
+  const double a1r = RH * (or1 - S * oi1), a1i = RH * (S * or1 + oi1);
+  const double a2r = -S * oi2, a2i = S * or2;
+  const double a3r = -RH * (or3 + S * oi3), a3i = RH * (S * or3 - oi3);
+  re[0] = er0 + or0; im[0] = ei0 + oi0; re[4] = er0 - or0; im[4] = ei0 - oi0;
+  re[1] = er1 + a1r; im[1] = ei1 + a1i; re[5] = er1 - a1r; im[5] = ei1 - a1i;
+  re[2] = er2 + a2r; im[2] = ei2 + a2i; re[6] = er2 - a2r; im[6] = ei2 - a2i;
+  re[3] = er3 + a3r; im[3] = ei3 + a3i; re[7] = er3 - a3r; im[7] = ei3 - a3i;
+}
+
+// A[k2] *= W64^(S j k2)
+template <int S> __device__ __forceinline__ void twiddle(double (&re)[8], double (&im)[8], const double2 (&tw)[8]) {
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    const double c = tw[k].x, s = S * tw[k].y;
+    const double r = re[k] * c - im[k] * s, i = re[k] * s + im[k] * c;
+    re[k] = r; im[k] = i;
+  }
+}
+
+__device__ __forceinline__ void load_tw(int j, double2 (&tw)[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) tw[k] = g_tw64[(j * k) & 63];
+}
+
+// ---- x then y, forward, real input ----
+__global__ __launch_bounds__(512) void k_fft_xy_fwd(const double* __restrict__ Q, double2* __restrict__ grid) {
+  extern __shared__ double lds[];
+  double* pr = lds;                 // [64][LS] real parts
+  double* pi = lds + FK * LS;       // imaginary parts
+  const int z = blockIdx.x, t = threadIdx.x;
+  double re[8], im[8];
+  double2 tw[8];
+  {      // x lines: 8 threads per line y
+    const int y = t >> 3, j = t & 7;
+    load_tw(j, tw);
+    const double* row = Q + (size_t)FK * (y + (size_t)FK * z);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { re[m] = row[j + 8 * m]; im[m] = 0.0; }
+    dft8<-1>(re, im);
+    twiddle<-1>(re, im, tw);
+    double* rr = pr + y * LS + j * 9; double* ri = pi + y * LS + j * 9;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { rr[k] = re[k]; ri[k] = im[k]; }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 8; ++n) { re[n] = pr[y * LS + n * 9 + j]; im[n] = pi[y * LS + n * 9 + j]; }
+    dft8<-1>(re, im);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { pr[y * LS + j + 8 * k] = re[k]; pi[y * LS + j + 8 * k] = im[k]; }      // X[kx = j + 8 k] of line y
+    __syncthreads();
+  }
+  {      // y lines: thread (kx, j), kx fastest
+    const int kx = t & 63, j = t >> 6;
+    load_tw(j, tw);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { re[m] = pr[(j + 8 * m) * LS + kx]; im[m] = pi[(j + 8 * m) * LS + kx]; }
+    dft8<-1>(re, im);
+    twiddle<-1>(re, im, tw);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { pr[(j * 8 + k) * LS + kx] = re[k]; pi[(j * 8 + k) * LS + kx] = im[k]; }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 8; ++n) { re[n] = pr[(n * 8 + j) * LS + kx]; im[n] = pi[(n * 8 + j) * LS + kx]; }
+    dft8<-1>(re, im);
+    double2* plane = grid + (size_t)FK * FK * z;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) plane[(size_t)FK * (j + 8 * k) + kx] = make_double2(re[k], im[k]);
+  }
+}
+
+// ---- z forward, x CB (+ energy), z backward: 16 x-neighbours of one y per workgroup, 8 threads per z-line ----
+__global__ __launch_bounds__(128) void k_fft_z_conv(double2* __restrict__ grid, const double* __restrict__ CB, double* __restrict__ part, double half_conv) {
+  __shared__ double pr[16 * 73], pi[16 * 73];
+  __shared__ double red[2];
+  const int t = threadIdx.x, lx = t & 15, j = t >> 4;
+  const int x = (blockIdx.x & 3) * 16 + lx, y = blockIdx.x >> 2;
+  const size_t col = (size_t)x + (size_t)FK * y, zs = (size_t)FK * FK;
+  double re[8], im[8];
+  double2 tw[8];
+  load_tw(j, tw);
+  double cb[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) { const double2 v = grid[col + zs * (j + 8 * m)]; re[m] = v.x; im[m] = v.y; }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) cb[m] = CB[col + zs * (j + 8 * m)];
+  double* er = pr + lx * 73; double* ei = pi + lx * 73;
+  dft8<-1>(re, im);
+  twiddle<-1>(re, im, tw);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { er[j * 9 + k] = re[k]; ei[j * 9 + k] = im[k]; }
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < 8; ++n) { re[n] = er[n * 9 + j]; im[n] = ei[n * 9 + j]; }
+  dft8<-1>(re, im);      // F[kz = j + 8 k]
+  double e = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { e += cb[k] * (re[k] * re[k] + im[k] * im[k]); re[k] *= cb[k]; im[k] *= cb[k]; }
+  dft8<1>(re, im);
+  twiddle<1>(re, im, tw);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { er[j * 9 + k] = re[k]; ei[j * 9 + k] = im[k]; }
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < 8; ++n) { re[n] = er[n * 9 + j]; im[n] = ei[n * 9 + j]; }
+  dft8<1>(re, im);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) grid[col + zs * (j + 8 * m)] = make_double2(re[m], im[m]);
+  if (part) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+    if ((t & 63) == 0) red[t >> 6] = e;
+    __syncthreads();
+    if (t == 0) part[blockIdx.x] = (red[0] + red[1]) * half_conv;
+  }
+}
+
+// ---- y then x, backward, real output ----
+__global__ __launch_bounds__(512) void k_fft_xy_inv(const double2* __restrict__ grid, double* __restrict__ theta) {
+  extern __shared__ double lds[];
+  double* pr = lds;
+  double* pi = lds + FK * LS;
+  const int z = blockIdx.x, t = threadIdx.x;
+  double re[8], im[8];
+  double2 tw[8];
+  {
+    const int kx = t & 63, j = t >> 6;
+    load_tw(j, tw);
+    const double2* plane = grid + (size_t)FK * FK * z;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { const double2 v = plane[(size_t)FK * (j + 8 * m) + kx]; re[m] = v.x; im[m] = v.y; }
+    dft8<1>(re, im);
+    twiddle<1>(re, im, tw);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { pr[(j * 8 + k) * LS + kx] = re[k]; pi[(j * 8 + k) * LS + kx] = im[k]; }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 8; ++n) { re[n] = pr[(n * 8 + j) * LS + kx]; im[n] = pi[(n * 8 + j) * LS + kx]; }
+    dft8<1>(re, im);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { pr[(j + 8 * k) * LS + kx] = re[k]; pi[(j + 8 * k) * LS + kx] = im[k]; }      // row y = j + 8 k, column kx
+    __syncthreads();
+  }
+  {
+    const int y = t >> 3, j = t & 7;
+    load_tw(j, tw);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { re[m] = pr[y * LS + j + 8 * m]; im[m] = pi[y * LS + j + 8 * m]; }
+    dft8<1>(re, im);
+    twiddle<1>(re, im, tw);
+    __syncthreads();
+    double* rr = pr + y * LS + j * 9; double* ri = pi + y * LS + j * 9;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { rr[k] = re[k]; ri[k] = im[k]; }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 8; ++n) { re[n] = pr[y * LS + n * 9 + j]; im[n] = pi[y * LS + n * 9 + j]; }
+    dft8<1>(re, im);
+    double* row = theta + (size_t)FK * (y + (size_t)FK * z);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) row[j + 8 * k] = re[k];
+  }
+}
+
+}  // namespace
+
+bool fft_lds_usable(const msevb_ctx* c) { return c->fft_own && c->K == FK; }
+
+// once per context (the twiddle table is a per-device symbol; LDS beyond 64 KB needs the attribute)
+int fft_lds_setup(msevb_ctx* c) {
+  if (c->K != FK) return MSEVB_OK;
+  double2 tw[64];
+  for (int m = 0; m < 64; ++m) { const double a = 2.0 * M_PI * m / 64.0; tw[m] = make_double2(cos(a), sin(a)); }
+  // exact values where they are exact
+  tw[0] = make_double2(1, 0); tw[16] = make_double2(0, 1); tw[32] = make_double2(-1, 0); tw[48] = make_double2(0, -1);
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tw64), tw, sizeof tw));
+  const int lds = 2 * FK * LS * (int)sizeof(double);
+  HIPCHK(hipFuncSetAttribute((const void*)k_fft_xy_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fft_xy_inv, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  return MSEVB_OK;
+}
+
+// theta = Re IFFT(CB FFT(Q)); Q and theta real [64^3] (may be the same buffer), work complex [64^3]; part (optional): 256 energy partials
+int fft_lds_solve(msevb_ctx* c, const double* Q, double2* work, double* theta, double* part, int* nblocks, hipStream_t st) {
+  const int lds = 2 * FK * LS * (int)sizeof(double);
+  hipLaunchKernelGGL(k_fft_xy_fwd, dim3(FK), dim3(512), lds, st, Q, work);
+  hipLaunchKernelGGL(k_fft_z_conv, dim3(FK * 4), dim3(128), 0, st, work, c->d_CB.p, part, 0.5 * c->conv);
+  hipLaunchKernelGGL(k_fft_xy_inv, dim3(FK), dim3(512), lds, st, work, theta);
+  HIPCHK(hipGetLastError());
+  if (nblocks) *nblocks = FK * 4;
+  return MSEVB_OK;
+}

@@ -53,8 +53,10 @@ __global__ void k_remove_momentum(int N, double n_free, const double* __restrict
 }
 
 // Fused step kernels of the device-resident MD loop -----------------------------------------------------------------------------
-// first half: one thread per molecule - removal of the centre-of-mass momentum measured at the end of the previous step (:125-177),
-// half kick + drift of the molecule's atoms (:469-486), then the molecule is shifted back into the box by its centre of mass
+// first half: EIGHT LANES per molecule (lane k = the molecule's k-th atom; a thread per molecule walked its atoms through three dependent,
+// uncoalesced loads each and took 17 us in front of everything else of the step) - removal of the centre-of-mass momentum measured at the
+// end of the previous step (:125-177), half kick + drift of the atom (:469-486), then the molecule is shifted back into the box by its
+// centre of mass, which the lanes sum in atom order from each other's registers (same sum, same bits as the serial loop).
 // remove == 2: the momentum is summed HERE from the per-block partial sums the previous step's second kernel left (every block sums them
 // again - 3 x nb numbers - which takes the reduction kernel and the 56-byte download out of the chain in front of the pair loop); block 0
 // also finishes the kinetic-energy / velocity sums of that step and posts all seven to `post` (pinned host memory) and to the energy slots.
@@ -62,8 +64,8 @@ __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt
                                                          const double* __restrict__ mass, const double* __restrict__ F, double* __restrict__ en,
                                                          double* __restrict__ v, double* __restrict__ x, BoxDev box, Langevin L,
                                                          const double* __restrict__ part, int nb, double* __restrict__ post, const int* __restrict__ frozen, double n_free) {
-  __shared__ double red[256];
-  __shared__ double tot[7];
+  static_assert(MAX_MOL_ATOMS == 8, "eight lanes per molecule");
+  __shared__ double red[7][4];
   double P[3] = {0.0, 0.0, 0.0};
   if (remove == 2) {
     const int slot[7] = {S_PX, S_PY, S_PZ, S_KE, S_VX, S_VY, S_VZ};
@@ -71,43 +73,57 @@ __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt
     for (int q = 0; q < nq; ++q) {
       double s = 0.0;
       for (int k = threadIdx.x; k < nb; k += 256) s += part[(size_t)slot[q] * MAX_BLOCKS + k];
-      red[threadIdx.x] = s;
-      __syncthreads();
-      for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
-      if (threadIdx.x == 0) tot[q] = red[0];
-      __syncthreads();
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = s;
     }
-    for (int d = 0; d < 3; ++d) P[d] = tot[d];
+    __syncthreads();
+    for (int d = 0; d < 3; ++d) P[d] = ((red[d][0] + red[d][1]) + red[d][2]) + red[d][3];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+      double tot[7];
+      for (int q = 0; q < 7; ++q) tot[q] = ((red[q][0] + red[q][1]) + red[q][2]) + red[q][3];
       en[S_PX] = tot[0]; en[S_PY] = tot[1]; en[S_PZ] = tot[2]; en[S_KE] = tot[3]; en[S_VX] = tot[4]; en[S_VY] = tot[5]; en[S_VZ] = tot[6];
       if (post) { post[0] = tot[3]; post[1] = tot[0]; post[2] = tot[1]; post[3] = tot[2]; post[4] = tot[4]; post[5] = tot[5]; post[6] = tot[6]; }      // order of the slots S_KE..S_VZ
     }
   } else if (remove == 1) { P[0] = en[S_PX]; P[1] = en[S_PY]; P[2] = en[S_PZ]; }
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
-  const int n = mol_natom[m];
-  double com[3] = {0, 0, 0}, mt = 0;
-  for (int k = 0; k < n; ++k) {
-    const int a = mol_atoms[m * MAX_MOL_ATOMS + k];
-    const double ma = mass[a];
-    if (frozen && frozen[a]) { for (int d = 0; d < 3; ++d) com[d] += x[3 * a + d] * ma; mt += ma; continue; }      // neither kicked nor moved
-    double z[3] = {0, 0, 0};
-    if (L.on) normal3(L, a, z);
-    for (int d = 0; d < 3; ++d) {
-      double vv = v[3 * a + d];
-      if (remove) vv -= P[d] / n_free / ma;
-      if (L.on) vv = L.a * vv + L.b * F[3 * a + d] / ma + L.c / sqrt(ma) * z[d];
-      else vv = vv + dt / 2.0 / ma * F[3 * a + d] * 100.0;
-      v[3 * a + d] = vv;
-      const double xx = x[3 * a + d] + vv * dt;
-      x[3 * a + d] = xx;
-      com[d] += xx * ma;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = t >> 3, k = t & 7, lane0 = (threadIdx.x & 63) & ~7;
+  const int n = m < M ? mol_natom[m] : 0;
+  const bool live = k < n;
+  const int a = live ? mol_atoms[m * MAX_MOL_ATOMS + k] : 0;
+  double ma = 0.0, xn[3] = {0.0, 0.0, 0.0}, vn[3] = {0.0, 0.0, 0.0};
+  bool moved = false;
+  if (live) {
+    ma = mass[a];
+    if (frozen && frozen[a]) { for (int d = 0; d < 3; ++d) xn[d] = x[3 * a + d]; }      // neither kicked nor moved
+    else {
+      moved = true;
+      double z[3] = {0, 0, 0};
+      if (L.on) normal3(L, a, z);
+      for (int d = 0; d < 3; ++d) {
+        double vv = v[3 * a + d];
+        if (remove) vv -= P[d] / n_free / ma;
+        if (L.on) vv = L.a * vv + L.b * F[3 * a + d] / ma + L.c / sqrt(ma) * z[d];
+        else vv = vv + dt / 2.0 / ma * F[3 * a + d] * 100.0;
+        vn[d] = vv;
+        xn[d] = x[3 * a + d] + vv * dt;
+      }
     }
-    mt += ma;
   }
-  double sh[3]; bool any = false;
-  for (int d = 0; d < 3; ++d) { const double f = com[d] / mt * box.invL[d]; sh[d] = f < 0.0 ? box.L[d] : (f > 1.0 ? -box.L[d] : 0.0); any |= sh[d] != 0.0; }
-  if (any) for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) x[3 * a + d] += sh[d]; }
+  // centre of mass: the atoms' contributions in atom order (uniform trip count over the wave: shuffles)
+  double com[3] = {0, 0, 0}, mt = 0;
+  const double c0 = xn[0] * ma, c1 = xn[1] * ma, c2 = xn[2] * ma;
+#pragma unroll
+  for (int j = 0; j < MAX_MOL_ATOMS; ++j) {
+    const double p0 = __shfl(c0, lane0 + j, 64), p1 = __shfl(c1, lane0 + j, 64), p2 = __shfl(c2, lane0 + j, 64), pm = __shfl(ma, lane0 + j, 64);
+    if (j < n) { com[0] += p0; com[1] += p1; com[2] += p2; mt += pm; }
+  }
+  if (!live) return;
+  double sh[3];
+  for (int d = 0; d < 3; ++d) { const double f = com[d] / mt * box.invL[d]; sh[d] = f < 0.0 ? box.L[d] : (f > 1.0 ? -box.L[d] : 0.0); }
+  const bool any = sh[0] != 0.0 || sh[1] != 0.0 || sh[2] != 0.0;
+  if (moved) for (int d = 0; d < 3; ++d) v[3 * a + d] = vn[d];
+  if (moved || any) for (int d = 0; d < 3; ++d) x[3 * a + d] = any ? xn[d] + sh[d] : xn[d];
 }
 // second half: one thread per atom - half kick with the |F| > 1e5 guard (:508-529) and the per-block partial sums of momentum and
 // kinetic energy of the kicked velocities (calculate_kinetic_energy, src/total_energy_forces.f90:106)
@@ -187,7 +203,7 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
   }
   const double inv_mass_sum = c->inv_mass_sum_free;
   const int* frz = c->any_frozen ? c->d_frozen.p : (const int*)nullptr;
-  const int nbm = (M + 255) / 256, nba = (N + 255) / 256;
+  const int nbm8 = (int)(((size_t)M * MAX_MOL_ATOMS + 255) / 256), nba = (N + 255) / 256;
   Langevin L{};
   if (c->nvt) {      // constants of langevin_integrator (src/md_integration.f90:225): the 1/sqrt(m) stays in the kernel
     const double g = c->friction, a = exp(-g * dt / 2.0);
@@ -200,7 +216,7 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
     L.kick = c->langevin_tick++;
     // EVB loop (no host synchronisation of its own): from the second step on the kernel reduces the previous step's partial sums itself
     const bool self_reduce = use_evb && s > 0;
-    hipLaunchKernelGGL(k_step_first_half, dim3(nbm), dim3(256), 0, c->stream, M, N, dt, self_reduce ? 2 : (s > 0 ? 1 : 0), c->d_mol_natom.p, c->d_mol_atoms.p, c->d_mass.p,
+    hipLaunchKernelGGL(k_step_first_half, dim3(nbm8), dim3(256), 0, c->stream, M, N, dt, self_reduce ? 2 : (s > 0 ? 1 : 0), c->d_mol_natom.p, c->d_mol_atoms.p, c->d_mass.p,
                        c->d_force.p, c->d_energies.p, c->d_vel.p, c->d_xyz.p, box, L, c->d_partials.p, nba, self_reduce ? h_ke + 7 * (size_t)(s - 1) : (double*)nullptr, frz, c->n_free);
     phase_end(c, PH_INTEGRATE);
     double epot = 0.0;

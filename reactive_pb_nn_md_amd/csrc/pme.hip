@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_pme_prep(int N, int K, int G, const dou
 
 // one thread per (atom, k3, k2); the 6 k1 taps are consecutive grid points (modulo wrap)
 __global__ __launch_bounds__(256) void k_pme_spread(int N, int K, const double* __restrict__ chg, const int* __restrict__ base,
-                                                    const double* __restrict__ w, double2* __restrict__ grid) {
+                                                    const double* __restrict__ w, double* __restrict__ grid, int gs) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)N * 36) return;
   const int i = (int)(t / 36), r = (int)(t % 36), k3 = r / 6, k2 = r % 6;
@@ -61,11 +61,11 @@ __global__ __launch_bounds__(256) void k_pme_spread(int N, int K, const double* 
   int n2 = base[3 * i + 1] - k2; if (n2 < 0) n2 += K;
   const double w23 = w[(3 * i + 1) * 6 + k2], w3 = w[(3 * i + 2) * 6 + k3];
   const int b1 = base[3 * i];
-  double2* row = grid + (size_t)K * (n2 + (size_t)K * n3);
+  double* row = grid + (size_t)gs * K * (n2 + (size_t)K * n3);
   for (int k1 = 0; k1 < 6; ++k1) {
     int n1 = b1 - k1; if (n1 < 0) n1 += K;
     const double v = q * w[(3 * i) * 6 + k1] * w23 * w3;
-    atomicAdd(&row[n1].x, v);
+    atomicAdd(&row[gs * n1], v);
   }
 }
 
@@ -79,7 +79,7 @@ constexpr int SPREAD_CHUNK = 64;      // atoms of a cell staged in LDS at a time
 // last list build fall back to a direct global atomic.
 __global__ __launch_bounds__(256) void k_pme_spread_tiles(int K, int3 nc, int3 T, const int* __restrict__ cell_start, const int* __restrict__ perm,
                                                           const double* __restrict__ chg, const int* __restrict__ base, const double* __restrict__ w,
-                                                          double2* __restrict__ grid) {
+                                                          double* __restrict__ grid, int gs) {      // gs = 2: real parts of a complex grid, 1: real grid
   extern __shared__ double tile[];
   const int cidx = blockIdx.x;
   const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_pme_spread_tiles(int K, int3 nc, int3 T
           int n1 = b1 - k1; if (n1 < 0) n1 += K;
           int n2 = b2 - k2; if (n2 < 0) n2 += K;
           int n3 = b3 - k3; if (n3 < 0) n3 += K;
-          atomicAdd(&grid[n1 + (size_t)K * (n2 + (size_t)K * n3)].x, v);
+          atomicAdd(&grid[gs * (n1 + (size_t)K * (n2 + (size_t)K * n3))], v);
         }
         l1 = l1 == 0 ? K - 1 : l1 - 1;
       }
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_pme_spread_tiles(int K, int3 nc, int3 T
       int n1 = (ox + r % P) % K; if (n1 < 0) n1 += K;
       int n2 = (oy + r / P) % K; if (n2 < 0) n2 += K;
       int n3 = (oz + k / P2) % K; if (n3 < 0) n3 += K;
-      atomicAdd(&grid[n1 + (size_t)K * (n2 + (size_t)K * n3)].x, v);
+      atomicAdd(&grid[gs * (n1 + (size_t)K * (n2 + (size_t)K * n3))], v);
     }
   }
 }
@@ -542,6 +542,7 @@ int pme_setup(msevb_ctx* c) {
     FFTCHK(rocfft_execution_info_set_work_buffer(c->fft_info, c->d_fft_work.p, wf));
   }
   FFTCHK(rocfft_execution_info_set_stream(c->fft_info, c->stream));
+  CHK(fft_lds_setup(c));
   return pme_build_green(c);
 }
 
@@ -677,7 +678,7 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
   // side stream it is captured once into a hipGraph and replayed with one launch (the ~14 launches cost the host ~80 us per step, and
   // the host is what decides when the EVB chains behind them can start).  Steps that sample the phase timers launch directly.
   struct Key { const void* p[9]; int v[8]; } key = {{c->d_grid.p, c->d_Q.p, c->d_theta.p, c->d_w.p, c->d_base.p, c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_fft_work.p},
-                                               {N, K, c->ncell[0], c->ncell[1], c->ncell[2], c->cells_valid ? 1 : 0, (c->spread_tiles ? 1 : 0) + (c->spread_mfma ? 2 : 0) + (c->spread_bricks ? 4 : 0), slot_recip}};
+                                               {N, K, c->ncell[0], c->ncell[1], c->ncell[2], c->cells_valid ? 1 : 0, (c->spread_tiles ? 1 : 0) + (c->spread_mfma ? 2 : 0) + (c->spread_bricks ? 4 : 0) + (fft_lds_usable(c) ? 8 : 0), slot_recip}};
   const bool use_graph = join_aux && c->graphs && !c->timing_now;
   bool capturing = false;
   int nbk = 0;
@@ -692,17 +693,22 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
     phase_begin(c, PH_SPREAD, st);
     CHK(pme_prepare_atoms(c, false));
     bool bricks = false;
+    const bool own = fft_lds_usable(c);      // 64^3: three-kernel solve on the REAL charge grid (fft_lds.hip) - spread straight into Q, no real<->complex passes
     {
       int3 T;
       T.x = (int)ceil((double)K / c->ncell[0]) + 8; T.y = (int)ceil((double)K / c->ncell[1]) + 8; T.z = (int)ceil((double)K / c->ncell[2]) + 8;
       const size_t tile_bytes = (size_t)spread_plane_stride(T) * T.z * sizeof(double) + (size_t)SPREAD_CHUNK * (18 * 8 + 8 + 12);      // tile + staged atom inputs
       bricks = c->cells_valid && c->spread_bricks && K >= 16 && T.x <= 16 && T.y <= 16 && T.z <= 16 && c->d_inv_perm.p;      // bricks of <= 8 points per axis
-      if (!bricks) HIPCHK(hipMemsetAsync(c->d_grid.p, 0, K3 * sizeof(double2), st));
-      if (bricks) {      // owner computes: no zero-fill (below), no atomics, no real-copy pass
+      const bool mfma = !bricks && c->cells_valid && c->spread_mfma && T.x <= 16 && T.y <= 16 && T.z <= 16 && K >= 16;
+      const bool to_real = own && !bricks && !mfma;
+      double* g = to_real ? c->d_Q.p : (double*)c->d_grid.p;
+      const int gs = to_real ? 1 : 2;
+      if (!bricks) HIPCHK(hipMemsetAsync(g, 0, K3 * sizeof(double) * gs, st));
+      if (bricks) {      // owner computes: no zero-fill, no atomics, no real-copy pass
         const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
         hipLaunchKernelGGL(k_pme_spread_bricks, dim3(ncell), dim3(256), (size_t)3 * BRICK_CHUNK * 8 * sizeof(double), st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]),
                            c->d_cell_start.p, c->d_base_s.p, c->d_w_s.p, c->d_posq.p, c->d_grid.p, c->d_Q.p, c->d_energies.p + S_BRICK);
-      } else if (c->cells_valid && c->spread_mfma && T.x <= 16 && T.y <= 16 && T.z <= 16 && K >= 16) {      // 16^3 tile per cell: the contraction over the cell's atoms on the matrix cores
+      } else if (mfma) {      // 16^3 tile per cell: the contraction over the cell's atoms on the matrix cores
         const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
         if (!c->attr_spread_mfma) { HIPCHK(hipFuncSetAttribute((const void*)k_pme_spread_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, SPREAD_MFMA_CHUNK * 48 * 8)); c->attr_spread_mfma = true; }
         hipLaunchKernelGGL(k_pme_spread_mfma, dim3(ncell), dim3(256), (size_t)SPREAD_MFMA_CHUNK * 48 * 8, st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]),
@@ -710,20 +716,23 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
       } else if (c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= K && T.y <= K && T.z <= K) {
         const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
         hipLaunchKernelGGL(k_pme_spread_tiles, dim3(ncell), dim3(256), tile_bytes, st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T,
-                           c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_base.p, c->d_w.p, c->d_grid.p);
+                           c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_base.p, c->d_w.p, g, gs);
       } else {
         const long nt = (long)N * 36;
-        hipLaunchKernelGGL(k_pme_spread, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, N, K, c->d_chg.p, c->d_base.p, c->d_w.p, c->d_grid.p);
+        hipLaunchKernelGGL(k_pme_spread, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, N, K, c->d_chg.p, c->d_base.p, c->d_w.p, g, gs);
       }
+      int nbc = (int)((K3 + 255) / 256);
+      if (nbc > 2048) nbc = 2048;
+      if (!bricks && !to_real) hipLaunchKernelGGL(k_copy_real, dim3(nbc), dim3(256), 0, st, K3, c->d_grid.p, c->d_Q.p);      // (the brick kernel writes Q itself)
     }
-    int nbc = (int)((K3 + 255) / 256);
-    if (nbc > 2048) nbc = 2048;
-    if (!bricks) hipLaunchKernelGGL(k_copy_real, dim3(nbc), dim3(256), 0, st, K3, c->d_grid.p, c->d_Q.p);      // (the brick kernel writes Q itself)
     HIPCHK(hipGetLastError());
     phase_end(c, PH_SPREAD, st);
     phase_begin(c, PH_FFT, st);
-    CHK(pme_convolve(c, c->d_grid.p, 1, c->d_partials.p + (size_t)slot_recip * MAX_BLOCKS, MAX_BLOCKS, &nbk));
-    hipLaunchKernelGGL(k_pme_real, dim3(1024), dim3(256), 0, st, K3, c->d_grid.p, c->d_theta.p);
+    if (own) CHK(fft_lds_solve(c, c->d_Q.p, c->d_grid.p, c->d_theta.p, c->d_partials.p + (size_t)slot_recip * MAX_BLOCKS, &nbk, st));
+    else {
+      CHK(pme_convolve(c, c->d_grid.p, 1, c->d_partials.p + (size_t)slot_recip * MAX_BLOCKS, MAX_BLOCKS, &nbk));
+      hipLaunchKernelGGL(k_pme_real, dim3(1024), dim3(256), 0, st, K3, c->d_grid.p, c->d_theta.p);
+    }
     phase_end(c, PH_FFT, st);
     if (capturing) {
       hipGraph_t g = nullptr;

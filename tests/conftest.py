@@ -20,6 +20,14 @@ def golden(name):
     return np.load(os.path.join(GOLD, name + ".npz"))
 
 
+def grid_diff(g, key, arr):
+    """largest deviation of a PME grid from the fixture's: the whole grid, or - 64^3 fixtures - every 61st point of it (+ its sum)"""
+    if key in g.files:
+        return np.abs(arr - g[key]).max()
+    st = int(g[key + "_sample_stride"])
+    return max(np.abs(arr.ravel()[::st] - g[key + "_sample"]).max(), abs(arr.sum() - float(g[key + "_sum"])) * 1e-3)
+
+
 def all_golden(prefix=""):
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, prefix + "*.npz")))
 

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import all_golden, golden, pre_switch_spec, reference_atom_order
+from conftest import all_golden, golden, grid_diff, pre_switch_spec, reference_atom_order
 from reactive_pb_nn_md_amd import api, forcefield, synth, system
 
 pytestmark = pytest.mark.gpu
@@ -54,7 +54,7 @@ def test_verlet_pair_set_identical(name):
     h.close()
 
 
-@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3", "std_n6_sapt_s6", "std_n6_lb_s9", "std_n6_rb_s10", "std_n6_ex3_s12", "std_n6_k20_s13"])
+@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3", "std_n6_sapt_s6", "std_n6_lb_s9", "std_n6_rb_s10", "std_n6_ex3_s12", "std_n6_k20_s13", "std_n6_k64_s17"])
 def test_stages_against_reference(name):
     g = golden(name)
     h = api.MsEvbHip(system.from_golden(g))
@@ -68,7 +68,7 @@ def test_stages_against_reference(name):
     assert np.abs(h.get_forces() - g["F_recip"]).max() < F_TOL and rel(er, g["E_recip"][0]) < E_RTOL
     Q, th, u, fr = h.pme_state()
     assert np.array_equal(u, g["xyz_scale"])                       # scaled coordinates bit-exact
-    assert np.abs(Q - g["Q_grid"]).max() < 1e-14 and np.abs(th - g["theta_conv_Q"]).max() < 1e-13
+    assert grid_diff(g, "Q_grid", Q) < 1e-14 and grid_diff(g, "theta_conv_Q", th) < 1e-13      # (64^3: the library's own LDS transform, fft_lds.hip, against MKL's)
     near, spl = h.pme_indices()
     assert np.array_equal(near, np.floor(g["xyz_scale"]).astype(np.int32))          # PME grid indices bit-exact
     arg = g["xyz_scale"][:, :, None] - (np.floor(g["xyz_scale"])[:, :, None] - np.arange(6)[None, None, :])
@@ -126,6 +126,30 @@ def test_mfma_charge_spreading_config_B():
     for k in (1, 2):
         assert rel(out[k][0], out[0][0]) < 1e-13 and np.abs(out[k][1] - out[0][1]).max() < 1e-13 and np.abs(out[k][2] - out[0][2]).max() < F_TOL, k
         assert np.abs(out[k][3] - out[0][3]).max() < 1e-8 * np.abs(out[0][3]).max() and np.abs(out[k][4] - out[0][4]).max() < 1e-8, k
+
+
+@pytest.mark.parametrize("stores", [0, 1])
+def test_own_lds_transform_against_rocfft_and_reference(stores):
+    """csrc/fft_lds.hip (64^3 grids: three kernels for FFT . CB . IFFT, src/pme.f90:73-125) against the rocFFT path (option fft_own=0) and the
+    real reference on evb_n6_d4_k64_s18: potential, reciprocal energy and force, then the whole MS-EVB call (the Hellmann-Feynman force goes
+    through a second solve, of the blended charge grid)"""
+    g = golden("evb_n6_d4_k64_s18")
+    res = []
+    for own in (1, 0):
+        h = api.MsEvbHip(system.from_golden(g))
+        h.set_option("fft_own", own)
+        h.set_option("evb_element_stores", stores)
+        h.construct_verlet_list()
+        h.zero_forces()
+        er = h.pme_reciprocal_space_energy_force()
+        Q, th, u, fr = h.pme_state()
+        Fr = h.get_forces()
+        e, F = h.ms_evb_calculate_total_force_energy()
+        assert rel(e, g["E_adiabatic"][0]) < E_RTOL and np.abs(F - g["F_adiabatic"]).max() < F_TOL, own
+        res.append((er, th, Fr, e, F))
+        h.close()
+    assert rel(res[0][0], res[1][0]) < 1e-14 and np.abs(res[0][1] - res[1][1]).max() < 1e-13 * np.abs(res[1][1]).max()
+    assert np.abs(res[0][2] - res[1][2]).max() < 1e-11 and rel(res[0][3], res[1][3]) < 1e-14 and np.abs(res[0][4] - res[1][4]).max() < 1e-10
 
 
 @pytest.mark.parametrize("name", ["std_n6_s3", "std_n6_k20_s13"])

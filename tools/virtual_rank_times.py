@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""One GPU, R virtual ranks (the Amdahl term of the strong-scaling layout without an 8-GPU node).
+
+For R in 1, 2, 4, 8 and every rank r < R: a context of its own with `msevb_comm_set_virtual(r, R)` + `shard_principal` (what msevb_comm_init
+switches on) runs the MS-EVB force call of BASELINE.json configs[2] (98 220 atoms, 8 diabats, 64^3) and then its share of the blend with a
+fixed ground-state vector - everything a rank does between the two collectives of a step, nothing of the collectives themselves (the
+all-gather carries 2S + 9 doubles, the all-reduce 24 B/atom = 2.4 MB).  Reported: the slowest rank's time over the one-rank time.
+
+    python tools/virtual_rank_times.py [calls]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from reactive_pb_nn_md_amd import api, forcefield, synth, system  # noqa: E402
+
+
+def rank_time(spec, r, R, eigvec, calls):
+    h = api.MsEvbHip(spec)
+    if R > 1:
+        h.set_option("shard_principal", 1)
+        h.comm_set_virtual(r, R)
+    h.construct_verlet_list()
+    for _ in range(5):
+        h.ms_evb_calculate_total_force_energy(want_force=False)
+        if R > 1:
+            h.evb_partial_blend(eigvec, download=False)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        h.ms_evb_calculate_total_force_energy(want_force=False)
+        if R > 1:
+            h.evb_partial_blend(eigvec, download=False)
+    dt = (time.perf_counter() - t0) / calls
+    D = h.evb_state()["D"]
+    h.close()
+    return dt, D
+
+
+def main():
+    calls = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    s = synth.make_system(32, n_diabat=8, seed=0, max_chain=3)      # bench.py's default workload
+    p = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"])
+    spec = system.from_synth(s, p, rc=9.0, rv=10.5, alpha=0.3, pme_grid=64, max_chain=3)
+    h = api.MsEvbHip(spec)
+    h.ms_evb_calculate_total_force_energy(want_force=False)
+    ev = h.evb_state()["eigvec"].copy()
+    h.close()
+    out = {}
+    t1 = None
+    for R in (1, 2, 4, 8):
+        ts = []
+        for r in range(R):
+            dt, D = rank_time(spec, r, R, ev, calls)
+            ts.append(dt * 1e6)
+        if R == 1:
+            t1 = ts[0]
+        out[R] = {"us_per_rank": [round(t, 1) for t in ts], "slowest_over_one_rank": round(max(ts) / t1, 3), "n_diabats": int(D)}
+        print("R=%d  slowest %.1f us  (x%.3f of one rank)  per rank: %s" % (R, max(ts), max(ts) / t1, " ".join("%.0f" % t for t in ts)), flush=True)
+    print(json.dumps({"workload": "98220 atoms, 8 diabats, 64^3, force call + own share of the blend, no collectives", "calls": calls, "ranks": out}))
+
+
+if __name__ == "__main__":
+    main()

@@ -154,6 +154,11 @@ def main():
     ap.add_argument("--rccl-single", action="store_true", help="diagnostic: N=1 with a one-rank RCCL communicator (cost of the two collectives per step)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (msevb_set_option), e.g. pair_tiles=0")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON record: libraries that write to file descriptor 1 on their own (RCCL prints a five-line
+    # version banner there when a communicator is created) go to stderr for the whole run
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -329,7 +334,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
 
 
 if __name__ == "__main__":

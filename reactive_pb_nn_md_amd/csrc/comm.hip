@@ -8,6 +8,33 @@
 
 static inline int slots_per_rank(const msevb_ctx* c, int D) { return D <= 1 ? 0 : (D - 1 + c->n_ranks - 1) / c->n_ranks; }
 
+// The payload of the per-step all-gather starts and ends on the host (the Hamiltonian entries are assembled there from the published
+// energies, the gathered ones feed the host's Jacobi).  No copy commands and no stream synchronisation around the collective: a kernel
+// reads the rank's payload straight from pinned host memory, a second one writes the gathered payloads back to pinned memory followed by
+// a sequence number the host spins on (a hipStreamSynchronize sleeps on an interrupt: 50-100 us to wake up, on the step's critical path).
+namespace {
+__global__ void k_comm_stage(const double* __restrict__ host_src, double* __restrict__ dst, int n) {
+  for (int k = threadIdx.x; k < n; k += blockDim.x) dst[k] = host_src[k];
+}
+__global__ void k_comm_publish(const double* __restrict__ src, double* __restrict__ host_dst, int n, volatile long long* flag, long long seq) {
+  for (int k = threadIdx.x; k < n; k += blockDim.x) host_dst[k] = src[k];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) *flag = seq;
+}
+int comm_wait(msevb_ctx* c, long long seq) {
+  volatile long long* flag = c->h_comm_flag;
+  for (long spins = 1;; ++spins) {
+    if (*flag >= seq) return MSEVB_OK;
+    if ((spins & 0x3fff) == 0) {      // a collective that failed never publishes: ask the stream now and then
+      const hipError_t e = hipStreamQuery(c->aux2);
+      if (e == hipSuccess) { if (*flag >= seq) return MSEVB_OK; FAIL(MSEVB_ERR_COMM, "all-gather finished without publishing its result"); }
+      if (e != hipErrorNotReady) FAIL(MSEVB_ERR_HIP, std::string("HIP error behind the EVB all-gather: ") + hipGetErrorString(e));
+    }
+  }
+}
+}  // namespace
+
 extern "C" {
 
 int msevb_comm_unique_id(void* id128) {
@@ -65,15 +92,25 @@ int msevb_comm_allgather_evb(msevb_ctx* c, int with_energies) {
   ncclComm_t comm = (ncclComm_t)c->nccl_comm;
   DBuf<double>& d_h = c->d_comm_h;
   if (d_h.alloc((size_t)R * P)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (comm)");
-  std::vector<double> h((size_t)R * P, 0.0), Hm((size_t)D * D, 0.0);
+  const size_t need = (size_t)(R + 1) * P;      // pinned: [R][P] gathered payloads, then this rank's own
+  if (need > c->h_comm_cap) {
+    HIPCHK(hipStreamSynchronize(c->aux2));
+    if (c->h_comm) HIPCHK(hipHostFree(c->h_comm));
+    c->h_comm_cap = 2 * need + 64;
+    HIPCHK(hipHostMalloc((void**)&c->h_comm, c->h_comm_cap * sizeof(double), hipHostMallocDefault));
+  }
+  if (!c->h_comm_flag) { HIPCHK(hipHostMalloc((void**)&c->h_comm_flag, 64, hipHostMallocDefault)); *c->h_comm_flag = 0; }
+  std::vector<double> Hm((size_t)D * D, 0.0);
   for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) Hm[(size_t)i * D + j] = c->H[i][j];
-  double* mine = h.data() + (size_t)c->rank * P;
+  double* all = c->h_comm;
+  double* mine = c->h_comm + (size_t)R * P;
   if (msevb_evb_payload_pack(D, R, c->rank, Hm.data(), c->parent, with_energies ? c->h_energies + S_ELEC_PAIR : nullptr, mine) != MSEVB_OK) FAIL(MSEVB_ERR_ARG, "EVB payload");      // S_ELEC_PAIR .. S_RECIP are contiguous
-  HIPCHK(hipMemcpyAsync(d_h.p + (size_t)c->rank * P, mine, (size_t)P * 8, hipMemcpyHostToDevice, c->aux2));
+  hipLaunchKernelGGL(k_comm_stage, dim3(1), dim3(128), 0, c->aux2, mine, d_h.p + (size_t)c->rank * P, P);
   if (ncclAllGather(d_h.p + (size_t)c->rank * P, d_h.p, (size_t)P, ncclDouble, comm, c->aux2) != ncclSuccess) FAIL(MSEVB_ERR_COMM, "ncclAllGather failed");
-  HIPCHK(hipMemcpyAsync(h.data(), d_h.p, h.size() * 8, hipMemcpyDeviceToHost, c->aux2));
-  HIPCHK(hipStreamSynchronize(c->aux2));      // aux2 already holds the energy downloads: the main stream keeps running
-  if (msevb_evb_payload_unpack(D, R, h.data(), c->parent, Hm.data(), with_energies ? c->h_energies + S_ELEC_PAIR : nullptr) != MSEVB_OK) FAIL(MSEVB_ERR_ARG, "EVB payload");
+  hipLaunchKernelGGL(k_comm_publish, dim3(1), dim3(256), 0, c->aux2, d_h.p, all, R * P, (volatile long long*)c->h_comm_flag, ++c->comm_seq);
+  HIPCHK(hipGetLastError());
+  CHK(comm_wait(c, c->comm_seq));      // aux2 already holds the energy downloads: the main stream keeps running
+  if (msevb_evb_payload_unpack(D, R, all, c->parent, Hm.data(), with_energies ? c->h_energies + S_ELEC_PAIR : nullptr) != MSEVB_OK) FAIL(MSEVB_ERR_ARG, "EVB payload");
   for (int d = 1; d < D; ++d) { c->H[d][d] = Hm[(size_t)d * D + d]; c->H[c->parent[d]][d] = Hm[(size_t)c->parent[d] * D + d]; }
   c->H[0][0] = Hm[0];
   return MSEVB_OK;
@@ -107,6 +144,8 @@ void msevb_comm_release(msevb_ctx* c) {
   if (c->aux2) (void)hipStreamSynchronize(c->aux2);
   (void)ncclCommDestroy((ncclComm_t)c->nccl_comm);
   c->nccl_comm = nullptr;
+  if (c->h_comm) { (void)hipHostFree(c->h_comm); c->h_comm = nullptr; c->h_comm_cap = 0; }
+  if (c->h_comm_flag) { (void)hipHostFree(c->h_comm_flag); c->h_comm_flag = nullptr; }
 }
 
 }  // extern "C"

@@ -315,6 +315,7 @@ struct msevb_ctx {
   std::vector<int> hop_log; long evb_calls = 0;
   void* evb_work = nullptr;            // EvbWork of evb.hip (created by the first EVB force call, freed by evb_release)
   DBuf<double> d_comm_h, d_comm_e;     // staging of the Hamiltonian all-gather / the energy all-reduce (comm.hip)
+  double* h_comm = nullptr; size_t h_comm_cap = 0; long long* h_comm_flag = nullptr; long long comm_seq = 0;      // pinned staging of the per-step all-gather (comm.hip)
   DBuf<int> d_bad;                     // 'force too large' flag of the integrator (integrate.hip)
   double* h_ke = nullptr; int h_ke_cap = 0;      // pinned kinetic-energy records of msevb_md_integrate_atomic
   bool attr_evb_solve = false;         // hipFuncSetAttribute done on this context's device

@@ -447,11 +447,11 @@ __global__ void k_mol_com(int M, const int* __restrict__ mol_natom, const int* _
 // thread-per-atom version kept 16 x 3 Zundel accumulators in scratch memory (dynamic indexing) and ran 4x longer.  The minimum image is
 // taken per molecule, relative to the Zundel centre of mass, with the molecular centres of mass precomputed per atom by k_mol_com.
 template <int QL>      // q-lanes per atom: 8 when every coupling has <= 8 Zundel atoms (water / hydronium), else 16
-__global__ __launch_bounds__(256) void k_evb_coupling(int N, int n_cp, const CouplingDesc* __restrict__ cps, const int* __restrict__ mol_of,
-                                                      const double* __restrict__ com_atom, const double* __restrict__ xyz, const double* __restrict__ chg,
-                                                      const double* __restrict__ exch_atomic,
-                                                      BoxDev box, double conv, double* __restrict__ Foff, size_t fstride, double* __restrict__ part,
-                                                      int part_stride, double* __restrict__ dVspec, int ic0) {
+__device__ __forceinline__ void evb_coupling_body(int N, int n_cp, const CouplingDesc* __restrict__ cps, const int* __restrict__ mol_of,
+                                                  const double* __restrict__ com_atom, const double* __restrict__ xyz, const double* __restrict__ chg,
+                                                  const double* __restrict__ exch_atomic,
+                                                  BoxDev box, double conv, double* __restrict__ Foff, size_t fstride, double* __restrict__ part,
+                                                  int part_stride, double* __restrict__ dVspec, int ic0, int nbx) {
   constexpr int APW = 64 / QL;      // atoms per wavefront trip
   __shared__ CouplingDesc cp;
   __shared__ double sF[MAX_SPEC][3];
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void k_evb_coupling(int N, int n_cp, const Cou
   __syncthreads();
   double* F = Foff + (size_t)cp.slot * fstride;
   const int lane = threadIdx.x & 63, q = lane & (QL - 1), js = lane / QL;
-  const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+  const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = nbx * (blockDim.x >> 6);
   const bool qlive = q < nz;
   const double zxq[3] = {zx[q][0], zx[q][1], zx[q][2]}, zqq = zq[q];
   double vex = 0.0, fzx = 0.0, fzy = 0.0, fzz = 0.0;
@@ -521,6 +521,21 @@ __global__ __launch_bounds__(256) void k_evb_coupling(int N, int n_cp, const Cou
   if (threadIdx.x == 0) part[(size_t)ic * part_stride + blockIdx.x] = red[0];
   for (int k = threadIdx.x; k < cp.n_spec * 3; k += blockDim.x) { const double v = sF[k / 3][k % 3]; if (v != 0.0) atomicAdd(&dVspec[((size_t)ic * CPL_BINS + (blockIdx.x % CPL_BINS)) * MAX_SPEC * 3 + k], v); }
 }
+// ONE launch for all couplings of a step: blockIdx.y < n_big -> the 16-lane body (the acid's coupling), else the 8-lane one; launched one
+// behind the other they cost 15 + 36 us of a latency-bound chain the host's turn waits for.  nb_big / nb_small workgroups per coupling.
+__global__ __launch_bounds__(256) void k_evb_coupling(int N, int n_cp, const CouplingDesc* __restrict__ cps, const int* __restrict__ mol_of,
+                                                      const double* __restrict__ com_atom, const double* __restrict__ xyz, const double* __restrict__ chg,
+                                                      const double* __restrict__ exch_atomic,
+                                                      BoxDev box, double conv, double* __restrict__ Foff, size_t fstride, double* __restrict__ part,
+                                                      int part_stride, double* __restrict__ dVspec, int n_big, int nb_big, int nb_small) {
+  if ((int)blockIdx.y < n_big) {
+    if ((int)blockIdx.x >= nb_big) return;
+    evb_coupling_body<16>(N, n_cp, cps, mol_of, com_atom, xyz, chg, exch_atomic, box, conv, Foff, fstride, part, part_stride, dVspec, 0, nb_big);
+  } else {
+    if ((int)blockIdx.x >= nb_small) return;
+    evb_coupling_body<8>(N, n_cp, cps, mol_of, com_atom, xyz, chg, exch_atomic, box, conv, Foff, fstride, part, part_stride, dVspec, 0, nb_small);
+  }
+}
 
 // evb_diabatic_coupling_function (src/ms_evb.f90:1180-1266)
 __device__ __forceinline__ void coupling_function(int ftype, const double* p, const double* q, const double* rOO, double& A, double& Vc, double dA[3][3]) {
@@ -545,20 +560,30 @@ __device__ __forceinline__ void coupling_function(int ftype, const double* p, co
   }
 }
 
-// one thread per coupling: special-molecule part of Vex (molecules of the chain that are neither donor nor acceptor),
-// geometric factor, element energy; writes {A, Vc+Vex, H_pd} and the forces of the special atoms
-__global__ void k_evb_coupling_finish(int n_cp, const CouplingDesc* __restrict__ cps, const double* __restrict__ exch_atomic, const double* __restrict__ mass,
-                                      BoxDev box, double conv, const double* __restrict__ Vex_env, double* __restrict__ dVspec,
-                                      double* __restrict__ Foff, size_t fstride, double* __restrict__ out /*[n_cp][3]*/) {
+// one wavefront per coupling: sum of the coupling kernel's partial sums (its row of `part`: n_big couplings with nb_big entries first, the
+// rest with nb_small), special-molecule part of Vex (molecules of the chain that are neither donor nor acceptor: lanes over the
+// (special atom, Zundel atom) pairs), geometric factor, element energy; writes {A, Vc+Vex, H_pd} and the forces of the special atoms.
+// (The serial version - one thread per coupling - was 33 us of the chain the host's turn waits for.)
+__global__ __launch_bounds__(64) void k_evb_coupling_finish(int n_cp, const CouplingDesc* __restrict__ cps, const double* __restrict__ exch_atomic, const double* __restrict__ mass,
+                                      BoxDev box, double conv, const double* __restrict__ part, int part_stride, int n_big, int nb_big, int nb_small, double* __restrict__ Vex_env,
+                                      double* __restrict__ dVspec, double* __restrict__ Foff, size_t fstride, double* __restrict__ out /*[n_cp][3]*/) {
   const int ic = blockIdx.x;
   if (ic >= n_cp) return;
-  __shared__ CouplingDesc cp;      // staged once: the serial part below walks the descriptor with dependent reads (global memory: 34 us per launch)
+  __shared__ CouplingDesc cp;      // staged once: the code below walks the descriptor with dependent reads
   {
     const int* src = (const int*)&cps[ic]; int* dst = (int*)&cp;
     for (int k = threadIdx.x; k < (int)(sizeof(CouplingDesc) / 4); k += blockDim.x) dst[k] = src[k];
   }
   __shared__ double dV[MAX_SPEC][3];
-  __shared__ bool inDA[MAX_SPEC];
+  __shared__ bool inDA[MAX_SPEC], other[MAX_SPEC];
+  __shared__ double shm_mol[MAX_CHAIN + 1][3];
+  __shared__ double zx[2 * MAX_MOL_ATOMS][3], zq[2 * MAX_MOL_ATOMS];
+  __shared__ int zs[2 * MAX_MOL_ATOMS];
+  double vex = 0.0;
+  {      // environment part of Vex: this coupling's row of partial sums
+    const int nb = ic < n_big ? nb_big : nb_small;
+    for (int k = threadIdx.x; k < nb; k += 64) vex += part[(size_t)ic * part_stride + k];
+  }
   __syncthreads();
   for (int k = threadIdx.x; k < cp.n_spec * 3; k += blockDim.x) {      // sum of the CPL_BINS copies the coupling kernels added into, which are left zeroed
     double* p = dVspec + (size_t)ic * CPL_BINS * MAX_SPEC * 3 + k;
@@ -570,54 +595,62 @@ __global__ void k_evb_coupling_finish(int n_cp, const CouplingDesc* __restrict__
     for (int b = 0; b < CPL_BINS; ++b) sum += v[b];
     (&dV[0][0])[k] = sum;
   }
+  for (int k = threadIdx.x; k < cp.n_spec; k += 64) inDA[k] = false;
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  double vex = Vex_env[ic];
-  for (int k = 0; k < cp.n_spec; ++k) inDA[k] = false;
-  for (int k = 0; k < cp.nD; ++k) inDA[cp.D_at[k]] = true;
-  for (int k = 0; k < cp.nA; ++k) inDA[cp.A_at[k]] = true;
-  for (int im = 0; im < cp.n_mols; ++im) {       // special molecules other than donor / acceptor
-    const int m = cp.mols[im];
-    bool any = false, isDA = false;
-    for (int b = 0; b < cp.n_spec; ++b) if (cp.spec[b].mol == m) { any = true; isDA |= inDA[b]; }
-    if (!any || isDA) continue;
-    double sh[3];
-    for (int d = 0; d < 3; ++d) sh[d] = floor((cp.mol_com[im][d] - cp.zc[d]) * box.invL[d] + 0.5) * box.L[d];
-    for (int b = 0; b < cp.n_spec; ++b) {
-      if (cp.spec[b].mol != m) continue;
-      const double qj = cp.spec[b].q;
-      for (int side = 0; side < 2; ++side) {
-        const int na = side == 0 ? cp.nD : cp.nA;
-        const int* lst = side == 0 ? cp.D_at : cp.A_at;
-        const double* shm = side == 0 ? cp.shiftd : cp.shifta;
-        for (int q = 0; q < na; ++q) {
-          const SpecAtom& a = cp.spec[lst[q]];
-          const double qi = (side == 1 && q == na - 1) ? cp.q_transfer : exch_atomic[a.type];
-          double rij[3];
-          for (int d = 0; d < 3; ++d) { const double xz = cp.zc[d] + (a.x[d] - cp.zc[d] - shm[d]); rij[d] = -(cp.spec[b].x[d] - xz - sh[d]); }
-          const double r2 = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2], r = sqrt(r2);
-          vex += qi * qj / r * conv;
-          const double g = -qi * qj / (r2 * r) * conv;
-          for (int d = 0; d < 3; ++d) { dV[lst[q]][d] += g * rij[d]; dV[b][d] -= g * rij[d]; }
-        }
-      }
+  const int nz = cp.nD + cp.nA;
+  if ((int)threadIdx.x < nz) {      // Zundel atoms: image next to the Zundel centre, exchange charge
+    const int q = threadIdx.x;
+    const bool acc = q >= cp.nD;
+    const int sp = acc ? cp.A_at[q - cp.nD] : cp.D_at[q];
+    const double* shm = acc ? cp.shifta : cp.shiftd;
+    for (int d = 0; d < 3; ++d) zx[q][d] = cp.zc[d] + (cp.spec[sp].x[d] - cp.zc[d] - shm[d]);
+    zq[q] = (acc && q == nz - 1) ? cp.q_transfer : exch_atomic[cp.spec[sp].type];
+    zs[q] = sp;
+    inDA[sp] = true;
+  }
+  if ((int)threadIdx.x < cp.n_mols) for (int d = 0; d < 3; ++d) shm_mol[threadIdx.x][d] = floor((cp.mol_com[threadIdx.x][d] - cp.zc[d]) * box.invL[d] + 0.5) * box.L[d];
+  __syncthreads();
+  for (int b = threadIdx.x; b < cp.n_spec; b += 64) {      // atoms of special molecules other than donor / acceptor
+    bool isDA = false;
+    for (int k = 0; k < cp.n_spec; ++k) if (cp.spec[k].mol == cp.spec[b].mol) isDA |= inDA[k];
+    other[b] = !isDA;
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < cp.n_spec * nz; it += 64) {
+    const int b = it / nz, q = it - b * nz;
+    if (!other[b]) continue;
+    int im = 0;
+    for (int k = 0; k < cp.n_mols; ++k) if (cp.mols[k] == cp.spec[b].mol) im = k;
+    const double qi = zq[q], qj = cp.spec[b].q;
+    double rij[3];
+    for (int d = 0; d < 3; ++d) rij[d] = -(cp.spec[b].x[d] - zx[q][d] - shm_mol[im][d]);
+    const double r2 = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2], r = sqrt(r2);
+    vex += qi * qj / r * conv;
+    const double g = -qi * qj / (r2 * r) * conv;
+    for (int d = 0; d < 3; ++d) { atomicAdd(&dV[zs[q]][d], g * rij[d]); atomicAdd(&dV[b][d], -g * rij[d]); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) vex += __shfl_xor(vex, o, 64);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Vex_env[ic] = vex;
+    // geometric factor (evb_diabatic_coupling_geometric, src/ms_evb.f90:1117-1174)
+    const SpecAtom &O1 = cp.spec[cp.gO1], &O2 = cp.spec[cp.gO2], &H = cp.spec[cp.gH];
+    double sh[3], rO2[3], rH[3], rOO[3], q[3];
+    for (int d = 0; d < 3; ++d) {
+      sh[d] = floor((O2.x[d] - O1.x[d]) * box.invL[d] + 0.5) * box.L[d];
+      rO2[d] = O1.x[d] + (O2.x[d] - O1.x[d] - sh[d]); rH[d] = O1.x[d] + (H.x[d] - O1.x[d] - sh[d]);
+      rOO[d] = O1.x[d] - rO2[d]; q[d] = (O1.x[d] + rO2[d]) / 2.0 - rH[d];
     }
+    double A, Vc, dA[3][3];
+    coupling_function(cp.ftype, cp.par, q, rOO, A, Vc, dA);
+    const double pre = Vc + vex;
+    for (int d = 0; d < 3; ++d) { dV[cp.gO1][d] += pre * dA[0][d] / A; dV[cp.gO2][d] += pre * dA[1][d] / A; dV[cp.gH][d] += pre * dA[2][d] / A; }
+    out[3 * ic] = A; out[3 * ic + 1] = pre; out[3 * ic + 2] = pre * A;
   }
-  // geometric factor (evb_diabatic_coupling_geometric, src/ms_evb.f90:1117-1174)
-  const SpecAtom &O1 = cp.spec[cp.gO1], &O2 = cp.spec[cp.gO2], &H = cp.spec[cp.gH];
-  double sh[3], rO2[3], rH[3], rOO[3], q[3];
-  for (int d = 0; d < 3; ++d) {
-    sh[d] = floor((O2.x[d] - O1.x[d]) * box.invL[d] + 0.5) * box.L[d];
-    rO2[d] = O1.x[d] + (O2.x[d] - O1.x[d] - sh[d]); rH[d] = O1.x[d] + (H.x[d] - O1.x[d] - sh[d]);
-    rOO[d] = O1.x[d] - rO2[d]; q[d] = (O1.x[d] + rO2[d]) / 2.0 - rH[d];
-  }
-  double A, Vc, dA[3][3];
-  coupling_function(cp.ftype, cp.par, q, rOO, A, Vc, dA);
-  const double pre = Vc + vex;
-  for (int d = 0; d < 3; ++d) { dV[cp.gO1][d] += pre * dA[0][d] / A; dV[cp.gO2][d] += pre * dA[1][d] / A; dV[cp.gH][d] += pre * dA[2][d] / A; }
+  __syncthreads();
   double* F = Foff + (size_t)cp.slot * fstride;
-  for (int k = 0; k < cp.n_spec; ++k) for (int d = 0; d < 3; ++d) F[3 * cp.spec[k].idx + d] = dV[k][d];   // still "dV": the factor -A goes into the blend coefficient
-  out[3 * ic] = A; out[3 * ic + 1] = pre; out[3 * ic + 2] = pre * A;
+  for (int k = threadIdx.x; k < cp.n_spec * 3; k += 64) F[3 * cp.spec[k / 3].idx + k % 3] = dV[k / 3][k % 3];   // still "dV": the factor -A goes into the blend coefficient
 }
 
 // Hellmann-Feynman blend: F = sum_d c_d^2 F_dd + 2 sum_(p,d) c_p c_d F_pd (src/ms_evb.f90:293-309).
@@ -1020,6 +1053,7 @@ struct EvbWork {   // persistent device scratch of one context
   // what the last force call left behind, for msevb_evb_partial_blend on the fast path (virtual-rank tests)
   int last_ngrid = 0, last_nra = 0, last_grid_of[MAX_DIABATS]; const RecipAtom* last_d_ra = nullptr; bool last_fast = false;
   bool counters_dirty = true, dv_dirty = true, mol_deferred = false;
+  bool pack_prefilled = false; hipEvent_t ev_prefill = nullptr;      // the blended charge grid starts as a copy of Q_1, made while the host waits for the energies
   std::vector<RegionRec> region, region_raw; std::vector<long long> region_key;
   std::vector<UnitDesc> units; std::vector<CouplingDesc> cps, cps_sorted; std::vector<RecipAtom> ras;      // descriptors of the current force call
 };
@@ -1248,8 +1282,10 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
     } else {
       if (w->d_grids.alloc_room(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended charge grid)");
       if (fft_lds_usable(c)) {      // real grid in, real potential out, in place in d_pack (d_grids is the transform's complex work space)
-        if (c->rank == 0) HIPCHK(hipMemcpyAsync(w->d_pack.p, c->d_Q.p, K3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        if (w->pack_prefilled) { if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_prefill, 0)); }      // (went out before the host's turn)
+        else if (c->rank == 0) HIPCHK(hipMemcpyAsync(w->d_pack.p, c->d_Q.p, K3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         else HIPCHK(hipMemsetAsync(w->d_pack.p, 0, K3 * sizeof(double), c->stream));
+        w->pack_prefilled = false;
         hipLaunchKernelGGL(k_evb_blend_patch, dim3((w->last_nst + 3) / 4), dim3(256), 0, c->stream, w->last_nst, w->d_stencils.p, gc, dcoef, K, w->d_pack.p, 1);
         HIPCHK(hipGetLastError());
         CHK(fft_lds_solve(c, w->d_pack.p, w->d_grids.p, w->d_pack.p, nullptr, nullptr, c->stream));
@@ -1628,21 +1664,6 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   HIPCHK(hipGetLastError());
   phase_end(c, PH_EVB_REAL, sr);
   stamp(c, 4, sr);
-  if (linear) {      // behind the real-space deltas on the descriptor stream: done long before the principal convolution, whose tail (k_evb_recip_linear) waits for it
-    if (ngrid) {      // stencil records of the special atoms (old and new state) and their mutual interaction through G = IFFT(CB)
-      const int nst = 2 * nra;
-      GridRanges granges;
-      { int g = 0; granges.start[0] = 0; for (int e = 0; e < nra; ++e) { while (g < ras[e].grid) granges.start[++g] = 2 * e; } while (g < ngrid) granges.start[++g] = nst; }
-      int max_ns = 0;
-      for (int g = 0; g < ngrid; ++g) max_ns = std::max(max_ns, granges.start[g + 1] - granges.start[g]);
-      if (ht_on && g_ht.n == 3) fprintf(stderr, "[msevb] recip entries %d, grids %d, most stencils per grid %d\n", nra, ngrid, max_ns);
-      hipLaunchKernelGGL(k_evb_stencils, dim3((nra + 63) / 64), dim3(64), 0, ss, nra, d_ra, w->d_obase.p, w->d_ow.p, w->d_odw.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p, w->d_stencils.p);
-      hipLaunchKernelGGL(k_evb_recip_pairs, dim3(max_ns, ngrid), dim3(256), 0, ss, granges, w->d_stencils.p, K, c->d_green.p, c->conv, c->kk[0][0], c->kk[0][1],
-                         c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p + MAX_DIABATS);
-      HIPCHK(hipGetLastError());
-    }
-    if (c->overlap) HIPCHK(hipEventRecord(w->ev_pairs, ss));
-  }
   if (c->overlap) HIPCHK(hipEventRecord(w->ev_join2, w->stream2));
   // ---- 6a'. off-diagonal elements (evb_diabatic_coupling, :1021): few, latency-bound kernels writing only d_Foff; on aux2 behind the
   //           diagonal deltas (the all-atom gather waits for those, only the blend for these)
@@ -1653,14 +1674,10 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     if (c->overlap) HIPCHK(hipStreamWaitEvent(so, w->ev_fork2, 0));
     // ~1000 workgroups per launch in all: every block pays a descriptor copy, two barriers and the Zundel reductions
     const int cpb_big = cpb, cpb_small = std::min(cpb, std::max(256, 6144 / std::max(ncp - ncp_big, 1)));      // few trips per wave: the kernels are latency-bound
-    if (ncp_big) hipLaunchKernelGGL(k_evb_coupling<16>, dim3(cpb_big, ncp_big), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, w->d_com_atom.p, c->d_xyz.p, c->d_chg.p,
-                                    w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p, 0);
-    if (ncp > ncp_big) hipLaunchKernelGGL(k_evb_coupling<8>, dim3(cpb_small, ncp - ncp_big), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, w->d_com_atom.p, c->d_xyz.p, c->d_chg.p,
-                                          w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p, ncp_big);
-    if (ncp_big) hipLaunchKernelGGL(k_sum_rows, dim3(ncp_big), dim3(256), 0, so, ncp_big, cpb_big, part_stride, part_cp, E_cp_env);
-    if (ncp > ncp_big) hipLaunchKernelGGL(k_sum_rows, dim3(ncp - ncp_big), dim3(256), 0, so, ncp - ncp_big, cpb_small, part_stride, part_cp + (size_t)ncp_big * part_stride, E_cp_env + ncp_big);
-    hipLaunchKernelGGL(k_evb_coupling_finish, dim3(ncp), dim3(64), 0, so, ncp, d_cps, w->d_exch.p, c->d_mass.p, box, c->conv, E_cp_env,
-                       w->d_dVspec.p, c->d_Foff.p, n3, d_cpout);
+    hipLaunchKernelGGL(k_evb_coupling, dim3(std::max(cpb_big, cpb_small), ncp), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, w->d_com_atom.p, c->d_xyz.p, c->d_chg.p,
+                       w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p, ncp_big, cpb_big, cpb_small);
+    hipLaunchKernelGGL(k_evb_coupling_finish, dim3(ncp), dim3(64), 0, so, ncp, d_cps, w->d_exch.p, c->d_mass.p, box, c->conv, (const double*)part_cp, part_stride, ncp_big, cpb_big, cpb_small,
+                       E_cp_env, w->d_dVspec.p, c->d_Foff.p, n3, d_cpout);
     HIPCHK(hipGetLastError());
     stamp(c, 7, so);
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_cpl, so));
@@ -1741,7 +1758,19 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     // energies relative to the principal diabat -> E_grid, forces on the special atoms -> the diabats' slots of the delta store
     // (the stencil records and the stencil-pair sums need no potential: they went out on the descriptor stream right behind the special
     //  atoms' stencils, step 5; here, behind the principal convolution, only the dots with theta_1 are left)
-    if (c->overlap) HIPCHK(hipStreamWaitEvent(sg, w->ev_pairs, 0));
+    // The stencil records and the stencil-pair sums need the special atoms' stencils only (descriptor stream, ev_fork2 - long done): they
+    // run HERE, on the stream of the principal front end right behind it, with the dots against theta_1 - no event hop in between, and not
+    // behind the environment chain of the descriptor stream, where they used to wait ~100 us for kernels they do not depend on
+    {
+      GridRanges granges;
+      { int g = 0; granges.start[0] = 0; for (int e = 0; e < nra; ++e) { while (g < ras[e].grid) granges.start[++g] = 2 * e; } while (g < ngrid) granges.start[++g] = nst; }
+      int max_ns = 0;
+      for (int g = 0; g < ngrid; ++g) max_ns = std::max(max_ns, granges.start[g + 1] - granges.start[g]);
+      if (ht_on && g_ht.n == 3) fprintf(stderr, "[msevb] recip entries %d, grids %d, most stencils per grid %d\n", nra, ngrid, max_ns);
+      hipLaunchKernelGGL(k_evb_stencils, dim3((nra + 63) / 64), dim3(64), 0, sg, nra, d_ra, w->d_obase.p, w->d_ow.p, w->d_odw.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p, w->d_stencils.p);
+      hipLaunchKernelGGL(k_evb_recip_pairs, dim3(max_ns, ngrid), dim3(256), 0, sg, granges, w->d_stencils.p, K, c->d_green.p, c->conv, c->kk[0][0], c->kk[0][1],
+                         c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p + MAX_DIABATS);
+    }
     hipLaunchKernelGGL(k_evb_recip_linear, dim3((nst + 3) / 4), dim3(256), 0, sg, nst, w->d_stencils.p, K, c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
                        c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p);
     hipLaunchKernelGGL(k_evb_grid_energy, dim3(1), dim3(128), 0, sg, ngrid, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid);
@@ -1762,6 +1791,13 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   phase_end(c, PH_EVB_RECIP, sg);
   stamp(c, 6, sg);
   CHK(fetch_A());
+  if (fast && ngrid && linear && fft_lds_usable(c) && !dev_solve) {      // start value of the blended charge grid (Q_1 on rank 0): needs no coefficient, so it goes out before the host's turn
+    if (!w->ev_prefill) HIPCHK(hipEventCreateWithFlags(&w->ev_prefill, hipEventDisableTiming));
+    if (c->rank == 0) HIPCHK(hipMemcpyAsync(w->d_pack.p, c->d_Q.p, K3 * sizeof(double), hipMemcpyDeviceToDevice, sg));
+    else HIPCHK(hipMemsetAsync(w->d_pack.p, 0, K3 * sizeof(double), sg));
+    HIPCHK(hipEventRecord(w->ev_prefill, sg));
+    w->pack_prefilled = true;
+  } else w->pack_prefilled = false;
   if (fast && ngrid && !linear) {      // own-stencil corrections of the special atoms -> delta store; behind the energy fetch on this stream: the host's turn does not wait for it
     hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, sg, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
                        w->d_sw.p, w->d_sdw.p, w->d_grids.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0],
@@ -1939,7 +1975,7 @@ void evb_release(msevb_ctx* c) {
     DBuf<double>* db[] = {&w->d_exch, &w->d_part, &w->d_E, &w->d_dVspec, &w->d_sw, &w->d_sdw, &w->d_Fdelta, &w->d_F11, &w->d_pack, &w->d_com_atom};
     for (auto b : db) b->release();
     w->d_stencils.release(); w->d_Elq.release(); w->d_ow.release(); w->d_odw.release(); w->d_obase.release(); w->d_tabs.release(); w->d_sbase.release(); w->d_counter.release(); w->d_grids.release(); w->d_region.release(); w->d_cand.release(); w->d_desc.release();
-    hipEvent_t* ev[] = {&w->ev_pairs, &w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA, &w->ev_solve, &w->ev_rs};
+    hipEvent_t* ev[] = {&w->ev_prefill, &w->ev_pairs, &w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA, &w->ev_solve, &w->ev_rs};
     for (auto e : ev) if (*e) (void)hipEventDestroy(*e);
     if (w->h_region) (void)hipHostFree(w->h_region);
     if (w->h_count) (void)hipHostFree(w->h_count);

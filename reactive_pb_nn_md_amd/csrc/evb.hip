@@ -259,9 +259,17 @@ __global__ __launch_bounds__(256) void k_evb_env(const int* __restrict__ n_cand,
 __global__ __launch_bounds__(64) void k_evb_special(int n_units, const UnitDesc* __restrict__ units, const EvbTablesDev* __restrict__ tabs, const MolTypeDev* __restrict__ mts,
                               const PairParam* __restrict__ pairpar, int nt, const double2* __restrict__ etab, double inv_dx,
                               const double* __restrict__ tt, const double* __restrict__ dtt, BoxDev box, double rc2, double alpha, double erf_factor,
-                              double conv, double pi_ref, double* __restrict__ Fstore, size_t fstride, double* __restrict__ Eout) {
+                              double conv, double pi_ref, double* __restrict__ Fstore, size_t fstride, double* __restrict__ Eout,
+                              const double* __restrict__ env_part, int env_nb, int env_stride, double* __restrict__ Eenv) {
   const int iu = blockIdx.x, lane = threadIdx.x;
   if (iu >= n_units) return;
+  if (env_part) {      // the unit's environment energy: sum of k_evb_env's per-block partial sums (was a k_sum_rows launch between the two kernels)
+    double e = 0.0;
+    for (int b = lane; b < env_nb; b += 64) e += env_part[(size_t)iu * env_stride + b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+    if (lane == 0) Eenv[iu] = e;
+  }
   __shared__ UnitDesc u;
   __shared__ EvbTablesDev tb;
   __shared__ double f[MAX_SPEC][3];
@@ -953,34 +961,55 @@ __global__ __launch_bounds__(64) void k_evb_solve(const SolveDesc* __restrict__ 
 
 __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms, const double* __restrict__ xyz,
                              const double* __restrict__ mass, BoxDev box, int* __restrict__ counter, RegionRec* __restrict__ out, int cap,
-                             int* __restrict__ cand_counter, RegionRec* __restrict__ out_host, int cap_host) {
+                             int* __restrict__ cand_counter, RegionRec* __restrict__ out_host, int cap_host,
+                             int* __restrict__ ticket, int* __restrict__ host_count, volatile long long* flag, long long seq) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m == 0) *cand_counter = 0;      // re-arm k_evb_candidates (which in turn re-arms `counter` for the next step)
-  if (m >= M) return;
-  double ch[3] = {0, 0, 0}, mh = 0;
-  for (int k = 0; k < mol_natom[hyd]; ++k) { const int a = mol_atoms[hyd * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) ch[d] += xyz[3 * a + d] * mass[a]; mh += mass[a]; }
-  const int n = mol_natom[m];
-  double com[3] = {0, 0, 0}, mt = 0;
-  for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) com[d] += xyz[3 * a + d] * mass[a]; mt += mass[a]; }
-  double dr[3];
-  for (int d = 0; d < 3; ++d) { com[d] /= mt; dr[d] = com[d] - ch[d] / mh; }
-  min_image(dr, box);
-  if (dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2] < R2) {
-    const int slot = atomicAdd(counter, 1);
-    if (slot < cap) {
-      RegionRec r; r.mol = m; r.natom = n;
-      for (int d = 0; d < 3; ++d) r.com[d] = com[d];
-      for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) r.x[k][d] = xyz[3 * a + d]; }
-      out[slot] = r;
-      if (slot < cap_host) out_host[slot] = r;      // pinned host memory, written directly: no copy command behind the kernel
+  if (m < M) {
+    double ch[3] = {0, 0, 0}, mh = 0;
+    for (int k = 0; k < mol_natom[hyd]; ++k) { const int a = mol_atoms[hyd * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) ch[d] += xyz[3 * a + d] * mass[a]; mh += mass[a]; }
+    const int n = mol_natom[m];
+    double com[3] = {0, 0, 0}, mt = 0;
+    for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) com[d] += xyz[3 * a + d] * mass[a]; mt += mass[a]; }
+    double dr[3];
+    for (int d = 0; d < 3; ++d) { com[d] /= mt; dr[d] = com[d] - ch[d] / mh; }
+    min_image(dr, box);
+    if (dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2] < R2) {
+      const int slot = atomicAdd(counter, 1);
+      if (slot < cap) {
+        RegionRec r; r.mol = m; r.natom = n;
+        for (int d = 0; d < 3; ++d) r.com[d] = com[d];
+        for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) r.x[k][d] = xyz[3 * a + d]; }
+        out[slot] = r;
+        if (slot < cap_host) out_host[slot] = r;      // pinned host memory, written directly: no copy command behind the kernel
+      }
     }
   }
+  // the workgroup that finishes last publishes the record count and the sequence number the host spins on (was a launch of its own
+  // on the path the host's turn waits for): every block makes its records visible to the host before it draws its ticket
+  __shared__ bool last;
+  __syncthreads();
+  if (threadIdx.x == 0) { __threadfence_system(); last = atomicAdd(ticket, 1) == (int)gridDim.x - 1; }
+  __syncthreads();
+  if (!last || threadIdx.x != 0) return;
+  __threadfence_system();
+  *host_count = atomicAdd(counter, 0);
+  *ticket = 0;
+  __threadfence_system();
+  *flag = seq;
 }
 
 // copies two small device arrays into pinned host memory (zero-copy stores): the energy downloads, without copy commands
 // flag != nullptr: after the data, the sequence number goes to pinned memory - the host spins on it instead of sleeping on an event
-__global__ void k_evb_publish(const double* __restrict__ a, int na, double* __restrict__ ha, const double* __restrict__ b, int nb, double* __restrict__ hb,
-                              volatile long long* flag = nullptr, long long seq = 0) {
+// ng > 0: first the diabats' grid energies, E_grid[g] = conv (E_lin[g] + E_quad[g] / 2), accumulators re-zeroed (k_evb_grid_energy - E_grid lies inside a)
+__global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, const double* __restrict__ b, int nb, double* __restrict__ hb,
+                              volatile long long* flag = nullptr, long long seq = 0, int ng = 0, double* E_lin = nullptr, double* E_quad = nullptr,
+                              double conv = 0.0, double* E_grid = nullptr) {      // (a and E_grid alias: no __restrict__ on them)
+  if (ng > 0) {
+    for (int g = threadIdx.x; g < ng; g += blockDim.x) { E_grid[g] = conv * (E_lin[g] + 0.5 * E_quad[g]); E_lin[g] = 0.0; E_quad[g] = 0.0; }
+    __threadfence_block();
+    __syncthreads();
+  }
   for (int k = threadIdx.x; k < na; k += blockDim.x) ha[k] = a[k];
   for (int k = threadIdx.x; k < nb; k += blockDim.x) hb[k] = b[k];
   if (flag) { __threadfence_system(); __syncthreads(); if (threadIdx.x == 0) *flag = seq; }
@@ -1368,10 +1397,10 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   // out on the MAIN stream, directly behind the integrator's first kernel (on a side stream it started one cross-queue event hop,
   // ~15 us, later; the pair loop, which it now precedes, has that much slack before the blend needs it)
   const hipStream_t s_reg = c->overlap && c->evb_region_main ? c->stream : w->stream2;
-  hipLaunchKernelGGL(k_evb_region, dim3((M + 255) / 256), dim3(256), 0, s_reg, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
-                     c->d_mass.p, box, w->d_counter.p, w->d_region.p, REGION_CAP, w->d_counter.p + 1, w->h_region, REGION_FAST);
   if (!w->h_flag) { HIPCHK(hipHostMalloc((void**)&w->h_flag, 64, hipHostMallocDefault)); memset(w->h_flag, 0, 64); }
-  hipLaunchKernelGGL(k_evb_publish_count, dim3(1), dim3(1), 0, s_reg, w->d_counter.p, w->h_count, (volatile long long*)(w->h_flag + 1), ++w->seq_R);
+  hipLaunchKernelGGL(k_evb_region, dim3((M + 255) / 256), dim3(256), 0, s_reg, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
+                     c->d_mass.p, box, w->d_counter.p, w->d_region.p, REGION_CAP, w->d_counter.p + 1, w->h_region, REGION_FAST,
+                     w->d_counter.p + 2, w->h_count, (volatile long long*)(w->h_flag + 1), ++w->seq_R);
   HIPCHK(hipEventRecord(w->ev_region, s_reg));
   HT(1);
   // ---- 2. principal diabat (calculate_total_force_energy, src/ms_evb.f90:411) - enqueued, not waited for
@@ -1657,10 +1686,9 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   }
   hipLaunchKernelGGL(k_evb_env, dim3(envb, nu), dim3(256), 0, sr, w->d_counter.p + 1, w->d_cand.p, nu, d_units, w->d_tabs.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p, c->d_mol_of.p,
                      c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, w->d_Fdelta.p, n3, part_units, part_stride);
-  hipLaunchKernelGGL(k_sum_rows, dim3(nu), dim3(256), 0, sr, nu, envb, part_stride, part_units, E_units_env);
   hipLaunchKernelGGL(k_evb_special, dim3(nu), dim3(64), 0, sr, nu, d_units, w->d_tabs.p, c->d_moltypes.p, c->d_pair_par.p, c->nt,
                      c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->alpha, 2.0 * c->alpha / c->pi_sqrt, c->conv, c->pi,
-                     w->d_Fdelta.p, n3, E_units_spec);
+                     w->d_Fdelta.p, n3, E_units_spec, (const double*)part_units, envb, part_stride, E_units_env);
   HIPCHK(hipGetLastError());
   phase_end(c, PH_EVB_REAL, sr);
   stamp(c, 4, sr);
@@ -1730,7 +1758,9 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     // published from the diabat grid stream, normally the last chain to finish: the waits for the other two chains' events are then
     // already satisfied and the publish kernel starts right behind the last energy kernel (a publish on another stream starts an event hop later)
     if (c->overlap) { HIPCHK(hipStreamWaitEvent(sg, w->ev_join2, 0)); if (ncp) HIPCHK(hipStreamWaitEvent(sg, w->ev_cpl, 0)); }
-    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, ++w->seq_A);
+    const bool lin_e = linear && ngrid > 0;
+    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, ++w->seq_A,
+                       lin_e ? ngrid : 0, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid);
     HIPCHK(hipGetLastError());
     stamp(c, 10, sg);
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, sg));
@@ -1773,7 +1803,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     }
     hipLaunchKernelGGL(k_evb_recip_linear, dim3((nst + 3) / 4), dim3(256), 0, sg, nst, w->d_stencils.p, K, c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
                        c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p);
-    hipLaunchKernelGGL(k_evb_grid_energy, dim3(1), dim3(128), 0, sg, ngrid, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid);
+    if (dev_solve) hipLaunchKernelGGL(k_evb_grid_energy, dim3(1), dim3(128), 0, sg, ngrid, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid);      // (otherwise fetch A's publish kernel does it)
     HIPCHK(hipGetLastError());
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_rs, sg));      // the special atoms' forces are in the delta store
   } else if (ngrid) {

@@ -117,7 +117,7 @@ int msevb_destroy(msevb_ctx* c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   pme_teardown(c);
   DBuf<int>* ib[] = {&c->d_atype, &c->d_mol_type, &c->d_mol_natom, &c->d_mol_atoms, &c->d_mol_of, &c->d_cell_of, &c->d_perm, &c->d_cell_keys_tmp,
-                     &c->d_perm_tmp, &c->d_cell_start, &c->d_inv_perm, &c->d_tile_max, &c->d_nbr, &c->d_nbr2, &c->d_prune_mode, &c->d_ticket, &c->d_frozen, &c->d_type_sorted, &c->d_mol_sorted, &c->d_base, &c->d_splindex, &c->d_base_s};
+                     &c->d_perm_tmp, &c->d_cell_start, &c->d_inv_perm, &c->d_tile_max, &c->d_nbr, &c->d_nbr2, &c->d_prune_mode, &c->d_frozen, &c->d_type_sorted, &c->d_mol_sorted, &c->d_base, &c->d_splindex, &c->d_base_s};
   for (auto b : ib) b->release();
   DBuf<double>* db[] = {&c->d_chg, &c->d_mass, &c->d_B6, &c->d_B5, &c->d_tt, &c->d_dtt, &c->d_CB, &c->d_xyz, &c->d_vel, &c->d_force, &c->d_force_recip,
                         &c->d_xyz_store, &c->d_disp, &c->d_maxdisp, &c->d_Q, &c->d_theta, &c->d_green, &c->d_w, &c->d_dw, &c->d_uscale, &c->d_partials, &c->d_energies,

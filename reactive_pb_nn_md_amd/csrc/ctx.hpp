@@ -292,7 +292,6 @@ struct msevb_ctx {
   int fft_batch = 1;
   bool fft_own = true;           // 64^3 grids: the library's own three-kernel LDS transform + convolution (fft_lds.hip) instead of rocFFT, option fft_own
   // reductions
-  DBuf<int> d_ticket;          // k_step_refresh: ticket counter of its last-block reduction
   DBuf<double> d_partials;     // [n_slots][MAX_BLOCKS]
   DBuf<double> d_energies;     // [32]
   double* h_energies = nullptr;  // pinned

@@ -316,10 +316,8 @@ __global__ __launch_bounds__(256) void k_step_refresh(int N, const int* __restri
                                                       const int* __restrict__ atype, const int* __restrict__ mol_of, double4* __restrict__ posq, int* __restrict__ type_s,
                                                       int* __restrict__ mol_s, double* __restrict__ store, double* __restrict__ disp, BoxDev box,
                                                       double* __restrict__ F, double* __restrict__ part1, double* __restrict__ part2,
-                                                      const double4* __restrict__ posq_prune, double* __restrict__ part3, double* __restrict__ part4,
-                                                      int* __restrict__ ticket, double* __restrict__ out, double prune_delta, int* __restrict__ prune_mode) {
+                                                      const double4* __restrict__ posq_prune, double* __restrict__ part3, double* __restrict__ part4) {
   __shared__ double s1[256], s2[256];
-  __shared__ bool last;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   double nrm = 0.0, nrm_p = 0.0;
   if (k < N) {
@@ -358,55 +356,20 @@ __global__ __launch_bounds__(256) void k_step_refresh(int N, const int* __restri
     __syncthreads();
   }
   if (threadIdx.x == 0) { part1[blockIdx.x] = s1[0]; part2[blockIdx.x] = s2[0]; }
-  if (posq_prune) {
-    __syncthreads();
-    s1[threadIdx.x] = nrm_p;
-    s2[threadIdx.x] = 0.0;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-      if (threadIdx.x < st) {
-        double a1 = s1[threadIdx.x], a2 = s2[threadIdx.x], b1 = s1[threadIdx.x + st], b2 = s2[threadIdx.x + st];
-        s1[threadIdx.x] = fmax(a1, b1);
-        s2[threadIdx.x] = fmax(fmin(a1, b1), fmax(a2, b2));
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) { part3[blockIdx.x] = s1[0]; part4[blockIdx.x] = s2[0]; }
-  }
-  // the workgroup that finishes LAST reduces the per-block maxima (what k_top2_final did in a launch of its own, 4 us + a launch gap in
-  // front of the pair loop): every block publishes its partial results, then draws a ticket
-  if (threadIdx.x == 0) { __threadfence(); last = atomicAdd(ticket, 1) == (int)gridDim.x - 1; }
+  if (!posq_prune) return;
   __syncthreads();
-  if (!last) return;
-  __threadfence();
-  const int nb = gridDim.x;
-  for (int set = 0; set < (posq_prune ? 2 : 1); ++set) {
-    const volatile double* q1 = set ? part3 : part1;
-    const volatile double* q2 = set ? part4 : part2;
-    double m1 = 0, m2 = 0;
-    for (int b = threadIdx.x; b < nb; b += 256) {
-      const double b1 = q1[b], b2 = q2[b];
-      const double n1 = fmax(m1, b1), n2 = fmax(fmin(m1, b1), fmax(m2, b2));
-      m1 = n1; m2 = n2;
+  s1[threadIdx.x] = nrm_p;
+  s2[threadIdx.x] = 0.0;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+      double a1 = s1[threadIdx.x], a2 = s2[threadIdx.x], b1 = s1[threadIdx.x + st], b2 = s2[threadIdx.x + st];
+      s1[threadIdx.x] = fmax(a1, b1);
+      s2[threadIdx.x] = fmax(fmin(a1, b1), fmax(a2, b2));
     }
     __syncthreads();
-    s1[threadIdx.x] = m1; s2[threadIdx.x] = m2;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-      if (threadIdx.x < st) {
-        double a1 = s1[threadIdx.x], a2 = s2[threadIdx.x], b1 = s1[threadIdx.x + st], b2 = s2[threadIdx.x + st];
-        s1[threadIdx.x] = fmax(a1, b1);
-        s2[threadIdx.x] = fmax(fmin(a1, b1), fmax(a2, b2));
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      out[2 * set] = s1[0]; out[2 * set + 1] = s2[0];
-      // prune_mode[2]: pruned rows exist for the CURRENT full rows (cleared by nb_prune_reset, set by a pair loop that wrote them)
-      if (set == 1) { const int use = prune_mode[2] != 0 && (s1[0] + s2[0]) < prune_delta; prune_mode[0] = use ? 2 : 1; prune_mode[1] += use ? 0 : 1; }
-    }
   }
-  if (threadIdx.x == 0) *ticket = 0;
+  if (threadIdx.x == 0) { part3[blockIdx.x] = s1[0]; part4[blockIdx.x] = s2[0]; }
 }
 
 // blockIdx.x = 0: displacement since the last list build -> out[0..1] (the host's rebuild flag); blockIdx.x = 1: displacement since the
@@ -470,17 +433,15 @@ int nb_prune_reset(msevb_ctx* c) {
 // displacement check + sorted-array refresh + force zeroing of a step that keeps the current list (one kernel + the tiny top-2 finish)
 int nb_step_refresh(msevb_ctx* c) {
   const int N = c->N, nb = (N + 255) / 256;
-  if (!c->d_ticket.p) {      // ticket counter of the kernel's last-block reduction (the kernel leaves it at zero)
-    if (c->d_ticket.alloc(1)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (ticket)");
-    HIPCHK(hipMemsetAsync(c->d_ticket.p, 0, sizeof(int), c->stream));
-  }
   const bool pr = c->prune && c->d_posq_prune.p && c->d_prune_mode.p;
   static_assert(S_MAXD2 == S_MAXD1 + 1 && S_PRD1 == S_MAXD1 + 2 && S_PRD2 == S_MAXD1 + 3, "displacement slots are contiguous");
   hipLaunchKernelGGL(k_step_refresh, dim3(nb), dim3(256), 0, c->stream, N, c->d_perm.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p, c->d_mol_of.p, c->d_posq.p,
                      c->d_type_sorted.p, c->d_mol_sorted.p, c->d_xyz_store.p, c->d_disp.p, make_box(c), c->d_force.p,
                      c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS,
-                     pr ? c->d_posq_prune.p : (const double4*)nullptr, c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS,
-                     c->d_ticket.p, c->d_energies.p + S_MAXD1, c->prune_delta, c->d_prune_mode.p);
+                     pr ? c->d_posq_prune.p : (const double4*)nullptr, c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS);
+  hipLaunchKernelGGL(k_top2_final, dim3(pr ? 2 : 1), dim3(256), 0, c->stream, nb, c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS,
+                     c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS, c->d_energies.p + S_MAXD1,
+                     c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS, c->prune_delta, c->d_prune_mode.p);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
 }

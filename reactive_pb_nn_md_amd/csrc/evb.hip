@@ -1701,7 +1701,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     hipLaunchKernelGGL(k_mol_com, dim3((M + 255) / 256), dim3(256), 0, so, M, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_mass.p, w->d_com_atom.p);      // positions only
     if (c->overlap) HIPCHK(hipStreamWaitEvent(so, w->ev_fork2, 0));
     // ~1000 workgroups per launch in all: every block pays a descriptor copy, two barriers and the Zundel reductions
-    const int cpb_big = cpb, cpb_small = std::min(cpb, std::max(256, 6144 / std::max(ncp - ncp_big, 1)));      // few trips per wave: the kernels are latency-bound
+    int cpb_big = cpb, cpb_small = std::min(cpb, std::max(256, 6144 / std::max(ncp - ncp_big, 1)));      // few trips per wave: the kernels are latency-bound
+    if (c->evb_coupling_blocks > 0) { cpb_big = std::min(cpb, c->evb_coupling_blocks); cpb_small = std::min(cpb, c->evb_coupling_blocks); }
     hipLaunchKernelGGL(k_evb_coupling, dim3(std::max(cpb_big, cpb_small), ncp), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, w->d_com_atom.p, c->d_xyz.p, c->d_chg.p,
                        w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p, ncp_big, cpb_big, cpb_small);
     hipLaunchKernelGGL(k_evb_coupling_finish, dim3(ncp), dim3(64), 0, so, ncp, d_cps, w->d_exch.p, c->d_mass.p, box, c->conv, (const double*)part_cp, part_stride, ncp_big, cpb_big, cpb_small,

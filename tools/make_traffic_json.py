@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """traffic.json from a tools/profile_round.sh output directory: per-launch HBM traffic of the kernels bench.py may report as dominant
-(FETCH_SIZE and WRITE_SIZE from their own --pmc passes, KiB -> bytes, NO gfx950 x2 correction applied: the pair loop's loads are 4-B coalesced
-list reads and LDS-tile staging, not the 16-B/lane streaming pattern that correction is calibrated for - MI355X_MICROARCH.md).
+(FETCH_SIZE and WRITE_SIZE from their own --pmc passes, KiB -> bytes; FETCH_SIZE x 2 on gfx950 as MI355X_MICROARCH.md prescribes - the
+counter tallies 128-byte requests at 64 bytes.  tools/calib/ checked that on this library's own access widths: coalesced reads of 4, 8, 16
+and 32 bytes per lane all report exactly half their bytes, 32-byte gathers report 64 bytes per record, stores and fp64 atomics report
+WRITE_SIZE exactly - profiles/r02_counter_calibration.txt).
 '_build' is the sha256 of the kernel sources the numbers were measured on: bench.py reports traffic = null when its own sources differ.
     python tools/make_traffic_json.py PROF_DIR [OUT.json]"""
 import glob, hashlib, json, os, sqlite3, sys
@@ -30,9 +32,13 @@ for sub, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             if e["kernel"] != short:
                 continue
             e[key.lower() + "_bytes_per_launch"] = e.get(key.lower() + "_bytes_per_launch", 0.0) + v / n * 1024.0
+FETCH_CORRECTION = 2.0
 for e in out.values():
-    e["hbm_bytes_per_launch"] = e.get("fetch_size_bytes_per_launch", 0.0) + e.get("write_size_bytes_per_launch", 0.0)
+    e["fetch_size_raw_bytes_per_launch"] = e.get("fetch_size_bytes_per_launch", 0.0)
+    e["fetch_size_bytes_per_launch"] = FETCH_CORRECTION * e["fetch_size_raw_bytes_per_launch"]
+    e["hbm_bytes_per_launch"] = e["fetch_size_bytes_per_launch"] + e.get("write_size_bytes_per_launch", 0.0)
 out["_workload"] = {"n_atoms": 98220, "n_diabats": 8, "pme_grid": 64, "note": "bench.py default workload (configs[2])"}
+out["_fetch_correction"] = FETCH_CORRECTION
 out["_build"] = build_id()
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))

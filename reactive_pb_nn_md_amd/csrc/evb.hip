@@ -1002,9 +1002,20 @@ __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ 
 // copies two small device arrays into pinned host memory (zero-copy stores): the energy downloads, without copy commands
 // flag != nullptr: after the data, the sequence number goes to pinned memory - the host spins on it instead of sleeping on an event
 // ng > 0: first the diabats' grid energies, E_grid[g] = conv (E_lin[g] + E_quad[g] / 2), accumulators re-zeroed (k_evb_grid_energy - E_grid lies inside a)
-__global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, const double* __restrict__ b, int nb, double* __restrict__ hb,
+__global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, const double* b, int nb, double* __restrict__ hb,
                               volatile long long* flag = nullptr, long long seq = 0, int ng = 0, double* E_lin = nullptr, double* E_quad = nullptr,
-                              double conv = 0.0, double* E_grid = nullptr) {      // (a and E_grid alias: no __restrict__ on them)
+                              double conv = 0.0, double* E_grid = nullptr, const double* __restrict__ slot_part = nullptr, int n_part = 0, double* slot_out = nullptr) {      // (a and E_grid alias: no __restrict__ on them)
+  if (n_part > 0) {      // pending partial sums of ONE energy slot (the principal reciprocal energy: was a k_reduce_slots launch in front of this kernel); slot_out may be b
+    __shared__ double red[256];
+    double s0 = 0.0;
+    for (int k = threadIdx.x; k < n_part; k += blockDim.x) s0 += slot_part[k];
+    red[threadIdx.x] = s0;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+    if (threadIdx.x == 0) *slot_out = red[0];
+    __threadfence_block();
+    __syncthreads();
+  }
   if (ng > 0) {
     for (int g = threadIdx.x; g < ng; g += blockDim.x) { E_grid[g] = conv * (E_lin[g] + 0.5 * E_quad[g]); E_lin[g] = 0.0; E_quad[g] = 0.0; }
     __threadfence_block();
@@ -1738,7 +1749,9 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   // loop) is added to the eigenvalue and to the reported Hamiltonian afterwards, off the critical path.  Both downloads are kernels that
   // write into pinned host memory (no copy commands).
   auto fetch_A = [&]() -> int {      // call after everything that produces a unit / coupling / grid energy has been enqueued
-    CHK(flush_one(c, S_RECIP, sg));                              // principal reciprocal energy: its partial sums are complete on `sg`
+    const int n_recip_part = dev_solve ? 0 : c->slot_count[S_RECIP];      // principal reciprocal energy: its partial sums are complete on `sg`;
+    if (dev_solve) CHK(flush_one(c, S_RECIP, sg));                          // reduced by the publish kernel below (one launch and its gap fewer in front of the host's turn)
+    else c->slot_count[S_RECIP] = 0;
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_E, sg));
     if (dev_solve) {
       if (c->overlap) { HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0)); if (ncp) HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_cpl, 0)); }
@@ -1761,7 +1774,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     if (c->overlap) { HIPCHK(hipStreamWaitEvent(sg, w->ev_join2, 0)); if (ncp) HIPCHK(hipStreamWaitEvent(sg, w->ev_cpl, 0)); }
     const bool lin_e = linear && ngrid > 0;
     hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, ++w->seq_A,
-                       lin_e ? ngrid : 0, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid);
+                       lin_e ? ngrid : 0, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid,
+                       (const double*)(c->d_partials.p + (size_t)S_RECIP * MAX_BLOCKS), n_recip_part, c->d_energies.p + S_RECIP);
     HIPCHK(hipGetLastError());
     stamp(c, 10, sg);
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, sg));
@@ -1771,7 +1785,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     CHK(flush_reductions(c));
     if (c->overlap) {
       HIPCHK(hipEventRecord(w->ev_flush, c->stream)); HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_flush, 0));
-      HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0));      // the principal reciprocal energy slot is reduced on the diabat grid stream (fetch A)
+      HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0));      // the principal reciprocal energy slot is reduced on the diabat grid stream (fetch A) ...
+      if (!dev_solve) HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_fetchA, 0));      // ... by its publish kernel
       if (defer_mol) HIPCHK(hipStreamWaitEvent(w->stream2, c->ev_join2, 0));      // per-molecule energies (aux3)
     }
     hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, ss, c->d_energies.p, (int)N_SLOTS, c->h_energies, (const double*)nullptr, 0, (double*)nullptr,

@@ -22,6 +22,8 @@
 #include <functional>
 #include <map>
 
+#include <atomic>
+
 #include "ctx.hpp"
 #include "devmath.hpp"
 
@@ -1026,6 +1028,26 @@ __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, 
   if (flag) { __threadfence_system(); __syncthreads(); if (threadIdx.x == 0) *flag = seq; }
 }
 
+// The blend phase is enqueued BEFORE the host has the ground-state vector: this kernel, first of the phase on the main stream, waits until
+// the host has written the blend coefficients to pinned memory (sequence number behind them), then copies them to device memory for
+// the kernels behind it.  What it saves is the launch latency of the phase (~6 launches, 25-35 us) between the host's Jacobi and the
+// first blend kernel.  It always terminates: the host writes -seq on every error path (CoefGuard), and after ~5 s of wall clock the
+// kernel raises the sticky fault flag and goes on (the force call then ends in MSEVB_ERR_NUMERIC).
+__global__ void k_evb_wait_coef(const double* h_coef, volatile long long* flag, long long seq, int n, double* __restrict__ d_coef, double* __restrict__ fault) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();      // 100 MHz
+    for (;;) {
+      const long long f = *flag;
+      if (f == seq || f == -seq) break;
+      if (wall_clock64() - t0 > 500000000LL) { *fault = 1.0; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __syncthreads();
+  __threadfence_system();
+  for (int k = threadIdx.x; k < n; k += blockDim.x) d_coef[k] = ((const volatile double*)h_coef)[k];
+}
+
 // publishes the record count of k_evb_region to pinned host memory
 __global__ void k_evb_publish_count(const int* __restrict__ counter, int* __restrict__ host_count, volatile long long* flag, long long seq) {
   *host_count = *counter;
@@ -1093,6 +1115,7 @@ struct EvbWork {   // persistent device scratch of one context
   // what the last force call left behind, for msevb_evb_partial_blend on the fast path (virtual-rank tests)
   int last_ngrid = 0, last_nra = 0, last_grid_of[MAX_DIABATS]; const RecipAtom* last_d_ra = nullptr; bool last_fast = false;
   bool counters_dirty = true, dv_dirty = true, mol_deferred = false;
+  double* h_coef = nullptr; long long seq_C = 0;      // pinned: blend coefficients for k_evb_wait_coef (its flag is h_flag[3])
   bool pack_prefilled = false; hipEvent_t ev_prefill = nullptr;      // the blended charge grid starts as a copy of Q_1, made while the host waits for the energies
   std::vector<RegionRec> region, region_raw; std::vector<long long> region_key;
   std::vector<UnitDesc> units; std::vector<CouplingDesc> cps, cps_sorted; std::vector<RecipAtom> ras;      // descriptors of the current force call
@@ -1886,12 +1909,32 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     CHK(fast_blend_phase(c, w, D, nullptr, grid_of.data(), ngrid, nra, d_ra, w->d_coef.p));
     phase_end(c, PH_EVB_BLEND);
   }
+  // host-side solve, blend phase enqueued ahead of it: the phase's kernels wait on the main stream behind k_evb_wait_coef for the
+  // coefficients the host writes to pinned memory after its Jacobi (single rank, fast path)
+  const bool prelaunch = !dev_solve && fast && c->overlap && c->n_ranks == 1 && !c->nccl_comm && c->evb_prelaunch_blend;
+  struct CoefGuard { volatile long long* flag = nullptr; long long seq = 0; ~CoefGuard() { if (flag) *flag = -seq; } } coef_guard;      // any early return releases the waiting kernel
+  int n_coef = 0;
+  if (prelaunch) {
+    BlendTerms bt0;
+    (void)blend_terms(c, D, nullptr, bt0);
+    n_coef = 1 + ngrid + bt0.n;
+    if (w->d_coef.alloc(1 + MAX_DIABATS + 2 * MAX_DIABATS)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blend coefficients)");
+    if (!w->h_coef) HIPCHK(hipHostMalloc((void**)&w->h_coef, (1 + 3 * MAX_DIABATS) * sizeof(double), hipHostMallocDefault));
+    const long long seq = ++w->seq_C;
+    hipLaunchKernelGGL(k_evb_wait_coef, dim3(1), dim3(64), 0, c->stream, (const double*)w->h_coef, (volatile long long*)(w->h_flag + 3), seq, n_coef, w->d_coef.p, c->d_energies.p + S_FAULT);
+    HIPCHK(hipGetLastError());
+    coef_guard.flag = (volatile long long*)(w->h_flag + 3); coef_guard.seq = seq;
+    phase_begin(c, PH_EVB_BLEND);
+    CHK(fast_blend_phase(c, w, D, nullptr, grid_of.data(), ngrid, nra, d_ra, w->d_coef.p));
+    phase_end(c, PH_EVB_BLEND);
+  }
   HT(8);
   // ---- 9. Hamiltonian without the principal diabat's energy (H' = H - E0 I), from fetch A (or from the device-side solve)
   if (dev_solve) HIPCHK(hipEventSynchronize(w->ev_solve));
   else if (c->overlap) {
     if (spin_wait((volatile long long*)w->h_flag, w->seq_A, w->ev_fetchA)) HIPCHK(hipErrorUnknown);
   } else HIPCHK(hipStreamSynchronize(c->stream));
+  HT(7);      // (7: the wait for fetch A alone; 9: Hamiltonian assembly; 10: Jacobi + blend enqueue / coefficient hand-over; 11: principal energy, wait for fetch B, switch)
   const double E_recip1 = dev_solve ? 0.0 : w->h_E[nE];                  // this rank's own (complete) principal reciprocal energy
   const bool sharded = c->shard_principal && c->n_ranks > 1;
   const bool partial = sharded && !c->nccl_comm;       // virtual ranks (tests): the caller sums the ranks' shares
@@ -1956,8 +1999,18 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     for (int i = 1; i < D; ++i) if (ev[i] < eg) { eg = ev[i]; g = i; }
     for (int i = 0; i < D; ++i) c->eigvec[i] = v[(size_t)i * D + g];
   }
-  if (!dev_solve) phase_begin(c, PH_EVB_BLEND);
+  if (!dev_solve && !prelaunch) phase_begin(c, PH_EVB_BLEND);
   if (dev_solve) {
+  } else if (prelaunch) {      // the phase is waiting on the main stream: coefficients {c_0^2, c_d^2 per grid, blend terms} in the order k_evb_solve writes them
+    BlendTerms bt;
+    (void)blend_terms(c, D, c->eigvec, bt);
+    w->h_coef[0] = c->eigvec[0] * c->eigvec[0];
+    for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) w->h_coef[1 + grid_of[d]] = c->eigvec[d] * c->eigvec[d];
+    for (int t = 0; t < bt.n; ++t) w->h_coef[1 + ngrid + t] = bt.coef[t];
+    if (1 + ngrid + bt.n != n_coef) FAIL(MSEVB_ERR_STATE, "blend coefficient count changed between the enqueue and the solve");
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    *coef_guard.flag = coef_guard.seq;
+    coef_guard.flag = nullptr;      // released
   } else if (fast) {
     CHK(fast_blend_phase(c, w, D, c->eigvec, grid_of.data(), ngrid, nra, d_ra));
   } else {
@@ -1967,7 +2020,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   }
   HIPCHK(hipGetLastError());
   if (c->nccl_comm) CHK(msevb_comm_allreduce_forces(c));
-  if (!dev_solve) phase_end(c, PH_EVB_BLEND);
+  if (!dev_solve && !prelaunch) phase_end(c, PH_EVB_BLEND);
+  HT(10);
   {   // the blend is enqueued: now the principal energy (it shifts the whole diagonal, not the ground-state vector)
     double E0 = 0.0;
     CHK(principal_energy(E0));
@@ -1979,7 +2033,6 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   c->principal = pr; c->new_hydronium = c->hydronium;
   for (int h = 0; h < c->max_chain; ++h) { if (c->plog[pr][h][0] < 0) break; c->new_hydronium = c->plog[pr][h][3]; }
   if (epot_out) *epot_out = eg;
-  HT(10);
   // ---- 12. principal-diabat switch (src/ms_evb.f90:218-227): adopt the new topology, rebuild the Verlet list
   if (c->new_hydronium != c->hydronium) {
     c->hop_log.push_back((int)c->evb_calls); c->hop_log.push_back(c->hydronium + 1); c->hop_log.push_back(c->new_hydronium + 1);

@@ -697,6 +697,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
   if (s == "spread_mfma") { c->spread_mfma = v != 0.0; return MSEVB_OK; }
+  if (s == "evb_defer_fold") { c->evb_defer_fold = v != 0.0; return MSEVB_OK; }
   if (s == "evb_prelaunch_blend") { c->evb_prelaunch_blend = v != 0.0; return MSEVB_OK; }
   if (s == "evb_coupling_blocks") { c->evb_coupling_blocks = (int)v; return MSEVB_OK; }
   if (s == "evb_region_main") { c->evb_region_main = v != 0.0; return MSEVB_OK; }

@@ -859,9 +859,15 @@ struct BlendTerms { int n; int slot[2 * MAX_DIABATS]; double coef[2 * MAX_DIABAT
 // F = w11 F11 + sum_d c_d^2 store_d + 2 sum c_p c_d F_pd with w11 = 1 (w11 < 1 only for a rank's PARTIAL blend, see evb_partial terms);
 // F holds F11 on entry and the blended force on exit.
 // zero_diag: Fdiag is the self-cleaning delta store itself (fast path): every diagonal slot read is reset for the next step.
-__global__ void k_evb_blend(size_t n3, BlendTerms bt, const double* __restrict__ dc, double w11, double* __restrict__ Fdiag, const double* __restrict__ Foff, size_t fstride, double* __restrict__ F, int zero_diag) {
+// Fs != nullptr: the pair loop's sorted-order force accumulator (k_pair_half) has not been folded into F yet - the principal force of atom i is
+// F[3 i + d] + Fs[d N + inv_perm[i]]; the accumulator is consumed (re-zeroed) here (k_pair_fold, a launch between the pair loop and the blend
+// phase on the step's critical path, is skipped by the fast path)
+__global__ void k_evb_blend(size_t n3, BlendTerms bt, const double* __restrict__ dc, double w11, double* __restrict__ Fdiag, const double* __restrict__ Foff, size_t fstride, double* __restrict__ F, int zero_diag,
+                            double* __restrict__ Fs = nullptr, const int* __restrict__ inv_perm = nullptr, int N = 0) {
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (size_t)gridDim.x * blockDim.x) {
-    double s = w11 * F[k];
+    double f11 = F[k];
+    if (Fs) { const size_t i = k / 3, a = (k - 3 * i) * (size_t)N + inv_perm[i]; f11 += Fs[a]; Fs[a] = 0.0; }
+    double s = w11 * f11;
     for (int t = 0; t < bt.n; ++t) {
       const int sl = bt.slot[t];
       const double cf = dc ? dc[t] : bt.coef[t];      // device-resident coefficients (k_evb_solve) or kernel arguments
@@ -1329,6 +1335,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   if (w11 == 0.0) {      // replicated (not sharded) principal diabat on a rank other than 0: F11 counts on rank 0 only, the gather below adds to zero
     if (c->overlap && w->mol_deferred) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // (the per-molecule kernel still adds to it)
     HIPCHK(hipMemsetAsync(c->d_force.p, 0, n3 * 8, c->stream));
+    if (c->fsorted_pending) { HIPCHK(hipMemsetAsync(c->d_fsorted.p, 0, n3 * 8, c->stream)); c->fsorted_pending = false; }
     w11 = 1.0;
   }
   // reciprocal space of the blend in ONE gather: blended potential of this rank's diabats (+ the principal one on rank 0) ...
@@ -1375,7 +1382,9 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   if (c->overlap) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0)); if (ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_rs, 0)); }
   if (c->overlap && w->mol_deferred) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // the principal diabat's per-molecule forces (aux3, behind the coupling chain)
   (void)nra; (void)d_ra;
-  hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, dcoef ? dcoef + 1 + ngrid : (const double*)nullptr, w11, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p, 1);
+  hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, dcoef ? dcoef + 1 + ngrid : (const double*)nullptr, w11, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p, 1,
+                     c->fsorted_pending ? c->d_fsorted.p : (double*)nullptr, c->d_inv_perm.p, c->N);
+  c->fsorted_pending = false;
   stamp(c, 9, c->stream);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
@@ -1444,8 +1453,9 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   const bool defer_mol = c->overlap && c->evb_defer_molecules;
   c->defer_molecules_now = defer_mol;
   c->ev_pos_ready = w->ev_in;      // new positions: what the PME front end waits for (not for the neighbourhood kernels behind them)
+  c->defer_fold_now = fast && c->evb_defer_fold;      // the blend kernel folds the pair loop's sorted-order accumulator in (k_evb_blend)
   const int rc_tfe = total_force_enqueue(c);
-  c->shard_now = false; c->skip_gather_now = false; c->defer_molecules_now = false; c->ev_pos_ready = nullptr;
+  c->shard_now = false; c->skip_gather_now = false; c->defer_molecules_now = false; c->ev_pos_ready = nullptr; c->defer_fold_now = false;
   CHK(rc_tfe);
   HT(2);
   if (spin_wait((volatile long long*)(w->h_flag + 1), w->seq_R, w->ev_region)) HIPCHK(hipErrorUnknown);
@@ -1804,10 +1814,11 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, sg));
     return MSEVB_OK;
   };
-  auto fetch_B = [&]() -> int {      // principal energy slots + Verlet displacement flag (main stream, behind the pair loop)
-    CHK(flush_reductions(c));
-    if (c->overlap) {
+  auto fetch_B = [&]() -> int {      // principal energy slots + Verlet displacement flag (behind the pair loop)
+    if (!c->overlap) CHK(flush_reductions(c));
+    if (c->overlap) {      // the reduction of the partial sums goes to the side stream too: the main stream runs from the pair loop straight into the blend phase
       HIPCHK(hipEventRecord(w->ev_flush, c->stream)); HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_flush, 0));
+      CHK(flush_range(c, 0, N_SLOTS - 1, w->stream2));
       HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0));      // the principal reciprocal energy slot is reduced on the diabat grid stream (fetch A) ...
       if (!dev_solve) HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_fetchA, 0));      // ... by its publish kernel
       if (defer_mol) HIPCHK(hipStreamWaitEvent(w->stream2, c->ev_join2, 0));      // per-molecule energies (aux3)

@@ -128,6 +128,29 @@ def test_mfma_charge_spreading_config_B():
         assert np.abs(out[k][3] - out[0][3]).max() < 1e-8 * np.abs(out[0][3]).max() and np.abs(out[k][4] - out[0][4]).max() < 1e-8, k
 
 
+@pytest.mark.parametrize("opts", [{"evb_defer_fold": 0}, {"evb_prelaunch_blend": 1}, {"evb_defer_molecules": 1}, {"evb_region_main": 1},
+                                  {"evb_coupling_blocks": 96}, {"evb_recip_linear": 0}, {"fft_own": 0, "evb_defer_fold": 0, "evb_prelaunch_blend": 1},
+                                  {"overlap": 0, "graphs": 0}])
+def test_schedule_options_leave_the_forces_alone(opts):
+    """the switchable pieces of the step schedule at BASELINE.json configs[2]: same Hamiltonian, same Hellmann-Feynman
+    force, same 12-step trajectory as the default schedule"""
+    spec = _synthetic(32, 8, 11, 64)
+    res = []
+    for o in ({}, opts):
+        h = api.MsEvbHip(spec)
+        for k, v in o.items():
+            h.set_option(k, v)
+        e, F = h.ms_evb_calculate_total_force_energy()
+        H = h.evb_state()["H"].copy()
+        h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 7))
+        tr = h.md_integrate_atomic(12, spec.delta_t, use_evb=True)
+        res.append((e, F, H, tr, h.get_positions()))
+        h.close()
+    a, b = res
+    assert rel(b[0], a[0]) < 1e-13 and np.abs(b[1] - a[1]).max() < 1e-9 and np.abs(b[2] - a[2]).max() < 1e-9 * np.abs(a[2]).max()
+    assert np.abs(b[3] - a[3]).max() < 1e-8 * np.abs(a[3]).max() and np.abs(b[4] - a[4]).max() < 1e-8
+
+
 @pytest.mark.parametrize("stores", [0, 1])
 def test_own_lds_transform_against_rocfft_and_reference(stores):
     """csrc/fft_lds.hip (64^3 grids: three kernels for FFT . CB . IFFT, src/pme.f90:73-125) against the rocFFT path (option fft_own=0) and the

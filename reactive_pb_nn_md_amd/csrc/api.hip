@@ -702,6 +702,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "evb_coupling_blocks") { c->evb_coupling_blocks = (int)v; return MSEVB_OK; }
   if (s == "evb_region_main") { c->evb_region_main = v != 0.0; return MSEVB_OK; }
   if (s == "evb_defer_molecules") { c->evb_defer_molecules = v != 0.0; return MSEVB_OK; }
+  if (s == "pme_tile_threads") { c->pme_tile_threads = v >= 512 ? 512 : 256; c->pme_graph_key[0] = 0; if (c->pme_graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)c->pme_graph_exec); c->pme_graph_exec = nullptr; } return MSEVB_OK; }
   if (s == "fft_own") { c->fft_own = v != 0.0; return MSEVB_OK; }
   if (s == "spread_bricks") { c->spread_bricks = v != 0.0; return MSEVB_OK; }
   if (s == "evb_device_solve") { c->evb_device_solve = v != 0.0; return MSEVB_OK; }

@@ -285,6 +285,7 @@ struct msevb_ctx {
   // up and down during a run and creating a plan pair costs milliseconds (a step costs 0.6 ms)
   std::map<int, std::pair<rocfft_plan, rocfft_plan>> plans_b;
   bool spread_tiles = true;
+  int pme_tile_threads = 512;    // workgroup size of the LDS-tile spread / gather kernels (option pme_tile_threads: 256 or 512)
   bool spread_bricks = false;    // option: owner-computes charge spreading on the matrix cores (k_pme_spread_bricks): every cell's workgroup writes ITS brick of the grid, no atomics, no zero-fill
                                  // (needs bricks of <= 8 points per axis, K >= 16).  Measured 63 us alone against 55 + 4 + 5 for the LDS-atomic tiles with fill and copy, 2-3 % slower in the overlapped step: off
   bool spread_mfma = false;      // charge spreading as a per-cell contraction on the matrix cores (v_mfma_f64_16x16x4_f64), option spread_mfma

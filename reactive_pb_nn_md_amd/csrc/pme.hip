@@ -77,7 +77,7 @@ constexpr int SPREAD_CHUNK = 64;      // atoms of a cell staged in LDS at a time
 // their 216-point stencils into an LDS tile with ds_add_f64, the tile is flushed once with global fp64 atomics
 // (non-zero points only): ~20x fewer HBM atomics than one per stencil point.  Atoms that drifted out of the tile since the
 // last list build fall back to a direct global atomic.
-__global__ __launch_bounds__(256) void k_pme_spread_tiles(int K, int3 nc, int3 T, const int* __restrict__ cell_start, const int* __restrict__ perm,
+__global__ __launch_bounds__(512) void k_pme_spread_tiles(int K, int3 nc, int3 T, const int* __restrict__ cell_start, const int* __restrict__ perm,
                                                           const double* __restrict__ chg, const int* __restrict__ base, const double* __restrict__ w,
                                                           double* __restrict__ grid, int gs) {      // gs = 2: real parts of a complex grid, 1: real grid
   extern __shared__ double tile[];
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void k_pme_gather(int N, int K, const double* 
 // (same origin, size and bank-conflict padding) once, the 8-lane groups then take the cell's atoms round-robin and read their 216 taps
 // from LDS instead of gathering them from L2.  Same loops and summation order per atom as k_pme_gather (bit-identical forces); an atom
 // whose stencil left the tile since the last list build is done from global memory by the same code.
-__global__ __launch_bounds__(256) void k_pme_gather_tiles(int K, int3 nc, int3 T, const int* __restrict__ cell_start, const int* __restrict__ perm,
+__global__ __launch_bounds__(512) void k_pme_gather_tiles(int K, int3 nc, int3 T, const int* __restrict__ cell_start, const int* __restrict__ perm,
                                                           const double* __restrict__ chg, const int* __restrict__ base, const double* __restrict__ w,
                                                           const double* __restrict__ dw, const double* __restrict__ theta, double conv, double k00, double k01,
                                                           double k02, double k10, double k11, double k12, double k20, double k21, double k22,
@@ -437,12 +437,26 @@ __global__ __launch_bounds__(256) void k_pme_gather_tiles(int K, int3 nc, int3 T
   const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
   const int ox = (int)floor((double)cx * K / nc.x) - 6, oy = (int)floor((double)cy * K / nc.y) - 6, oz = (int)floor((double)cz * K / nc.z) - 6;
   const int P = T.x | 1, P2 = spread_plane_stride(T);
-  for (int r = threadIdx.x; r < T.x * T.y * T.z; r += blockDim.x) {      // stage: x fastest (coalesced rows of T.x points)
-    const int a = r % T.x, b = (r / T.x) % T.y, cc = r / (T.x * T.y);
-    int n1 = ox + a; n1 += n1 < 0 ? K : 0; n1 -= n1 >= K ? K : 0;
-    int n2 = oy + b; n2 += n2 < 0 ? K : 0; n2 -= n2 >= K ? K : 0;
-    int n3 = oz + cc; n3 += n3 < 0 ? K : 0; n3 -= n3 >= K ? K : 0;
-    tile[a + P * b + P2 * cc] = theta[n1 + (size_t)K * (n2 + (size_t)K * n3)];
+  {      // stage: x fastest (coalesced rows of T.x points); four loads in flight per thread (one per trip left the fill latency-bound: 16 dependent trips)
+    const int ntile = T.x * T.y * T.z, txy = T.x * T.y;
+    for (int r0 = threadIdx.x; r0 < ntile; r0 += 4 * blockDim.x) {
+      double v[4]; int dst[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * blockDim.x;
+        dst[u] = -1;
+        if (r < ntile) {
+          const int cc = r / txy, rem = r - cc * txy, b = rem / T.x, a = rem - b * T.x;
+          int n1 = ox + a; n1 += n1 < 0 ? K : 0; n1 -= n1 >= K ? K : 0;
+          int n2 = oy + b; n2 += n2 < 0 ? K : 0; n2 -= n2 >= K ? K : 0;
+          int n3 = oz + cc; n3 += n3 < 0 ? K : 0; n3 -= n3 >= K ? K : 0;
+          v[u] = theta[n1 + (size_t)K * (n2 + (size_t)K * n3)];
+          dst[u] = a + P * b + P2 * cc;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (dst[u] >= 0) tile[dst[u]] = v[u];
+    }
   }
   __syncthreads();
   const int s = cell_start[cidx], e = cell_start[cidx + 1];
@@ -650,7 +664,7 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
     const size_t tile_bytes = (size_t)spread_plane_stride(T) * T.z * sizeof(double);
     if (c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= c->K && T.y <= c->K && T.z <= c->K) {      // workgroup per cell, potential staged in LDS
       const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
-      hipLaunchKernelGGL(k_pme_gather_tiles, dim3(ncell), dim3(256), tile_bytes, c->stream, c->K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T, c->d_cell_start.p, c->d_perm.p,
+      hipLaunchKernelGGL(k_pme_gather_tiles, dim3(ncell), dim3(c->pme_tile_threads), tile_bytes, c->stream, c->K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T, c->d_cell_start.p, c->d_perm.p,
                          chg, c->d_base.p, c->d_w.p, c->d_dw.p, theta ? theta : c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2],
                          c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, atomic ? 1 : 0, add_lo, add_hi);
       HIPCHK(hipGetLastError());
@@ -715,7 +729,7 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
                            c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_base.p, c->d_w.p, c->d_grid.p);
       } else if (c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= K && T.y <= K && T.z <= K) {
         const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
-        hipLaunchKernelGGL(k_pme_spread_tiles, dim3(ncell), dim3(256), tile_bytes, st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T,
+        hipLaunchKernelGGL(k_pme_spread_tiles, dim3(ncell), dim3(c->pme_tile_threads), tile_bytes, st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T,
                            c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_base.p, c->d_w.p, g, gs);
       } else {
         const long nt = (long)N * 36;

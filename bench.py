@@ -13,6 +13,7 @@ Hellmann-Feynman forces: total work is fixed -> "scaling": "strong".
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import ctypes as C
 import json
 import os
@@ -28,6 +29,9 @@ from reactive_pb_nn_md_amd import api, forcefield, synth, system  # noqa: E402
 
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X fp64 vector: 256 CUs x 64 lanes x 2 x 2.4 GHz
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
+
+
+TRAFFIC_SOURCES = ("ctx.hpp", "devmath.hpp", "gather_dev.hpp", "molecule.hip", "molecule_dev.hpp", "neighbor.hip", "pair.hip", "pme.hip")      # same list in tools/make_traffic_json.py
 
 
 def algorithmic_bytes(N, K, D, D_local, half_list_entries):
@@ -286,12 +290,9 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             wl = tj.get("_workload", {})
-            import glob
-            import hashlib
-            hh = hashlib.sha256()
-            for fsrc in sorted(glob.glob(os.path.join(ROOT, "reactive_pb_nn_md_amd", "csrc", "*.h*"))):
-                hh.update(open(fsrc, "rb").read())
-            # the PMC passes are a separate (committed) measurement: only quoted when they were taken on THESE kernel sources, this workload, default options
+            hh = hashlib.sha256()      # the sources of the kernels traffic.json covers (pair loop, PME spread / gather, per-molecule terms) and of the list they read
+            for name in TRAFFIC_SOURCES:
+                hh.update(open(os.path.join(ROOT, "reactive_pb_nn_md_amd", "csrc", name), "rb").read())
             if dom in tj and world == 1 and wl.get("n_atoms") == spec.n_atom and wl.get("pme_grid") == spec.pme_grid and use_evb and not args.opt and tj.get("_build") == hh.hexdigest():
                 traffic = int(tj[dom]["hbm_bytes_per_launch"])
         except (OSError, ValueError, KeyError):

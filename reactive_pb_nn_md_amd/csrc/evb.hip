@@ -2092,6 +2092,7 @@ void evb_release(msevb_ctx* c) {
     if (w->h_desc) (void)hipHostFree(w->h_desc);
     if (w->h_solve) (void)hipHostFree(w->h_solve);
     if (w->h_flag) (void)hipHostFree(w->h_flag);
+    if (w->h_coef) (void)hipHostFree(w->h_coef);
     w->d_coef.release();
     if (w->h_E) (void)hipHostFree(w->h_E);
     delete w;

@@ -4,7 +4,7 @@
 counter tallies 128-byte requests at 64 bytes.  tools/calib/ checked that on this library's own access widths: coalesced reads of 4, 8, 16
 and 32 bytes per lane all report exactly half their bytes, 32-byte gathers report 64 bytes per record, stores and fp64 atomics report
 WRITE_SIZE exactly - profiles/r02_counter_calibration.txt).
-'_build' is the sha256 of the kernel sources the numbers were measured on: bench.py reports traffic = null when its own sources differ.
+'_build' is the sha256 of the sources of the measured kernels (TRAFFIC_SOURCES): bench.py reports traffic = null when its own sources differ.
     python tools/make_traffic_json.py PROF_DIR [OUT.json]"""
 import glob, hashlib, json, os, sqlite3, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,10 +14,13 @@ phase_of = {"k_pair_half": "real space (pair loop)", "k_pair": "real space (pair
             "k_pme_gather_tiles": "Q grid derivatives (gather)", "k_molecules": "intra-molecular (non-bonded + bonded)"}
 
 
-def build_id():
+TRAFFIC_SOURCES = ("ctx.hpp", "devmath.hpp", "gather_dev.hpp", "molecule.hip", "molecule_dev.hpp", "neighbor.hip", "pair.hip", "pme.hip")      # same list in bench.py
+
+
+def build_id():      # the sources of the kernels this file covers (pair loop, PME spread / gather, per-molecule terms) and of the list they read
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "reactive_pb_nn_md_amd", "csrc", "*.h*"))):
-        h.update(open(f, "rb").read())
+    for name in TRAFFIC_SOURCES:
+        h.update(open(os.path.join(ROOT, "reactive_pb_nn_md_amd", "csrc", name), "rb").read())
     return h.hexdigest()
 
 

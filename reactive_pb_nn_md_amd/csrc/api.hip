@@ -606,7 +606,7 @@ int total_force_enqueue(msevb_ctx* c) {
     CHK(pme_tail(c, true));                                          // main: wait for aux, gather (skipped by the EVB fast path)
     if (!c->defer_molecules_now) {
       HIPCHK(hipEventRecord(c->ev_join2, c->aux3));
-      HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
+      if (!c->skip_side_joins_now) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
     }
   } else {
     if (rebuild) CHK(nb_build_finish(c, true));
@@ -697,6 +697,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
   if (s == "spread_mfma") { c->spread_mfma = v != 0.0; return MSEVB_OK; }
+  if (s == "evb_single_join") { c->evb_single_join = v != 0.0; return MSEVB_OK; }
   if (s == "evb_defer_fold") { c->evb_defer_fold = v != 0.0; return MSEVB_OK; }
   if (s == "evb_prelaunch_blend") { c->evb_prelaunch_blend = v != 0.0; return MSEVB_OK; }
   if (s == "evb_coupling_blocks") { c->evb_coupling_blocks = (int)v; return MSEVB_OK; }

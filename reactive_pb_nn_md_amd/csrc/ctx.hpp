@@ -191,6 +191,7 @@ struct msevb_ctx {
   bool skip_gather_now = false;      // EVB fast path: the principal reciprocal force comes with the blended gather
   bool shard_principal = false;
   hipEvent_t ev_pos_ready = nullptr;      // set by the MS-EVB call around total_force_enqueue: positions of this step are final
+  bool skip_side_joins_now = false, evb_single_join = true;      // MS-EVB fast path: the main stream waits ONCE for the side streams (a barrier packet behind the pair loop costs several us each)
   bool defer_fold_now = false, fsorted_pending = false, evb_defer_fold = true;      // MS-EVB fast path: k_pair_fold's work is done by k_evb_blend
   bool evb_prelaunch_blend = false;        // option: the blend phase is enqueued before the host's Jacobi and waits on the device for its coefficients (evb.hip, k_evb_wait_coef)
   int evb_coupling_blocks = 0;            // option: workgroups per coupling in k_evb_coupling (0: the built-in choice)

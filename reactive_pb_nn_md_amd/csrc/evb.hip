@@ -1043,7 +1043,7 @@ __global__ void k_evb_wait_coef(const double* h_coef, volatile long long* flag, 
   if (threadIdx.x == 0) {
     const long long t0 = wall_clock64();      // 100 MHz
     for (;;) {
-      const long long f = *flag;
+      const long long f = __hip_atomic_load((const long long*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (fine-grained host memory: see the allocation)
       if (f == seq || f == -seq) break;
       if (wall_clock64() - t0 > 500000000LL) { *fault = 1.0; break; }
       __builtin_amdgcn_s_sleep(4);
@@ -1121,7 +1121,8 @@ struct EvbWork {   // persistent device scratch of one context
   // what the last force call left behind, for msevb_evb_partial_blend on the fast path (virtual-rank tests)
   int last_ngrid = 0, last_nra = 0, last_grid_of[MAX_DIABATS]; const RecipAtom* last_d_ra = nullptr; bool last_fast = false;
   bool counters_dirty = true, dv_dirty = true, mol_deferred = false;
-  double* h_coef = nullptr; long long seq_C = 0;      // pinned: blend coefficients for k_evb_wait_coef (its flag is h_flag[3])
+  double* h_coef = nullptr; long long seq_C = 0;      // pinned, coherent: blend coefficients for k_evb_wait_coef + its flag behind them
+  bool side_valid = false; hipEvent_t ev_side = nullptr;      // recorded on the front-end stream once it has waited for every other side chain: the ONE event the blend phase waits for
   bool pack_prefilled = false; hipEvent_t ev_prefill = nullptr;      // the blended charge grid starts as a copy of Q_1, made while the host waits for the energies
   std::vector<RegionRec> region, region_raw; std::vector<long long> region_key;
   std::vector<UnitDesc> units; std::vector<CouplingDesc> cps, cps_sorted; std::vector<RecipAtom> ras;      // descriptors of the current force call
@@ -1333,7 +1334,8 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   BlendTerms bt;
   double w11 = blend_terms(c, D, ev, bt);
   if (w11 == 0.0) {      // replicated (not sharded) principal diabat on a rank other than 0: F11 counts on rank 0 only, the gather below adds to zero
-    if (c->overlap && w->mol_deferred) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // (the per-molecule kernel still adds to it)
+    if (c->overlap && w->side_valid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0));      // (the per-molecule kernel still adds to it)
+    else if (c->overlap && w->mol_deferred) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
     HIPCHK(hipMemsetAsync(c->d_force.p, 0, n3 * 8, c->stream));
     if (c->fsorted_pending) { HIPCHK(hipMemsetAsync(c->d_fsorted.p, 0, n3 * 8, c->stream)); c->fsorted_pending = false; }
     w11 = 1.0;
@@ -1341,7 +1343,9 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   // reciprocal space of the blend in ONE gather: blended potential of this rank's diabats (+ the principal one on rank 0) ...
   GridCoefs gc; gc.n = ngrid; gc.c0 = 0.0;
   if (ev) { gc.c0 = c->rank == 0 ? ev[0] * ev[0] : 0.0; for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gc.c[grid_of[d]] = ev[d] * ev[d]; }
-  if (c->overlap && ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // convolved diabat grids / grid energies (aux)
+  const bool one_wait = c->overlap && w->side_valid;      // every side chain of this force call behind ONE event
+  if (one_wait) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0));
+  else if (c->overlap && ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // convolved diabat grids / grid energies (aux)
   stamp(c, 8, c->stream);
   if (w->d_pack.alloc(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended potential)");
   if (w->last_linear) {
@@ -1352,7 +1356,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
     } else {
       if (w->d_grids.alloc_room(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended charge grid)");
       if (fft_lds_usable(c)) {      // real grid in, real potential out, in place in d_pack (d_grids is the transform's complex work space)
-        if (w->pack_prefilled) { if (c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_prefill, 0)); }      // (went out before the host's turn)
+        if (w->pack_prefilled) { if (c->overlap && !one_wait) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_prefill, 0)); }      // (went out before the host's turn)
         else if (c->rank == 0) HIPCHK(hipMemcpyAsync(w->d_pack.p, c->d_Q.p, K3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         else HIPCHK(hipMemsetAsync(w->d_pack.p, 0, K3 * sizeof(double), c->stream));
         w->pack_prefilled = false;
@@ -1379,8 +1383,8 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   }
   // ... the special atoms' own-stencil corrections per diabat are in the delta store already (k_evb_recip_special ran at the end of the
   // diabat grid chain, before the host's turn); the blend consumes the store and re-zeroes it
-  if (c->overlap) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0)); if (ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_rs, 0)); }
-  if (c->overlap && w->mol_deferred) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // the principal diabat's per-molecule forces (aux3, behind the coupling chain)
+  if (c->overlap && !one_wait) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0)); if (ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_rs, 0)); }
+  if (c->overlap && !one_wait && w->mol_deferred) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // the principal diabat's per-molecule forces (aux3, behind the coupling chain)
   (void)nra; (void)d_ra;
   hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, dcoef ? dcoef + 1 + ngrid : (const double*)nullptr, w11, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p, 1,
                      c->fsorted_pending ? c->d_fsorted.p : (double*)nullptr, c->d_inv_perm.p, c->N);
@@ -1454,8 +1458,11 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   c->defer_molecules_now = defer_mol;
   c->ev_pos_ready = w->ev_in;      // new positions: what the PME front end waits for (not for the neighbourhood kernels behind them)
   c->defer_fold_now = fast && c->evb_defer_fold;      // the blend kernel folds the pair loop's sorted-order accumulator in (k_evb_blend)
+  const bool single_join = fast && c->overlap && c->evb_single_join && !c->evb_device_solve;      // the main stream does not wait for the side streams one by one behind the pair loop
+  c->skip_side_joins_now = single_join;
+  w->side_valid = false;
   const int rc_tfe = total_force_enqueue(c);
-  c->shard_now = false; c->skip_gather_now = false; c->defer_molecules_now = false; c->ev_pos_ready = nullptr; c->defer_fold_now = false;
+  c->shard_now = false; c->skip_gather_now = false; c->defer_molecules_now = false; c->ev_pos_ready = nullptr; c->defer_fold_now = false; c->skip_side_joins_now = false;
   CHK(rc_tfe);
   HT(2);
   if (spin_wait((volatile long long*)(w->h_flag + 1), w->seq_R, w->ev_region)) HIPCHK(hipErrorUnknown);
@@ -1821,7 +1828,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       CHK(flush_range(c, 0, N_SLOTS - 1, w->stream2));
       HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0));      // the principal reciprocal energy slot is reduced on the diabat grid stream (fetch A) ...
       if (!dev_solve) HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_fetchA, 0));      // ... by its publish kernel
-      if (defer_mol) HIPCHK(hipStreamWaitEvent(w->stream2, c->ev_join2, 0));      // per-molecule energies (aux3)
+      if (defer_mol || single_join) HIPCHK(hipStreamWaitEvent(w->stream2, c->ev_join2, 0));      // per-molecule energies (aux3)
     }
     hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, ss, c->d_energies.p, (int)N_SLOTS, c->h_energies, (const double*)nullptr, 0, (double*)nullptr,
                        (volatile long long*)(w->h_flag + 2), ++w->seq_B);
@@ -1878,6 +1885,12 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipEventRecord(w->ev_prefill, sg));
     w->pack_prefilled = true;
   } else w->pack_prefilled = false;
+  if (single_join) {      // sg has waited for the environment chain and the couplings (fetch A) and holds the front end, the grid chain and the copy itself: + the per-molecule kernel
+    if (!w->ev_side) HIPCHK(hipEventCreateWithFlags(&w->ev_side, hipEventDisableTiming));
+    HIPCHK(hipStreamWaitEvent(sg, c->ev_join2, 0));
+    HIPCHK(hipEventRecord(w->ev_side, sg));
+    w->side_valid = true;
+  }
   if (fast && ngrid && !linear) {      // own-stencil corrections of the special atoms -> delta store; behind the energy fetch on this stream: the host's turn does not wait for it
     hipLaunchKernelGGL(k_evb_recip_special, dim3((nra + 3) / 4), dim3(256), 0, sg, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, c->d_dw.p, w->d_sbase.p,
                        w->d_sw.p, w->d_sdw.p, w->d_grids.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0],
@@ -1913,7 +1926,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   // ---- 8. off-diagonal elements: few, latency-bound kernels writing only d_Foff -> side stream, beside the reciprocal space
   //         and the diagonal real-space deltas (forked in step 5b, joined here)
   HIPCHK(hipGetLastError());
-  if (ncp && c->overlap) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_cpl, 0));      // off-diagonal force stores complete
+  if (ncp && c->overlap && !single_join) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_cpl, 0));      // off-diagonal force stores complete
   if (dev_solve) {      // the blend phase goes out NOW, behind the device-side solve: no host round trip between the energies and the blend
     HIPCHK(hipStreamWaitEvent(c->stream, w->ev_solve, 0));
     phase_begin(c, PH_EVB_BLEND);
@@ -1930,11 +1943,14 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     (void)blend_terms(c, D, nullptr, bt0);
     n_coef = 1 + ngrid + bt0.n;
     if (w->d_coef.alloc(1 + MAX_DIABATS + 2 * MAX_DIABATS)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blend coefficients)");
-    if (!w->h_coef) HIPCHK(hipHostMalloc((void**)&w->h_coef, (1 + 3 * MAX_DIABATS) * sizeof(double), hipHostMallocDefault));
+    // COHERENT (fine-grained) pinned memory: a running kernel reads it uncached.  Default pinned memory may sit in the GPU's L2 until a
+    // kernel boundary - the waiting kernel then saw the host's flag ~30 us late (measured)
+    if (!w->h_coef) { HIPCHK(hipHostMalloc((void**)&w->h_coef, (2 + 3 * MAX_DIABATS) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped)); memset(w->h_coef, 0, (2 + 3 * MAX_DIABATS) * sizeof(double)); }
+    volatile long long* cflag = (volatile long long*)(w->h_coef + 1 + 3 * MAX_DIABATS);
     const long long seq = ++w->seq_C;
-    hipLaunchKernelGGL(k_evb_wait_coef, dim3(1), dim3(64), 0, c->stream, (const double*)w->h_coef, (volatile long long*)(w->h_flag + 3), seq, n_coef, w->d_coef.p, c->d_energies.p + S_FAULT);
+    hipLaunchKernelGGL(k_evb_wait_coef, dim3(1), dim3(64), 0, c->stream, (const double*)w->h_coef, cflag, seq, n_coef, w->d_coef.p, c->d_energies.p + S_FAULT);
     HIPCHK(hipGetLastError());
-    coef_guard.flag = (volatile long long*)(w->h_flag + 3); coef_guard.seq = seq;
+    coef_guard.flag = cflag; coef_guard.seq = seq;
     phase_begin(c, PH_EVB_BLEND);
     CHK(fast_blend_phase(c, w, D, nullptr, grid_of.data(), ngrid, nra, d_ra, w->d_coef.p));
     phase_end(c, PH_EVB_BLEND);
@@ -1996,6 +2012,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     for (int d = 0; d < D; ++d) if (d == 0 || owned(c, d)) c->H[d][d] += E0;
     if (epot_out) *epot_out = c->H[0][0];
     if (fast) w->delta_dirty = true;      // no blend consumed the delta store: msevb_evb_partial_blend may still, the next call re-zeroes it
+    if (c->overlap && w->side_valid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0));      // nobody else joins the side streams for this call
     rearm.ok = true;
     return MSEVB_OK;
   }
@@ -2085,7 +2102,7 @@ void evb_release(msevb_ctx* c) {
     DBuf<double>* db[] = {&w->d_exch, &w->d_part, &w->d_E, &w->d_dVspec, &w->d_sw, &w->d_sdw, &w->d_Fdelta, &w->d_F11, &w->d_pack, &w->d_com_atom};
     for (auto b : db) b->release();
     w->d_stencils.release(); w->d_Elq.release(); w->d_ow.release(); w->d_odw.release(); w->d_obase.release(); w->d_tabs.release(); w->d_sbase.release(); w->d_counter.release(); w->d_grids.release(); w->d_region.release(); w->d_cand.release(); w->d_desc.release();
-    hipEvent_t* ev[] = {&w->ev_prefill, &w->ev_pairs, &w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA, &w->ev_solve, &w->ev_rs};
+    hipEvent_t* ev[] = {&w->ev_side, &w->ev_prefill, &w->ev_pairs, &w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA, &w->ev_solve, &w->ev_rs};
     for (auto e : ev) if (*e) (void)hipEventDestroy(*e);
     if (w->h_region) (void)hipHostFree(w->h_region);
     if (w->h_count) (void)hipHostFree(w->h_count);

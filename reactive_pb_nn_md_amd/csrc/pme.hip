@@ -769,7 +769,7 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
 
 // tail on the main stream: wait for the front end, gather (atomic adds when other force kernels may still be running)
 int pme_tail(msevb_ctx* c, bool join_aux) {
-  if (join_aux) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  if (join_aux && !c->skip_side_joins_now) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));      // (MS-EVB fast path: ONE wait for all side streams in front of the blend phase)
   if (c->skip_gather_now) return MSEVB_OK;      // EVB fast path: the reciprocal force comes with the gather of the blended potential
   phase_begin(c, PH_GATHER);
   CHK(pme_gather(c, c->d_grid.p, c->d_chg.p, c->d_force_recip.p, c->d_force.p, join_aux));

@@ -451,28 +451,42 @@ __global__ void k_mol_com(int M, const int* __restrict__ mol_natom, const int* _
 
 // ---- off-diagonal element -------------------------------------------------------------------------------------------------
 // exchange-charge Coulomb sum over all NON-special molecules (evb_diabatic_coupling_electrostatics, src/ms_evb.f90:1276).
-// lane = (atom j, Zundel atom q): QL q-lanes x 64/QL atoms per wavefront trip.  Every lane evaluates ONE pair; the force on atom j is the
-// butterfly sum over its 16 q-lanes (lanes q = 0..2 store x,y,z: the atoms of a trip are consecutive, so the store is contiguous), the
-// force on Zundel atom q accumulates per lane over the trips and is reduced over the 4 atom-lanes at the end.  No private arrays: the
-// thread-per-atom version kept 16 x 3 Zundel accumulators in scratch memory (dynamic indexing) and ran 4x longer.  The minimum image is
-// taken per molecule, relative to the Zundel centre of mass, with the molecular centres of mass precomputed per atom by k_mol_com.
-template <int QL>      // q-lanes per atom: 8 when every coupling has <= 8 Zundel atoms (water / hydronium), else 16
-__device__ __forceinline__ void evb_coupling_body(int N, int n_cp, const CouplingDesc* __restrict__ cps, const int* __restrict__ mol_of,
-                                                  const double* __restrict__ com_atom, const double* __restrict__ xyz, const double* __restrict__ chg,
-                                                  const double* __restrict__ exch_atomic,
-                                                  BoxDev box, double conv, double* __restrict__ Foff, size_t fstride, double* __restrict__ part,
-                                                  int part_stride, double* __restrict__ dVspec, int ic0, int nbx) {
-  constexpr int APW = 64 / QL;      // atoms per wavefront trip
+// The minimum image is taken per molecule, relative to the Zundel centre of mass, with the molecular centres of mass precomputed per atom by
+// k_mol_com.  QL = 8 when the coupling has <= 8 Zundel atoms (water / hydronium), else 16.
+// sum over the 16 lanes of each DPP row, left in every lane of the row (the pair kernel's row_sum16: four cross-lane moves inside the VALU, no
+// ds_bpermute through the LDS pipe)
+template <int CTRL>
+__device__ __forceinline__ double evb_dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double evb_row_sum16(double v) {
+  v += evb_dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += evb_dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += evb_dpp_mov<0x141>(v);      // row_half_mirror
+  v += evb_dpp_mov<0x140>(v);      // row_mirror
+  return v;
+}
+
+// ONE THREAD PER ATOM: the thread takes the minimum image and the "special molecule" test once per atom (round 2's first version, a lane per
+// (atom, Zundel atom) pair, repeated them on every lane: 52 us alone against 47), then walks the coupling's Zundel atoms (positions and exchange charges broadcast from LDS) with the
+// loop unrolled, so that the QL x 3 Zundel-force accumulators are registers; they are reduced over the workgroup once, at the end.
+template <int QL>
+__device__ __forceinline__ void evb_coupling_body_atoms(int N, int n_cp, const CouplingDesc* __restrict__ cps, const int* __restrict__ mol_of,
+                                                        const double* __restrict__ com_atom, const double* __restrict__ xyz, const double* __restrict__ chg,
+                                                        const double* __restrict__ exch_atomic,
+                                                        BoxDev box, double conv, double* __restrict__ Foff, size_t fstride, double* __restrict__ part,
+                                                        int part_stride, double* __restrict__ dVspec, int ic0, int nbx) {
   __shared__ CouplingDesc cp;
-  __shared__ double sF[MAX_SPEC][3];
-  __shared__ double red[256];
-  __shared__ double zx[QL][3], zq[QL];                      // Zundel atoms: image next to the Zundel centre, exchange charge
+  __shared__ double zx[QL][3], zq[QL];
   __shared__ int zspec[QL];
+  __shared__ double red[QL * 3 + 1];
   const int ic = ic0 + blockIdx.y;
   {
     const int* src = (const int*)&cps[ic]; int* dst = (int*)&cp;
     for (int k = threadIdx.x; k < (int)(sizeof(CouplingDesc) / 4); k += blockDim.x) dst[k] = src[k];
-    for (int k = threadIdx.x; k < MAX_SPEC * 3; k += blockDim.x) (&sF[0][0])[k] = 0.0;
+    for (int k = threadIdx.x; k < QL * 3 + 1; k += blockDim.x) red[k] = 0.0;
   }
   __syncthreads();
   const int nz = cp.nD + cp.nA;
@@ -486,50 +500,59 @@ __device__ __forceinline__ void evb_coupling_body(int N, int n_cp, const Couplin
       for (int d = 0; d < 3; ++d) zx[q][d] = cp.zc[d] + (a.x[d] - cp.zc[d] - shm[d]);
       zq[q] = (acc && q == nz - 1) ? cp.q_transfer : exch_atomic[a.type];
       zspec[q] = sp;
-    } else { zx[q][0] = zx[q][1] = zx[q][2] = 0.0; zq[q] = 0.0; zspec[q] = 0; }
+    } else { zx[q][0] = zx[q][1] = zx[q][2] = 0.0; zq[q] = 0.0; zspec[q] = 0; }      // a zero charge: the padded q contribute exact zeros
   }
   __syncthreads();
   double* F = Foff + (size_t)cp.slot * fstride;
-  const int lane = threadIdx.x & 63, q = lane & (QL - 1), js = lane / QL;
-  const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = nbx * (blockDim.x >> 6);
-  const bool qlive = q < nz;
-  const double zxq[3] = {zx[q][0], zx[q][1], zx[q][2]}, zqq = zq[q];
-  double vex = 0.0, fzx = 0.0, fzy = 0.0, fzz = 0.0;
-  for (int j0 = wave_g * APW; j0 < N; j0 += n_waves * APW) {      // wave-uniform trip count
-    const int j = j0 + js;
-    double fx = 0.0, fy = 0.0, fz = 0.0;
-    bool special = j >= N;
-    const int m = special ? 0 : mol_of[j];
+  double fz[QL][3];
+#pragma unroll
+  for (int q = 0; q < QL; ++q) fz[q][0] = fz[q][1] = fz[q][2] = 0.0;
+  double vex = 0.0;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += nbx * blockDim.x) {
+    const int m = mol_of[j];
+    bool special = false;
     for (int k = 0; k < cp.n_mols; ++k) special |= (cp.mols[k] == m);
-    if (!special && qlive) {
-      double rij[3];
-      for (int d = 0; d < 3; ++d) {
-        const double sh = floor((com_atom[3 * j + d] - cp.zc[d]) * box.invL[d] + 0.5) * box.L[d];
-        rij[d] = -(xyz[3 * j + d] - zxq[d] - sh);
+    double fx = 0.0, fy = 0.0, fz_ = 0.0;
+    if (!special) {
+      double xs[3];
+      for (int d = 0; d < 3; ++d) xs[d] = xyz[3 * j + d] - floor((com_atom[3 * j + d] - cp.zc[d]) * box.invL[d] + 0.5) * box.L[d];
+      const double qj = chg[j] * conv;
+#pragma unroll
+      for (int q = 0; q < QL; ++q) {
+        if (q >= nz) break;      // (uniform)
+        const double r0 = -(xs[0] - zx[q][0]), r1 = -(xs[1] - zx[q][1]), r2c = -(xs[2] - zx[q][2]);
+        const double r2 = r0 * r0 + r1 * r1 + r2c * r2c;
+        double r, inv_r;
+        sqrt_rsqrt(r2, r, inv_r);
+        const double qq = zq[q] * qj * inv_r;
+        vex += qq;
+        const double g = qq * inv_r * inv_r;      // = -(-qq / r^2)
+        const double f0 = g * r0, f1 = g * r1, f2 = g * r2c;
+        fx += f0; fy += f1; fz_ += f2;
+        fz[q][0] -= f0; fz[q][1] -= f1; fz[q][2] -= f2;
       }
-      const double r2 = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2];
-      double r, inv_r;
-      sqrt_rsqrt(r2, r, inv_r);                     // one v_rsq_f64 + two Newton steps instead of an IEEE sqrt and two divisions
-      const double qq = zqq * chg[j] * conv * inv_r;
-      vex += qq;
-      const double g = -qq * inv_r * inv_r;
-      fx = -g * rij[0]; fy = -g * rij[1]; fz = -g * rij[2];
-      fzx -= fx; fzy -= fy; fzz -= fz;
     }
-#pragma unroll
-    for (int o = 1; o < QL; o <<= 1) { fx += __shfl_xor(fx, o, 64); fy += __shfl_xor(fy, o, 64); fz += __shfl_xor(fz, o, 64); }
-    // dVex of atom j (0 for special atoms: k_evb_coupling_finish assigns them); the factor -A goes into the blend coefficient
-    if (j < N && q < 3) F[3 * (size_t)j + q] = q == 0 ? fx : q == 1 ? fy : fz;
+    F[3 * (size_t)j] = fx; F[3 * (size_t)j + 1] = fy; F[3 * (size_t)j + 2] = fz_;      // dVex of atom j (0 for special atoms: k_evb_coupling_finish assigns them)
   }
-  // forces on the Zundel atoms: sum over the atom-lanes of the wave, one LDS add per (wave, q, component)
+  // workgroup sums of the Zundel forces and of Vex: DPP row sums, then one LDS add per 16-lane row
+  const int lane = threadIdx.x & 63;
 #pragma unroll
-  for (int o = QL; o < 64; o <<= 1) { fzx += __shfl_xor(fzx, o, 64); fzy += __shfl_xor(fzy, o, 64); fzz += __shfl_xor(fzz, o, 64); }
-  if (js == 0 && qlive) { atomicAdd(&sF[zspec[q]][0], fzx); atomicAdd(&sF[zspec[q]][1], fzy); atomicAdd(&sF[zspec[q]][2], fzz); }
-  red[threadIdx.x] = vex;
+  for (int q = 0; q < QL; ++q)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const double v = evb_row_sum16(fz[q][d]);
+      if ((lane & 15) == 0 && q < nz) atomicAdd(&red[3 * q + d], v);
+    }
+  {
+    const double v = evb_row_sum16(vex);
+    if ((lane & 15) == 0) atomicAdd(&red[QL * 3], v);
+  }
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
-  if (threadIdx.x == 0) part[(size_t)ic * part_stride + blockIdx.x] = red[0];
-  for (int k = threadIdx.x; k < cp.n_spec * 3; k += blockDim.x) { const double v = sF[k / 3][k % 3]; if (v != 0.0) atomicAdd(&dVspec[((size_t)ic * CPL_BINS + (blockIdx.x % CPL_BINS)) * MAX_SPEC * 3 + k], v); }
+  if (threadIdx.x == 0) part[(size_t)ic * part_stride + blockIdx.x] = red[QL * 3];
+  for (int k = threadIdx.x; k < nz * 3; k += blockDim.x) {
+    const double v = red[k];
+    if (v != 0.0) atomicAdd(&dVspec[((size_t)ic * CPL_BINS + (blockIdx.x % CPL_BINS)) * MAX_SPEC * 3 + 3 * zspec[k / 3] + k % 3], v);
+  }
 }
 // ONE launch for all couplings of a step: blockIdx.y < n_big -> the 16-lane body (the acid's coupling), else the 8-lane one; launched one
 // behind the other they cost 15 + 36 us of a latency-bound chain the host's turn waits for.  nb_big / nb_small workgroups per coupling.
@@ -540,10 +563,10 @@ __global__ __launch_bounds__(256) void k_evb_coupling(int N, int n_cp, const Cou
                                                       int part_stride, double* __restrict__ dVspec, int n_big, int nb_big, int nb_small) {
   if ((int)blockIdx.y < n_big) {
     if ((int)blockIdx.x >= nb_big) return;
-    evb_coupling_body<16>(N, n_cp, cps, mol_of, com_atom, xyz, chg, exch_atomic, box, conv, Foff, fstride, part, part_stride, dVspec, 0, nb_big);
+    evb_coupling_body_atoms<16>(N, n_cp, cps, mol_of, com_atom, xyz, chg, exch_atomic, box, conv, Foff, fstride, part, part_stride, dVspec, 0, nb_big);
   } else {
     if ((int)blockIdx.x >= nb_small) return;
-    evb_coupling_body<8>(N, n_cp, cps, mol_of, com_atom, xyz, chg, exch_atomic, box, conv, Foff, fstride, part, part_stride, dVspec, 0, nb_small);
+    evb_coupling_body_atoms<8>(N, n_cp, cps, mol_of, com_atom, xyz, chg, exch_atomic, box, conv, Foff, fstride, part, part_stride, dVspec, 0, nb_small);
   }
 }
 
@@ -1753,6 +1776,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     if (c->overlap) HIPCHK(hipStreamWaitEvent(so, w->ev_fork2, 0));
     // ~1000 workgroups per launch in all: every block pays a descriptor copy, two barriers and the Zundel reductions
     int cpb_big = cpb, cpb_small = std::min(cpb, std::max(256, 6144 / std::max(ncp - ncp_big, 1)));      // few trips per wave: the kernels are latency-bound
+    cpb_big = cpb_small = std::min(cpb, std::max(32, (N + 1023) / 1024));      // thread per atom: ~4 atoms per thread, so that the final workgroup reductions are amortised
     if (c->evb_coupling_blocks > 0) { cpb_big = std::min(cpb, c->evb_coupling_blocks); cpb_small = std::min(cpb, c->evb_coupling_blocks); }
     hipLaunchKernelGGL(k_evb_coupling, dim3(std::max(cpb_big, cpb_small), ncp), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, w->d_com_atom.p, c->d_xyz.p, c->d_chg.p,
                        w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p, ncp_big, cpb_big, cpb_small);

@@ -115,6 +115,7 @@ int msevb_destroy(msevb_ctx* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_fork0) (void)hipEventDestroy(c->ev_fork0);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_refresh) (void)hipEventDestroy(c->ev_refresh);
   pme_teardown(c);
   DBuf<int>* ib[] = {&c->d_atype, &c->d_mol_type, &c->d_mol_natom, &c->d_mol_atoms, &c->d_mol_of, &c->d_cell_of, &c->d_perm, &c->d_cell_keys_tmp,
                      &c->d_perm_tmp, &c->d_cell_start, &c->d_inv_perm, &c->d_tile_max, &c->d_nbr, &c->d_nbr2, &c->d_prune_mode, &c->d_frozen, &c->d_type_sorted, &c->d_mol_sorted, &c->d_base, &c->d_splindex, &c->d_base_s};
@@ -592,6 +593,12 @@ int total_force_enqueue(msevb_ctx* c) {
   if (rebuild) {      // cells + sorted arrays now; the rows are filled below, beside what only needs the cells
     CHK(nb_build_begin(c)); c->flag_verlet_list = 0;
     HIPCHK(hipMemsetAsync(c->d_force.p, 0, 3 * (size_t)c->N * 8, c->stream));
+  } else if (c->refresh_side_now && c->overlap && c->ev_pos_ready) {      // beside the neighbourhood kernel, which holds the main stream right now
+    if (!c->ev_refresh) HIPCHK(hipEventCreateWithFlags(&c->ev_refresh, hipEventDisableTiming));
+    HIPCHK(hipStreamWaitEvent(c->aux3, c->ev_pos_ready, 0));
+    CHK(nb_step_refresh(c, c->aux3));
+    HIPCHK(hipEventRecord(c->ev_refresh, c->aux3));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_refresh, 0));
   } else CHK(nb_step_refresh(c));
   if (c->overlap) {     // independent chains, all adding to the force with fp64 atomics
     HIPCHK(aux_fork(c));

@@ -191,6 +191,7 @@ struct msevb_ctx {
   bool skip_gather_now = false;      // EVB fast path: the principal reciprocal force comes with the blended gather
   bool shard_principal = false;
   hipEvent_t ev_pos_ready = nullptr;      // set by the MS-EVB call around total_force_enqueue: positions of this step are final
+  bool refresh_side_now = false; hipEvent_t ev_refresh = nullptr;      // MS-EVB call with the neighbourhood kernel on the main stream: the refresh kernels run beside it on aux3
   bool skip_side_joins_now = false, evb_single_join = true;      // MS-EVB fast path: the main stream waits ONCE for the side streams (a barrier packet behind the pair loop costs several us each)
   bool defer_fold_now = false, fsorted_pending = false, evb_defer_fold = true;      // MS-EVB fast path: k_pair_fold's work is done by k_evb_blend
   bool evb_prelaunch_blend = false;        // option: the blend phase is enqueued before the host's Jacobi and waits on the device for its coefficients (evb.hip, k_evb_wait_coef)
@@ -356,7 +357,7 @@ extern "C" int msevb_comm_allreduce_forces(msevb_ctx* c);   // comm.hip
 void evb_release(msevb_ctx* c);        // evb.hip: per-context EVB scratch
 extern "C" void msevb_comm_release(msevb_ctx* c);   // comm.hip: destroys the RCCL communicator, if any
 int flush_one(msevb_ctx* c, int slot, hipStream_t st);      // api.hip
-int nb_step_refresh(msevb_ctx* c);      // refresh + displacement check + zero forces (neighbor.hip)
+int nb_step_refresh(msevb_ctx* c, hipStream_t st = nullptr);      // refresh + displacement check + zero forces (neighbor.hip)
 int nb_check_displacements(msevb_ctx* c, int initialize, int* flag);
 int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw);              // pair.hip
 int molecule_forces(msevb_ctx* c, int slot0, bool do_nb, bool do_bonded, hipStream_t st = nullptr);  // molecule.hip

@@ -1483,9 +1483,10 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   c->defer_fold_now = fast && c->evb_defer_fold;      // the blend kernel folds the pair loop's sorted-order accumulator in (k_evb_blend)
   const bool single_join = fast && c->overlap && c->evb_single_join && !c->evb_device_solve;      // the main stream does not wait for the side streams one by one behind the pair loop
   c->skip_side_joins_now = single_join;
+  c->refresh_side_now = c->overlap && c->evb_region_main;
   w->side_valid = false;
   const int rc_tfe = total_force_enqueue(c);
-  c->shard_now = false; c->skip_gather_now = false; c->defer_molecules_now = false; c->ev_pos_ready = nullptr; c->defer_fold_now = false; c->skip_side_joins_now = false;
+  c->shard_now = false; c->skip_gather_now = false; c->defer_molecules_now = false; c->ev_pos_ready = nullptr; c->defer_fold_now = false; c->skip_side_joins_now = false; c->refresh_side_now = false;
   CHK(rc_tfe);
   HT(2);
   if (spin_wait((volatile long long*)(w->h_flag + 1), w->seq_R, w->ev_region)) HIPCHK(hipErrorUnknown);

@@ -431,15 +431,16 @@ int nb_prune_reset(msevb_ctx* c) {
 }
 
 // displacement check + sorted-array refresh + force zeroing of a step that keeps the current list (one kernel + the tiny top-2 finish)
-int nb_step_refresh(msevb_ctx* c) {
+int nb_step_refresh(msevb_ctx* c, hipStream_t st) {
+  if (!st) st = c->stream;
   const int N = c->N, nb = (N + 255) / 256;
   const bool pr = c->prune && c->d_posq_prune.p && c->d_prune_mode.p;
   static_assert(S_MAXD2 == S_MAXD1 + 1 && S_PRD1 == S_MAXD1 + 2 && S_PRD2 == S_MAXD1 + 3, "displacement slots are contiguous");
-  hipLaunchKernelGGL(k_step_refresh, dim3(nb), dim3(256), 0, c->stream, N, c->d_perm.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p, c->d_mol_of.p, c->d_posq.p,
+  hipLaunchKernelGGL(k_step_refresh, dim3(nb), dim3(256), 0, st, N, c->d_perm.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p, c->d_mol_of.p, c->d_posq.p,
                      c->d_type_sorted.p, c->d_mol_sorted.p, c->d_xyz_store.p, c->d_disp.p, make_box(c), c->d_force.p,
                      c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS,
                      pr ? c->d_posq_prune.p : (const double4*)nullptr, c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS);
-  hipLaunchKernelGGL(k_top2_final, dim3(pr ? 2 : 1), dim3(256), 0, c->stream, nb, c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS,
+  hipLaunchKernelGGL(k_top2_final, dim3(pr ? 2 : 1), dim3(256), 0, st, nb, c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS,
                      c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS, c->d_energies.p + S_MAXD1,
                      c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS, c->prune_delta, c->d_prune_mode.p);
   HIPCHK(hipGetLastError());

@@ -6,7 +6,6 @@
 
 #include "ctx.hpp"
 
-static inline int slots_per_rank(const msevb_ctx* c, int D) { return D <= 1 ? 0 : (D - 1 + c->n_ranks - 1) / c->n_ranks; }
 
 // The payload of the per-step all-gather starts and ends on the host (the Hamiltonian entries are assembled there from the published
 // energies, the gathered ones feed the host's Jacobi).  No copy commands and no stream synchronisation around the collective: a kernel

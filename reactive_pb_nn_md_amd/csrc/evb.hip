@@ -1077,13 +1077,6 @@ __global__ void k_evb_wait_coef(const double* h_coef, volatile long long* flag, 
   for (int k = threadIdx.x; k < n; k += blockDim.x) d_coef[k] = ((const volatile double*)h_coef)[k];
 }
 
-// publishes the record count of k_evb_region to pinned host memory
-__global__ void k_evb_publish_count(const int* __restrict__ counter, int* __restrict__ host_count, volatile long long* flag, long long seq) {
-  *host_count = *counter;
-  __threadfence_system();      // the records k_evb_region wrote to pinned memory on this stream are visible before the flag
-  *flag = seq;
-}
-
 __global__ void k_sum_rows(int nrow, int ncol, int stride, const double* __restrict__ part, double* __restrict__ out) {
   const int r = blockIdx.x;
   __shared__ double red[256];

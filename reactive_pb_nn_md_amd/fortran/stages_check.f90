@@ -1,0 +1,112 @@
+!==============================================================================
+! Test program (built by `make link_check` in the dev container, run by tests/test_gpu_fortran.py on the GPU box):
+! the reference's OWN stage procedures on the CPU against the GPU-backed procedures of the same name and argument list in module
+! msevb_hip_stages (reactive_pb_nn_md_amd/fortran/msevb_hip_stages.f90), in ONE process, on the data structures the reference's
+! start-up sequence builds from the input files:
+!   construct_verlet_list + real_space_energy_force   src/general_routines.f90:1339, src/pair_int_real_space.f90:60
+!   pme_reciprocal_space_energy_force (+ Q_grid, theta_conv_Q, E_recip left in PME_data)   src/pme.f90:28
+!   grid_Q / derivative_grid_Q                        src/pme.f90:184, :346
+!   intra_molecular_energy_force                      src/intra_bonded_interactions.f90:17
+!   md_integrate_atomic (one NVE step)                src/md_integration.f90:438
+! (the reference's FFT calls land in libmsevb_dfti.so, its spreading, gather, pair loop and bonded terms run on the CPU).
+! Prints one line per stage: "stage <name> dF <max force deviation> dE <max energy deviation> ...".
+! usage: stages_check gro ffpmt top simpmt traj log hop a   (the reference's eight arguments)
+!==============================================================================
+program stages_check
+  use routines, ref_construct_verlet_list => construct_verlet_list, ref_update_verlet_displacements => update_verlet_displacements
+  use global_variables
+  use simulation_parameters
+  use initialize_routines
+  use pair_int_real_space, only : ref_real_space => real_space_energy_force
+  use pme_routines, only : ref_pme => pme_reciprocal_space_energy_force, ref_grid_Q => grid_Q, ref_derivative_grid_Q => derivative_grid_Q
+  use bonded_interactions, only : ref_bonded => intra_molecular_energy_force
+  use md_integration, only : ref_md_integrate_atomic => md_integrate_atomic
+  use msevb_hip_stages, only : gpu_construct_verlet_list => construct_verlet_list, gpu_real_space => real_space_energy_force, &
+       gpu_pme => pme_reciprocal_space_energy_force, gpu_grid_Q => grid_Q, gpu_derivative_grid_Q_all => derivative_grid_Q_all, &
+       gpu_bonded => intra_molecular_energy_force, gpu_md_integrate_atomic => md_integrate_atomic
+  implicit none
+
+  Type(system_data_type)                               :: system_data
+  Type(molecule_data_type), dimension(:), allocatable  :: molecule_data
+  Type(atom_data_type)                                 :: atom_data
+  Type(integrator_data_type)                           :: integrator_data
+  Type(file_io_data_type)                              :: file_io_data
+  Type(verlet_list_data_type)                          :: verlet_list_data
+  Type(PME_data_type)                                  :: PME_data
+
+  integer :: N, K, i
+  real*8, allocatable :: f_ref(:,:), Q_ref(:,:,:), th_ref(:,:,:), xyz_scale(:,:), f_one(:,:), x0(:,:), v0(:,:), f0(:,:), x_ref(:,:), v_ref(:,:)
+  real*8 :: e1, e2, e3, kk(3,3), force(3), dmax
+
+  !----- start-up, as src/main_ms_evb.f90:37-84 (restart logic bypassed); the force call inside initialize_energy_force is the GPU one
+  call initialize_constants( file_io_data , verlet_list_data , PME_data )
+  call sort_input_files( file_io_data )
+  restart_trajectory = "no"
+  n_old_trajectory = 0
+  trajectory_step = 0
+  call read_simulation_parameters( file_io_data%ifile_simpmt_file_h, file_io_data%ifile_simpmt, system_data, integrator_data, verlet_list_data, PME_data )
+  call initialize_simulation( system_data, molecule_data, atom_data, file_io_data, verlet_list_data, PME_data )
+  open( file_io_data%ofile_traj_file_h, file=file_io_data%ofile_traj, status='replace' )
+  open( file_io_data%ofile_log_file_h,  file=file_io_data%ofile_log, status='replace' )
+  call initialize_energy_force( system_data, molecule_data, atom_data, verlet_list_data, PME_data, file_io_data, integrator_data )
+
+  N = system_data%total_atoms
+  K = PME_data%pme_grid
+  allocate(f_ref(3,N), Q_ref(K,K,K), th_ref(K,K,K), xyz_scale(3,N), f_one(3,N), x0(3,N), v0(3,N), f0(3,N), x_ref(3,N), v_ref(3,N))
+
+  !----- 1. Verlet list + real space
+  call ref_construct_verlet_list( verlet_list_data, atom_data, molecule_data, N, system_data%box, system_data%xyz_to_box_transform )
+  atom_data%force = 0d0; system_data%E_elec = 0d0; system_data%E_vdw = 0d0
+  call ref_real_space( system_data, molecule_data, atom_data, verlet_list_data, PME_data )
+  f_ref = atom_data%force(:,1:N); e1 = system_data%E_elec; e2 = system_data%E_vdw
+  call gpu_construct_verlet_list( verlet_list_data, atom_data, molecule_data, N, system_data%box, system_data%xyz_to_box_transform )
+  atom_data%force = 0d0; system_data%E_elec = 0d0; system_data%E_vdw = 0d0
+  call gpu_real_space( system_data, molecule_data, atom_data, verlet_list_data, PME_data )
+  write(*,'(A,4ES12.4)') "stage real_space dF dE", maxval(abs(atom_data%force(:,1:N) - f_ref)), max(abs(system_data%E_elec - e1), abs(system_data%E_vdw - e2)), e1, e2
+
+  !----- 2. reciprocal space
+  atom_data%force = 0d0; system_data%E_elec = 0d0
+  call ref_pme( system_data, atom_data, PME_data )
+  f_ref = atom_data%force(:,1:N); e1 = PME_data%E_recip; Q_ref = PME_data%Q_grid; th_ref = PME_data%theta_conv_Q
+  atom_data%force = 0d0; system_data%E_elec = 0d0
+  call gpu_pme( system_data, atom_data, PME_data )
+  write(*,'(A,5ES12.4)') "stage pme dF dE dQ dtheta", maxval(abs(atom_data%force(:,1:N) - f_ref)), abs(PME_data%E_recip - e1), &
+       maxval(abs(PME_data%Q_grid - Q_ref)), maxval(abs(PME_data%theta_conv_Q - th_ref)), e1
+
+  !----- 3. grid_Q and derivative_grid_Q at the reference's own granularity (scaled coordinates in, one atom per reference call)
+  call construct_reciprocal_lattice_vector(kk, system_data%box)
+  call create_scaled_direct_coordinates(xyz_scale, atom_data%xyz, N, kk, K)
+  call ref_grid_Q(Q_ref, atom_data%charge, xyz_scale, PME_data)
+  call gpu_grid_Q(PME_data%Q_grid, atom_data%charge, xyz_scale, PME_data)
+  dmax = maxval(abs(PME_data%Q_grid - Q_ref))
+  do i = 1, N
+     call ref_derivative_grid_Q(force, th_ref, atom_data%charge, xyz_scale, i, PME_data, kk, constants%conv_e2A_kJmol, 0)
+     f_ref(:,i) = force
+  end do
+  call gpu_derivative_grid_Q_all(f_one, th_ref, atom_data%charge, xyz_scale, PME_data, kk, constants%conv_e2A_kJmol)
+  write(*,'(A,2ES12.4)') "stage grid_Q_derivative dF dQ", maxval(abs(f_one - f_ref)), dmax
+
+  !----- 4. bonded
+  atom_data%force = 0d0; system_data%E_bond = 0d0; system_data%E_angle = 0d0; system_data%E_dihedral = 0d0
+  call ref_bonded( system_data, molecule_data, atom_data )
+  f_ref = atom_data%force(:,1:N); e1 = system_data%E_bond; e2 = system_data%E_angle; e3 = system_data%E_dihedral
+  atom_data%force = 0d0; system_data%E_bond = 0d0; system_data%E_angle = 0d0; system_data%E_dihedral = 0d0
+  call gpu_bonded( system_data, molecule_data, atom_data )
+  write(*,'(A,5ES12.4)') "stage bonded dF dE", maxval(abs(atom_data%force(:,1:N) - f_ref)), &
+       max(abs(system_data%E_bond - e1), abs(system_data%E_angle - e2), abs(system_data%E_dihedral - e3)), e1, e2, e3
+
+  !----- 5. one velocity-Verlet step: the reference's integrator (its force call is the GPU module) against the device-resident one
+  atom_data%force = 0d0; system_data%E_elec = 0d0; system_data%E_vdw = 0d0; system_data%E_bond = 0d0; system_data%E_angle = 0d0; system_data%E_dihedral = 0d0
+  call gpu_real_space( system_data, molecule_data, atom_data, verlet_list_data, PME_data )
+  call gpu_pme( system_data, atom_data, PME_data )
+  call gpu_bonded( system_data, molecule_data, atom_data )
+  x0 = atom_data%xyz(:,1:N); v0 = atom_data%velocity(:,1:N); f0 = atom_data%force(:,1:N)
+  call ref_md_integrate_atomic( system_data, molecule_data, atom_data, integrator_data, verlet_list_data, PME_data, file_io_data )
+  x_ref = atom_data%xyz(:,1:N); v_ref = atom_data%velocity(:,1:N); f_ref = atom_data%force(:,1:N)
+  atom_data%xyz(:,1:N) = x0; atom_data%velocity(:,1:N) = v0; atom_data%force(:,1:N) = f0
+  call gpu_md_integrate_atomic( system_data, molecule_data, atom_data, integrator_data, verlet_list_data, PME_data, file_io_data )
+  write(*,'(A,3ES12.4)') "stage md_step dx dv dF", maxval(abs(atom_data%xyz(:,1:N) - x_ref)), maxval(abs(atom_data%velocity(:,1:N) - v_ref)), &
+       maxval(abs(atom_data%force(:,1:N) - f_ref))
+
+  write(*,'(A)') "stages_check done"
+end program stages_check

@@ -121,3 +121,33 @@ def test_unchanged_reference_main_program_on_the_gpu_library(tmp_path, name, evb
     assert np.all(np.isfinite(etot)) and np.abs(etot - etot[0]).max() < 0.05 * abs(etot[0]), etot
     frames = open(tmp_path / "traj.gro").read().count("step")
     assert frames >= 7 or os.path.getsize(tmp_path / "traj.gro") > 7 * 30 * s.n_atom
+
+
+def test_fortran_stage_procedures_against_the_reference_on_the_cpu(tmp_path):
+    """oracle/_ref/stages_check (reactive_pb_nn_md_amd/fortran/stages_check.f90, built by `make link_check`): in ONE Fortran process, on the
+    data structures the reference's own start-up builds from the input files of fixture std_n6_s3, the reference's stage procedures on the
+    CPU against the procedures of the same names and argument lists in module msevb_hip_stages (GPU): real_space_energy_force after
+    construct_verlet_list, pme_reciprocal_space_energy_force (forces, E_recip, Q_grid, theta_conv_Q), grid_Q / derivative_grid_Q,
+    intra_molecular_energy_force, and one step of md_integrate_atomic."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "stages_check")
+    if not os.path.exists(exe):
+        pytest.skip("stages_check not built (needs the reference sources: dev container only)")
+    import ref_inputs
+    from reactive_pb_nn_md_amd import forcefield, synth
+    g = golden("std_n6_s3")
+    s = synth.make_system(int(g["gen_n_side"]), n_diabat=int(g["gen_n_diabat"]), seed=int(g["gen_seed"]))
+    ff = forcefield.ch3so3h_water_forcefield()
+    ref_inputs.write_gro(str(tmp_path / "sys.gro"), s)
+    ref_inputs.write_ffpmt(str(tmp_path / "ff.pmt"), ff)
+    ref_inputs.write_top(str(tmp_path / "sys.top"), ff)
+    ref_inputs.write_simpmt(str(tmp_path / "sim.pmt"), n_step=1, rc=7.0, rv=8.0, nslist=16, pme_grid=16)
+    r = subprocess.run("ulimit -s unlimited; exec %s sys.gro ff.pmt sys.top sim.pmt traj.gro out.log hop.out a.out" % exe, shell=True, cwd=str(tmp_path),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "stages_check done" in r.stdout, r.stdout[-3000:]
+    st = {ln.split()[1]: [float(x) for x in ln.split() if x[0] in "-0123456789."] for ln in r.stdout.splitlines() if ln.startswith("stage ")}
+    assert set(st) == {"real_space", "pme", "grid_Q_derivative", "bonded", "md_step"}, r.stdout[-2000:]
+    assert st["real_space"][0] < 1e-9 and st["real_space"][1] < 1e-9 * max(abs(st["real_space"][2]), abs(st["real_space"][3]))
+    assert st["pme"][0] < 1e-9 and st["pme"][1] < 1e-10 * abs(st["pme"][4]) and st["pme"][2] < 1e-13 and st["pme"][3] < 1e-12
+    assert st["grid_Q_derivative"][0] < 1e-9 and st["grid_Q_derivative"][1] < 1e-13
+    assert st["bonded"][0] < 1e-9 and st["bonded"][1] < 1e-10 * max(abs(st["bonded"][2]), abs(st["bonded"][3]), 1.0)
+    assert st["md_step"][0] < 1e-10 and st["md_step"][1] < 1e-9 and st["md_step"][2] < 1e-8

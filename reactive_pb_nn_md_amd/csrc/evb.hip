@@ -1138,6 +1138,7 @@ struct EvbWork {   // persistent device scratch of one context
   int last_ngrid = 0, last_nra = 0, last_grid_of[MAX_DIABATS]; const RecipAtom* last_d_ra = nullptr; bool last_fast = false;
   bool counters_dirty = true, dv_dirty = true, mol_deferred = false;
   double* h_coef = nullptr; long long seq_C = 0;      // pinned, coherent: blend coefficients for k_evb_wait_coef + its flag behind them
+  hipEvent_t ev_chains = nullptr;      // environment chain + couplings done (recorded on the descriptor stream)
   bool side_valid = false; hipEvent_t ev_side = nullptr;      // recorded on the front-end stream once it has waited for every other side chain: the ONE event the blend phase waits for
   bool pack_prefilled = false; hipEvent_t ev_prefill = nullptr;      // the blended charge grid starts as a copy of Q_1, made while the host waits for the energies
   std::vector<RegionRec> region, region_raw; std::vector<long long> region_key;
@@ -1829,7 +1830,14 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     }
     // published from the diabat grid stream, normally the last chain to finish: the waits for the other two chains' events are then
     // already satisfied and the publish kernel starts right behind the last energy kernel (a publish on another stream starts an event hop later)
-    if (c->overlap) { HIPCHK(hipStreamWaitEvent(sg, w->ev_join2, 0)); if (ncp) HIPCHK(hipStreamWaitEvent(sg, w->ev_cpl, 0)); }
+    // ... behind ONE barrier packet: the descriptor stream (idle since its environment chain) waits for the coupling chain and records the
+    // event this stream waits for (two waits in front of the publish kernel were two barrier packets of ~10 us on the way to the host's turn)
+    if (c->overlap) {
+      if (!w->ev_chains) HIPCHK(hipEventCreateWithFlags(&w->ev_chains, hipEventDisableTiming));
+      if (ncp) HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_cpl, 0));
+      HIPCHK(hipEventRecord(w->ev_chains, w->stream2));
+      HIPCHK(hipStreamWaitEvent(sg, w->ev_chains, 0));
+    }
     const bool lin_e = linear && ngrid > 0;
     hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, ++w->seq_A,
                        lin_e ? ngrid : 0, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid,
@@ -2120,7 +2128,7 @@ void evb_release(msevb_ctx* c) {
     DBuf<double>* db[] = {&w->d_exch, &w->d_part, &w->d_E, &w->d_dVspec, &w->d_sw, &w->d_sdw, &w->d_Fdelta, &w->d_F11, &w->d_pack, &w->d_com_atom};
     for (auto b : db) b->release();
     w->d_stencils.release(); w->d_Elq.release(); w->d_ow.release(); w->d_odw.release(); w->d_obase.release(); w->d_tabs.release(); w->d_sbase.release(); w->d_counter.release(); w->d_grids.release(); w->d_region.release(); w->d_cand.release(); w->d_desc.release();
-    hipEvent_t* ev[] = {&w->ev_side, &w->ev_prefill, &w->ev_pairs, &w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA, &w->ev_solve, &w->ev_rs};
+    hipEvent_t* ev[] = {&w->ev_chains, &w->ev_side, &w->ev_prefill, &w->ev_pairs, &w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA, &w->ev_solve, &w->ev_rs};
     for (auto e : ev) if (*e) (void)hipEventDestroy(*e);
     if (w->h_region) (void)hipHostFree(w->h_region);
     if (w->h_count) (void)hipHostFree(w->h_count);

@@ -1462,7 +1462,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   // ~15 us, later; the pair loop, which it now precedes, has that much slack before the blend needs it)
   const hipStream_t s_reg = c->overlap && c->evb_region_main ? c->stream : w->stream2;
   if (!w->h_flag) { HIPCHK(hipHostMalloc((void**)&w->h_flag, 64, hipHostMallocDefault)); memset(w->h_flag, 0, 64); }
-  hipLaunchKernelGGL(k_evb_region, dim3((M + 255) / 256), dim3(256), 0, s_reg, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
+  hipLaunchKernelGGL(k_evb_region, dim3((M + 1023) / 1024), dim3(1024), 0, s_reg, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
                      c->d_mass.p, box, w->d_counter.p, w->d_region.p, REGION_CAP, w->d_counter.p + 1, w->h_region, REGION_FAST,
                      w->d_counter.p + 2, w->h_count, (volatile long long*)(w->h_flag + 1), ++w->seq_R);
   HIPCHK(hipEventRecord(w->ev_region, s_reg));

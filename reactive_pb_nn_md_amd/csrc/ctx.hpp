@@ -192,6 +192,7 @@ struct msevb_ctx {
   bool shard_principal = false;
   hipEvent_t ev_pos_ready = nullptr;      // set by the MS-EVB call around total_force_enqueue: positions of this step are final
   bool refresh_side_now = false; hipEvent_t ev_refresh = nullptr;      // MS-EVB call with the neighbourhood kernel on the main stream: the refresh kernels run beside it on aux3
+  bool pme_split_now = false, pme_split_pending = false, evb_pme_split = true; int pme_split_slot = 0;      // MS-EVB fast path: spread now, solve later (behind the stencil-pair kernels on aux)
   bool skip_side_joins_now = false, evb_single_join = true;      // MS-EVB fast path: the main stream waits ONCE for the side streams (a barrier packet behind the pair loop costs several us each)
   bool defer_fold_now = false, fsorted_pending = false, evb_defer_fold = true;      // MS-EVB fast path: k_pair_fold's work is done by k_evb_blend
   bool evb_prelaunch_blend = false;        // option: the blend phase is enqueued before the host's Jacobi and waits on the device for its coefficients (evb.hip, k_evb_wait_coef)
@@ -364,6 +365,7 @@ int molecule_forces(msevb_ctx* c, int slot0, bool do_nb, bool do_bonded, hipStre
 int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux = false);
 int pme_front(msevb_ctx* c, int slot_recip, bool join_aux);
 int pme_tail(msevb_ctx* c, bool join_aux);                           // pme.hip
+int pme_front_finish(msevb_ctx* c);                                  // the solve of a split front end (pme_split_now)
 int pme_setup(msevb_ctx* c);
 int pme_build_green(msevb_ctx* c);   // after the CB array changed (box change)
 void pme_teardown(msevb_ctx* c);

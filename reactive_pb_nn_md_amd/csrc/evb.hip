@@ -1477,10 +1477,11 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   c->defer_fold_now = fast && c->evb_defer_fold;      // the blend kernel folds the pair loop's sorted-order accumulator in (k_evb_blend)
   const bool single_join = fast && c->overlap && c->evb_single_join && !c->evb_device_solve;      // the main stream does not wait for the side streams one by one behind the pair loop
   c->skip_side_joins_now = single_join;
+  c->pme_split_now = single_join && c->evb_pme_split && c->evb_recip_linear && c->d_green.p && fft_lds_usable(c);      // spread now; the solve goes out behind the stencil-pair kernels (step 6b)
   c->refresh_side_now = c->overlap && c->evb_region_main;
   w->side_valid = false;
   const int rc_tfe = total_force_enqueue(c);
-  c->shard_now = false; c->skip_gather_now = false; c->defer_molecules_now = false; c->ev_pos_ready = nullptr; c->defer_fold_now = false; c->skip_side_joins_now = false; c->refresh_side_now = false;
+  c->shard_now = false; c->skip_gather_now = false; c->defer_molecules_now = false; c->ev_pos_ready = nullptr; c->defer_fold_now = false; c->skip_side_joins_now = false; c->pme_split_now = false; c->refresh_side_now = false;
   CHK(rc_tfe);
   HT(2);
   if (spin_wait((volatile long long*)(w->h_flag + 1), w->seq_R, w->ev_region)) HIPCHK(hipErrorUnknown);
@@ -1863,6 +1864,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     return MSEVB_OK;
   };
   // ---- 6b. reciprocal space of the owned diabats (calculate_reciprocal_space_pme, :1962)
+  if (!(ngrid && linear)) CHK(pme_front_finish(c));      // (no stencil kernels to put in front of it)
   phase_begin(c, PH_EVB_RECIP, sg);
   stamp(c, 5, sg);
   const int nst = 2 * nra;
@@ -1884,6 +1886,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       hipLaunchKernelGGL(k_evb_recip_pairs, dim3(max_ns, ngrid), dim3(256), 0, sg, granges, w->d_stencils.p, K, c->d_green.p, c->conv, c->kk[0][0], c->kk[0][1],
                          c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p + MAX_DIABATS);
     }
+    CHK(pme_front_finish(c));      // (split front end: the principal solve goes out here, behind the kernels above that do not need its result)
     hipLaunchKernelGGL(k_evb_recip_linear, dim3((nst + 3) / 4), dim3(256), 0, sg, nst, w->d_stencils.p, K, c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
                        c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p);
     if (dev_solve) hipLaunchKernelGGL(k_evb_grid_energy, dim3(1), dim3(128), 0, sg, ngrid, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid);      // (otherwise fetch A's publish kernel does it)

@@ -692,7 +692,7 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
   // side stream it is captured once into a hipGraph and replayed with one launch (the ~14 launches cost the host ~80 us per step, and
   // the host is what decides when the EVB chains behind them can start).  Steps that sample the phase timers launch directly.
   struct Key { const void* p[9]; int v[8]; } key = {{c->d_grid.p, c->d_Q.p, c->d_theta.p, c->d_w.p, c->d_base.p, c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_fft_work.p},
-                                               {N, K, c->ncell[0], c->ncell[1], c->ncell[2], c->cells_valid ? 1 : 0, (c->spread_tiles ? 1 : 0) + (c->spread_mfma ? 2 : 0) + (c->spread_bricks ? 4 : 0) + (fft_lds_usable(c) ? 8 : 0), slot_recip}};
+                                               {N, K, c->ncell[0], c->ncell[1], c->ncell[2], c->cells_valid ? 1 : 0, (c->spread_tiles ? 1 : 0) + (c->spread_mfma ? 2 : 0) + (c->spread_bricks ? 4 : 0) + (fft_lds_usable(c) ? 8 : 0) + (c->pme_split_now ? 16 : 0), slot_recip}};
   const bool use_graph = join_aux && c->graphs && !c->timing_now;
   bool capturing = false;
   int nbk = 0;
@@ -741,6 +741,8 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
     }
     HIPCHK(hipGetLastError());
     phase_end(c, PH_SPREAD, st);
+    if (c->pme_split_now && own) {      // the caller enqueues the solve itself (pme_front_finish), behind work of its own on this stream
+    } else {
     phase_begin(c, PH_FFT, st);
     if (own) CHK(fft_lds_solve(c, c->d_Q.p, c->d_grid.p, c->d_theta.p, c->d_partials.p + (size_t)slot_recip * MAX_BLOCKS, &nbk, st));
     else {
@@ -748,6 +750,7 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
       hipLaunchKernelGGL(k_pme_real, dim3(1024), dim3(256), 0, st, K3, c->d_grid.p, c->d_theta.p);
     }
     phase_end(c, PH_FFT, st);
+    }
     if (capturing) {
       hipGraph_t g = nullptr;
       if (hipStreamEndCapture(st, &g) == hipSuccess && g) {
@@ -761,9 +764,23 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
       if (!c->graphs) FAIL(MSEVB_ERR_HIP, "hipGraph capture of the PME front end failed (set option graphs=0)");
     }
   }
-  CHK(reduce_partials(c, slot_recip, nbk));
   c->pme_st = nullptr;
+  if (c->pme_split_now && fft_lds_usable(c)) { c->pme_split_pending = true; c->pme_split_slot = slot_recip; return MSEVB_OK; }
+  CHK(reduce_partials(c, slot_recip, nbk));
   if (join_aux) HIPCHK(hipEventRecord(c->ev_join, c->aux));
+  return MSEVB_OK;
+}
+
+// second half of a split front end (MS-EVB call): the solve, on `aux`, behind whatever the caller has put there since
+int pme_front_finish(msevb_ctx* c) {
+  if (!c->pme_split_pending) return MSEVB_OK;
+  c->pme_split_pending = false;
+  int nbk = 0;
+  phase_begin(c, PH_FFT, c->aux);
+  CHK(fft_lds_solve(c, c->d_Q.p, c->d_grid.p, c->d_theta.p, c->d_partials.p + (size_t)c->pme_split_slot * MAX_BLOCKS, &nbk, c->aux));
+  phase_end(c, PH_FFT, c->aux);
+  CHK(reduce_partials(c, c->pme_split_slot, nbk));
+  HIPCHK(hipEventRecord(c->ev_join, c->aux));
   return MSEVB_OK;
 }
 

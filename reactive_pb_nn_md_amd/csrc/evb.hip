@@ -519,17 +519,18 @@ __device__ __forceinline__ void evb_coupling_body_atoms(int N, int n_cp, const C
       const double qj = chg[j] * conv;
 #pragma unroll
       for (int q = 0; q < QL; ++q) {
-        if (q >= nz) break;      // (uniform)
-        const double r0 = -(xs[0] - zx[q][0]), r1 = -(xs[1] - zx[q][1]), r2c = -(xs[2] - zx[q][2]);
-        const double r2 = r0 * r0 + r1 * r1 + r2c * r2c;
-        double r, inv_r;
-        sqrt_rsqrt(r2, r, inv_r);
-        const double qq = zq[q] * qj * inv_r;
-        vex += qq;
-        const double g = qq * inv_r * inv_r;      // = -(-qq / r^2)
-        const double f0 = g * r0, f1 = g * r1, f2 = g * r2c;
-        fx += f0; fy += f1; fz_ += f2;
-        fz[q][0] -= f0; fz[q][1] -= f1; fz[q][2] -= f2;
+        if (q < nz) {      // (uniform; no break: the loop must unroll completely, or fz[][] goes to scratch memory - 400 B per thread and 45 us with it)
+          const double r0 = -(xs[0] - zx[q][0]), r1 = -(xs[1] - zx[q][1]), r2c = -(xs[2] - zx[q][2]);
+          const double r2 = r0 * r0 + r1 * r1 + r2c * r2c;
+          double r, inv_r;
+          sqrt_rsqrt(r2, r, inv_r);
+          const double qq = zq[q] * qj * inv_r;
+          vex += qq;
+          const double g = qq * inv_r * inv_r;      // = -(-qq / r^2)
+          const double f0 = g * r0, f1 = g * r1, f2 = g * r2c;
+          fx += f0; fy += f1; fz_ += f2;
+          fz[q][0] -= f0; fz[q][1] -= f1; fz[q][2] -= f2;
+        }
       }
     }
     F[3 * (size_t)j] = fx; F[3 * (size_t)j + 1] = fy; F[3 * (size_t)j + 2] = fz_;      // dVex of atom j (0 for special atoms: k_evb_coupling_finish assigns them)

@@ -146,7 +146,11 @@ int msevb_set_stream(msevb_ctx* c, void* s) {
   if (c->fft_info) rocfft_execution_info_set_stream(c->fft_info, c->stream);
   return MSEVB_OK;
 }
-int msevb_synchronize(msevb_ctx* c) { HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
+int msevb_synchronize(msevb_ctx* c) {      // every stream the library enqueues on (the side streams normally end in an event the main stream waits for)
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (hipStream_t st : {c->aux, c->aux2, c->aux3}) if (st) HIPCHK(hipStreamSynchronize(st));
+  return MSEVB_OK;
+}
 
 int msevb_set_system(msevb_ctx* c, int N, int M, const double* box, double rc, double rv, double alpha, int K, int order, int spline_grid, int erfc_grid) {
   if (!c || N <= 0 || M <= 0 || !box || K <= 0) { if (c) c->err = "msevb_set_system: bad argument"; return MSEVB_ERR_ARG; }

@@ -268,6 +268,13 @@ struct msevb_ctx {
   // largest displacements since the last pruning add up to prune_delta; d_prune_mode[0]: 1 = this step prunes, 2 = this step uses the rows
   bool prune = true; double prune_delta = 0.6; int prune_lo = -1, prune_hi = -1;
   DBuf<int> d_nbr2, d_prune_mode; DBuf<unsigned> d_nbr2_count; DBuf<double4> d_posq_prune;
+  // flat per-cell pair list of k_pair_flat (pair_flat.hip): the cell's pairs within rc + prune_delta, rows padded to 16 entries; cell c's list starts at
+  // cell_start[c] * nbr_cap + 64 c, d_cell_trips[c] = its length in 64-entry trips
+  DBuf<int> d_flat; DBuf<unsigned> d_cell_trips;
+  int pair_flat_opt = 1;         // option pair_flat: 0 = k_pair_half on per-atom rows (round 2's kernel; still what force fields with a live SAPT term run)
+  bool pair_taylor = false;      // option pair_taylor: one Ewald-table row per pair, the other one from the table's own derivatives (pair_flat.hip)
+  bool attr_pair_flat[6] = {false, false, false, false, false, false};
+  int cell_atoms_max = 0;        // most atoms in ONE cell the last build saw (the pair kernels' row metadata holds PAIR_CELL_MAX)
   bool nbr_stats_copy_pending = false;      // in-kernel row statistics of a deferred rebuild still have to be downloaded
   bool nbr_check_pending = false;      // a deferred rebuild's row statistics have not been looked at yet
   int* h_nbr_stats = nullptr;          // pinned: {tile_max, pad, count_max, pad, count_sum lo, hi}
@@ -361,6 +368,8 @@ int flush_one(msevb_ctx* c, int slot, hipStream_t st);      // api.hip
 int nb_step_refresh(msevb_ctx* c, hipStream_t st = nullptr);      // refresh + displacement check + zero forces (neighbor.hip)
 int nb_check_displacements(msevb_ctx* c, int initialize, int* flag);
 int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw);              // pair.hip
+bool pair_flat_usable(const msevb_ctx* c);                                // pair_flat.hip
+int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int nblocks, int slot_elec, int slot_vdw);
 int molecule_forces(msevb_ctx* c, int slot0, bool do_nb, bool do_bonded, hipStream_t st = nullptr);  // molecule.hip
 int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux = false);
 int pme_front(msevb_ctx* c, int slot_recip, bool join_aux);

@@ -60,6 +60,7 @@ __global__ void k_tile_max(int ncell, int3 nc, const int* __restrict__ cell_star
   int tot = 0;
   for (int s = 0; s < ns; ++s) tot += cell_start[slots[s] + 1] - cell_start[slots[s]];
   atomicMax(out, tot);
+  atomicMax(out + 6, cell_start[cidx + 1] - cell_start[cidx]);      // most atoms in one cell (the half-list pair kernels keep row metadata for PAIR_CELL_MAX)
   if (nc.x >= 3 && nc.y >= 3 && nc.z >= 3) {
     cell_half_neighbourhood(cidx, nc.x, nc.y, nc.z, slots);
     tot = 0;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
     if (threadIdx.x == 0) {
       unsigned m = 0; unsigned long long sm = 0;
       for (int k = 0; k < wpb; ++k) { m = max(m, s_max[k]); sm += s_sum[k]; }
-      atomicMax((unsigned*)stats + 2, m); atomicAdd((unsigned long long*)(stats + 4), sm); atomicMax(stats + (HALF ? 1 : 0), ntile);
+      atomicMax((unsigned*)stats + 2, m); atomicAdd((unsigned long long*)(stats + 4), sm); atomicMax(stats + (HALF ? 1 : 0), ntile); atomicMax(stats + 6, i1 - cell_start[cidx]);
     }
   }
 }
@@ -509,7 +510,7 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
   auto decide_format = [&]() {
     const int cap = ((int)(c->half_tile_max * 1.08) + 63) & ~63;
     const size_t bytes = (size_t)cap * PAIR_TILE_ATOM_BYTES + (size_t)c->nt * c->nt * sizeof(PairParam) + 2048;
-    c->pair_tiles = tile_build_ok && c->pair_tiles_opt != 0 && c->half_tile_max > 0 && bytes <= (size_t)PAIR_TILE_LDS_BYTES;
+    c->pair_tiles = tile_build_ok && c->pair_tiles_opt != 0 && c->half_tile_max > 0 && bytes <= (size_t)PAIR_TILE_LDS_BYTES && c->cell_atoms_max <= PAIR_CELL_MAX;
     c->half_tile_cap = c->pair_tiles ? cap : 0;
   };
   auto fill = [&](bool want_inline = false) -> int {
@@ -540,7 +541,7 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
     c->nbr_cap = 0;      // k_count_stats must not cut the counted rows
     CHK(stats(true));
     if (cap_before == 0 || (unsigned)h_stats[2] > cap_before) set_cap((unsigned)h_stats[2]); else c->nbr_cap = cap_before;
-    c->tile_atoms_max = h_stats[0]; c->half_tile_max = h_stats[1];
+    c->tile_atoms_max = h_stats[0]; c->half_tile_max = h_stats[1]; c->cell_atoms_max = h_stats[6];
     decide_format();
     CHK(fill());
     CHK(stats(false));
@@ -554,8 +555,9 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
     } else {
       CHK(stats(true));
       c->tile_atoms_max = h_stats[0];
-      const bool tile_grew = c->pair_tiles && h_stats[1] > c->half_tile_cap;      // a half neighbourhood outgrew the pair kernel's LDS tile
+      const bool tile_grew = c->pair_tiles && (h_stats[1] > c->half_tile_cap || h_stats[6] > PAIR_CELL_MAX);      // a half neighbourhood outgrew the pair kernel's LDS tile, or one cell its row metadata
       if (h_stats[1] > 0) c->half_tile_max = h_stats[1];
+      c->cell_atoms_max = h_stats[6];
       if ((unsigned)h_stats[2] > c->nbr_cap || tile_grew) {
         if ((unsigned)h_stats[2] > c->nbr_cap) set_cap((unsigned)h_stats[2]);
         decide_format(); CHK(fill()); CHK(stats(false));
@@ -584,8 +586,9 @@ int nb_check_overflow(msevb_ctx* c) {
   c->nbr_check_pending = false;
   const int* h = c->h_nbr_stats;
   if (h[0] > 0) c->tile_atoms_max = h[0];
-  const bool tile_grew = c->pair_tiles && h[1] > c->half_tile_cap;      // a half neighbourhood outgrew the LDS tile of the pair kernel (which skipped that cell)
+  const bool tile_grew = c->pair_tiles && (h[1] > c->half_tile_cap || h[6] > PAIR_CELL_MAX);      // a half neighbourhood outgrew the LDS tile of the pair kernel, or one cell its row metadata (the kernel skipped that cell)
   if (h[1] > 0) c->half_tile_max = h[1];
+  if (h[6] > 0) c->cell_atoms_max = h[6];
   if ((unsigned)h[2] > c->nbr_cap || tile_grew) {
     if ((unsigned)h[2] > c->nbr_cap) c->nbr_cap = ((unsigned)((unsigned)h[2] * 1.15) + 64u + 63u) & ~63u;
     c->list_valid = false;

@@ -512,6 +512,9 @@ int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw) {
       HIPCHK(hipMemsetAsync(c->d_fsorted.p, 0, 3 * (size_t)N * 8, c->stream));
       c->fsorted_pending = false;
     }
+    if (pr && pair_flat_usable(c)) {      // flat per-cell list (pair_flat.hip)
+      CHK(pair_flat_launch(c, c_lo, c_hi, nblocks, slot_elec, slot_vdw));
+    } else {
     // the SAPT instantiation needs > 128 VGPRs: 512 threads (8 waves) per cell instead of 1024
     void (*kern)(int, int, int3, int, const int*, const double4*, const int*, const unsigned*, const unsigned*, const int*, const PairParam*, int, const double2*, double, int,
                  const double*, const double*, BoxDev, double, double*, double*, double*, int*, int*, unsigned*, double4*, double, int) =
@@ -528,6 +531,7 @@ int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw) {
                        c->d_cell_start.p, c->d_posq.p, c->d_type_sorted.p, c->d_nbr_start.p, c->d_nbr_count.p, c->d_nbr.p, c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx,
                        c->erfc_grid, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, c->d_fsorted.p, c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS,
                        c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS, c->d_prune_mode.p, c->d_nbr2.p, c->d_nbr2_count.p, c->d_posq_prune.p, rp * rp, N);
+    }
     if (c->defer_fold_now) c->fsorted_pending = true;      // MS-EVB fast path: k_evb_blend adds the accumulator to the force array (and re-zeroes it)
     else hipLaunchKernelGGL(k_pair_fold, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, c->d_perm.p, c->d_fsorted.p, c->d_force.p);
   } else {

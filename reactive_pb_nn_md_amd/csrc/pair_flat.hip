@@ -1,0 +1,372 @@
+// Real-space pair loop on a FLAT per-cell pair list (replaces pairwise_real_space_verlet, src/pair_int_real_space.f90:135-321, with
+// the Ewald table interpolation :698-760 and Lennard-Jones :621-645, for force fields without a live SAPT term; those run k_pair_half).
+//
+// One 1024-thread workgroup per cell of the neighbour grid, as k_pair_half (pair.hip), but the list the force loop reads is not a set of
+// per-atom rows any more:
+//   * FLAT LIST.  All pairs (i in the cell, j in the cell's half neighbourhood, r < r_c + delta) of a cell are one contiguous array of
+//     32-bit entries { pair-type index (10 bits) | a = i's position in the cell (9 bits) | j = partner's position in the tile (12 bits) },
+//     sorted by a, every row padded to a multiple of 16 entries with entries that name a far-away dummy atom.  A trip is 64 consecutive
+//     entries: no row cursor, no scalar bookkeeping, every wave of the workgroup gets the same number of trips (a contiguous chunk), and
+//     a row's end wastes at most 15 lanes instead of 63 (lane utilisation 96 % against 77 % for 64-entry trips of single rows).
+//   * The 16 lanes of a DPP row always belong to ONE atom i: the force on i accumulates in registers across trips and is summed over the
+//     DPP row (row_sum16) and added to the LDS force tile only when the row's atom changes (one trip in three).
+//   * TILE as structure of arrays in LDS (x[], y[], z[], q[], fx[], fy[], fz[] at a compile-time pitch behind the 8 KB Lennard-Jones table, from LDS
+//     address 0: the kernel has no static LDS): 8 j is the address of the two ds_read2st64_b64 of a partner's {x,y,z,q}, 8 j + constant that of the
+//     three ds_add_f64 of its force (the array starts are instruction offsets); the (type_i,type_j) Lennard-Jones
+//     table holds {C12, C6, 12 C12, 6 C6} (32 B, zeros for pairs without a Lennard-Jones term: no select in the loop).
+//   * No validity masks: padding entries point at a tile slot 1e4 A away, r^2 is clamped to r_c^2 for the table look-up, and everything
+//     that accumulates sits behind ONE exec mask (r^2 < r_c^2).  r and 1/r come from v_rsq_f64 + one coupled Newton step.
+//   * The list is written by the kernel itself on the steps whose displacement test (k_top2_final, neighbor.hip) says the old one no
+//     longer covers r_c: phase P1 compacts the entries within r_c + delta of the builder's rows (wave per row) into scratch rows,
+//     phase P2 packs them into the flat format, then the force loop runs on the list just written.
+// Software pipeline of the force loop as in k_pair_half: entries of trip t + 2 loading, table rows of trip t + 1 requested, trip t computing.
+#include <algorithm>
+#include "ctx.hpp"
+
+namespace {
+
+constexpr int PF_LJ_BYTES = 8192;      // Lennard-Jones table at LDS address 0: 256 pair types x {C12, C6, 12 C12, 6 C6}
+constexpr int PF_J_BITS = 12, PF_A_BITS = 9, PF_A_SHIFT = PF_J_BITS, PF_T_SHIFT = PF_J_BITS + PF_A_BITS;
+static_assert((1 << PF_A_BITS) == PAIR_CELL_MAX, "row field of a flat-list entry");
+
+template <int CTRL>
+__device__ __forceinline__ double pf_dpp(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double pf_row_sum16(double v) {      // sum over the 16 lanes of a DPP row, left in every lane of the row
+  v += pf_dpp<0xB1>(v); v += pf_dpp<0x4E>(v); v += pf_dpp<0x141>(v); v += pf_dpp<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ double pf_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// LDS by ADDRESS: the kernel's only LDS is its dynamic block, which therefore starts at LDS address 0 (checked at kernel entry), and the hot
+// loop addresses it with plain integers - through the symbol the compiler adds its (unknown until link time) base to every address in a VALU
+// instruction of its own and cannot fold the array starts into the instructions' offset fields.
+typedef __attribute__((address_space(3))) double pf_lds_f64;
+__device__ __forceinline__ double pf_ld(unsigned addr) { return *(const pf_lds_f64*)(size_t)addr; }
+__device__ __forceinline__ void pf_lds_add(unsigned addr, double v) {      // ds_add_f64, no return value
+  (void)__hip_atomic_fetch_add((pf_lds_f64*)(size_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// address of an atom's fx in the force tile (fy, fz follow at the pitch: instruction offsets) from 8 x its tile position; opaque to the
+// compiler, which otherwise folds the three array starts into three separate 32-bit constants and adds each in an instruction of its own
+template <int P>
+__device__ __forceinline__ unsigned pf_force_addr(unsigned a8) { unsigned f = a8 + (PF_LJ_BYTES + 32u * P); asm("" : "+v"(f)); return f; }
+
+struct PairFlatArgs {
+  int c_lo, c_hi; int3 nc; int tile_cap;
+  const int* cell_start; const double4* posq; const int* type_s;
+  const unsigned* nbr_start; const unsigned* nbr_count; const int* nbr;      // the builder's rows (tile-local half list, neighbor.hip)
+  const PairParam* pairpar; int nt;
+  const double2* etab; double inv_dx, dx, delta /* alpha dx */;
+  BoxDev box; double rc2;
+  double* Fs; double* part_el; double* part_vdw;
+  int* prune_state; int* scratch; int* flat; unsigned* cell_trips; unsigned stride;
+  double4* posq_prune; double rp2; int N_all;
+};
+
+struct PfTrip {      // what stage A leaves for stage B (per lane)
+  double dx, dy, dz, r2, qq, inv_r, c1, xb;
+  double2 t0, t1;
+  unsigned ja, aa, pa;      // byte offsets: 8 j, 8 a, 32 x pair type
+};
+
+// Stage A of a trip: decode, partner and owner positions from the tile, r^2, r and 1/r, the Ewald-table rows requested.
+// The table is the reference's: row(r) = ceil(r / dx), value = c1 T[row] + c2 T[row + 1] with c2 = (r/dx + 1) - row (src/pair_int_real_space.f90:751-756;
+// T[k] tabulates r = k dx, so the interpolant is taken one interval up - reproduced as it is).
+// TAYLOR: only the upper row {T_B, S_B} is fetched; the lower one follows from it to 1e-16 because both tables are built from erfc and its
+// own derivative: S - T = x (2/sqrt(pi)) exp(-x^2) conv (tables.cpp), i.e. -T' x, and T'', T''', S', S'', S''' are that times polynomials in x.
+template <int P, bool TAYLOR>
+__device__ __forceinline__ void pf_stage_a(unsigned e, double rc2, double inv_dx, double delta, const char* etab, PfTrip& s) {
+#pragma clang fp contract(fast)
+  s.ja = (e & ((1u << PF_J_BITS) - 1u)) << 3;
+  s.aa = (e >> (PF_A_SHIFT - 3)) & (((1u << PF_A_BITS) - 1u) << 3);
+  s.pa = (e >> (PF_T_SHIFT - 5)) & (0x3ffu << 5);
+  constexpr unsigned X = PF_LJ_BYTES;
+  const double xj = pf_ld(s.ja + X), yj = pf_ld(s.ja + X + 8 * P), zj = pf_ld(s.ja + X + 16 * P), qj = pf_ld(s.ja + X + 24 * P);
+  const double xi = pf_ld(s.aa + X), yi = pf_ld(s.aa + X + 8 * P), zi = pf_ld(s.aa + X + 16 * P), qi = pf_ld(s.aa + X + 24 * P);
+  s.dx = xi - xj; s.dy = yi - yj; s.dz = zi - zj;
+  s.r2 = s.dx * s.dx + s.dy * s.dy + s.dz * s.dz;
+  s.qq = qi * qj;
+  const double a = fmin(s.r2, rc2);
+  // r = sqrt(a), 1/r: v_rsq_f64 seed + ONE coupled Newton (Goldschmidt) step: relative error ~1e-15, far inside the tolerances of DESIGN.md 5
+  const double y0 = __builtin_amdgcn_rsq(a);
+  double g = a * y0, h = 0.5 * y0;
+  const double d = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, d, g); h = __builtin_fma(h, d, h);
+  s.inv_r = h + h;
+  const double x1 = g * inv_dx, cx = ceil(x1);
+  s.c1 = cx - x1;
+  if (TAYLOR) s.xb = __builtin_fma(cx, delta, delta);      // alpha r_B, r_B = (row + 1) dx
+  const int row = max((int)cx, 1);      // (r = 0 / NaN must not read in front of the table; the table has one spare row behind r_c)
+  const unsigned off = (unsigned)row << 4;
+  s.t1 = *(const double2*)(etab + off);
+  if (!TAYLOR) s.t0 = *(const double2*)(etab + off - 16);
+}
+
+__device__ __forceinline__ int pf_tile_to_sorted(int p, const int* s_lo, const int* s_off) {
+  int s = 0;
+  while (s + 1 < HALF_SLOTS && p >= s_off[s + 1]) ++s;
+  return s_lo[s] + (p - s_off[s]);
+}
+
+// the reference's own r^2 (src/pair_int_real_space.f90:222-226), for pairs within rounding of the cutoff
+__device__ __forceinline__ double pf_exact_r2(const double4& pi, const double4& pj, const BoxDev& box) {
+#pragma clang fp contract(off)
+  double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+  dx = dx - box.L[0] * floor(dx * box.invL[0] + 0.5); dy = dy - box.L[1] * floor(dy * box.invL[1] + 0.5); dz = dz - box.L[2] * floor(dz * box.invL[2] + 0.5);
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+struct PfSmall { double red[2][16]; int lo[HALF_SLOTS], off[HALF_SLOTS + 1]; unsigned cnt2[PAIR_CELL_MAX], off2[PAIR_CELL_MAX + 1]; unsigned char typ[PAIR_CELL_MAX]; };
+
+struct PfAcc { double fx, fy, fz, e_el, e_vdw; unsigned a_prev; };
+
+template <int P>
+__device__ __forceinline__ void pf_flush_row(PfAcc& acc, int lane) {      // every active lane's DPP row is complete
+  const double sx = pf_row_sum16(acc.fx), sy = pf_row_sum16(acc.fy), sz = pf_row_sum16(acc.fz);
+  if ((lane & 15) == 0) { const unsigned f = pf_force_addr<P>(acc.a_prev); pf_lds_add(f, sx); pf_lds_add(f + 8 * P, sy); pf_lds_add(f + 16 * P, sz); }
+  acc.fx = 0.0; acc.fy = 0.0; acc.fz = 0.0;
+}
+
+// Stage B: interaction arithmetic of a trip whose table rows were requested a trip ago; LDS force adds.
+template <int P, bool TAYLOR>
+__device__ __forceinline__ void pf_stage_b(const PfTrip& s, int lane, double rc2, double rc2_lo, double rc2_hi, double dxg, double delta, const BoxDev& box,
+                                           const double4* __restrict__ posq, int cs, const int* s_lo, const int* s_off, PfAcc& acc) {
+#pragma clang fp contract(fast)
+  if (__ballot(s.aa != acc.a_prev)) {      // (wave-uniform test) some DPP row has moved on to its next atom: its owner's force joins the tile
+    if (s.aa != acc.a_prev) { pf_flush_row<P>(acc, lane); acc.a_prev = s.aa; }
+  }
+  const double C12 = pf_ld(s.pa), C6 = pf_ld(s.pa + 8), C12x12 = pf_ld(s.pa + 16), C6x6 = pf_ld(s.pa + 24);
+  double ev, sv;      // erfc and force-scale interpolants
+  if (TAYLOR) {
+    const double D = s.t1.y - s.t1.x;                 // x_B E_B, E = (2/sqrt(pi)) exp(-x^2) conv = -T'
+    const double sd = s.c1 * dxg;                      // r_B - (r + dx)
+    const double q = __builtin_fma(s.c1, dxg, dxg) * s.inv_r;      // (r_B - r) / r
+    const double w = __builtin_fma(q, __builtin_fma(q, __builtin_fma(q, -1.0, 1.0), -1.0), 1.0);      // r / r_B = 1 - q + q^2 - q^3
+    const double gE = D * (sd * s.inv_r) * w;         // alpha (r_B - r - dx) E_B
+    const double x = s.xb, d2 = delta * delta;
+    const double bt = __builtin_fma(x, __builtin_fma(x, d2 * (2.0 / 3.0), delta), 1.0 - d2 * (1.0 / 3.0));
+    const double bs = __builtin_fma(x, __builtin_fma(x, __builtin_fma(x, __builtin_fma(x, d2 * (4.0 / 3.0), 2.0 * delta), 2.0 - d2 * (10.0 / 3.0)), -2.0 * delta), d2 * (2.0 / 3.0));
+    ev = __builtin_fma(gE, bt, s.t1.x);
+    sv = __builtin_fma(gE, bs, s.t1.y);
+  } else {
+    const double c2 = 1.0 - s.c1;
+    ev = s.c1 * s.t0.x + c2 * s.t1.x;
+    sv = s.c1 * s.t0.y + c2 * s.t1.y;
+  }
+  const double inv_r2 = s.inv_r * s.inv_r, qr = s.qq * s.inv_r;
+  const double r6i = inv_r2 * inv_r2 * inv_r2;
+  const double evdw = __builtin_fma(C12, r6i, -C6) * r6i;                                  // C12/r^12 - C6/r^6
+  const double fs = __builtin_fma(__builtin_fma(C12x12, r6i, -C6x6) * r6i, inv_r2, qr * inv_r2 * sv);      // force on i = fs * dr
+  bool in = s.r2 < rc2_lo;
+  const unsigned long long m_in = __ballot(in), m_near = __ballot(s.r2 < rc2_hi);
+  if (m_in != m_near) {      // rare: on the cutoff to within rounding - the reference's arithmetic on the raw coordinates decides
+    if (((m_near & ~m_in) >> lane) & 1ull) in = pf_exact_r2(posq[cs + (int)(s.aa >> 3)], posq[pf_tile_to_sorted((int)(s.ja >> 3), s_lo, s_off)], box) < rc2;
+  }
+  if (in) {
+    const double gx = fs * s.dx, gy = fs * s.dy, gz = fs * s.dz;
+    acc.fx += gx; acc.fy += gy; acc.fz += gz;
+    acc.e_el = __builtin_fma(qr, ev, acc.e_el); acc.e_vdw += evdw;
+    const unsigned f = pf_force_addr<P>(s.ja);
+    pf_lds_add(f, -gx); pf_lds_add(f + 8 * P, -gy); pf_lds_add(f + 16 * P, -gz);
+  }
+}
+
+// LDS (all dynamic, from address 0): [0, 8 K) Lennard-Jones table; then positions x, y, z, q and the force tile fx, fy, fz (P doubles each; slot ntile = the
+// dummy partner); then the small arrays of PfSmall
+template <int P, bool TAYLOR>
+__global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
+  extern __shared__ double4 pf_lds4[];
+  char* lds = (char*)pf_lds4;
+  PfSmall& sm = *(PfSmall*)(lds + PF_LJ_BYTES + 56 * P);
+  int* s_lo = sm.lo; int* s_off = sm.off; unsigned* s_cnt2 = sm.cnt2; unsigned* s_off2 = sm.off2; unsigned char* s_typ = sm.typ;
+  if ((unsigned)(size_t)(__attribute__((address_space(3))) char*)pf_lds4 != 0u) __builtin_trap();      // (see pf_ld)
+  const int mode = __builtin_amdgcn_readfirstlane(A.prune_state[0]);      // 2: the flat list still covers r_c; otherwise it is rewritten first
+  if (mode != 2) {      // snapshot of ALL positions (the displacement check runs over every atom, also when the cells are sharded over ranks)
+    const int chunk = (A.N_all + gridDim.x - 1) / gridDim.x, k0 = blockIdx.x * chunk, k1 = min(A.N_all, k0 + chunk);
+    for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x) A.posq_prune[k] = A.posq[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.prune_state[2] = 1;      // seen by the NEXT step's k_top2_final: a list exists for the current rows
+  }
+  const int cidx = A.c_lo + xcd_block(blockIdx.x, gridDim.x);      // one XCD works on one contiguous eighth of the cells (a slab)
+  if (cidx >= A.c_hi) { if (threadIdx.x == 0) { A.part_el[blockIdx.x] = 0.0; A.part_vdw[blockIdx.x] = 0.0; } return; }
+  if (threadIdx.x < HALF_SLOTS) {
+    int slots[HALF_SLOTS];
+    cell_half_neighbourhood(cidx, A.nc.x, A.nc.y, A.nc.z, slots);
+    s_lo[threadIdx.x] = A.cell_start[slots[threadIdx.x]]; s_off[threadIdx.x + 1] = A.cell_start[slots[threadIdx.x] + 1] - A.cell_start[slots[threadIdx.x]];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { int off = 0; for (int s = 0; s < HALF_SLOTS; ++s) { const int n = s_off[s + 1]; s_off[s] = off; off += n; } s_off[HALF_SLOTS] = off; }
+  __syncthreads();
+  const int ntile = s_off[HALF_SLOTS], na = s_off[1], cs = s_lo[0];
+  if (ntile > A.tile_cap || ntile >= P || na > PAIR_CELL_MAX) {      // larger than the tile this list was built for: the host sees it in the build statistics and repeats the call
+    if (threadIdx.x == 0) { A.part_el[blockIdx.x] = 0.0; A.part_vdw[blockIdx.x] = 0.0; }
+    return;
+  }
+  double* tp = (double*)(lds + PF_LJ_BYTES); double* tf = tp + 4 * P;
+  {      // stage the tile: coordinates relative to the cell centre, at the periodic image nearest to it (>= 4 cells per axis: every tile atom is within 2 cells of it)
+    const int cx = cidx % A.nc.x, cy = (cidx / A.nc.x) % A.nc.y, cz = cidx / (A.nc.x * A.nc.y);
+    const double ox = (cx + 0.5) * A.box.L[0] / A.nc.x, oy = (cy + 0.5) * A.box.L[1] / A.nc.y, oz = (cz + 0.5) * A.box.L[2] / A.nc.z;
+    for (int p = threadIdx.x; p <= ntile; p += blockDim.x) {
+      double4 t = make_double4(1.0e4, 1.0e4, 1.0e4, 0.0);      // slot ntile: the partner of the padding entries
+      if (p < ntile) {
+        const double4 q = A.posq[pf_tile_to_sorted(p, s_lo, s_off)];
+        t.x = q.x - ox; t.x = t.x - A.box.L[0] * floor(t.x * A.box.invL[0] + 0.5);
+        t.y = q.y - oy; t.y = t.y - A.box.L[1] * floor(t.y * A.box.invL[1] + 0.5);
+        t.z = q.z - oz; t.z = t.z - A.box.L[2] * floor(t.z * A.box.invL[2] + 0.5);
+        t.w = q.w;
+      }
+      tp[p] = t.x; tp[P + p] = t.y; tp[2 * P + p] = t.z; tp[3 * P + p] = t.w;
+      tf[p] = 0.0; tf[P + p] = 0.0; tf[2 * P + p] = 0.0;
+    }
+    for (int a = threadIdx.x; a < na; a += blockDim.x) s_typ[a] = (unsigned char)A.type_s[cs + a];
+    double4* ppt = (double4*)lds;
+    for (int k = threadIdx.x; k < A.nt * A.nt; k += blockDim.x) {
+      const PairParam q = A.pairpar[k];
+      ppt[k] = q.type == 0 ? make_double4(q.p[0], q.p[1], 12.0 * q.p[0], 6.0 * q.p[1]) : make_double4(0.0, 0.0, 0.0, 0.0);
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+  int* flat = A.flat + ((size_t)cs * A.stride + 64 * (size_t)cidx);      // the cell's list: room for its rows at the builder's stride + one trip of padding
+  unsigned ntrips;
+  if (mode != 2) {
+    // ---- P1: the entries of the builder's rows within r_c + delta, compacted in order into scratch rows (wave per row)
+    for (int a = wave; a < na; a += wpb) {
+      const unsigned r0 = A.nbr_start[cs + a], n = A.nbr_count[cs + a];
+      const double xi = tp[a], yi = tp[P + a], zi = tp[2 * P + a];
+      const unsigned head = ((unsigned)s_typ[a] * (unsigned)A.nt) << PF_T_SHIFT | ((unsigned)a << PF_A_SHIFT);
+      unsigned tot = 0;
+      for (unsigned k0 = 0; k0 < n; k0 += 64) {
+        const unsigned k = k0 + lane;
+        const bool v = k < n;
+        const unsigned e = v ? (unsigned)A.nbr[r0 + k] : (unsigned)ntile;
+        const unsigned j = e & NBR_IDX_MASK;
+        const double ddx = xi - tp[j], ddy = yi - tp[P + j], ddz = zi - tp[2 * P + j];
+        const bool keep = v && (ddx * ddx + ddy * ddy + ddz * ddz) < A.rp2;
+        const unsigned long long m = __ballot(keep);
+        if (keep) A.scratch[r0 + tot + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (int)(head + ((e >> NBR_IDX_BITS) << PF_T_SHIFT) + j);
+        tot += (unsigned)__popcll(m);
+      }
+      if (lane == 0) s_cnt2[a] = tot;
+    }
+    __syncthreads();
+    // ---- P2: rows padded to 16 entries, packed back to back; the cell's list padded to whole trips
+    if (wave == 0) {      // exclusive prefix sum of the padded row lengths: 8 rows per lane, shuffles across the wave
+      unsigned loc[8], sum = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int a = 8 * lane + q; loc[q] = a < na ? (s_cnt2[a] + 15u) & ~15u : 0u; sum += loc[q]; }
+      unsigned inc = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const unsigned t = (unsigned)__shfl_up((int)inc, o, 64); if (lane >= o) inc += t; }
+      unsigned run = inc - sum;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int a = 8 * lane + q; if (a < na) s_off2[a] = run; run += loc[q]; }
+      if (lane == 63) s_off2[PAIR_CELL_MAX] = inc;
+    }
+    __syncthreads();
+    const unsigned total = s_off2[PAIR_CELL_MAX];
+    ntrips = (total + 63u) >> 6;
+    for (int a = wave; a < na; a += wpb) {
+      const unsigned r0 = A.nbr_start[cs + a], n = s_cnt2[a], np = (n + 15u) & ~15u, o = s_off2[a];
+      const int pad = (int)(((unsigned)a << PF_A_SHIFT) + (unsigned)ntile);
+      for (unsigned k = lane; k < np; k += 64) flat[o + k] = k < n ? A.scratch[r0 + k] : pad;
+    }
+    if (threadIdx.x < 64 && total + threadIdx.x < (ntrips << 6)) flat[total + threadIdx.x] = ntile;      // (row 0, dummy partner)
+    if (threadIdx.x == 0) A.cell_trips[cidx] = ntrips;
+    __syncthreads();      // the list is read back by other waves of this workgroup (same CU: its stores are in L2 once vmcnt has drained)
+  } else {
+    ntrips = A.cell_trips[cidx];
+  }
+  // ---- force loop: wave w takes trips [t0, t1) of the cell's list
+  const unsigned t0 = (unsigned)(((unsigned long long)ntrips * (unsigned)wave) / (unsigned)wpb), t1 = (unsigned)(((unsigned long long)ntrips * (unsigned)(wave + 1)) / (unsigned)wpb);
+  const double rc2_lo = A.rc2 * (1.0 - 1e-9), rc2_hi = A.rc2 * (1.0 + 1e-9);
+  const char* etab = (const char*)A.etab;
+  PfAcc acc; acc.fx = 0.0; acc.fy = 0.0; acc.fz = 0.0; acc.e_el = 0.0; acc.e_vdw = 0.0; acc.a_prev = 0u;
+  if (t0 < t1) {
+    const int* src = flat + ((size_t)t0 << 6) + lane;
+    const unsigned e_none = (unsigned)ntile;
+    unsigned e1 = t0 + 1 < t1 ? (unsigned)src[64] : e_none;
+    PfTrip sa, sb;
+    pf_stage_a<P, TAYLOR>((unsigned)src[0], A.rc2, A.inv_dx, A.delta, etab, sa);
+    acc.a_prev = sa.aa;
+    for (unsigned t = t0; t < t1; t += 2) {      // two trips per turn: the two stage-A states swap roles instead of being copied
+      const unsigned e2 = t + 2 < t1 ? (unsigned)src[128] : e_none;                                                      // entries of trip t + 2: load issued
+      pf_stage_a<P, TAYLOR>(e1, A.rc2, A.inv_dx, A.delta, etab, sb);                                                // trip t + 1: table rows requested (behind the last trip: a trip of padding)
+      pf_stage_b<P, TAYLOR>(sa, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, acc);      // trip t: arithmetic
+      if (t + 1 >= t1) break;
+      e1 = t + 3 < t1 ? (unsigned)src[192] : e_none;
+      pf_stage_a<P, TAYLOR>(e2, A.rc2, A.inv_dx, A.delta, etab, sa);
+      pf_stage_b<P, TAYLOR>(sb, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, acc);
+      src += 128;
+    }
+    pf_flush_row<P>(acc, lane);
+  }
+  const double e_el = pf_wave_sum(acc.e_el), e_vdw = pf_wave_sum(acc.e_vdw);
+  if (lane == 0) { sm.red[0][wave] = e_el; sm.red[1][wave] = e_vdw; }
+  __syncthreads();      // ... and every wave's LDS force adds are done
+  if (threadIdx.x == 0) {
+    double a_ = 0, b_ = 0;
+    for (int w = 0; w < wpb; ++w) { a_ += sm.red[0][w]; b_ += sm.red[1][w]; }
+    A.part_el[blockIdx.x] = a_;      // half list: every pair once
+    A.part_vdw[blockIdx.x] = b_;
+  }
+  // flush the force tile: runs of consecutive sorted atoms per cell, one coalesced fp64 atomic per component (partners no pair reached stay out)
+  for (int p = threadIdx.x; p < ntile; p += blockDim.x) {
+    const double vx = tf[p], vy = tf[P + p], vz = tf[2 * P + p];
+    if (vx != 0.0 || vy != 0.0 || vz != 0.0) {
+      const int j = pf_tile_to_sorted(p, s_lo, s_off);
+      atomicAdd(&A.Fs[j], vx); atomicAdd(&A.Fs[(size_t)A.N_all + j], vy); atomicAdd(&A.Fs[2 * (size_t)A.N_all + j], vz);
+    }
+  }
+}
+
+template <int P, bool TAYLOR>
+int pf_launch(msevb_ctx* c, const PairFlatArgs& A, int nblocks, size_t lds, bool& attr_done) {
+  auto kern = k_pair_flat<P, TAYLOR>;
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LJ_BYTES + 56 * P + (int)sizeof(PfSmall)));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(1024), lds, c->stream, A);
+  return MSEVB_OK;
+}
+
+}  // namespace
+
+// the flat-list kernel serves: half list on tiles, rolling pruning on, no live SAPT term, <= 16 atom types, tile + dummy slot within the largest pitch
+bool pair_flat_usable(const msevb_ctx* c) {
+  return c->pair_flat_opt != 0 && c->pair_tiles && !c->has_sapt && c->nt <= 16 && c->half_tile_cap + 1 <= 2560 && c->prune && c->rc + c->prune_delta < c->rv;
+}
+
+// called by pair_forces (pair.hip) in place of the k_pair_half launch; the caller has sized the pruning state and the sorted-order accumulator
+int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int nblocks, int slot_elec, int slot_vdw) {
+  const int N = c->N, ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
+  const size_t need = c->d_nbr.n + 64 * (size_t)ncell + 64;
+  if (c->d_flat.n < need || c->d_cell_trips.n < (size_t)ncell) {      // (only behind a rebuild that enlarged the rows: the pruning state has been reset with it)
+    if (c->d_flat.alloc(need) || c->d_cell_trips.alloc(ncell)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (flat pair list)");
+  }
+  PairFlatArgs A;
+  A.c_lo = c_lo; A.c_hi = c_hi; A.nc = make_int3(c->ncell[0], c->ncell[1], c->ncell[2]); A.tile_cap = c->half_tile_cap;
+  A.cell_start = c->d_cell_start.p; A.posq = c->d_posq.p; A.type_s = c->d_type_sorted.p;
+  A.nbr_start = c->d_nbr_start.p; A.nbr_count = c->d_nbr_count.p; A.nbr = c->d_nbr.p;
+  A.pairpar = c->d_pair_par.p; A.nt = c->nt;
+  A.etab = c->d_ewald_tab.p; A.inv_dx = 1.0 / c->erfc_dx; A.dx = c->erfc_dx; A.delta = c->alpha * c->erfc_dx;
+  for (int d = 0; d < 3; ++d) { A.box.L[d] = c->box[d]; A.box.invL[d] = 1.0 / c->box[d]; }
+  A.rc2 = c->rc * c->rc;
+  A.Fs = c->d_fsorted.p; A.part_el = c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS; A.part_vdw = c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS;
+  A.prune_state = c->d_prune_mode.p; A.scratch = c->d_nbr2.p; A.flat = c->d_flat.p; A.cell_trips = c->d_cell_trips.p; A.stride = c->nbr_cap;
+  A.posq_prune = c->d_posq_prune.p;
+  const double rp = c->rc + c->prune_delta;
+  A.rp2 = rp * rp; A.N_all = N;
+  const int need_slots = c->half_tile_cap + 1;
+  const size_t lj = PF_LJ_BYTES + sizeof(PfSmall);
+  const bool ty = c->pair_taylor;
+  if (need_slots <= 1024) return ty ? pf_launch<1024, true>(c, A, nblocks, 56 * 1024 + lj, c->attr_pair_flat[0]) : pf_launch<1024, false>(c, A, nblocks, 56 * 1024 + lj, c->attr_pair_flat[1]);
+  if (need_slots <= 2048) return ty ? pf_launch<2048, true>(c, A, nblocks, 56 * 2048 + lj, c->attr_pair_flat[2]) : pf_launch<2048, false>(c, A, nblocks, 56 * 2048 + lj, c->attr_pair_flat[3]);
+  return ty ? pf_launch<2560, true>(c, A, nblocks, 56 * 2560 + lj, c->attr_pair_flat[4]) : pf_launch<2560, false>(c, A, nblocks, 56 * 2560 + lj, c->attr_pair_flat[5]);
+}

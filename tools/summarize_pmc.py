@@ -6,7 +6,10 @@ only = sys.argv[2:] or None
 tab = collections.defaultdict(dict)
 for f in sorted(glob.glob(os.path.join(d, "**", "*results.db"), recursive=True)):
     c = sqlite3.connect(f)
-    for name, ctr, n, v, dur in c.execute("select kernel_name,counter_name,count(*),sum(value),sum(duration) from counters_collection group by kernel_name,counter_name"):
+    # PMC_MAXDUR_US: only dispatches shorter than this (the pair kernel's launches that rewrite their list are a population of their own)
+    lim = float(os.environ.get("PMC_MAXDUR_US", "0")) * 1e3
+    where = ("where duration < %f " % lim) if lim > 0 else ""
+    for name, ctr, n, v, dur in c.execute("select kernel_name,counter_name,count(*),sum(value),sum(duration) from counters_collection " + where + "group by kernel_name,counter_name"):
         k = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40]
         tab[k][ctr] = v / n
         tab[k]["_us"] = dur / n / 1e3

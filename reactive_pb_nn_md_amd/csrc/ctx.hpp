@@ -268,12 +268,13 @@ struct msevb_ctx {
   // largest displacements since the last pruning add up to prune_delta; d_prune_mode[0]: 1 = this step prunes, 2 = this step uses the rows
   bool prune = true; double prune_delta = 0.6; int prune_lo = -1, prune_hi = -1;
   DBuf<int> d_nbr2, d_prune_mode; DBuf<unsigned> d_nbr2_count; DBuf<double4> d_posq_prune;
-  // flat per-cell pair list of k_pair_flat (pair_flat.hip): the cell's pairs within rc + prune_delta, rows padded to 16 entries; cell c's list starts at
-  // cell_start[c] * nbr_cap + 64 c, d_cell_trips[c] = its length in 64-entry trips
-  DBuf<int> d_flat; DBuf<unsigned> d_cell_trips;
+  // flat per-cell pair list of k_pair_flat (pair_flat.hip): the cell's pairs within rc + prune_delta, rows padded to 16 entries, one segment per wave of the
+  // cell's workgroup; cell c's list starts at cell_start[c] * (nbr_cap + 16) + 1408 c, d_cell_trips[16 c + w] = {offset, length in 64-entry trips} of wave w's segment
+  DBuf<int> d_flat; DBuf<uint2> d_cell_trips;
   int pair_flat_opt = 1;         // option pair_flat: 0 = k_pair_half on per-atom rows (round 2's kernel; still what force fields with a live SAPT term run)
-  bool pair_taylor = false;      // option pair_taylor: one Ewald-table row per pair, the other one from the table's own derivatives (pair_flat.hip)
-  bool attr_pair_flat[6] = {false, false, false, false, false, false};
+  bool prune_freeze = false;     // diagnostics (tools/time_stage.py): stage calls on unchanged positions keep the pair list of the first call instead of rewriting it every time
+  bool pair_taylor = true;       // option pair_taylor (default on): one Ewald-table row per pair, the other one from the table's own derivatives (pair_flat.hip); 0 = both rows gathered
+  bool attr_pair_flat[8] = {false, false, false, false, false, false, false, false};
   int cell_atoms_max = 0;        // most atoms in ONE cell the last build saw (the pair kernels' row metadata holds PAIR_CELL_MAX)
   bool nbr_stats_copy_pending = false;      // in-kernel row statistics of a deferred rebuild still have to be downloaded
   bool nbr_check_pending = false;      // a deferred rebuild's row statistics have not been looked at yet

@@ -416,7 +416,7 @@ int nb_refresh_sorted(msevb_ctx* c) {
   hipLaunchKernelGGL(k_gather_sorted, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, c->d_perm.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p,
                      c->d_mol_of.p, c->d_posq.p, c->d_type_sorted.p, c->d_mol_sorted.p, c->d_inv_perm.p);
   HIPCHK(hipGetLastError());
-  return nb_prune_reset(c);      // positions were replaced wholesale: whatever pruned rows exist are not known to cover them
+  return c->prune_freeze ? MSEVB_OK : nb_prune_reset(c);      // positions were replaced wholesale: whatever pruned rows exist are not known to cover them
 }
 
 // the next pair loop runs on the full rows and writes fresh pruned ones

@@ -500,7 +500,8 @@ int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw) {
     const size_t lds = (size_t)c->half_tile_cap * PAIR_TILE_ATOM_BYTES + (size_t)c->nt * c->nt * sizeof(PairParam);
     const bool pr = c->prune && c->rc + c->prune_delta < c->rv;
     if (pr) {
-      if (c->d_nbr2.alloc(c->d_nbr.n) || c->d_nbr2_count.alloc(N) || c->d_posq_prune.alloc(N)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (pruned pair list)");
+      const bool flat = pair_flat_usable(c);      // (k_pair_flat keeps its list in d_flat)
+      if ((!flat && (c->d_nbr2.alloc(c->d_nbr.n) || c->d_nbr2_count.alloc(N))) || c->d_posq_prune.alloc(N)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (pruned pair list)");
       if (!c->d_prune_mode.p || c->prune_lo != -2 - c_lo || c->prune_hi != c_hi) { CHK(nb_prune_reset(c)); c->prune_lo = -2 - c_lo; c->prune_hi = c_hi; }      // (cell ranges are kept apart from the atom ranges of k_pair)
     }
     if (!c->d_fsorted.p) {

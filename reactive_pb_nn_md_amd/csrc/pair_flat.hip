@@ -23,7 +23,17 @@
 #include <algorithm>
 #include "ctx.hpp"
 
+// PF_EXP (diagnostic builds only, tools/pair_exp.sh): bit 0 no Ewald-table loads, bit 1 no LDS force adds for the partners, bit 2 no Lennard-Jones table reads,
+// bit 3 partner positions not read from the tile, bit 8 shader-clock stamps of the kernel's phases (printed by a few workgroups), bit 5 no force loop at all, bit 6 no flush of the force tile - wrong forces, the run time says what each of them costs
+#ifndef PF_EXP
+#define PF_EXP 0
+#endif
+
 namespace {
+
+// (the list entries - 75 MB per launch at 98 k atoms - are loaded with the default cache policy: with the non-temporal hint the stage call took
+// 240 instead of 194 us, the list no longer being served from the 256 MB Infinity Cache, where it survives from one step to the next)
+__device__ __forceinline__ unsigned pf_ld_entry(const int* p) { return (unsigned)*p; }
 
 constexpr int PF_LJ_BYTES = 8192;      // Lennard-Jones table at LDS address 0: 256 pair types x {C12, C6, 12 C12, 6 C6}
 constexpr int PF_J_BITS = 12, PF_A_BITS = 9, PF_A_SHIFT = PF_J_BITS, PF_T_SHIFT = PF_J_BITS + PF_A_BITS;
@@ -65,7 +75,7 @@ struct PairFlatArgs {
   const double2* etab; double inv_dx, dx, delta /* alpha dx */;
   BoxDev box; double rc2;
   double* Fs; double* part_el; double* part_vdw;
-  int* prune_state; int* scratch; int* flat; unsigned* cell_trips; unsigned stride;
+  int* prune_state; int* flat; uint2* cell_trips; unsigned stride;
   double4* posq_prune; double rp2; int N_all;
 };
 
@@ -75,23 +85,36 @@ struct PfTrip {      // what stage A leaves for stage B (per lane)
   unsigned ja, aa, pa;      // byte offsets: 8 j, 8 a, 32 x pair type
 };
 
-// Stage A of a trip: decode, partner and owner positions from the tile, r^2, r and 1/r, the Ewald-table rows requested.
+// Stage A of a trip in two parts, so that the LDS reads of trip t + 1 are under way while trip t's arithmetic (stage B) runs:
+//   pf_stage_a_read: decode, partner and owner {x,y,z,q} requested from the tile;
+//   pf_stage_a_math: r^2, r and 1/r, the Ewald-table rows requested.
 // The table is the reference's: row(r) = ceil(r / dx), value = c1 T[row] + c2 T[row + 1] with c2 = (r/dx + 1) - row (src/pair_int_real_space.f90:751-756;
 // T[k] tabulates r = k dx, so the interpolant is taken one interval up - reproduced as it is).
 // TAYLOR: only the upper row {T_B, S_B} is fetched; the lower one follows from it to 1e-16 because both tables are built from erfc and its
-// own derivative: S - T = x (2/sqrt(pi)) exp(-x^2) conv (tables.cpp), i.e. -T' x, and T'', T''', S', S'', S''' are that times polynomials in x.
-template <int P, bool TAYLOR>
-__device__ __forceinline__ void pf_stage_a(unsigned e, double rc2, double inv_dx, double delta, const char* etab, PfTrip& s) {
-#pragma clang fp contract(fast)
-  s.ja = (e & ((1u << PF_J_BITS) - 1u)) << 3;
-  s.aa = (e >> (PF_A_SHIFT - 3)) & (((1u << PF_A_BITS) - 1u) << 3);
-  s.pa = (e >> (PF_T_SHIFT - 5)) & (0x3ffu << 5);
+// own derivative: S - T = x (2/sqrt(pi)) exp(-x^2) conv (tables.cpp), i.e. -x dT/dx, and the higher derivatives of T and S are that times polynomials in x.
+struct PfRaw { double xj, yj, zj, qj, xi, yi, zi, qi; unsigned ja, aa, pa; };
+
+template <int P>
+__device__ __forceinline__ void pf_stage_a_read(unsigned e, PfRaw& w) {
+  w.ja = (e & ((1u << PF_J_BITS) - 1u)) << 3;
+  w.aa = (e >> (PF_A_SHIFT - 3)) & (((1u << PF_A_BITS) - 1u) << 3);
+  w.pa = (e >> (PF_T_SHIFT - 5)) & (0x3ffu << 5);
   constexpr unsigned X = PF_LJ_BYTES;
-  const double xj = pf_ld(s.ja + X), yj = pf_ld(s.ja + X + 8 * P), zj = pf_ld(s.ja + X + 16 * P), qj = pf_ld(s.ja + X + 24 * P);
-  const double xi = pf_ld(s.aa + X), yi = pf_ld(s.aa + X + 8 * P), zi = pf_ld(s.aa + X + 16 * P), qi = pf_ld(s.aa + X + 24 * P);
-  s.dx = xi - xj; s.dy = yi - yj; s.dz = zi - zj;
+#if PF_EXP & 8
+  w.xj = (double)(w.ja >> 3) * 0.01; w.yj = 3.0; w.zj = 4.0; w.qj = 0.4;
+#else
+  w.xj = pf_ld(w.ja + X); w.yj = pf_ld(w.ja + X + 8 * P); w.zj = pf_ld(w.ja + X + 16 * P); w.qj = pf_ld(w.ja + X + 24 * P);
+#endif
+  w.xi = pf_ld(w.aa + X); w.yi = pf_ld(w.aa + X + 8 * P); w.zi = pf_ld(w.aa + X + 16 * P); w.qi = pf_ld(w.aa + X + 24 * P);
+}
+
+template <bool TAYLOR>
+__device__ __forceinline__ void pf_stage_a_math(const PfRaw& w, double rc2, double inv_dx, double delta, const char* etab, PfTrip& s) {
+#pragma clang fp contract(fast)
+  s.ja = w.ja; s.aa = w.aa; s.pa = w.pa;
+  s.dx = w.xi - w.xj; s.dy = w.yi - w.yj; s.dz = w.zi - w.zj;
   s.r2 = s.dx * s.dx + s.dy * s.dy + s.dz * s.dz;
-  s.qq = qi * qj;
+  s.qq = w.qi * w.qj;
   const double a = fmin(s.r2, rc2);
   // r = sqrt(a), 1/r: v_rsq_f64 seed + ONE coupled Newton (Goldschmidt) step: relative error ~1e-15, far inside the tolerances of DESIGN.md 5
   const double y0 = __builtin_amdgcn_rsq(a);
@@ -104,8 +127,12 @@ __device__ __forceinline__ void pf_stage_a(unsigned e, double rc2, double inv_dx
   if (TAYLOR) s.xb = __builtin_fma(cx, delta, delta);      // alpha r_B, r_B = (row + 1) dx
   const int row = max((int)cx, 1);      // (r = 0 / NaN must not read in front of the table; the table has one spare row behind r_c)
   const unsigned off = (unsigned)row << 4;
+#if PF_EXP & 1
+  s.t1 = make_double2((double)off, 2.0); s.t0 = make_double2(1.0, (double)off);
+#else
   s.t1 = *(const double2*)(etab + off);
   if (!TAYLOR) s.t0 = *(const double2*)(etab + off - 16);
+#endif
 }
 
 __device__ __forceinline__ int pf_tile_to_sorted(int p, const int* s_lo, const int* s_off) {
@@ -122,9 +149,10 @@ __device__ __forceinline__ double pf_exact_r2(const double4& pi, const double4& 
   return (dx * dx + dy * dy) + dz * dz;
 }
 
-struct PfSmall { double red[2][16]; int lo[HALF_SLOTS], off[HALF_SLOTS + 1]; unsigned cnt2[PAIR_CELL_MAX], off2[PAIR_CELL_MAX + 1]; unsigned char typ[PAIR_CELL_MAX]; };
+struct PfSmall { double red[2][16]; int lo[HALF_SLOTS], off[HALF_SLOTS + 1]; unsigned off2[PAIR_CELL_MAX + 1], cnt[PAIR_CELL_MAX]; unsigned char typ[PAIR_CELL_MAX]; };
 
-struct PfAcc { double fx, fy, fz, e_el, e_vdw; unsigned a_prev; };
+struct PfAcc { double fx, fy, fz, e_el, e_vdw; unsigned a_prev;
+};
 
 template <int P>
 __device__ __forceinline__ void pf_flush_row(PfAcc& acc, int lane) {      // every active lane's DPP row is complete
@@ -141,7 +169,11 @@ __device__ __forceinline__ void pf_stage_b(const PfTrip& s, int lane, double rc2
   if (__ballot(s.aa != acc.a_prev)) {      // (wave-uniform test) some DPP row has moved on to its next atom: its owner's force joins the tile
     if (s.aa != acc.a_prev) { pf_flush_row<P>(acc, lane); acc.a_prev = s.aa; }
   }
+#if PF_EXP & 4
+  const double C12 = (double)s.pa, C6 = 2.0, C12x12 = 3.0, C6x6 = 4.0;
+#else
   const double C12 = pf_ld(s.pa), C6 = pf_ld(s.pa + 8), C12x12 = pf_ld(s.pa + 16), C6x6 = pf_ld(s.pa + 24);
+#endif
   double ev, sv;      // erfc and force-scale interpolants
   if (TAYLOR) {
     const double D = s.t1.y - s.t1.x;                 // x_B E_B, E = (2/sqrt(pi)) exp(-x^2) conv = -T'
@@ -172,8 +204,12 @@ __device__ __forceinline__ void pf_stage_b(const PfTrip& s, int lane, double rc2
     const double gx = fs * s.dx, gy = fs * s.dy, gz = fs * s.dz;
     acc.fx += gx; acc.fy += gy; acc.fz += gz;
     acc.e_el = __builtin_fma(qr, ev, acc.e_el); acc.e_vdw += evdw;
+#if PF_EXP & 2
+    acc.e_vdw += gx + gy + gz;
+#else
     const unsigned f = pf_force_addr<P>(s.ja);
     pf_lds_add(f, -gx); pf_lds_add(f + 8 * P, -gy); pf_lds_add(f + 16 * P, -gz);
+#endif
   }
 }
 
@@ -184,8 +220,11 @@ __global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
   extern __shared__ double4 pf_lds4[];
   char* lds = (char*)pf_lds4;
   PfSmall& sm = *(PfSmall*)(lds + PF_LJ_BYTES + 56 * P);
-  int* s_lo = sm.lo; int* s_off = sm.off; unsigned* s_cnt2 = sm.cnt2; unsigned* s_off2 = sm.off2; unsigned char* s_typ = sm.typ;
+  int* s_lo = sm.lo; int* s_off = sm.off; unsigned* s_off2 = sm.off2; unsigned* s_cnt = sm.cnt; unsigned char* s_typ = sm.typ;
   if ((unsigned)(size_t)(__attribute__((address_space(3))) char*)pf_lds4 != 0u) __builtin_trap();      // (see pf_ld)
+#if PF_EXP & 256
+  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
   const int mode = __builtin_amdgcn_readfirstlane(A.prune_state[0]);      // 2: the flat list still covers r_c; otherwise it is rewritten first
   if (mode != 2) {      // snapshot of ALL positions (the displacement check runs over every atom, also when the cells are sharded over ranks)
     const int chunk = (A.N_all + gridDim.x - 1) / gridDim.x, k0 = blockIdx.x * chunk, k1 = min(A.N_all, k0 + chunk);
@@ -194,13 +233,17 @@ __global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
   }
   const int cidx = A.c_lo + xcd_block(blockIdx.x, gridDim.x);      // one XCD works on one contiguous eighth of the cells (a slab)
   if (cidx >= A.c_hi) { if (threadIdx.x == 0) { A.part_el[blockIdx.x] = 0.0; A.part_vdw[blockIdx.x] = 0.0; } return; }
-  if (threadIdx.x < HALF_SLOTS) {
+  if (threadIdx.x < 64) {      // the 14 cells of the half neighbourhood: first atom and tile offset of each (prefix sum across the lanes)
     int slots[HALF_SLOTS];
     cell_half_neighbourhood(cidx, A.nc.x, A.nc.y, A.nc.z, slots);
-    s_lo[threadIdx.x] = A.cell_start[slots[threadIdx.x]]; s_off[threadIdx.x + 1] = A.cell_start[slots[threadIdx.x] + 1] - A.cell_start[slots[threadIdx.x]];
+    const int sl = min((int)threadIdx.x, HALF_SLOTS - 1);
+    const int lo = A.cell_start[slots[sl]], n = threadIdx.x < HALF_SLOTS ? A.cell_start[slots[sl] + 1] - lo : 0;
+    int inc = n;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { const int t = __shfl_up(inc, o, 64); if ((int)threadIdx.x >= o) inc += t; }
+    if (threadIdx.x < HALF_SLOTS) { s_lo[threadIdx.x] = lo; s_off[threadIdx.x] = inc - n; }
+    if (threadIdx.x == HALF_SLOTS - 1) s_off[HALF_SLOTS] = inc;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) { int off = 0; for (int s = 0; s < HALF_SLOTS; ++s) { const int n = s_off[s + 1]; s_off[s] = off; off += n; } s_off[HALF_SLOTS] = off; }
   __syncthreads();
   const int ntile = s_off[HALF_SLOTS], na = s_off[1], cs = s_lo[0];
   if (ntile > A.tile_cap || ntile >= P || na > PAIR_CELL_MAX) {      // larger than the tile this list was built for: the host sees it in the build statistics and repeats the call
@@ -208,20 +251,36 @@ __global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
     return;
   }
   double* tp = (double*)(lds + PF_LJ_BYTES); double* tf = tp + 4 * P;
+  // tile position -> sorted atom: p + (lo[s] - off[s]) for the slot s that holds p, as a sum of 13 selects on scalar operands (a search through the LDS
+  // copies is a chain of 14 dependent reads per atom)
+  int t2s_off[HALF_SLOTS], t2s_add[HALF_SLOTS];
+#pragma unroll
+  for (int k = 0; k < HALF_SLOTS; ++k) {
+    t2s_off[k] = __builtin_amdgcn_readfirstlane(s_off[k]);
+    const int d = __builtin_amdgcn_readfirstlane(s_lo[k] - s_off[k]);
+    t2s_add[k] = k ? d - __builtin_amdgcn_readfirstlane(s_lo[k - 1] - s_off[k - 1]) : d;
+  }
+  auto tile_to_sorted = [&](int p) -> int {
+    int j = p + t2s_add[0];
+#pragma unroll
+    for (int k = 1; k < HALF_SLOTS; ++k) j += p >= t2s_off[k] ? t2s_add[k] : 0;
+    return j;
+  };
   {      // stage the tile: coordinates relative to the cell centre, at the periodic image nearest to it (>= 4 cells per axis: every tile atom is within 2 cells of it)
     const int cx = cidx % A.nc.x, cy = (cidx / A.nc.x) % A.nc.y, cz = cidx / (A.nc.x * A.nc.y);
     const double ox = (cx + 0.5) * A.box.L[0] / A.nc.x, oy = (cy + 0.5) * A.box.L[1] / A.nc.y, oz = (cz + 0.5) * A.box.L[2] / A.nc.z;
     for (int p = threadIdx.x; p <= ntile; p += blockDim.x) {
       double4 t = make_double4(1.0e4, 1.0e4, 1.0e4, 0.0);      // slot ntile: the partner of the padding entries
       if (p < ntile) {
-        const double4 q = A.posq[pf_tile_to_sorted(p, s_lo, s_off)];
+        const double4 q = A.posq[tile_to_sorted(p)];
         t.x = q.x - ox; t.x = t.x - A.box.L[0] * floor(t.x * A.box.invL[0] + 0.5);
         t.y = q.y - oy; t.y = t.y - A.box.L[1] * floor(t.y * A.box.invL[1] + 0.5);
         t.z = q.z - oz; t.z = t.z - A.box.L[2] * floor(t.z * A.box.invL[2] + 0.5);
         t.w = q.w;
       }
       tp[p] = t.x; tp[P + p] = t.y; tp[2 * P + p] = t.z; tp[3 * P + p] = t.w;
-      tf[p] = 0.0; tf[P + p] = 0.0; tf[2 * P + p] = 0.0;
+      if (mode != 2) ((float4*)tf)[p] = make_float4((float)t.x, (float)t.y, (float)t.z, 0.0f);      // single-precision copy for the pruning pass, in the (still unused) force tile
+      else { tf[p] = 0.0; tf[P + p] = 0.0; tf[2 * P + p] = 0.0; }
     }
     for (int a = threadIdx.x; a < na; a += blockDim.x) s_typ[a] = (unsigned char)A.type_s[cs + a];
     double4* ppt = (double4*)lds;
@@ -232,34 +291,19 @@ __global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
-  int* flat = A.flat + ((size_t)cs * A.stride + 64 * (size_t)cidx);      // the cell's list: room for its rows at the builder's stride + one trip of padding
-  unsigned ntrips;
+#if PF_EXP & 256
+  const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
+  // The cell's list is 16 SEGMENTS, one per wave: a wave writes its segment (when the list is rewritten) and reads it back in its force loop, here
+  // and in the launches that keep the list - no scratch copy, no workgroup barrier between the two.  Room: the cell's rows at (stride + 16) + 1408.
+  int* cell_flat = A.flat + ((size_t)cs * (A.stride + 16u) + 1408 * (size_t)cidx);
+  unsigned seg_off, seg_trips;
   if (mode != 2) {
-    // ---- P1: the entries of the builder's rows within r_c + delta, compacted in order into scratch rows (wave per row)
-    for (int a = wave; a < na; a += wpb) {
-      const unsigned r0 = A.nbr_start[cs + a], n = A.nbr_count[cs + a];
-      const double xi = tp[a], yi = tp[P + a], zi = tp[2 * P + a];
-      const unsigned head = ((unsigned)s_typ[a] * (unsigned)A.nt) << PF_T_SHIFT | ((unsigned)a << PF_A_SHIFT);
-      unsigned tot = 0;
-      for (unsigned k0 = 0; k0 < n; k0 += 64) {
-        const unsigned k = k0 + lane;
-        const bool v = k < n;
-        const unsigned e = v ? (unsigned)A.nbr[r0 + k] : (unsigned)ntile;
-        const unsigned j = e & NBR_IDX_MASK;
-        const double ddx = xi - tp[j], ddy = yi - tp[P + j], ddz = zi - tp[2 * P + j];
-        const bool keep = v && (ddx * ddx + ddy * ddy + ddz * ddz) < A.rp2;
-        const unsigned long long m = __ballot(keep);
-        if (keep) A.scratch[r0 + tot + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (int)(head + ((e >> NBR_IDX_BITS) << PF_T_SHIFT) + j);
-        tot += (unsigned)__popcll(m);
-      }
-      if (lane == 0) s_cnt2[a] = tot;
-    }
-    __syncthreads();
-    // ---- P2: rows padded to 16 entries, packed back to back; the cell's list padded to whole trips
-    if (wave == 0) {      // exclusive prefix sum of the padded row lengths: 8 rows per lane, shuffles across the wave
+    // ---- the builder's rows cut into 64-entry pieces ("full trips"), dealt to the waves in equal numbers; exclusive prefix of the pieces per row
+    if (wave == 0) {      // 8 rows per lane, shuffles across the wave
       unsigned loc[8], sum = 0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { const int a = 8 * lane + q; loc[q] = a < na ? (s_cnt2[a] + 15u) & ~15u : 0u; sum += loc[q]; }
+      for (int q = 0; q < 8; ++q) { const int a = 8 * lane + q; const unsigned n = a < na ? A.nbr_count[cs + a] : 0u; if (a < na) s_cnt[a] = n; loc[q] = (n + 63u) >> 6; sum += loc[q]; }
       unsigned inc = sum;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) { const unsigned t = (unsigned)__shfl_up((int)inc, o, 64); if (lane >= o) inc += t; }
@@ -269,46 +313,122 @@ __global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
       if (lane == 63) s_off2[PAIR_CELL_MAX] = inc;
     }
     __syncthreads();
-    const unsigned total = s_off2[PAIR_CELL_MAX];
-    ntrips = (total + 63u) >> 6;
-    for (int a = wave; a < na; a += wpb) {
-      const unsigned r0 = A.nbr_start[cs + a], n = s_cnt2[a], np = (n + 15u) & ~15u, o = s_off2[a];
-      const int pad = (int)(((unsigned)a << PF_A_SHIFT) + (unsigned)ntile);
-      for (unsigned k = lane; k < np; k += 64) flat[o + k] = k < n ? A.scratch[r0 + k] : pad;
+    const unsigned TT = s_off2[PAIR_CELL_MAX];
+    unsigned ft = (unsigned)(((unsigned long long)TT * (unsigned)wave) / (unsigned)wpb);
+    const unsigned ft1 = (unsigned)(((unsigned long long)TT * (unsigned)(wave + 1)) / (unsigned)wpb);
+    int a = 0;
+    if (ft < ft1) {      // the row that holds piece ft: the last one whose prefix is <= ft
+      int lo = 0, hi = na;
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off2[mid] <= ft) lo = mid; else hi = mid; }
+      a = lo;
     }
-    if (threadIdx.x < 64 && total + threadIdx.x < (ntrips << 6)) flat[total + threadIdx.x] = ntile;      // (row 0, dummy partner)
-    if (threadIdx.x == 0) A.cell_trips[cidx] = ntrips;
-    __syncthreads();      // the list is read back by other waves of this workgroup (same CU: its stores are in L2 once vmcnt has drained)
+    // Upper bound of what the waves before this one write: their pieces (64 each), 15 padding entries per row part (a rows + one split per wave), 63 per segment end
+    seg_off = 64u * (ft + (unsigned)wave + (((unsigned)a + (unsigned)wave + 3u) >> 2));
+    int* out = cell_flat + seg_off;
+    // The wave's pieces as a stream {row, offset in the row}; PF_BATCH pieces are loaded together and the next batch is requested before the current one is
+    // looked at (the rows come from HBM: 2 x 4 pieces of 256 B per wave in flight, 32 KB per CU; twice as many measured the same).
+    constexpr int PF_BATCH = 4;
+    const float4* tq = (const float4*)tf;
+    const float rp2f = (float)A.rp2 + 2e-3f;
+    struct Piece { int a; unsigned k0, n; };      // (wave-uniform)
+    int pa = a; unsigned pk = ft < ft1 ? (ft - s_off2[a]) << 6 : 0u, pn = ft < ft1 ? s_cnt[a] : 0u, left = ft1 - ft;
+    const int* rows = A.nbr + (size_t)cs * A.stride;      // (row i of the builder starts at i x stride)
+    auto next_piece = [&](Piece& pc) -> unsigned {      // returns the piece's entry of this lane (0xffffffff: none)
+      if (left == 0) { pc.a = -1; pc.k0 = 0; pc.n = 0; return 0xffffffffu; }
+      while (pk >= pn) { ++pa; pk = 0; pn = s_cnt[pa]; }      // (rows without entries hold no piece)
+      pc.a = pa; pc.k0 = pk; pc.n = pn;
+      const unsigned k = pk + lane;
+      const unsigned e = k < pn ? (unsigned)rows[(size_t)pa * A.stride + k] : 0xffffffffu;
+      pk += 64; --left;
+      return e;
+    };
+    Piece pc[PF_BATCH], pd[PF_BATCH]; unsigned ec[PF_BATCH], ed[PF_BATCH];
+#pragma unroll
+    for (int q = 0; q < PF_BATCH; ++q) ec[q] = next_piece(pc[q]);
+    unsigned o = 0, tot = 0;
+    int a_last = a;
+    while (pc[0].a >= 0) {
+#pragma unroll
+      for (int q = 0; q < PF_BATCH; ++q) ed[q] = next_piece(pd[q]);      // the batch after this one: loads issued
+#pragma unroll
+      for (int q = 0; q < PF_BATCH; ++q) {
+        if (pc[q].a < 0) break;
+        const int ra = pc[q].a;
+        const unsigned e = ec[q];
+        const bool v = e != 0xffffffffu;
+        const unsigned j = v ? (e & NBR_IDX_MASK) : (unsigned)ntile;
+        const float4 fi = tq[ra], fj = tq[j];      // tile coordinates are within 2.5 cells of the cell centre: r^2 is good to 2e-4 A^2 in single precision,
+        const float ddx = fi.x - fj.x, ddy = fi.y - fj.y, ddz = fi.z - fj.z;      // and an entry too many in the list costs nothing but its lane
+        const bool keep = v && (ddx * ddx + ddy * ddy + ddz * ddz) < rp2f;
+        const unsigned long long m = __ballot(keep);
+        const unsigned head = ((unsigned)s_typ[ra] * (unsigned)A.nt) << PF_T_SHIFT | ((unsigned)ra << PF_A_SHIFT);
+        if (keep) out[o + tot + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (int)(head + ((e >> NBR_IDX_BITS) << PF_T_SHIFT) + j);
+        tot += (unsigned)__popcll(m);
+        const int na_next = q + 1 < PF_BATCH ? pc[q + 1].a : pd[0].a;      // the row of the piece that follows (-1: none)
+        if (na_next != ra) {      // the row part ends: padded to 16 entries (dummy partner, same row)
+          const unsigned np = (tot + 15u) & ~15u;
+          if (tot + lane < np) out[o + tot + lane] = (int)(((unsigned)ra << PF_A_SHIFT) + (unsigned)ntile);
+          o += np; tot = 0; a_last = ra;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < PF_BATCH; ++q) { pc[q] = pd[q]; ec[q] = ed[q]; }
+    }
+    seg_trips = (o + 63u) >> 6;
+    if (o + lane < (seg_trips << 6)) out[o + lane] = (int)(((unsigned)a_last << PF_A_SHIFT) + (unsigned)ntile);
+    if (lane == 0) A.cell_trips[(size_t)cidx * 16 + wave] = make_uint2(seg_off, seg_trips);
+    __syncthreads();      // (the stores of the wave's segment have left it, which is all its own reads of the segment need: same CU, write-through L1)
+    for (int p = threadIdx.x; p <= ntile; p += blockDim.x) { tf[p] = 0.0; tf[P + p] = 0.0; tf[2 * P + p] = 0.0; }      // the force tile held the single-precision copy
+    __syncthreads();
   } else {
-    ntrips = A.cell_trips[cidx];
+    const uint2 sg = A.cell_trips[(size_t)cidx * 16 + wave];
+    seg_off = sg.x; seg_trips = sg.y;
   }
-  // ---- force loop: wave w takes trips [t0, t1) of the cell's list
-  const unsigned t0 = (unsigned)(((unsigned long long)ntrips * (unsigned)wave) / (unsigned)wpb), t1 = (unsigned)(((unsigned long long)ntrips * (unsigned)(wave + 1)) / (unsigned)wpb);
+  // ---- force loop over the wave's segment
+  const unsigned t0 = 0u, t1 = seg_trips;
   const double rc2_lo = A.rc2 * (1.0 - 1e-9), rc2_hi = A.rc2 * (1.0 + 1e-9);
   const char* etab = (const char*)A.etab;
-  PfAcc acc; acc.fx = 0.0; acc.fy = 0.0; acc.fz = 0.0; acc.e_el = 0.0; acc.e_vdw = 0.0; acc.a_prev = 0u;
-  if (t0 < t1) {
-    const int* src = flat + ((size_t)t0 << 6) + lane;
+  PfAcc acc;
+  acc.fx = 0.0; acc.fy = 0.0; acc.fz = 0.0; acc.e_el = 0.0; acc.e_vdw = 0.0; acc.a_prev = 0u;
+  if (t0 < t1 && !(PF_EXP & 32)) {
+    // Two trips in flight per wave: geometry of trip t + 1 (its table rows requested) in front of the arithmetic of trip t, whose rows were requested a
+    // trip ago; the entries of trip t + 2 loading.  (A third stage - tile reads of trip t + 2 issued before the arithmetic of trip t - measured the same
+    // 140 us and costs 20 registers: the loop is bound by the throughput of the LDS, the vector-memory address path and the fp64 pipe together, not by a wait.)
+    // Entry loads are UNCONDITIONAL (behind the wave's last trip they read the next wave's entries or the list's padding - the allocation has trips to
+    // spare - and a select discards them): a load inside a branch makes the compiler wait for ALL outstanding loads at the join, table rows included.
+    const int* src = cell_flat + seg_off + lane;
     const unsigned e_none = (unsigned)ntile;
-    unsigned e1 = t0 + 1 < t1 ? (unsigned)src[64] : e_none;
-    PfTrip sa, sb;
-    pf_stage_a<P, TAYLOR>((unsigned)src[0], A.rc2, A.inv_dx, A.delta, etab, sa);
+    PfRaw w; PfTrip sa, sb;
+    unsigned ea = pf_ld_entry(src + 64), eb;
+    pf_stage_a_read<P>(pf_ld_entry(src), w);
+    ea = t0 + 1 < t1 ? ea : e_none;
+    pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sa);
     acc.a_prev = sa.aa;
-    for (unsigned t = t0; t < t1; t += 2) {      // two trips per turn: the two stage-A states swap roles instead of being copied
-      const unsigned e2 = t + 2 < t1 ? (unsigned)src[128] : e_none;                                                      // entries of trip t + 2: load issued
-      pf_stage_a<P, TAYLOR>(e1, A.rc2, A.inv_dx, A.delta, etab, sb);                                                // trip t + 1: table rows requested (behind the last trip: a trip of padding)
+    for (unsigned t = t0; t < t1; t += 2) {      // two trips per turn: the states swap roles instead of being copied
+      eb = pf_ld_entry(src + 128);                                                                                  // entries of trip t + 2
+      pf_stage_a_read<P>(ea, w);
+      pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sb);                                               // trip t + 1: geometry, table rows requested (behind the last trip: padding)
       pf_stage_b<P, TAYLOR>(sa, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, acc);      // trip t: arithmetic
+      eb = t + 2 < t1 ? eb : e_none;
       if (t + 1 >= t1) break;
-      e1 = t + 3 < t1 ? (unsigned)src[192] : e_none;
-      pf_stage_a<P, TAYLOR>(e2, A.rc2, A.inv_dx, A.delta, etab, sa);
+      ea = pf_ld_entry(src + 192);
+      pf_stage_a_read<P>(eb, w);
+      pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sa);
       pf_stage_b<P, TAYLOR>(sb, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, acc);
+      ea = t + 3 < t1 ? ea : e_none;
       src += 128;
     }
     pf_flush_row<P>(acc, lane);
   }
+#if PF_EXP & 256
+  const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
   const double e_el = pf_wave_sum(acc.e_el), e_vdw = pf_wave_sum(acc.e_vdw);
   if (lane == 0) { sm.red[0][wave] = e_el; sm.red[1][wave] = e_vdw; }
   __syncthreads();      // ... and every wave's LDS force adds are done
+#if PF_EXP & 256
+  const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+#endif
   if (threadIdx.x == 0) {
     double a_ = 0, b_ = 0;
     for (int w = 0; w < wpb; ++w) { a_ += sm.red[0][w]; b_ += sm.red[1][w]; }
@@ -316,13 +436,19 @@ __global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
     A.part_vdw[blockIdx.x] = b_;
   }
   // flush the force tile: runs of consecutive sorted atoms per cell, one coalesced fp64 atomic per component (partners no pair reached stay out)
+  if (!(PF_EXP & 64))
   for (int p = threadIdx.x; p < ntile; p += blockDim.x) {
     const double vx = tf[p], vy = tf[P + p], vz = tf[2 * P + p];
     if (vx != 0.0 || vy != 0.0 || vz != 0.0) {
-      const int j = pf_tile_to_sorted(p, s_lo, s_off);
+      const int j = tile_to_sorted(p);
       atomicAdd(&A.Fs[j], vx); atomicAdd(&A.Fs[(size_t)A.N_all + j], vy); atomicAdd(&A.Fs[2 * (size_t)A.N_all + j], vz);
     }
   }
+#if PF_EXP & 256
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0 && (wave == 0 || wave == 15) && (blockIdx.x % 97) == 5 && mode == 2)
+    printf("pf diag block %d wave %d trips %u..%u: staging %llu clk, loop %llu, wait for the other waves %llu, flush %llu\n", blockIdx.x, wave, t0, t1, ts1 - ts0, ts2 - ts1, ts3 - ts2, __builtin_amdgcn_s_memtime() - ts3);
+#endif
 }
 
 template <int P, bool TAYLOR>
@@ -333,6 +459,7 @@ int pf_launch(msevb_ctx* c, const PairFlatArgs& A, int nblocks, size_t lds, bool
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(1024), lds, c->stream, A);
+  if (c->prune_freeze) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->d_prune_mode.p, 2, 1, c->stream));      // diagnostics: the next stage call reads this list
   return MSEVB_OK;
 }
 
@@ -346,9 +473,9 @@ bool pair_flat_usable(const msevb_ctx* c) {
 // called by pair_forces (pair.hip) in place of the k_pair_half launch; the caller has sized the pruning state and the sorted-order accumulator
 int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int nblocks, int slot_elec, int slot_vdw) {
   const int N = c->N, ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
-  const size_t need = c->d_nbr.n + 64 * (size_t)ncell + 64;
-  if (c->d_flat.n < need || c->d_cell_trips.n < (size_t)ncell) {      // (only behind a rebuild that enlarged the rows: the pruning state has been reset with it)
-    if (c->d_flat.alloc(need) || c->d_cell_trips.alloc(ncell)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (flat pair list)");
+  const size_t need = (size_t)N * (c->nbr_cap + 16) + 1408 * (size_t)ncell + 6 * 64;      // (+ the trips the force loop's unconditional entry loads may reach behind the last cell's list)
+  if (c->d_flat.n < need || c->d_cell_trips.n < 16 * (size_t)ncell) {      // (only behind a rebuild that enlarged the rows: the pruning state has been reset with it)
+    if (c->d_flat.alloc(need) || c->d_cell_trips.alloc(16 * (size_t)ncell)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (flat pair list)");
   }
   PairFlatArgs A;
   A.c_lo = c_lo; A.c_hi = c_hi; A.nc = make_int3(c->ncell[0], c->ncell[1], c->ncell[2]); A.tile_cap = c->half_tile_cap;
@@ -359,7 +486,7 @@ int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int nblocks, int slot_ele
   for (int d = 0; d < 3; ++d) { A.box.L[d] = c->box[d]; A.box.invL[d] = 1.0 / c->box[d]; }
   A.rc2 = c->rc * c->rc;
   A.Fs = c->d_fsorted.p; A.part_el = c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS; A.part_vdw = c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS;
-  A.prune_state = c->d_prune_mode.p; A.scratch = c->d_nbr2.p; A.flat = c->d_flat.p; A.cell_trips = c->d_cell_trips.p; A.stride = c->nbr_cap;
+  A.prune_state = c->d_prune_mode.p; A.flat = c->d_flat.p; A.cell_trips = c->d_cell_trips.p; A.stride = c->nbr_cap;
   A.posq_prune = c->d_posq_prune.p;
   const double rp = c->rc + c->prune_delta;
   A.rp2 = rp * rp; A.N_all = N;
@@ -368,5 +495,6 @@ int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int nblocks, int slot_ele
   const bool ty = c->pair_taylor;
   if (need_slots <= 1024) return ty ? pf_launch<1024, true>(c, A, nblocks, 56 * 1024 + lj, c->attr_pair_flat[0]) : pf_launch<1024, false>(c, A, nblocks, 56 * 1024 + lj, c->attr_pair_flat[1]);
   if (need_slots <= 2048) return ty ? pf_launch<2048, true>(c, A, nblocks, 56 * 2048 + lj, c->attr_pair_flat[2]) : pf_launch<2048, false>(c, A, nblocks, 56 * 2048 + lj, c->attr_pair_flat[3]);
+  if (need_slots <= 2304) return ty ? pf_launch<2304, true>(c, A, nblocks, 56 * 2304 + lj, c->attr_pair_flat[6]) : pf_launch<2304, false>(c, A, nblocks, 56 * 2304 + lj, c->attr_pair_flat[7]);      // (the largest pitch that keeps all four position arrays within the 16-bit offset field)
   return ty ? pf_launch<2560, true>(c, A, nblocks, 56 * 2560 + lj, c->attr_pair_flat[4]) : pf_launch<2560, false>(c, A, nblocks, 56 * 2560 + lj, c->attr_pair_flat[5]);
 }

@@ -124,7 +124,7 @@ int msevb_destroy(msevb_ctx* c) {
                         &c->d_xyz_store, &c->d_disp, &c->d_maxdisp, &c->d_Q, &c->d_theta, &c->d_green, &c->d_w, &c->d_dw, &c->d_uscale, &c->d_partials, &c->d_energies,
                         &c->d_Fdiag, &c->d_Foff};
   for (auto b : db) b->release();
-  c->d_pair_par.release(); c->d_moltypes.release(); c->d_ewald_tab.release(); c->d_nbr_count.release(); c->d_nbr2_count.release(); c->d_posq_prune.release(); c->d_flat.release(); c->d_cell_trips.release(); c->d_nbr_start.release();
+  c->d_pair_par.release(); c->d_moltypes.release(); c->d_ewald_tab.release(); c->d_ewald_tay.release(); c->d_nbr_count.release(); c->d_nbr_split.release(); c->d_nbr2_count.release(); c->d_posq_prune.release(); c->d_flat.release(); c->d_cell_trips.release(); c->d_nbr_start.release();
   c->d_w_s.release(); c->d_comm_h.release(); c->d_comm_e.release(); c->d_bad.release(); c->d_fsorted.release();
   if (c->h_ke) (void)hipHostFree(c->h_ke);
   c->d_sort_tmp.release(); c->d_posq.release(); c->d_grid.release(); c->d_fft_work.release(); c->d_fft_work_b.release();
@@ -364,7 +364,7 @@ int msevb_finalize(msevb_ctx* c) {
       c->d_mol_atoms.alloc((size_t)M * MAX_MOL_ATOMS) || c->d_mol_of.alloc(N) || c->d_xyz.alloc(3 * (size_t)N) || c->d_vel.alloc(3 * (size_t)N) ||
       c->d_force.alloc(3 * (size_t)N) || c->d_posq.alloc(N) || c->d_type_sorted.alloc(N) || c->d_mol_sorted.alloc(N) ||
       c->d_partials.alloc((size_t)N_SLOTS * MAX_BLOCKS) || c->d_energies.alloc(N_SLOTS) || c->d_pair_par.alloc(nt * nt) || c->d_moltypes.alloc(c->nmt) ||
-      c->d_ewald_tab.alloc(c->erfc_grid + 2) || c->d_B6.alloc(c->spline_grid) || c->d_B5.alloc(c->spline_grid) || c->d_tt.alloc(4 * TT_GRID) ||
+      c->d_ewald_tab.alloc(c->erfc_grid + 2) || c->d_ewald_tay.alloc(c->erfc_grid + 2) || c->d_B6.alloc(c->spline_grid) || c->d_B5.alloc(c->spline_grid) || c->d_tt.alloc(4 * TT_GRID) ||
       c->d_dtt.alloc(4 * TT_GRID) || c->d_CB.alloc(c->t_CB.size()))
     FAIL(MSEVB_ERR_HIP, "hipMalloc failed");
   CHK(upload_topology(c));
@@ -385,6 +385,9 @@ int msevb_finalize(msevb_ctx* c) {
   for (int i = 0; i <= c->erfc_grid; ++i) et[i] = make_double2(c->t_erfc[i], c->t_scale[i]);
   et[c->erfc_grid + 1] = et[c->erfc_grid];
   HIPCHK(hipMemcpy(c->d_ewald_tab.p, et.data(), et.size() * sizeof(double2), hipMemcpyHostToDevice));
+  for (int i = 0; i <= c->erfc_grid; ++i) et[i].y = c->t_ewE[i];
+  et[c->erfc_grid + 1] = et[c->erfc_grid];
+  HIPCHK(hipMemcpy(c->d_ewald_tay.p, et.data(), et.size() * sizeof(double2), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->d_B6.p, c->t_B6.data(), c->t_B6.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->d_B5.p, c->t_B5.data(), c->t_B5.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->d_tt.p, c->t_tt.data(), c->t_tt.size() * 8, hipMemcpyHostToDevice));
@@ -736,6 +739,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "evb_element_stores") { c->evb_element_stores = v != 0.0; return MSEVB_OK; }
   if (s == "shard_principal") { c->shard_principal = v != 0.0; return MSEVB_OK; }
   if (s == "pair_flat") { c->pair_flat_opt = (int)v; if (c->prune && c->finalized) (void)nb_prune_reset(c); return MSEVB_OK; }
+  if (s == "pair_split") { c->pair_split_opt = (int)v; return MSEVB_OK; }
   if (s == "prune_freeze") { c->prune_freeze = v != 0.0; return MSEVB_OK; }
   if (s == "pair_taylor") { c->pair_taylor = v != 0.0; return MSEVB_OK; }
   if (s == "pair_tiles") { c->pair_tiles_opt = (int)v; c->list_valid = false; return MSEVB_OK; }

@@ -231,7 +231,7 @@ struct msevb_ctx {
   bool pin_host_arrays = false;      // opt-in (option pin_host_arrays): only safe when the caller's arrays live as long as the context uses them
   struct PinnedUser { const void* p; size_t bytes; int hits; bool registered; } pinned_user[8] = {};
   // tables
-  std::vector<double> t_B6, t_B5, t_erfc, t_scale, t_tt, t_dtt, t_CB;
+  std::vector<double> t_B6, t_B5, t_erfc, t_scale, t_ewE, t_tt, t_dtt, t_CB;
   double erfc_dx = 0, ewald_self = 0, kk[3][3];
 
   // ---- EVB host tables
@@ -250,6 +250,7 @@ struct msevb_ctx {
   DBuf<PairParam> d_pair_par;
   DBuf<MolTypeDev> d_moltypes;
   DBuf<double2> d_ewald_tab;     // {erfc_table, ewaldscale_table} interleaved
+  DBuf<double2> d_ewald_tay;     // {erfc_table, E = (ewaldscale - erfc) / (alpha r)}: the one row per pair k_pair_flat fetches (pair_flat.hip)
   DBuf<double> d_B6, d_B5, d_tt, d_dtt, d_CB;
   // ---- device: per step
   DBuf<double> d_xyz, d_vel, d_force, d_force_recip;
@@ -258,7 +259,7 @@ struct msevb_ctx {
   // neighbour structure (sorted order)
   int ncell[3] = {1, 1, 1};
   DBuf<int> d_cell_of, d_perm, d_cell_keys_tmp, d_perm_tmp, d_cell_start, d_inv_perm, d_tile_max;
-  DBuf<unsigned> d_nbr_count, d_nbr_start;
+  DBuf<unsigned> d_nbr_count, d_nbr_start, d_nbr_split;      // split: entries of a half-list row that lie in the first 7 cells of the half neighbourhood (pair_flat.hip, two workgroups per cell)
   DBuf<int> d_nbr;
   DBuf<char> d_sort_tmp;
   size_t n_nbr = 0;
@@ -269,12 +270,15 @@ struct msevb_ctx {
   bool prune = true; double prune_delta = 0.6; int prune_lo = -1, prune_hi = -1;
   DBuf<int> d_nbr2, d_prune_mode; DBuf<unsigned> d_nbr2_count; DBuf<double4> d_posq_prune;
   // flat per-cell pair list of k_pair_flat (pair_flat.hip): the cell's pairs within rc + prune_delta, rows padded to 16 entries, one segment per wave of the
-  // cell's workgroup; cell c's list starts at cell_start[c] * (nbr_cap + 16) + 1408 c, d_cell_trips[16 c + w] = {offset, length in 64-entry trips} of wave w's segment
+  // cell's workgroup; cell c's list starts at cell_start[c] * (nbr_cap + 96) + 3584 c, d_cell_trips[32 c + 16 h + w] = {offset, length in 64-entry trips} of the segment of wave w of workgroup h
   DBuf<int> d_flat; DBuf<uint2> d_cell_trips;
   int pair_flat_opt = 1;         // option pair_flat: 0 = k_pair_half on per-atom rows (round 2's kernel; still what force fields with a live SAPT term run)
   bool prune_freeze = false;     // diagnostics (tools/time_stage.py): stage calls on unchanged positions keep the pair list of the first call instead of rewriting it every time
   bool pair_taylor = true;       // option pair_taylor (default on): one Ewald-table row per pair, the other one from the table's own derivatives (pair_flat.hip); 0 = both rows gathered
-  bool attr_pair_flat[8] = {false, false, false, false, false, false, false, false};
+  bool attr_pair_flat[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
+  int pair_split_opt = 0;        // option pair_split (measured slower, off): 1 = two workgroups per cell when the sub-tiles fit (2 x 12 waves per CU), 2 = the same with 2 x 8 waves and the pipelined loop, 0 = one workgroup per cell
+  bool pair_split_now = false;
+  int sub_tile_max = 0;          // largest sub-tile (own cell + 6 / + 7 forward cells) the last build saw
   int cell_atoms_max = 0;        // most atoms in ONE cell the last build saw (the pair kernels' row metadata holds PAIR_CELL_MAX)
   bool nbr_stats_copy_pending = false;      // in-kernel row statistics of a deferred rebuild still have to be downloaded
   bool nbr_check_pending = false;      // a deferred rebuild's row statistics have not been looked at yet
@@ -370,7 +374,7 @@ int nb_step_refresh(msevb_ctx* c, hipStream_t st = nullptr);      // refresh + d
 int nb_check_displacements(msevb_ctx* c, int initialize, int* flag);
 int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw);              // pair.hip
 bool pair_flat_usable(const msevb_ctx* c);                                // pair_flat.hip
-int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int nblocks, int slot_elec, int slot_vdw);
+int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int slot_elec, int slot_vdw, int* nblocks);
 int molecule_forces(msevb_ctx* c, int slot0, bool do_nb, bool do_bonded, hipStream_t st = nullptr);  // molecule.hip
 int pme_forces(msevb_ctx* c, int slot_recip, bool join_aux = false);
 int pme_front(msevb_ctx* c, int slot_recip, bool join_aux);

@@ -66,6 +66,9 @@ __global__ void k_tile_max(int ncell, int3 nc, const int* __restrict__ cell_star
     tot = 0;
     for (int s = 0; s < HALF_SLOTS; ++s) tot += cell_start[slots[s] + 1] - cell_start[slots[s]];
     atomicMax(out + 1, tot);
+    int lo7 = 0;
+    for (int s = 0; s < 7; ++s) lo7 += cell_start[slots[s] + 1] - cell_start[slots[s]];
+    atomicMax(out + 7, max(lo7, cell_start[cidx + 1] - cell_start[cidx] + tot - lo7));      // largest sub-tile of the split pair kernel
   }
 }
 
@@ -141,7 +144,7 @@ __device__ __forceinline__ bool nbr_decide_fp64(const double4& pr, double xi, do
 template <bool HALF>
 __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int* __restrict__ cell_start, const double4* __restrict__ posq, const int* __restrict__ mol_s,
                                                           const int* __restrict__ type_s, BoxDev box, double rv2, unsigned cap, int tile_cap,
-                                                          unsigned* __restrict__ count, unsigned* __restrict__ start, int* __restrict__ nbr, int* __restrict__ stats) {
+                                                          unsigned* __restrict__ count, unsigned* __restrict__ start, int* __restrict__ nbr, int* __restrict__ stats, unsigned* __restrict__ split) {
   extern __shared__ float4 t4[];                          // {x, y, z, molecule (int bits)}[tile_cap], then the entry words int[tile_cap]
   __shared__ int s_lo[27], s_off[28], s_ns;
   __shared__ double s_shift[27][3];
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
   }
   __syncthreads();
   const int ns = s_ns, ntile = s_off[ns];
+  const int off7 = HALF ? s_off[7] : 0;      // tile position of the eighth cell: rows are cut there for the two workgroups per cell of the split pair kernel (pair_flat.hip)
   const bool in_lds = ntile <= tile_cap;
   int* te = (int*)(t4 + tile_cap + 2);      // (+ 2 spare float4: the last pair of an odd-sized tile reads one entry past it)
   // cell centre: tile coordinates are within +-1.5 cells of it
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
     const double xi = pr.x - box.L[0] * floor(pr.x * box.invL[0]), yi = pr.y - box.L[1] * floor(pr.y * box.invL[1]), zi = pr.z - box.L[2] * floor(pr.z * box.invL[2]);
     const float fx = (float)(xi - ox), fy = (float)(yi - oy), fz = (float)(zi - oz);
     const int mi = mol_s[i];
-    unsigned total = 0;
+    unsigned total = 0, total_lo = 0;
     const unsigned base = (unsigned)i * cap;
     const int pfirst = HALF ? i - cell_start[cidx] + 1 : 0;      // half list: first tile position that counts as a partner of this atom
     if (in_lds) {
@@ -227,6 +231,7 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
         if (hA && slotA < cap) nbr[base + slotA] = en.x;
         if (hB && slotB < cap) nbr[base + slotB] = en.y;
         total += (unsigned)(__popcll(mA) + __popcll(mB));
+        if (HALF && p0 < off7) total_lo += (unsigned)(__popcll(__ballot(hA && pA < off7)) + __popcll(__ballot(hB && pB < off7)));
       }
     } else {           // neighbourhood larger than the tile: the same decisions from global memory
       for (int sl = 0; sl < ns; ++sl) {
@@ -243,10 +248,11 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
             if (slot < cap) nbr[base + slot] = (int)(idx | ((unsigned)type_s[j] << NBR_IDX_BITS));
           }
           total += (unsigned)__popcll(m);
+          if (HALF) total_lo += (unsigned)__popcll(__ballot(hit && o + p < off7));
         }
       }
     }
-    if (lane == 0) { count[i] = stats ? min(total, cap) : total; start[i] = base; }      // with in-kernel statistics the row is cut here (see k_count_stats)
+    if (lane == 0) { count[i] = stats ? min(total, cap) : total; start[i] = base; if (HALF && split) split[i] = min(total_lo, cap); }      // with in-kernel statistics the row is cut here (see k_count_stats)
     wmax = max(wmax, total); wsum += total;
   }
   if (stats) {      // {largest neighbourhood, -, longest row (uncut), -, sum of the row lengths (64 bit)}: one atomic each per workgroup
@@ -258,6 +264,7 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
       unsigned m = 0; unsigned long long sm = 0;
       for (int k = 0; k < wpb; ++k) { m = max(m, s_max[k]); sm += s_sum[k]; }
       atomicMax((unsigned*)stats + 2, m); atomicAdd((unsigned long long*)(stats + 4), sm); atomicMax(stats + (HALF ? 1 : 0), ntile); atomicMax(stats + 6, i1 - cell_start[cidx]);
+      if (HALF) atomicMax(stats + 7, max(s_off[7], s_off[1] + ntile - s_off[7]));
     }
   }
 }
@@ -462,7 +469,7 @@ int nb_build_begin(msevb_ctx* c) {
   const int ncell = nc.x * nc.y * nc.z;
   const BoxDev box = make_box(c);
   if (c->d_cell_of.alloc(N) || c->d_perm.alloc(N) || c->d_cell_keys_tmp.alloc(N) || c->d_perm_tmp.alloc(N) || c->d_cell_start.alloc(ncell + 1) ||
-      c->d_nbr_count.alloc(N + 1) || c->d_nbr_start.alloc(N + 1) || c->d_inv_perm.alloc(N))
+      c->d_nbr_count.alloc(N + 1) || c->d_nbr_start.alloc(N + 1) || c->d_nbr_split.alloc(N + 1) || c->d_inv_perm.alloc(N))
     FAIL(MSEVB_ERR_HIP, "hipMalloc failed (neighbour structure)");
   hipLaunchKernelGGL(k_cell_assign, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, c->d_xyz.p, box, nc, c->d_cell_keys_tmp.p, c->d_perm_tmp.p);
   int bits = 1;
@@ -526,7 +533,7 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
       if (seen > 0 && seen * 1.03 > NBR_TILE_CAP2) tile_cap = std::min(NBR_TILE_CAP, ((int)(seen * 1.08) + 63) & ~63);
       if (want_inline) { HIPCHK(hipMemsetAsync(d_stats, 0, 8 * sizeof(int), c->stream)); inline_stats = true; }
       hipLaunchKernelGGL(kern, dim3(ncell), dim3(1024), (size_t)tile_cap * NBR_TILE_BYTES + 64, c->stream, nc, c->d_cell_start.p, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, box, rv2,
-                         c->nbr_cap, tile_cap, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p, want_inline ? d_stats : (int*)nullptr);
+                         c->nbr_cap, tile_cap, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p, want_inline ? d_stats : (int*)nullptr, c->d_nbr_split.p);
     } else
       hipLaunchKernelGGL((k_neighbors<true>), grid, block, 0, c->stream, N, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, c->d_cell_of.p, c->d_cell_start.p, box, nc, rv2,
                          c->nbr_cap, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p);
@@ -541,7 +548,7 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
     c->nbr_cap = 0;      // k_count_stats must not cut the counted rows
     CHK(stats(true));
     if (cap_before == 0 || (unsigned)h_stats[2] > cap_before) set_cap((unsigned)h_stats[2]); else c->nbr_cap = cap_before;
-    c->tile_atoms_max = h_stats[0]; c->half_tile_max = h_stats[1]; c->cell_atoms_max = h_stats[6];
+    c->tile_atoms_max = h_stats[0]; c->half_tile_max = h_stats[1]; c->cell_atoms_max = h_stats[6]; c->sub_tile_max = h_stats[7];
     decide_format();
     CHK(fill());
     CHK(stats(false));
@@ -557,7 +564,7 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
       c->tile_atoms_max = h_stats[0];
       const bool tile_grew = c->pair_tiles && (h_stats[1] > c->half_tile_cap || h_stats[6] > PAIR_CELL_MAX);      // a half neighbourhood outgrew the pair kernel's LDS tile, or one cell its row metadata
       if (h_stats[1] > 0) c->half_tile_max = h_stats[1];
-      c->cell_atoms_max = h_stats[6];
+      c->cell_atoms_max = h_stats[6]; if (h_stats[7] > 0) c->sub_tile_max = h_stats[7];
       if ((unsigned)h_stats[2] > c->nbr_cap || tile_grew) {
         if ((unsigned)h_stats[2] > c->nbr_cap) set_cap((unsigned)h_stats[2]);
         decide_format(); CHK(fill()); CHK(stats(false));
@@ -589,6 +596,7 @@ int nb_check_overflow(msevb_ctx* c) {
   const bool tile_grew = c->pair_tiles && (h[1] > c->half_tile_cap || h[6] > PAIR_CELL_MAX);      // a half neighbourhood outgrew the LDS tile of the pair kernel, or one cell its row metadata (the kernel skipped that cell)
   if (h[1] > 0) c->half_tile_max = h[1];
   if (h[6] > 0) c->cell_atoms_max = h[6];
+  if (h[7] > 0) c->sub_tile_max = h[7];
   if ((unsigned)h[2] > c->nbr_cap || tile_grew) {
     if ((unsigned)h[2] > c->nbr_cap) c->nbr_cap = ((unsigned)((unsigned)h[2] * 1.15) + 64u + 63u) & ~63u;
     c->list_valid = false;

@@ -514,7 +514,7 @@ int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw) {
       c->fsorted_pending = false;
     }
     if (pr && pair_flat_usable(c)) {      // flat per-cell list (pair_flat.hip)
-      CHK(pair_flat_launch(c, c_lo, c_hi, nblocks, slot_elec, slot_vdw));
+      CHK(pair_flat_launch(c, c_lo, c_hi, slot_elec, slot_vdw, &nblocks));
     } else {
     // the SAPT instantiation needs > 128 VGPRs: 512 threads (8 waves) per cell instead of 1024
     void (*kern)(int, int, int3, int, const int*, const double4*, const int*, const unsigned*, const unsigned*, const int*, const PairParam*, int, const double2*, double, int,

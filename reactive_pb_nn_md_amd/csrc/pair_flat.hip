@@ -17,8 +17,9 @@
 //   * No validity masks: padding entries point at a tile slot 1e4 A away, r^2 is clamped to r_c^2 for the table look-up, and everything
 //     that accumulates sits behind ONE exec mask (r^2 < r_c^2).  r and 1/r come from v_rsq_f64 + one coupled Newton step.
 //   * The list is written by the kernel itself on the steps whose displacement test (k_top2_final, neighbor.hip) says the old one no
-//     longer covers r_c: phase P1 compacts the entries within r_c + delta of the builder's rows (wave per row) into scratch rows,
-//     phase P2 packs them into the flat format, then the force loop runs on the list just written.
+//     longer covers r_c: the builder's rows are cut into 64-entry pieces, every wave takes an equal share of the pieces, keeps the entries within
+//     r_c + delta (single-precision copy of the tile, batched loads) and writes them - converted, padded - straight into ITS segment of the cell's
+//     list, which it then reads back in its force loop; the launches that keep the list find their segment in d_cell_trips.
 // Software pipeline of the force loop as in k_pair_half: entries of trip t + 2 loading, table rows of trip t + 1 requested, trip t computing.
 #include <algorithm>
 #include "ctx.hpp"
@@ -35,7 +36,8 @@ namespace {
 // 240 instead of 194 us, the list no longer being served from the 256 MB Infinity Cache, where it survives from one step to the next)
 __device__ __forceinline__ unsigned pf_ld_entry(const int* p) { return (unsigned)*p; }
 
-constexpr int PF_LJ_BYTES = 8192;      // Lennard-Jones table at LDS address 0: 256 pair types x {C12, C6, 12 C12, 6 C6}
+// Lennard-Jones table at LDS address 0: 256 pair types x {C12, C6, 12 C12, 6 C6}; the split geometry (pitch 1344, two workgroups per CU) has room for 144
+constexpr int pf_lj_bytes(int P) { return P == 1344 ? 4608 : 8192; }
 constexpr int PF_J_BITS = 12, PF_A_BITS = 9, PF_A_SHIFT = PF_J_BITS, PF_T_SHIFT = PF_J_BITS + PF_A_BITS;
 static_assert((1 << PF_A_BITS) == PAIR_CELL_MAX, "row field of a flat-list entry");
 
@@ -65,12 +67,12 @@ __device__ __forceinline__ void pf_lds_add(unsigned addr, double v) {      // ds
 // address of an atom's fx in the force tile (fy, fz follow at the pitch: instruction offsets) from 8 x its tile position; opaque to the
 // compiler, which otherwise folds the three array starts into three separate 32-bit constants and adds each in an instruction of its own
 template <int P>
-__device__ __forceinline__ unsigned pf_force_addr(unsigned a8) { unsigned f = a8 + (PF_LJ_BYTES + 32u * P); asm("" : "+v"(f)); return f; }
+__device__ __forceinline__ unsigned pf_force_addr(unsigned a8) { unsigned f = a8 + (pf_lj_bytes(P) + 32u * P); asm("" : "+v"(f)); return f; }
 
 struct PairFlatArgs {
   int c_lo, c_hi; int3 nc; int tile_cap;
   const int* cell_start; const double4* posq; const int* type_s;
-  const unsigned* nbr_start; const unsigned* nbr_count; const int* nbr;      // the builder's rows (tile-local half list, neighbor.hip)
+  const unsigned* nbr_count; const unsigned* nbr_split; const int* nbr;      // the builder's rows (tile-local half list, neighbor.hip)
   const PairParam* pairpar; int nt;
   const double2* etab; double inv_dx, dx, delta /* alpha dx */;
   BoxDev box; double rc2;
@@ -90,8 +92,9 @@ struct PfTrip {      // what stage A leaves for stage B (per lane)
 //   pf_stage_a_math: r^2, r and 1/r, the Ewald-table rows requested.
 // The table is the reference's: row(r) = ceil(r / dx), value = c1 T[row] + c2 T[row + 1] with c2 = (r/dx + 1) - row (src/pair_int_real_space.f90:751-756;
 // T[k] tabulates r = k dx, so the interpolant is taken one interval up - reproduced as it is).
-// TAYLOR: only the upper row {T_B, S_B} is fetched; the lower one follows from it to 1e-16 because both tables are built from erfc and its
-// own derivative: S - T = x (2/sqrt(pi)) exp(-x^2) conv (tables.cpp), i.e. -x dT/dx, and the higher derivatives of T and S are that times polynomials in x.
+// TAYLOR: ONE row {T_B, E_B} of a second table is fetched instead of two rows {T, S}: both reference tables are built from erfc and its own derivative,
+// S = T + x E with E = (2/sqrt(pi)) exp(-x^2) conv = -dT/dx (tables.cpp), and the higher derivatives of T and S are E times polynomials in x, so the
+// lower row follows from the upper one to 1e-16 (third-order expansion over one table interval, alpha dx = 2.7e-5).
 struct PfRaw { double xj, yj, zj, qj, xi, yi, zi, qi; unsigned ja, aa, pa; };
 
 template <int P>
@@ -99,7 +102,7 @@ __device__ __forceinline__ void pf_stage_a_read(unsigned e, PfRaw& w) {
   w.ja = (e & ((1u << PF_J_BITS) - 1u)) << 3;
   w.aa = (e >> (PF_A_SHIFT - 3)) & (((1u << PF_A_BITS) - 1u) << 3);
   w.pa = (e >> (PF_T_SHIFT - 5)) & (0x3ffu << 5);
-  constexpr unsigned X = PF_LJ_BYTES;
+  constexpr unsigned X = pf_lj_bytes(P);
 #if PF_EXP & 8
   w.xj = (double)(w.ja >> 3) * 0.01; w.yj = 3.0; w.zj = 4.0; w.qj = 0.4;
 #else
@@ -135,9 +138,9 @@ __device__ __forceinline__ void pf_stage_a_math(const PfRaw& w, double rc2, doub
 #endif
 }
 
-__device__ __forceinline__ int pf_tile_to_sorted(int p, const int* s_lo, const int* s_off) {
+__device__ __forceinline__ int pf_tile_to_sorted(int p, const int* s_lo, const int* s_off, int ns) {
   int s = 0;
-  while (s + 1 < HALF_SLOTS && p >= s_off[s + 1]) ++s;
+  while (s + 1 < ns && p >= s_off[s + 1]) ++s;
   return s_lo[s] + (p - s_off[s]);
 }
 
@@ -149,7 +152,8 @@ __device__ __forceinline__ double pf_exact_r2(const double4& pi, const double4& 
   return (dx * dx + dy * dy) + dz * dz;
 }
 
-struct PfSmall { double red[2][16]; int lo[HALF_SLOTS], off[HALF_SLOTS + 1]; unsigned off2[PAIR_CELL_MAX + 1], cnt[PAIR_CELL_MAX]; unsigned char typ[PAIR_CELL_MAX]; };
+struct PfSmall { double red[2][16]; int lo[HALF_SLOTS], off[HALF_SLOTS + 1], full, off7; unsigned tt0, tt; unsigned char typ[PAIR_CELL_MAX]; };
+struct PfRows { unsigned off2[PAIR_CELL_MAX], cnt[PAIR_CELL_MAX], beg[PAIR_CELL_MAX]; };      // per-row scratch of the pruning pass: in the third force array, behind the single-precision copy of the tile
 
 struct PfAcc { double fx, fy, fz, e_el, e_vdw; unsigned a_prev;
 };
@@ -164,7 +168,7 @@ __device__ __forceinline__ void pf_flush_row(PfAcc& acc, int lane) {      // eve
 // Stage B: interaction arithmetic of a trip whose table rows were requested a trip ago; LDS force adds.
 template <int P, bool TAYLOR>
 __device__ __forceinline__ void pf_stage_b(const PfTrip& s, int lane, double rc2, double rc2_lo, double rc2_hi, double dxg, double delta, const BoxDev& box,
-                                           const double4* __restrict__ posq, int cs, const int* s_lo, const int* s_off, PfAcc& acc) {
+                                           const double4* __restrict__ posq, int cs, const int* s_lo, const int* s_off, int ns, PfAcc& acc) {
 #pragma clang fp contract(fast)
   if (__ballot(s.aa != acc.a_prev)) {      // (wave-uniform test) some DPP row has moved on to its next atom: its owner's force joins the tile
     if (s.aa != acc.a_prev) { pf_flush_row<P>(acc, lane); acc.a_prev = s.aa; }
@@ -176,16 +180,12 @@ __device__ __forceinline__ void pf_stage_b(const PfTrip& s, int lane, double rc2
 #endif
   double ev, sv;      // erfc and force-scale interpolants
   if (TAYLOR) {
-    const double D = s.t1.y - s.t1.x;                 // x_B E_B, E = (2/sqrt(pi)) exp(-x^2) conv = -T'
-    const double sd = s.c1 * dxg;                      // r_B - (r + dx)
-    const double q = __builtin_fma(s.c1, dxg, dxg) * s.inv_r;      // (r_B - r) / r
-    const double w = __builtin_fma(q, __builtin_fma(q, __builtin_fma(q, -1.0, 1.0), -1.0), 1.0);      // r / r_B = 1 - q + q^2 - q^3
-    const double gE = D * (sd * s.inv_r) * w;         // alpha (r_B - r - dx) E_B
+    const double gE = (s.c1 * delta) * s.t1.y;        // alpha (r_B - r - dx) E_B: the fetched row is {T_B, E_B}, E = (2/sqrt(pi)) exp(-x^2) conv = -dT/dx (d_ewald_tay)
     const double x = s.xb, d2 = delta * delta;
     const double bt = __builtin_fma(x, __builtin_fma(x, d2 * (2.0 / 3.0), delta), 1.0 - d2 * (1.0 / 3.0));
     const double bs = __builtin_fma(x, __builtin_fma(x, __builtin_fma(x, __builtin_fma(x, d2 * (4.0 / 3.0), 2.0 * delta), 2.0 - d2 * (10.0 / 3.0)), -2.0 * delta), d2 * (2.0 / 3.0));
     ev = __builtin_fma(gE, bt, s.t1.x);
-    sv = __builtin_fma(gE, bs, s.t1.y);
+    sv = __builtin_fma(gE, bs, __builtin_fma(x, s.t1.y, s.t1.x));      // S_B = T_B + x_B E_B
   } else {
     const double c2 = 1.0 - s.c1;
     ev = s.c1 * s.t0.x + c2 * s.t1.x;
@@ -198,7 +198,7 @@ __device__ __forceinline__ void pf_stage_b(const PfTrip& s, int lane, double rc2
   bool in = s.r2 < rc2_lo;
   const unsigned long long m_in = __ballot(in), m_near = __ballot(s.r2 < rc2_hi);
   if (m_in != m_near) {      // rare: on the cutoff to within rounding - the reference's arithmetic on the raw coordinates decides
-    if (((m_near & ~m_in) >> lane) & 1ull) in = pf_exact_r2(posq[cs + (int)(s.aa >> 3)], posq[pf_tile_to_sorted((int)(s.ja >> 3), s_lo, s_off)], box) < rc2;
+    if (((m_near & ~m_in) >> lane) & 1ull) in = pf_exact_r2(posq[cs + (int)(s.aa >> 3)], posq[pf_tile_to_sorted((int)(s.ja >> 3), s_lo, s_off, ns)], box) < rc2;
   }
   if (in) {
     const double gx = fs * s.dx, gy = fs * s.dy, gz = fs * s.dz;
@@ -213,14 +213,22 @@ __device__ __forceinline__ void pf_stage_b(const PfTrip& s, int lane, double rc2
   }
 }
 
-// LDS (all dynamic, from address 0): [0, 8 K) Lennard-Jones table; then positions x, y, z, q and the force tile fx, fy, fz (P doubles each; slot ntile = the
-// dummy partner); then the small arrays of PfSmall
-template <int P, bool TAYLOR>
-__global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
+// LDS (all dynamic, from address 0): Lennard-Jones table (8 KB; 4 KB in the split geometry); then positions x, y, z, q and the force tile fx, fy, fz (P doubles
+// each; slot ntile = the dummy partner); then the small arrays of PfSmall.
+// SPLIT: TWO workgroups per cell - workgroup h = 0 works on the pairs whose partner lies in the cell itself or in the first 6 forward cells, h = 1 on the
+// last 7 forward cells (the builder's rows are in tile order and carry the position of the cut, d_nbr_split) - so that a sub-tile (the cell + 6 or 7 cells,
+// ~1 100 atoms) needs < 80 KB and two workgroups share a CU: 24 waves per CU instead of 16, and one workgroup stages or flushes while the other computes.
+template <int P, bool TAYLOR, bool SPLIT, int THREADS, int MINW, bool PIPE>
+__global__ __launch_bounds__(THREADS, MINW) void k_pair_flat(const PairFlatArgs A) {
+  constexpr int NS = SPLIT ? 8 : HALF_SLOTS;      // cells in the (sub-)tile
+  constexpr int LJB = pf_lj_bytes(P);
   extern __shared__ double4 pf_lds4[];
   char* lds = (char*)pf_lds4;
-  PfSmall& sm = *(PfSmall*)(lds + PF_LJ_BYTES + 56 * P);
-  int* s_lo = sm.lo; int* s_off = sm.off; unsigned* s_off2 = sm.off2; unsigned* s_cnt = sm.cnt; unsigned char* s_typ = sm.typ;
+  PfSmall& sm = *(PfSmall*)(lds + LJB + 56 * P);
+  int* s_lo = sm.lo; int* s_off = sm.off; unsigned char* s_typ = sm.typ;
+  static_assert(sizeof(PfRows) <= 8 * P, "pruning scratch fits the third force array");
+  PfRows& pr = *(PfRows*)(lds + LJB + 32 * P + 16 * P);
+  unsigned* s_off2 = pr.off2; unsigned* s_cnt = pr.cnt; unsigned* s_beg = pr.beg;
   if ((unsigned)(size_t)(__attribute__((address_space(3))) char*)pf_lds4 != 0u) __builtin_trap();      // (see pf_ld)
 #if PF_EXP & 256
   const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
@@ -231,31 +239,37 @@ __global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
     for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x) A.posq_prune[k] = A.posq[k];
     if (blockIdx.x == 0 && threadIdx.x == 0) A.prune_state[2] = 1;      // seen by the NEXT step's k_top2_final: a list exists for the current rows
   }
-  const int cidx = A.c_lo + xcd_block(blockIdx.x, gridDim.x);      // one XCD works on one contiguous eighth of the cells (a slab)
+  const int lb = xcd_block(blockIdx.x, gridDim.x);      // one XCD works on one contiguous eighth of the cells (a slab)
+  const int cidx = A.c_lo + (SPLIT ? lb >> 1 : lb), h = SPLIT ? (lb & 1) : 0;
   if (cidx >= A.c_hi) { if (threadIdx.x == 0) { A.part_el[blockIdx.x] = 0.0; A.part_vdw[blockIdx.x] = 0.0; } return; }
-  if (threadIdx.x < 64) {      // the 14 cells of the half neighbourhood: first atom and tile offset of each (prefix sum across the lanes)
+  if (threadIdx.x < 64) {      // the cells of the (sub-)tile: first atom and tile offset of each (prefix sums across the lanes)
     int slots[HALF_SLOTS];
     cell_half_neighbourhood(cidx, A.nc.x, A.nc.y, A.nc.z, slots);
-    const int sl = min((int)threadIdx.x, HALF_SLOTS - 1);
-    const int lo = A.cell_start[slots[sl]], n = threadIdx.x < HALF_SLOTS ? A.cell_start[slots[sl] + 1] - lo : 0;
-    int inc = n;
+    const int tid = threadIdx.x, sl = min(tid, HALF_SLOTS - 1);
+    const int lo = A.cell_start[slots[sl]], n = tid < HALF_SLOTS ? A.cell_start[slots[sl] + 1] - lo : 0;
+    const bool mine = tid < HALF_SLOTS && (!SPLIT || (h == 0 ? tid <= 6 : (tid == 0 || tid >= 7)));
+    const int nm = mine ? n : 0;
+    int incf = n, incm = nm;
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) { const int t = __shfl_up(inc, o, 64); if ((int)threadIdx.x >= o) inc += t; }
-    if (threadIdx.x < HALF_SLOTS) { s_lo[threadIdx.x] = lo; s_off[threadIdx.x] = inc - n; }
-    if (threadIdx.x == HALF_SLOTS - 1) s_off[HALF_SLOTS] = inc;
+    for (int o = 1; o < 16; o <<= 1) { const int t = __shfl_up(incf, o, 64), u = __shfl_up(incm, o, 64); if (tid >= o) { incf += t; incm += u; } }
+    const unsigned long long mm = __ballot(mine);
+    const int k = __popcll(mm & ((1ull << tid) - 1ull));      // position of this cell in the (sub-)tile
+    if (mine) { s_lo[k] = lo; s_off[k] = incm - nm; }
+    if (tid == HALF_SLOTS - 1) { sm.full = incf; s_off[NS] = incm; if (SPLIT && h == 0) { s_lo[NS - 1] = 0; s_off[NS - 1] = incm; } }
+    if (tid == 6) sm.off7 = incf;
   }
   __syncthreads();
-  const int ntile = s_off[HALF_SLOTS], na = s_off[1], cs = s_lo[0];
-  if (ntile > A.tile_cap || ntile >= P || na > PAIR_CELL_MAX) {      // larger than the tile this list was built for: the host sees it in the build statistics and repeats the call
+  const int ntile = s_off[NS], na = s_off[1], cs = s_lo[0];
+  if (sm.full > A.tile_cap || ntile >= P || na > PAIR_CELL_MAX) {      // larger than the tile this list was built for: the host sees it in the build statistics and repeats the call
     if (threadIdx.x == 0) { A.part_el[blockIdx.x] = 0.0; A.part_vdw[blockIdx.x] = 0.0; }
     return;
   }
-  double* tp = (double*)(lds + PF_LJ_BYTES); double* tf = tp + 4 * P;
-  // tile position -> sorted atom: p + (lo[s] - off[s]) for the slot s that holds p, as a sum of 13 selects on scalar operands (a search through the LDS
-  // copies is a chain of 14 dependent reads per atom)
-  int t2s_off[HALF_SLOTS], t2s_add[HALF_SLOTS];
+  double* tp = (double*)(lds + LJB); double* tf = tp + 4 * P;
+  // tile position -> sorted atom: p + (lo[s] - off[s]) for the cell s that holds p, as a sum of selects on scalar operands (a search through the LDS
+  // copies is a chain of dependent reads per atom)
+  int t2s_off[NS], t2s_add[NS];
 #pragma unroll
-  for (int k = 0; k < HALF_SLOTS; ++k) {
+  for (int k = 0; k < NS; ++k) {
     t2s_off[k] = __builtin_amdgcn_readfirstlane(s_off[k]);
     const int d = __builtin_amdgcn_readfirstlane(s_lo[k] - s_off[k]);
     t2s_add[k] = k ? d - __builtin_amdgcn_readfirstlane(s_lo[k - 1] - s_off[k - 1]) : d;
@@ -263,7 +277,7 @@ __global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
   auto tile_to_sorted = [&](int p) -> int {
     int j = p + t2s_add[0];
 #pragma unroll
-    for (int k = 1; k < HALF_SLOTS; ++k) j += p >= t2s_off[k] ? t2s_add[k] : 0;
+    for (int k = 1; k < NS; ++k) j += p >= t2s_off[k] ? t2s_add[k] : 0;
     return j;
   };
   {      // stage the tile: coordinates relative to the cell centre, at the periodic image nearest to it (>= 4 cells per axis: every tile atom is within 2 cells of it)
@@ -290,30 +304,47 @@ __global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
     }
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int wpb = THREADS / 64;
 #if PF_EXP & 256
   const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
-  // The cell's list is 16 SEGMENTS, one per wave: a wave writes its segment (when the list is rewritten) and reads it back in its force loop, here
-  // and in the launches that keep the list - no scratch copy, no workgroup barrier between the two.  Room: the cell's rows at (stride + 16) + 1408.
-  int* cell_flat = A.flat + ((size_t)cs * (A.stride + 16u) + 1408 * (size_t)cidx);
+  // The cell's list is one SEGMENT per wave (of either workgroup): a wave writes its segment (when the list is rewritten) and reads it back in its force loop,
+  // here and in the launches that keep the list - no scratch copy.  Room: the cell's rows at (stride + 96) + 3584.
+  int* cell_flat = A.flat + ((size_t)cs * (A.stride + 96u) + 3584 * (size_t)cidx);
+  uint2* meta = A.cell_trips + ((size_t)cidx * 2 + h) * 16 + wave;
   unsigned seg_off, seg_trips;
   if (mode != 2) {
-    // ---- the builder's rows cut into 64-entry pieces ("full trips"), dealt to the waves in equal numbers; exclusive prefix of the pieces per row
+    // ---- the builder's rows (this workgroup's part of each) cut into 64-entry pieces, dealt to the waves in equal numbers; exclusive prefix of the pieces per row
     if (wave == 0) {      // 8 rows per lane, shuffles across the wave
-      unsigned loc[8], sum = 0;
+      unsigned loc[8], sum = 0, sum0 = 0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { const int a = 8 * lane + q; const unsigned n = a < na ? A.nbr_count[cs + a] : 0u; if (a < na) s_cnt[a] = n; loc[q] = (n + 63u) >> 6; sum += loc[q]; }
+      for (int q = 0; q < 8; ++q) {
+        const int a = 8 * lane + q;
+        unsigned n = 0, b = 0;
+        if (a < na) {
+          const unsigned nall = A.nbr_count[cs + a], sp = SPLIT ? min(A.nbr_split[cs + a], nall) : 0u;
+          n = SPLIT ? (h ? nall - sp : sp) : nall; b = (SPLIT && h) ? sp : 0u;
+          s_cnt[a] = n; s_beg[a] = b;
+          if (SPLIT && h) sum0 += (sp + 63u) >> 6;      // (pieces of the other workgroup: its segments come first in the cell's list)
+        }
+        loc[q] = (n + 63u) >> 6; sum += loc[q];
+      }
       unsigned inc = sum;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) { const unsigned t = (unsigned)__shfl_up((int)inc, o, 64); if (lane >= o) inc += t; }
       unsigned run = inc - sum;
 #pragma unroll
       for (int q = 0; q < 8; ++q) { const int a = 8 * lane + q; if (a < na) s_off2[a] = run; run += loc[q]; }
-      if (lane == 63) s_off2[PAIR_CELL_MAX] = inc;
+      if (lane == 63) sm.tt = inc;
+      if (SPLIT && h) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum0 += (unsigned)__shfl_xor((int)sum0, o, 64);
+        if (lane == 0) sm.tt0 = sum0;
+      }
     }
     __syncthreads();
-    const unsigned TT = s_off2[PAIR_CELL_MAX];
+    const unsigned TT = sm.tt;
     unsigned ft = (unsigned)(((unsigned long long)TT * (unsigned)wave) / (unsigned)wpb);
     const unsigned ft1 = (unsigned)(((unsigned long long)TT * (unsigned)(wave + 1)) / (unsigned)wpb);
     int a = 0;
@@ -322,8 +353,10 @@ __global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
       while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off2[mid] <= ft) lo = mid; else hi = mid; }
       a = lo;
     }
-    // Upper bound of what the waves before this one write: their pieces (64 each), 15 padding entries per row part (a rows + one split per wave), 63 per segment end
-    seg_off = 64u * (ft + (unsigned)wave + (((unsigned)a + (unsigned)wave + 3u) >> 2));
+    // Upper bound of what the waves before this one write: their pieces (64 each), 15 padding entries per row part (a rows + one split per wave), 63 per
+    // segment end; in front of workgroup 1's segments, all of workgroup 0's
+    const unsigned base_h = (SPLIT && h) ? 64u * (sm.tt0 + (unsigned)wpb + (((unsigned)na + (unsigned)wpb + 3u) >> 2)) : 0u;
+    seg_off = base_h + 64u * (ft + (unsigned)wave + (((unsigned)a + (unsigned)wave + 3u) >> 2));
     int* out = cell_flat + seg_off;
     // The wave's pieces as a stream {row, offset in the row}; PF_BATCH pieces are loaded together and the next batch is requested before the current one is
     // looked at (the rows come from HBM: 2 x 4 pieces of 256 B per wave in flight, 32 KB per CU; twice as many measured the same).
@@ -333,12 +366,13 @@ __global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
     struct Piece { int a; unsigned k0, n; };      // (wave-uniform)
     int pa = a; unsigned pk = ft < ft1 ? (ft - s_off2[a]) << 6 : 0u, pn = ft < ft1 ? s_cnt[a] : 0u, left = ft1 - ft;
     const int* rows = A.nbr + (size_t)cs * A.stride;      // (row i of the builder starts at i x stride)
+    const unsigned jshift = (SPLIT && h) ? (unsigned)(sm.off7 - na) : 0u;      // tile position -> sub-tile position for the partners of workgroup 1
     auto next_piece = [&](Piece& pc) -> unsigned {      // returns the piece's entry of this lane (0xffffffff: none)
       if (left == 0) { pc.a = -1; pc.k0 = 0; pc.n = 0; return 0xffffffffu; }
       while (pk >= pn) { ++pa; pk = 0; pn = s_cnt[pa]; }      // (rows without entries hold no piece)
       pc.a = pa; pc.k0 = pk; pc.n = pn;
       const unsigned k = pk + lane;
-      const unsigned e = k < pn ? (unsigned)rows[(size_t)pa * A.stride + k] : 0xffffffffu;
+      const unsigned e = k < pn ? (unsigned)rows[(size_t)pa * A.stride + s_beg[pa] + k] : 0xffffffffu;
       pk += 64; --left;
       return e;
     };
@@ -356,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
         const int ra = pc[q].a;
         const unsigned e = ec[q];
         const bool v = e != 0xffffffffu;
-        const unsigned j = v ? (e & NBR_IDX_MASK) : (unsigned)ntile;
+        const unsigned j = v ? (e & NBR_IDX_MASK) - jshift : (unsigned)ntile;
         const float4 fi = tq[ra], fj = tq[j];      // tile coordinates are within 2.5 cells of the cell centre: r^2 is good to 2e-4 A^2 in single precision,
         const float ddx = fi.x - fj.x, ddy = fi.y - fj.y, ddz = fi.z - fj.z;      // and an entry too many in the list costs nothing but its lane
         const bool keep = v && (ddx * ddx + ddy * ddy + ddz * ddz) < rp2f;
@@ -376,12 +410,12 @@ __global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
     }
     seg_trips = (o + 63u) >> 6;
     if (o + lane < (seg_trips << 6)) out[o + lane] = (int)(((unsigned)a_last << PF_A_SHIFT) + (unsigned)ntile);
-    if (lane == 0) A.cell_trips[(size_t)cidx * 16 + wave] = make_uint2(seg_off, seg_trips);
+    if (lane == 0) *meta = make_uint2(seg_off, seg_trips);
     __syncthreads();      // (the stores of the wave's segment have left it, which is all its own reads of the segment need: same CU, write-through L1)
     for (int p = threadIdx.x; p <= ntile; p += blockDim.x) { tf[p] = 0.0; tf[P + p] = 0.0; tf[2 * P + p] = 0.0; }      // the force tile held the single-precision copy
     __syncthreads();
   } else {
-    const uint2 sg = A.cell_trips[(size_t)cidx * 16 + wave];
+    const uint2 sg = *meta;
     seg_off = sg.x; seg_trips = sg.y;
   }
   // ---- force loop over the wave's segment
@@ -391,32 +425,47 @@ __global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
   PfAcc acc;
   acc.fx = 0.0; acc.fy = 0.0; acc.fz = 0.0; acc.e_el = 0.0; acc.e_vdw = 0.0; acc.a_prev = 0u;
   if (t0 < t1 && !(PF_EXP & 32)) {
-    // Two trips in flight per wave: geometry of trip t + 1 (its table rows requested) in front of the arithmetic of trip t, whose rows were requested a
-    // trip ago; the entries of trip t + 2 loading.  (A third stage - tile reads of trip t + 2 issued before the arithmetic of trip t - measured the same
-    // 140 us and costs 20 registers: the loop is bound by the throughput of the LDS, the vector-memory address path and the fp64 pipe together, not by a wait.)
     // Entry loads are UNCONDITIONAL (behind the wave's last trip they read the next wave's entries or the list's padding - the allocation has trips to
     // spare - and a select discards them): a load inside a branch makes the compiler wait for ALL outstanding loads at the join, table rows included.
     const int* src = cell_flat + seg_off + lane;
     const unsigned e_none = (unsigned)ntile;
-    PfRaw w; PfTrip sa, sb;
-    unsigned ea = pf_ld_entry(src + 64), eb;
-    pf_stage_a_read<P>(pf_ld_entry(src), w);
-    ea = t0 + 1 < t1 ? ea : e_none;
-    pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sa);
-    acc.a_prev = sa.aa;
-    for (unsigned t = t0; t < t1; t += 2) {      // two trips per turn: the states swap roles instead of being copied
-      eb = pf_ld_entry(src + 128);                                                                                  // entries of trip t + 2
-      pf_stage_a_read<P>(ea, w);
-      pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sb);                                               // trip t + 1: geometry, table rows requested (behind the last trip: padding)
-      pf_stage_b<P, TAYLOR>(sa, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, acc);      // trip t: arithmetic
-      eb = t + 2 < t1 ? eb : e_none;
-      if (t + 1 >= t1) break;
-      ea = pf_ld_entry(src + 192);
-      pf_stage_a_read<P>(eb, w);
+    PfRaw w; PfTrip sa;
+    if (PIPE) {
+      // Two trips in flight per wave: geometry of trip t + 1 (its table rows requested) in front of the arithmetic of trip t, whose rows were requested a
+      // trip ago; the entries of trip t + 2 loading.  (A third stage - tile reads of trip t + 2 issued before the arithmetic of trip t - measured the same
+      // and costs 20 registers: the loop is bound by the throughput of the LDS, the vector-memory address path and the fp64 pipe together, not by a wait.)
+      PfTrip sb;
+      unsigned ea = pf_ld_entry(src + 64), eb;
+      pf_stage_a_read<P>(pf_ld_entry(src), w);
+      ea = t0 + 1 < t1 ? ea : e_none;
       pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sa);
-      pf_stage_b<P, TAYLOR>(sb, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, acc);
-      ea = t + 3 < t1 ? ea : e_none;
-      src += 128;
+      acc.a_prev = sa.aa;
+      for (unsigned t = t0; t < t1; t += 2) {      // two trips per turn: the states swap roles instead of being copied
+        eb = pf_ld_entry(src + 128);                                                                                  // entries of trip t + 2
+        pf_stage_a_read<P>(ea, w);
+        pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sb);                                               // trip t + 1: geometry, table rows requested (behind the last trip: padding)
+        pf_stage_b<P, TAYLOR>(sa, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, NS, acc);      // trip t: arithmetic
+        eb = t + 2 < t1 ? eb : e_none;
+        if (t + 1 >= t1) break;
+        ea = pf_ld_entry(src + 192);
+        pf_stage_a_read<P>(eb, w);
+        pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sa);
+        pf_stage_b<P, TAYLOR>(sb, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, NS, acc);
+        ea = t + 3 < t1 ? ea : e_none;
+        src += 128;
+      }
+    } else {
+      // One trip at a time (80 registers: six waves per SIMD): the table rows are requested and waited for inside the trip, the other waves cover the wait
+      unsigned e = pf_ld_entry(src);
+      bool first = true;
+      for (unsigned t = t0; t < t1; ++t) {
+        const unsigned en = pf_ld_entry(src + 64);      // entries of the next trip
+        pf_stage_a_read<P>(e, w);
+        pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sa);
+        if (first) { acc.a_prev = sa.aa; first = false; }
+        pf_stage_b<P, TAYLOR>(sa, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, NS, acc);
+        e = en; src += 64;
+      }
     }
     pf_flush_row<P>(acc, lane);
   }
@@ -446,19 +495,20 @@ __global__ __launch_bounds__(1024) void k_pair_flat(const PairFlatArgs A) {
   }
 #if PF_EXP & 256
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0 && (wave == 0 || wave == 15) && (blockIdx.x % 97) == 5 && mode == 2)
-    printf("pf diag block %d wave %d trips %u..%u: staging %llu clk, loop %llu, wait for the other waves %llu, flush %llu\n", blockIdx.x, wave, t0, t1, ts1 - ts0, ts2 - ts1, ts3 - ts2, __builtin_amdgcn_s_memtime() - ts3);
+  if (lane == 0 && (wave == 0 || wave == wpb - 1) && (blockIdx.x % 97) == 5 && mode == 2)
+    printf("pf diag block %d wave %d trips %u: staging %llu clk, loop %llu, wait for the other waves %llu, flush %llu\n", blockIdx.x, wave, t1, ts1 - ts0, ts2 - ts1, ts3 - ts2, __builtin_amdgcn_s_memtime() - ts3);
 #endif
 }
 
-template <int P, bool TAYLOR>
-int pf_launch(msevb_ctx* c, const PairFlatArgs& A, int nblocks, size_t lds, bool& attr_done) {
-  auto kern = k_pair_flat<P, TAYLOR>;
+template <int P, bool TAYLOR, bool SPLIT, int THREADS, int MINW, bool PIPE>
+int pf_launch(msevb_ctx* c, const PairFlatArgs& A, int nblocks, bool& attr_done) {
+  auto kern = k_pair_flat<P, TAYLOR, SPLIT, THREADS, MINW, PIPE>;
+  constexpr int lds = pf_lj_bytes(P) + 56 * P + (int)sizeof(PfSmall);
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LJ_BYTES + 56 * P + (int)sizeof(PfSmall)));
+    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(1024), lds, c->stream, A);
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(THREADS), lds, c->stream, A);
   if (c->prune_freeze) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->d_prune_mode.p, 2, 1, c->stream));      // diagnostics: the next stage call reads this list
   return MSEVB_OK;
 }
@@ -469,20 +519,30 @@ int pf_launch(msevb_ctx* c, const PairFlatArgs& A, int nblocks, size_t lds, bool
 bool pair_flat_usable(const msevb_ctx* c) {
   return c->pair_flat_opt != 0 && c->pair_tiles && !c->has_sapt && c->nt <= 16 && c->half_tile_cap + 1 <= 2560 && c->prune && c->rc + c->prune_delta < c->rv;
 }
+// two workgroups per cell: the sub-tiles the last build saw (+ 3 %) fit the 1344-atom pitch, and the Lennard-Jones table 4.5 KB
+bool pair_flat_split(const msevb_ctx* c) {
+  return c->pair_split_opt != 0 && c->nt <= 12 && c->sub_tile_max > 0 && (int)(c->sub_tile_max * 1.03) + 1 < 1344;
+}
 
 // called by pair_forces (pair.hip) in place of the k_pair_half launch; the caller has sized the pruning state and the sorted-order accumulator
-int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int nblocks, int slot_elec, int slot_vdw) {
+int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int slot_elec, int slot_vdw, int* nblocks_out) {
   const int N = c->N, ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
-  const size_t need = (size_t)N * (c->nbr_cap + 16) + 1408 * (size_t)ncell + 6 * 64;      // (+ the trips the force loop's unconditional entry loads may reach behind the last cell's list)
-  if (c->d_flat.n < need || c->d_cell_trips.n < 16 * (size_t)ncell) {      // (only behind a rebuild that enlarged the rows: the pruning state has been reset with it)
-    if (c->d_flat.alloc(need) || c->d_cell_trips.alloc(16 * (size_t)ncell)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (flat pair list)");
+  const size_t need = (size_t)N * (c->nbr_cap + 96) + 3584 * (size_t)ncell + 6 * 64;      // (+ the trips the force loop's unconditional entry loads may reach behind the last cell's list)
+  if (c->d_flat.n < need || c->d_cell_trips.n < 32 * (size_t)ncell) {      // (only behind a rebuild that enlarged the rows: the pruning state has been reset with it)
+    if (c->d_flat.alloc(need) || c->d_cell_trips.alloc(32 * (size_t)ncell)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (flat pair list)");
   }
+  const bool split = pair_flat_split(c);
+  { static const bool dbg = getenv("MSEVB_PAIR_DEBUG") != nullptr; if (dbg) fprintf(stderr, "pair_flat: half tile max %d cap %d, sub-tile max %d, largest cell %d, nt %d, split %d\n", c->half_tile_max, c->half_tile_cap, c->sub_tile_max, c->cell_atoms_max, c->nt, (int)split); }
+  if (split != c->pair_split_now) { CHK(nb_prune_reset(c)); c->pair_split_now = split; }      // (the two geometries keep different lists)
+  const int nblocks = round_up8(std::max((c_hi - c_lo) * (split ? 2 : 1), 1));
+  if (nblocks > MAX_BLOCKS) FAIL(MSEVB_ERR_LIMIT, "pair_forces: too many cells");
+  *nblocks_out = nblocks;
   PairFlatArgs A;
   A.c_lo = c_lo; A.c_hi = c_hi; A.nc = make_int3(c->ncell[0], c->ncell[1], c->ncell[2]); A.tile_cap = c->half_tile_cap;
   A.cell_start = c->d_cell_start.p; A.posq = c->d_posq.p; A.type_s = c->d_type_sorted.p;
-  A.nbr_start = c->d_nbr_start.p; A.nbr_count = c->d_nbr_count.p; A.nbr = c->d_nbr.p;
+  A.nbr_count = c->d_nbr_count.p; A.nbr_split = c->d_nbr_split.p; A.nbr = c->d_nbr.p;
   A.pairpar = c->d_pair_par.p; A.nt = c->nt;
-  A.etab = c->d_ewald_tab.p; A.inv_dx = 1.0 / c->erfc_dx; A.dx = c->erfc_dx; A.delta = c->alpha * c->erfc_dx;
+  A.etab = c->pair_taylor ? c->d_ewald_tay.p : c->d_ewald_tab.p; A.inv_dx = 1.0 / c->erfc_dx; A.dx = c->erfc_dx; A.delta = c->alpha * c->erfc_dx;
   for (int d = 0; d < 3; ++d) { A.box.L[d] = c->box[d]; A.box.invL[d] = 1.0 / c->box[d]; }
   A.rc2 = c->rc * c->rc;
   A.Fs = c->d_fsorted.p; A.part_el = c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS; A.part_vdw = c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS;
@@ -490,11 +550,15 @@ int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int nblocks, int slot_ele
   A.posq_prune = c->d_posq_prune.p;
   const double rp = c->rc + c->prune_delta;
   A.rp2 = rp * rp; A.N_all = N;
-  const int need_slots = c->half_tile_cap + 1;
-  const size_t lj = PF_LJ_BYTES + sizeof(PfSmall);
   const bool ty = c->pair_taylor;
-  if (need_slots <= 1024) return ty ? pf_launch<1024, true>(c, A, nblocks, 56 * 1024 + lj, c->attr_pair_flat[0]) : pf_launch<1024, false>(c, A, nblocks, 56 * 1024 + lj, c->attr_pair_flat[1]);
-  if (need_slots <= 2048) return ty ? pf_launch<2048, true>(c, A, nblocks, 56 * 2048 + lj, c->attr_pair_flat[2]) : pf_launch<2048, false>(c, A, nblocks, 56 * 2048 + lj, c->attr_pair_flat[3]);
-  if (need_slots <= 2304) return ty ? pf_launch<2304, true>(c, A, nblocks, 56 * 2304 + lj, c->attr_pair_flat[6]) : pf_launch<2304, false>(c, A, nblocks, 56 * 2304 + lj, c->attr_pair_flat[7]);      // (the largest pitch that keeps all four position arrays within the 16-bit offset field)
-  return ty ? pf_launch<2560, true>(c, A, nblocks, 56 * 2560 + lj, c->attr_pair_flat[4]) : pf_launch<2560, false>(c, A, nblocks, 56 * 2560 + lj, c->attr_pair_flat[5]);
+  bool* at = c->attr_pair_flat;
+  if (split) {
+    if (c->pair_split_opt == 2) return ty ? pf_launch<1344, true, true, 512, 4, true>(c, A, nblocks, at[8]) : pf_launch<1344, false, true, 512, 4, true>(c, A, nblocks, at[9]);      // (2 x 8 waves, pipelined loop)
+    return ty ? pf_launch<1344, true, true, 768, 6, false>(c, A, nblocks, at[10]) : pf_launch<1344, false, true, 768, 6, false>(c, A, nblocks, at[11]);      // 2 x 12 waves, 80 registers
+  }
+  const int need_slots = c->half_tile_cap + 1;
+  if (need_slots <= 1024) return ty ? pf_launch<1024, true, false, 1024, 4, true>(c, A, nblocks, at[0]) : pf_launch<1024, false, false, 1024, 4, true>(c, A, nblocks, at[1]);
+  if (need_slots <= 2048) return ty ? pf_launch<2048, true, false, 1024, 4, true>(c, A, nblocks, at[2]) : pf_launch<2048, false, false, 1024, 4, true>(c, A, nblocks, at[3]);
+  if (need_slots <= 2304) return ty ? pf_launch<2304, true, false, 1024, 4, true>(c, A, nblocks, at[6]) : pf_launch<2304, false, false, 1024, 4, true>(c, A, nblocks, at[7]);      // (the largest pitch that keeps all four position arrays within the 16-bit offset field)
+  return ty ? pf_launch<2560, true, false, 1024, 4, true>(c, A, nblocks, at[4]) : pf_launch<2560, false, false, 1024, 4, true>(c, A, nblocks, at[5]);
 }

@@ -113,11 +113,13 @@ int build_tables(msevb_ctx* c) {
   }
   c->t_erfc.resize(E + 1);
   c->t_scale.resize(E + 1);
+  c->t_ewE.resize(E + 1);
   c->erfc_dx = c->rc / double(E);
   for (int i = 1; i <= E + 1; ++i) {
     const double r = double(i) * c->erfc_dx, ar = r * c->alpha;
     c->t_erfc[i - 1] = std::erfc(ar) * c->conv;
     c->t_scale[i - 1] = c->t_erfc[i - 1] + ar * 2.0 / c->pi_sqrt * std::exp(-ar * ar) * c->conv;
+    c->t_ewE[i - 1] = 2.0 / c->pi_sqrt * std::exp(-ar * ar) * c->conv;      // E = -dT/d(alpha r): scale = erfc + (alpha r) E; what pair_flat.hip expands both tables with
   }
   double fact[13];
   fact[1] = 1.0;

@@ -27,9 +27,10 @@ def run(opts, reps=30):
     return np.array(e[:2]), F, (time.time() - t0) / reps * 1e3
 
 base = run({"pair_flat": 0, "prune_freeze": 0, "pair_taylor": 0})
-print("k_pair_half              E_elec %.9f E_vdw %.9f   %.3f ms/call" % (base[0][0], base[0][1], base[2]))
-for name, o in (("flat, list rewritten", {"pair_flat": 1, "prune_freeze": 0, "pair_taylor": 0}), ("flat, list kept", {"pair_flat": 1, "prune_freeze": 1, "pair_taylor": 0}),
-                ("flat + taylor, list kept", {"pair_flat": 1, "prune_freeze": 1, "pair_taylor": 1})):
-    r = run(o)
-    print("%-24s E_elec %.9f E_vdw %.9f   %.3f ms/call   dE %.2e %.2e   max|dF| %.3e (max|F| %.1f)" %
-          (name, r[0][0], r[0][1], r[2], r[0][0] - base[0][0], r[0][1] - base[0][1], np.abs(r[1] - base[1]).max(), np.abs(base[1]).max()))
+print("k_pair_half                          E_elec %.9f E_vdw %.9f   %.3f ms/call" % (base[0][0], base[0][1], base[2]))
+for split in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1,2".split(","))]:
+    for name, o in (("list rewritten", {"prune_freeze": 0, "pair_taylor": 1}), ("list kept", {"prune_freeze": 1, "pair_taylor": 1}), ("list kept, two table rows", {"prune_freeze": 1, "pair_taylor": 0})):
+        o = dict(o, pair_flat=1, pair_split=split)
+        r = run(o)
+        print("flat split=%d %-24s E_elec %.9f E_vdw %.9f   %.3f ms/call   dE %.2e %.2e   max|dF| %.3e (max|F| %.1f)" %
+              (split, name, r[0][0], r[0][1], r[2], r[0][0] - base[0][0], r[0][1] - base[0][1], np.abs(r[1] - base[1]).max(), np.abs(base[1]).max()))

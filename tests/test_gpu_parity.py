@@ -1037,3 +1037,20 @@ def test_verlet_rebuild_flag_and_error_paths():
     with pytest.raises(api.MsevbError):
         h.ms_evb_calculate_total_force_energy()       # EVB tables were not set for a non-EVB fixture
     h.close()
+
+
+@pytest.mark.gpu
+def test_rccl_two_ranks_when_two_gpus_are_visible():
+    """tools/rccl_two_rank_check.py under torchrun with 2 ranks (one GPU each): the sharded MS-EVB call over a real 2-rank RCCL communicator equals the
+    single-rank call.  Skipped on a one-GPU box (the driver's multi-GPU node runs it)."""
+    import subprocess, json, socket, sys
+    import torch
+    from conftest import ROOT
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "tools", "rccl_two_rank_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["ranks_seen"] == 2 and out["ok"], out

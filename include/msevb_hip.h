@@ -86,6 +86,11 @@ int msevb_get_forces(msevb_ctx* ctx, double* force /*(3,N) host*/);
 /* atom_data%force as the host holds it (a host that changed its arrays between two steps of msevb_md_integrate_atomic: the first
    half-kick of velocity Verlet, src/md_integration.f90:478, uses the forces of the previous force call) */
 int msevb_set_forces(msevb_ctx* ctx, const double* force /*(3,N) host*/);
+/* Atom order of the CALLER's arrays.  The reference re-packs its host arrays when the principal diabat changes (the proton's slot moves to the
+   acceptor's block, src/ms_evb.f90:2677-2836, called from :218-227); the library never moves atoms.  host_to_library(N), 1-based: entry i = the
+   library's index of the caller's atom i (NULL: same order).  From then on every (3,N) array that crosses the ABI - positions, velocities,
+   forces, in either direction - is permuted on the device; tables, plans, the Verlet list and its capacity stay as they are. */
+int msevb_set_host_order(msevb_ctx* ctx, const int* host_to_library);
 void* msevb_device_forces(msevb_ctx* ctx);      /* device pointer to force(3,N), valid until destroy */
 void* msevb_device_positions(msevb_ctx* ctx);
 

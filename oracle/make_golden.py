@@ -84,7 +84,7 @@ def compact(d, keep_store=True):
     return out
 
 
-def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, proton_shift=0.0, so3h_eref=None, standard=False, rb=False, cf2=False, freeze=(), md_temp=300.0, nbaro=0, **simkw):
+def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, proton_shift=0.0, so3h_eref=None, standard=False, rb=False, cf2=False, freeze=(), md_temp=300.0, nbaro=0, box_scale=None, **simkw):
     if ONLY and name not in ONLY:
         return
     ff = forcefield.ch3so3h_water_forcefield()
@@ -104,6 +104,8 @@ def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=Fa
         import dataclasses
         ff = dataclasses.replace(ff, reference_energy=dict(ff.reference_energy, so3h=so3h_eref))
     s = synth.make_system(n_side, n_diabat=n_diabat, seed=seed, proton_shift=proton_shift)
+    if box_scale is not None:      # orthorhombic box: the same atoms, the cell stretched (vacuum at the faces)
+        s.box = s.box * np.asarray(box_scale, dtype=float)
     vel = None
     if md_steps:
         p = forcefield.build_params(ff, moltype_order=["h2o", "so3h"])
@@ -119,6 +121,7 @@ def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=Fa
     out["gen_so3h_eref"] = np.array(np.nan if so3h_eref is None else so3h_eref)
     out["gen_xyz"] = s.xyz
     out["gen_hydronium"] = np.array(s.hydronium)
+    out["gen_box_scale"] = np.asarray([1.0, 1.0, 1.0] if box_scale is None else box_scale, dtype=float)
     if vel is not None:
         out["md_velocity0"] = vel
     os.makedirs(GOLD, exist_ok=True)
@@ -161,6 +164,10 @@ def main():
     # Monte-Carlo barostat (monte_carlo_barostat, :231-386): 2 MD steps, then 6 x (move, MD step) at 2 000 bar with a 0.4 % trial step;
     # baro_rand holds the two random numbers each move drew (trial length, Metropolis test)
     case("npt_std_n6_s15", 6, 1, 15, evb=False, md_steps=2, nbaro=6, pressure=2000.0, baroscale=0.004, **small)
+    # ORTHORHOMBIC (non-cubic) boxes: the reference's CB array takes V = box(1,1)^3 whatever the other edges are (src/pme.f90:646), its reciprocal lattice the
+    # true volume (src/general_routines.f90:473) - both reproduced by tables.cpp and pinned here
+    case("std_n6_ortho_s19", 6, 1, 19, evb=False, box_scale=(1.0, 1.07, 1.15), **small)
+    case("evb_n6_d4_ortho_s20", 6, 4, 20, evb=True, keep_store=False, box_scale=(1.0, 1.07, 1.15), **small)
     # principal-diabat switch (src/ms_evb.f90:218-227).  Acid proton started next to its acceptor and the acid's reference energy
     # raised by 850 kJ/mol (the unrelaxed lattice otherwise keeps the acid diabat ~800 kJ/mol below): the reference's FIRST EVB force
     # call (during its initialisation) hands the proton to the water, so everything this fixture holds - 'xyz', topology, Hamiltonian,

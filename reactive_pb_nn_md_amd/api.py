@@ -156,6 +156,15 @@ class MsEvbHip:
         a = np.ascontiguousarray(xyz, dtype=np.float64)
         self._chk(self.L.msevb_set_positions(self.ctx, _dp(a)))
 
+    def set_host_order(self, host_to_library=None):
+        """atom order of the caller's (N,3) arrays: entry i = the library's index (0-based here) of the caller's atom i; None = same order.
+        What a Fortran host calls after the reference re-packed its arrays on a proton hop (msevb_set_host_order, include/msevb_hip.h)"""
+        if host_to_library is None:
+            self._chk(self.L.msevb_set_host_order(self.ctx, None))
+        else:
+            a = np.ascontiguousarray(np.asarray(host_to_library) + 1, dtype=np.int32)
+            self._chk(self.L.msevb_set_host_order(self.ctx, _ip(a)))
+
     def set_frozen_types(self, atype_freeze):
         """atype_freeze (src/md_integration.f90:473, :512): atoms of these types keep position and velocity"""
         a = np.ascontiguousarray(atype_freeze, dtype=np.int32)

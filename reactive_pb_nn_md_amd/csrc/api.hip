@@ -63,6 +63,15 @@ int fetch_energies(msevb_ctx* c) {
   return MSEVB_OK;
 }
 
+// caller order <-> library order of a (3,N) array (msevb_set_host_order): scatter = 1: lib[perm[i]] = host[i]; 0: host[i] = lib[perm[i]]
+__global__ void k_permute3(int N, const int* __restrict__ perm, const double* __restrict__ src, double* __restrict__ dst, int scatter) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int j = perm[i];
+  const int s = scatter ? i : j, d = scatter ? j : i;
+  dst[3 * (size_t)d] = src[3 * (size_t)s]; dst[3 * (size_t)d + 1] = src[3 * (size_t)s + 1]; dst[3 * (size_t)d + 2] = src[3 * (size_t)s + 2];
+}
+
 extern "C" {
 
 int msevb_create(msevb_ctx** out, int device_id) {
@@ -124,7 +133,7 @@ int msevb_destroy(msevb_ctx* c) {
                         &c->d_xyz_store, &c->d_disp, &c->d_maxdisp, &c->d_Q, &c->d_theta, &c->d_green, &c->d_w, &c->d_dw, &c->d_uscale, &c->d_partials, &c->d_energies,
                         &c->d_Fdiag, &c->d_Foff};
   for (auto b : db) b->release();
-  c->d_pair_par.release(); c->d_moltypes.release(); c->d_ewald_tab.release(); c->d_ewald_tay.release(); c->d_nbr_count.release(); c->d_nbr_split.release(); c->d_nbr2_count.release(); c->d_posq_prune.release(); c->d_flat.release(); c->d_cell_trips.release(); c->d_nbr_start.release();
+  c->d_pair_par.release(); c->d_moltypes.release(); c->d_ewald_tab.release(); c->d_ewald_tay.release(); c->d_nbr_count.release(); c->d_nbr_split.release(); c->d_host_perm.release(); c->d_stage3.release(); c->d_nbr2_count.release(); c->d_posq_prune.release(); c->d_flat.release(); c->d_cell_trips.release(); c->d_nbr_start.release();
   c->d_w_s.release(); c->d_comm_h.release(); c->d_comm_e.release(); c->d_bad.release(); c->d_fsorted.release();
   if (c->h_ke) (void)hipHostFree(c->h_ke);
   c->d_sort_tmp.release(); c->d_posq.release(); c->d_grid.release(); c->d_fft_work.release(); c->d_fft_work_b.release();
@@ -435,10 +444,44 @@ void pin_user_buffer(msevb_ctx* c, const void* p, size_t bytes) {
   c->pinned_user[k] = {p, bytes, 1, false};
 }
 
+int msevb_set_host_order(msevb_ctx* c, const int* h2l) {
+  NEED_FINAL();
+  if (!h2l) { c->host_perm_on = false; return MSEVB_OK; }
+  std::vector<int> p(c->N); std::vector<char> seen(c->N, 0);
+  bool ident = true;
+  for (int i = 0; i < c->N; ++i) {
+    const int j = h2l[i] - 1;
+    if (j < 0 || j >= c->N || seen[j]) FAIL(MSEVB_ERR_ARG, "msevb_set_host_order: not a permutation of 1..N");
+    seen[j] = 1; p[i] = j; ident = ident && j == i;
+  }
+  if (ident) { c->host_perm_on = false; return MSEVB_OK; }
+  if (c->d_host_perm.alloc(c->N) || c->d_stage3.alloc(3 * (size_t)c->N)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (host order)");
+  HIPCHK(hipMemcpy(c->d_host_perm.p, p.data(), (size_t)c->N * sizeof(int), hipMemcpyHostToDevice));
+  c->host_perm_on = true;
+  return MSEVB_OK;
+}
+// (3,N) arrays across the ABI: straight copies, or through the caller's atom order (msevb_set_host_order); asynchronous on the main stream
+int upload_atoms3(msevb_ctx* c, double* dst_dev, const double* src_host) {
+  const size_t bytes = 3 * (size_t)c->N * 8;
+  if (!c->host_perm_on) { HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream)); return MSEVB_OK; }
+  HIPCHK(hipMemcpyAsync(c->d_stage3.p, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_permute3, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, c->N, c->d_host_perm.p, (const double*)c->d_stage3.p, dst_dev, 1);
+  HIPCHK(hipGetLastError());
+  return MSEVB_OK;
+}
+int download_atoms3(msevb_ctx* c, double* dst_host, const double* src_dev) {
+  const size_t bytes = 3 * (size_t)c->N * 8;
+  if (!c->host_perm_on) { HIPCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream)); return MSEVB_OK; }
+  hipLaunchKernelGGL(k_permute3, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, c->N, c->d_host_perm.p, src_dev, c->d_stage3.p, 0);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(dst_host, c->d_stage3.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  return MSEVB_OK;
+}
+
 int msevb_set_positions(msevb_ctx* c, const double* xyz) {
   NEED_FINAL();
   pin_user_buffer(c, xyz, 3 * (size_t)c->N * 8);
-  HIPCHK(hipMemcpyAsync(c->d_xyz.p, xyz, 3 * (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream));
+  CHK(upload_atoms3(c, c->d_xyz.p, xyz));
   HIPCHK(hipMemsetAsync(c->d_energies.p + S_FAULT, 0, 8, c->stream));      // new coordinates: the sticky bad-coordinate flag starts over
   c->h_energies[S_FAULT] = 0.0;
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -462,11 +505,11 @@ int msevb_set_box(msevb_ctx* c, const double* box3) {
   return MSEVB_OK;
 }
 
-int msevb_get_positions(msevb_ctx* c, double* xyz) { NEED_FINAL(); HIPCHK(hipMemcpyAsync(xyz, c->d_xyz.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
-int msevb_set_velocities(msevb_ctx* c, const double* v) { NEED_FINAL(); HIPCHK(hipMemcpyAsync(c->d_vel.p, v, 3 * (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
-int msevb_get_velocities(msevb_ctx* c, double* v) { NEED_FINAL(); HIPCHK(hipMemcpyAsync(v, c->d_vel.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
-int msevb_get_forces(msevb_ctx* c, double* f) { NEED_FINAL(); HIPCHK(hipMemcpyAsync(f, c->d_force.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
-int msevb_set_forces(msevb_ctx* c, const double* f) { NEED_FINAL(); if (!f) return MSEVB_ERR_ARG; HIPCHK(hipMemcpyAsync(c->d_force.p, f, 3 * (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
+int msevb_get_positions(msevb_ctx* c, double* xyz) { NEED_FINAL(); CHK(download_atoms3(c, xyz, c->d_xyz.p)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
+int msevb_set_velocities(msevb_ctx* c, const double* v) { NEED_FINAL(); CHK(upload_atoms3(c, c->d_vel.p, v)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
+int msevb_get_velocities(msevb_ctx* c, double* v) { NEED_FINAL(); CHK(download_atoms3(c, v, c->d_vel.p)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
+int msevb_get_forces(msevb_ctx* c, double* f) { NEED_FINAL(); CHK(download_atoms3(c, f, c->d_force.p)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
+int msevb_set_forces(msevb_ctx* c, const double* f) { NEED_FINAL(); if (!f) return MSEVB_ERR_ARG; CHK(upload_atoms3(c, c->d_force.p, f)); HIPCHK(hipStreamSynchronize(c->stream)); return MSEVB_OK; }
 void* msevb_device_forces(msevb_ctx* c) { return c ? c->d_force.p : nullptr; }
 void* msevb_device_positions(msevb_ctx* c) { return c ? c->d_xyz.p : nullptr; }
 
@@ -652,7 +695,7 @@ int msevb_calculate_total_force_energy(msevb_ctx* c, double* energies, double* f
   NEED_FINAL();
   do {      // repeated only when a list row outgrew its stride in a rebuild (the stride has grown by then)
     CHK(total_force_enqueue(c));
-    if (force) { pin_user_buffer(c, force, 3 * (size_t)c->N * 8); HIPCHK(hipMemcpyAsync(force, c->d_force.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream)); }
+    if (force) { pin_user_buffer(c, force, 3 * (size_t)c->N * 8); CHK(download_atoms3(c, force, c->d_force.p)); }
     CHK(fetch_energies(c));
   } while (nb_check_overflow(c));
   double en[MSEVB_N_ENERGY];

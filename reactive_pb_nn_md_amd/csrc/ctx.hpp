@@ -228,6 +228,7 @@ struct msevb_ctx {
   // handed out again (numpy temporaries) would keep a stale registration.
   // frozen atom types (atype_freeze): d_frozen = per-atom flags (nullptr when nothing is frozen), n_free = atoms that are integrated
   std::vector<int> freeze_type; DBuf<int> d_frozen; bool any_frozen = false; double n_free = 0.0, inv_mass_sum_free = 0.0;
+  DBuf<int> d_host_perm; DBuf<double> d_stage3; bool host_perm_on = false;      // msevb_set_host_order: caller's atom i = library atom d_host_perm[i]
   bool pin_host_arrays = false;      // opt-in (option pin_host_arrays): only safe when the caller's arrays live as long as the context uses them
   struct PinnedUser { const void* p; size_t bytes; int hits; bool registered; } pinned_user[8] = {};
   // tables
@@ -401,6 +402,8 @@ double volume32(const double box[3]);
 extern "C" int total_force_enqueue(msevb_ctx* c);
 extern "C" int total_force_collect(msevb_ctx* c, double* en);
 extern "C" int upload_topology(msevb_ctx* c);
+extern "C" int upload_atoms3(msevb_ctx* c, double* dst_dev, const double* src_host);      // api.hip: (3,N) arrays in the caller's atom order (msevb_set_host_order)
+extern "C" int download_atoms3(msevb_ctx* c, double* dst_host, const double* src_dev);
 int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part_stride, int* nblocks);
 int pme_prepare_atoms(msevb_ctx* c, bool with_indices);
 bool fft_lds_usable(const msevb_ctx* c);                              // fft_lds.hip

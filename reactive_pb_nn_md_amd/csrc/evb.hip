@@ -2154,7 +2154,7 @@ int msevb_ms_evb_calculate_total_force_energy(msevb_ctx* c, double* epot, double
   (void)hipSetDevice(c->device);
   double e = 0;
   CHK(evb_force_energy(c, &e));
-  if (force) { pin_user_buffer(c, force, 3 * (size_t)c->N * 8); HIPCHK(hipMemcpyAsync(force, c->d_force.p, 3 * (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream)); }
+  if (force) { pin_user_buffer(c, force, 3 * (size_t)c->N * 8); CHK(download_atoms3(c, force, c->d_force.p)); }
   HIPCHK(hipStreamSynchronize(c->stream));
   if (epot) *epot = e;
   return MSEVB_OK;

@@ -19,7 +19,7 @@
 !==============================================================================
 module ms_evb
   use ms_evb_ref, ms_evb_calculate_total_force_energy_cpu => ms_evb_calculate_total_force_energy
-  use total_energy_forces, only : msevb_hip_ms_evb_force_energy, msevb_hip_invalidate
+  use total_energy_forces, only : msevb_hip_ms_evb_force_energy, msevb_hip_remap
   implicit none
   integer, save, private :: i_step_hip = 0      ! diagonalize_evb_hamiltonian's own step counter (src/ms_evb.f90:265,:347)
 
@@ -65,11 +65,11 @@ contains
     i_step_hip = i_step_hip + 1
 
     ! principal-diabat switch (src/ms_evb.f90:218-227): the host arrays are re-topologised by the reference's OWN routine (it moves the
-    ! proton's array slot and every atom in between, forces and velocities included); the device copy, which never moves atoms, is dropped
-    ! and uploaded again in the new order by the next force call.  The Verlet list lives on the device: nothing to rebuild here.
+    ! proton's array slot and every atom in between, forces and velocities included); the device copy, which never moves atoms, stays as it is
+    ! and is told the host's new atom order (msevb_set_host_order).  The Verlet list lives on the device: nothing to rebuild here.
     if ( new_i_mole_hydronium /= i_mole_hydronium ) then
        call evb_change_diabat_data_structure_topology( principle_diabat, i_mole_hydronium, system_data, molecule_data, atom_data, hydronium_molecule_index )
-       call msevb_hip_invalidate()
+       call msevb_hip_remap( system_data, molecule_data )
     endif
 
   end subroutine ms_evb_calculate_total_force_energy

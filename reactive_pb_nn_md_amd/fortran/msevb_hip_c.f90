@@ -156,6 +156,11 @@ module msevb_hip_c
        integer(c_int), intent(out) :: atom_type_index(*), mol_n_atom(*), mol_type_index(*), mol_atom_index(8,*), hydronium_molecule
        real(c_double), intent(out) :: charge(*)
      end function
+     integer(c_int) function msevb_set_host_order(ctx, host_to_library) bind(C, name="msevb_set_host_order")
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+       integer(c_int), intent(in) :: host_to_library(*)
+     end function
      integer(c_int) function msevb_md_integrate_atomic(ctx, n_steps, delta_t, use_evb, energies_out) bind(C, name="msevb_md_integrate_atomic")
        import :: c_ptr, c_int, c_double
        type(c_ptr), value :: ctx

@@ -51,6 +51,35 @@ contains
     uploaded = .false.
   end subroutine msevb_hip_invalidate
 
+  !-- host arrays were re-ordered by the reference's evb_change_diabat_data_structure_topology (principal-diabat switch, src/ms_evb.f90:218-227): the
+  !   library, which never moves atoms, is told where each of the host's atoms sits in ITS order; tables, FFT plans, the captured graph, the
+  !   Verlet list and its capacity, the RCCL communicator all stay.  Molecule m is the same molecule on both sides and its atoms are in the same
+  !   local order (the library re-topologises exactly as the reference does, msevb_get_topology).
+  subroutine msevb_hip_remap(system_data, molecule_data)
+    type(system_data_type), intent(in) :: system_data
+    type(molecule_data_type), dimension(:), intent(in) :: molecule_data
+    integer(c_int), allocatable :: at(:), mn(:), mt(:), ma(:,:), perm(:)
+    real(c_double), allocatable :: chg(:)
+    integer(c_int) :: hyd
+    integer :: m, k, n
+    integer(8) :: t0, t1, rate
+    if (.not. c_associated(ctx)) return
+    call system_clock(t0, rate)
+    n = system_data%total_atoms
+    allocate(at(n), chg(n), mn(system_data%n_mole), mt(system_data%n_mole), ma(8, system_data%n_mole), perm(n))
+    call msevb_check(ctx, msevb_get_topology(ctx, at, chg, mn, mt, ma, hyd), "msevb_get_topology")
+    perm = 0
+    do m = 1, system_data%n_mole
+       if (mn(m) /= molecule_data(m)%n_atom) stop "msevb_hip_remap: the library and the host disagree about a molecule's size after the proton hop"
+       do k = 1, mn(m)
+          perm(molecule_data(m)%atom_index(k)) = ma(k, m)
+       end do
+    end do
+    call msevb_check(ctx, msevb_set_host_order(ctx, perm), "msevb_set_host_order")
+    call system_clock(t1)
+    write(*,'(A,F9.3,A,I0,A)') " msevb_hip_remap: host atom order handed to the GPU library in ", 1d3 * dble(t1 - t0) / dble(rate), " ms (", n, " atoms; context, tables, plans and list kept)"
+  end subroutine msevb_hip_remap
+
   integer function env_int(name, default)
     character(*), intent(in) :: name
     integer, intent(in) :: default
@@ -94,6 +123,12 @@ contains
        if (ios /= 0) stop "MSEVB_COMM_FILE unreadable"
     end if
     call msevb_check(ctx, msevb_comm_init(ctx, id, rank, nranks), "msevb_comm_init")
+    ! the join is a collective: every rank has read the id by now.  The file goes, so that a later run (or a later join of this one) that names the
+    ! same path cannot pick up this run's id
+    if (rank == 0) then
+       open(unit=97, file=fname(1:l), status='old', iostat=ios)
+       if (ios == 0) close(97, status='delete')
+    end if
   end subroutine msevb_hip_join_communicator
 
   !-- push every table the hot path reads to the GPU library (once; again after a box change)

@@ -54,7 +54,7 @@ def test_verlet_pair_set_identical(name):
     h.close()
 
 
-@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3", "std_n6_sapt_s6", "std_n6_lb_s9", "std_n6_rb_s10", "std_n6_ex3_s12", "std_n6_k20_s13", "std_n6_k64_s17"])
+@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3", "std_n6_sapt_s6", "std_n6_lb_s9", "std_n6_rb_s10", "std_n6_ex3_s12", "std_n6_k20_s13", "std_n6_k64_s17", "std_n6_ortho_s19"])
 def test_stages_against_reference(name):
     g = golden(name)
     h = api.MsEvbHip(system.from_golden(g))
@@ -1054,3 +1054,29 @@ def test_rccl_two_ranks_when_two_gpus_are_visible():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["ranks_seen"] == 2 and out["ok"], out
+
+
+@pytest.mark.gpu
+def test_host_atom_order_permutation():
+    """msevb_set_host_order: the caller's arrays in ANOTHER atom order than the library's (what the reference's host arrays are after a proton hop,
+    src/ms_evb.f90:2677-2836) - positions in, forces / positions / velocities out are the same numbers, permuted; nothing else is re-uploaded."""
+    import time
+    g = golden("evb_n6_d4_s2")
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    e0, F0 = h.ms_evb_calculate_total_force_energy()
+    rng = np.random.default_rng(5)
+    p = rng.permutation(spec.n_atom)              # caller's atom i = library atom p[i]
+    t0 = time.time(); h.set_host_order(p); dt = time.time() - t0
+    h.set_positions(spec.xyz[p])
+    e1, F1 = h.ms_evb_calculate_total_force_energy()
+    assert abs(e1 - e0) < 1e-10 * abs(e0) and np.abs(F1 - F0[p]).max() < 1e-9
+    assert np.array_equal(h.get_positions(), spec.xyz[p])
+    v = rng.normal(size=(spec.n_atom, 3)); h.set_velocities(v)
+    assert np.array_equal(h.get_velocities(), v)
+    h.set_host_order(None)
+    assert np.array_equal(h.get_positions(), spec.xyz) and np.array_equal(h.get_velocities()[p], v)
+    with pytest.raises(RuntimeError):
+        h.set_host_order(np.zeros(spec.n_atom, dtype=int))      # not a permutation
+    assert dt < 0.05
+    h.close()

@@ -168,6 +168,8 @@ def main():
     # true volume (src/general_routines.f90:473) - both reproduced by tables.cpp and pinned here
     case("std_n6_ortho_s19", 6, 1, 19, evb=False, box_scale=(1.0, 1.07, 1.15), **small)
     case("evb_n6_d4_ortho_s20", 6, 4, 20, evb=True, keep_store=False, box_scale=(1.0, 1.07, 1.15), **small)
+    # unit vectors of the MS-EVB3 repulsion procedures (rep3_*, bm_*, rep_switch_table: ref_driver.f90 calls them on their own)
+    case("evb_n6_d4_rep_s25", 6, 4, 25, evb=True, keep_store=False, **small)
     # principal-diabat switch (src/ms_evb.f90:218-227).  Acid proton started next to its acceptor and the acid's reference energy
     # raised by 850 kJ/mol (the unrelaxed lattice otherwise keeps the acid diabat ~800 kJ/mol below): the reference's FIRST EVB force
     # call (during its initialisation) hands the proton to the water, so everything this fixture holds - 'xyz', topology, Hamiltonian,

@@ -80,6 +80,8 @@ void orc_set_evb(OrcSys*, const int* acid, const int* base, const int* conj_mol,
 /* full EVB force call (src/ms_evb.f90:181): returns adiabatic energy, fills F (principal atom order).
    Every diabat is evaluated FROM SCRATCH in its own topology (independent of the product's delta scheme). */
 double orc_evb_force_energy(OrcSys*, double* F);
+double orc_evb_repulsion_principal(OrcSys*, double* F);      /* src/ms_evb.f90:2259-2478 on the principal topology */
+void orc_evb_rep_switch(double r, double rs, double rc, double* sw, double* dsw);      /* :2484 */
 int  orc_evb_n_diabat(OrcSys*);
 void orc_evb_get(OrcSys*, int* proton_log /*[D][max_chain][5]*/, int* parent /*[D]*/, double* H /*[D][D]*/,
                  double* eigvec /*[D]*/, double* F_diag /*[D][N][3]*/, double* F_off /*[D][N][3]*/);

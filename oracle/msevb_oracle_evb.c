@@ -340,6 +340,10 @@ static int jacobi(int n, double* a /*[n][n] row-major, a[i][j]*/, double* d, dou
 #undef V
 }
 
+/* ms_evb_intermolecular_repulsion of the principal topology alone (src/ms_evb.f90:2259): energy returned, forces ADDED to F; and the switching function */
+double orc_evb_repulsion_principal(OrcSys* s, double* F) { OrcTopo P = orc_principal_topo(s); return evb_repulsion(s, &P, F); }
+void orc_evb_rep_switch(double r, double rs, double rc, double* sw, double* dsw) { rep_switch(r, rs, rc, sw, dsw); }
+
 /* ---------------------------------------------------------------- the EVB force call */
 /* construct_evb_hamiltonian (src/ms_evb.f90:375-489) + diagonalize_evb_hamiltonian (:242-351) */
 double orc_evb_force_energy_noverlet(OrcSys* s, double* F) {

@@ -24,7 +24,7 @@ def lib():
             build()
         L = C.CDLL(path)
         L.orc_create.restype = C.c_void_p
-        for f in ("orc_total", "orc_ewald_self", "orc_md_step", "orc_kinetic_energy", "orc_evb_force_energy"):
+        for f in ("orc_total", "orc_ewald_self", "orc_md_step", "orc_kinetic_energy", "orc_evb_force_energy", "orc_evb_repulsion_principal"):
             getattr(L, f).restype = C.c_double
         _LIB = L
     return _LIB
@@ -182,6 +182,17 @@ class Oracle:
         mn, mt, ma = np.zeros(M, dtype=np.int32), np.zeros(M, dtype=np.int32), np.zeros((M, 8), dtype=np.int32)
         self.L.orc_get_topology(self.h, _p(at, C.c_int), _p(ch, C.c_double), _p(mn, C.c_int), _p(mt, C.c_int), _p(ma, C.c_int))
         return dict(atom_type_index=at, charge=ch, mol_n_atom=mn, mol_type_index=mt, mol_atom_index=ma)
+
+    def evb_repulsion_principal(self):
+        """ms_evb_intermolecular_repulsion (three-atom + Born-Mayer terms) of the principal topology: (energy, forces)"""
+        F = np.zeros((self.N, 3))
+        e = self.L.orc_evb_repulsion_principal(self.h, _p(F, C.c_double))
+        return float(e), F
+
+    def rep_switch(self, r, rs, rc):
+        sw, dsw = C.c_double(), C.c_double()
+        self.L.orc_evb_rep_switch(C.c_double(r), C.c_double(rs), C.c_double(rc), C.byref(sw), C.byref(dsw))
+        return sw.value, dsw.value
 
     def evb(self):
         F = np.zeros((self.N, 3))

@@ -358,6 +358,27 @@ program ref_dump
 
   !----- stage 6: EVB Hamiltonian (src/ms_evb.f90:375, :242)
   if (ms_evb_simulation == "yes") then
+     ! stand-alone MS-EVB3 repulsion procedures on the principal topology (src/ms_evb.f90:2295, :2405, :2484): energy and force arrays of each term
+     block
+       real*8, allocatable :: frep(:,:)
+       real*8 :: erep, swv(2,61), rr
+       integer :: ks
+       allocate(frep(3,N))
+       frep = 0d0; erep = 0d0
+       call ms_evb_three_atom_repulsion( frep, erep, hydronium_molecule_index(1), system_data, molecule_data, atom_data )
+       call dump_s('rep3_E', erep)
+       call dump_r8('rep3_F', frep, (/3,N/))
+       frep = 0d0; erep = 0d0
+       call ms_evb_born_mayer( frep, erep, hydronium_molecule_index(1), system_data, molecule_data, atom_data )
+       call dump_s('bm_E', erep)
+       call dump_r8('bm_F', frep, (/3,N/))
+       do ks = 1, 61      ! ms_evb_repulsive_switch on r = 2.00, 2.02, ... 3.20 with rs = 2.4, rc = 3.0
+          rr = 2d0 + 0.02d0 * dble(ks - 1)
+          call ms_evb_repulsive_switch( swv(1,ks), swv(2,ks), rr, 2.4d0, 3.0d0 )
+       end do
+       call dump_r8('rep_switch_table', swv, (/2,61/))
+       deallocate(frep)
+     end block
      call construct_evb_hamiltonian( hydronium_molecule_index(1),  system_data, molecule_data, atom_data, verlet_list_data, PME_data, file_io_data )
      D = diabat_index
      call dump_is('n_diabat', D)

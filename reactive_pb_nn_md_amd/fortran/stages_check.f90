@@ -8,6 +8,9 @@
 !   grid_Q / derivative_grid_Q                        src/pme.f90:184, :346
 !   intra_molecular_energy_force                      src/intra_bonded_interactions.f90:17
 !   md_integrate_atomic (one NVE step)                src/md_integration.f90:438
+!   ms_evb_calculate_total_force_energy (EVB build: stages_check_evb)   src/ms_evb.f90:181 - the reference's own routine (diabat enumeration, topology
+!                                                     hand-overs, per-diabat real-space and reciprocal updates, couplings, Jacobi on the CPU; only its
+!                                                     principal-diabat force call and its FFTs land on the GPU side) against the drop-in's
 ! (the reference's FFT calls land in libmsevb_dfti.so, its spreading, gather, pair loop and bonded terms run on the CPU).
 ! Prints one line per stage: "stage <name> dF <max force deviation> dE <max energy deviation> ...".
 ! usage: stages_check gro ffpmt top simpmt traj log hop a   (the reference's eight arguments)
@@ -21,6 +24,7 @@ program stages_check
   use pme_routines, only : ref_pme => pme_reciprocal_space_energy_force, ref_grid_Q => grid_Q, ref_derivative_grid_Q => derivative_grid_Q
   use bonded_interactions, only : ref_bonded => intra_molecular_energy_force
   use md_integration, only : ref_md_integrate_atomic => md_integrate_atomic
+  use ms_evb, only : ms_evb_calculate_total_force_energy, ms_evb_calculate_total_force_energy_cpu, evb_hamiltonian, diabat_index
   use msevb_hip_stages, only : gpu_construct_verlet_list => construct_verlet_list, gpu_real_space => real_space_energy_force, &
        gpu_pme => pme_reciprocal_space_energy_force, gpu_grid_Q => grid_Q, gpu_derivative_grid_Q_all => derivative_grid_Q_all, &
        gpu_bonded => intra_molecular_energy_force, gpu_md_integrate_atomic => md_integrate_atomic
@@ -101,12 +105,30 @@ program stages_check
   call gpu_pme( system_data, atom_data, PME_data )
   call gpu_bonded( system_data, molecule_data, atom_data )
   x0 = atom_data%xyz(:,1:N); v0 = atom_data%velocity(:,1:N); f0 = atom_data%force(:,1:N)
+  if (ms_evb_simulation == "no") then      ! (the EVB build integrates through the reference's own md_integrate_atomic + module ms_evb: nothing of its own to compare)
   call ref_md_integrate_atomic( system_data, molecule_data, atom_data, integrator_data, verlet_list_data, PME_data, file_io_data )
   x_ref = atom_data%xyz(:,1:N); v_ref = atom_data%velocity(:,1:N); f_ref = atom_data%force(:,1:N)
   atom_data%xyz(:,1:N) = x0; atom_data%velocity(:,1:N) = v0; atom_data%force(:,1:N) = f0
   call gpu_md_integrate_atomic( system_data, molecule_data, atom_data, integrator_data, verlet_list_data, PME_data, file_io_data )
   write(*,'(A,3ES12.4)') "stage md_step dx dv dF", maxval(abs(atom_data%xyz(:,1:N) - x_ref)), maxval(abs(atom_data%velocity(:,1:N) - v_ref)), &
        maxval(abs(atom_data%force(:,1:N) - f_ref))
+  end if
+
+  !----- 6. EVB build only: the whole MS-EVB force call, the reference's routine against the drop-in's, same process, same data structures
+  if (ms_evb_simulation == "yes") then
+     block
+       real*8, allocatable :: h_ref(:,:)
+       integer :: d_ref
+       atom_data%xyz(:,1:N) = x0; atom_data%velocity(:,1:N) = v0
+       call ms_evb_calculate_total_force_energy_cpu( system_data, molecule_data, atom_data, verlet_list_data, PME_data, file_io_data, integrator_data%n_output, integrator_data, trajectory_step )
+       f_ref = atom_data%force(:,1:N); e1 = system_data%potential_energy; d_ref = diabat_index
+       allocate(h_ref(d_ref, d_ref)); h_ref = evb_hamiltonian(1:d_ref, 1:d_ref)
+       atom_data%force = 0d0
+       call ms_evb_calculate_total_force_energy( system_data, molecule_data, atom_data, verlet_list_data, PME_data, file_io_data, integrator_data%n_output, integrator_data, trajectory_step )
+       write(*,'(A,3ES12.4,2I4,ES12.4)') "stage evb dF dE dH", maxval(abs(atom_data%force(:,1:N) - f_ref)), abs(system_data%potential_energy - e1), &
+            maxval(abs(evb_hamiltonian(1:d_ref, 1:d_ref) - h_ref)), d_ref, diabat_index, e1
+     end block
+  end if
 
   write(*,'(A)') "stages_check done"
 end program stages_check

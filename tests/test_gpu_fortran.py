@@ -192,3 +192,31 @@ def test_unchanged_reference_main_program_across_a_proton_hop(tmp_path):
     assert abs(log[0][0] - g["E_adiabatic"][0]) <= 1e-5 * abs(g["E_adiabatic"][0]), (log[0][0], g["E_adiabatic"][0])
     etot = np.array([log[k][0] + log[k][1] for k in range(9)])
     assert np.all(np.isfinite(etot)) and np.abs(etot - etot[0]).max() < 0.05 * abs(etot[0]), etot
+
+
+def test_fortran_evb_force_call_against_the_reference_routine(tmp_path):
+    """oracle/_ref/stages_check_evb (the EVB build of stages_check.f90): in ONE Fortran process the reference's own ms_evb_calculate_total_force_energy
+    (linked beside the drop-in as ms_evb_calculate_total_force_energy_cpu: its diabat enumeration, topology hand-overs, per-diabat real-space and
+    reciprocal-space updates, couplings and Jacobi all run on the CPU) against the drop-in's nine-argument procedure of the same name, on fixture
+    evb_n6_d4_s2's input files: forces to 1e-9 kJ/mol/A, the adiabatic energy and every Hamiltonian entry to 1e-10 relative."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "stages_check_evb")
+    if not os.path.exists(exe):
+        pytest.skip("stages_check_evb not built (needs the reference sources: dev container only)")
+    import ref_inputs
+    from reactive_pb_nn_md_amd import forcefield, synth
+    g = golden("evb_n6_d4_s2")
+    s = synth.make_system(int(g["gen_n_side"]), n_diabat=int(g["gen_n_diabat"]), seed=int(g["gen_seed"]))
+    ff = forcefield.ch3so3h_water_forcefield()
+    ref_inputs.write_gro(str(tmp_path / "sys.gro"), s)
+    ref_inputs.write_ffpmt(str(tmp_path / "ff.pmt"), ff)
+    ref_inputs.write_top(str(tmp_path / "sys.top"), ff)
+    ref_inputs.write_simpmt(str(tmp_path / "sim.pmt"), n_step=1, rc=7.0, rv=8.0, nslist=16, pme_grid=16)
+    r = subprocess.run("ulimit -s unlimited; exec %s sys.gro ff.pmt sys.top sim.pmt traj.gro out.log hop.out a.out" % exe, shell=True, cwd=str(tmp_path),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "stages_check done" in r.stdout, r.stdout[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("stage evb")]
+    assert line, r.stdout[-3000:]
+    t = line[0].split()
+    dF, dE, dH, d_ref, d_gpu, e = float(t[5]), float(t[6]), float(t[7]), int(t[8]), int(t[9]), float(t[10])
+    assert d_ref == d_gpu == int(g["n_diabat"][0])
+    assert dF < 1e-9 and dE < 1e-10 * abs(e) and dH < 1e-10 * abs(e), line[0]

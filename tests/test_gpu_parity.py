@@ -993,6 +993,42 @@ def test_config_4_workload_eight_virtual_ranks(stores):
     assert np.abs(Fsum - Fblend).max() < F_TOL
 
 
+def test_repulsion_of_the_principal_diabat_against_reference():
+    """MS-EVB3 repulsion terms on their own (fixture evb_n6_d4_rep_s25: ms_evb_three_atom_repulsion + ms_evb_born_mayer called stand-alone by the
+    reference driver): H_11 - E(principal force field) - reference energy of the hydronium is exactly their sum."""
+    g = golden("evb_n6_d4_rep_s25")
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    h.ms_evb_calculate_total_force_energy()
+    H00 = h.evb_state()["H"][0, 0]
+    en, _ = h.calculate_total_force_energy()
+    e_hyd = g["evb_reference_energy"][int(g["mol_type_index"][int(g["hydronium_molecule"][0]) - 1]) - 1]
+    rep = H00 - en["potential"] - e_hyd
+    assert abs(rep - (g["rep3_E"][0] + g["bm_E"][0])) < 1e-9, (rep, g["rep3_E"][0], g["bm_E"][0])
+    h.close()
+
+
+def test_config_B_evb_against_oracle(oracle_lib):
+    """BASELINE.json configs[2] at its own size: the WHOLE MS-EVB force call (98 220 atoms, 8 diabats, 64^3) against the CPU oracle, which evaluates
+    every diabat from scratch in its own topology - Hamiltonian, adiabatic energy, Hellmann-Feynman force, diabat enumeration."""
+    s = synth.make_system(32, n_diabat=8, seed=0, max_chain=3)
+    p = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"])
+    spec = system.from_synth(s, p, rc=9.0, rv=10.5, alpha=0.3, pme_grid=64, max_chain=3)
+    h = api.MsEvbHip(spec)
+    e, F = h.ms_evb_calculate_total_force_energy()
+    st = h.evb_state()
+    o = oracle_lib.Oracle(spec, threads=min(32, os.cpu_count() or 8))
+    o.verlet_build()
+    r = o.evb()
+    assert st["D"] == r["D"] == 8
+    plog_o = r["proton_log"].copy(); plog_o[plog_o >= 0] += 1      # the oracle counts from 0, the library reports the reference's 1-based log
+    assert np.array_equal(st["proton_log"], plog_o) and np.array_equal(st["coupling_matrix"], np.where(r["parent"] >= 0, r["parent"] + 1, -1))
+    Hs = np.triu(st["H"]); Ho = np.triu(r["H"])
+    assert np.abs(Hs - Ho).max() < 1e-11 * np.abs(Ho).max(), np.abs(Hs - Ho).max()
+    assert rel(e, r["E"]) < 1e-11 and np.abs(F - r["F"]).max() < 1e-8, (e, r["E"], np.abs(F - r["F"]).max())
+    h.close()
+
+
 def test_config_C_against_oracle(oracle_lib):
     """BASELINE.json configs[4] on one GPU: 985 362 atoms, 128^3 grid, 16 planted diabats (chains of 4 hops).  Principal-diabat force call
     against the CPU oracle at full size (one call), schedule independence, Jacobi ground state == LAPACK, third law."""

@@ -201,3 +201,18 @@ def test_dfti_adapter_against_numpy_fft(tmp_path):
         assert L.dfti_compute_backward_z_(desc, x.ctypes.data_as(C.c_void_p)) == 0
         assert np.abs(x - a * a.size).max() < 1e-12 * a.size                                     # unnormalised both ways
         assert L.dfti_free_descriptor_external_(desc) == 0 and not desc[0]
+
+
+def test_repulsion_procedures_against_reference(oracle_lib):
+    """ms_evb_three_atom_repulsion, ms_evb_born_mayer, ms_evb_repulsive_switch (src/ms_evb.f90:2295, :2405, :2484) called ON THEIR OWN by the reference
+    driver on the principal topology (fixture evb_n6_d4_rep_s25): the oracle's restatement of their sum, and of the switching function."""
+    g = golden("evb_n6_d4_rep_s25")
+    o = oracle_lib.Oracle(system.from_golden(g))
+    e, F = o.evb_repulsion_principal()
+    e_ref = g["rep3_E"][0] + g["bm_E"][0]
+    assert e_ref > 1.0 and abs(e - e_ref) < 1e-12 * abs(e_ref)
+    assert np.abs(F - (g["rep3_F"] + g["bm_F"])).max() < 1e-12 * np.abs(g["rep3_F"]).max()
+    tab = g["rep_switch_table"].reshape(61, 2)
+    for k in range(61):
+        sw, dsw = o.rep_switch(2.0 + 0.02 * k, 2.4, 3.0)
+        assert sw == tab[k, 0] and dsw == tab[k, 1], (k, sw, dsw, tab[k])

@@ -320,6 +320,7 @@ static int resolve_moltypes(msevb_ctx* c, std::vector<MolTypeDev>& out) {
 }
 
 int upload_topology(msevb_ctx* c) {   // atom types / charges / molecule membership (changes with the principal diabat)
+  c->topo_epoch++;
   const int N = c->N, M = c->M;
   HIPCHK(hipMemcpyAsync(c->d_atype.p, c->h_atype.data(), N * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->d_chg.p, c->h_chg.data(), N * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -495,6 +496,7 @@ int msevb_set_box(msevb_ctx* c, const double* box3) {
   for (int d = 0; d < 3; ++d) { if (!(box3[d] > 0.0)) FAIL(MSEVB_ERR_ARG, "box lengths must be positive"); L = box3[d] < L ? box3[d] : L; }
   if (!(c->rc < c->rv && c->rv < 0.5 * L)) FAIL(MSEVB_ERR_ARG, "need real_space_cutoff < verlet_cutoff < L/2 (src/general_routines.f90:1115-1130)");
   HIPCHK(hipDeviceSynchronize());
+  c->topo_epoch++;
   for (int d = 0; d < 3; ++d) c->box[d] = box3[d];
   CHK(build_box_tables(c));
   HIPCHK(hipMemcpy(c->d_CB.p, c->t_CB.data(), c->t_CB.size() * 8, hipMemcpyHostToDevice));
@@ -750,6 +752,8 @@ int msevb_get_phase_times(msevb_ctx* c, int* n, const char** names, double* ms, 
 int msevb_reset_phase_times(msevb_ctx* c) { (void)hipStreamSynchronize(c->stream); phase_harvest(c); for (int p = 0; p < PH_COUNT; ++p) { c->ph[p].ms = 0; c->ph[p].calls = 0; } return MSEVB_OK; }
 int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   const std::string s(name);
+  c->topo_epoch++;
+  if (s == "evb_speculate") { c->evb_speculate = v != 0.0; return MSEVB_OK; }
   if (s == "phase_timing") { c->timing = v != 0.0; c->timing_now = false; return MSEVB_OK; }
   if (s == "phase_timing_stride") { c->timing_stride = v < 1.0 ? 1 : (int)v; return MSEVB_OK; }
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }

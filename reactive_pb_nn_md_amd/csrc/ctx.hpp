@@ -347,6 +347,8 @@ struct msevb_ctx {
   // NVT: Langevin leap-frog kicks (langevin_integrator, src/md_integration.f90:186-228) instead of the plain half kicks
   int stamps_on = -1; unsigned long long* h_stamps = nullptr; double stamp_sum[16] = {0}; long stamp_n = 0, stamp_step = 0;
   bool evb_recip_linear = true;      // diabats' reciprocal space through the linear response of theta to the charge differences (evb.hip): no transform per diabat
+  bool evb_speculate = true;         // MS-EVB step without a host wait for the neighbourhood record while the diabat tree stays the same (evb.hip, SpecPlan); 0 = enumerate every step
+  long topo_epoch = 0;               // bumped by everything that can change what a recorded diabat tree means (topology upload, box, options)
   bool evb_device_solve = false;     // single rank: H' assembly + Jacobi + blend coefficients in a kernel (no host round trip before the blend)
   bool nvt = false; double friction = 0.1 /* 1/ps, the reference's default */, temperature = 300.0; unsigned long long langevin_seed = 0, langevin_tick = 0;
 };

@@ -64,6 +64,7 @@ struct EvbTablesDev {
   int pa_types[MAX_INTERACTION][2]; double pa_par[MAX_INTERACTION][5];
   double exch_atomic[MAX_TYPES];
   double screen2;     // squared screening radius (heavy atom - any atom) beyond which every repulsion term is zero
+  int reactive_p[MAX_MOLTYPES][MAX_MOL_ATOMS], reactive_b[MAX_MOLTYPES][MAX_MOL_ATOMS];      // evb_reactive_protons / evb_reactive_basic_atoms of the molecule types
 };
 
 struct CouplingDesc {   // one off-diagonal element, evaluated in the acceptor topology of diabat d
@@ -153,8 +154,9 @@ __device__ __forceinline__ double evb_repulsion_atom(const UnitDesc& u, const Ev
 // per step so that the environment kernel of every unit walks ~2 % of the box instead of all atoms.  Also re-arms the counter
 // of k_evb_region for the next step.
 __global__ __launch_bounds__(256) void k_evb_candidates(int N, double cx, double cy, double cz, double R2, const double* __restrict__ xyz, BoxDev box,
-                                                        int* __restrict__ counter, int* __restrict__ cand, int* __restrict__ region_counter) {
+                                                        int* __restrict__ counter, int* __restrict__ cand, int* __restrict__ region_counter, const double* __restrict__ sphere = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sphere) { cx = sphere[0]; cy = sphere[1]; cz = sphere[2]; R2 = sphere[3]; }      // speculative step: centre and radius from k_evb_refresh
   if (i == 0) *region_counter = 0;
   bool in = false;
   if (i < N) {
@@ -991,11 +993,157 @@ __global__ __launch_bounds__(64) void k_evb_solve(const SolveDesc* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// SPECULATIVE EVB STEP (f2): the diabat tree (which protons can hop where) changes every few dozen steps, the positions every step.
+// On a step that enumerated the tree itself the host leaves a SpecPlan on the device: for every descriptor (unit, coupling, reciprocal
+// atom) which diabat and how many hops its topology has behind it, the atoms each hop made whole (evb_change_data_structures_proton_transfer,
+// src/ms_evb.f90:876), and - for every molecule the depth-first search expanded - the reactive pairs it found (find_evb_reactive_neighbors,
+// :702-764).  The next step then does NOT wait for the neighbourhood record: k_evb_region re-evaluates the search predicates of the expanded
+// donors on the new positions (same expressions as the host's search; found pairs must be exactly the recorded ones), k_evb_refresh rewrites the
+// positions, centres of mass and shifts inside the descriptors already on the device, and the host enqueues the side chains at once.
+// Its verdict travels with the first energy fetch; a changed tree (rare) makes the host repeat the force call the long way (MSEVB_RETRY).
+constexpr int SPEC_MAX_PAIRS = 12, SPEC_MAX_DONORS = 32;
+struct SpecPlan {
+  int n_units, n_cps, n_ras, n_donors, n_pairs_total, hyd;
+  int unit_d[MAX_UNITS], unit_k[MAX_UNITS];                                          // diabat of the unit, hops its topology has behind it
+  int cp_d[MAX_DIABATS], cp_nhop[MAX_DIABATS], cp_ra0[MAX_DIABATS], cp_ra1[MAX_DIABATS];   // diabat / hops of a coupling; its diabat's reciprocal-space atoms [ra0, ra1)
+  int mw_n[MAX_DIABATS][MAX_CHAIN], mw_atoms[MAX_DIABATS][MAX_CHAIN][MAX_MOL_ATOMS];   // acceptor's atoms in the order make_molecule_whole walked them
+  int donor_mol[SPEC_MAX_DONORS], donor_np[SPEC_MAX_DONORS], donor_pair[SPEC_MAX_DONORS][SPEC_MAX_PAIRS][3];   // {proton (local), acceptor molecule, basic atom (local)}
+};
+
+// the tree check inside k_evb_region: thread = molecule j, against every expanded donor (their centres of mass and proton positions once per workgroup in LDS)
+__device__ __forceinline__ void spec_check_molecule(const SpecPlan* __restrict__ pl, const EvbTablesDev* __restrict__ tb, const int* __restrict__ mol_type, int m, int M,
+                                                    const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms, const double* __restrict__ xyz, const double* __restrict__ mass,
+                                                    const BoxDev& box, const double* com_m /* of molecule m, valid when m < M */, int* __restrict__ check) {
+  __shared__ double s_com[SPEC_MAX_DONORS][3], s_x[SPEC_MAX_DONORS][MAX_MOL_ATOMS][3];
+  const int nd = pl->n_donors;
+  if ((int)threadIdx.x < nd) {
+    const int i = pl->donor_mol[threadIdx.x], n = mol_natom[i];
+    double c[3] = {0, 0, 0}, mt = 0;
+    for (int k = 0; k < n; ++k) { const int a = mol_atoms[i * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) { c[d] += xyz[3 * a + d] * mass[a]; s_x[threadIdx.x][k][d] = xyz[3 * a + d]; } mt += mass[a]; }
+    for (int d = 0; d < 3; ++d) s_com[threadIdx.x][d] = c[d] / mt;
+  }
+  __syncthreads();
+  if (m >= M) return;
+  const int tj = mol_type[m], nj = mol_natom[m];
+  for (int q = 0; q < nd; ++q) {
+    const int i = pl->donor_mol[q];
+    if (i == m) continue;
+    double sh[3], dc[3];
+    for (int d = 0; d < 3; ++d) { sh[d] = floor((com_m[d] - s_com[q][d]) * box.invL[d] + 0.5) * box.L[d]; dc[d] = com_m[d] - s_com[q][d] - sh[d]; }
+    if (dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2] >= 25.0) continue;       // evb_first_solvation_cutoff
+    const int ti = mol_type[i], ni = mol_natom[i];
+    for (int ia = 0; ia < ni; ++ia) {
+      if (tb->reactive_p[ti][ia] != 1) continue;
+      for (int ja = 0; ja < nj; ++ja) {
+        if (tb->reactive_b[tj][ja] != 1) continue;
+        const int a = mol_atoms[m * MAX_MOL_ATOMS + ja];
+        double r[3];
+        for (int d = 0; d < 3; ++d) r[d] = xyz[3 * a + d] - s_x[q][ia][d] - sh[d];
+        if (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] >= 6.25) continue;           // evb_reactive_pair_distance
+        bool known = false;
+        for (int p = 0; p < pl->donor_np[q]; ++p) known = known || (pl->donor_pair[q][p][0] == ia && pl->donor_pair[q][p][1] == m && pl->donor_pair[q][p][2] == ja);
+        if (known) atomicAdd(&check[0], 1); else atomicOr(&check[1], 1);
+      }
+    }
+  }
+}
+
+// one WAVE per descriptor (lane = special atom): descriptors refreshed in place; the last workgroup to finish writes the candidate sphere and the
+// verdict of the tree check (-> device word for later kernels, pinned word for the host).  scratch: {far^2 bits (64), ticket, pad}
+__global__ __launch_bounds__(64) void k_evb_refresh(const SpecPlan* __restrict__ pl, UnitDesc* __restrict__ units, CouplingDesc* __restrict__ cps, RecipAtom* __restrict__ ras,
+                                                     const double* __restrict__ xyz, const double* __restrict__ mass, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms,
+                                                     BoxDev box, double extra_R, double* __restrict__ sphere, int* __restrict__ check, int* __restrict__ verdict_host,
+                                                     unsigned long long* __restrict__ scratch) {
+  __shared__ double s_pos[MAX_SPEC][3], s_c[3];
+  const int lane = threadIdx.x, b = blockIdx.x, nu = pl->n_units;
+  const bool is_unit = b < nu;
+  const int e = b - nu;
+  SpecAtom* spec = is_unit ? units[b].spec : cps[e].spec;
+  const int n_spec = is_unit ? units[b].n_spec : cps[e].n_spec, d = is_unit ? pl->unit_d[b] : pl->cp_d[e], khops = is_unit ? pl->unit_k[b] : pl->cp_nhop[e];
+  if (lane == 0) {      // centre of the candidate sphere: the hydronium's centre of mass (as k_evb_region computes the record's)
+    double ch[3] = {0, 0, 0}, mh = 0;
+    const int hyd = pl->hyd;
+    for (int k = 0; k < mol_natom[hyd]; ++k) { const int a = mol_atoms[hyd * MAX_MOL_ATOMS + k]; for (int q = 0; q < 3; ++q) ch[q] += xyz[3 * a + q] * mass[a]; mh += mass[a]; }
+    for (int q = 0; q < 3; ++q) s_c[q] = ch[q] / mh;
+  }
+  // today's coordinates, then the make-whole passes of the hops this topology has behind it (a chain along the acceptor's atoms: one shuffle per link)
+  const bool act = lane < n_spec;
+  const int my = act ? spec[lane].idx : -1;
+  double p[3] = {0, 0, 0};
+  if (act) for (int q = 0; q < 3; ++q) p[q] = xyz[3 * (size_t)my + q];
+  for (int h = 0; h < khops; ++h) {
+    const int n = pl->mw_n[d][h];
+    int mine = -1;
+    for (int i = 0; i < n; ++i) if (pl->mw_atoms[d][h][i] == my) mine = i;
+    for (int i = 1; i < n; ++i) {
+      const unsigned long long mp = __ballot(mine == i - 1);
+      const int lp = mp ? __ffsll((long long)mp) - 1 : 0;
+      const double px = __shfl(p[0], lp, 64), py = __shfl(p[1], lp, 64), pz = __shfl(p[2], lp, 64);
+      if (mine == i) {
+        const double pr[3] = {px, py, pz};
+        double sh[3];
+        for (int q = 0; q < 3; ++q) sh[q] = floor((p[q] - pr[q]) * box.invL[q] + 0.5) * box.L[q];
+        if (fabs(sh[0]) > 1e-6 || fabs(sh[1]) > 1e-6 || fabs(sh[2]) > 1e-6) for (int q = 0; q < 3; ++q) p[q] = pr[q] + (p[q] - pr[q] - sh[q]);
+      }
+    }
+  }
+  __syncthreads();
+  double d2 = 0.0;
+  if (act) for (int q = 0; q < 3; ++q) { spec[lane].x[q] = p[q]; s_pos[lane][q] = p[q]; double dd = p[q] - s_c[q]; dd -= box.L[q] * floor(dd / box.L[q] + 0.5); d2 += dd * dd; }
+  if (!is_unit) d2 = 0.0;      // (the host takes the radius from the units' atoms)
+  for (int o = 32; o > 0; o >>= 1) d2 = fmax(d2, __shfl_xor(d2, o, 64));
+  __syncthreads();
+  if (!is_unit) {
+    CouplingDesc& cp = cps[e];
+    if (lane < cp.n_mols) {      // centres of mass in the molecules' atom order of this topology (mol_com_h)
+      double s[3] = {0, 0, 0}, mt = 0;
+      for (int k = 0; k < cp.n_spec; ++k) if (cp.spec[k].mol == cp.mols[lane]) { const double ma = mass[cp.spec[k].idx]; for (int q = 0; q < 3; ++q) s[q] = s[q] + s_pos[k][q] * ma; mt = mt + ma; }
+      for (int q = 0; q < 3; ++q) cp.mol_com[lane][q] = s[q] / mt;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (lane == 0) {      // zundel_r_com (src/ms_evb.f90:2946)
+      int kD = 0, kA = 0;
+      for (int m = 0; m < cp.n_mols; ++m) { if (cp.mols[m] == cp.spec[cp.D_at[0]].mol) kD = m; if (cp.mols[m] == cp.spec[cp.A_at[0]].mol) kA = m; }
+      double mdt = 0, mat = 0;
+      for (int k = 0; k < cp.nD; ++k) mdt = mdt + mass[cp.spec[cp.D_at[k]].idx];
+      for (int k = 0; k < cp.nA; ++k) mat = mat + mass[cp.spec[cp.A_at[k]].idx];
+      for (int q = 0; q < 3; ++q) {
+        const double cd = cp.mol_com[kD][q], ca = cp.mol_com[kA][q];
+        const double sha = floor((ca - cd) * box.invL[q] + 0.5) * box.L[q];
+        const double rca = cd + (ca - cd - sha);
+        cp.zc[q] = (mdt * cd + mat * rca) / (mdt + mat); cp.shiftd[q] = 0.0; cp.shifta[q] = sha;
+      }
+    }
+    // positions of the reciprocal-space atoms of this coupling's diabat: those of its final topology
+    for (int r = pl->cp_ra0[e] + lane; r < pl->cp_ra1[e]; r += 64) {
+      int k = 0;
+      for (int q = 0; q < cp.n_spec; ++q) if (cp.spec[q].idx == ras[r].idx) k = q;
+      for (int q = 0; q < 3; ++q) ras[r].x_new[q] = s_pos[k][q];
+    }
+  }
+  if (lane != 0) return;
+  atomicMax(scratch, (unsigned long long)__double_as_longlong(d2));      // (non-negative doubles order like their bit patterns)
+  __threadfence();
+  if (atomicAdd((unsigned*)(scratch + 1), 1u) != gridDim.x - 1) return;
+  __threadfence();
+  const double f2 = __longlong_as_double((long long)atomicAdd(scratch, 0ull));
+  const double R = sqrt(f2) + extra_R;
+  sphere[0] = s_c[0]; sphere[1] = s_c[1]; sphere[2] = s_c[2]; sphere[3] = R * R;
+  const int ok = (atomicAdd(&check[1], 0) == 0 && atomicAdd(&check[0], 0) == pl->n_pairs_total) ? 1 : 0;
+  check[0] = 0; check[1] = 0; check[2] = ok;
+  scratch[0] = 0ull; scratch[1] = 0ull;
+  *verdict_host = ok ? 1 : -1;
+}
+
 __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms, const double* __restrict__ xyz,
                              const double* __restrict__ mass, BoxDev box, int* __restrict__ counter, RegionRec* __restrict__ out, int cap,
                              int* __restrict__ cand_counter, RegionRec* __restrict__ out_host, int cap_host,
-                             int* __restrict__ ticket, int* __restrict__ host_count, volatile long long* flag, long long seq) {
+                             int* __restrict__ ticket, int* __restrict__ host_count, volatile long long* flag, long long seq,
+                             const SpecPlan* __restrict__ plan = nullptr, const EvbTablesDev* __restrict__ tabs = nullptr, const int* __restrict__ mol_type = nullptr, int* __restrict__ check = nullptr) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  double com_m[3] = {0, 0, 0};
   if (m == 0) *cand_counter = 0;      // re-arm k_evb_candidates (which in turn re-arms `counter` for the next step)
   if (m < M) {
     double ch[3] = {0, 0, 0}, mh = 0;
@@ -1004,7 +1152,7 @@ __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ 
     double com[3] = {0, 0, 0}, mt = 0;
     for (int k = 0; k < n; ++k) { const int a = mol_atoms[m * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) com[d] += xyz[3 * a + d] * mass[a]; mt += mass[a]; }
     double dr[3];
-    for (int d = 0; d < 3; ++d) { com[d] /= mt; dr[d] = com[d] - ch[d] / mh; }
+    for (int d = 0; d < 3; ++d) { com[d] /= mt; dr[d] = com[d] - ch[d] / mh; com_m[d] = com[d]; }
     min_image(dr, box);
     if (dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2] < R2) {
       const int slot = atomicAdd(counter, 1);
@@ -1017,6 +1165,7 @@ __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ 
       }
     }
   }
+  if (plan) spec_check_molecule(plan, tabs, mol_type, m, M, mol_natom, mol_atoms, xyz, mass, box, com_m, check);      // speculative step: is the diabat tree still the recorded one?
   // the workgroup that finishes last publishes the record count and the sequence number the host spins on (was a launch of its own
   // on the path the host's turn waits for): every block makes its records visible to the host before it draws its ticket
   __shared__ bool last;
@@ -1144,6 +1293,12 @@ struct EvbWork {   // persistent device scratch of one context
   bool pack_prefilled = false; hipEvent_t ev_prefill = nullptr;      // the blended charge grid starts as a copy of Q_1, made while the host waits for the energies
   std::vector<RegionRec> region, region_raw; std::vector<long long> region_key;
   std::vector<UnitDesc> units; std::vector<CouplingDesc> cps, cps_sorted; std::vector<RecipAtom> ras;      // descriptors of the current force call
+  // speculative step (SpecPlan above): what the last step that enumerated the tree itself left behind
+  SpecPlan plan; bool plan_valid = false, plan_fits = true; long plan_epoch = -1;
+  DBuf<SpecPlan> d_plan; DBuf<double> d_sphere; DBuf<int> d_check; DBuf<unsigned long long> d_refresh_scratch;
+  int pl_D = 0, pl_plog[MAX_DIABATS][MAX_CHAIN][5], pl_parent[MAX_DIABATS], pl_ngrid = 0, pl_ncp_big = 0;
+  std::vector<std::vector<int>> pl_units_of; std::vector<int> pl_grid_of, pl_cp_of; std::vector<double> pl_eref_delta;
+  long spec_steps = 0, spec_misses = 0;
 };
 // host-side section timing (MSEVB_HOST_TIMING=1): where the CPU thread spends the step
 struct HostTimes { double t[12] = {0}; long n = 0; };
@@ -1181,7 +1336,7 @@ void mol_com_h(const msevb_ctx* c, const HTopo& t, HMol& m) {
 }
 
 // evb_change_data_structures_proton_transfer (src/ms_evb.f90:843-932) on the compact topology
-int apply_hop_h(msevb_ctx* c, const EvbWork* w, HTopo& t, int md, int ip_local, int ma, int iheavy_local) {
+int apply_hop_h(msevb_ctx* c, const EvbWork* w, HTopo& t, int md, int ip_local, int ma, int iheavy_local, int* mw_atoms = nullptr, int* mw_n = nullptr) {
   const int kd = ensure_mol(c, w, t, md), ka0 = ensure_mol(c, w, t, ma);
   if (kd < 0 || ka0 < 0) FAIL(MSEVB_ERR_LIMIT, "EVB: proton-hop molecule outside the gathered neighbourhood");
   HMol& D = t.mols[kd];
@@ -1193,6 +1348,7 @@ int apply_hop_h(msevb_ctx* c, const EvbWork* w, HTopo& t, int md, int ip_local, 
   A.atoms[A.natom] = gp; A.natom += 1;
   t.atoms[gp].mol = ma;
   t.hydronium = ma;
+  if (mw_atoms) { *mw_n = A.natom; for (int i = 0; i < A.natom; ++i) mw_atoms[i] = A.atoms[i]; }      // (what k_evb_refresh replays on the next steps' positions)
   for (int i = 1; i < A.natom; ++i) {    // make_molecule_whole (src/general_routines.f90:1065)
     HAtom& prev = t.atoms[A.atoms[i - 1]];
     HAtom& cur = t.atoms[A.atoms[i]];
@@ -1463,9 +1619,18 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   // ~15 us, later; the pair loop, which it now precedes, has that much slack before the blend needs it)
   const hipStream_t s_reg = c->overlap && c->evb_region_main ? c->stream : w->stream2;
   if (!w->h_flag) { HIPCHK(hipHostMalloc((void**)&w->h_flag, 64, hipHostMallocDefault)); memset(w->h_flag, 0, 64); }
+  // SPECULATIVE STEP: the tree of the last enumeration is assumed to hold; k_evb_region checks that on the device while the host goes straight on
+  const bool spec = c->evb_speculate && c->overlap && w->plan_valid && w->plan_epoch == c->topo_epoch && w->plan.hyd == c->hydronium && !c->evb_device_solve && w->tabs_uploaded;
+  if (!w->d_check.p) {
+    if (w->d_plan.alloc(1) || w->d_sphere.alloc(4) || w->d_check.alloc(4) || w->d_refresh_scratch.alloc(2)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB plan)");
+    HIPCHK(hipMemsetAsync(w->d_check.p, 0, 4 * sizeof(int), w->stream2)); HIPCHK(hipMemsetAsync(w->d_refresh_scratch.p, 0, 16, w->stream2));      // (k_evb_refresh leaves the counters zeroed)
+  }
+  int* h_verdict = (int*)(w->h_flag + 4);
+  *h_verdict = 0;
   hipLaunchKernelGGL(k_evb_region, dim3((M + 1023) / 1024), dim3(1024), 0, s_reg, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
                      c->d_mass.p, box, w->d_counter.p, w->d_region.p, REGION_CAP, w->d_counter.p + 1, w->h_region, REGION_FAST,
-                     w->d_counter.p + 2, w->h_count, (volatile long long*)(w->h_flag + 1), ++w->seq_R);
+                     w->d_counter.p + 2, w->h_count, (volatile long long*)(w->h_flag + 1), ++w->seq_R,
+                     spec ? (const SpecPlan*)w->d_plan.p : (const SpecPlan*)nullptr, (const EvbTablesDev*)w->d_tabs.p, (const int*)c->d_mol_type.p, w->d_check.p);
   HIPCHK(hipEventRecord(w->ev_region, s_reg));
   HT(1);
   // ---- 2. principal diabat (calculate_total_force_energy, src/ms_evb.f90:411) - enqueued, not waited for
@@ -1485,6 +1650,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   c->shard_now = false; c->skip_gather_now = false; c->defer_molecules_now = false; c->ev_pos_ready = nullptr; c->defer_fold_now = false; c->skip_side_joins_now = false; c->pme_split_now = false; c->refresh_side_now = false;
   CHK(rc_tfe);
   HT(2);
+  auto fetch_region = [&]() -> int {
   if (spin_wait((volatile long long*)(w->h_flag + 1), w->seq_R, w->ev_region)) HIPCHK(hipErrorUnknown);
   const int nreg = *w->h_count;
   if (nreg > REGION_CAP) FAIL(MSEVB_ERR_LIMIT, "EVB neighbourhood buffer too small");
@@ -1501,11 +1667,20 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     std::sort(w->region_key.begin(), w->region_key.end());
     for (int k = 0; k < nreg; ++k) w->region[k] = src[(int)(w->region_key[k] & 0xffffffff)];
   }
+  return MSEVB_OK;
+  };
+  if (!spec) CHK(fetch_region());
   HT(3);
   // ---- 3. diabat enumeration on the principal topology (evb_conduct_proton_transfer_recursive, :498)
   for (int d = 0; d < MAX_DIABATS; ++d) { c->parent[d] = -1; for (int h = 0; h < MAX_CHAIN; ++h) for (int q = 0; q < 5; ++q) c->plog[d][h][q] = -1; }
   c->D = 1;
-  {
+  SpecPlan& plan = w->plan;
+  if (spec) {      // the recorded tree
+    c->D = w->pl_D;
+    memcpy(c->plog, w->pl_plog, sizeof c->plog); memcpy(c->parent, w->pl_parent, sizeof c->parent);
+  } else {
+    w->plan_valid = false; w->plan_fits = true;
+    plan.n_donors = 0; plan.n_pairs_total = 0; plan.hyd = c->hydronium;
     struct Frame { int mol, diabat; };
     // recursion implemented with an explicit lambda to keep the reference's DFS order
     std::function<int(int, int)> rec = [&](int im_donor, int d_donor) -> int {
@@ -1515,6 +1690,9 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       const RegionRec* ri = find_region(w, im_donor);
       if (!ri) FAIL(MSEVB_ERR_LIMIT, "EVB: donor outside the gathered neighbourhood");
       const MolTypeHost& mt = c->h_mt[c->h_mol_type[im_donor]];
+      int dq = -1; bool dnew = false;      // this molecule's entry among the expanded donors of the plan (its pairs are recorded once)
+      for (int q = 0; q < plan.n_donors; ++q) if (plan.donor_mol[q] == im_donor) dq = q;
+      if (dq < 0) { if (plan.n_donors < SPEC_MAX_DONORS) { dq = plan.n_donors++; plan.donor_mol[dq] = im_donor; plan.donor_np[dq] = 0; dnew = true; } else w->plan_fits = false; }
       // molecules of the donor's first solvation shell, once per donor (not once per proton), in ascending molecule index
       struct Near { int k; double sh[3]; };
       Near near[64]; int n_near = 0;
@@ -1538,6 +1716,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
             if (mj.reactive_basic[ja] != 1) continue;
             double r[3]; for (int d = 0; d < 3; ++d) r[d] = rj.x[ja][d] - ri->x[ia][d] - sh[d];
             if (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] >= 6.25) continue;           // evb_reactive_pair_distance = 2.5 (src/glob_v.f90:55)
+            if (dnew) { if (plan.donor_np[dq] < SPEC_MAX_PAIRS) { int* pp = plan.donor_pair[dq][plan.donor_np[dq]++]; pp[0] = ia; pp[1] = rj.mol; pp[2] = ja; plan.n_pairs_total++; } else w->plan_fits = false; }
             if (c->D >= MAX_DIABATS) FAIL(MSEVB_ERR_LIMIT, "Found more diabat states than evb_max_states");
             const int d = c->D++;
             c->parent[d] = d_donor;
@@ -1556,16 +1735,21 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   const int D = c->D, S = slots_per_rank(c, D), n_off = c->n_ranks * S, n_diag = 1 + n_off;
   HT(4);
   // ---- 4. evaluation units / couplings / recip patches of the diabats owned by this rank
-  std::vector<UnitDesc>& units = w->units; units.clear();      // (kept in the work area: the 2.4 kB descriptors are not re-allocated every step)
-  std::vector<CouplingDesc>& cps = w->cps; cps.clear();
-  std::vector<RecipAtom>& ras = w->ras; ras.clear();
+  std::vector<UnitDesc>& units = w->units;      // (kept in the work area: the 2.4 kB descriptors are not re-allocated every step)
+  std::vector<CouplingDesc>& cps = w->cps;
+  std::vector<RecipAtom>& ras = w->ras;
   std::vector<int> grid_of(D, -1), cp_of(D, -1);
   std::vector<double> eref_delta(D, 0.0);
   std::vector<std::vector<int>> units_of(D);
   HTopo P; P.hydronium = c->hydronium;
+  int ngrid = 0, ncp_big = 0;
+  if (spec) { units_of = w->pl_units_of; grid_of = w->pl_grid_of; cp_of = w->pl_cp_of; eref_delta = w->pl_eref_delta; ngrid = w->pl_ngrid; ncp_big = w->pl_ncp_big; }
+  else {
+  units.clear(); cps.clear(); ras.clear();
   if (ensure_mol(c, w, P, c->hydronium) < 0) FAIL(MSEVB_ERR_LIMIT, "EVB: hydronium outside region");
-  { UnitDesc u; CHK(make_unit(c, P, -1, -1, +1.0, 0, 0, 1, u)); units_of[0].push_back((int)units.size()); units.push_back(u); }
-  int ngrid = 0;
+  auto push_unit = [&](const UnitDesc& u, int d, int k) { if ((int)units.size() < MAX_UNITS) { plan.unit_d[units.size()] = d; plan.unit_k[units.size()] = k; } units_of[d].push_back((int)units.size()); units.push_back(u); };
+  { UnitDesc u; CHK(make_unit(c, P, -1, -1, +1.0, 0, 0, 1, u)); push_unit(u, 0, 0); }
+  std::vector<int> cp_d_unsorted, cp_nhop_unsorted;
   for (int d = 1; d < D; ++d) {
     if (!owned(c, d)) continue;
     HTopo T = P;
@@ -1576,10 +1760,10 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       if (c->plog[d][h][0] < 0) break;
       md = T.hydronium; ma = c->plog[d][h][3];
       if (ensure_mol(c, w, T, md) < 0 || ensure_mol(c, w, T, ma) < 0) FAIL(MSEVB_ERR_LIMIT, "EVB: hop molecule outside region");
-      { UnitDesc u; CHK(make_unit(c, T, md, ma, -1.0, slot, 1, 0, u)); units_of[d].push_back((int)units.size()); units.push_back(u); }
+      { UnitDesc u; CHK(make_unit(c, T, md, ma, -1.0, slot, 1, 0, u)); push_unit(u, d, h); }
       int typ_old = -1; for (const HMol& m : T.mols) if (m.id == T.hydronium) typ_old = m.type;
-      CHK(apply_hop_h(c, w, T, md, c->plog[d][h][1], ma, c->plog[d][h][4]));
-      { UnitDesc u; CHK(make_unit(c, T, md, ma, +1.0, slot, 1, h == nhop - 1 ? 1 : 0, u)); units_of[d].push_back((int)units.size()); units.push_back(u); }
+      CHK(apply_hop_h(c, w, T, md, c->plog[d][h][1], ma, c->plog[d][h][4], plan.mw_atoms[d][h], &plan.mw_n[d][h]));
+      { UnitDesc u; CHK(make_unit(c, T, md, ma, +1.0, slot, 1, h == nhop - 1 ? 1 : 0, u)); push_unit(u, d, h + 1); }
       int typ_new = -1; for (const HMol& m : T.mols) if (m.id == T.hydronium) typ_new = m.type;
       eref_delta[d] += c->e_ref[typ_new] - c->e_ref[typ_old];
     }
@@ -1618,9 +1802,9 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     for (int k = 0; k < 10; ++k) cp.par[k] = c->cp_par[ic][k];
     cp_of[d] = (int)cps.size();
     cps.push_back(cp);
+    cp_d_unsorted.push_back(d); cp_nhop_unsorted.push_back(nhop);
   }
   // couplings with more than 8 Zundel atoms first: they take the 16-lane instantiation of k_evb_coupling, the rest the 8-lane one
-  int ncp_big = 0;
   {
     std::vector<int> order(cps.size());
     for (size_t k = 0; k < order.size(); ++k) order[k] = (int)k;
@@ -1630,7 +1814,15 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     for (size_t k = 0; k < order.size(); ++k) { sorted[k] = cps[order[k]]; newpos[order[k]] = (int)k; if (sorted[k].nD + sorted[k].nA > 8) ncp_big++; }
     cps.swap(sorted);
     for (int d = 0; d < D; ++d) if (cp_of[d] >= 0) cp_of[d] = newpos[cp_of[d]];
+    for (size_t k = 0; k < order.size(); ++k) { plan.cp_d[k] = cp_d_unsorted[order[k]]; plan.cp_nhop[k] = cp_nhop_unsorted[order[k]]; }
+    for (size_t k = 0; k < cps.size(); ++k) { plan.cp_ra0[k] = 0; plan.cp_ra1[k] = 0; }
+    for (int d = 0; d < D; ++d) if (grid_of[d] >= 0 && cp_of[d] >= 0) {      // (a diabat's reciprocal-space atoms are contiguous)
+      int r0 = -1, r1 = -1;
+      for (int r = 0; r < (int)ras.size(); ++r) if (ras[r].grid == grid_of[d]) { if (r0 < 0) r0 = r; r1 = r + 1; }
+      if (r0 >= 0) { plan.cp_ra0[cp_of[d]] = r0; plan.cp_ra1[cp_of[d]] = r1; }
+    }
   }
+  }      // (!spec)
   const int nu = (int)units.size(), ncp = (int)cps.size(), nra = (int)ras.size();
   HT(5);
   // ---- 5. device buffers
@@ -1650,6 +1842,10 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     memcpy(tb.da_types, c->da_types, sizeof tb.da_types); memcpy(tb.da_par, c->da_par, sizeof tb.da_par);
     memcpy(tb.pa_types, c->pa_types, sizeof tb.pa_types); memcpy(tb.pa_par, c->pa_par, sizeof tb.pa_par);
     memcpy(tb.exch_atomic, c->e_exch_atomic, sizeof tb.exch_atomic);
+    for (int t = 0; t < c->nmt && t < MAX_MOLTYPES; ++t) for (int k = 0; k < MAX_MOL_ATOMS; ++k) {
+      tb.reactive_p[t][k] = k < (int)c->h_mt[t].reactive_protons.size() ? c->h_mt[t].reactive_protons[k] : 0;
+      tb.reactive_b[t][k] = k < (int)c->h_mt[t].reactive_basic.size() ? c->h_mt[t].reactive_basic[k] : 0;
+    }
     double rmax = 0.0;
     for (int k = 0; k < c->n_da; ++k) rmax = std::max(rmax, c->da_par[k][5]);
     for (int k = 0; k < c->n_pa; ++k) rmax = std::max(rmax, c->pa_par[k][4] + 3.0);
@@ -1677,9 +1873,11 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipHostMalloc((void**)&w->h_desc, w->desc_cap, hipHostMallocDefault));
     if (w->d_desc.alloc(w->desc_cap)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB descriptors)");
   }
+  if (!spec) {
   memcpy(w->h_desc + off_u, units.data(), (size_t)nu * sizeof(UnitDesc));
   if (ncp) memcpy(w->h_desc + off_c, cps.data(), (size_t)ncp * sizeof(CouplingDesc));
   if (nra) memcpy(w->h_desc + off_r, ras.data(), (size_t)nra * sizeof(RecipAtom));
+  }
   BlendTerms bt_dev;      // slots of the blend terms (the coefficients will come from the device)
   if (dev_solve) {
     SolveDesc* sd = (SolveDesc*)(w->h_desc + off_s);
@@ -1698,7 +1896,18 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     (void)blend_terms(c, D, nullptr, bt_dev, sd->term_i, sd->term_j);
     sd->nterm = bt_dev.n;
   }
-  HIPCHK(hipMemcpyAsync(w->d_desc.p, w->h_desc, desc_bytes, hipMemcpyHostToDevice, ss));
+  if (!spec) {
+    HIPCHK(hipMemcpyAsync(w->d_desc.p, w->h_desc, desc_bytes, hipMemcpyHostToDevice, ss));
+    // the plan for the steps that follow (they start from these descriptors): only when everything fitted its fixed-size tables
+    plan.n_units = nu; plan.n_cps = ncp; plan.n_ras = nra;
+    if (w->plan_fits && nu <= MAX_UNITS && ncp <= MAX_DIABATS && c->evb_speculate) HIPCHK(hipMemcpyAsync(w->d_plan.p, &plan, sizeof(SpecPlan), hipMemcpyHostToDevice, ss));
+    else w->plan_fits = false;
+  } else {      // descriptors of the last enumeration, already on the device: today's geometry written into them by one small kernel
+    hipLaunchKernelGGL(k_evb_refresh, dim3(nu + ncp), dim3(64), 0, ss, (const SpecPlan*)w->d_plan.p, (UnitDesc*)(w->d_desc.p + off_u), (CouplingDesc*)(w->d_desc.p + off_c), (RecipAtom*)(w->d_desc.p + off_r),
+                       (const double*)c->d_xyz.p, (const double*)c->d_mass.p, (const int*)c->d_mol_natom.p, (const int*)c->d_mol_atoms.p, box, std::max(c->rc, w->screen_r) + 0.5, w->d_sphere.p, w->d_check.p, h_verdict, w->d_refresh_scratch.p);
+    HIPCHK(hipGetLastError());
+    w->spec_steps++;
+  }
   const UnitDesc* d_units = (const UnitDesc*)(w->d_desc.p + off_u);
   const CouplingDesc* d_cps = (const CouplingDesc*)(w->d_desc.p + off_c);
   const RecipAtom* d_ra = (const RecipAtom*)(w->d_desc.p + off_r);
@@ -1742,7 +1951,9 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   // ---- 6a. real-space / bonded / repulsion deltas of all units (ms_evb_diabat_force_energy, :1421)
   const hipStream_t sr = ss;     // on aux2 behind the descriptors: beside the principal force and the reciprocal space of the diabats
   phase_begin(c, PH_EVB_REAL, sr);
-  {
+  if (spec) {
+    hipLaunchKernelGGL(k_evb_candidates, dim3((N + 255) / 256), dim3(256), 0, sr, N, 0.0, 0.0, 0.0, 0.0, c->d_xyz.p, box, w->d_counter.p + 1, w->d_cand.p, w->d_counter.p, (const double*)w->d_sphere.p);
+  } else {
     // candidate sphere: centre = hydronium COM, radius = farthest special atom + max(cutoff, repulsion screen) + a little
     const RegionRec* rh = find_region(w, c->hydronium);
     double far2 = 0.0;
@@ -1991,6 +2202,11 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   else if (c->overlap) {
     if (spin_wait((volatile long long*)w->h_flag, w->seq_A, w->ev_fetchA)) HIPCHK(hipErrorUnknown);
   } else HIPCHK(hipStreamSynchronize(c->stream));
+  if (spec && *h_verdict != 1) {      // the tree has changed (or the check never ran): this call's side chains worked on a stale topology - the whole call again, the long way
+    w->plan_valid = false; w->spec_misses++;
+    if (c->overlap && w->side_valid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0));
+    return MSEVB_RETRY;
+  }
   HT(7);      // (7: the wait for fetch A alone; 9: Hamiltonian assembly; 10: Jacobi + blend enqueue / coefficient hand-over; 11: principal energy, wait for fetch B, switch)
   const double E_recip1 = dev_solve ? 0.0 : w->h_E[nE];                  // this rank's own (complete) principal reciprocal energy
   const bool sharded = c->shard_principal && c->n_ranks > 1;
@@ -2094,6 +2310,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   // ---- 12. principal-diabat switch (src/ms_evb.f90:218-227): adopt the new topology, rebuild the Verlet list
   if (c->new_hydronium != c->hydronium) {
     c->hop_log.push_back((int)c->evb_calls); c->hop_log.push_back(c->hydronium + 1); c->hop_log.push_back(c->new_hydronium + 1);
+    if (spec) { CHK(fetch_region()); if (ensure_mol(c, w, P, c->hydronium) < 0) FAIL(MSEVB_ERR_LIMIT, "EVB: hydronium outside region"); }      // (the host has not looked at the neighbourhood record yet)
+    w->plan_valid = false;
     HTopo T = P;
     for (int h = 0; h < c->max_chain; ++h) { if (c->plog[pr][h][0] < 0) break; CHK(apply_hop_h(c, w, T, T.hydronium, c->plog[pr][h][1], c->plog[pr][h][3], c->plog[pr][h][4])); }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -2111,8 +2329,14 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     CHK(nb_build(c));
     c->flag_verlet_list = 0;
   }
+  if (!spec && w->plan_fits && c->evb_speculate && c->new_hydronium == c->hydronium) {      // what the next steps start from
+    w->pl_D = D; memcpy(w->pl_plog, c->plog, sizeof c->plog); memcpy(w->pl_parent, c->parent, sizeof c->parent);
+    w->pl_units_of = units_of; w->pl_grid_of = grid_of; w->pl_cp_of = cp_of; w->pl_eref_delta = eref_delta; w->pl_ngrid = ngrid; w->pl_ncp_big = ncp_big;
+    w->plan_valid = true; w->plan_epoch = c->topo_epoch;
+  }
   rearm.ok = true;
   HT(11); g_ht.n++;
+  if (ht_on && (g_ht.n % 100) == 0) fprintf(stderr, "[msevb] speculative steps %ld, of which the tree had changed %ld\n", w->spec_steps, w->spec_misses);
   return MSEVB_OK;
 }
 

@@ -1042,10 +1042,17 @@ def test_config_C_against_oracle(oracle_lib):
     o.verlet_build()
     e_o, E_o, F_o = o.total()
     assert rel(en["potential"], e_o) < E_RTOL and np.abs(F - F_o).max() < 1e-8
-    del o
     e1, F1 = h.ms_evb_calculate_total_force_energy()
     st = h.evb_state()
     assert st["D"] == 16 and abs(np.linalg.norm(st["eigvec"]) - 1.0) < 1e-12
+    # the WHOLE MS-EVB call against the oracle at this size (16 diabats, each from scratch in its own topology on the CPU: about a minute)
+    r = o.evb()
+    del o
+    plog_o = r["proton_log"].copy(); plog_o[plog_o >= 0] += 1
+    assert r["D"] == 16 and np.array_equal(st["proton_log"], plog_o) and np.array_equal(st["coupling_matrix"], np.where(r["parent"] >= 0, r["parent"] + 1, -1))
+    assert np.abs(np.triu(st["H"]) - np.triu(r["H"])).max() < 1e-11 * np.abs(r["H"]).max()
+    assert rel(e1, r["E"]) < 1e-11 and np.abs(F1 - r["F"]).max() < 1e-8, (e1, r["E"], np.abs(F1 - r["F"]).max())
+    del r
     w = np.linalg.eigvalsh(np.triu(st["H"]) + np.triu(st["H"], 1).T)
     assert rel(e1, w[0]) < 1e-12
     assert rel(st["H"][0, 0], en["potential"] + (st["H"][0, 0] - en["potential"])) < 1e-15

@@ -1056,6 +1056,7 @@ __global__ __launch_bounds__(64) void k_evb_refresh(const SpecPlan* __restrict__
                                                      BoxDev box, double extra_R, double* __restrict__ sphere, int* __restrict__ check, int* __restrict__ verdict_host,
                                                      unsigned long long* __restrict__ scratch) {
   __shared__ double s_pos[MAX_SPEC][3], s_c[3];
+  __shared__ int s_mw[MAX_CHAIN][MAX_MOL_ATOMS], s_mwn[MAX_CHAIN];
   const int lane = threadIdx.x, b = blockIdx.x, nu = pl->n_units;
   const bool is_unit = b < nu;
   const int e = b - nu;
@@ -1068,14 +1069,17 @@ __global__ __launch_bounds__(64) void k_evb_refresh(const SpecPlan* __restrict__
     for (int q = 0; q < 3; ++q) s_c[q] = ch[q] / mh;
   }
   // today's coordinates, then the make-whole passes of the hops this topology has behind it (a chain along the acceptor's atoms: one shuffle per link)
+  if (lane < MAX_CHAIN * MAX_MOL_ATOMS) s_mw[lane / MAX_MOL_ATOMS][lane % MAX_MOL_ATOMS] = pl->mw_atoms[d][lane / MAX_MOL_ATOMS][lane % MAX_MOL_ATOMS];      // (one parallel load instead of a chain of dependent ones)
+  if (lane < MAX_CHAIN) s_mwn[lane] = pl->mw_n[d][lane];
   const bool act = lane < n_spec;
   const int my = act ? spec[lane].idx : -1;
   double p[3] = {0, 0, 0};
   if (act) for (int q = 0; q < 3; ++q) p[q] = xyz[3 * (size_t)my + q];
+  __syncthreads();
   for (int h = 0; h < khops; ++h) {
-    const int n = pl->mw_n[d][h];
+    const int n = s_mwn[h];
     int mine = -1;
-    for (int i = 0; i < n; ++i) if (pl->mw_atoms[d][h][i] == my) mine = i;
+    for (int i = 0; i < n; ++i) if (s_mw[h][i] == my) mine = i;
     for (int i = 1; i < n; ++i) {
       const unsigned long long mp = __ballot(mine == i - 1);
       const int lp = mp ? __ffsll((long long)mp) - 1 : 0;

@@ -31,7 +31,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X fp64 vector: 256 CUs x 64 lanes x 2 x
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
 
 
-TRAFFIC_SOURCES = ("ctx.hpp", "devmath.hpp", "gather_dev.hpp", "molecule.hip", "molecule_dev.hpp", "neighbor.hip", "pair.hip", "pme.hip")      # same list in tools/make_traffic_json.py
+TRAFFIC_SOURCES = ("ctx.hpp", "devmath.hpp", "gather_dev.hpp", "molecule.hip", "molecule_dev.hpp", "neighbor.hip", "pair.hip", "pair_flat.hip", "pme.hip")      # same list in tools/make_traffic_json.py
 
 
 def algorithmic_bytes(N, K, D, D_local, half_list_entries):

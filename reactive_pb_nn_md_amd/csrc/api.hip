@@ -130,7 +130,7 @@ int msevb_destroy(msevb_ctx* c) {
                      &c->d_perm_tmp, &c->d_cell_start, &c->d_inv_perm, &c->d_tile_max, &c->d_nbr, &c->d_nbr2, &c->d_prune_mode, &c->d_frozen, &c->d_type_sorted, &c->d_mol_sorted, &c->d_base, &c->d_splindex, &c->d_base_s};
   for (auto b : ib) b->release();
   DBuf<double>* db[] = {&c->d_chg, &c->d_mass, &c->d_B6, &c->d_B5, &c->d_tt, &c->d_dtt, &c->d_CB, &c->d_xyz, &c->d_vel, &c->d_force, &c->d_force_recip,
-                        &c->d_xyz_store, &c->d_disp, &c->d_maxdisp, &c->d_Q, &c->d_theta, &c->d_green, &c->d_w, &c->d_dw, &c->d_uscale, &c->d_partials, &c->d_energies,
+                        &c->d_xyz_store, &c->d_disp, &c->d_maxdisp, &c->d_Q, &c->d_theta, &c->d_green, &c->d_w, &c->d_dw, &c->d_uscale, &c->d_uscale_s, &c->d_partials, &c->d_energies,
                         &c->d_Fdiag, &c->d_Foff};
   for (auto b : db) b->release();
   c->d_pair_par.release(); c->d_moltypes.release(); c->d_ewald_tab.release(); c->d_ewald_tay.release(); c->d_nbr_count.release(); c->d_nbr_split.release(); c->d_host_perm.release(); c->d_stage3.release(); c->d_nbr2_count.release(); c->d_posq_prune.release(); c->d_flat.release(); c->d_cell_trips.release(); c->d_nbr_start.release();
@@ -758,6 +758,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "phase_timing_stride") { c->timing_stride = v < 1.0 ? 1 : (int)v; return MSEVB_OK; }
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
+  if (s == "pme_weightless") { c->pme_weightless = v != 0.0; return MSEVB_OK; }
   if (s == "spread_mfma") { c->spread_mfma = v != 0.0; return MSEVB_OK; }
   if (s == "evb_pme_split") { c->evb_pme_split = v != 0.0; return MSEVB_OK; }
   if (s == "evb_single_join") { c->evb_single_join = v != 0.0; return MSEVB_OK; }

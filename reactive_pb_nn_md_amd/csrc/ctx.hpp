@@ -293,7 +293,7 @@ struct msevb_ctx {
   DBuf<double> d_Q;            // real copy of the spread grid (kept for the EVB delta path)
   DBuf<double> d_theta;        // real part of the convolved grid (theta_conv_Q)
   DBuf<double> d_green;        // G = IFFT(CB): real-space kernel of the reciprocal sum (theta = G * Q), K^3
-  DBuf<double> d_w, d_dw, d_uscale;   // per atom: B6 weights [N][3][6], derivative weights, scaled coords
+  DBuf<double> d_w, d_dw, d_uscale, d_uscale_s;   // per atom: B6 weights [N][3][6], derivative weights, scaled coords
   DBuf<int> d_base, d_splindex;       // nearpt [N][3], B6 rows [N][3][6]
   DBuf<int> d_base_s, d_brick_flag; DBuf<double> d_w_s;      // cell-sorted copies of nearpt / B6 weights for the brick spread; its overflow flag
   rocfft_plan plan_fwd = nullptr, plan_bwd = nullptr;
@@ -301,6 +301,10 @@ struct msevb_ctx {
   // up and down during a run and creating a plan pair costs milliseconds (a step costs 0.6 ms)
   std::map<int, std::pair<rocfft_plan, rocfft_plan>> plans_b;
   bool spread_tiles = true;
+  bool pme_weightless = true;       // tiled spread / gather recompute the B-spline weights from (uscale, nearpt) and the tables: no 288 B/atom weight store
+  bool weights_needed_now = false;  // this call has another reader of d_w / d_dw (set by the MS-EVB call for its per-diabat-transform paths)
+  int attr_gather_wl = 0;           // dynamic LDS the weight-free gather has been allowed so far
+  bool weights_valid = false;       // d_w / d_dw hold this step's weights (k_pme_prep ran, not k_pme_prep_light)
   int pme_tile_threads = 512;    // workgroup size of the LDS-tile spread / gather kernels (option pme_tile_threads: 256 or 512)
   bool spread_bricks = false;    // option: owner-computes charge spreading on the matrix cores (k_pme_spread_bricks): every cell's workgroup writes ITS brick of the grid, no atomics, no zero-fill
                                  // (needs bricks of <= 8 points per axis, K >= 16).  Measured 63 us alone against 55 + 4 + 5 for the LDS-atomic tiles with fill and copy, 2-3 % slower in the overlapped step: off
@@ -408,6 +412,7 @@ extern "C" int upload_atoms3(msevb_ctx* c, double* dst_dev, const double* src_ho
 extern "C" int download_atoms3(msevb_ctx* c, double* dst_host, const double* src_dev);
 int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part_stride, int* nblocks);
 int pme_prepare_atoms(msevb_ctx* c, bool with_indices);
+bool pme_weightless_now(const msevb_ctx* c);
 bool fft_lds_usable(const msevb_ctx* c);                              // fft_lds.hip
 int fft_lds_setup(msevb_ctx* c);
 int fft_lds_solve(msevb_ctx* c, const double* Q, double2* work, double* theta, double* part, int* nblocks, hipStream_t st);

@@ -1649,8 +1649,10 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   c->skip_side_joins_now = single_join;
   c->pme_split_now = single_join && c->evb_pme_split && c->evb_recip_linear && c->d_green.p && fft_lds_usable(c);      // spread now; the solve goes out behind the stencil-pair kernels (step 6b)
   c->refresh_side_now = c->overlap && c->evb_region_main;
+  c->weights_needed_now = !(fast && c->evb_recip_linear && c->d_green.p);      // per-diabat transforms / element stores read the principal diabat's weights (k_evb_patch, k_stencil_gather, k_evb_recip_special)
   w->side_valid = false;
   const int rc_tfe = total_force_enqueue(c);
+  c->weights_needed_now = false;
   c->shard_now = false; c->skip_gather_now = false; c->defer_molecules_now = false; c->ev_pos_ready = nullptr; c->defer_fold_now = false; c->skip_side_joins_now = false; c->pme_split_now = false; c->refresh_side_now = false;
   CHK(rc_tfe);
   HT(2);

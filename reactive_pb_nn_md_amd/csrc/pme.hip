@@ -49,6 +49,70 @@ __global__ __launch_bounds__(256) void k_pme_prep(int N, int K, int G, const dou
   dw[t] = d;
 }
 
+// The same scaled coordinate and nearest grid point WITHOUT the 36 weights per atom (option pme_weightless, the default on the tiled
+// spread / gather): one thread per (atom, axis), 36 B written per atom instead of 324 B.  The tiled kernels below recompute the weights
+// from uscale / base and the spline tables with the arithmetic of k_pme_prep (pme_tap_w / pme_taps3), so the values are the same bits.
+__global__ __launch_bounds__(256) void k_pme_prep_light(int N, int K, const double* __restrict__ xyz, double k00, double k01, double k02, double k10, double k11,
+                                                        double k12, double k20, double k21, double k22, double* __restrict__ uscale, int* __restrict__ base,
+                                                        double* __restrict__ fault, const int* __restrict__ inv_perm, double* __restrict__ uscale_s,
+                                                        int* __restrict__ base_s) {      // *_s: the same values in cell-sorted atom order (what the tiled kernels read, coalesced)
+#pragma clang fp contract(off)
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * N) return;
+  const int i = t / 3, l = t - 3 * i;
+  const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  const double ka = l == 0 ? k00 : l == 1 ? k10 : k20, kb = l == 0 ? k01 : l == 1 ? k11 : k21, kc = l == 0 ? k02 : l == 1 ? k12 : k22;
+  double u = (double)K * ((ka * x + kb * y) + kc * z);
+  if (u < 0.0) u = u + (double)K; else if (u >= (double)K) u = u - (double)K;
+  if (!(u >= 0.0 && u < (double)K)) { *fault = 1.0; u = 0.5; }
+  if (fabs(fmod(u, 1.0)) < 1e-6) u = u + 1e-6;
+  const int np = (int)floor(u);
+  uscale[t] = u; base[t] = np;
+  const int ts = 3 * inv_perm[i] + l;
+  uscale_s[ts] = u; base_s[ts] = np;
+}
+
+// Table rows without the fp64 divisions: (int)ceil(a / div * G) equals ceil(a * (G / div)) unless the product lies within ~1e-10 of an integer
+// (the reference rounds twice, the product once: both are a few 1e-11 from the exact quotient at G = 1e5).  A wavefront in which any lane comes
+// closer than 1e-9 takes the reference's own expression for all its lanes - a scalar branch with no memory operation behind it, so the
+// table loads of all taps go out together.
+__device__ __forceinline__ double pme_tap_w(double u, int np, int k, double G, const double* __restrict__ B6) {
+  const double a1 = u - (double)(np - k);
+  const double t = a1 * (G / 6.0), ct = ceil(t), gap = ct - t;
+  int r = (int)ct;
+  if (__builtin_expect(__any(gap < 1e-9 || gap > 1.0 - 1e-9), 0)) r = (int)ceil(a1 / 6.0 * G);
+  return B6[r - 1];
+}
+// weight and derivative weight of tap k of the three axes (u, np: scaled coordinate and nearest grid point per axis) - the values k_pme_prep
+// stores (src/pme.f90:220-247, :412-414); nine independent table loads
+__device__ __forceinline__ void pme_taps3(double u1, double u2, double u3, int n1, int n2, int n3, int k, double G, const double* __restrict__ B6,
+                                          const double* __restrict__ B5, double (&w)[3], double (&dw)[3]) {
+  const double u[3] = {u1, u2, u3};
+  const int np[3] = {n1, n2, n3};
+  const double G6 = G / 6.0, G5 = G / 5.0;
+  double a1[3], a2[3];
+  int r6[3], ra[3], rb[3];
+  bool rare = false;
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    a1[l] = u[l] - (double)(np[l] - k); a2[l] = a1[l] - 1.0;
+    const double t6 = a1[l] * G6, c6 = ceil(t6), ta = a1[l] * G5, ca = ceil(ta), tb = a2[l] * G5, cb = ceil(tb);
+    const double g6 = c6 - t6, ga = ca - ta, gb = cb - tb;
+    rare |= g6 < 1e-9 || g6 > 1.0 - 1e-9 || ga < 1e-9 || ga > 1.0 - 1e-9 || gb < 1e-9 || gb > 1.0 - 1e-9;
+    r6[l] = (int)c6; ra[l] = (int)ca; rb[l] = (int)cb;
+  }
+  if (__builtin_expect(__any(rare), 0)) {
+#pragma unroll
+    for (int l = 0; l < 3; ++l) { r6[l] = (int)ceil(a1[l] / 6.0 * G); ra[l] = (int)ceil(a1[l] / 5.0 * G); rb[l] = (int)ceil(a2[l] / 5.0 * G); }
+  }
+  const int Gi = (int)G;
+  double v6[3], va[3], vb[3];
+#pragma unroll
+  for (int l = 0; l < 3; ++l) { v6[l] = B6[r6[l] - 1]; va[l] = B5[min(ra[l], Gi) - 1]; vb[l] = B5[max(rb[l], 1) - 1]; }      // (rows of terms that do not apply are clamped into the table, their values dropped)
+#pragma unroll
+  for (int l = 0; l < 3; ++l) { w[l] = v6[l]; dw[l] = (a1[l] < 5.0 ? va[l] : 0.0) - (0.0 < a2[l] ? vb[l] : 0.0); }
+}
+
 // one thread per (atom, k3, k2); the 6 k1 taps are consecutive grid points (modulo wrap)
 __global__ __launch_bounds__(256) void k_pme_spread(int N, int K, const double* __restrict__ chg, const int* __restrict__ base,
                                                     const double* __restrict__ w, double* __restrict__ grid, int gs) {
@@ -79,7 +143,8 @@ constexpr int SPREAD_CHUNK = 64;      // atoms of a cell staged in LDS at a time
 // last list build fall back to a direct global atomic.
 __global__ __launch_bounds__(512) void k_pme_spread_tiles(int K, int3 nc, int3 T, const int* __restrict__ cell_start, const int* __restrict__ perm,
                                                           const double* __restrict__ chg, const int* __restrict__ base, const double* __restrict__ w,
-                                                          double* __restrict__ grid, int gs) {      // gs = 2: real parts of a complex grid, 1: real grid
+                                                          double* __restrict__ grid, int gs,      // gs = 2: real parts of a complex grid, 1: real grid
+                                                          const double* __restrict__ uscale, const double* __restrict__ B6, int G) {      // w == nullptr: weights from the table
   extern __shared__ double tile[];
   const int cidx = blockIdx.x;
   const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
@@ -100,8 +165,13 @@ __global__ __launch_bounds__(512) void k_pme_spread_tiles(int K, int3 nc, int3 T
   for (int c0 = s; c0 < e; c0 += SPREAD_CHUNK) {
     const int n = min(SPREAD_CHUNK, e - c0);
     __syncthreads();      // tile zeroed / previous chunk consumed
-    for (int k = threadIdx.x; k < n * 18; k += blockDim.x) { const int a = k / 18, r = k - 18 * a; sw[k] = w[(size_t)perm[c0 + a] * 18 + r]; }
-    for (int k = threadIdx.x; k < n * 3; k += blockDim.x) { const int a = k / 3, r = k - 3 * a; sb[k] = base[3 * perm[c0 + a] + r]; }
+    if (w) for (int k = threadIdx.x; k < n * 18; k += blockDim.x) { const int a = k / 18, r = k - 18 * a; sw[k] = w[(size_t)perm[c0 + a] * 18 + r]; }
+    else for (int k = threadIdx.x; k < n * 18; k += blockDim.x) {
+      const int a = k / 18, r = k - 18 * a, l = r / 6, i3 = 3 * (c0 + a) + l;      // (uscale / base in cell-sorted order here)
+      sw[k] = pme_tap_w(uscale[i3], base[i3], r - 6 * l, (double)G, B6);
+    }
+    if (w) for (int k = threadIdx.x; k < n * 3; k += blockDim.x) { const int a = k / 3, r = k - 3 * a; sb[k] = base[3 * perm[c0 + a] + r]; }
+    else for (int k = threadIdx.x; k < n * 3; k += blockDim.x) sb[k] = base[3 * c0 + k];
     for (int a = threadIdx.x; a < n; a += blockDim.x) sq[a] = chg[perm[c0 + a]];
     __syncthreads();
     for (int t = threadIdx.x; t < n * 36; t += blockDim.x) {
@@ -525,6 +595,148 @@ __global__ __launch_bounds__(512) void k_pme_gather_tiles(int K, int3 nc, int3 T
   }
 }
 
+// The same gather WITHOUT the weight store (k_pme_prep_light: uscale / base in cell-sorted order).  Lane `sub` of an atom's 8-lane group takes
+// tap `sub` of the three axes from the spline tables (pme_taps3: the bits k_pme_prep stores); the group exchanges the x and y
+// values through 192 B of LDS of its own (the group sits inside one wavefront: in-order LDS, no workgroup barrier), the z tap stays with its
+// lane.  The table loads of an atom go out one trip ahead: trip 0's before the tile fill, from global (u, nearpt); the later ones before the
+// stencil sums of the trip in front of them, from the cell's (u, nearpt) staged in LDS beside the tile - no global load waits inside the loop.
+// Same sums in the same order as k_pme_gather_tiles: bit-identical forces.
+__global__ __launch_bounds__(512) void k_pme_gather_tiles_wl(int K, int3 nc, int3 T, const int* __restrict__ cell_start, const int* __restrict__ perm,
+                                                             const double* __restrict__ chg, const int* __restrict__ base_s, const double* __restrict__ uscale_s,
+                                                             const double* __restrict__ B6, const double* __restrict__ B5, int G, int cap,
+                                                             const double* __restrict__ theta, double conv, double k00, double k01,
+                                                             double k02, double k10, double k11, double k12, double k20, double k21, double k22,
+                                                             double* __restrict__ F_recip, double* __restrict__ F, int atomic, int add_lo, int add_hi) {
+  extern __shared__ double tile[];
+  const int cidx = blockIdx.x;
+  const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
+  const int ox = (int)floor((double)cx * K / nc.x) - 6, oy = (int)floor((double)cy * K / nc.y) - 6, oz = (int)floor((double)cz * K / nc.z) - 6;
+  const int P = T.x | 1, P2 = spread_plane_stride(T);
+  const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3, ngrp = blockDim.x >> 3;
+  double* const xw = tile + P2 * T.z + 24 * grp;      // {w_x[6], w_y[6], dw_x[6], dw_y[6]} of the group's atom
+  double* const cu = tile + P2 * T.z + 24 * ngrp;     // [3 cap] scaled coordinates of the cell's atoms ...
+  int* const cb = (int*)(cu + 3 * cap);                // [3 cap] ... and their nearest grid points
+  const int s = cell_start[cidx], e = cell_start[cidx + 1];
+  const double Gd = (double)G;
+  // taps of the atom one trip ahead (registers): x, y, z weights and derivative weights of tap `sub`, nearest grid points, atom, charge
+  double nw1 = 0.0, nw2 = 0.0, nw3 = 0.0, nd1 = 0.0, nd2 = 0.0, nd3 = 0.0, nq = 0.0;
+  int nb1 = 0, nb2 = 0, nb3 = 0, ni = 0;
+  if (s + grp < e) {
+    const int ia = s + grp;
+    ni = perm[ia]; nq = chg[ni];
+    if (sub < 6) {
+      nb1 = base_s[3 * ia]; nb2 = base_s[3 * ia + 1]; nb3 = base_s[3 * ia + 2];
+      const double u1 = uscale_s[3 * ia], u2 = uscale_s[3 * ia + 1], u3 = uscale_s[3 * ia + 2];
+      double tw[3], td[3];
+      pme_taps3(u1, u2, u3, nb1, nb2, nb3, sub, Gd, B6, B5, tw, td);
+      nw1 = tw[0]; nw2 = tw[1]; nw3 = tw[2]; nd1 = td[0]; nd2 = td[1]; nd3 = td[2];
+    }
+  }
+  const bool staged = e - s <= cap;      // (a cell larger than the host knew: the later trips read (u, nearpt) from global memory as trip 0 does)
+  if (staged) for (int k = threadIdx.x; k < 3 * (e - s); k += blockDim.x) { cu[k] = uscale_s[3 * s + k]; cb[k] = base_s[3 * s + k]; }
+  {      // stage the potential: x fastest (coalesced rows of T.x points); four loads in flight per thread
+    const int ntile = T.x * T.y * T.z, txy = T.x * T.y;
+    for (int r0 = threadIdx.x; r0 < ntile; r0 += 4 * blockDim.x) {
+      double v[4]; int dst[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * blockDim.x;
+        dst[u] = -1;
+        if (r < ntile) {
+          const int cc = r / txy, rem = r - cc * txy, b = rem / T.x, a = rem - b * T.x;
+          int n1 = ox + a; n1 += n1 < 0 ? K : 0; n1 -= n1 >= K ? K : 0;
+          int n2 = oy + b; n2 += n2 < 0 ? K : 0; n2 -= n2 >= K ? K : 0;
+          int n3 = oz + cc; n3 += n3 < 0 ? K : 0; n3 -= n3 >= K ? K : 0;
+          v[u] = theta[n1 + (size_t)K * (n2 + (size_t)K * n3)];
+          dst[u] = a + P * b + P2 * cc;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (dst[u] >= 0) tile[dst[u]] = v[u];
+    }
+  }
+  __syncthreads();
+  for (int a0 = s; a0 < e; a0 += ngrp) {      // uniform trip count per wave (shuffles below)
+    const int ia = a0 + grp;
+    const bool live = ia < e;
+    const int i = ni, b1 = nb1, b2 = nb2, b3 = nb3;
+    const double w3 = nw3, d3 = nd3, q = nq;
+    if (live && sub < 6) { xw[sub] = nw1; xw[6 + sub] = nw2; xw[12 + sub] = nd1; xw[18 + sub] = nd2; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double w1[6], d1[6];
+    if (live && sub < 6) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { w1[k] = xw[k]; d1[k] = xw[12 + k]; }
+    }
+    {      // the next trip's atom: table loads in flight during this trip's sums
+      const int ja = ia + ngrp;
+      if (ja < e) {
+        ni = perm[ja]; nq = chg[ni];
+        if (sub < 6) {
+          const int o = 3 * (ja - s);
+          double u1, u2, u3;
+          if (staged) { nb1 = cb[o]; nb2 = cb[o + 1]; nb3 = cb[o + 2]; u1 = cu[o]; u2 = cu[o + 1]; u3 = cu[o + 2]; }
+          else { nb1 = base_s[3 * ja]; nb2 = base_s[3 * ja + 1]; nb3 = base_s[3 * ja + 2]; u1 = uscale_s[3 * ja]; u2 = uscale_s[3 * ja + 1]; u3 = uscale_s[3 * ja + 2]; }
+          double tw[3], td[3];
+          pme_taps3(u1, u2, u3, nb1, nb2, nb3, sub, Gd, B6, B5, tw, td);
+          nw1 = tw[0]; nw2 = tw[1]; nw3 = tw[2]; nd1 = td[0]; nd2 = td[1]; nd3 = td[2];
+        }
+      }
+    }
+    double f1 = 0.0, f2 = 0.0, f3 = 0.0;
+    if (live && sub < 6) {
+      // tile-local coordinate of tap 0 per axis; the 6 taps walk down: all inside the tile <=> 5 <= l < T
+      int l1 = b1 - ox; l1 += l1 < 0 ? K : 0; l1 -= l1 >= K ? K : 0;
+      int l2 = b2 - oy; l2 += l2 < 0 ? K : 0; l2 -= l2 >= K ? K : 0;
+      int l3 = b3 - oz; l3 += l3 < 0 ? K : 0; l3 -= l3 >= K ? K : 0;
+      const bool in_tile = l1 >= 5 && l1 < T.x && l2 >= 5 && l2 < T.y && l3 >= 5 && l3 < T.z;
+      if (in_tile) {
+        const double* plane = tile + P2 * (l3 - sub) + l1;
+#pragma unroll
+        for (int k2 = 0; k2 < 6; ++k2) {
+          const double* row = plane + P * (l2 - k2);
+          const double w2 = xw[6 + k2], d2 = xw[18 + k2];
+          double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { const double th = row[-k]; s0 += w1[k] * th; s1 += d1[k] * th; }
+          f1 += s1 * w2 * w3; f2 += s0 * d2 * w3; f3 += s0 * w2 * d3;
+        }
+      } else {      // the stencil left the tile since the last list build: from global memory
+        int n3 = b3 - sub; if (n3 < 0) n3 += K;
+        int n1[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { int n = b1 - k; if (n < 0) n += K; n1[k] = n; }
+#pragma unroll
+        for (int k2 = 0; k2 < 6; ++k2) {
+          int n2 = b2 - k2; if (n2 < 0) n2 += K;
+          const double* row = theta + (size_t)K * (n2 + (size_t)K * n3);
+          const double w2 = xw[6 + k2], d2 = xw[18 + k2];
+          double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { const double th = row[n1[k]]; s0 += w1[k] * th; s1 += d1[k] * th; }
+          f1 += s1 * w2 * w3; f2 += s0 * d2 * w3; f3 += s0 * w2 * d3;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();      // (the next trip's taps overwrite xw)
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); f3 += __shfl_xor(f3, o, 64); }
+    if (live && sub == 0) {
+      const double sc = q * conv;
+      f1 *= sc; f2 *= sc; f3 *= sc;
+      const double Kd = (double)K;
+      const double fx = -Kd * (k00 * f1 + k10 * f2 + k20 * f3);
+      const double fy = -Kd * (k01 * f1 + k11 * f2 + k21 * f3);
+      const double fz = -Kd * (k02 * f1 + k12 * f2 + k22 * f3);
+      F_recip[3 * i] = fx; F_recip[3 * i + 1] = fy; F_recip[3 * i + 2] = fz;
+      if (F && i >= add_lo && i < add_hi) {
+        if (atomic) { atomicAdd(&F[3 * i], fx); atomicAdd(&F[3 * i + 1], fy); atomicAdd(&F[3 * i + 2], fz); }
+        else { F[3 * i] += fx; F[3 * i + 1] += fy; F[3 * i + 2] += fz; }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // stream of the PME front end (prep ... inverse FFT): the side stream while the principal pair loop runs on the main one
@@ -540,7 +752,7 @@ int pme_setup(msevb_ctx* c) {
   if (!g_rocfft_ready) { if (rocfft_setup() != rocfft_status_success) FAIL(MSEVB_ERR_FFT, "rocfft_setup failed"); g_rocfft_ready = true; }
   const int batch = c->fft_batch < 1 ? 1 : c->fft_batch;
   if (c->d_grid.alloc(K3 * batch) || c->d_Q.alloc(K3) || c->d_theta.alloc(K3) || c->d_w.alloc(18 * (size_t)N) || c->d_dw.alloc(18 * (size_t)N) || c->d_uscale.alloc(3 * (size_t)N) ||
-      c->d_base.alloc(3 * (size_t)N) || c->d_base_s.alloc(3 * (size_t)N) || c->d_w_s.alloc(18 * (size_t)N) || c->d_splindex.alloc(18 * (size_t)N) || c->d_force_recip.alloc(3 * (size_t)N))
+      c->d_base.alloc(3 * (size_t)N) || c->d_base_s.alloc(3 * (size_t)N) || c->d_uscale_s.alloc(3 * (size_t)N) || c->d_w_s.alloc(18 * (size_t)N) || c->d_splindex.alloc(18 * (size_t)N) || c->d_force_recip.alloc(3 * (size_t)N))
     FAIL(MSEVB_ERR_HIP, "hipMalloc failed (PME)");
   size_t len[3] = {(size_t)K, (size_t)K, (size_t)K};
   pme_teardown(c);
@@ -643,9 +855,30 @@ int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part
   return MSEVB_OK;
 }
 
+// whether the tiled spread / gather serve this context (workgroup per neighbour cell, tile in LDS)
+static bool pme_tiles_ok(const msevb_ctx* c) {
+  int3 T;
+  T.x = (int)ceil((double)c->K / c->ncell[0]) + 8; T.y = (int)ceil((double)c->K / c->ncell[1]) + 8; T.z = (int)ceil((double)c->K / c->ncell[2]) + 8;
+  const size_t tile_bytes = (size_t)spread_plane_stride(T) * T.z * sizeof(double) + (size_t)SPREAD_CHUNK * (18 * 8 + 8 + 12);
+  return c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= c->K && T.y <= c->K && T.z <= c->K;
+}
+// no weight store this call: the tiled kernels run, nothing else that reads d_w / d_dw does (the caller says so: weights_needed_now)
+bool pme_weightless_now(const msevb_ctx* c) {
+  const bool other_spread = c->cells_valid && (c->spread_bricks || c->spread_mfma);
+  return c->pme_weightless && !c->weights_needed_now && pme_tiles_ok(c) && !other_spread;
+}
+
 int pme_prepare_atoms(msevb_ctx* c, bool with_indices) {
   const int N = c->N;
   const long nt = 18L * N;
+  if (!with_indices && pme_weightless_now(c)) {
+    hipLaunchKernelGGL(k_pme_prep_light, dim3((unsigned)((3 * N + 255) / 256)), dim3(256), 0, pme_stream(c), N, c->K, c->d_xyz.p, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
+                       c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_uscale.p, c->d_base.p, c->d_energies.p + S_FAULT, c->d_inv_perm.p, c->d_uscale_s.p, c->d_base_s.p);
+    HIPCHK(hipGetLastError());
+    c->weights_valid = false;
+    return MSEVB_OK;
+  }
+  c->weights_valid = true;
   hipLaunchKernelGGL(k_pme_prep, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, pme_stream(c), N, c->K, c->spline_grid, c->d_xyz.p, c->kk[0][0], c->kk[0][1],
                      c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, c->d_uscale.p,
                      c->d_base.p, with_indices ? c->d_splindex.p : (int*)nullptr, c->d_w.p, c->d_dw.p, c->d_energies.p + S_FAULT,
@@ -664,6 +897,15 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
     const size_t tile_bytes = (size_t)spread_plane_stride(T) * T.z * sizeof(double);
     if (c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= c->K && T.y <= c->K && T.z <= c->K) {      // workgroup per cell, potential staged in LDS
       const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
+      if (!c->weights_valid) {      // k_pme_prep_light ran: per workgroup 192 B of LDS per 8-lane group + 36 B per atom of the largest cell
+        const int cap = std::min(std::max((int)(c->cell_atoms_max * 1.05) + 1, 16), 1024);      // (the largest cell of the last build whose statistics the host has seen)
+        const size_t lds = tile_bytes + (size_t)c->pme_tile_threads * 24 + (size_t)cap * 36 + 8;
+        if (lds > 160 * 1024) FAIL(MSEVB_ERR_LIMIT, "pme_gather: cell too large for the weight-free gather (set option pme_weightless=0)");
+        if (lds > 64 * 1024 && c->attr_gather_wl < (int)lds) { HIPCHK(hipFuncSetAttribute((const void*)k_pme_gather_tiles_wl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); c->attr_gather_wl = (int)lds; }
+        hipLaunchKernelGGL(k_pme_gather_tiles_wl, dim3(ncell), dim3(c->pme_tile_threads), lds, c->stream, c->K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T, c->d_cell_start.p, c->d_perm.p,
+                           chg, c->d_base_s.p, c->d_uscale_s.p, c->d_B6.p, c->d_B5.p, c->spline_grid, cap, theta ? theta : c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
+                           c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, atomic ? 1 : 0, add_lo, add_hi);
+      } else
       hipLaunchKernelGGL(k_pme_gather_tiles, dim3(ncell), dim3(c->pme_tile_threads), tile_bytes, c->stream, c->K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T, c->d_cell_start.p, c->d_perm.p,
                          chg, c->d_base.p, c->d_w.p, c->d_dw.p, theta ? theta : c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2],
                          c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, atomic ? 1 : 0, add_lo, add_hi);
@@ -671,6 +913,7 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
       return MSEVB_OK;
     }
   }
+  if (!c->weights_valid) FAIL(MSEVB_ERR_STATE, "pme_gather: the per-atom weights of this step were not stored (option pme_weightless) and the tiled gather does not serve this context");
   hipLaunchKernelGGL(k_pme_gather, dim3((N * 8 + 255) / 256), dim3(256), 0, c->stream, N, c->K, chg, c->d_base.p, c->d_w.p, c->d_dw.p, theta ? theta : c->d_theta.p, c->conv, c->kk[0][0],
                      c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, atomic ? 1 : 0, add_lo, add_hi);
   HIPCHK(hipGetLastError());
@@ -692,7 +935,7 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
   // side stream it is captured once into a hipGraph and replayed with one launch (the ~14 launches cost the host ~80 us per step, and
   // the host is what decides when the EVB chains behind them can start).  Steps that sample the phase timers launch directly.
   struct Key { const void* p[9]; int v[8]; } key = {{c->d_grid.p, c->d_Q.p, c->d_theta.p, c->d_w.p, c->d_base.p, c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_fft_work.p},
-                                               {N, K, c->ncell[0], c->ncell[1], c->ncell[2], c->cells_valid ? 1 : 0, (c->spread_tiles ? 1 : 0) + (c->spread_mfma ? 2 : 0) + (c->spread_bricks ? 4 : 0) + (fft_lds_usable(c) ? 8 : 0) + (c->pme_split_now ? 16 : 0), slot_recip}};
+                                               {N, K, c->ncell[0], c->ncell[1], c->ncell[2], c->cells_valid ? 1 : 0, (c->spread_tiles ? 1 : 0) + (c->spread_mfma ? 2 : 0) + (c->spread_bricks ? 4 : 0) + (fft_lds_usable(c) ? 8 : 0) + (c->pme_split_now ? 16 : 0) + (pme_weightless_now(c) ? 32 : 0), slot_recip}};
   const bool use_graph = join_aux && c->graphs && !c->timing_now;
   bool capturing = false;
   int nbk = 0;
@@ -730,7 +973,7 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
       } else if (c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= K && T.y <= K && T.z <= K) {
         const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
         hipLaunchKernelGGL(k_pme_spread_tiles, dim3(ncell), dim3(c->pme_tile_threads), tile_bytes, st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T,
-                           c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_base.p, c->d_w.p, g, gs);
+                           c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->weights_valid ? c->d_base.p : c->d_base_s.p, c->weights_valid ? c->d_w.p : (const double*)nullptr, g, gs, c->d_uscale_s.p, c->d_B6.p, c->spline_grid);
       } else {
         const long nt = (long)N * 36;
         hipLaunchKernelGGL(k_pme_spread, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, N, K, c->d_chg.p, c->d_base.p, c->d_w.p, g, gs);

@@ -128,6 +128,32 @@ def test_mfma_charge_spreading_config_B():
         assert np.abs(out[k][3] - out[0][3]).max() < 1e-8 * np.abs(out[0][3]).max() and np.abs(out[k][4] - out[0][4]).max() < 1e-8, k
 
 
+def test_pme_without_the_weight_store_changes_nothing():
+    """option pme_weightless (default on): k_pme_prep_light keeps (u, nearpt) only and the tiled spread / gather take the B-spline weights from the
+    tables themselves (grid_Q / derivative_grid_Q, src/pme.f90:184-262, :346-493, table rows :220-247, :412-414) - the SAME bits as with the
+    324 B/atom store of k_pme_prep, at BASELINE.json configs[2] size; the MS-EVB call with per-diabat transforms still gets its stored weights"""
+    spec = _synthetic(32, 8, 11, 64)
+    out = []
+    for wl in (0, 1):
+        h = api.MsEvbHip(spec)
+        h.set_option("pme_weightless", wl)
+        h.construct_verlet_list()
+        h.zero_forces()
+        er = h.pme_reciprocal_space_energy_force()
+        Q, th, u, fr = h.pme_state()
+        F = h.get_forces()
+        e, Fe = h.ms_evb_calculate_total_force_energy()
+        h.set_option("evb_recip_linear", 0)
+        e2, Fe2 = h.ms_evb_calculate_total_force_energy()
+        out.append((er, Q, th, u, F, e, Fe, e2, Fe2))
+        h.close()
+    a, b = out
+    # (the weights are the same bits; the LDS atomics of the spread add them in order of arrival, so the grids agree to rounding)
+    assert rel(a[0], b[0]) < 1e-14 and np.abs(a[1] - b[1]).max() < 1e-14 and np.abs(a[2] - b[2]).max() < 1e-13 and np.array_equal(a[3], b[3]) and np.abs(a[4] - b[4]).max() < 1e-12
+    assert rel(a[5], b[5]) < 1e-14 and np.abs(a[6] - b[6]).max() < 1e-11      # (the EVB call sums with atomics: order of arrival, not bits)
+    assert rel(a[7], b[7]) < 1e-14 and np.abs(a[8] - b[8]).max() < 1e-11
+
+
 @pytest.mark.parametrize("opts", [{"evb_defer_fold": 0}, {"evb_prelaunch_blend": 1}, {"evb_defer_molecules": 1}, {"evb_region_main": 1},
                                   {"evb_coupling_blocks": 96}, {"evb_recip_linear": 0}, {"fft_own": 0, "evb_defer_fold": 0, "evb_prelaunch_blend": 1},
                                   {"overlap": 0, "graphs": 0}])

@@ -6,7 +6,7 @@ switches on) runs the MS-EVB force call of BASELINE.json configs[2] (98 220 atom
 fixed ground-state vector - everything a rank does between the two collectives of a step, nothing of the collectives themselves (the
 all-gather carries 2S + 9 doubles, the all-reduce 24 B/atom = 2.4 MB).  Reported: the slowest rank's time over the one-rank time.
 
-    python tools/virtual_rank_times.py [calls]
+    python tools/virtual_rank_times.py [calls] [B|C]      (C = configs[4]'s size: 985 527 atoms, 16 diabats, 128^3)
 """
 import json
 import os
@@ -42,9 +42,11 @@ def rank_time(spec, r, R, eigvec, calls):
 
 def main():
     calls = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    s = synth.make_system(32, n_diabat=8, seed=0, max_chain=3)      # bench.py's default workload
+    cfg = sys.argv[2] if len(sys.argv) > 2 else "B"
+    n_side, n_dia, grid, chain = (69, 16, 128, 4) if cfg == "C" else (32, 8, 64, 3)      # B = bench.py's default workload
+    s = synth.make_system(n_side, n_diabat=n_dia, seed=0, max_chain=chain)
     p = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"])
-    spec = system.from_synth(s, p, rc=9.0, rv=10.5, alpha=0.3, pme_grid=64, max_chain=3)
+    spec = system.from_synth(s, p, rc=9.0, rv=10.5, alpha=0.3, pme_grid=grid, max_chain=chain)
     h = api.MsEvbHip(spec)
     h.ms_evb_calculate_total_force_energy(want_force=False)
     ev = h.evb_state()["eigvec"].copy()
@@ -60,7 +62,7 @@ def main():
             t1 = ts[0]
         out[R] = {"us_per_rank": [round(t, 1) for t in ts], "slowest_over_one_rank": round(max(ts) / t1, 3), "n_diabats": int(D)}
         print("R=%d  slowest %.1f us  (x%.3f of one rank)  per rank: %s" % (R, max(ts), max(ts) / t1, " ".join("%.0f" % t for t in ts)), flush=True)
-    print(json.dumps({"workload": "98220 atoms, 8 diabats, 64^3, force call + own share of the blend, no collectives", "calls": calls, "ranks": out}))
+    print(json.dumps({"workload": "%d atoms, %d diabats, %d^3, force call + own share of the blend, no collectives" % (spec.n_atom, n_dia, grid), "calls": calls, "ranks": out}))
 
 
 if __name__ == "__main__":

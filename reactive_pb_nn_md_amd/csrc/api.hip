@@ -760,6 +760,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
   if (s == "pme_weightless") { c->pme_weightless = v != 0.0; return MSEVB_OK; }
   if (s == "spread_mfma") { c->spread_mfma = v != 0.0; return MSEVB_OK; }
+  if (s == "gather_mfma") { c->gather_mfma = v != 0.0; return MSEVB_OK; }
   if (s == "evb_pme_split") { c->evb_pme_split = v != 0.0; return MSEVB_OK; }
   if (s == "evb_single_join") { c->evb_single_join = v != 0.0; return MSEVB_OK; }
   if (s == "evb_defer_fold") { c->evb_defer_fold = v != 0.0; return MSEVB_OK; }

@@ -737,6 +737,153 @@ __global__ __launch_bounds__(512) void k_pme_gather_tiles_wl(int K, int3 nc, int
   }
 }
 
+// MFMA gather (option gather_mfma; north_star: "... spreading/GATHERING contraction"): the transpose of k_pme_spread_mfma.  One workgroup
+// (4 waves) per neighbour cell, the cell's 16^3 potential tile in LDS.  For 16 atoms at a time and every plane z of the tile two GEMMs
+//     G_z[y][a] = sum_x theta_z[y][x] Wx_a[x],     H_z[y][a] = sum_x theta_z[y][x] dWx_a[x]          (M = y = 16, N = atoms = 16, K = x = 16)
+// on v_mfma_f64_16x16x4_f64 (A[row = y = lane & 15][k = lane >> 4] = theta_z[y][4 j + k], B[k][col = a = lane & 15] = the atom's DENSE x vector,
+// built from its six taps; D[row = y = (lane >> 4) + 4 v][col = a]), then per lane the y and z contractions of derivative_grid_Q
+// (src/pme.f90:346-493):  f1 += Wz[z] sum_y Wy[y] H,  f2 += Wz[z] sum_y dWy[y] G,  f3 += dWz[z] sum_y Wy[y] G, and a 4-lane sum over the y quarters.
+// A wave takes the cell's 16-atom blocks round-robin.  16/6 of the direct loop's multiply-adds along x and all 16 x 16 (y, z) pairs instead of
+// 6 x 6: the matrix cores of gfx950 run fp64 at the rate of the vector units, so this is a measurement, not the default.
+// Atoms whose stencil left the tile since the last list build are gathered from global memory, 8 lanes per atom, as k_pme_gather does.
+constexpr int GM_ROW = 17, GM_PLANE = 17 * 16;      // LDS pitches of the potential tile (doubles): the 16 rows an A operand reads fall into distinct banks
+__global__ __launch_bounds__(256) void k_pme_gather_mfma(int K, int3 nc, const int* __restrict__ cell_start, const int* __restrict__ perm,
+                                                         const double* __restrict__ chg, const int* __restrict__ base, const double* __restrict__ w,
+                                                         const double* __restrict__ dw, const double* __restrict__ theta, double conv, double k00, double k01,
+                                                         double k02, double k10, double k11, double k12, double k20, double k21, double k22,
+                                                         double* __restrict__ F_recip, double* __restrict__ F, int atomic, int add_lo, int add_hi) {
+  extern __shared__ double sm[];
+  double* tile = sm;                                   // [16][16][17]
+  double* sw_all = sm + 16 * GM_PLANE;                 // [4 waves][16 atoms][36]: w[3][6], dw[3][6]
+  int* sl_all = (int*)(sw_all + 4 * 16 * 36);          // [4][16][4]: tile-local tap-0 coordinates, atom (or -1)
+  __shared__ int s_out[512], s_nout;
+  const int cidx = blockIdx.x;
+  const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
+  const int ox = (int)floor((double)cx * K / nc.x) - 6, oy = (int)floor((double)cy * K / nc.y) - 6, oz = (int)floor((double)cz * K / nc.z) - 6;
+  const int s = cell_start[cidx], e = cell_start[cidx + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_nout = 0;
+  for (int r0 = threadIdx.x; r0 < 4096; r0 += 4 * blockDim.x) {      // the whole 16^3 tile, x fastest, four loads in flight per thread
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * blockDim.x, a = r & 15, b = (r >> 4) & 15, cc = r >> 8;
+      int n1 = ox + a; n1 += n1 < 0 ? K : 0; n1 -= n1 >= K ? K : 0;
+      int n2 = oy + b; n2 += n2 < 0 ? K : 0; n2 -= n2 >= K ? K : 0;
+      int n3 = oz + cc; n3 += n3 < 0 ? K : 0; n3 -= n3 >= K ? K : 0;
+      v[u] = theta[n1 + (size_t)K * (n2 + (size_t)K * n3)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int r = r0 + u * blockDim.x; tile[(r & 15) + GM_ROW * ((r >> 4) & 15) + GM_PLANE * (r >> 8)] = v[u]; }
+  }
+  __syncthreads();
+  double* sw = sw_all + wave * 16 * 36;
+  int* sl = sl_all + wave * 16 * 4;
+  const int col = lane & 15, kq = lane >> 4;
+  const double Kd = (double)K;
+  for (int b0 = s + 16 * wave; b0 < e; b0 += 64) {      // this wave's 16-atom blocks
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();      // (the block before has been read)
+    if (lane < 16) {
+      const int ia = b0 + lane;
+      int i = -1, l1 = 5, l2 = 5, l3 = 5;
+      if (ia < e) {
+        i = perm[ia];
+        l1 = base[3 * i] - ox; l1 += l1 < 0 ? K : 0; l1 -= l1 >= K ? K : 0;
+        l2 = base[3 * i + 1] - oy; l2 += l2 < 0 ? K : 0; l2 -= l2 >= K ? K : 0;
+        l3 = base[3 * i + 2] - oz; l3 += l3 < 0 ? K : 0; l3 -= l3 >= K ? K : 0;
+        if (!(l1 >= 5 && l1 < 16 && l2 >= 5 && l2 < 16 && l3 >= 5 && l3 < 16)) { const int slot = atomicAdd(&s_nout, 1); if (slot < 512) s_out[slot] = i; i = -1; l1 = l2 = l3 = 5; }      // (the host launches this kernel for cells of <= 512 atoms)
+      }
+      sl[4 * lane] = l1; sl[4 * lane + 1] = l2; sl[4 * lane + 2] = l3; sl[4 * lane + 3] = i;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int k = lane; k < 16 * 36; k += 64) {
+      const int a = k / 36, r = k - 36 * a, i = sl[4 * a + 3];
+      sw[k] = i < 0 ? 0.0 : r < 18 ? w[(size_t)i * 18 + r] : dw[(size_t)i * 18 + r - 18];      // (an atom that is not done here has zero weights)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int l1 = sl[4 * col], l2 = sl[4 * col + 1], l3 = sl[4 * col + 2], i = sl[4 * col + 3];
+    const double* swa = sw + 36 * col;
+    double bx[4], bdx[4], wy[4], dwy[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int dx = l1 - (4 * j + kq), dy = l2 - (kq + 4 * j);
+      const bool okx = dx >= 0 && dx < 6, oky = dy >= 0 && dy < 6;
+      const int cxk = okx ? dx : 0, cyk = oky ? dy : 0;
+      bx[j] = okx ? swa[cxk] : 0.0; bdx[j] = okx ? swa[18 + cxk] : 0.0;
+      wy[j] = oky ? swa[6 + cyk] : 0.0; dwy[j] = oky ? swa[24 + cyk] : 0.0;
+    }
+    double f1 = 0.0, f2 = 0.0, f3 = 0.0;
+    for (int z = 0; z < 16; ++z) {
+      const int dz = l3 - z;
+      const bool okz = dz >= 0 && dz < 6;
+      if (!__any(okz)) continue;      // no atom of the block reaches this plane
+      const double wz = okz ? swa[12 + dz] : 0.0, dwz = okz ? swa[30 + dz] : 0.0;
+      mfma_d4 G = (mfma_d4){0.0, 0.0, 0.0, 0.0}, H = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+      const double* arow = tile + GM_PLANE * z + GM_ROW * col + kq;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double av = arow[4 * j];
+        G = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bx[j], G, 0, 0, 0);
+        H = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bdx[j], H, 0, 0, 0);
+      }
+      double p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) { p1 += wy[v] * H[v]; p2 += dwy[v] * G[v]; p3 += wy[v] * G[v]; }
+      f1 += wz * p1; f2 += wz * p2; f3 += dwz * p3;
+    }
+    f1 += __shfl_xor(f1, 16, 64); f2 += __shfl_xor(f2, 16, 64); f3 += __shfl_xor(f3, 16, 64);
+    f1 += __shfl_xor(f1, 32, 64); f2 += __shfl_xor(f2, 32, 64); f3 += __shfl_xor(f3, 32, 64);
+    if (kq == 0 && i >= 0) {
+      const double sc = chg[i] * conv;
+      f1 *= sc; f2 *= sc; f3 *= sc;
+      const double fx = -Kd * (k00 * f1 + k10 * f2 + k20 * f3);
+      const double fy = -Kd * (k01 * f1 + k11 * f2 + k21 * f3);
+      const double fz = -Kd * (k02 * f1 + k12 * f2 + k22 * f3);
+      F_recip[3 * i] = fx; F_recip[3 * i + 1] = fy; F_recip[3 * i + 2] = fz;
+      if (F && i >= add_lo && i < add_hi) {
+        if (atomic) { atomicAdd(&F[3 * i], fx); atomicAdd(&F[3 * i + 1], fy); atomicAdd(&F[3 * i + 2], fz); }
+        else { F[3 * i] += fx; F[3 * i + 1] += fy; F[3 * i + 2] += fz; }
+      }
+    }
+  }
+  __syncthreads();
+  const int nout = min(s_nout, 512);
+  const int sub = threadIdx.x & 7;
+  for (int o0 = 0; o0 < nout; o0 += 32) {      // stencils that left the tile: from global memory, 8 lanes per atom (uniform trip count per wave: shuffles)
+    const int o = o0 + (threadIdx.x >> 3);
+    const bool live = o < nout;
+    const int i = live ? s_out[o] : 0;
+    double f1 = 0.0, f2 = 0.0, f3 = 0.0;
+    if (live && sub < 6) {
+      const int b1 = base[3 * i], b2 = base[3 * i + 1], b3 = base[3 * i + 2];
+      const double* wi = w + (size_t)i * 18;
+      const double* dwi = dw + (size_t)i * 18;
+      int n3 = b3 - sub; if (n3 < 0) n3 += K;
+      for (int k2 = 0; k2 < 6; ++k2) {
+        int n2 = b2 - k2; if (n2 < 0) n2 += K;
+        const double* row = theta + (size_t)K * (n2 + (size_t)K * n3);
+        double s0 = 0.0, s1 = 0.0;
+        for (int k = 0; k < 6; ++k) { int n1 = b1 - k; if (n1 < 0) n1 += K; const double th = row[n1]; s0 += wi[k] * th; s1 += dwi[k] * th; }
+        f1 += s1 * wi[6 + k2] * wi[12 + sub]; f2 += s0 * dwi[6 + k2] * wi[12 + sub]; f3 += s0 * wi[6 + k2] * dwi[12 + sub];
+      }
+    }
+#pragma unroll
+    for (int q = 4; q > 0; q >>= 1) { f1 += __shfl_xor(f1, q, 64); f2 += __shfl_xor(f2, q, 64); f3 += __shfl_xor(f3, q, 64); }
+    if (live && sub == 0) {
+      const double sc = chg[i] * conv;
+      f1 *= sc; f2 *= sc; f3 *= sc;
+      const double fx = -Kd * (k00 * f1 + k10 * f2 + k20 * f3);
+      const double fy = -Kd * (k01 * f1 + k11 * f2 + k21 * f3);
+      const double fz = -Kd * (k02 * f1 + k12 * f2 + k22 * f3);
+      F_recip[3 * i] = fx; F_recip[3 * i + 1] = fy; F_recip[3 * i + 2] = fz;
+      if (F && i >= add_lo && i < add_hi) {
+        if (atomic) { atomicAdd(&F[3 * i], fx); atomicAdd(&F[3 * i + 1], fy); atomicAdd(&F[3 * i + 2], fz); }
+        else { F[3 * i] += fx; F[3 * i + 1] += fy; F[3 * i + 2] += fz; }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // stream of the PME front end (prep ... inverse FFT): the side stream while the principal pair loop runs on the main one
@@ -864,7 +1011,7 @@ static bool pme_tiles_ok(const msevb_ctx* c) {
 }
 // no weight store this call: the tiled kernels run, nothing else that reads d_w / d_dw does (the caller says so: weights_needed_now)
 bool pme_weightless_now(const msevb_ctx* c) {
-  const bool other_spread = c->cells_valid && (c->spread_bricks || c->spread_mfma);
+  const bool other_spread = c->cells_valid && (c->spread_bricks || c->spread_mfma || c->gather_mfma);      // (kernels that read the stored weights)
   return c->pme_weightless && !c->weights_needed_now && pme_tiles_ok(c) && !other_spread;
 }
 
@@ -895,6 +1042,15 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
     int3 T;
     T.x = (int)ceil((double)c->K / c->ncell[0]) + 8; T.y = (int)ceil((double)c->K / c->ncell[1]) + 8; T.z = (int)ceil((double)c->K / c->ncell[2]) + 8;
     const size_t tile_bytes = (size_t)spread_plane_stride(T) * T.z * sizeof(double);
+    if (c->gather_mfma && c->cells_valid && c->weights_valid && T.x <= 16 && T.y <= 16 && T.z <= 16 && c->K >= 16 && c->cell_atoms_max <= 512) {      // 16^3 tile per cell, x contraction on the matrix cores
+      const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
+      const size_t lds = (size_t)16 * GM_PLANE * 8 + 4 * 16 * 36 * 8 + 4 * 16 * 4 * 4;
+      hipLaunchKernelGGL(k_pme_gather_mfma, dim3(ncell), dim3(256), lds, c->stream, c->K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), c->d_cell_start.p, c->d_perm.p, chg, c->d_base.p,
+                         c->d_w.p, c->d_dw.p, theta ? theta : c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1],
+                         c->kk[2][2], F_recip, F_add, atomic ? 1 : 0, add_lo, add_hi);
+      HIPCHK(hipGetLastError());
+      return MSEVB_OK;
+    }
     if (c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= c->K && T.y <= c->K && T.z <= c->K) {      // workgroup per cell, potential staged in LDS
       const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
       if (!c->weights_valid) {      // k_pme_prep_light ran: per workgroup 192 B of LDS per 8-lane group + 36 B per atom of the largest cell

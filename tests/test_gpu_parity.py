@@ -128,6 +128,30 @@ def test_mfma_charge_spreading_config_B():
         assert np.abs(out[k][3] - out[0][3]).max() < 1e-8 * np.abs(out[0][3]).max() and np.abs(out[k][4] - out[0][4]).max() < 1e-8, k
 
 
+def test_mfma_force_interpolation_config_B():
+    """option gather_mfma: derivative_grid_Q (src/pme.f90:346-493) with the x contraction of every 16-atom block on the matrix cores
+    (k_pme_gather_mfma, the transpose of the MFMA spread) at BASELINE.json configs[2] - the reciprocal forces of the default gather, also
+    along a trajectory on which stencils leave their cell's tile (those atoms are gathered from global memory)"""
+    spec = _synthetic(32, 8, 11, 64)
+    out = []
+    for mfma in (0, 1):
+        h = api.MsEvbHip(spec)
+        h.set_option("gather_mfma", mfma)
+        h.construct_verlet_list()
+        h.zero_forces()
+        er = h.pme_reciprocal_space_energy_force()
+        F = h.get_forces()
+        h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 99))
+        e, Fe = h.ms_evb_calculate_total_force_energy()
+        tr = h.md_integrate_atomic(25, spec.delta_t, use_evb=True)
+        out.append((er, F, e, Fe, tr, h.get_positions()))
+        h.close()
+    a, b = out
+    assert rel(a[0], b[0]) < 1e-13 and np.abs(a[1] - b[1]).max() < F_TOL and np.abs(a[1]).max() > 1.0
+    assert rel(a[2], b[2]) < 1e-13 and np.abs(a[3] - b[3]).max() < 1e-10
+    assert np.abs(a[4] - b[4]).max() < 1e-8 * np.abs(a[4]).max() and np.abs(a[5] - b[5]).max() < 1e-8
+
+
 def test_pme_without_the_weight_store_changes_nothing():
     """option pme_weightless (default on): k_pme_prep_light keeps (u, nearpt) only and the tiled spread / gather take the B-spline weights from the
     tables themselves (grid_Q / derivative_grid_Q, src/pme.f90:184-262, :346-493, table rows :220-247, :412-414) - the SAME bits as with the

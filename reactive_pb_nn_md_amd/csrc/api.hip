@@ -659,6 +659,7 @@ int total_force_enqueue(msevb_ctx* c) {
     stamp(c, 1, c->stream);
     CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));                    // main: the pair loop (longest) goes out first
     stamp(c, 2, c->stream);
+    if (c->evb_pair_first) { if (!c->ev_pair_done) HIPCHK(hipEventCreateWithFlags(&c->ev_pair_done, hipEventDisableTiming)); HIPCHK(hipEventRecord(c->ev_pair_done, c->stream)); }
     if (!c->defer_molecules_now)                                     // (the MS-EVB call sends them out itself, behind its coupling chain on the same stream)
       CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux3));    // aux3: per-molecule terms (few, long threads); aux2 stays free for the
                                                                      // EVB descriptors + environment chain, which the host enqueues next
@@ -761,6 +762,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "pme_weightless") { c->pme_weightless = v != 0.0; return MSEVB_OK; }
   if (s == "spread_mfma") { c->spread_mfma = v != 0.0; return MSEVB_OK; }
   if (s == "gather_mfma") { c->gather_mfma = v != 0.0; return MSEVB_OK; }
+  if (s == "evb_pair_first") { c->evb_pair_first = v != 0.0; return MSEVB_OK; }
   if (s == "evb_pme_split") { c->evb_pme_split = v != 0.0; return MSEVB_OK; }
   if (s == "evb_single_join") { c->evb_single_join = v != 0.0; return MSEVB_OK; }
   if (s == "evb_defer_fold") { c->evb_defer_fold = v != 0.0; return MSEVB_OK; }

@@ -310,6 +310,7 @@ struct msevb_ctx {
                                  // (needs bricks of <= 8 points per axis, K >= 16).  Measured 63 us alone against 55 + 4 + 5 for the LDS-atomic tiles with fill and copy, 2-3 % slower in the overlapped step: off
   bool spread_mfma = false;      // charge spreading as a per-cell contraction on the matrix cores (v_mfma_f64_16x16x4_f64), option spread_mfma
   bool attr_spread_mfma = false;
+  bool evb_pair_first = false; hipEvent_t ev_pair_done = nullptr;      // schedule experiment (option evb_pair_first): diabat chains behind the pair loop
   bool gather_mfma = false;      // force interpolation with the x contraction on the matrix cores (k_pme_gather_mfma), option gather_mfma: measured, not the default
   bool has_sapt = false;     // some (type_i,type_j) entry has non-zero SAPT coefficients
   rocfft_execution_info fft_info = nullptr, fft_info_b = nullptr;      // single-grid plans (their work buffer is baked into the captured PME graph) / batched plans

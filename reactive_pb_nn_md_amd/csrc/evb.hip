@@ -1949,6 +1949,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   }
   w->last_linear = linear; w->last_nst = 2 * nra;
   if (c->overlap) {      // descriptors + special stencils are on the device: the main stream and the off-diagonal chain may use them
+    if (c->evb_pair_first && c->ev_pair_done) HIPCHK(hipStreamWaitEvent(ss, c->ev_pair_done, 0));      // (schedule experiment: the diabat chains start behind the pair loop instead of beside it)
     HIPCHK(hipEventRecord(w->ev_fork2, ss));
     HIPCHK(hipStreamWaitEvent(c->stream, w->ev_fork2, 0));
     HIPCHK(hipStreamWaitEvent(c->aux, w->ev_fork2, 0));

@@ -84,9 +84,12 @@ __device__ __forceinline__ double pme_tap_w(double u, int np, int k, double G, c
   return B6[r - 1];
 }
 // weight and derivative weight of tap k of the three axes (u, np: scaled coordinate and nearest grid point per axis) - the values k_pme_prep
-// stores (src/pme.f90:220-247, :412-414); nine independent table loads
-__device__ __forceinline__ void pme_taps3(double u1, double u2, double u3, int n1, int n2, int n3, int k, double G, const double* __restrict__ B6,
-                                          const double* __restrict__ B5, double (&w)[3], double (&dw)[3]) {
+// stores (src/pme.f90:220-247, :412-414) - in two halves, so that a caller can put work between the nine table loads and their first use:
+// pme_taps3_issue computes the rows and starts the loads (rows of terms that do not apply are clamped into the table), pme_taps3_finish drops
+// the values of those terms and forms the derivative weight.
+struct TapRaw { double v6[3], va[3], vb[3]; int mask; };      // mask: bit l = (a1 < 5) of axis l, bit 3 + l = (0 < a2)
+__device__ __forceinline__ void pme_taps3_issue(double u1, double u2, double u3, int n1, int n2, int n3, int k, double G, const double* __restrict__ B6,
+                                                const double* __restrict__ B5, TapRaw& r) {
   const double u[3] = {u1, u2, u3};
   const int np[3] = {n1, n2, n3};
   const double G6 = G / 6.0, G5 = G / 5.0;
@@ -106,11 +109,16 @@ __device__ __forceinline__ void pme_taps3(double u1, double u2, double u3, int n
     for (int l = 0; l < 3; ++l) { r6[l] = (int)ceil(a1[l] / 6.0 * G); ra[l] = (int)ceil(a1[l] / 5.0 * G); rb[l] = (int)ceil(a2[l] / 5.0 * G); }
   }
   const int Gi = (int)G;
-  double v6[3], va[3], vb[3];
+  r.mask = 0;
 #pragma unroll
-  for (int l = 0; l < 3; ++l) { v6[l] = B6[r6[l] - 1]; va[l] = B5[min(ra[l], Gi) - 1]; vb[l] = B5[max(rb[l], 1) - 1]; }      // (rows of terms that do not apply are clamped into the table, their values dropped)
+  for (int l = 0; l < 3; ++l) {
+    r.v6[l] = B6[min(max(r6[l], 1), Gi) - 1]; r.va[l] = B5[min(max(ra[l], 1), Gi) - 1]; r.vb[l] = B5[min(max(rb[l], 1), Gi) - 1];
+    r.mask |= (a1[l] < 5.0 ? 1 << l : 0) | (0.0 < a2[l] ? 8 << l : 0);
+  }
+}
+__device__ __forceinline__ void pme_taps3_finish(const TapRaw& r, double (&w)[3], double (&dw)[3]) {
 #pragma unroll
-  for (int l = 0; l < 3; ++l) { w[l] = v6[l]; dw[l] = (a1[l] < 5.0 ? va[l] : 0.0) - (0.0 < a2[l] ? vb[l] : 0.0); }
+  for (int l = 0; l < 3; ++l) { w[l] = r.v6[l]; dw[l] = ((r.mask >> l) & 1 ? r.va[l] : 0.0) - ((r.mask >> (3 + l)) & 1 ? r.vb[l] : 0.0); }
 }
 
 // one thread per (atom, k3, k2); the 6 k1 taps are consecutive grid points (modulo wrap)
@@ -601,7 +609,7 @@ __global__ __launch_bounds__(512) void k_pme_gather_tiles(int K, int3 nc, int3 T
 // lane.  The table loads of an atom go out one trip ahead: trip 0's before the tile fill, from global (u, nearpt); the later ones before the
 // stencil sums of the trip in front of them, from the cell's (u, nearpt) staged in LDS beside the tile - no global load waits inside the loop.
 // Same sums in the same order as k_pme_gather_tiles: bit-identical forces.
-__global__ __launch_bounds__(512) void k_pme_gather_tiles_wl(int K, int3 nc, int3 T, const int* __restrict__ cell_start, const int* __restrict__ perm,
+__global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, int3 T, const int* __restrict__ cell_start, const int* __restrict__ perm,
                                                              const double* __restrict__ chg, const int* __restrict__ base_s, const double* __restrict__ uscale_s,
                                                              const double* __restrict__ B6, const double* __restrict__ B5, int G, int cap,
                                                              const double* __restrict__ theta, double conv, double k00, double k01,
@@ -615,25 +623,32 @@ __global__ __launch_bounds__(512) void k_pme_gather_tiles_wl(int K, int3 nc, int
   const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3, ngrp = blockDim.x >> 3;
   double* const xw = tile + P2 * T.z + 24 * grp;      // {w_x[6], w_y[6], dw_x[6], dw_y[6]} of the group's atom
   double* const cu = tile + P2 * T.z + 24 * ngrp;     // [3 cap] scaled coordinates of the cell's atoms ...
-  int* const cb = (int*)(cu + 3 * cap);                // [3 cap] ... and their nearest grid points
+  int* const cb = (int*)(cu + 3 * cap);                // [3 cap] ... their nearest grid points,
+  double* const cq = (double*)(cb + 3 * cap + (cap & 1));      // [cap] charges
+  int* const ci = (int*)(cq + cap);                    // [cap] and atom indices
   const int s = cell_start[cidx], e = cell_start[cidx + 1];
   const double Gd = (double)G;
-  // taps of the atom one trip ahead (registers): x, y, z weights and derivative weights of tap `sub`, nearest grid points, atom, charge
-  double nw1 = 0.0, nw2 = 0.0, nw3 = 0.0, nd1 = 0.0, nd2 = 0.0, nd3 = 0.0, nq = 0.0;
+  // the atom one trip ahead (registers): raw table values of tap `sub` of the three axes, nearest grid points, atom, charge.  Lanes without an
+  // atom (sub >= 6, no atom left) look up a harmless coordinate: the loads go out unconditionally, no branch between them and their first use
+  TapRaw nt;
+  double nq = 0.0;
   int nb1 = 0, nb2 = 0, nb3 = 0, ni = 0;
-  if (s + grp < e) {
-    const int ia = s + grp;
-    ni = perm[ia]; nq = chg[ni];
-    if (sub < 6) {
-      nb1 = base_s[3 * ia]; nb2 = base_s[3 * ia + 1]; nb3 = base_s[3 * ia + 2];
-      const double u1 = uscale_s[3 * ia], u2 = uscale_s[3 * ia + 1], u3 = uscale_s[3 * ia + 2];
-      double tw[3], td[3];
-      pme_taps3(u1, u2, u3, nb1, nb2, nb3, sub, Gd, B6, B5, tw, td);
-      nw1 = tw[0]; nw2 = tw[1]; nw3 = tw[2]; nd1 = td[0]; nd2 = td[1]; nd3 = td[2];
-    }
-  }
-  const bool staged = e - s <= cap;      // (a cell larger than the host knew: the later trips read (u, nearpt) from global memory as trip 0 does)
-  if (staged) for (int k = threadIdx.x; k < 3 * (e - s); k += blockDim.x) { cu[k] = uscale_s[3 * s + k]; cb[k] = base_s[3 * s + k]; }
+  // Load order of the prologue (the memory counter retires in order): trip 0's (u, nearpt) first, then the cell's staging values into registers
+  // (thread k takes atom k), then - as soon as trip 0's coordinates are there - its nine table loads and the charges, then the tile; the LDS
+  // stores of the staging values come behind the tile fill, so one wait covers everything that has been in flight beside it.
+  const int n_cell = e - s;
+  const bool staged = n_cell <= cap && n_cell <= (int)blockDim.x;      // (a cell larger than the host knew: the later trips read global memory as trip 0 does)
+  const int iac = s + grp < e ? s + grp : max(e - 1, 0);      // (no atom for this group: any valid one, never used)
+  nb1 = base_s[3 * iac]; nb2 = base_s[3 * iac + 1]; nb3 = base_s[3 * iac + 2];
+  const double tu1 = uscale_s[3 * iac], tu2 = uscale_s[3 * iac + 1], tu3 = uscale_s[3 * iac + 2];
+  ni = perm[iac];
+  const bool st_on = staged && (int)threadIdx.x < n_cell;
+  const int ks = st_on ? s + (int)threadIdx.x : iac;
+  const double su1 = uscale_s[3 * ks], su2 = uscale_s[3 * ks + 1], su3 = uscale_s[3 * ks + 2];
+  const int sb1 = base_s[3 * ks], sb2 = base_s[3 * ks + 1], sb3 = base_s[3 * ks + 2], si = perm[ks];
+  pme_taps3_issue(tu1, tu2, tu3, nb1, nb2, nb3, sub < 6 ? sub : 0, Gd, B6, B5, nt);
+  nq = chg[ni];
+  const double sq = chg[si];
   {      // stage the potential: x fastest (coalesced rows of T.x points); four loads in flight per thread
     const int ntile = T.x * T.y * T.z, txy = T.x * T.y;
     for (int r0 = threadIdx.x; r0 < ntile; r0 += 4 * blockDim.x) {
@@ -655,33 +670,35 @@ __global__ __launch_bounds__(512) void k_pme_gather_tiles_wl(int K, int3 nc, int
       for (int u = 0; u < 4; ++u) if (dst[u] >= 0) tile[dst[u]] = v[u];
     }
   }
+  if (st_on) {
+    const int k = threadIdx.x;
+    cu[3 * k] = su1; cu[3 * k + 1] = su2; cu[3 * k + 2] = su3; cb[3 * k] = sb1; cb[3 * k + 1] = sb2; cb[3 * k + 2] = sb3; ci[k] = si; cq[k] = sq;
+  }
   __syncthreads();
   for (int a0 = s; a0 < e; a0 += ngrp) {      // uniform trip count per wave (shuffles below)
     const int ia = a0 + grp;
     const bool live = ia < e;
     const int i = ni, b1 = nb1, b2 = nb2, b3 = nb3;
-    const double w3 = nw3, d3 = nd3, q = nq;
-    if (live && sub < 6) { xw[sub] = nw1; xw[6 + sub] = nw2; xw[12 + sub] = nd1; xw[18 + sub] = nd2; }
+    const double q = nq;
+    double tw[3], td[3];
+    pme_taps3_finish(nt, tw, td);      // (first use of the table values that went out one trip ago)
+    const double w3 = tw[2], d3 = td[2];
+    if (live && sub < 6) { xw[sub] = tw[0]; xw[6 + sub] = tw[1]; xw[12 + sub] = td[0]; xw[18 + sub] = td[1]; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double w1[6], d1[6];
     if (live && sub < 6) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) { w1[k] = xw[k]; d1[k] = xw[12 + k]; }
     }
-    {      // the next trip's atom: table loads in flight during this trip's sums
-      const int ja = ia + ngrp;
-      if (ja < e) {
-        ni = perm[ja]; nq = chg[ni];
-        if (sub < 6) {
-          const int o = 3 * (ja - s);
-          double u1, u2, u3;
-          if (staged) { nb1 = cb[o]; nb2 = cb[o + 1]; nb3 = cb[o + 2]; u1 = cu[o]; u2 = cu[o + 1]; u3 = cu[o + 2]; }
-          else { nb1 = base_s[3 * ja]; nb2 = base_s[3 * ja + 1]; nb3 = base_s[3 * ja + 2]; u1 = uscale_s[3 * ja]; u2 = uscale_s[3 * ja + 1]; u3 = uscale_s[3 * ja + 2]; }
-          double tw[3], td[3];
-          pme_taps3(u1, u2, u3, nb1, nb2, nb3, sub, Gd, B6, B5, tw, td);
-          nw1 = tw[0]; nw2 = tw[1]; nw3 = tw[2]; nd1 = td[0]; nd2 = td[1]; nd3 = td[2];
-        }
+    {      // the next trip's atom (the last atom of the cell again when there is none): table loads in flight during this trip's sums
+      const int jc = min(ia + ngrp, e - 1) - s;
+      double u1, u2, u3;
+      if (staged) { ni = ci[jc]; nq = cq[jc]; nb1 = cb[3 * jc]; nb2 = cb[3 * jc + 1]; nb3 = cb[3 * jc + 2]; u1 = cu[3 * jc]; u2 = cu[3 * jc + 1]; u3 = cu[3 * jc + 2]; }
+      else {
+        const int jg = s + jc;
+        ni = perm[jg]; nq = chg[ni]; nb1 = base_s[3 * jg]; nb2 = base_s[3 * jg + 1]; nb3 = base_s[3 * jg + 2]; u1 = uscale_s[3 * jg]; u2 = uscale_s[3 * jg + 1]; u3 = uscale_s[3 * jg + 2];
       }
+      pme_taps3_issue(u1, u2, u3, nb1, nb2, nb3, sub < 6 ? sub : 0, Gd, B6, B5, nt);
     }
     double f1 = 0.0, f2 = 0.0, f3 = 0.0;
     if (live && sub < 6) {
@@ -701,19 +718,16 @@ __global__ __launch_bounds__(512) void k_pme_gather_tiles_wl(int K, int3 nc, int
           for (int k = 0; k < 6; ++k) { const double th = row[-k]; s0 += w1[k] * th; s1 += d1[k] * th; }
           f1 += s1 * w2 * w3; f2 += s0 * d2 * w3; f3 += s0 * w2 * d3;
         }
-      } else {      // the stencil left the tile since the last list build: from global memory
+      } else {      // the stencil left the tile since the last list build: from global memory (rare: loops kept rolled, registers belong to the path above)
         int n3 = b3 - sub; if (n3 < 0) n3 += K;
-        int n1[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { int n = b1 - k; if (n < 0) n += K; n1[k] = n; }
-#pragma unroll
+#pragma unroll 1
         for (int k2 = 0; k2 < 6; ++k2) {
           int n2 = b2 - k2; if (n2 < 0) n2 += K;
           const double* row = theta + (size_t)K * (n2 + (size_t)K * n3);
           const double w2 = xw[6 + k2], d2 = xw[18 + k2];
           double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) { const double th = row[n1[k]]; s0 += w1[k] * th; s1 += d1[k] * th; }
+#pragma unroll 1
+          for (int k = 0; k < 6; ++k) { int n1 = b1 - k; if (n1 < 0) n1 += K; const double th = row[n1]; s0 += xw[k] * th; s1 += xw[12 + k] * th; }
           f1 += s1 * w2 * w3; f2 += s0 * d2 * w3; f3 += s0 * w2 * d3;
         }
       }
@@ -1053,9 +1067,9 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
     }
     if (c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= c->K && T.y <= c->K && T.z <= c->K) {      // workgroup per cell, potential staged in LDS
       const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
-      if (!c->weights_valid) {      // k_pme_prep_light ran: per workgroup 192 B of LDS per 8-lane group + 36 B per atom of the largest cell
+      if (!c->weights_valid) {      // k_pme_prep_light ran: per workgroup 192 B of LDS per 8-lane group + 48 B per atom of the largest cell
         const int cap = std::min(std::max((int)(c->cell_atoms_max * 1.05) + 1, 16), 1024);      // (the largest cell of the last build whose statistics the host has seen)
-        const size_t lds = tile_bytes + (size_t)c->pme_tile_threads * 24 + (size_t)cap * 36 + 8;
+        const size_t lds = tile_bytes + (size_t)c->pme_tile_threads * 24 + (size_t)cap * 48 + 16;
         if (lds > 160 * 1024) FAIL(MSEVB_ERR_LIMIT, "pme_gather: cell too large for the weight-free gather (set option pme_weightless=0)");
         if (lds > 64 * 1024 && c->attr_gather_wl < (int)lds) { HIPCHK(hipFuncSetAttribute((const void*)k_pme_gather_tiles_wl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); c->attr_gather_wl = (int)lds; }
         hipLaunchKernelGGL(k_pme_gather_tiles_wl, dim3(ncell), dim3(c->pme_tile_threads), lds, c->stream, c->K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T, c->d_cell_start.p, c->d_perm.p,

@@ -410,6 +410,20 @@ int msevb_finalize(msevb_ctx* c) {
   c->list_valid = false;
   c->flag_verlet_list = 1;
   c->finalized = true;
+  // MSEVB_OPTIONS="name=value,name=value": msevb_set_option calls for hosts that have no other way to make them (the unchanged Fortran main
+  // program) and for bisecting a schedule; an unknown name is an error, as it is through the entry point
+  if (const char* env = getenv("MSEVB_OPTIONS")) {
+    std::string all(env);
+    size_t p = 0;
+    while (p < all.size()) {
+      size_t q = all.find(',', p); if (q == std::string::npos) q = all.size();
+      const std::string kv = all.substr(p, q - p); p = q + 1;
+      const size_t eq = kv.find('=');
+      if (kv.empty()) continue;
+      if (eq == std::string::npos) FAIL(MSEVB_ERR_ARG, "MSEVB_OPTIONS: expected name=value");
+      CHK(msevb_set_option(c, kv.substr(0, eq).c_str(), atof(kv.c_str() + eq + 1)));
+    }
+  }
   return MSEVB_OK;
 }
 

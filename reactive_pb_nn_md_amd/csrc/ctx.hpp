@@ -153,8 +153,16 @@ struct DBuf {  // device buffer
     if (p) (void)hipFree(p);
     p = nullptr;
     n = 0;
-    if (hipMalloc((void**)&p, (count ? count : 1) * sizeof(T)) != hipSuccess) return -1;
+    // + DBUF_TAIL bytes behind every buffer: kernels that issue their loads unconditionally (clamped indices, selects instead of branches -
+    // pair_flat.hip, the weight-free gather) or read a 16-byte record at the last element may touch a few bytes past `count` elements; those
+    // bytes must be mapped.  MSEVB_DBUF_TAIL=0 (diagnostic) allocates exactly.
+    static const size_t tail = getenv("MSEVB_DBUF_TAIL") ? (size_t)atol(getenv("MSEVB_DBUF_TAIL")) : 1024;
+    if (hipMalloc((void**)&p, (count ? count : 1) * sizeof(T) + tail) != hipSuccess) return -1;
     n = count;
+    // MSEVB_POISON=1 (diagnostic): fresh device memory reads as NaN / -1 instead of whatever the allocator hands back (zeros in a young process,
+    // another context's data later), so that a read of something nobody wrote shows in the first test that does it, not in the fortieth
+    static const bool poison = getenv("MSEVB_POISON") != nullptr;
+    if (poison) (void)hipMemset(p, 0xFF, (count ? count : 1) * sizeof(T));
     return 0;
   }
   // for buffers whose size follows the diabat count: grow with half as much again, so that a tree gaining a diabat or two during a run

@@ -208,12 +208,137 @@ __global__ __launch_bounds__(512) void k_fft_xy_inv(const double2* __restrict__ 
   }
 }
 
+
+// =====================================================================================================================================
+// 128^3 (BASELINE.json configs[4]): a z plane is 256 KB, so the three axes go one at a time - five kernels, each streaming the 33.5 MB
+// complex grid once in and once out (x forward reads the 16.8 MB REAL charge grid, x backward writes the REAL potential):
+//   k_fft128_x<-1>  : 16 x-lines per workgroup, 8 threads per line
+//   k_fft128_yz<-1> : y lines, 16 x-neighbours per workgroup (256 B contiguous per row), in place
+//   k_fft128_z_conv : z lines forward, x CB (+ energy partial), backward - the line stays in its registers
+//   k_fft128_yz<+1>, k_fft128_x<+1>
+// A 128-point line is 8 x 16: the thread j of a line holds x[j + 8 m], m = 0..15, does a 16-point DFT over m in registers (two radix-8
+// butterflies + W16), twiddles by W128^(j k2), the 8 threads exchange through LDS, thread j takes k2 = j and j + 8 and does two radix-8
+// butterflies over the threads' index: X[k2 + 16 k1] - which is X[j + 8 m'] with m' = 2 k1 + (k2 >= 8), the layout it started with.
+constexpr int FN = 128;
+constexpr double C16 = 0.92387953251128675613, S16 = 0.38268343236508977173;      // cos, sin of pi / 8
+__device__ double2 g_tw128[128];      // W128^m = (cos, sin)(2 pi m / 128)
+
+template <int S> __device__ __forceinline__ void dft16(double (&re)[16], double (&im)[16]) {
+  double er[8], ei[8], orr[8], oi[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) { er[m] = re[2 * m]; ei[m] = im[2 * m]; orr[m] = re[2 * m + 1]; oi[m] = im[2 * m + 1]; }
+  dft8<S>(er, ei);
+  dft8<S>(orr, oi);
+  // O[k] *= W16^k = (cos(k pi/8), S sin(k pi/8))
+  const double wc[8] = {1.0, C16, RH, S16, 0.0, -S16, -RH, -C16}, ws[8] = {0.0, S16, RH, C16, 1.0, C16, RH, S16};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const double c = wc[k], sn = S * ws[k];
+    const double tr = orr[k] * c - oi[k] * sn, ti = orr[k] * sn + oi[k] * c;
+    re[k] = er[k] + tr; im[k] = ei[k] + ti; re[k + 8] = er[k] - tr; im[k + 8] = ei[k] - ti;
+  }
+}
+
+// one 128-point line held by 8 threads (j = 0..7; in and out: element j + 8 m in slot m); xr / xi: the line's LDS scratch, 8 x 17 doubles each.
+// The caller's workgroup must reach this call with all its threads (two barriers inside).
+template <int S> __device__ __forceinline__ void line128(double (&re)[16], double (&im)[16], int j, double* xr, double* xi) {
+  dft16<S>(re, im);
+#pragma unroll
+  for (int k = 1; k < 16; ++k) {
+    const double2 w = g_tw128[(j * k) & 127];
+    const double c = w.x, sn = S * w.y;
+    const double r = re[k] * c - im[k] * sn, i = re[k] * sn + im[k] * c;
+    re[k] = r; im[k] = i;
+  }
+  __syncthreads();      // (scratch of the transform before this one has been read)
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { xr[j * 17 + k] = re[k]; xi[j * 17 + k] = im[k]; }
+  __syncthreads();
+  double ar[8], ai[8], br[8], bi[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) { ar[n] = xr[n * 17 + j]; ai[n] = xi[n * 17 + j]; br[n] = xr[n * 17 + j + 8]; bi[n] = xi[n * 17 + j + 8]; }
+  dft8<S>(ar, ai);
+  dft8<S>(br, bi);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { re[2 * k] = ar[k]; im[2 * k] = ai[k]; re[2 * k + 1] = br[k]; im[2 * k + 1] = bi[k]; }
+}
+
+constexpr int L128 = 8 * 17 + 1;      // scratch doubles per line and part (odd: neighbouring lines start in different banks)
+
+// x lines: workgroup = 16 consecutive y of one z, 8 threads per line.  S = -1: real charge grid in, complex out; S = +1: complex in, real part out.
+template <int S> __global__ __launch_bounds__(128) void k_fft128_x(const double* __restrict__ Q, double2* __restrict__ grid, double* __restrict__ theta) {
+  __shared__ double pr[16 * L128], pi[16 * L128];
+  const int t = threadIdx.x, j = t & 7, l = t >> 3;
+  const size_t row = (size_t)FN * ((size_t)(blockIdx.x & 7) * 16 + l + (size_t)FN * (blockIdx.x >> 3));
+  double re[16], im[16];
+  if (S < 0) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { re[m] = Q[row + j + 8 * m]; im[m] = 0.0; }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { const double2 v = grid[row + j + 8 * m]; re[m] = v.x; im[m] = v.y; }
+  }
+  line128<S>(re, im, j, pr + l * L128, pi + l * L128);
+  if (S < 0) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) grid[row + j + 8 * m] = make_double2(re[m], im[m]);
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) theta[row + j + 8 * m] = re[m];
+  }
+}
+
+// y lines in place: workgroup = 16 neighbouring x of one z
+template <int S> __global__ __launch_bounds__(128) void k_fft128_y(double2* __restrict__ grid) {
+  __shared__ double pr[16 * L128], pi[16 * L128];
+  const int t = threadIdx.x, lx = t & 15, j = t >> 4;
+  const size_t col = (size_t)(blockIdx.x & 7) * 16 + lx + (size_t)FN * FN * (blockIdx.x >> 3);
+  double re[16], im[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) { const double2 v = grid[col + (size_t)FN * (j + 8 * m)]; re[m] = v.x; im[m] = v.y; }
+  line128<S>(re, im, j, pr + lx * L128, pi + lx * L128);
+#pragma unroll
+  for (int m = 0; m < 16; ++m) grid[col + (size_t)FN * (j + 8 * m)] = make_double2(re[m], im[m]);
+}
+
+// z lines forward, x CB (+ energy partial: 1/2 conv sum CB |F|^2, src/pme.f90:100-125), z lines backward; workgroup = 16 neighbouring x of one y
+__global__ __launch_bounds__(128) void k_fft128_z_conv(double2* __restrict__ grid, const double* __restrict__ CB, double* __restrict__ part, double half_conv) {
+  __shared__ double pr[16 * L128], pi[16 * L128];
+  __shared__ double red[2];
+  const int t = threadIdx.x, lx = t & 15, j = t >> 4;
+  const size_t col = (size_t)(blockIdx.x & 7) * 16 + lx + (size_t)FN * (blockIdx.x >> 3), zs = (size_t)FN * FN;
+  double re[16], im[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) { const double2 v = grid[col + zs * (j + 8 * m)]; re[m] = v.x; im[m] = v.y; }
+  line128<-1>(re, im, j, pr + lx * L128, pi + lx * L128);
+  double e = 0.0;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) { const double cb = CB[col + zs * (j + 8 * m)]; e += cb * (re[m] * re[m] + im[m] * im[m]); re[m] *= cb; im[m] *= cb; }
+  line128<1>(re, im, j, pr + lx * L128, pi + lx * L128);
+#pragma unroll
+  for (int m = 0; m < 16; ++m) grid[col + zs * (j + 8 * m)] = make_double2(re[m], im[m]);
+  if (part) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+    if ((t & 63) == 0) red[t >> 6] = e;
+    __syncthreads();
+    if (t == 0) part[blockIdx.x] = (red[0] + red[1]) * half_conv;
+  }
+}
+
 }  // namespace
 
-bool fft_lds_usable(const msevb_ctx* c) { return c->fft_own && c->K == FK; }
+bool fft_lds_usable(const msevb_ctx* c) { return c->fft_own && (c->K == FK || c->K == FN); }
 
 // once per context (the twiddle table is a per-device symbol; LDS beyond 64 KB needs the attribute)
 int fft_lds_setup(msevb_ctx* c) {
+  if (c->K == FN) {
+    double2 tw[128];
+    for (int m = 0; m < 128; ++m) { const double a = 2.0 * M_PI * m / 128.0; tw[m] = make_double2(cos(a), sin(a)); }
+    tw[0] = make_double2(1, 0); tw[32] = make_double2(0, 1); tw[64] = make_double2(-1, 0); tw[96] = make_double2(0, -1);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tw128), tw, sizeof tw));
+    return MSEVB_OK;
+  }
   if (c->K != FK) return MSEVB_OK;
   double2 tw[64];
   for (int m = 0; m < 64; ++m) { const double a = 2.0 * M_PI * m / 64.0; tw[m] = make_double2(cos(a), sin(a)); }
@@ -228,6 +353,16 @@ int fft_lds_setup(msevb_ctx* c) {
 
 // theta = Re IFFT(CB FFT(Q)); Q and theta real [64^3] (may be the same buffer), work complex [64^3]; part (optional): 256 energy partials
 int fft_lds_solve(msevb_ctx* c, const double* Q, double2* work, double* theta, double* part, int* nblocks, hipStream_t st) {
+  if (c->K == FN) {      // five kernels, 1024 workgroups of 128 threads each
+    hipLaunchKernelGGL(k_fft128_x<-1>, dim3(FN * 8), dim3(128), 0, st, Q, work, (double*)nullptr);
+    hipLaunchKernelGGL(k_fft128_y<-1>, dim3(FN * 8), dim3(128), 0, st, work);
+    hipLaunchKernelGGL(k_fft128_z_conv, dim3(FN * 8), dim3(128), 0, st, work, c->d_CB.p, part, 0.5 * c->conv);
+    hipLaunchKernelGGL(k_fft128_y<1>, dim3(FN * 8), dim3(128), 0, st, work);
+    hipLaunchKernelGGL(k_fft128_x<1>, dim3(FN * 8), dim3(128), 0, st, (const double*)nullptr, work, theta);
+    HIPCHK(hipGetLastError());
+    if (nblocks) *nblocks = FN * 8;
+    return MSEVB_OK;
+  }
   const int lds = 2 * FK * LS * (int)sizeof(double);
   hipLaunchKernelGGL(k_fft_xy_fwd, dim3(FK), dim3(512), lds, st, Q, work);
   hipLaunchKernelGGL(k_fft_z_conv, dim3(FK * 4), dim3(128), 0, st, work, c->d_CB.p, part, 0.5 * c->conv);

@@ -225,6 +225,29 @@ def test_own_lds_transform_against_rocfft_and_reference(stores):
     assert np.abs(res[0][2] - res[1][2]).max() < 1e-11 and rel(res[0][3], res[1][3]) < 1e-14 and np.abs(res[0][4] - res[1][4]).max() < 1e-10
 
 
+def test_own_128_transform_against_rocfft():
+    """csrc/fft_lds.hip, 128^3 grids (BASELINE.json configs[4]'s grid: five kernels for FFT . CB . IFFT, src/pme.f90:73-125, a 128-point line as
+    8 x 16 across 8 threads) against the rocFFT path (option fft_own=0) on a 10 125-atom box: potential, reciprocal energy and force, and the
+    MS-EVB call, whose Hellmann-Feynman force goes through a second solve (of the blended charge grid).  The rocFFT path itself is pinned to the
+    oracle at this grid size by test_config_C_against_oracle."""
+    spec = _synthetic(15, 4, 5, 128)
+    res = []
+    for own in (1, 0):
+        h = api.MsEvbHip(spec)
+        h.set_option("fft_own", own)
+        h.construct_verlet_list()
+        h.zero_forces()
+        er = h.pme_reciprocal_space_energy_force()
+        Q, th, u, fr = h.pme_state()
+        Fr = h.get_forces()
+        e, F = h.ms_evb_calculate_total_force_energy()
+        res.append((er, th, Fr, e, F))
+        h.close()
+    a, b = res
+    assert np.abs(b[1]).max() > 1e-3 and np.abs(a[1] - b[1]).max() < 1e-13 * np.abs(b[1]).max()
+    assert rel(a[0], b[0]) < 1e-13 and np.abs(a[2] - b[2]).max() < 1e-11 and rel(a[3], b[3]) < 1e-13 and np.abs(a[4] - b[4]).max() < 1e-10
+
+
 @pytest.mark.parametrize("name", ["std_n6_s3", "std_n6_k20_s13"])
 def test_pme_stage_entry_points_against_reference(name):
     """grid_Q / modify_Q_grid / derivative_grid_Q (src/pme.f90:184, :275, :346) at the reference's own granularity (host arrays and SCALED

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = sys.argv[1]
 dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "traffic.json")
 phase_of = {"k_pair_flat": "real space (pair loop)", "k_pair_half": "real space (pair loop)", "k_pair": "real space (pair loop)", "k_pme_spread_tiles": "Q_grid (spread)",
-            "k_pme_gather_tiles": "Q grid derivatives (gather)", "k_molecules": "intra-molecular (non-bonded + bonded)"}
+            "k_pme_gather_tiles": "Q grid derivatives (gather)", "k_pme_gather_tiles_wl": "Q grid derivatives (gather)", "k_molecules": "intra-molecular (non-bonded + bonded)"}
 
 
 TRAFFIC_SOURCES = ("ctx.hpp", "devmath.hpp", "gather_dev.hpp", "molecule.hip", "molecule_dev.hpp", "neighbor.hip", "pair.hip", "pair_flat.hip", "pme.hip")      # same list in bench.py

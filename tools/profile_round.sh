@@ -17,6 +17,7 @@ rm -rf $OUT/kt
 # 2. the same kernels alone on the GPU (one queue, no graph): stand-alone durations
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $B --steps 30 --warmup 5 --opt overlap=0 --opt graphs=0 > $OUT/kts.log 2>&1
 python3 $R/tools/summarize_prof.py $OUT > $OUT/serial_kernel_stats.txt 2>&1 || true
+python3 $R/tools/pair_modes.py $OUT > $OUT/pair_modes.txt 2>&1 || true      # pair kernel: launches that read their list / that rewrite it
 rm -rf $OUT/kt
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in their own passes (MI355X_MICROARCH.md: they do not fit one pass), default schedule
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o f -- $B --steps 10 --warmup 2 > $OUT/fetch.log 2>&1

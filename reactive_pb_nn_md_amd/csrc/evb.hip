@@ -1189,7 +1189,23 @@ __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ 
 // ng > 0: first the diabats' grid energies, E_grid[g] = conv (E_lin[g] + E_quad[g] / 2), accumulators re-zeroed (k_evb_grid_energy - E_grid lies inside a)
 __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, const double* b, int nb, double* __restrict__ hb,
                               volatile long long* flag = nullptr, long long seq = 0, int ng = 0, double* E_lin = nullptr, double* E_quad = nullptr,
-                              double conv = 0.0, double* E_grid = nullptr, const double* __restrict__ slot_part = nullptr, int n_part = 0, double* slot_out = nullptr) {      // (a and E_grid alias: no __restrict__ on them)
+                              double conv = 0.0, double* E_grid = nullptr, const double* __restrict__ slot_part = nullptr, int n_part = 0, double* slot_out = nullptr,
+                              const long long* chain_done = nullptr, long long chain_seq = 0, int n_chains = 0, double* fault = nullptr) {      // (a and E_grid alias: no __restrict__ on them)
+  // n_chains > 0: the kernels on OTHER streams whose energies this kernel publishes end with k_evb_mark(chain_done + k, chain_seq); wait for
+  // those marks here instead of through two cross-stream event hops in front of this kernel (~10 us each on the way to the host's turn).
+  // The marks are enqueued before this kernel in host order, so streams that share a hardware queue cannot deadlock; after 2 s of wall
+  // clock the sticky fault flag is raised and the kernel goes on (the force call then ends in MSEVB_ERR_NUMERIC).
+  if (n_chains > 0) {
+    if (threadIdx.x == 0) {
+      const long long t0 = wall_clock64();      // 100 MHz
+      for (int k = 0; k < n_chains; ++k)
+        while (__hip_atomic_load(chain_done + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != chain_seq) {
+          if (wall_clock64() - t0 > 200000000LL) { if (fault) *fault = 1.0; break; }      // 2 s (the first launch of a kernel in a process can take milliseconds to load)
+          __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+  }
   if (n_part > 0) {      // pending partial sums of ONE energy slot (the principal reciprocal energy: was a k_reduce_slots launch in front of this kernel); slot_out may be b
     __shared__ double red[256];
     double s0 = 0.0;
@@ -1216,6 +1232,9 @@ __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, 
 // the kernels behind it.  What it saves is the launch latency of the phase (~6 launches, 25-35 us) between the host's Jacobi and the
 // first blend kernel.  It always terminates: the host writes -seq on every error path (CoefGuard), and after ~5 s of wall clock the
 // kernel raises the sticky fault flag and goes on (the force call then ends in MSEVB_ERR_NUMERIC).
+// last kernel of a side chain: its stream has finished everything in front of it
+__global__ void k_evb_mark(long long* p, long long seq) { __hip_atomic_store(p, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
 __global__ void k_evb_wait_coef(const double* h_coef, volatile long long* flag, long long seq, int n, double* __restrict__ d_coef, double* __restrict__ fault) {
   if (threadIdx.x == 0) {
     const long long t0 = wall_clock64();      // 100 MHz
@@ -1293,13 +1312,16 @@ struct EvbWork {   // persistent device scratch of one context
   bool counters_dirty = true, dv_dirty = true, mol_deferred = false;
   double* h_coef = nullptr; long long seq_C = 0;      // pinned, coherent: blend coefficients for k_evb_wait_coef + its flag behind them
   hipEvent_t ev_chains = nullptr;      // environment chain + couplings done (recorded on the descriptor stream)
+  bool side_by_A = false;        // every side chain the blend phase needs has ended once fetch A is published (spinning publish kernel, prefill in front of it,
+                                 // no kernel behind it): the host, which has seen fetch A, enqueues the blend phase without a GPU-side wait for ev_side
+  bool side_wo_mol = false;      // ev_side does not cover the per-molecule kernel (aux3, c->ev_join2): only k_evb_blend reads what that kernel adds, so only it waits
   bool side_valid = false; hipEvent_t ev_side = nullptr;      // recorded on the front-end stream once it has waited for every other side chain: the ONE event the blend phase waits for
   bool pack_prefilled = false; hipEvent_t ev_prefill = nullptr;      // the blended charge grid starts as a copy of Q_1, made while the host waits for the energies
   std::vector<RegionRec> region, region_raw; std::vector<long long> region_key;
   std::vector<UnitDesc> units; std::vector<CouplingDesc> cps, cps_sorted; std::vector<RecipAtom> ras;      // descriptors of the current force call
   // speculative step (SpecPlan above): what the last step that enumerated the tree itself left behind
   SpecPlan plan; bool plan_valid = false, plan_fits = true; long plan_epoch = -1;
-  DBuf<SpecPlan> d_plan; DBuf<double> d_sphere; DBuf<int> d_check; DBuf<unsigned long long> d_refresh_scratch;
+  DBuf<SpecPlan> d_plan; DBuf<double> d_sphere; DBuf<int> d_check; DBuf<unsigned long long> d_refresh_scratch; DBuf<long long> d_chain_done;
   int pl_D = 0, pl_plog[MAX_DIABATS][MAX_CHAIN][5], pl_parent[MAX_DIABATS], pl_ngrid = 0, pl_ncp_big = 0;
   std::vector<std::vector<int>> pl_units_of; std::vector<int> pl_grid_of, pl_cp_of; std::vector<double> pl_eref_delta;
   long spec_steps = 0, spec_misses = 0;
@@ -1512,7 +1534,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   BlendTerms bt;
   double w11 = blend_terms(c, D, ev, bt);
   if (w11 == 0.0) {      // replicated (not sharded) principal diabat on a rank other than 0: F11 counts on rank 0 only, the gather below adds to zero
-    if (c->overlap && w->side_valid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0));      // (the per-molecule kernel still adds to it)
+    if (c->overlap && w->side_valid) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0)); if (w->side_wo_mol) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0)); }      // (the per-molecule kernel still adds to it)
     else if (c->overlap && w->mol_deferred) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
     HIPCHK(hipMemsetAsync(c->d_force.p, 0, n3 * 8, c->stream));
     if (c->fsorted_pending) { HIPCHK(hipMemsetAsync(c->d_fsorted.p, 0, n3 * 8, c->stream)); c->fsorted_pending = false; }
@@ -1522,8 +1544,8 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   GridCoefs gc; gc.n = ngrid; gc.c0 = 0.0;
   if (ev) { gc.c0 = c->rank == 0 ? ev[0] * ev[0] : 0.0; for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gc.c[grid_of[d]] = ev[d] * ev[d]; }
   const bool one_wait = c->overlap && w->side_valid;      // every side chain of this force call behind ONE event
-  if (one_wait) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0));
-  else if (c->overlap && ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // convolved diabat grids / grid energies (aux)
+  if (one_wait && !w->side_by_A) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0));      // (side_by_A: whoever enqueues this phase has seen fetch A, or has put k_evb_wait_coef in front of it)
+  else if (c->overlap && ngrid && !one_wait) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // convolved diabat grids / grid energies (aux)
   stamp(c, 8, c->stream);
   if (w->d_pack.alloc(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended potential)");
   if (w->last_linear) {
@@ -1534,7 +1556,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
     } else {
       if (w->d_grids.alloc_room(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended charge grid)");
       if (fft_lds_usable(c)) {      // real grid in, real potential out, in place in d_pack (d_grids is the transform's complex work space)
-        if (w->pack_prefilled) { if (c->overlap && !one_wait) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_prefill, 0)); }      // (went out before the host's turn)
+        if (w->pack_prefilled) { if (c->overlap && (!one_wait || w->side_by_A)) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_prefill, 0)); }      // (went out before the host's turn)
         else if (c->rank == 0) HIPCHK(hipMemcpyAsync(w->d_pack.p, c->d_Q.p, K3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         else HIPCHK(hipMemsetAsync(w->d_pack.p, 0, K3 * sizeof(double), c->stream));
         w->pack_prefilled = false;
@@ -1563,6 +1585,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   // diabat grid chain, before the host's turn); the blend consumes the store and re-zeroes it
   if (c->overlap && !one_wait) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0)); if (ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_rs, 0)); }
   if (c->overlap && !one_wait && w->mol_deferred) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // the principal diabat's per-molecule forces (aux3, behind the coupling chain)
+  if (one_wait && w->side_wo_mol) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // ... which the ONE event left out: patch, solve and gather of the blend phase run beside that kernel
   (void)nra; (void)d_ra;
   hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, dcoef ? dcoef + 1 + ngrid : (const double*)nullptr, w11, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p, 1,
                      c->fsorted_pending ? c->d_fsorted.p : (double*)nullptr, c->d_inv_perm.p, c->N);
@@ -1650,7 +1673,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   c->pme_split_now = single_join && c->evb_pme_split && c->evb_recip_linear && c->d_green.p && fft_lds_usable(c);      // spread now; the solve goes out behind the stencil-pair kernels (step 6b)
   c->refresh_side_now = c->overlap && c->evb_region_main;
   c->weights_needed_now = !(fast && c->evb_recip_linear && c->d_green.p);      // per-diabat transforms / element stores read the principal diabat's weights (k_evb_patch, k_stencil_gather, k_evb_recip_special)
-  w->side_valid = false;
+  w->side_valid = false; w->side_wo_mol = false; w->side_by_A = false;
   const int rc_tfe = total_force_enqueue(c);
   c->weights_needed_now = false;
   c->shard_now = false; c->skip_gather_now = false; c->defer_molecules_now = false; c->ev_pos_ready = nullptr; c->defer_fold_now = false; c->skip_side_joins_now = false; c->pme_split_now = false; c->refresh_side_now = false;
@@ -1839,7 +1862,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       w->d_tabs.alloc(1) || w->d_exch.alloc(MAX_TYPES) || w->d_part.alloc_room((size_t)n_rows * part_stride) ||
       w->d_E.alloc_room(2 * n_rows + 3 * std::max(ncp, 1) + 8) || w->d_dVspec.alloc((size_t)MAX_DIABATS * CPL_BINS * MAX_SPEC * 3) ||
       w->d_sbase.alloc_room(3 * std::max(nra, 1)) || w->d_sw.alloc_room(18 * (size_t)std::max(nra, 1)) || w->d_sdw.alloc_room(18 * (size_t)std::max(nra, 1)) ||
-      w->d_grids.alloc_room(K3 * std::max(ngrid, 1)) || w->d_pack.alloc_room(K3 * std::max(ngrid, 1)) || w->d_F11.alloc(n3) || w->d_com_atom.alloc(n3))
+      w->d_grids.alloc_room(K3 * std::max(ngrid, 1)) || w->d_pack.alloc_room(fast ? K3 : K3 * std::max(ngrid, 1)) /* (fast path: one blended grid; it may hold the prefilled Q_1 already: no re-allocation) */ || w->d_F11.alloc(n3) || w->d_com_atom.alloc(n3))
     FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB work buffers)");
   c->evb_cap = D;
   if (!w->tabs_uploaded) {
@@ -1981,6 +2004,11 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   HIPCHK(hipGetLastError());
   phase_end(c, PH_EVB_REAL, sr);
   stamp(c, 4, sr);
+  const bool pub_spin = c->overlap && c->evb_publish_spin && !dev_solve;      // fetch A's publish kernel waits for the chains' marks, not for their events
+  if (pub_spin) {
+    if (!w->d_chain_done.p) { if (w->d_chain_done.alloc(2)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (chain marks)"); HIPCHK(hipMemset(w->d_chain_done.p, 0, 16)); }      // (synchronous, once per context: the two marks come from different streams)
+    hipLaunchKernelGGL(k_evb_mark, dim3(1), dim3(1), 0, sr, w->d_chain_done.p, w->seq_A + 1);
+  }
   if (c->overlap) HIPCHK(hipEventRecord(w->ev_join2, w->stream2));
   // ---- 6a'. off-diagonal elements (evb_diabatic_coupling, :1021): few, latency-bound kernels writing only d_Foff; on aux2 behind the
   //           diagonal deltas (the all-atom gather waits for those, only the blend for these)
@@ -1999,6 +2027,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
                        E_cp_env, w->d_dVspec.p, c->d_Foff.p, n3, d_cpout);
     HIPCHK(hipGetLastError());
     stamp(c, 7, so);
+    if (pub_spin) hipLaunchKernelGGL(k_evb_mark, dim3(1), dim3(1), 0, so, w->d_chain_done.p + 1, w->seq_A + 1);
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_cpl, so));
   }
   if (defer_mol) {      // the principal diabat's per-molecule terms: behind the coupling chain on aux3 (they ran in front of it and held it up by ~80 us)
@@ -2052,16 +2081,18 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     // already satisfied and the publish kernel starts right behind the last energy kernel (a publish on another stream starts an event hop later)
     // ... behind ONE barrier packet: the descriptor stream (idle since its environment chain) waits for the coupling chain and records the
     // event this stream waits for (two waits in front of the publish kernel were two barrier packets of ~10 us on the way to the host's turn)
-    if (c->overlap) {
+    if (c->overlap && !pub_spin) {
       if (!w->ev_chains) HIPCHK(hipEventCreateWithFlags(&w->ev_chains, hipEventDisableTiming));
       if (ncp) HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_cpl, 0));
       HIPCHK(hipEventRecord(w->ev_chains, w->stream2));
       HIPCHK(hipStreamWaitEvent(sg, w->ev_chains, 0));
     }
     const bool lin_e = linear && ngrid > 0;
-    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, ++w->seq_A,
+    const long long seqA = ++w->seq_A;      // (the chains' marks carry this number)
+    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, seqA,
                        lin_e ? ngrid : 0, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid,
-                       (const double*)(c->d_partials.p + (size_t)S_RECIP * MAX_BLOCKS), n_recip_part, c->d_energies.p + S_RECIP);
+                       (const double*)(c->d_partials.p + (size_t)S_RECIP * MAX_BLOCKS), n_recip_part, c->d_energies.p + S_RECIP,
+                       pub_spin ? (const long long*)w->d_chain_done.p : (const long long*)nullptr, seqA, pub_spin ? (ncp ? 2 : 1) : 0, c->d_energies.p + S_FAULT);
     HIPCHK(hipGetLastError());
     stamp(c, 10, sg);
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, sg));
@@ -2125,17 +2156,20 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   }
   phase_end(c, PH_EVB_RECIP, sg);
   stamp(c, 6, sg);
-  CHK(fetch_A());
-  if (fast && ngrid && linear && fft_lds_usable(c) && !dev_solve) {      // start value of the blended charge grid (Q_1 on rank 0): needs no coefficient, so it goes out before the host's turn
+  w->pack_prefilled = false;
+  if (fast && ngrid && linear && fft_lds_usable(c) && !dev_solve) {      // start value of the blended charge grid (Q_1 on rank 0): needs no coefficient, so it goes out in front of the energy fetch (the stream idles there until the other chains have ended)
     if (!w->ev_prefill) HIPCHK(hipEventCreateWithFlags(&w->ev_prefill, hipEventDisableTiming));
     if (c->rank == 0) HIPCHK(hipMemcpyAsync(w->d_pack.p, c->d_Q.p, K3 * sizeof(double), hipMemcpyDeviceToDevice, sg));
     else HIPCHK(hipMemsetAsync(w->d_pack.p, 0, K3 * sizeof(double), sg));
     HIPCHK(hipEventRecord(w->ev_prefill, sg));
     w->pack_prefilled = true;
-  } else w->pack_prefilled = false;
+  }
+  CHK(fetch_A());
   if (single_join) {      // sg has waited for the environment chain and the couplings (fetch A) and holds the front end, the grid chain and the copy itself: + the per-molecule kernel
     if (!w->ev_side) HIPCHK(hipEventCreateWithFlags(&w->ev_side, hipEventDisableTiming));
-    HIPCHK(hipStreamWaitEvent(sg, c->ev_join2, 0));
+    w->side_by_A = pub_spin && linear && fast && c->evb_late_mol_join;
+    w->side_wo_mol = c->evb_late_mol_join && fast;      // the per-molecule kernel (aux3, behind the coupling chain) ends ~40 us after the chains: the blend phase starts without it
+    if (!w->side_wo_mol) HIPCHK(hipStreamWaitEvent(sg, c->ev_join2, 0));
     HIPCHK(hipEventRecord(w->ev_side, sg));
     w->side_valid = true;
   }
@@ -2211,7 +2245,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   } else HIPCHK(hipStreamSynchronize(c->stream));
   if (spec && *h_verdict != 1) {      // the tree has changed (or the check never ran): this call's side chains worked on a stale topology - the whole call again, the long way
     w->plan_valid = false; w->spec_misses++;
-    if (c->overlap && w->side_valid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0));
+    if (c->overlap && w->side_valid) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0)); if (w->side_wo_mol) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0)); }
     return MSEVB_RETRY;
   }
   HT(7);      // (7: the wait for fetch A alone; 9: Hamiltonian assembly; 10: Jacobi + blend enqueue / coefficient hand-over; 11: principal energy, wait for fetch B, switch)
@@ -2265,7 +2299,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     for (int d = 0; d < D; ++d) if (d == 0 || owned(c, d)) c->H[d][d] += E0;
     if (epot_out) *epot_out = c->H[0][0];
     if (fast) w->delta_dirty = true;      // no blend consumed the delta store: msevb_evb_partial_blend may still, the next call re-zeroes it
-    if (c->overlap && w->side_valid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0));      // nobody else joins the side streams for this call
+    if (c->overlap && w->side_valid) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0)); if (w->side_wo_mol) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0)); }      // nobody else joins the side streams for this call
     rearm.ok = true;
     return MSEVB_OK;
   }
@@ -2371,7 +2405,7 @@ void evb_release(msevb_ctx* c) {
     if (w->h_solve) (void)hipHostFree(w->h_solve);
     if (w->h_flag) (void)hipHostFree(w->h_flag);
     if (w->h_coef) (void)hipHostFree(w->h_coef);
-    w->d_coef.release();
+    w->d_coef.release(); w->d_plan.release(); w->d_sphere.release(); w->d_check.release(); w->d_refresh_scratch.release(); w->d_chain_done.release();
     if (w->h_E) (void)hipHostFree(w->h_E);
     delete w;
   }

@@ -694,6 +694,7 @@ int total_force_enqueue(msevb_ctx* c) {
 int total_force_collect(msevb_ctx* c, double* en) {
   const double* h = c->h_energies;
   // the index arithmetic of the reference (and ours) covers atoms at most one box image away; a blown-up trajectory is reported, not run
+  if (h[S_FAULT] == 2.0) FAIL(MSEVB_ERR_NUMERIC, "the energy-fetch kernel gave up waiting for the side chains of the MS-EVB call (2 s): a kernel of those chains never finished");
   if (h[S_FAULT] != 0.0) FAIL(MSEVB_ERR_NUMERIC, "atom coordinates are not finite or more than one box length outside the cell (unstable trajectory?)");
   if (c->list_valid) {   // flag for the NEXT call (src/general_routines.f90:1320-1326)
     const double skin = 1.2 * (c->rv - c->rc);

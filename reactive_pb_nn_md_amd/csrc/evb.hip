@@ -1200,7 +1200,7 @@ __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, 
       const long long t0 = wall_clock64();      // 100 MHz
       for (int k = 0; k < n_chains; ++k)
         while (__hip_atomic_load(chain_done + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != chain_seq) {
-          if (wall_clock64() - t0 > 200000000LL) { if (fault) *fault = 1.0; break; }      // 2 s (the first launch of a kernel in a process can take milliseconds to load)
+          if (wall_clock64() - t0 > 200000000LL) { if (fault) *fault = 2.0; break; }      // 2 s (the first launch of a kernel in a process can take milliseconds to load)
           __builtin_amdgcn_s_sleep(2);
         }
     }

@@ -780,6 +780,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "evb_pair_first") { c->evb_pair_first = v != 0.0; return MSEVB_OK; }
   if (s == "evb_pme_split") { c->evb_pme_split = v != 0.0; return MSEVB_OK; }
   if (s == "evb_publish_spin") { c->evb_publish_spin = v != 0.0; return MSEVB_OK; }
+  if (s == "evb_region_aside") { c->evb_region_aside = v != 0.0; return MSEVB_OK; }
   if (s == "evb_late_mol_join") { c->evb_late_mol_join = v != 0.0; return MSEVB_OK; }
   if (s == "evb_single_join") { c->evb_single_join = v != 0.0; return MSEVB_OK; }
   if (s == "evb_defer_fold") { c->evb_defer_fold = v != 0.0; return MSEVB_OK; }

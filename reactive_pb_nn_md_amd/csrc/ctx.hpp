@@ -318,6 +318,7 @@ struct msevb_ctx {
                                  // (needs bricks of <= 8 points per axis, K >= 16).  Measured 63 us alone against 55 + 4 + 5 for the LDS-atomic tiles with fill and copy, 2-3 % slower in the overlapped step: off
   bool spread_mfma = false;      // charge spreading as a per-cell contraction on the matrix cores (v_mfma_f64_16x16x4_f64), option spread_mfma
   bool attr_spread_mfma = false;
+  bool evb_region_aside = false;     // speculative step: the neighbourhood kernel (record + tree check) runs beside the descriptor chain, not in front of it
   bool evb_late_mol_join = true;     // MS-EVB fast path: the blend phase waits for the per-molecule kernel only in front of k_evb_blend, not at its start
   bool evb_publish_spin = true;      // fetch A's publish kernel waits for the side chains' marks on the device (no cross-stream event hops in front of the host's turn)
   bool evb_pair_first = false; hipEvent_t ev_pair_done = nullptr;      // schedule experiment (option evb_pair_first): diabat chains behind the pair loop

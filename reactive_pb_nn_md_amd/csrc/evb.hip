@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_evb_candidates(int N, double cx, double
                                                         int* __restrict__ counter, int* __restrict__ cand, int* __restrict__ region_counter, const double* __restrict__ sphere = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (sphere) { cx = sphere[0]; cy = sphere[1]; cz = sphere[2]; R2 = sphere[3]; }      // speculative step: centre and radius from k_evb_refresh
-  if (i == 0) *region_counter = 0;
+  if (i == 0 && region_counter) *region_counter = 0;
   bool in = false;
   if (i < N) {
     double dr[3] = {xyz[3 * i] - cx, xyz[3 * i + 1] - cy, xyz[3 * i + 2] - cz};
@@ -1054,7 +1054,7 @@ __device__ __forceinline__ void spec_check_molecule(const SpecPlan* __restrict__
 __global__ __launch_bounds__(64) void k_evb_refresh(const SpecPlan* __restrict__ pl, UnitDesc* __restrict__ units, CouplingDesc* __restrict__ cps, RecipAtom* __restrict__ ras,
                                                      const double* __restrict__ xyz, const double* __restrict__ mass, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms,
                                                      BoxDev box, double extra_R, double* __restrict__ sphere, int* __restrict__ check, int* __restrict__ verdict_host,
-                                                     unsigned long long* __restrict__ scratch) {
+                                                     unsigned long long* __restrict__ scratch, int* __restrict__ cand_counter = nullptr) {      // verdict_host == nullptr: k_evb_region, on a stream of its own, delivers it; cand_counter: re-armed here instead
   __shared__ double s_pos[MAX_SPEC][3], s_c[3];
   __shared__ int s_mw[MAX_CHAIN][MAX_MOL_ATOMS], s_mwn[MAX_CHAIN];
   const int lane = threadIdx.x, b = blockIdx.x, nu = pl->n_units;
@@ -1135,9 +1135,11 @@ __global__ __launch_bounds__(64) void k_evb_refresh(const SpecPlan* __restrict__
   const double f2 = __longlong_as_double((long long)atomicAdd(scratch, 0ull));
   const double R = sqrt(f2) + extra_R;
   sphere[0] = s_c[0]; sphere[1] = s_c[1]; sphere[2] = s_c[2]; sphere[3] = R * R;
+  scratch[0] = 0ull; scratch[1] = 0ull;
+  if (cand_counter) *cand_counter = 0;
+  if (!verdict_host) return;
   const int ok = (atomicAdd(&check[1], 0) == 0 && atomicAdd(&check[0], 0) == pl->n_pairs_total) ? 1 : 0;
   check[0] = 0; check[1] = 0; check[2] = ok;
-  scratch[0] = 0ull; scratch[1] = 0ull;
   *verdict_host = ok ? 1 : -1;
 }
 
@@ -1145,10 +1147,11 @@ __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ 
                              const double* __restrict__ mass, BoxDev box, int* __restrict__ counter, RegionRec* __restrict__ out, int cap,
                              int* __restrict__ cand_counter, RegionRec* __restrict__ out_host, int cap_host,
                              int* __restrict__ ticket, int* __restrict__ host_count, volatile long long* flag, long long seq,
-                             const SpecPlan* __restrict__ plan = nullptr, const EvbTablesDev* __restrict__ tabs = nullptr, const int* __restrict__ mol_type = nullptr, int* __restrict__ check = nullptr) {
+                             const SpecPlan* __restrict__ plan = nullptr, const EvbTablesDev* __restrict__ tabs = nullptr, const int* __restrict__ mol_type = nullptr, int* __restrict__ check = nullptr,
+                             int* __restrict__ verdict_host = nullptr) {      // verdict_host: this kernel runs BESIDE the descriptor chain (own stream): it delivers the verdict of the tree check and re-arms its own counter
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   double com_m[3] = {0, 0, 0};
-  if (m == 0) *cand_counter = 0;      // re-arm k_evb_candidates (which in turn re-arms `counter` for the next step)
+  if (m == 0 && !verdict_host) *cand_counter = 0;      // re-arm k_evb_candidates (which in turn re-arms `counter` for the next step)
   if (m < M) {
     double ch[3] = {0, 0, 0}, mh = 0;
     for (int k = 0; k < mol_natom[hyd]; ++k) { const int a = mol_atoms[hyd * MAX_MOL_ATOMS + k]; for (int d = 0; d < 3; ++d) ch[d] += xyz[3 * a + d] * mass[a]; mh += mass[a]; }
@@ -1180,6 +1183,12 @@ __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ 
   __threadfence_system();
   *host_count = atomicAdd(counter, 0);
   *ticket = 0;
+  if (verdict_host) {      // every workgroup's check counts are in (each drew its ticket behind them)
+    const int ok = (atomicAdd(&check[1], 0) == 0 && atomicAdd(&check[0], 0) == plan->n_pairs_total) ? 1 : 0;
+    check[0] = 0; check[1] = 0; check[2] = ok;
+    *counter = 0;
+    *verdict_host = ok ? 1 : -1;
+  }
   __threadfence_system();
   *flag = seq;
 }
@@ -1644,7 +1653,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   // The neighbourhood record is the first thing the host's turn needs, and everything the side chains do starts behind that turn: it goes
   // out on the MAIN stream, directly behind the integrator's first kernel (on a side stream it started one cross-queue event hop,
   // ~15 us, later; the pair loop, which it now precedes, has that much slack before the blend needs it)
-  const hipStream_t s_reg = c->overlap && c->evb_region_main ? c->stream : w->stream2;
+  hipStream_t s_reg = c->overlap && c->evb_region_main ? c->stream : w->stream2;
   if (!w->h_flag) { HIPCHK(hipHostMalloc((void**)&w->h_flag, 64, hipHostMallocDefault)); memset(w->h_flag, 0, 64); }
   // SPECULATIVE STEP: the tree of the last enumeration is assumed to hold; k_evb_region checks that on the device while the host goes straight on
   const bool spec = c->evb_speculate && c->overlap && w->plan_valid && w->plan_epoch == c->topo_epoch && w->plan.hyd == c->hydronium && !c->evb_device_solve && w->tabs_uploaded;
@@ -1654,10 +1663,16 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   }
   int* h_verdict = (int*)(w->h_flag + 4);
   *h_verdict = 0;
+  // speculative step with couplings: nothing on the device needs the neighbourhood record, only the host's verdict does - the kernel goes to the
+  // coupling stream (idle until the descriptors are refreshed; its chain ends with a mark the energy fetch waits for, so the verdict is
+  // in pinned memory before the host looks), and the descriptor chain starts with k_evb_refresh instead of behind 24-37 us of scanning
+  const bool region_aside = spec && !c->evb_region_main && c->evb_region_aside && c->evb_publish_spin && w->plan.n_cps > 0;
+  if (region_aside) { s_reg = c->aux3; HIPCHK(hipStreamWaitEvent(c->aux3, w->ev_in, 0)); }
   hipLaunchKernelGGL(k_evb_region, dim3((M + 1023) / 1024), dim3(1024), 0, s_reg, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
                      c->d_mass.p, box, w->d_counter.p, w->d_region.p, REGION_CAP, w->d_counter.p + 1, w->h_region, REGION_FAST,
                      w->d_counter.p + 2, w->h_count, (volatile long long*)(w->h_flag + 1), ++w->seq_R,
-                     spec ? (const SpecPlan*)w->d_plan.p : (const SpecPlan*)nullptr, (const EvbTablesDev*)w->d_tabs.p, (const int*)c->d_mol_type.p, w->d_check.p);
+                     spec ? (const SpecPlan*)w->d_plan.p : (const SpecPlan*)nullptr, (const EvbTablesDev*)w->d_tabs.p, (const int*)c->d_mol_type.p, w->d_check.p,
+                     region_aside ? h_verdict : (int*)nullptr);
   HIPCHK(hipEventRecord(w->ev_region, s_reg));
   HT(1);
   // ---- 2. principal diabat (calculate_total_force_energy, src/ms_evb.f90:411) - enqueued, not waited for
@@ -1933,7 +1948,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     else w->plan_fits = false;
   } else {      // descriptors of the last enumeration, already on the device: today's geometry written into them by one small kernel
     hipLaunchKernelGGL(k_evb_refresh, dim3(nu + ncp), dim3(64), 0, ss, (const SpecPlan*)w->d_plan.p, (UnitDesc*)(w->d_desc.p + off_u), (CouplingDesc*)(w->d_desc.p + off_c), (RecipAtom*)(w->d_desc.p + off_r),
-                       (const double*)c->d_xyz.p, (const double*)c->d_mass.p, (const int*)c->d_mol_natom.p, (const int*)c->d_mol_atoms.p, box, std::max(c->rc, w->screen_r) + 0.5, w->d_sphere.p, w->d_check.p, h_verdict, w->d_refresh_scratch.p);
+                       (const double*)c->d_xyz.p, (const double*)c->d_mass.p, (const int*)c->d_mol_natom.p, (const int*)c->d_mol_atoms.p, box, std::max(c->rc, w->screen_r) + 0.5, w->d_sphere.p, w->d_check.p, region_aside ? (int*)nullptr : h_verdict, w->d_refresh_scratch.p,
+                       region_aside ? w->d_counter.p + 1 : (int*)nullptr);
     HIPCHK(hipGetLastError());
     w->spec_steps++;
   }
@@ -1982,7 +1998,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   const hipStream_t sr = ss;     // on aux2 behind the descriptors: beside the principal force and the reciprocal space of the diabats
   phase_begin(c, PH_EVB_REAL, sr);
   if (spec) {
-    hipLaunchKernelGGL(k_evb_candidates, dim3((N + 255) / 256), dim3(256), 0, sr, N, 0.0, 0.0, 0.0, 0.0, c->d_xyz.p, box, w->d_counter.p + 1, w->d_cand.p, w->d_counter.p, (const double*)w->d_sphere.p);
+    hipLaunchKernelGGL(k_evb_candidates, dim3((N + 255) / 256), dim3(256), 0, sr, N, 0.0, 0.0, 0.0, 0.0, c->d_xyz.p, box, w->d_counter.p + 1, w->d_cand.p, region_aside ? (int*)nullptr : w->d_counter.p, (const double*)w->d_sphere.p);
   } else {
     // candidate sphere: centre = hydronium COM, radius = farthest special atom + max(cutoff, repulsion screen) + a little
     const RegionRec* rh = find_region(w, c->hydronium);

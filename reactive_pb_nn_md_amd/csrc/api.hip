@@ -570,8 +570,10 @@ int msevb_get_verlet_list(msevb_ctx* c, int* vp, int* nl, long* nn) {
       off[0] = 0;
       for (int s = 0; s < HALF_SLOTS; ++s) off[s + 1] = off[s] + cstart[slots[s] + 1] - cstart[slots[s]];
     }
+    if ((size_t)st[k] + cnt[k] > nb.size()) { char b[160]; snprintf(b, sizeof b, "msevb_get_verlet_list: row %d of the device list is out of range (start %u, count %u, stride %u)", k, st[k], cnt[k], c->nbr_cap); FAIL(MSEVB_ERR_STATE, b); }
     for (unsigned q = st[k]; q < st[k] + cnt[k]; ++q) {
       int js = (int)((unsigned)nb[q] & NBR_IDX_MASK);
+      if (!c->pair_tiles && js >= N) { char b[160]; snprintf(b, sizeof b, "msevb_get_verlet_list: entry %u of row %d names atom %d of %d", q - st[k], k, js, N); FAIL(MSEVB_ERR_STATE, b); }
       if (c->pair_tiles) {      // every pair is stored once, with the atom that comes first in its cell's half neighbourhood
         int s = 0; while (s + 1 < HALF_SLOTS && js >= off[s + 1]) ++s;
         js = cstart[slots[s]] + (js - off[s]);

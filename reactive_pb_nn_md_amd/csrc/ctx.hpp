@@ -162,7 +162,7 @@ struct DBuf {  // device buffer
     // MSEVB_POISON=1 (diagnostic): fresh device memory reads as NaN / -1 instead of whatever the allocator hands back (zeros in a young process,
     // another context's data later), so that a read of something nobody wrote shows in the first test that does it, not in the fortieth
     static const bool poison = getenv("MSEVB_POISON") != nullptr;
-    if (poison) (void)hipMemset(p, 0xFF, (count ? count : 1) * sizeof(T));
+    if (poison) { (void)hipMemset(p, 0xFF, (count ? count : 1) * sizeof(T)); (void)hipDeviceSynchronize(); }      // (hipMemset of device memory may return early; the library's streams do not wait for the null stream)
     return 0;
   }
   // for buffers whose size follows the diabat count: grow with half as much again, so that a tree gaining a diabat or two during a run

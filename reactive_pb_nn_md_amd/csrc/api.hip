@@ -125,6 +125,7 @@ int msevb_destroy(msevb_ctx* c) {
   if (c->ev_fork0) (void)hipEventDestroy(c->ev_fork0);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_refresh) (void)hipEventDestroy(c->ev_refresh);
+  if (c->ev_weights) (void)hipEventDestroy(c->ev_weights);
   pme_teardown(c);
   DBuf<int>* ib[] = {&c->d_atype, &c->d_mol_type, &c->d_mol_natom, &c->d_mol_atoms, &c->d_mol_of, &c->d_cell_of, &c->d_perm, &c->d_cell_keys_tmp,
                      &c->d_perm_tmp, &c->d_cell_start, &c->d_inv_perm, &c->d_tile_max, &c->d_nbr, &c->d_nbr2, &c->d_prune_mode, &c->d_frozen, &c->d_type_sorted, &c->d_mol_sorted, &c->d_base, &c->d_splindex, &c->d_base_s};
@@ -647,6 +648,7 @@ void stamps_report(msevb_ctx* c) {
 // the principal-diabat force call, everything enqueued on the stream; energies land in c->h_energies after fetch_energies()
 int total_force_enqueue(msevb_ctx* c) {
   c->timing_now = c->timing && (c->timing_tick++ % c->timing_stride) == 0;
+  c->weights_side = false;      // (set again by pme_side_weights when the MS-EVB call has the stored weights made for THIS call's positions)
   // Verlet freshness: src/total_energy_forces.f90:30-39 (rebuild when the flag was raised by the previous call)
   CHK(nb_settle(c));
   stamp(c, 0, c->stream);
@@ -777,6 +779,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
   if (s == "pme_weightless") { c->pme_weightless = v != 0.0; return MSEVB_OK; }
+  if (s == "pme_side_weights") { c->pme_side_weights = v != 0.0; return MSEVB_OK; }
   if (s == "spread_mfma") { c->spread_mfma = v != 0.0; return MSEVB_OK; }
   if (s == "gather_mfma") { c->gather_mfma = v != 0.0; return MSEVB_OK; }
   if (s == "evb_pair_first") { c->evb_pair_first = v != 0.0; return MSEVB_OK; }

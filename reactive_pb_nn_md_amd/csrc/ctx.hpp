@@ -312,6 +312,7 @@ struct msevb_ctx {
   bool pme_weightless = true;       // tiled spread / gather recompute the B-spline weights from (uscale, nearpt) and the tables: no 288 B/atom weight store
   bool weights_needed_now = false;  // this call has another reader of d_w / d_dw (set by the MS-EVB call for its per-diabat-transform paths)
   int attr_gather_wl = 0;           // dynamic LDS the weight-free gather has been allowed so far
+  bool pme_side_weights = false; bool weights_side = false; hipEvent_t ev_weights = nullptr;      // MS-EVB fast path: stored weights computed on a side stream for the blend phase's gather (pme_side_weights)
   bool weights_valid = false;       // d_w / d_dw hold this step's weights (k_pme_prep ran, not k_pme_prep_light)
   int pme_tile_threads = 512;    // workgroup size of the LDS-tile spread / gather kernels (option pme_tile_threads: 256 or 512)
   bool spread_bricks = false;    // option: owner-computes charge spreading on the matrix cores (k_pme_spread_bricks): every cell's workgroup writes ITS brick of the grid, no atomics, no zero-fill
@@ -426,6 +427,7 @@ extern "C" int download_atoms3(msevb_ctx* c, double* dst_host, const double* src
 int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part_stride, int* nblocks);
 int pme_prepare_atoms(msevb_ctx* c, bool with_indices);
 bool pme_weightless_now(const msevb_ctx* c);
+int pme_side_weights(msevb_ctx* c, hipStream_t st, hipEvent_t after);
 bool fft_lds_usable(const msevb_ctx* c);                              // fft_lds.hip
 int fft_lds_setup(msevb_ctx* c);
 int fft_lds_solve(msevb_ctx* c, const double* Q, double2* work, double* theta, double* part, int* nblocks, hipStream_t st);

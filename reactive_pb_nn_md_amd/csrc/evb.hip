@@ -1689,10 +1689,13 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   c->refresh_side_now = c->overlap && c->evb_region_main;
   c->weights_needed_now = !(fast && c->evb_recip_linear && c->d_green.p);      // per-diabat transforms / element stores read the principal diabat's weights (k_evb_patch, k_stencil_gather, k_evb_recip_special)
   w->side_valid = false; w->side_wo_mol = false; w->side_by_A = false;
+  const bool side_w = fast && c->overlap && c->pme_side_weights && pme_weightless_now(c);      // the blend phase's gather reads stored weights made beside the front end
+  if (side_w) CHK(pme_side_weights(c, c->aux3, w->ev_in));
   const int rc_tfe = total_force_enqueue(c);
   c->weights_needed_now = false;
   c->shard_now = false; c->skip_gather_now = false; c->defer_molecules_now = false; c->ev_pos_ready = nullptr; c->defer_fold_now = false; c->skip_side_joins_now = false; c->pme_split_now = false; c->refresh_side_now = false;
   CHK(rc_tfe);
+  if (side_w) c->weights_side = true;      // (total_force_enqueue cleared it)
   HT(2);
   auto fetch_region = [&]() -> int {
   if (spin_wait((volatile long long*)(w->h_flag + 1), w->seq_R, w->ev_region)) HIPCHK(hipErrorUnknown);

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_pme_prep(int N, int K, int G, const dou
   if (!(u >= 0.0 && u < (double)K)) { *fault = 1.0; u = 0.5; }      // more than one box away, or not a number: flag it, stay inside the grid
   if (fabs(fmod(u, 1.0)) < 1e-6) u = u + 1e-6;
   const int np = (int)floor(u);
-  if (k == 0) { uscale[3 * i + l] = u; base[3 * i + l] = np; }
+  if (k == 0 && uscale) { uscale[3 * i + l] = u; base[3 * i + l] = np; }      // (uscale == nullptr: weights only, beside k_pme_prep_light - pme_side_weights)
   const int n = np - k;
   const double a1 = u - (double)n, a2 = a1 - 1.0;
   const int g6 = (int)ceil(a1 / 6.0 * (double)G);
@@ -1029,6 +1029,22 @@ bool pme_weightless_now(const msevb_ctx* c) {
   return c->pme_weightless && !c->weights_needed_now && pme_tiles_ok(c) && !other_spread;
 }
 
+// MS-EVB fast path with a weight-free front end: the 36 stored weights per atom all the same, by k_pme_prep (weights only) on an idle side stream
+// at the very start of the step (`after` = the new positions), for the ONE gather of the blend phase - which sits on the step's critical path
+// and takes 30 us with stored weights, 40 recomputing table rows.  pme_gather waits for ev_weights.
+int pme_side_weights(msevb_ctx* c, hipStream_t st, hipEvent_t after) {
+  if (!c->pme_side_weights) return MSEVB_OK;
+  if (!c->ev_weights) HIPCHK(hipEventCreateWithFlags(&c->ev_weights, hipEventDisableTiming));
+  HIPCHK(hipStreamWaitEvent(st, after, 0));      // (the new positions)
+  const long nt = 18L * c->N;
+  hipLaunchKernelGGL(k_pme_prep, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, c->N, c->K, c->spline_grid, c->d_xyz.p, c->kk[0][0], c->kk[0][1],
+                     c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, (double*)nullptr,
+                     (int*)nullptr, (int*)nullptr, c->d_w.p, c->d_dw.p, c->d_energies.p + S_FAULT, (const int*)nullptr, (int*)nullptr, (double*)nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(c->ev_weights, st));
+  return MSEVB_OK;
+}
+
 int pme_prepare_atoms(msevb_ctx* c, bool with_indices) {
   const int N = c->N;
   const long nt = 18L * N;
@@ -1036,10 +1052,10 @@ int pme_prepare_atoms(msevb_ctx* c, bool with_indices) {
     hipLaunchKernelGGL(k_pme_prep_light, dim3((unsigned)((3 * N + 255) / 256)), dim3(256), 0, pme_stream(c), N, c->K, c->d_xyz.p, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
                        c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_uscale.p, c->d_base.p, c->d_energies.p + S_FAULT, c->d_inv_perm.p, c->d_uscale_s.p, c->d_base_s.p);
     HIPCHK(hipGetLastError());
-    c->weights_valid = false;
+    c->weights_valid = false; c->weights_side = false;
     return MSEVB_OK;
   }
-  c->weights_valid = true;
+  c->weights_valid = true; c->weights_side = false;
   hipLaunchKernelGGL(k_pme_prep, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, pme_stream(c), N, c->K, c->spline_grid, c->d_xyz.p, c->kk[0][0], c->kk[0][1],
                      c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_B6.p, c->d_B5.p, c->d_uscale.p,
                      c->d_base.p, with_indices ? c->d_splindex.p : (int*)nullptr, c->d_w.p, c->d_dw.p, c->d_energies.p + S_FAULT,
@@ -1067,7 +1083,8 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
     }
     if (c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= c->K && T.y <= c->K && T.z <= c->K) {      // workgroup per cell, potential staged in LDS
       const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
-      if (!c->weights_valid) {      // k_pme_prep_light ran: per workgroup 192 B of LDS per 8-lane group + 48 B per atom of the largest cell
+      if (!c->weights_valid && c->weights_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_weights, 0));      // (k_pme_weights filled them in on a side stream meanwhile)
+      if (!c->weights_valid && !c->weights_side) {      // k_pme_prep_light ran: per workgroup 192 B of LDS per 8-lane group + 48 B per atom of the largest cell
         const int cap = std::min(std::max((int)(c->cell_atoms_max * 1.05) + 1, 16), 1024);      // (the largest cell of the last build whose statistics the host has seen)
         const size_t lds = tile_bytes + (size_t)c->pme_tile_threads * 24 + (size_t)cap * 48 + 16;
         if (lds > 160 * 1024) FAIL(MSEVB_ERR_LIMIT, "pme_gather: cell too large for the weight-free gather (set option pme_weightless=0)");
@@ -1083,7 +1100,7 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
       return MSEVB_OK;
     }
   }
-  if (!c->weights_valid) FAIL(MSEVB_ERR_STATE, "pme_gather: the per-atom weights of this step were not stored (option pme_weightless) and the tiled gather does not serve this context");
+  if (!c->weights_valid && !c->weights_side) FAIL(MSEVB_ERR_STATE, "pme_gather: the per-atom weights of this step were not stored (option pme_weightless) and the tiled gather does not serve this context");
   hipLaunchKernelGGL(k_pme_gather, dim3((N * 8 + 255) / 256), dim3(256), 0, c->stream, N, c->K, chg, c->d_base.p, c->d_w.p, c->d_dw.p, theta ? theta : c->d_theta.p, c->conv, c->kk[0][0],
                      c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, atomic ? 1 : 0, add_lo, add_hi);
   HIPCHK(hipGetLastError());

@@ -22,10 +22,12 @@ __global__ __launch_bounds__(256) void k_stencil_from_u(int n, int K, int G, con
   const int np = (int)floor(u);
   if (k == 0) base[3 * i + l] = np;
   const double a1 = u - (double)(np - k), a2 = a1 - 1.0;
-  w[t] = B6[(int)ceil(a1 / 6.0 * (double)G) - 1];
+  // a scaled coordinate that IS an integer gives a1 = 0 at k = 0 and row 0 (the reference reads B6_spline(0), outside its table): the callers of
+  // these entry points hand in arbitrary coordinates, so the rows are held inside the tables (row 1 = the table's value next to zero)
+  w[t] = B6[min(max((int)ceil(a1 / 6.0 * (double)G), 1), G) - 1];
   double d = 0.0;
-  if (a1 < 5.0) d = B5[(int)ceil(a1 / 5.0 * (double)G) - 1];
-  if (0.0 < a2) d = d - B5[(int)ceil(a2 / 5.0 * (double)G) - 1];
+  if (a1 < 5.0) d = B5[min(max((int)ceil(a1 / 5.0 * (double)G), 1), G) - 1];
+  if (0.0 < a2) d = d - B5[min(max((int)ceil(a2 / 5.0 * (double)G), 1), G) - 1];
   dw[t] = d;
 }
 

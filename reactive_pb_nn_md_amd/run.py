@@ -122,19 +122,25 @@ def main(argv=None):
         en = h.md_integrate_atomic(nb, dt, use_evb=use_evb)
         done += nb
         step = n_old + done
+        def write_hops(at_block_end):
+            # every hop of the block with its OWN step, as the reference writes them (src/ms_evb.f90:331-335): the library logs the number
+            # of the EVB force call a switch happened in; read BEFORE the barostat makes force calls of its own, the block's MD calls are the
+            # last nb of them (a there-and-back pair shows both); a switch inside a barostat force call belongs to the barostat's step
+            hops, calls = h.hop_log()
+            if hop is not None:
+                for call, h_from, h_to in hops:
+                    hop.write(" step  %d\n proton hop from  %d  to  %d\n" % (step - (calls - int(call)) if at_block_end else step, h_from, h_to))
+                hop.flush()
+        if use_evb:
+            write_hops(True)
         if baro is not None and step % barofreq == 0:
             t = h.topology()
             acc, e_now = baro.move(h, en[-1, 0], use_evb, _mol_atoms(t), spec.mass, spec.n_mole)
             en[-1, 0] = e_now
             spec = h.spec
+            if use_evb:
+                write_hops(False)
         if use_evb:
-            # every hop of the block with its OWN step, as the reference writes them (src/ms_evb.f90:331-335): the library logs the number
-            # of the EVB force call a switch happened in; the block's calls are the last nb of them (a there-and-back pair shows both)
-            hops, calls = h.hop_log()
-            if hop is not None:
-                for call, h_from, h_to in hops:
-                    hop.write(" step  %d\n proton hop from  %d  to  %d\n" % (step - (calls - int(call)), h_from, h_to))
-                hop.flush()
             hyd = h.topology()["hydronium_molecule"]
         if done % max(1, n_output) == 0:
             t5 = None

@@ -183,6 +183,21 @@ int msevb_evb_partial_blend(msevb_ctx* ctx, const double* eigvec, double* force)
 /* average device time (ms) of each phase over the calls since the last reset, names as the reference's debug trace */
 int msevb_get_phase_times(msevb_ctx* ctx, int* n, const char** names, double* ms, long* calls);
 int msevb_reset_phase_times(msevb_ctx* ctx);
+/* Switches of the library (0 / 1 unless a unit is given); the environment variable MSEVB_OPTIONS="name=value,..." applies the same calls at
+   msevb_finalize.  Defaults are the measured best on MI355X; every alternative is kept because a test or DESIGN.md / HISTORY.md compares against it.
+     physics / integrator : ensemble_nvt (0), friction_coeff (1/ps), temperature (K), langevin_seed; evb_element_stores (0: keep F_dd / F_pd of every
+                            Hamiltonian element as the reference's evb_forces_store does), evb_recip_linear (1: diabats' reciprocal space by linear
+                            response, 0: one transform pair per diabat as src/ms_evb.f90:1962 does)
+     pair loop            : pair_tiles (-1 auto), pair_flat (1: flat per-cell list, pair_flat.hip), pair_taylor (1: one-row Ewald table), pair_prune (1),
+                            prune_delta (0.6 A), pair_split (0), pair_threads (1024), prune_freeze (diagnostic), nbr_tiles (1), nbr_cap (row stride)
+     PME                  : fft_own (1: own 64^3 / 128^3 transforms, 0: rocFFT), spread_tiles (1), pme_weightless (1: no per-atom weight store),
+                            pme_side_weights (0), spread_mfma (0), spread_bricks (0), gather_mfma (0), pme_tile_threads (512), fft_batch
+     schedule             : overlap (1: four streams), graphs (1: front end replayed as a hipGraph), evb_speculate (1), evb_publish_spin (1),
+                            evb_late_mol_join (1), evb_single_join (1), evb_defer_fold (1), evb_pme_split (1), evb_defer_molecules (0),
+                            evb_prelaunch_blend (0), evb_region_main (0), evb_region_aside (0), evb_pair_first (0), evb_device_solve (0),
+                            evb_coupling_blocks (0 = auto), pin_host_arrays (0)
+     multi-GPU            : shard_principal (set by msevb_comm_init)
+     measurement          : phase_timing (0), phase_timing_stride (8) */
 int msevb_set_option(msevb_ctx* ctx, const char* name, double value);
 
 #ifdef __cplusplus

@@ -137,7 +137,7 @@ int msevb_destroy(msevb_ctx* c) {
   c->d_pair_par.release(); c->d_moltypes.release(); c->d_ewald_tab.release(); c->d_ewald_tay.release(); c->d_nbr_count.release(); c->d_nbr_split.release(); c->d_host_perm.release(); c->d_stage3.release(); c->d_nbr2_count.release(); c->d_posq_prune.release(); c->d_flat.release(); c->d_cell_trips.release(); c->d_nbr_start.release();
   c->d_w_s.release(); c->d_comm_h.release(); c->d_comm_e.release(); c->d_bad.release(); c->d_fsorted.release();
   if (c->h_ke) (void)hipHostFree(c->h_ke);
-  c->d_sort_tmp.release(); c->d_posq.release(); c->d_grid.release(); c->d_fft_work.release(); c->d_fft_work_b.release();
+  c->d_sort_tmp.release(); c->d_sort_hist.release(); c->d_posq.release(); c->d_grid.release(); c->d_fft_work.release(); c->d_fft_work_b.release();
   for (int p = 0; p < PH_COUNT; ++p) for (hipEvent_t e : c->ph[p].ev) (void)hipEventDestroy(e);
   if (c->h_energies) (void)hipHostFree(c->h_energies);
   if (c->h_nbr_stats) (void)hipHostFree(c->h_nbr_stats);
@@ -779,6 +779,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
   if (s == "spread_tiles") { c->spread_tiles = v != 0.0; return MSEVB_OK; }
   if (s == "pme_weightless") { c->pme_weightless = v != 0.0; return MSEVB_OK; }
+  if (s == "cell_sort_own") { c->cell_sort_own = v != 0.0; return MSEVB_OK; }
   if (s == "pme_side_weights") { c->pme_side_weights = v != 0.0; return MSEVB_OK; }
   if (s == "spread_mfma") { c->spread_mfma = v != 0.0; return MSEVB_OK; }
   if (s == "gather_mfma") { c->gather_mfma = v != 0.0; return MSEVB_OK; }

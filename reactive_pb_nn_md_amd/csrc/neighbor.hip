@@ -29,6 +29,91 @@ __global__ void k_cell_assign(int N, const double* __restrict__ xyz, BoxDev box,
   vals[i] = i;
 }
 
+// ---- stable counting sort of the atoms by cell (what hipcub's radix sort delivers - ascending cell, ties in atom order - in four kernels instead
+// of ten: the radix passes are 5 us each with 10 us between them, 125 us of every list rebuild)
+constexpr int CS_APB = 256;      // atoms per block of the histogram / scatter kernels
+// cell of every atom (k_cell_assign's arithmetic) + per-block histogram row hist[b][cell]
+__global__ __launch_bounds__(256) void k_cs_hist(int N, const double* __restrict__ xyz, BoxDev box, int3 nc, int ncell, int* __restrict__ keys, int* __restrict__ hist) {
+  extern __shared__ int s_h[];
+  for (int k = threadIdx.x; k < ncell; k += blockDim.x) s_h[k] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * CS_APB + threadIdx.x;
+  if (i < N) {
+    int cc[3];
+    const int ncv[3] = {nc.x, nc.y, nc.z};
+    for (int d = 0; d < 3; ++d) {
+      double f = xyz[3 * i + d] * box.invL[d];
+      f = f - floor(f);
+      int v = (int)(f * ncv[d]);
+      if (v >= ncv[d]) v = ncv[d] - 1;
+      if (v < 0) v = 0;
+      cc[d] = v;
+    }
+    const int key = cc[0] + nc.x * (cc[1] + nc.y * cc[2]);
+    keys[i] = key;
+    atomicAdd(&s_h[key], 1);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < ncell; k += blockDim.x) hist[(size_t)blockIdx.x * ncell + k] = s_h[k];
+}
+// hist[b][cell] -> number of the cell's atoms in the blocks before b: one wavefront per cell, lane l takes a contiguous run of blocks, the
+// runs' totals meet in a wave scan (a thread per cell walking all blocks was 97 us of dependent loads)
+__global__ __launch_bounds__(64) void k_cs_scan(int nblk, int ncell, int* __restrict__ hist, int* __restrict__ cell_total) {
+  const int k = blockIdx.x, lane = threadIdx.x;
+  const int per = (nblk + 63) / 64, b0 = lane * per, b1 = min(b0 + per, nblk);
+  int v[16];      // per <= 16: N <= 262144 atoms in blocks of 256
+  int sum = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { v[q] = (q < per && b0 + q < b1) ? hist[(size_t)(b0 + q) * ncell + k] : 0; sum += v[q]; }
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+  int run = incl - sum;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) if (q < per && b0 + q < b1) { hist[(size_t)(b0 + q) * ncell + k] = run; run += v[q]; }
+  if (lane == 63) cell_total[k] = incl;
+}
+// cell_start[] = exclusive prefix of the cells' totals (<= 4096 cells, one workgroup)
+__global__ __launch_bounds__(1024) void k_cs_cells(int ncell, int N, const int* __restrict__ cell_total, int* __restrict__ cell_start) {
+  __shared__ int s_w[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int v[4], sum = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int k = 4 * t + q; v[q] = k < ncell ? cell_total[k] : 0; sum += v[q]; }
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(incl, o, 64); if (lane >= o) incl += x; }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += s_w[w];
+  int run = base + incl - sum;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int k = 4 * t + q; if (k < ncell) cell_start[k] = run; run += v[q]; }
+  if (t == 0) cell_start[ncell] = N;
+}
+// one wavefront per block of CS_APB atoms, chunks of 64 in atom order: position = cell_start + atoms of the cell in earlier blocks + earlier
+// atoms of the cell in this block (lanes of a chunk rank themselves with 64 shuffles, one lane per cell advances the cell's counter)
+__global__ __launch_bounds__(64) void k_cs_scatter(int N, int ncell, const int* __restrict__ keys, const int* __restrict__ hist, const int* __restrict__ cell_start,
+                                                   int* __restrict__ perm, int* __restrict__ cell_of) {
+  extern __shared__ int s_c[];
+  const int lane = threadIdx.x;
+  for (int k = lane; k < ncell; k += 64) s_c[k] = cell_start[k] + hist[(size_t)blockIdx.x * ncell + k];
+  __syncthreads();
+  for (int c0 = 0; c0 < CS_APB; c0 += 64) {
+    const int i = blockIdx.x * CS_APB + c0 + lane;
+    const int key = i < N ? keys[i] : -1;
+    int rank = 0, cnt = 0;
+    for (int l = 0; l < 64; ++l) { const int kl = __shfl(key, l, 64); if (kl == key) { ++cnt; if (l < lane) ++rank; } }
+    int base = 0;
+    if (key >= 0) base = s_c[key];      // (every lane of the cell's group reads the counter before its first lane advances it: one wavefront, in-order LDS)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (key >= 0 && rank == 0) s_c[key] = base + cnt;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (key >= 0) { perm[base + rank] = i; cell_of[base + rank] = key; }
+  }
+}
+
 __global__ void k_cell_bounds(int N, int ncell, const int* __restrict__ keys, int* __restrict__ cell_start) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= N) return;
@@ -471,6 +556,19 @@ int nb_build_begin(msevb_ctx* c) {
   if (c->d_cell_of.alloc(N) || c->d_perm.alloc(N) || c->d_cell_keys_tmp.alloc(N) || c->d_perm_tmp.alloc(N) || c->d_cell_start.alloc(ncell + 1) ||
       c->d_nbr_count.alloc(N + 1) || c->d_nbr_start.alloc(N + 1) || c->d_nbr_split.alloc(N + 1) || c->d_inv_perm.alloc(N))
     FAIL(MSEVB_ERR_HIP, "hipMalloc failed (neighbour structure)");
+  if (c->cell_sort_own && N <= 262144 && ncell <= 4096) {      // four kernels; the same permutation as the radix sort below (stable)
+    const int nblk = (N + CS_APB - 1) / CS_APB;
+    if (c->d_sort_hist.alloc((size_t)nblk * ncell + ncell)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (sort workspace)");
+    hipLaunchKernelGGL(k_cs_hist, dim3(nblk), dim3(256), (size_t)ncell * sizeof(int), c->stream, N, c->d_xyz.p, box, nc, ncell, c->d_cell_keys_tmp.p, c->d_sort_hist.p);
+    hipLaunchKernelGGL(k_cs_scan, dim3(ncell), dim3(64), 0, c->stream, nblk, ncell, c->d_sort_hist.p, c->d_sort_hist.p + (size_t)nblk * ncell);
+    hipLaunchKernelGGL(k_cs_cells, dim3(1), dim3(1024), 0, c->stream, ncell, N, (const int*)(c->d_sort_hist.p + (size_t)nblk * ncell), c->d_cell_start.p);
+    hipLaunchKernelGGL(k_cs_scatter, dim3(nblk), dim3(64), (size_t)ncell * sizeof(int), c->stream, N, ncell, c->d_cell_keys_tmp.p, c->d_sort_hist.p, c->d_cell_start.p, c->d_perm.p, c->d_cell_of.p);
+    HIPCHK(hipGetLastError());
+    CHK(nb_refresh_sorted(c));
+    c->list_valid = false;
+    c->cells_valid = true;
+    return MSEVB_OK;
+  }
   hipLaunchKernelGGL(k_cell_assign, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, c->d_xyz.p, box, nc, c->d_cell_keys_tmp.p, c->d_perm_tmp.p);
   int bits = 1;
   while ((1 << bits) < ncell) ++bits;

@@ -152,6 +152,27 @@ def test_mfma_force_interpolation_config_B():
     assert np.abs(a[4] - b[4]).max() < 1e-8 * np.abs(a[4]).max() and np.abs(a[5] - b[5]).max() < 1e-8
 
 
+def test_own_cell_sort_against_radix_sort():
+    """the list rebuild's cell sort (construct_verlet_list_grid's cell assignment, src/general_routines.f90:1408-1470): the library's stable
+    counting sort (three kernels) against hipcub's radix sort (option cell_sort_own=0) at BASELINE.json configs[2] size and on a small
+    fixture - the same half list, the same energies, the same 20-step trajectory (which rebuilds the list on the way)"""
+    for spec in (_synthetic(32, 8, 11, 64), system.from_golden(golden("evb_n6_d4_s2"))):
+        out = []
+        for own in (1, 0):
+            h = api.MsEvbHip(spec)
+            h.set_option("cell_sort_own", own)
+            h.construct_verlet_list()
+            vp, nl = h.get_verlet_list()
+            en = h.calculate_total_force_energy(want_force=False)[0]
+            h.set_velocities(synth.maxwell_boltzmann(spec.mass, 600.0, 5))
+            tr = h.md_integrate_atomic(20, spec.delta_t, use_evb=False)
+            out.append((vp, nl, en["potential"], tr))
+            h.close()
+        a, b = out
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and rel(a[2], b[2]) < 1e-13
+        assert np.abs(a[3] - b[3]).max() < 1e-9 * np.abs(b[3]).max()
+
+
 def test_pme_without_the_weight_store_changes_nothing():
     """option pme_weightless (default on): k_pme_prep_light keeps (u, nearpt) only and the tiled spread / gather take the B-spline weights from the
     tables themselves (grid_Q / derivative_grid_Q, src/pme.f90:184-262, :346-493, table rows :220-247, :412-414) - the SAME bits as with the

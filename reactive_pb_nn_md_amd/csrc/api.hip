@@ -814,7 +814,12 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "evb_element_stores") { c->evb_element_stores = v != 0.0; return MSEVB_OK; }
   if (s == "shard_principal") { c->shard_principal = v != 0.0; return MSEVB_OK; }
   if (s == "pair_flat") { c->pair_flat_opt = (int)v; if (c->prune && c->finalized) (void)nb_prune_reset(c); return MSEVB_OK; }
-  if (s == "pair_split") { c->pair_split_opt = (int)v; return MSEVB_OK; }
+  if (s == "pair_split") {      // the rows' cut positions are counted by the list build only while the option is on: a list built without them is rebuilt now
+    const bool was = c->pair_split_opt != 0;
+    c->pair_split_opt = (int)v;
+    if (!was && c->pair_split_opt != 0 && c->list_valid) CHK(nb_build(c));
+    return MSEVB_OK;
+  }
   if (s == "prune_freeze") { c->prune_freeze = v != 0.0; return MSEVB_OK; }
   if (s == "pair_taylor") { c->pair_taylor = v != 0.0; return MSEVB_OK; }
   if (s == "pair_tiles") { c->pair_tiles_opt = (int)v; c->list_valid = false; return MSEVB_OK; }

@@ -226,7 +226,7 @@ __device__ __forceinline__ bool nbr_decide_fp64(const double4& pr, double xi, do
 // HALF: the tile is the HALF neighbourhood (the cell + its 13 forward cells, cell_half_neighbourhood order), an atom keeps the partners
 // that come AFTER it in the tile (same cell: larger sorted index; forward cells: all) - every pair once - and the entries hold the
 // partner's position in the tile: the list of the half-list LDS pair kernel (pair.hip).  The set of unordered pairs is the same.
-template <bool HALF>
+template <bool HALF, bool SPLIT>      // SPLIT: also count where every row crosses into the eighth cell of its tile (only the split pair kernel, option pair_split, reads that)
 __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int* __restrict__ cell_start, const double4* __restrict__ posq, const int* __restrict__ mol_s,
                                                           const int* __restrict__ type_s, BoxDev box, double rv2, unsigned cap, int tile_cap,
                                                           unsigned* __restrict__ count, unsigned* __restrict__ start, int* __restrict__ nbr, int* __restrict__ stats, unsigned* __restrict__ split) {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
         if (hA && slotA < cap) nbr[base + slotA] = en.x;
         if (hB && slotB < cap) nbr[base + slotB] = en.y;
         total += (unsigned)(__popcll(mA) + __popcll(mB));
-        if (HALF && p0 < off7) total_lo += (unsigned)(__popcll(__ballot(hA && pA < off7)) + __popcll(__ballot(hB && pB < off7)));
+        if (SPLIT && p0 < off7) total_lo += (unsigned)(__popcll(__ballot(hA && pA < off7)) + __popcll(__ballot(hB && pB < off7)));
       }
     } else {           // neighbourhood larger than the tile: the same decisions from global memory
       for (int sl = 0; sl < ns; ++sl) {
@@ -333,11 +333,11 @@ __global__ __launch_bounds__(1024, 2) void k_neighbors_tiles(int3 nc, const int*
             if (slot < cap) nbr[base + slot] = (int)(idx | ((unsigned)type_s[j] << NBR_IDX_BITS));
           }
           total += (unsigned)__popcll(m);
-          if (HALF) total_lo += (unsigned)__popcll(__ballot(hit && o + p < off7));
+          if (SPLIT) total_lo += (unsigned)__popcll(__ballot(hit && o + p < off7));
         }
       }
     }
-    if (lane == 0) { count[i] = stats ? min(total, cap) : total; start[i] = base; if (HALF && split) split[i] = min(total_lo, cap); }      // with in-kernel statistics the row is cut here (see k_count_stats)
+    if (lane == 0) { count[i] = stats ? min(total, cap) : total; start[i] = base; if (SPLIT) split[i] = min(total_lo, cap); }      // with in-kernel statistics the row is cut here (see k_count_stats)
     wmax = max(wmax, total); wsum += total;
   }
   if (stats) {      // {largest neighbourhood, -, longest row (uncut), -, sum of the row lengths (64 bit)}: one atomic each per workgroup
@@ -622,7 +622,7 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
     if (c->d_nbr.alloc((size_t)N * c->nbr_cap)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (neighbour list)");
     inline_stats = false;
     if (tile_build_ok) {
-      auto kern = c->pair_tiles ? k_neighbors_tiles<true> : k_neighbors_tiles<false>;
+      auto kern = c->pair_tiles ? (c->pair_split_opt ? k_neighbors_tiles<true, true> : k_neighbors_tiles<true, false>) : k_neighbors_tiles<false, false>;
       HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NBR_TILE_CAP * NBR_TILE_BYTES + 64));      // per device: cheap, every launch
       // tile: sized from the largest neighbourhood the last build saw
       // (a larger one is scanned from global memory).  Up to NBR_TILE_CAP2 atoms two workgroups share a CU's 160 KB.

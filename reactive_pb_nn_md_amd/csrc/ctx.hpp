@@ -270,6 +270,7 @@ struct msevb_ctx {
   DBuf<int> d_cell_of, d_perm, d_cell_keys_tmp, d_perm_tmp, d_cell_start, d_inv_perm, d_tile_max;
   DBuf<unsigned> d_nbr_count, d_nbr_start, d_nbr_split;      // split: entries of a half-list row that lie in the first 7 cells of the half neighbourhood (pair_flat.hip, two workgroups per cell)
   DBuf<int> d_nbr;
+  bool attr_nbr_tiles[3] = {false, false, false};
   DBuf<char> d_sort_tmp; DBuf<int> d_sort_hist; bool cell_sort_own = true;      // cell sort of a list rebuild: own stable counting sort (three kernels) / hipcub radix sort (option cell_sort_own)
   size_t n_nbr = 0;
   unsigned nbr_cap = 0;          // row stride of the Verlet list (0: not sized yet)

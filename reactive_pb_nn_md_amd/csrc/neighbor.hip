@@ -623,7 +623,8 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
     inline_stats = false;
     if (tile_build_ok) {
       auto kern = c->pair_tiles ? (c->pair_split_opt ? k_neighbors_tiles<true, true> : k_neighbors_tiles<true, false>) : k_neighbors_tiles<false, false>;
-      HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NBR_TILE_CAP * NBR_TILE_BYTES + 64));      // per device: cheap, every launch
+      const int which = c->pair_tiles ? (c->pair_split_opt ? 2 : 1) : 0;
+      if (!c->attr_nbr_tiles[which]) { HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NBR_TILE_CAP * NBR_TILE_BYTES + 64)); c->attr_nbr_tiles[which] = true; }      // (once per context: the call costs ~30 us of host time in front of the row kernel)
       // tile: sized from the largest neighbourhood the last build saw
       // (a larger one is scanned from global memory).  Up to NBR_TILE_CAP2 atoms two workgroups share a CU's 160 KB.
       int tile_cap = NBR_TILE_CAP2;

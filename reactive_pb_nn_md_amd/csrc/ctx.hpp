@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/msevb_hip.h"
@@ -144,31 +145,64 @@ struct PhaseTimer {   // HIP events on the library's stream around a phase; harv
 
 enum Phase { PH_VERLET = 0, PH_SORT, PH_PAIR, PH_MOLECULE, PH_SPREAD, PH_FFT, PH_GATHER, PH_EVB_REAL, PH_EVB_RECIP, PH_EVB_BLEND, PH_INTEGRATE, PH_COUNT };
 
+// ---- guard allocator (diagnostic, MSEVB_GUARD=1 / 2) -------------------------------------------------------------------------------
+// Every device buffer gets its own virtual-address reservation whose mapped part ENDS on the buffer's last byte (mode 1: the page
+// behind it is reserved but never mapped) or STARTS on its first byte (mode 2: the page in front of it is unmapped).  A kernel that
+// reads or writes one element past / in front of an array then faults at once, at an address guard_report() can name, instead of
+// landing in whatever the allocator placed there.  MSEVB_GUARD_LOG=1 prints every allocation with the source line that made it.
+struct GuardRec { void* base; size_t reserved, mapped_off, mapped; hipMemGenericAllocationHandle_t h; void* user; size_t bytes; const char* file; int line; };
+inline std::map<void*, GuardRec>& guard_registry() { static std::map<void*, GuardRec> r; return r; }
+inline std::mutex& guard_mutex() { static std::mutex m; return m; }
+inline int guard_mode() { static const int m = getenv("MSEVB_GUARD") ? atoi(getenv("MSEVB_GUARD")) : 0; return m; }
+inline void* guard_alloc(size_t bytes, const char* file, int line) {
+  int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  hipMemAllocationProp prop = {}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+  size_t gran = 0; if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || !gran) return nullptr;
+  const size_t mapped = (bytes + gran - 1) / gran * gran, reserved = mapped + 2 * gran;
+  GuardRec r = {}; r.reserved = reserved; r.mapped = mapped; r.mapped_off = gran; r.bytes = bytes; r.file = file; r.line = line;
+  if (hipMemAddressReserve(&r.base, reserved, gran, nullptr, 0) != hipSuccess) return nullptr;
+  if (hipMemCreate(&r.h, mapped, &prop, 0) != hipSuccess) { (void)hipMemAddressFree(r.base, reserved); return nullptr; }
+  char* m0 = (char*)r.base + gran;
+  hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+  if (hipMemMap(m0, mapped, 0, r.h, 0) != hipSuccess || hipMemSetAccess(m0, mapped, &acc, 1) != hipSuccess) { (void)hipMemRelease(r.h); (void)hipMemAddressFree(r.base, reserved); return nullptr; }
+  r.user = guard_mode() == 2 ? (void*)m0 : (void*)(m0 + mapped - bytes);      // mode 1: last byte = last mapped byte
+  static const bool log = getenv("MSEVB_GUARD_LOG") != nullptr;
+  if (log) fprintf(stderr, "msevb guard: %p..%p (%zu B) mapped %p..%p  %s:%d\n", r.user, (char*)r.user + bytes, bytes, m0, m0 + mapped, file, line);
+  std::lock_guard<std::mutex> g(guard_mutex());
+  guard_registry()[r.user] = r;
+  return r.user;
+}
+inline bool guard_free(void* user) {
+  GuardRec r;
+  { std::lock_guard<std::mutex> g(guard_mutex()); auto it = guard_registry().find(user); if (it == guard_registry().end()) return false; r = it->second; guard_registry().erase(it); }
+  (void)hipDeviceSynchronize();
+  (void)hipMemUnmap((char*)r.base + r.mapped_off, r.mapped); (void)hipMemRelease(r.h); (void)hipMemAddressFree(r.base, r.reserved);
+  return true;
+}
+
 template <class T>
-struct DBuf {  // device buffer
+struct DBuf {  // device buffer, exactly `count` elements: no kernel of this library may touch a byte outside [p, p + n)
   T* p = nullptr;
   size_t n = 0;
-  int alloc(size_t count) {
+  int alloc(size_t count, const char* file = __builtin_FILE(), int line = __builtin_LINE()) {
     if (count <= n && p) return 0;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    n = 0;
-    // + DBUF_TAIL bytes behind every buffer: kernels that issue their loads unconditionally (clamped indices, selects instead of branches -
-    // pair_flat.hip, the weight-free gather) or read a 16-byte record at the last element may touch a few bytes past `count` elements; those
-    // bytes must be mapped.  MSEVB_DBUF_TAIL=0 (diagnostic) allocates exactly.
-    static const size_t tail = getenv("MSEVB_DBUF_TAIL") ? (size_t)atol(getenv("MSEVB_DBUF_TAIL")) : 1024;
-    if (hipMalloc((void**)&p, (count ? count : 1) * sizeof(T) + tail) != hipSuccess) return -1;
+    release();
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    // MSEVB_DBUF_TAIL=<bytes> (diagnostic): extra mapped bytes behind every buffer - what round 3 shipped with (1024) to hide an overrun
+    static const size_t tail = getenv("MSEVB_DBUF_TAIL") ? (size_t)atol(getenv("MSEVB_DBUF_TAIL")) : 0;
+    if (guard_mode()) { p = (T*)guard_alloc(bytes, file, line); if (!p) return -1; }
+    else if (hipMalloc((void**)&p, bytes + tail) != hipSuccess) { p = nullptr; return -1; }
     n = count;
     // MSEVB_POISON=1 (diagnostic): fresh device memory reads as NaN / -1 instead of whatever the allocator hands back (zeros in a young process,
     // another context's data later), so that a read of something nobody wrote shows in the first test that does it, not in the fortieth
     static const bool poison = getenv("MSEVB_POISON") != nullptr;
-    if (poison) { (void)hipMemset(p, 0xFF, (count ? count : 1) * sizeof(T)); (void)hipDeviceSynchronize(); }      // (hipMemset of device memory may return early; the library's streams do not wait for the null stream)
+    if (poison) { (void)hipMemset(p, 0xFF, bytes); (void)hipDeviceSynchronize(); }      // (hipMemset of device memory may return early; the library's streams do not wait for the null stream)
     return 0;
   }
   // for buffers whose size follows the diabat count: grow with half as much again, so that a tree gaining a diabat or two during a run
   // does not free + allocate (a device synchronisation and milliseconds) every time
-  int alloc_room(size_t count) { return (count <= n && p) ? 0 : alloc(count + count / 2); }
-  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  int alloc_room(size_t count, const char* file = __builtin_FILE(), int line = __builtin_LINE()) { return (count <= n && p) ? 0 : alloc(count + count / 2, file, line); }
+  void release() { if (p && !(guard_mode() && guard_free(p))) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
 struct EvbHop { int donor_mol, proton_local, heavy_local, acceptor_mol, acceptor_heavy_local; };

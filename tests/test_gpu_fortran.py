@@ -1,5 +1,10 @@
-"""The Fortran host path on the GPU: a flang-built driver (reactive_pb_nn_md_amd/fortran/fortran_smoke.f90) feeds the same
-arrays through the iso_c_binding interfaces (msevb_hip_c.f90) and must reproduce the reference's golden energies."""
+"""The Fortran host path on the GPU: a flang-built driver (reactive_pb_nn_md_amd/fortran/fortran_smoke.f90, ours - nothing of the reference is
+linked into it) feeds the arrays of the committed fixtures through the iso_c_binding interfaces (msevb_hip_c.f90) and must reproduce the
+numbers the real reference computed for them: a plain force call, an MS-EVB force call, the same call with the host arrays in another atom
+order (msevb_set_host_order: the host side of a proton hop), and a block of md_integrate_atomic.
+
+The tests further down run executables that contain REFERENCE objects (oracle/_ref/, built by `make link_check` in the dev container).  oracle/_ref/
+does not travel to the GPU box (.gpurunignore), so they skip there by construction; they run where a GPU and the reference are both present."""
 import os
 import subprocess
 
@@ -11,8 +16,11 @@ from reactive_pb_nn_md_amd import system
 
 pytestmark = pytest.mark.gpu
 
+SMOKE = os.path.join(ROOT, "reactive_pb_nn_md_amd", "fortran", "fortran_smoke")
 
-def write_spec(path, spec):
+
+def write_spec(path, spec, evb=False, md=None):
+    """md = dict(nsteps, dt, use_evb, vel (N,3), perm (N,) 0-based host_to_library) or None"""
     p = spec.params
     nt, nmt = p.n_atom_type, len(p.moltypes)
     f32 = lambda a: np.asfortranarray(np.asarray(a, dtype=np.int32)).tobytes(order="F")
@@ -38,29 +46,86 @@ def write_spec(path, spec):
             if len(m["dihedrals"]):
                 f.write(f32((m["dihedrals"] + 1).T))
             f.write(f32(m["excl"]) + f32(m["reactive_protons"]) + f32(m["reactive_basic"]))
+        if not evb and md is None:
+            return
+        f.write(f32([1 if evb else 0]))
+        if evb:      # the argument list of msevb_set_evb, in its order (api.py: _set_evb)
+            e, ldi = p.evb, 15
+
+            def table(rows, nty, npar):
+                ti, tp = np.zeros((ldi, nty), dtype=np.int32), np.zeros((ldi, npar))
+                for r, (tys, par) in enumerate(rows):
+                    ti[r, :] = np.array(tys) + 1
+                    tp[r, :len(par)] = par
+                return f32(ti) + f64(tp)
+            cp_t = np.zeros(ldi, dtype=np.int32)
+            cp_t[:len(e["coupling"])] = [c[1] for c in e["coupling"]]
+            f.write(f32([ldi]) + f32(e["acid"]) + f32(e["base"]) + f32(e["conjugate_mol"] + 1) + f32(e["proton_type"] + 1) + f32(e["heavy_type"] + 1)
+                    + f32(e["conjugate_atype"] + 1) + f64(e["reference_energy"]) + f64(e["exch_atomic"]) + f64(e["exch_proton"])
+                    + table(e["donor_acceptor"], 3, 6) + table(e["proton_acceptor"], 2, 5) + table([(c[0], c[2]) for c in e["coupling"]], 3, 10)
+                    + f32(cp_t) + f32([int(spec.hydronium) + 1, int(spec.max_chain)]))
+        f.write(f32([1 if md is not None else 0]))
+        if md is not None:
+            f.write(f32([md["nsteps"]]) + f64([md["dt"]]) + f32([1 if md["use_evb"] else 0]) + f64(np.asarray(md["vel"]).T) + f32(np.asarray(md["perm"]) + 1))
+
+
+def run_smoke(tmp_path, spec, **kw):
+    if not os.path.exists(SMOKE):
+        pytest.skip("fortran_smoke not built (flang missing at build time)")
+    path, out = str(tmp_path / "spec.bin"), str(tmp_path / "state.bin")
+    write_spec(path, spec, **kw)
+    r = subprocess.run([SMOKE, path, out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "fortran_smoke done" in r.stdout, r.stdout[-3000:]
+    rec = {}
+    for line in r.stdout.splitlines():
+        t = line.split()
+        if t and t[0] in ("ENERGIES", "FORCESUM", "EVB", "EVBFORCESUM", "HOSTORDER", "HOSTORDERXYZ"):
+            rec[t[0]] = [float(x) for x in t[1:]]
+        if t and t[0] == "MD":
+            rec.setdefault("MD", []).append([float(t[2]), float(t[3])])
+    return rec, out
 
 
 def test_fortran_driver_reproduces_reference_energies(tmp_path):
-    exe = os.path.join(ROOT, "reactive_pb_nn_md_amd", "fortran", "fortran_smoke")
-    if not os.path.exists(exe):
-        pytest.skip("fortran_smoke not built (flang missing at build time)")
     g = golden("std_n6_s3")
     spec = system.from_golden(g)
-    path = str(tmp_path / "spec.bin")
-    write_spec(path, spec)
-    r = subprocess.run([exe, path], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout
-    en = fs = None
-    for line in r.stdout.splitlines():
-        if line.startswith("ENERGIES"):
-            en = [float(x) for x in line.split()[1:]]
-        if line.startswith("FORCESUM"):
-            fs = [float(x) for x in line.split()[1:]]
-    assert en is not None and fs is not None, r.stdout
+    rec, _ = run_smoke(tmp_path, spec)
+    en, fs = rec["ENERGIES"], rec["FORCESUM"]
     ref = [g["E_total"][0], g["E_elec_total"][0], g["E_vdw_total"][0], g["E_bond"][0], g["E_angle"][0], g["E_dihedral"][0]]
     for a, b in zip(en, ref):
         assert abs(a - b) < 1e-11 * max(abs(b), 1.0), (en, ref)
     assert np.allclose(fs, np.abs(g["F_total"]).sum(0), rtol=1e-12)
+
+
+def test_fortran_driver_evb_call_and_host_atom_order(tmp_path):
+    """ms_evb_calculate_total_force_energy through the Fortran bindings on fixture evb_n6_d4_s2 (adiabatic energy, diabat count and the
+    Hellmann-Feynman force of the real reference), then the same call after msevb_set_host_order with a random permutation of the host arrays:
+    forces come back permuted, positions read back as they were sent, the energy does not move."""
+    g = golden("evb_n6_d4_s2")
+    spec = system.from_golden(g)
+    perm = np.random.default_rng(7).permutation(spec.n_atom)
+    rec, out = run_smoke(tmp_path, spec, evb=True, md=dict(nsteps=0, dt=spec.delta_t, use_evb=True, vel=np.zeros((spec.n_atom, 3)), perm=perm))
+    e, D = rec["EVB"][0], int(rec["EVB"][1])
+    assert D == int(g["n_diabat"][0])
+    assert abs(e - g["E_adiabatic"][0]) < 1e-10 * abs(g["E_adiabatic"][0])
+    F = np.fromfile(out + ".evb").reshape(spec.n_atom, 3)
+    assert np.abs(F - g["F_adiabatic"]).max() < 1e-8
+    assert rec["HOSTORDER"][0] < 1e-9 and rec["HOSTORDER"][1] < 1e-10 * abs(e) and rec["HOSTORDERXYZ"][0] == 0.0
+
+
+@pytest.mark.parametrize("name,evb", [("md_std_n6_s4", False), ("md_evb_n6_d2_s5", True)])
+def test_fortran_driver_md_block_against_reference_trajectory(tmp_path, name, evb):
+    """msevb_md_integrate_atomic from Fortran: the reference's own trajectory fixtures (energies per step, end positions, velocities, forces)."""
+    g = golden(name)
+    spec = system.from_golden(g)
+    n = int(g["md_nsteps"][0])
+    rec, out = run_smoke(tmp_path, spec, evb=evb, md=dict(nsteps=n, dt=spec.delta_t, use_evb=evb, vel=g["md_velocity0"], perm=np.arange(spec.n_atom)))
+    en = np.array(rec["MD"])
+    assert en.shape == (n, 2)
+    assert np.abs(en[:, 0] - g["md_energy"][:, 0]).max() < 1e-9 * np.abs(g["md_energy"][:, 0]).max()
+    assert np.abs(en[:, 1] - g["md_energy"][:, 1]).max() < 1e-8 * np.abs(g["md_energy"][:, 1]).max()
+    st = np.fromfile(out).reshape(3, spec.n_atom, 3)
+    assert np.abs(st[0] - g["md_xyz"]).max() < 1e-10 and np.abs(st[1] - g["md_velocity"]).max() < 1e-9 and np.abs(st[2] - g["md_force"]).max() < 1e-7
 
 
 def _parse_log(path):

@@ -199,6 +199,10 @@ int msevb_reset_phase_times(msevb_ctx* ctx);
      multi-GPU            : shard_principal (set by msevb_comm_init)
      measurement          : phase_timing (0), phase_timing_stride (8) */
 int msevb_set_option(msevb_ctx* ctx, const char* name, double value);
+/* Which kernels serve this context (tests assert that a fixture reaches the production kernels): "pair_kernel" (after a list build: 0 = k_pair on
+   the full fixed-stride list, boxes under 4 cells per axis; 1 = k_pair_half; 2 = k_pair_flat), "list_build_tiles", "pme_tiles" (tiled spread / gather),
+   "pme_weightless", "fft_own", "n_cells", "cells_per_axis_min", "n_diabat" */
+int msevb_get_info(msevb_ctx* ctx, const char* name, double* value);
 
 #ifdef __cplusplus
 }

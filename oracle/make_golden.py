@@ -84,7 +84,7 @@ def compact(d, keep_store=True):
     return out
 
 
-def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, proton_shift=0.0, so3h_eref=None, standard=False, rb=False, cf2=False, freeze=(), md_temp=300.0, nbaro=0, box_scale=None, **simkw):
+def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=False, proton_shift=0.0, so3h_eref=None, standard=False, rb=False, cf2=False, freeze=(), md_temp=300.0, nbaro=0, box_scale=None, bifurcate=(), **simkw):
     if ONLY and name not in ONLY:
         return
     ff = forcefield.ch3so3h_water_forcefield()
@@ -103,7 +103,7 @@ def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=Fa
     if so3h_eref is not None:
         import dataclasses
         ff = dataclasses.replace(ff, reference_energy=dict(ff.reference_energy, so3h=so3h_eref))
-    s = synth.make_system(n_side, n_diabat=n_diabat, seed=seed, proton_shift=proton_shift)
+    s = synth.make_system(n_side, n_diabat=n_diabat, seed=seed, proton_shift=proton_shift, bifurcate=bifurcate)
     if box_scale is not None:      # orthorhombic box: the same atoms, the cell stretched (vacuum at the faces)
         s.box = s.box * np.asarray(box_scale, dtype=float)
     vel = None
@@ -121,6 +121,7 @@ def case(name, n_side, n_diabat, seed, evb, keep_store=True, md_steps=0, sapt=Fa
     out["gen_so3h_eref"] = np.array(np.nan if so3h_eref is None else so3h_eref)
     out["gen_xyz"] = s.xyz
     out["gen_hydronium"] = np.array(s.hydronium)
+    out["gen_bifurcate"] = np.asarray(bifurcate, dtype=np.int64)
     out["gen_box_scale"] = np.asarray([1.0, 1.0, 1.0] if box_scale is None else box_scale, dtype=float)
     if vel is not None:
         out["md_velocity0"] = vel
@@ -170,6 +171,15 @@ def main():
     case("evb_n6_d4_ortho_s20", 6, 4, 20, evb=True, keep_store=False, box_scale=(1.0, 1.07, 1.15), **small)
     # unit vectors of the MS-EVB3 repulsion procedures (rep3_*, bm_*, rep_switch_table: ref_driver.f90 calls them on their own)
     case("evb_n6_d4_rep_s25", 6, 4, 25, evb=True, keep_store=False, **small)
+    # Boxes with >= 4 neighbour cells per axis (12^3 lattice sites, L = 37.2 A, r_v = 8 A): the library's PRODUCTION kernels (half list on LDS tiles,
+    # flat-list pair kernel, tiled list build, tiled charge spreading / force interpolation) run against the reference's own numbers
+    big = dict(rc=7.0, rv=8.0, nslist=16)
+    case("std_n12_k32_s26", 12, 1, 26, evb=False, pme_grid=32, **big)
+    case("evb_n12_d8_k64_s27", 12, 8, 27, evb=True, keep_store=False, pme_grid=64, **big)
+    case("md_evb_n12_d4_s29", 12, 4, 29, evb=True, md_steps=4, keep_store=False, pme_grid=32, **big)
+    # 16 diabats with the reference's compile-time evb_max_chain = 3 (src/glob_v.f90:65): the acid proton and one third-shell hydrogen
+    # have TWO acceptors each (synth.py: bifurcate) - 1 + 2 + 4 + 9 states
+    case("evb_n12_d16_bif_s31", 12, 16, 31, evb=True, keep_store=False, pme_grid=32, bifurcate=(0, 5), **big)
     # principal-diabat switch (src/ms_evb.f90:218-227).  Acid proton started next to its acceptor and the acid's reference energy
     # raised by 850 kJ/mol (the unrelaxed lattice otherwise keeps the acid diabat ~800 kJ/mol below): the reference's FIRST EVB force
     # call (during its initialisation) hands the proton to the water, so everything this fixture holds - 'xyz', topology, Hamiltonian,

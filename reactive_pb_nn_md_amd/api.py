@@ -372,6 +372,11 @@ class MsEvbHip:
     def set_option(self, name, value):
         self._chk(self.L.msevb_set_option(self.ctx, name.encode(), C.c_double(value)))
 
+    def info(self, name):
+        v = C.c_double()
+        self._chk(self.L.msevb_get_info(self.ctx, name.encode(), C.byref(v)))
+        return v.value
+
     def phase_times(self):
         n = C.c_int()
         names = (C.c_char_p * 16)()

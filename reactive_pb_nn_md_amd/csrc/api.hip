@@ -826,5 +826,19 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   c->err = "unknown option " + s;
   return MSEVB_ERR_ARG;
 }
+int msevb_get_info(msevb_ctx* c, const char* name, double* value) {
+  const std::string s(name);
+  if (!value) FAIL(MSEVB_ERR_ARG, "msevb_get_info: value is NULL");
+  if (s == "pair_kernel") { *value = !c->list_valid ? -1.0 : c->pair_tiles ? (pair_flat_usable(c) ? 2.0 : 1.0) : 0.0; return MSEVB_OK; }
+  if (s == "list_build_tiles") { *value = c->list_valid && c->nbr_tiles_used ? 1.0 : 0.0; return MSEVB_OK; }
+  if (s == "pme_tiles") { *value = pme_tiles_ok(c) ? 1.0 : 0.0; return MSEVB_OK; }
+  if (s == "pme_weightless") { *value = pme_weightless_now(c) ? 1.0 : 0.0; return MSEVB_OK; }
+  if (s == "n_cells") { *value = (double)c->ncell[0] * c->ncell[1] * c->ncell[2]; return MSEVB_OK; }
+  if (s == "cells_per_axis_min") { *value = (double)std::min(c->ncell[0], std::min(c->ncell[1], c->ncell[2])); return MSEVB_OK; }
+  if (s == "fft_own") { *value = fft_lds_usable(c) ? 1.0 : 0.0; return MSEVB_OK; }
+  if (s == "n_diabat") { *value = (double)c->D; return MSEVB_OK; }
+  c->err = "unknown info " + s;
+  return MSEVB_ERR_ARG;
+}
 
 }  // extern "C"

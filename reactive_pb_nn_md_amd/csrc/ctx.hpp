@@ -176,7 +176,9 @@ inline bool guard_free(void* user) {
   GuardRec r;
   { std::lock_guard<std::mutex> g(guard_mutex()); auto it = guard_registry().find(user); if (it == guard_registry().end()) return false; r = it->second; guard_registry().erase(it); }
   (void)hipDeviceSynchronize();
-  (void)hipMemUnmap((char*)r.base + r.mapped_off, r.mapped); (void)hipMemRelease(r.h); (void)hipMemAddressFree(r.base, r.reserved);
+  // the physical memory goes back, the ADDRESS RANGE is never handed out again: a kernel that still uses the buffer faults (use after free), and no
+  // later mapping can appear at an address a translation cache may still hold (re-mapping freed ranges gave wrong copies in the stage entry points)
+  (void)hipMemUnmap((char*)r.base + r.mapped_off, r.mapped); (void)hipMemRelease(r.h);
   return true;
 }
 
@@ -223,6 +225,7 @@ struct msevb_ctx {
   bool overlap = true;
   bool cells_valid = false;      // cell_start / perm are current (a list build is in progress or done)
   bool nbr_tiles = true;         // LDS-staged list build (workgroup per cell) when there are enough cells
+  bool nbr_tiles_used = false;   // ... and whether the last build was one (msevb_get_info)
   bool graphs = true;            // replay the PME front end as a hipGraph on the side stream
   void* pme_graph_exec = nullptr; char pme_graph_key[128] = {0}; int pme_graph_nbk = 0;
   // multi-rank EVB: the principal diabat's pair loop, per-molecule terms and reciprocal-force accumulation are split over the ranks by
@@ -402,7 +405,7 @@ struct msevb_ctx {
   bool evb_recip_linear = true;      // diabats' reciprocal space through the linear response of theta to the charge differences (evb.hip): no transform per diabat
   bool evb_speculate = true;         // MS-EVB step without a host wait for the neighbourhood record while the diabat tree stays the same (evb.hip, SpecPlan); 0 = enumerate every step
   long topo_epoch = 0;               // bumped by everything that can change what a recorded diabat tree means (topology upload, box, options)
-  bool evb_device_solve = false;     // single rank: H' assembly + Jacobi + blend coefficients in a kernel (no host round trip before the blend)
+  bool evb_device_solve = true;      // single rank, no element stores: H' assembly + round-robin Jacobi + blend coefficients in a kernel on the main stream, the blend phase behind it (no host turn on the critical path); 0 = host Jacobi
   bool nvt = false; double friction = 0.1 /* 1/ps, the reference's default */, temperature = 300.0; unsigned long long langevin_seed = 0, langevin_tick = 0;
 };
 
@@ -462,6 +465,7 @@ extern "C" int download_atoms3(msevb_ctx* c, double* dst_host, const double* src
 int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part_stride, int* nblocks);
 int pme_prepare_atoms(msevb_ctx* c, bool with_indices);
 bool pme_weightless_now(const msevb_ctx* c);
+bool pme_tiles_ok(const msevb_ctx* c);
 int pme_side_weights(msevb_ctx* c, hipStream_t st, hipEvent_t after);
 bool fft_lds_usable(const msevb_ctx* c);                              // fft_lds.hip
 int fft_lds_setup(msevb_ctx* c);

@@ -817,15 +817,18 @@ __global__ __launch_bounds__(256) void k_evb_recip_pairs(GridRanges gr, const St
       const int idx = lane + 64 * ch;
       const bool live = idx < 121;
       const int o1 = live ? idx % 11 : 0, o2 = live ? idx / 11 : 0;
-      int n1 = d1 - (o1 - 5); n1 += n1 < 0 ? K : 0; n1 -= n1 >= K ? K : 0;      // |d| < K, |o| <= 5 < K: one wrap either way (no integer division)
-      int n2 = d2 - (o2 - 5); n2 += n2 < 0 ? K : 0; n2 -= n2 >= K ? K : 0;
+      // |d| <= K - 1 (two stencils on either side of the periodic boundary), |o| <= 5: d - o lies in [-(K + 4), K + 4], which takes TWO wraps to
+      // bring into [0, K) (K >= 6).  Round 3 wrapped once: a pair of special atoms straddling the box boundary then read green[-4..-1 + ...] - a wrong
+      // table element for most (n2, n3), and for n2 = n3 = 0 the bytes in front of the buffer (the page fault of HISTORY.md D, found with MSEVB_GUARD=1)
+      int n1 = d1 - (o1 - 5); n1 += n1 < 0 ? K : 0; n1 += n1 < 0 ? K : 0; n1 -= n1 >= K ? K : 0; n1 -= n1 >= K ? K : 0;
+      int n2 = d2 - (o2 - 5); n2 += n2 < 0 ? K : 0; n2 += n2 < 0 ? K : 0; n2 -= n2 >= K ? K : 0; n2 -= n2 >= K ? K : 0;
       const double* row = green + n1 + (size_t)K * n2;
       const double w1 = sW[wv][0][0][o1], w2 = sW[wv][1][0][o2];
       const double cc = live ? qS * w1 * w2 : 0.0, ca = live ? qS * sW[wv][0][1][o1] * w2 : 0.0, cb = live ? qS * w1 * sW[wv][1][1][o2] : 0.0;
       double Gv[11];
 #pragma unroll
       for (int o3 = 0; o3 < 11; ++o3) {
-        int n3 = d3 - (o3 - 5); n3 += n3 < 0 ? K : 0; n3 -= n3 >= K ? K : 0;
+        int n3 = d3 - (o3 - 5); n3 += n3 < 0 ? K : 0; n3 += n3 < 0 ? K : 0; n3 -= n3 >= K ? K : 0; n3 -= n3 >= K ? K : 0;
         Gv[o3] = row[(size_t)K * K * n3];
       }
 #pragma unroll
@@ -849,14 +852,6 @@ __global__ __launch_bounds__(256) void k_evb_recip_pairs(GridRanges gr, const St
     atomicAdd(&F[3 * T.idx + 2], -Kd * (k02 * f1 + k12 * f2 + k22 * f3) * s);
     atomicAdd(&E_quad[g], qT * en);
   }
-}
-
-// E_grid[g] = conv (linear + 1/2 quadratic): the diabat's reciprocal energy RELATIVE to the principal one; accumulators re-zeroed
-__global__ void k_evb_grid_energy(int ng, double* __restrict__ E_lin, double* __restrict__ E_quad, double conv, double* __restrict__ E_grid) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= ng) return;
-  E_grid[g] = conv * (E_lin[g] + 0.5 * E_quad[g]);
-  E_lin[g] = 0.0; E_quad[g] = 0.0;
 }
 
 // blended charge grid: grid += sum over the stencils of c_d^2 q S (the grid holds Q_1 on rank 0, zero on the others); coefficients as kernel
@@ -905,9 +900,14 @@ __global__ void k_evb_blend(size_t n3, BlendTerms bt, const double* __restrict__
 }
 
 // ---- Hamiltonian assembly + Jacobi + blend coefficients ON THE DEVICE (single rank, fast path): the blend phase is enqueued behind this
-// kernel without a host round trip (fetch -> host Jacobi -> launch cost ~60 us of the step's critical path).  One wavefront; every
-// scalar decision and every element update is the arithmetic of the host versions (H' assembly in evb_force_energy_once, jacobi_h =
-// jacobi of src/general_routines.f90:2013-2088), lanes only spread independent k-loops, so the result is bit-identical to the host path.
+// kernel on the main stream without a host round trip (fetch -> host Jacobi -> launch cost 27-35 us of the step's critical path, and kept
+// the host from enqueueing ahead).  diagonalize_evb_hamiltonian + jacobi (src/ms_evb.f90:242-330, src/general_routines.f90:2013-2088): the
+// reference's cyclic Jacobi visits the n(n-1)/2 element pairs one after the other (~200 dependent rotations at D = 8: 108 us on one
+// wavefront, round 2).  Here the SAME rotations (same angle formula, same "negligible element" rule, same stop criterion: every
+// off-diagonal element exactly zero) are applied in the round-robin order of a tournament: n/2 disjoint pairs per round, n - 1 rounds per
+// sweep, all pairs of a round at once.  Jacobi converges for either ordering to the same eigenvectors; the results differ from the host's
+// row-cyclic sweep in the last bits only (test_device_side_hamiltonian_solve: 1e-13), and the sign of the vector is immaterial (the blend
+// uses products c_i c_j).  H' assembly as in evb_force_energy_body (host).
 struct SolveDesc {
   int D, nu, ncp, ngrid, nterm, unit00;
   double e_hyd, Hp_norep, once;
@@ -916,19 +916,35 @@ struct SolveDesc {
   int term_i[2 * MAX_DIABATS], term_j[2 * MAX_DIABATS];      // blend terms in blend_terms() order (i == j: diagonal)
   // followed in memory by: int unit_idx[unit_off[D]]; double unit_sign[unit_off[D]] (8-byte aligned)
 };
-// out_host: {status, lowest eigenvalue of H', eigvec[D], cpl_A[D], H'[D*D] row-major (upper triangle filled)}
-__global__ __launch_bounds__(64) void k_evb_solve(const SolveDesc* __restrict__ sd, const int* __restrict__ unit_idx, const double* __restrict__ unit_sign,
-                                                  const double* __restrict__ E, const double* __restrict__ e_recip1, double* __restrict__ dcoef, double* __restrict__ out_host) {
+// out_host: {status, lowest eigenvalue of H', eigvec[D], cpl_A[D], H'[D*D] row-major (upper triangle filled)}, then done_flag = done_seq (pinned memory, the host spins on it)
+// wait_mark: device-side mark of the kernel that completes the energies (k_evb_publish on the grid stream) - this kernel sits on the MAIN stream
+// behind the pair loop and must not start reading E before that one is done; no cross-stream event hop (~10 us each)
+__global__ __launch_bounds__(256) void k_evb_solve(const SolveDesc* __restrict__ sd, const int* __restrict__ unit_idx, const double* __restrict__ unit_sign,
+                                                   const double* __restrict__ E, const double* __restrict__ e_recip1, double* __restrict__ dcoef, double* __restrict__ out_host,
+                                                   const long long* wait_mark, long long wait_seq, volatile long long* done_flag, long long done_seq, double* fault) {
 #pragma clang fp contract(off)
-  extern __shared__ double sh[];      // A[n*n], V[n*n], d[n], b[n], z[n], cplA[n]
-  const int n = sd->D, lane = threadIdx.x;
-  double* A = sh; double* V = A + n * n; double* dd = V + n * n; double* bb = dd + n; double* zz = bb + n; double* cA = zz + n;
+  extern __shared__ double sh[];      // A[n*n], V[n*n], cplA[n], per pair of a round: c, s, d_p - t a_pq, d_q + t a_pq (n/2 each) and p, q (ints)
+  const int n = sd->D, tid = threadIdx.x, nth = blockDim.x;
+  const int m = (n + 1) & ~1, hp = m / 2;      // tournament over m players (an odd n plays with a dummy that sits out)
+  double* A = sh; double* V = A + n * n; double* cA = V + n * n; double* rc = cA + n; double* rs = rc + hp; double* rdp = rs + hp; double* rdq = rdp + hp;
+  int* rp = (int*)(rdq + hp); int* rq = rp + hp;
+  __shared__ int s_nonzero;
+  if (wait_mark) {
+    if (tid == 0) {
+      const long long t0 = wall_clock64();      // 100 MHz
+      while (__hip_atomic_load(wait_mark, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != wait_seq) {
+        if (wall_clock64() - t0 > 200000000LL) { if (fault) *fault = 2.0; break; }      // 2 s, as k_evb_publish
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+  }
   const int nu = sd->nu, ncp = sd->ncp, ngrid = sd->ngrid;
-  for (int k = lane; k < n * n; k += 64) { A[k] = 0.0; V[k] = (k / n == k % n) ? 1.0 : 0.0; }
-  for (int k = lane; k < n; k += 64) { zz[k] = 0.0; cA[k] = 0.0; }
+  for (int k = tid; k < n * n; k += nth) { A[k] = 0.0; V[k] = (k / n == k % n) ? 1.0 : 0.0; }
+  for (int k = tid; k < n; k += nth) cA[k] = 0.0;
   __syncthreads();
   const double Er1 = *e_recip1;
-  for (int d = lane; d < n; d += 64) {
+  for (int d = tid; d < n; d += nth) {
     if (d == 0) { const int iu = sd->unit00; A[0] = sd->Hp_norep + sd->once * (E[iu] + E[nu + iu]); }
     else {
       double e = sd->e_hyd + sd->eref_delta[d];
@@ -942,55 +958,74 @@ __global__ __launch_bounds__(64) void k_evb_solve(const SolveDesc* __restrict__ 
     }
   }
   __syncthreads();
-  for (int k = lane; k < n * n; k += 64) out_host[2 + 2 * n + k] = (k / n <= k % n) ? A[k] : 0.0;      // H' as the host assembles it (upper triangle)
-  for (int k = lane; k < n; k += 64) { bb[k] = A[k * n + k]; dd[k] = bb[k]; }
-  __syncthreads();
+  for (int k = tid; k < n * n; k += nth) out_host[2 + 2 * n + k] = (k / n <= k % n) ? A[k] : 0.0;      // H' as the host assembles it (upper triangle)
   int status = -1;
   for (int it = 1; it <= 50; ++it) {
-    double sm = 0.0;      // every lane runs the same serial sum: the threshold must not depend on a reduction order
-    for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) sm += fabs(A[i * n + j]);
-    if (sm == 0.0) { status = 0; break; }
-    const double tresh = it < 4 ? 0.2 * sm / (double)(n * n) : 0.0;
-    for (int ip = 0; ip < n - 1; ++ip) for (int iq = ip + 1; iq < n; ++iq) {
-      const double apq = A[ip * n + iq];
-      const double g = 100.0 * fabs(apq);
-      if (it > 4 && fabs(dd[ip]) + g == fabs(dd[ip]) && fabs(dd[iq]) + g == fabs(dd[iq])) { __syncthreads(); if (lane == 0) A[ip * n + iq] = 0.0; __syncthreads(); }
-      else if (fabs(apq) > tresh) {
-        double h = dd[iq] - dd[ip], t;
-        if (fabs(h) + g == fabs(h)) t = apq / h;
-        else { const double theta = 0.5 * h / apq; t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta)); if (theta < 0.0) t = -t; }
-        const double cs = 1.0 / sqrt(1 + t * t), s = t * cs, tau = s / (1.0 + cs);
-        h = t * apq;
-        __syncthreads();
-        if (lane == 0) { zz[ip] -= h; zz[iq] += h; dd[ip] -= h; dd[iq] += h; A[ip * n + iq] = 0.0; }
-        // the four k-loops of the rotation touch disjoint elements: one lane per k
-        for (int k = lane; k < n; k += 64) {
-          double *x = nullptr, *y = nullptr;
-          if (k < ip) { x = &A[k * n + ip]; y = &A[k * n + iq]; }
-          else if (k > ip && k < iq) { x = &A[ip * n + k]; y = &A[k * n + iq]; }
-          else if (k > iq) { x = &A[ip * n + k]; y = &A[iq * n + k]; }
-          if (x) { const double gg = *x, hh = *y; *x = gg - s * (hh + gg * tau); *y = hh + s * (gg - hh * tau); }
-          double* vx = &V[k * n + ip]; double* vy = &V[k * n + iq];
-          const double gg = *vx, hh = *vy; *vx = gg - s * (hh + gg * tau); *vy = hh + s * (gg - hh * tau);
-        }
-        __syncthreads();
+    if (tid == 0) s_nonzero = 0;
+    __syncthreads();
+    { int nz = 0; for (int k = tid; k < n * n; k += nth) if (k / n < k % n && A[k] != 0.0) nz = 1; if (nz) s_nonzero = 1; }
+    __syncthreads();
+    if (!s_nonzero) { status = 0; break; }
+    __syncthreads();
+    for (int r = 0; r < m - 1; ++r) {
+      for (int k = tid; k < hp; k += nth) {      // the pairs of round r, each with its rotation (src/general_routines.f90:2043-2062)
+        int p = k == 0 ? m - 1 : (r + k) % (m - 1), q = k == 0 ? r : (r - k + (m - 1)) % (m - 1);
+        if (p > q) { const int t = p; p = q; q = t; }
+        double c = 1.0, s = 0.0, ndp = 0.0, ndq = 0.0;
+        if (q < n) {
+          const double apq = A[p * n + q], dp = A[p * n + p], dq = A[q * n + q];
+          const double g = 100.0 * fabs(apq);
+          if (it > 4 && fabs(dp) + g == fabs(dp) && fabs(dq) + g == fabs(dq)) { A[p * n + q] = 0.0; A[q * n + p] = 0.0; }
+          else if (apq != 0.0) {
+            const double hd = dq - dp;
+            double t;
+            if (fabs(hd) + g == fabs(hd)) t = apq / hd;
+            else { const double theta = 0.5 * hd / apq; t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta)); if (theta < 0.0) t = -t; }
+            c = 1.0 / sqrt(1 + t * t); s = t * c;
+            const double h = t * apq;
+            ndp = dp - h; ndq = dq + h;
+          }
+        } else q = -1;
+        rp[k] = p; rq[k] = q; rc[k] = c; rs[k] = s; rdp[k] = ndp; rdq[k] = ndq;
       }
+      __syncthreads();
+      for (int w = tid; w < n * hp; w += nth) {      // columns p, q of A and of V (A <- A J, V <- V J)
+        const int i = w / hp, k = w % hp, p = rp[k], q = rq[k];
+        const double s = rs[k];
+        if (q < 0 || s == 0.0) continue;
+        const double c = rc[k];
+        const double ap = A[i * n + p], aq = A[i * n + q]; A[i * n + p] = c * ap - s * aq; A[i * n + q] = s * ap + c * aq;
+        const double vp = V[i * n + p], vq = V[i * n + q]; V[i * n + p] = c * vp - s * vq; V[i * n + q] = s * vp + c * vq;
+      }
+      __syncthreads();
+      for (int w = tid; w < n * hp; w += nth) {      // rows p, q (A <- J^T A)
+        const int j = w / hp, k = w % hp, p = rp[k], q = rq[k];
+        const double s = rs[k];
+        if (q < 0 || s == 0.0) continue;
+        const double c = rc[k];
+        const double ap = A[p * n + j], aq = A[q * n + j]; A[p * n + j] = c * ap - s * aq; A[q * n + j] = s * ap + c * aq;
+      }
+      __syncthreads();
+      for (int k = tid; k < hp; k += nth) {      // the annihilated element is zero, the diagonal moves by t a_pq (the reference's update, :2055-2059: no cancellation)
+        const int p = rp[k], q = rq[k];
+        if (q < 0 || rs[k] == 0.0) continue;
+        A[p * n + q] = 0.0; A[q * n + p] = 0.0; A[p * n + p] = rdp[k]; A[q * n + q] = rdq[k];
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    for (int i = lane; i < n; i += 64) { bb[i] += zz[i]; dd[i] = bb[i]; zz[i] = 0.0; }
-    __syncthreads();
   }
   // ground state, blend coefficients
-  int gidx = 0; double eg = dd[0];
-  for (int i = 1; i < n; ++i) if (dd[i] < eg) { eg = dd[i]; gidx = i; }
-  if (lane == 0) { out_host[0] = (double)status; out_host[1] = eg; dcoef[0] = V[gidx] * V[gidx]; }
-  for (int k = lane; k < n; k += 64) { out_host[2 + k] = V[k * n + gidx]; out_host[2 + n + k] = cA[k]; }
-  for (int d = 1 + lane; d < n; d += 64) if (sd->grid_of[d] >= 0) { const double ev = V[d * n + gidx]; dcoef[1 + sd->grid_of[d]] = ev * ev; }
-  for (int t = lane; t < sd->nterm; t += 64) {
+  int gidx = 0; double eg = A[0];
+  for (int i = 1; i < n; ++i) if (A[i * n + i] < eg) { eg = A[i * n + i]; gidx = i; }
+  if (tid == 0) { out_host[0] = (double)status; out_host[1] = eg; dcoef[0] = V[gidx] * V[gidx]; }
+  for (int k = tid; k < n; k += nth) { out_host[2 + k] = V[k * n + gidx]; out_host[2 + n + k] = cA[k]; }
+  for (int d = 1 + tid; d < n; d += nth) if (sd->grid_of[d] >= 0) { const double ev = V[d * n + gidx]; dcoef[1 + sd->grid_of[d]] = ev * ev; }
+  for (int t = tid; t < sd->nterm; t += nth) {
     const int i = sd->term_i[t], j = sd->term_j[t];
     const double ei = V[i * n + gidx], ej = V[j * n + gidx];
     dcoef[1 + ngrid + t] = i == j ? ei * ej : 2.0 * ei * ej * -cA[j];
   }
+  if (done_flag) { __threadfence_system(); __syncthreads(); if (tid == 0) *done_flag = done_seq; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -1199,7 +1234,7 @@ __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ 
 __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, const double* b, int nb, double* __restrict__ hb,
                               volatile long long* flag = nullptr, long long seq = 0, int ng = 0, double* E_lin = nullptr, double* E_quad = nullptr,
                               double conv = 0.0, double* E_grid = nullptr, const double* __restrict__ slot_part = nullptr, int n_part = 0, double* slot_out = nullptr,
-                              const long long* chain_done = nullptr, long long chain_seq = 0, int n_chains = 0, double* fault = nullptr) {      // (a and E_grid alias: no __restrict__ on them)
+                              const long long* chain_done = nullptr, long long chain_seq = 0, int n_chains = 0, double* fault = nullptr, long long* done_mark = nullptr) {      // (a and E_grid alias: no __restrict__ on them)
   // n_chains > 0: the kernels on OTHER streams whose energies this kernel publishes end with k_evb_mark(chain_done + k, chain_seq); wait for
   // those marks here instead of through two cross-stream event hops in front of this kernel (~10 us each on the way to the host's turn).
   // The marks are enqueued before this kernel in host order, so streams that share a hardware queue cannot deadlock; after 2 s of wall
@@ -1234,6 +1269,7 @@ __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, 
   for (int k = threadIdx.x; k < na; k += blockDim.x) ha[k] = a[k];
   for (int k = threadIdx.x; k < nb; k += blockDim.x) hb[k] = b[k];
   if (flag) { __threadfence_system(); __syncthreads(); if (threadIdx.x == 0) *flag = seq; }
+  if (done_mark) { __syncthreads(); if (threadIdx.x == 0) __hip_atomic_store(done_mark, chain_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }      // everything the device-side solve reads is in place
 }
 
 // The blend phase is enqueued BEFORE the host has the ground-state vector: this kernel, first of the phase on the main stream, waits until
@@ -1310,7 +1346,7 @@ struct EvbWork {   // persistent device scratch of one context
   hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
   RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
   long long* h_flag = nullptr; long long seq_A = 0, seq_R = 0, seq_B = 0;      // pinned: sequence number of the last published fetch A
-  DBuf<double> d_coef; double* h_solve = nullptr; size_t h_solve_cap = 0; hipEvent_t ev_solve = nullptr;      // device-side Hamiltonian solve (k_evb_solve)
+  DBuf<double> d_coef; double* h_solve = nullptr; size_t h_solve_cap = 0; hipEvent_t ev_solve = nullptr; long long seq_S = 0; bool side_by_mark = false;      // device-side Hamiltonian solve (k_evb_solve)
   char* h_desc = nullptr; DBuf<char> d_desc; size_t desc_cap = 0;   // units | couplings | recip atoms, one pinned block -> one upload
   double* h_E = nullptr; size_t hE_cap = 0;                         // pinned
   int grids_cap = 0;
@@ -1553,7 +1589,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   GridCoefs gc; gc.n = ngrid; gc.c0 = 0.0;
   if (ev) { gc.c0 = c->rank == 0 ? ev[0] * ev[0] : 0.0; for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gc.c[grid_of[d]] = ev[d] * ev[d]; }
   const bool one_wait = c->overlap && w->side_valid;      // every side chain of this force call behind ONE event
-  if (one_wait && !w->side_by_A) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0));      // (side_by_A: whoever enqueues this phase has seen fetch A, or has put k_evb_wait_coef in front of it)
+  if (one_wait && !w->side_by_A && !w->side_by_mark) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0));      // (side_by_A: whoever enqueues this phase has seen fetch A, or has put k_evb_wait_coef in front of it)
   else if (c->overlap && ngrid && !one_wait) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // convolved diabat grids / grid energies (aux)
   stamp(c, 8, c->stream);
   if (w->d_pack.alloc(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended potential)");
@@ -1565,7 +1601,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
     } else {
       if (w->d_grids.alloc_room(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended charge grid)");
       if (fft_lds_usable(c)) {      // real grid in, real potential out, in place in d_pack (d_grids is the transform's complex work space)
-        if (w->pack_prefilled) { if (c->overlap && (!one_wait || w->side_by_A)) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_prefill, 0)); }      // (went out before the host's turn)
+        if (w->pack_prefilled) { if (c->overlap && (!one_wait || w->side_by_A) && !w->side_by_mark) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_prefill, 0)); }      // (went out before the host's turn)
         else if (c->rank == 0) HIPCHK(hipMemcpyAsync(w->d_pack.p, c->d_Q.p, K3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         else HIPCHK(hipMemsetAsync(w->d_pack.p, 0, K3 * sizeof(double), c->stream));
         w->pack_prefilled = false;
@@ -1656,7 +1692,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   hipStream_t s_reg = c->overlap && c->evb_region_main ? c->stream : w->stream2;
   if (!w->h_flag) { HIPCHK(hipHostMalloc((void**)&w->h_flag, 64, hipHostMallocDefault)); memset(w->h_flag, 0, 64); }
   // SPECULATIVE STEP: the tree of the last enumeration is assumed to hold; k_evb_region checks that on the device while the host goes straight on
-  const bool spec = c->evb_speculate && c->overlap && w->plan_valid && w->plan_epoch == c->topo_epoch && w->plan.hyd == c->hydronium && !c->evb_device_solve && w->tabs_uploaded;
+  const bool spec = c->evb_speculate && c->overlap && w->plan_valid && w->plan_epoch == c->topo_epoch && w->plan.hyd == c->hydronium && w->tabs_uploaded;
   if (!w->d_check.p) {
     if (w->d_plan.alloc(1) || w->d_sphere.alloc(4) || w->d_check.alloc(4) || w->d_refresh_scratch.alloc(2)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB plan)");
     HIPCHK(hipMemsetAsync(w->d_check.p, 0, 4 * sizeof(int), w->stream2)); HIPCHK(hipMemsetAsync(w->d_refresh_scratch.p, 0, 16, w->stream2));      // (k_evb_refresh leaves the counters zeroed)
@@ -1683,7 +1719,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   c->defer_molecules_now = defer_mol;
   c->ev_pos_ready = w->ev_in;      // new positions: what the PME front end waits for (not for the neighbourhood kernels behind them)
   c->defer_fold_now = fast && c->evb_defer_fold;      // the blend kernel folds the pair loop's sorted-order accumulator in (k_evb_blend)
-  const bool single_join = fast && c->overlap && c->evb_single_join && !c->evb_device_solve;      // the main stream does not wait for the side streams one by one behind the pair loop
+  const bool single_join = fast && c->overlap && c->evb_single_join;      // the main stream does not wait for the side streams one by one behind the pair loop
   c->skip_side_joins_now = single_join;
   c->pme_split_now = single_join && c->evb_pme_split && c->evb_recip_linear && c->d_green.p && fft_lds_usable(c);      // spread now; the solve goes out behind the stencil-pair kernels (step 6b)
   c->refresh_side_now = c->overlap && c->evb_region_main;
@@ -2023,9 +2059,9 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   HIPCHK(hipGetLastError());
   phase_end(c, PH_EVB_REAL, sr);
   stamp(c, 4, sr);
-  const bool pub_spin = c->overlap && c->evb_publish_spin && !dev_solve;      // fetch A's publish kernel waits for the chains' marks, not for their events
+  const bool pub_spin = c->overlap && c->evb_publish_spin;      // fetch A's publish kernel waits for the chains' marks, not for their events
   if (pub_spin) {
-    if (!w->d_chain_done.p) { if (w->d_chain_done.alloc(2)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (chain marks)"); HIPCHK(hipMemset(w->d_chain_done.p, 0, 16)); }      // (synchronous, once per context: the two marks come from different streams)
+    if (!w->d_chain_done.p) { if (w->d_chain_done.alloc(4)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (chain marks)"); HIPCHK(hipMemset(w->d_chain_done.p, 0, 32)); }      // (synchronous, once per context: the two marks come from different streams)
     hipLaunchKernelGGL(k_evb_mark, dim3(1), dim3(1), 0, sr, w->d_chain_done.p, w->seq_A + 1);
   }
   if (c->overlap) HIPCHK(hipEventRecord(w->ev_join2, w->stream2));
@@ -2077,26 +2113,9 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   // loop) is added to the eigenvalue and to the reported Hamiltonian afterwards, off the critical path.  Both downloads are kernels that
   // write into pinned host memory (no copy commands).
   auto fetch_A = [&]() -> int {      // call after everything that produces a unit / coupling / grid energy has been enqueued
-    const int n_recip_part = dev_solve ? 0 : c->slot_count[S_RECIP];      // principal reciprocal energy: its partial sums are complete on `sg`;
-    if (dev_solve) CHK(flush_one(c, S_RECIP, sg));                          // reduced by the publish kernel below (one launch and its gap fewer in front of the host's turn)
-    else c->slot_count[S_RECIP] = 0;
+    const int n_recip_part = c->slot_count[S_RECIP];      // principal reciprocal energy: its partial sums are complete on `sg`;
+    c->slot_count[S_RECIP] = 0;                           // reduced by the publish kernel below (one launch and its gap fewer in front of the host's turn)
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_E, sg));
-    if (dev_solve) {
-      if (c->overlap) { HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0)); if (ncp) HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_cpl, 0)); }
-      const size_t need = 2 + 2 * (size_t)D + (size_t)D * D;
-      if (need > w->h_solve_cap) {
-        if (w->h_solve) HIPCHK(hipHostFree(w->h_solve));
-        w->h_solve_cap = 2 * need + 64;
-        HIPCHK(hipHostMalloc((void**)&w->h_solve, w->h_solve_cap * sizeof(double), hipHostMallocDefault));
-      }
-      if (w->d_coef.alloc(1 + MAX_DIABATS + 2 * MAX_DIABATS)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blend coefficients)");
-      if (!c->attr_evb_solve) { HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * MAX_DIABATS * MAX_DIABATS + 4 * MAX_DIABATS) * 8)); c->attr_evb_solve = true; }
-      hipLaunchKernelGGL(k_evb_solve, dim3(1), dim3(64), (size_t)(2 * D * D + 4 * D) * 8, ss, (const SolveDesc*)(w->d_desc.p + off_s), (const int*)(w->d_desc.p + off_si),
-                         (const double*)(w->d_desc.p + off_ss), w->d_E.p, linear ? w->d_Elq.p + 2 * MAX_DIABATS /* zero: the grid energies are differences already */ : c->d_energies.p + S_RECIP, w->d_coef.p, w->h_solve);
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipEventRecord(w->ev_solve, ss));
-      return MSEVB_OK;
-    }
     // published from the diabat grid stream, normally the last chain to finish: the waits for the other two chains' events are then
     // already satisfied and the publish kernel starts right behind the last energy kernel (a publish on another stream starts an event hop later)
     // ... behind ONE barrier packet: the descriptor stream (idle since its environment chain) waits for the coupling chain and records the
@@ -2112,7 +2131,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, seqA,
                        lin_e ? ngrid : 0, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid,
                        (const double*)(c->d_partials.p + (size_t)S_RECIP * MAX_BLOCKS), n_recip_part, c->d_energies.p + S_RECIP,
-                       pub_spin ? (const long long*)w->d_chain_done.p : (const long long*)nullptr, seqA, pub_spin ? (ncp ? 2 : 1) : 0, c->d_energies.p + S_FAULT);
+                       pub_spin ? (const long long*)w->d_chain_done.p : (const long long*)nullptr, seqA, pub_spin ? (ncp ? 2 : 1) : 0, c->d_energies.p + S_FAULT,
+                       dev_solve && pub_spin ? w->d_chain_done.p + 2 : (long long*)nullptr);      // device solve: k_evb_solve (main stream) starts on this mark
     HIPCHK(hipGetLastError());
     stamp(c, 10, sg);
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, sg));
@@ -2159,7 +2179,6 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     CHK(pme_front_finish(c));      // (split front end: the principal solve goes out here, behind the kernels above that do not need its result)
     hipLaunchKernelGGL(k_evb_recip_linear, dim3((nst + 3) / 4), dim3(256), 0, sg, nst, w->d_stencils.p, K, c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
                        c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p);
-    if (dev_solve) hipLaunchKernelGGL(k_evb_grid_energy, dim3(1), dim3(128), 0, sg, ngrid, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid);      // (otherwise fetch A's publish kernel does it)
     HIPCHK(hipGetLastError());
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_rs, sg));      // the special atoms' forces are in the delta store
   } else if (ngrid) {
@@ -2177,7 +2196,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   phase_end(c, PH_EVB_RECIP, sg);
   stamp(c, 6, sg);
   w->pack_prefilled = false;
-  if (fast && ngrid && linear && fft_lds_usable(c) && !dev_solve) {      // start value of the blended charge grid (Q_1 on rank 0): needs no coefficient, so it goes out in front of the energy fetch (the stream idles there until the other chains have ended)
+  if (fast && ngrid && linear && fft_lds_usable(c)) {      // start value of the blended charge grid (Q_1 on rank 0): needs no coefficient, so it goes out in front of the energy fetch (the stream idles there until the other chains have ended)
     if (!w->ev_prefill) HIPCHK(hipEventCreateWithFlags(&w->ev_prefill, hipEventDisableTiming));
     if (c->rank == 0) HIPCHK(hipMemcpyAsync(w->d_pack.p, c->d_Q.p, K3 * sizeof(double), hipMemcpyDeviceToDevice, sg));
     else HIPCHK(hipMemsetAsync(w->d_pack.p, 0, K3 * sizeof(double), sg));
@@ -2229,10 +2248,27 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   //         and the diagonal real-space deltas (forked in step 5b, joined here)
   HIPCHK(hipGetLastError());
   if (ncp && c->overlap && !single_join) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_cpl, 0));      // off-diagonal force stores complete
-  if (dev_solve) {      // the blend phase goes out NOW, behind the device-side solve: no host round trip between the energies and the blend
-    HIPCHK(hipStreamWaitEvent(c->stream, w->ev_solve, 0));
+  if (dev_solve) {      // the blend phase goes out NOW, on the main stream behind the device-side solve: no host round trip between the energies and the blend
+    const size_t need = 2 + 2 * (size_t)D + (size_t)D * D;
+    if (need > w->h_solve_cap) {
+      if (w->h_solve) HIPCHK(hipHostFree(w->h_solve));
+      w->h_solve_cap = 2 * need + 64;
+      HIPCHK(hipHostMalloc((void**)&w->h_solve, w->h_solve_cap * sizeof(double), hipHostMallocDefault));
+    }
+    if (w->d_coef.alloc(1 + MAX_DIABATS + 2 * MAX_DIABATS)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blend coefficients)");
+    const int hp = (D + 1) / 2;
+    const size_t lds = ((size_t)2 * D * D + D + 4 * hp) * 8 + 2 * hp * 4 + 16;
+    if (!c->attr_evb_solve) { const int Dm = MAX_DIABATS, hm = Dm / 2; HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * Dm * Dm + Dm + 4 * hm) * 8 + 2 * hm * 4 + 16)); c->attr_evb_solve = true; }
+    if (c->overlap && !pub_spin) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_fetchA, 0));      // (without the marks: one event hop)
     phase_begin(c, PH_EVB_BLEND);
+    hipLaunchKernelGGL(k_evb_solve, dim3(1), dim3(D <= 16 ? 64 : 256), lds, c->stream, (const SolveDesc*)(w->d_desc.p + off_s), (const int*)(w->d_desc.p + off_si),
+                       (const double*)(w->d_desc.p + off_ss), w->d_E.p, linear ? w->d_Elq.p + 2 * MAX_DIABATS /* zero: the grid energies are differences already */ : c->d_energies.p + S_RECIP, w->d_coef.p, w->h_solve,
+                       pub_spin ? (const long long*)(w->d_chain_done.p + 2) : (const long long*)nullptr, w->seq_A, (volatile long long*)(w->h_flag + 6), ++w->seq_S, c->d_energies.p + S_FAULT);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(w->ev_solve, c->stream));
+    w->side_by_mark = pub_spin;      // the mark this kernel waited for follows every side chain (and the Q_1 copy) of this call: no event waits in the phase
     CHK(fast_blend_phase(c, w, D, nullptr, grid_of.data(), ngrid, nra, d_ra, w->d_coef.p));
+    w->side_by_mark = false;
     phase_end(c, PH_EVB_BLEND);
   }
   // host-side solve, blend phase enqueued ahead of it: the phase's kernels wait on the main stream behind k_evb_wait_coef for the
@@ -2259,8 +2295,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   }
   HT(8);
   // ---- 9. Hamiltonian without the principal diabat's energy (H' = H - E0 I), from fetch A (or from the device-side solve)
-  if (dev_solve) HIPCHK(hipEventSynchronize(w->ev_solve));
-  else if (c->overlap) {
+  if (c->overlap) {
     if (spin_wait((volatile long long*)w->h_flag, w->seq_A, w->ev_fetchA)) HIPCHK(hipErrorUnknown);
   } else HIPCHK(hipStreamSynchronize(c->stream));
   if (spec && *h_verdict != 1) {      // the tree has changed (or the check never ran): this call's side chains worked on a stale topology - the whole call again, the long way
@@ -2269,19 +2304,15 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     return MSEVB_RETRY;
   }
   HT(7);      // (7: the wait for fetch A alone; 9: Hamiltonian assembly; 10: Jacobi + blend enqueue / coefficient hand-over; 11: principal energy, wait for fetch B, switch)
-  const double E_recip1 = dev_solve ? 0.0 : w->h_E[nE];                  // this rank's own (complete) principal reciprocal energy
+  const double E_recip1 = w->h_E[nE];                  // this rank's own (complete) principal reciprocal energy
   const bool sharded = c->shard_principal && c->n_ranks > 1;
   const bool partial = sharded && !c->nccl_comm;       // virtual ranks (tests): the caller sums the ranks' shares
   memset(c->H, 0, sizeof c->H);
   auto unitE = [&](int iu) { return w->h_E[iu] + w->h_E[nu + iu]; };
   const double once = (partial && c->rank != 0) ? 0.0 : 1.0;      // replicated terms count once over virtual ranks
   const double Hp_norep = once * c->e_ref[c->h_mol_type[c->hydronium]];
-  if (dev_solve) {
-    const double* hs = w->h_solve;
-    if (hs[0] != 0.0) FAIL(MSEVB_ERR_NUMERIC, "too many iterations in jacobi");
-    for (int i = 0; i < D; ++i) { c->eigvec[i] = hs[2 + i]; c->cpl_A[i] = hs[2 + D + i]; for (int j = i; j < D; ++j) c->H[i][j] = hs[2 + 2 * D + (size_t)i * D + j]; }
-  } else c->H[0][0] = Hp_norep + once * unitE(units_of[0][0]);
-  for (int d = 1; d < D && !dev_solve; ++d) {
+  c->H[0][0] = Hp_norep + once * unitE(units_of[0][0]);
+  for (int d = 1; d < D; ++d) {
     if (!owned(c, d)) continue;
     double e = c->e_ref[c->h_mol_type[c->hydronium]] + eref_delta[d];
     for (int iu : units_of[d]) e += units[iu].sign * unitE(iu);
@@ -2325,8 +2356,13 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   }
   // ---- 11. diagonalise H', blend (diagonalize_evb_hamiltonian, :242)
   double eg = 0.0;
-  if (dev_solve) eg = w->h_solve[1];
-  else {
+  if (dev_solve) {      // eigenvalue and ground-state vector of the device's Jacobi (the blend behind it is running already)
+    if (c->overlap) { if (spin_wait((volatile long long*)(w->h_flag + 6), w->seq_S, w->ev_solve)) HIPCHK(hipErrorUnknown); } else HIPCHK(hipStreamSynchronize(c->stream));
+    const double* hs = w->h_solve;
+    if (hs[0] != 0.0) FAIL(MSEVB_ERR_NUMERIC, "too many iterations in jacobi");
+    eg = hs[1];
+    for (int i = 0; i < D; ++i) c->eigvec[i] = hs[2 + i];
+  } else {
     std::vector<double> a((size_t)D * D), ev(D), v((size_t)D * D);
     for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) { a[(size_t)i * D + j] = c->H[i][j]; a[(size_t)j * D + i] = c->H[i][j]; }
     if (jacobi_h(D, a, ev, v) != 0) FAIL(MSEVB_ERR_NUMERIC, "too many iterations in jacobi");

@@ -610,6 +610,7 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
   };
   bool inline_stats = false;      // the fill kernel left {tile max, half tile max, row max, row sum} in d_stats and cut overlong rows itself
   const bool tile_build_ok = ncell >= NBR_TILE_MIN_CELLS && c->nbr_tiles && nc.x >= 4 && nc.y >= 4 && nc.z >= 4;      // workgroup per cell, neighbourhood staged in LDS
+  c->nbr_tiles_used = tile_build_ok;
   // Format of THIS build: half list with tile-local entries (the LDS pair kernel, pair.hip) when the largest half neighbourhood the
   // previous build saw (+ 8 %) fits the pair kernel's LDS tile; a build that meets a larger one is repeated (nb_check_overflow).
   auto decide_format = [&]() {

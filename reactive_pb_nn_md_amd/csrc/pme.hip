@@ -1017,7 +1017,7 @@ int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part
 }
 
 // whether the tiled spread / gather serve this context (workgroup per neighbour cell, tile in LDS)
-static bool pme_tiles_ok(const msevb_ctx* c) {
+bool pme_tiles_ok(const msevb_ctx* c) {
   int3 T;
   T.x = (int)ceil((double)c->K / c->ncell[0]) + 8; T.y = (int)ceil((double)c->K / c->ncell[1]) + 8; T.z = (int)ceil((double)c->K / c->ncell[2]) + 8;
   const size_t tile_bytes = (size_t)spread_plane_stride(T) * T.z * sizeof(double) + (size_t)SPREAD_CHUNK * (18 * 8 + 8 + 12);

@@ -190,6 +190,12 @@ module msevb_hip_c
        character(kind=c_char), intent(in) :: name(*)      ! NUL-terminated, e.g. "overlap"//c_null_char
        real(c_double), value :: value
      end function
+     integer(c_int) function msevb_get_info(ctx, name, value) bind(C, name="msevb_get_info")
+       import :: c_ptr, c_int, c_double, c_char
+       type(c_ptr), value :: ctx
+       character(kind=c_char), intent(in) :: name(*)      ! NUL-terminated, e.g. "overlap"//c_null_char
+       real(c_double), intent(out) :: value
+     end function
      ! ---- the remaining entry points of include/msevb_hip.h ----
      integer(c_int) function msevb_set_stream(ctx, hip_stream) bind(C, name="msevb_set_stream")
        import :: c_ptr, c_int

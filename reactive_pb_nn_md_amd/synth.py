@@ -50,10 +50,13 @@ def _unit(v):
     return v / np.linalg.norm(v)
 
 
-def _plant_tree(acid_xyz, n_water, max_chain):
+def _plant_tree(acid_xyz, n_water, max_chain, bifurcate=()):
     """Waters H-bonded to the acid proton, breadth first: O placed 1.6 A beyond each donating
     H along the donor O-H axis (dist(H,O_acc)=1.6 < evb_reactive_pair_distance=2.5,
-    reference: src/glob_v.f90:55, src/ms_evb.f90:747)."""
+    reference: src/glob_v.f90:55, src/ms_evb.f90:747).
+    bifurcate: numbers (breadth-first, 0 = the acid proton) of the donating hydrogens that get TWO acceptors, 2.2 A away at +-50 degrees
+    off the O-H axis (both inside the 2.5 A search radius, 3.4 A apart): more than 2^k diabats per hop depth without a longer chain -
+    SURVEY.md 8d's way to 16 diabats with the reference's compile-time evb_max_chain = 3."""
     waters = []
     if n_water == 0:
         return waters
@@ -63,18 +66,30 @@ def _plant_tree(acid_xyz, n_water, max_chain):
     p0 = _unit(np.cross(a0, np.array([0.3, 0.5, 0.81])))
     queue = [(o_ah, h_a, p0, 1)]
     c, s = np.cos(np.deg2rad(54.735)), np.sin(np.deg2rad(54.735))
+    link = 0
     while queue and len(waters) < n_water:
         o_d, h_d, p, depth = queue.pop(0)
         a = _unit(h_d - o_d)
         p = _unit(p - np.dot(p, a) * a)
-        o_new = h_d + 1.6 * a
-        h1 = o_new + 1.0 * (c * a + s * p)
-        h2 = o_new + 1.0 * (c * a - s * p)
-        waters.append(np.stack([o_new, h1, h2]))
-        if depth < max_chain:
+        if link in bifurcate:
+            cb, sb = np.cos(np.deg2rad(50.0)), np.sin(np.deg2rad(50.0))
+            places = [(h_d + 2.2 * (cb * a + sb * p), _unit(cb * a + sb * p)), (h_d + 2.2 * (cb * a - sb * p), _unit(cb * a - sb * p))]
+        else:
+            places = [(h_d + 1.6 * a, a)]
+        link += 1
+        for o_new, ax in places:
+            if len(waters) >= n_water:
+                break
             q = _unit(np.cross(a, p))
-            queue.append((o_new, h1, q, depth + 1))
-            queue.append((o_new, h2, q, depth + 1))
+            pp = p if len(places) == 1 else q      # the hydrogens of a bifurcated pair open out of the plane the two acceptors lie in
+            pp = _unit(pp - np.dot(pp, ax) * ax)
+            h1 = o_new + 1.0 * (c * ax + s * pp)
+            h2 = o_new + 1.0 * (c * ax - s * pp)
+            waters.append(np.stack([o_new, h1, h2]))
+            if depth < max_chain:
+                qq = _unit(np.cross(ax, pp))
+                queue.append((o_new, h1, qq, depth + 1))
+                queue.append((o_new, h2, qq, depth + 1))
     return waters
 
 
@@ -90,14 +105,14 @@ def _random_rotations(rng, n):
 
 def make_system(n_side: int, n_diabat: int = 1, seed: int = 0, max_chain: int = 3,
                 acid_position: str = "middle", quantize_gro: bool = True, liquid_like: bool = False,
-                proton_shift: float = 0.0) -> System:
+                proton_shift: float = 0.0, bifurcate=()) -> System:
     """n_side^3 lattice sites (box = n_side*3.1 A); n_diabat = 1 + number of planted waters
     (1, 2, 4 -> partial tree, 8 -> full depth-3 binary tree, 16 needs max_chain=4)."""
     rng = np.random.default_rng(seed)
     L = n_side * SPACING
     centre = np.full(3, 0.5 * L)
     acid = _ACID + centre - _ACID[1]
-    tree = _plant_tree(acid, n_diabat - 1, max_chain)
+    tree = _plant_tree(acid, n_diabat - 1, max_chain, tuple(bifurcate))
     if proton_shift:      # acid proton moved along O-H towards its planted acceptor: > ~0.3 A makes the acceptor's diabat the principal one
         acid = acid.copy()
         acid[5] += proton_shift * _unit(acid[5] - acid[4])

@@ -27,7 +27,7 @@ def test_tables_bit_exact(oracle_lib, name):
     assert o.ewald_self() == g["Ewald_self"][0]
 
 
-@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3"])
+@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3", "std_n12_k32_s26"])
 def test_verlet_list_identical(oracle_lib, name):
     g = golden(name)
     spec = system.from_golden(g)
@@ -43,7 +43,7 @@ def test_verlet_list_identical(oracle_lib, name):
     assert h.hexdigest() == str(g["neighbor_pairs_sha256"])
 
 
-@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3", "std_n6_sapt_s6", "std_n6_lb_s9", "std_n6_rb_s10", "std_n6_ex3_s12", "std_n6_k20_s13", "std_n6_k64_s17", "std_n6_ortho_s19"])
+@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3", "std_n6_sapt_s6", "std_n6_lb_s9", "std_n6_rb_s10", "std_n6_ex3_s12", "std_n6_k20_s13", "std_n6_k64_s17", "std_n6_ortho_s19", "std_n12_k32_s26"])
 def test_stages(oracle_lib, name):
     g = golden(name)
     o = oracle_lib.Oracle(system.from_golden(g))
@@ -98,7 +98,8 @@ def test_evb_from_scratch_equals_reference_delta(oracle_lib, name):
 
 
 @pytest.mark.parametrize("name,evb", [("md_std_n6_s4", False), ("md_evb_n6_d2_s5", True), ("md_std_n6_frz_s14", False),
-                                      ("md_std_n6_rebuild_s21", False), ("md_evb_n6_d4_rebuild_s24", True), ("md_evb_n6_d4_drop_s22", True)])
+                                      ("md_std_n6_rebuild_s21", False), ("md_evb_n6_d4_rebuild_s24", True), ("md_evb_n6_d4_drop_s22", True),
+                                      ("md_evb_n12_d4_s29", True)])
 def test_md_trajectory(oracle_lib, name, evb):
     """the *_rebuild_* / *_drop_* fixtures are 60 reference steps at 600 K that cross 6-7 Verlet-list rebuilds
     (update_verlet_displacements, src/general_routines.f90:1259-1337) and changes of the diabat count (4 -> 5 -> 6, 4 -> 1)"""

@@ -135,7 +135,7 @@ int msevb_destroy(msevb_ctx* c) {
                         &c->d_Fdiag, &c->d_Foff};
   for (auto b : db) b->release();
   c->d_pair_par.release(); c->d_moltypes.release(); c->d_ewald_tab.release(); c->d_ewald_tay.release(); c->d_nbr_count.release(); c->d_nbr_split.release(); c->d_host_perm.release(); c->d_stage3.release(); c->d_nbr2_count.release(); c->d_posq_prune.release(); c->d_flat.release(); c->d_cell_trips.release(); c->d_nbr_start.release();
-  c->d_w_s.release(); c->d_comm_h.release(); c->d_comm_e.release(); c->d_bad.release(); c->d_fsorted.release();
+  c->d_w_s.release(); c->d_rows_s.release(); c->d_brick_flag.release(); c->d_comm_h.release(); c->d_comm_e.release(); c->d_bad.release(); c->d_fsorted.release();
   if (c->h_ke) (void)hipHostFree(c->h_ke);
   c->d_sort_tmp.release(); c->d_sort_hist.release(); c->d_posq.release(); c->d_grid.release(); c->d_fft_work.release(); c->d_fft_work_b.release();
   for (int p = 0; p < PH_COUNT; ++p) for (hipEvent_t e : c->ph[p].ev) (void)hipEventDestroy(e);
@@ -822,6 +822,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   }
   if (s == "prune_freeze") { c->prune_freeze = v != 0.0; return MSEVB_OK; }
   if (s == "pair_taylor") { c->pair_taylor = v != 0.0; return MSEVB_OK; }
+  if (s == "pair_pipe") { c->pair_pipe = v != 0.0; return MSEVB_OK; }
   if (s == "pair_tiles") { c->pair_tiles_opt = (int)v; c->list_valid = false; return MSEVB_OK; }
   c->err = "unknown option " + s;
   return MSEVB_ERR_ARG;

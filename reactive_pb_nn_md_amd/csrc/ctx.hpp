@@ -322,7 +322,8 @@ struct msevb_ctx {
   int pair_flat_opt = 1;         // option pair_flat: 0 = k_pair_half on per-atom rows (round 2's kernel; still what force fields with a live SAPT term run)
   bool prune_freeze = false;     // diagnostics (tools/time_stage.py): stage calls on unchanged positions keep the pair list of the first call instead of rewriting it every time
   bool pair_taylor = true;       // option pair_taylor (default on): one Ewald-table row per pair, the other one from the table's own derivatives (pair_flat.hip); 0 = both rows gathered
-  bool attr_pair_flat[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
+  bool attr_pair_flat[16] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};
+  bool pair_pipe = true;         // option pair_pipe: 1 = two trips in flight per wave (128 registers), 0 = one trip at a time (80)
   int pair_split_opt = 0;        // option pair_split (measured slower, off): 1 = two workgroups per cell when the sub-tiles fit (2 x 12 waves per CU), 2 = the same with 2 x 8 waves and the pipelined loop, 0 = one workgroup per cell
   bool pair_split_now = false;
   int sub_tile_max = 0;          // largest sub-tile (own cell + 6 / + 7 forward cells) the last build saw
@@ -341,6 +342,7 @@ struct msevb_ctx {
   DBuf<double> d_green;        // G = IFFT(CB): real-space kernel of the reciprocal sum (theta = G * Q), K^3
   DBuf<double> d_w, d_dw, d_uscale, d_uscale_s;   // per atom: B6 weights [N][3][6], derivative weights, scaled coords
   DBuf<int> d_base, d_splindex;       // nearpt [N][3], B6 rows [N][3][6]
+  DBuf<int2> d_rows_s;      // cell-sorted row seeds of the B-spline tables per (atom, axis), pme_row_seed (pme.hip)
   DBuf<int> d_base_s, d_brick_flag; DBuf<double> d_w_s;      // cell-sorted copies of nearpt / B6 weights for the brick spread; its overflow flag
   rocfft_plan plan_fwd = nullptr, plan_bwd = nullptr;
   // batched plans by batch size (= number of non-principal diabat grids): kept for the life of the context, because the diabat count moves

@@ -101,7 +101,7 @@ template <int P>
 __device__ __forceinline__ void pf_stage_a_read(unsigned e, PfRaw& w) {
   w.ja = (e & ((1u << PF_J_BITS) - 1u)) << 3;
   w.aa = (e >> (PF_A_SHIFT - 3)) & (((1u << PF_A_BITS) - 1u) << 3);
-  w.pa = (e >> (PF_T_SHIFT - 5)) & (0x3ffu << 5);
+  w.pa = ((e >> (PF_T_SHIFT - 5)) & (0x3ffu << 5)) | (e & 0x80000000u);      // bit 31: the pair type has a Lennard-Jones term (set by the rewrite)
   constexpr unsigned X = pf_lj_bytes(P);
 #if PF_EXP & 8
   w.xj = (double)(w.ja >> 3) * 0.01; w.yj = 3.0; w.zj = 4.0; w.qj = 0.4;
@@ -152,7 +152,7 @@ __device__ __forceinline__ double pf_exact_r2(const double4& pi, const double4& 
   return (dx * dx + dy * dy) + dz * dz;
 }
 
-struct PfSmall { double red[2][16]; int lo[HALF_SLOTS], off[HALF_SLOTS + 1], full, off7; unsigned tt0, tt; unsigned char typ[PAIR_CELL_MAX]; };
+struct PfSmall { double red[2][16]; int lo[HALF_SLOTS], off[HALF_SLOTS + 1], full, off7; unsigned tt0, tt; unsigned ljm[16] /* per atom type: bit t set = the pair with type t has a Lennard-Jones term */; unsigned char typ[PAIR_CELL_MAX]; };
 struct PfRows { unsigned off2[PAIR_CELL_MAX], cnt[PAIR_CELL_MAX], beg[PAIR_CELL_MAX]; };      // per-row scratch of the pruning pass: in the third force array, behind the single-precision copy of the tile
 
 struct PfAcc { double fx, fy, fz, e_el, e_vdw; unsigned a_prev;
@@ -173,11 +173,6 @@ __device__ __forceinline__ void pf_stage_b(const PfTrip& s, int lane, double rc2
   if (__ballot(s.aa != acc.a_prev)) {      // (wave-uniform test) some DPP row has moved on to its next atom: its owner's force joins the tile
     if (s.aa != acc.a_prev) { pf_flush_row<P>(acc, lane); acc.a_prev = s.aa; }
   }
-#if PF_EXP & 4
-  const double C12 = (double)s.pa, C6 = 2.0, C12x12 = 3.0, C6x6 = 4.0;
-#else
-  const double C12 = pf_ld(s.pa), C6 = pf_ld(s.pa + 8), C12x12 = pf_ld(s.pa + 16), C6x6 = pf_ld(s.pa + 24);
-#endif
   double ev, sv;      // erfc and force-scale interpolants
   if (TAYLOR) {
     const double gE = (s.c1 * delta) * s.t1.y;        // alpha (r_B - r - dx) E_B: the fetched row is {T_B, E_B}, E = (2/sqrt(pi)) exp(-x^2) conv = -dT/dx (d_ewald_tay)
@@ -192,9 +187,21 @@ __device__ __forceinline__ void pf_stage_b(const PfTrip& s, int lane, double rc2
     sv = s.c1 * s.t0.y + c2 * s.t1.y;
   }
   const double inv_r2 = s.inv_r * s.inv_r, qr = s.qq * s.inv_r;
-  const double r6i = inv_r2 * inv_r2 * inv_r2;
-  const double evdw = __builtin_fma(C12, r6i, -C6) * r6i;                                  // C12/r^12 - C6/r^6
-  const double fs = __builtin_fma(__builtin_fma(C12x12, r6i, -C6x6) * r6i, inv_r2, qr * inv_r2 * sv);      // force on i = fs * dr
+  double evdw = 0.0, flj = 0.0;
+  // Lennard-Jones only in trips that hold a pair with such a term (wave-uniform test of the entries' flag bit): in water two rows in three belong
+  // to hydrogens, whose pairs have none - their trips skip four LDS reads and eight instructions per entry
+  if (__ballot((int)s.pa < 0)) {
+    const unsigned pa = s.pa & 0x7fffffffu;
+#if PF_EXP & 4
+    const double C12 = (double)pa, C6 = 2.0, C12x12 = 3.0, C6x6 = 4.0;
+#else
+    const double C12 = pf_ld(pa), C6 = pf_ld(pa + 8), C12x12 = pf_ld(pa + 16), C6x6 = pf_ld(pa + 24);      // (zeros for a pair type without the term)
+#endif
+    const double r6i = inv_r2 * inv_r2 * inv_r2;
+    evdw = __builtin_fma(C12, r6i, -C6) * r6i;                                  // C12/r^12 - C6/r^6
+    flj = __builtin_fma(C12x12, r6i, -C6x6) * r6i * inv_r2;
+  }
+  const double fs = __builtin_fma(qr * inv_r2, sv, flj);      // force on i = fs * dr
   bool in = s.r2 < rc2_lo;
   const unsigned long long m_in = __ballot(in), m_near = __ballot(s.r2 < rc2_hi);
   if (m_in != m_near) {      // rare: on the cutoff to within rounding - the reference's arithmetic on the raw coordinates decides
@@ -302,6 +309,11 @@ __global__ __launch_bounds__(THREADS, MINW) void k_pair_flat(const PairFlatArgs 
       const PairParam q = A.pairpar[k];
       ppt[k] = q.type == 0 ? make_double4(q.p[0], q.p[1], 12.0 * q.p[0], 6.0 * q.p[1]) : make_double4(0.0, 0.0, 0.0, 0.0);
     }
+    if (mode != 2 && (int)threadIdx.x < A.nt) {
+      unsigned m = 0;
+      for (int t = 0; t < A.nt; ++t) { const PairParam q = A.pairpar[threadIdx.x * A.nt + t]; if (q.type == 0 && (q.p[0] != 0.0 || q.p[1] != 0.0)) m |= 1u << t; }
+      sm.ljm[threadIdx.x] = m;
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -395,8 +407,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_pair_flat(const PairFlatArgs 
         const float ddx = fi.x - fj.x, ddy = fi.y - fj.y, ddz = fi.z - fj.z;      // and an entry too many in the list costs nothing but its lane
         const bool keep = v && (ddx * ddx + ddy * ddy + ddz * ddz) < rp2f;
         const unsigned long long m = __ballot(keep);
-        const unsigned head = ((unsigned)s_typ[ra] * (unsigned)A.nt) << PF_T_SHIFT | ((unsigned)ra << PF_A_SHIFT);
-        if (keep) out[o + tot + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (int)(head + ((e >> NBR_IDX_BITS) << PF_T_SHIFT) + j);
+        const unsigned ti = (unsigned)s_typ[ra], ljm = sm.ljm[ti];
+        const unsigned head = (ti * (unsigned)A.nt) << PF_T_SHIFT | ((unsigned)ra << PF_A_SHIFT);
+        if (keep) out[o + tot + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (int)((head + ((e >> NBR_IDX_BITS) << PF_T_SHIFT) + j) | (((ljm >> (e >> NBR_IDX_BITS)) & 1u) << 31));
         tot += (unsigned)__popcll(m);
         const int na_next = q + 1 < PF_BATCH ? pc[q + 1].a : pd[0].a;      // the row of the piece that follows (-1: none)
         if (na_next != ra) {      // the row part ends: padded to 16 entries (dummy partner, same row)
@@ -557,6 +570,10 @@ int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int slot_elec, int slot_v
     return ty ? pf_launch<1344, true, true, 768, 6, false>(c, A, nblocks, at[10]) : pf_launch<1344, false, true, 768, 6, false>(c, A, nblocks, at[11]);      // 2 x 12 waves, 80 registers
   }
   const int need_slots = c->half_tile_cap + 1;
+  if (!c->pair_pipe) {      // option pair_pipe = 0: one trip at a time in <= 80 registers - the four waves per SIMD of a tile's workgroup then leave 192 registers per lane for waves of the side chains
+    if (need_slots <= 2048) return ty ? pf_launch<2048, true, false, 1024, 6, false>(c, A, nblocks, at[12]) : pf_launch<2048, false, false, 1024, 6, false>(c, A, nblocks, at[13]);
+    return ty ? pf_launch<2560, true, false, 1024, 6, false>(c, A, nblocks, at[14]) : pf_launch<2560, false, false, 1024, 6, false>(c, A, nblocks, at[15]);
+  }
   if (need_slots <= 1024) return ty ? pf_launch<1024, true, false, 1024, 4, true>(c, A, nblocks, at[0]) : pf_launch<1024, false, false, 1024, 4, true>(c, A, nblocks, at[1]);
   if (need_slots <= 2048) return ty ? pf_launch<2048, true, false, 1024, 4, true>(c, A, nblocks, at[2]) : pf_launch<2048, false, false, 1024, 4, true>(c, A, nblocks, at[3]);
   if (need_slots <= 2304) return ty ? pf_launch<2304, true, false, 1024, 4, true>(c, A, nblocks, at[6]) : pf_launch<2304, false, false, 1024, 4, true>(c, A, nblocks, at[7]);      // (the largest pitch that keeps all four position arrays within the 16-bit offset field)

@@ -49,13 +49,44 @@ __global__ __launch_bounds__(256) void k_pme_prep(int N, int K, int G, const dou
   dw[t] = d;
 }
 
+// ---- table rows in integer arithmetic -------------------------------------------------------------------------------
+// The reference's row of tap k is ceil(a / 6 * G) with a = u - (nearpt - k) = f + k, f = u - nearpt in (0, 1) (src/pme.f90:220-247; exact in
+// fp64), and ceil(a / 5 * G), ceil((a - 1) / 5 * G) for the two B5 rows of the derivative weight (:412-414).  With G = 6 q6 + rho6:
+//     (f + k) G / 6 = X + k q6 + k rho6 / 6,   X = f G / 6  =>  row = k q6 + floor(k rho6 / 6) + floor(X) + 1 + [6 frac(X) + (k rho6 mod 6) >= 6]
+// as long as 6 frac(X) is not within 1e-8 of an integer (then the reference's two roundings decide: `rare`, the callers take its own
+// expression for the whole wavefront).  So ONE product, floor and class per atom and axis (here, by k_pme_prep_light) replace a product, a
+// ceil, a subtraction and two compares per TAP in the tiled kernels (36 v_ceil_f64 per lane and trip of the gather, round 3).  Same for G / 5.
+// seed.x = floor(X) | class6 << 16 | rare << 31,  seed.y = floor(Y) | class5 << 16,  Y = f G / 5
+__device__ __forceinline__ int2 pme_row_seed(double f, double G) {
+#pragma clang fp contract(off)
+  const double X = f * (G / 6.0), Y = f * (G / 5.0);
+  const double c6 = floor(X), c5 = floor(Y);
+  const double s6 = (X - c6) * 6.0, s5 = (Y - c5) * 5.0;
+  const double k6 = floor(s6), k5 = floor(s5);
+  const bool rare = s6 - k6 < 1e-8 || s6 - k6 > 1.0 - 1e-8 || s5 - k5 < 1e-8 || s5 - k5 > 1.0 - 1e-8;
+  return make_int2((int)c6 | ((int)k6 << 16) | (rare ? (int)0x80000000u : 0), (int)c5 | ((int)k5 << 16));
+}
+// per-tap constants of a lane (its tap k is fixed): row = A + floor part of the seed + [class + m >= modulus]
+struct RowTap { int A6, m6, A5a, m5a, A5b, m5b; };
+__device__ __forceinline__ RowTap pme_row_tap(int k, int Gi) {
+  const int q6 = Gi / 6, r6 = Gi % 6, q5 = Gi / 5, r5 = Gi % 5, kb = k - 1;      // (kb = -1 for tap 0: its (a - 1) term does not apply, the row is clamped into the table)
+  RowTap t;
+  t.A6 = k * q6 + (k * r6) / 6 + 1; t.m6 = (k * r6) % 6;
+  t.A5a = k * q5 + (k * r5) / 5 + 1; t.m5a = (k * r5) % 5;
+  t.A5b = kb >= 0 ? kb * q5 + (kb * r5) / 5 + 1 : -Gi; t.m5b = kb >= 0 ? (kb * r5) % 5 : 0;
+  return t;
+}
+__device__ __forceinline__ int pme_row6(int2 sd, const RowTap& t) { return t.A6 + (sd.x & 0xffff) + ((((sd.x >> 16) & 7) + t.m6) >= 6 ? 1 : 0); }
+__device__ __forceinline__ int pme_row5a(int2 sd, const RowTap& t) { return t.A5a + (sd.y & 0xffff) + ((((sd.y >> 16) & 7) + t.m5a) >= 5 ? 1 : 0); }
+__device__ __forceinline__ int pme_row5b(int2 sd, const RowTap& t) { return t.A5b + (sd.y & 0xffff) + ((((sd.y >> 16) & 7) + t.m5b) >= 5 ? 1 : 0); }
+
 // The same scaled coordinate and nearest grid point WITHOUT the 36 weights per atom (option pme_weightless, the default on the tiled
 // spread / gather): one thread per (atom, axis), 36 B written per atom instead of 324 B.  The tiled kernels below recompute the weights
 // from uscale / base and the spline tables with the arithmetic of k_pme_prep (pme_tap_w / pme_taps3), so the values are the same bits.
 __global__ __launch_bounds__(256) void k_pme_prep_light(int N, int K, const double* __restrict__ xyz, double k00, double k01, double k02, double k10, double k11,
                                                         double k12, double k20, double k21, double k22, double* __restrict__ uscale, int* __restrict__ base,
                                                         double* __restrict__ fault, const int* __restrict__ inv_perm, double* __restrict__ uscale_s,
-                                                        int* __restrict__ base_s) {      // *_s: the same values in cell-sorted atom order (what the tiled kernels read, coalesced)
+                                                        int* __restrict__ base_s, int2* __restrict__ rows_s, double G) {      // *_s: the same values in cell-sorted atom order (what the tiled kernels read, coalesced)
 #pragma clang fp contract(off)
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 3 * N) return;
@@ -70,6 +101,7 @@ __global__ __launch_bounds__(256) void k_pme_prep_light(int N, int K, const doub
   uscale[t] = u; base[t] = np;
   const int ts = 3 * inv_perm[i] + l;
   uscale_s[ts] = u; base_s[ts] = np;
+  rows_s[ts] = pme_row_seed(u - (double)np, G);
 }
 
 // Table rows without the fp64 divisions: (int)ceil(a / div * G) equals ceil(a * (G / div)) unless the product lies within ~1e-10 of an integer
@@ -116,6 +148,21 @@ __device__ __forceinline__ void pme_taps3_issue(double u1, double u2, double u3,
     r.mask |= (a1[l] < 5.0 ? 1 << l : 0) | (0.0 < a2[l] ? 8 << l : 0);
   }
 }
+// the same from the row seeds of k_pme_prep_light: integer adds per tap; a wavefront with a seed in a tie zone reads (u, nearpt) of its atoms (usrc, bsrc
+// + 3 x the atom's position in the cell-sorted order) and takes the arithmetic above - rare, and the only global load of the function
+__device__ __forceinline__ void pme_taps3_issue_rows(int2 s1, int2 s2, int2 s3, const RowTap& t, int k, int Gi, const double* __restrict__ B6, const double* __restrict__ B5,
+                                                     const double* __restrict__ usrc, const int* __restrict__ bsrc, int at3, TapRaw& r) {
+  if (__builtin_expect(__any((s1.x | s2.x | s3.x) < 0), 0)) {
+    pme_taps3_issue(usrc[at3], usrc[at3 + 1], usrc[at3 + 2], bsrc[at3], bsrc[at3 + 1], bsrc[at3 + 2], k, (double)Gi, B6, B5, r);
+    return;
+  }
+  const int2 sd[3] = {s1, s2, s3};
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    r.v6[l] = B6[min(max(pme_row6(sd[l], t), 1), Gi) - 1]; r.va[l] = B5[min(max(pme_row5a(sd[l], t), 1), Gi) - 1]; r.vb[l] = B5[min(max(pme_row5b(sd[l], t), 1), Gi) - 1];
+  }
+  r.mask = (k < 5 ? 7 : 0) | (k >= 1 ? 56 : 0);      // a1 = f + k < 5 <=> k <= 4; 0 < a2 = f + k - 1 <=> k >= 1 (0 < f < 1: k_pme_prep_light keeps u off the integers)
+}
 __device__ __forceinline__ void pme_taps3_finish(const TapRaw& r, double (&w)[3], double (&dw)[3]) {
 #pragma unroll
   for (int l = 0; l < 3; ++l) { w[l] = r.v6[l]; dw[l] = ((r.mask >> l) & 1 ? r.va[l] : 0.0) - ((r.mask >> (3 + l)) & 1 ? r.vb[l] : 0.0); }
@@ -152,7 +199,7 @@ constexpr int SPREAD_CHUNK = 64;      // atoms of a cell staged in LDS at a time
 __global__ __launch_bounds__(512) void k_pme_spread_tiles(int K, int3 nc, int3 T, const int* __restrict__ cell_start, const int* __restrict__ perm,
                                                           const double* __restrict__ chg, const int* __restrict__ base, const double* __restrict__ w,
                                                           double* __restrict__ grid, int gs,      // gs = 2: real parts of a complex grid, 1: real grid
-                                                          const double* __restrict__ uscale, const double* __restrict__ B6, int G) {      // w == nullptr: weights from the table
+                                                          const double* __restrict__ uscale, const double* __restrict__ B6, int G, const int2* __restrict__ rows_s) {      // w == nullptr: weights from the table (row seeds of k_pme_prep_light)
   extern __shared__ double tile[];
   const int cidx = blockIdx.x;
   const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
@@ -174,9 +221,15 @@ __global__ __launch_bounds__(512) void k_pme_spread_tiles(int K, int3 nc, int3 T
     const int n = min(SPREAD_CHUNK, e - c0);
     __syncthreads();      // tile zeroed / previous chunk consumed
     if (w) for (int k = threadIdx.x; k < n * 18; k += blockDim.x) { const int a = k / 18, r = k - 18 * a; sw[k] = w[(size_t)perm[c0 + a] * 18 + r]; }
-    else for (int k = threadIdx.x; k < n * 18; k += blockDim.x) {
-      const int a = k / 18, r = k - 18 * a, l = r / 6, i3 = 3 * (c0 + a) + l;      // (uscale / base in cell-sorted order here)
-      sw[k] = pme_tap_w(uscale[i3], base[i3], r - 6 * l, (double)G, B6);
+    else for (int k0 = 0; k0 < n * 18; k0 += blockDim.x) {      // (trip count uniform over the workgroup: the tie-zone test below is a wave vote)
+      const int k = k0 + threadIdx.x, kk = min(k, n * 18 - 1);
+      const int a = kk / 18, r = kk - 18 * a, l = r / 6, tap = r - 6 * l, i3 = 3 * (c0 + a) + l;      // (seeds / uscale / base in cell-sorted order here)
+      const int2 sd = rows_s[i3];
+      int row = tap * (G / 6) + (tap * (G % 6)) / 6 + 1 + (sd.x & 0xffff) + ((((sd.x >> 16) & 7) + (tap * (G % 6)) % 6) >= 6 ? 1 : 0);
+      double wv;
+      if (__builtin_expect(__any(sd.x < 0), 0)) wv = pme_tap_w(uscale[i3], base[i3], tap, (double)G, B6);
+      else wv = B6[min(max(row, 1), G) - 1];
+      if (k < n * 18) sw[k] = wv;
     }
     if (w) for (int k = threadIdx.x; k < n * 3; k += blockDim.x) { const int a = k / 3, r = k - 3 * a; sb[k] = base[3 * perm[c0 + a] + r]; }
     else for (int k = threadIdx.x; k < n * 3; k += blockDim.x) sb[k] = base[3 * c0 + k];
@@ -610,7 +663,7 @@ __global__ __launch_bounds__(512) void k_pme_gather_tiles(int K, int3 nc, int3 T
 // stencil sums of the trip in front of them, from the cell's (u, nearpt) staged in LDS beside the tile - no global load waits inside the loop.
 // Same sums in the same order as k_pme_gather_tiles: bit-identical forces.
 __global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, int3 T, const int* __restrict__ cell_start, const int* __restrict__ perm,
-                                                             const double* __restrict__ chg, const int* __restrict__ base_s, const double* __restrict__ uscale_s,
+                                                             const double* __restrict__ chg, const int* __restrict__ base_s, const double* __restrict__ uscale_s, const int2* __restrict__ rows_s,
                                                              const double* __restrict__ B6, const double* __restrict__ B5, int G, int cap,
                                                              const double* __restrict__ theta, double conv, double k00, double k01,
                                                              double k02, double k10, double k11, double k12, double k20, double k21, double k22,
@@ -622,12 +675,12 @@ __global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, 
   const int P = T.x | 1, P2 = spread_plane_stride(T);
   const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3, ngrp = blockDim.x >> 3;
   double* const xw = tile + P2 * T.z + 24 * grp;      // {w_x[6], w_y[6], dw_x[6], dw_y[6]} of the group's atom
-  double* const cu = tile + P2 * T.z + 24 * ngrp;     // [3 cap] scaled coordinates of the cell's atoms ...
+  int2* const cu = (int2*)(tile + P2 * T.z + 24 * ngrp);     // [3 cap] row seeds of the cell's atoms (pme_row_seed) ...
   int* const cb = (int*)(cu + 3 * cap);                // [3 cap] ... their nearest grid points,
   double* const cq = (double*)(cb + 3 * cap + (cap & 1));      // [cap] charges
   int* const ci = (int*)(cq + cap);                    // [cap] and atom indices
   const int s = cell_start[cidx], e = cell_start[cidx + 1];
-  const double Gd = (double)G;
+  const RowTap rt = pme_row_tap(sub < 6 ? sub : 0, G);      // this lane's tap: constants of its table rows
   // the atom one trip ahead (registers): raw table values of tap `sub` of the three axes, nearest grid points, atom, charge.  Lanes without an
   // atom (sub >= 6, no atom left) look up a harmless coordinate: the loads go out unconditionally, no branch between them and their first use
   TapRaw nt;
@@ -640,13 +693,13 @@ __global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, 
   const bool staged = n_cell <= cap && n_cell <= (int)blockDim.x;      // (a cell larger than the host knew: the later trips read global memory as trip 0 does)
   const int iac = s + grp < e ? s + grp : max(e - 1, 0);      // (no atom for this group: any valid one, never used)
   nb1 = base_s[3 * iac]; nb2 = base_s[3 * iac + 1]; nb3 = base_s[3 * iac + 2];
-  const double tu1 = uscale_s[3 * iac], tu2 = uscale_s[3 * iac + 1], tu3 = uscale_s[3 * iac + 2];
+  const int2 tr1 = rows_s[3 * iac], tr2 = rows_s[3 * iac + 1], tr3 = rows_s[3 * iac + 2];
   ni = perm[iac];
   const bool st_on = staged && (int)threadIdx.x < n_cell;
   const int ks = st_on ? s + (int)threadIdx.x : iac;
-  const double su1 = uscale_s[3 * ks], su2 = uscale_s[3 * ks + 1], su3 = uscale_s[3 * ks + 2];
+  const int2 su1 = rows_s[3 * ks], su2 = rows_s[3 * ks + 1], su3 = rows_s[3 * ks + 2];
   const int sb1 = base_s[3 * ks], sb2 = base_s[3 * ks + 1], sb3 = base_s[3 * ks + 2], si = perm[ks];
-  pme_taps3_issue(tu1, tu2, tu3, nb1, nb2, nb3, sub < 6 ? sub : 0, Gd, B6, B5, nt);
+  pme_taps3_issue_rows(tr1, tr2, tr3, rt, sub < 6 ? sub : 0, G, B6, B5, uscale_s, base_s, 3 * iac, nt);
   nq = chg[ni];
   const double sq = chg[si];
   {      // stage the potential: x fastest (coalesced rows of T.x points); four loads in flight per thread
@@ -692,13 +745,13 @@ __global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, 
     }
     {      // the next trip's atom (the last atom of the cell again when there is none): table loads in flight during this trip's sums
       const int jc = min(ia + ngrp, e - 1) - s;
-      double u1, u2, u3;
+      int2 u1, u2, u3;
       if (staged) { ni = ci[jc]; nq = cq[jc]; nb1 = cb[3 * jc]; nb2 = cb[3 * jc + 1]; nb3 = cb[3 * jc + 2]; u1 = cu[3 * jc]; u2 = cu[3 * jc + 1]; u3 = cu[3 * jc + 2]; }
       else {
         const int jg = s + jc;
-        ni = perm[jg]; nq = chg[ni]; nb1 = base_s[3 * jg]; nb2 = base_s[3 * jg + 1]; nb3 = base_s[3 * jg + 2]; u1 = uscale_s[3 * jg]; u2 = uscale_s[3 * jg + 1]; u3 = uscale_s[3 * jg + 2];
+        ni = perm[jg]; nq = chg[ni]; nb1 = base_s[3 * jg]; nb2 = base_s[3 * jg + 1]; nb3 = base_s[3 * jg + 2]; u1 = rows_s[3 * jg]; u2 = rows_s[3 * jg + 1]; u3 = rows_s[3 * jg + 2];
       }
-      pme_taps3_issue(u1, u2, u3, nb1, nb2, nb3, sub < 6 ? sub : 0, Gd, B6, B5, nt);
+      pme_taps3_issue_rows(u1, u2, u3, rt, sub < 6 ? sub : 0, G, B6, B5, uscale_s, base_s, 3 * (s + jc), nt);
     }
     double f1 = 0.0, f2 = 0.0, f3 = 0.0;
     if (live && sub < 6) {
@@ -913,7 +966,7 @@ int pme_setup(msevb_ctx* c) {
   if (!g_rocfft_ready) { if (rocfft_setup() != rocfft_status_success) FAIL(MSEVB_ERR_FFT, "rocfft_setup failed"); g_rocfft_ready = true; }
   const int batch = c->fft_batch < 1 ? 1 : c->fft_batch;
   if (c->d_grid.alloc(K3 * batch) || c->d_Q.alloc(K3) || c->d_theta.alloc(K3) || c->d_w.alloc(18 * (size_t)N) || c->d_dw.alloc(18 * (size_t)N) || c->d_uscale.alloc(3 * (size_t)N) ||
-      c->d_base.alloc(3 * (size_t)N) || c->d_base_s.alloc(3 * (size_t)N) || c->d_uscale_s.alloc(3 * (size_t)N) || c->d_w_s.alloc(18 * (size_t)N) || c->d_splindex.alloc(18 * (size_t)N) || c->d_force_recip.alloc(3 * (size_t)N))
+      c->d_base.alloc(3 * (size_t)N) || c->d_base_s.alloc(3 * (size_t)N) || c->d_uscale_s.alloc(3 * (size_t)N) || c->d_rows_s.alloc(3 * (size_t)N) || c->d_w_s.alloc(18 * (size_t)N) || c->d_splindex.alloc(18 * (size_t)N) || c->d_force_recip.alloc(3 * (size_t)N))
     FAIL(MSEVB_ERR_HIP, "hipMalloc failed (PME)");
   size_t len[3] = {(size_t)K, (size_t)K, (size_t)K};
   pme_teardown(c);
@@ -1050,7 +1103,7 @@ int pme_prepare_atoms(msevb_ctx* c, bool with_indices) {
   const long nt = 18L * N;
   if (!with_indices && pme_weightless_now(c)) {
     hipLaunchKernelGGL(k_pme_prep_light, dim3((unsigned)((3 * N + 255) / 256)), dim3(256), 0, pme_stream(c), N, c->K, c->d_xyz.p, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
-                       c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_uscale.p, c->d_base.p, c->d_energies.p + S_FAULT, c->d_inv_perm.p, c->d_uscale_s.p, c->d_base_s.p);
+                       c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], c->d_uscale.p, c->d_base.p, c->d_energies.p + S_FAULT, c->d_inv_perm.p, c->d_uscale_s.p, c->d_base_s.p, c->d_rows_s.p, (double)c->spline_grid);
     HIPCHK(hipGetLastError());
     c->weights_valid = false; c->weights_side = false;
     return MSEVB_OK;
@@ -1090,7 +1143,7 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
         if (lds > 160 * 1024) FAIL(MSEVB_ERR_LIMIT, "pme_gather: cell too large for the weight-free gather (set option pme_weightless=0)");
         if (lds > 64 * 1024 && c->attr_gather_wl < (int)lds) { HIPCHK(hipFuncSetAttribute((const void*)k_pme_gather_tiles_wl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); c->attr_gather_wl = (int)lds; }
         hipLaunchKernelGGL(k_pme_gather_tiles_wl, dim3(ncell), dim3(c->pme_tile_threads), lds, c->stream, c->K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T, c->d_cell_start.p, c->d_perm.p,
-                           chg, c->d_base_s.p, c->d_uscale_s.p, c->d_B6.p, c->d_B5.p, c->spline_grid, cap, theta ? theta : c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
+                           chg, c->d_base_s.p, c->d_uscale_s.p, c->d_rows_s.p, c->d_B6.p, c->d_B5.p, c->spline_grid, cap, theta ? theta : c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
                            c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, atomic ? 1 : 0, add_lo, add_hi);
       } else
       hipLaunchKernelGGL(k_pme_gather_tiles, dim3(ncell), dim3(c->pme_tile_threads), tile_bytes, c->stream, c->K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T, c->d_cell_start.p, c->d_perm.p,
@@ -1160,7 +1213,7 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
       } else if (c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= K && T.y <= K && T.z <= K) {
         const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
         hipLaunchKernelGGL(k_pme_spread_tiles, dim3(ncell), dim3(c->pme_tile_threads), tile_bytes, st, K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T,
-                           c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->weights_valid ? c->d_base.p : c->d_base_s.p, c->weights_valid ? c->d_w.p : (const double*)nullptr, g, gs, c->d_uscale_s.p, c->d_B6.p, c->spline_grid);
+                           c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->weights_valid ? c->d_base.p : c->d_base_s.p, c->weights_valid ? c->d_w.p : (const double*)nullptr, g, gs, c->d_uscale_s.p, c->d_B6.p, c->spline_grid, c->d_rows_s.p);
       } else {
         const long nt = (long)N * 36;
         hipLaunchKernelGGL(k_pme_spread, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, N, K, c->d_chg.p, c->d_base.p, c->d_w.p, g, gs);

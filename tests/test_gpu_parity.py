@@ -33,7 +33,10 @@ def production_kernels(h, name):
     half list, tiled weight-free spread / gather - asserted, so that a change of the dispatch rules cannot silently take them off the fixtures"""
     if "_n12_" not in name:
         return
-    assert h.info("cells_per_axis_min") >= 4 and h.info("list_build_tiles") == 1 and h.info("pair_kernel") == 2 and h.info("pme_tiles") == 1
+    assert h.info("cells_per_axis_min") >= 4 and h.info("list_build_tiles") == 1 and h.info("pair_kernel") == 2
+    # the PME tile of a cell (K / cells + 8 points per axis) must fit 64 KB of LDS: 32^3 on 4 cells per axis does (16^3), 64^3 does not (24^3; the
+    # benchmark's 64^3 on 9 cells per axis does: 16^3) - those fixtures take the plain spread / gather
+    assert h.info("pme_tiles") == (1 if h.spec.pme_grid <= 32 else 0)
 
 
 @pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3"])
@@ -337,26 +340,35 @@ def test_evb_against_reference(name, stores):
 
 
 @pytest.mark.parametrize("name", ["evb_n6_d4_s2", "evb_n6_d8_s1", "evb_n6_d4_k64_s18"])
-def test_evb_translated_across_the_periodic_boundary(name):
-    """The reference's numbers are invariant under a translation of the whole box.  Shifted by half a box (whole molecules, as the reference keeps
-    them) the acid and its hydrogen-bonded waters straddle the periodic boundary: their PME stencils sit on both sides of the grid's wrap-around,
+def test_evb_translated_across_the_periodic_boundary(oracle_lib, name):
+    """The fixtures hold the acid in the middle of the box.  Shifted by half / a quarter of a box (whole molecules, as the reference keeps them)
+    the acid and its hydrogen-bonded waters straddle the periodic boundary: their PME stencils sit on both sides of the grid's wrap-around,
     which is where the stencil-pair sums of the diabats' reciprocal space (k_evb_recip_pairs) indexed their table with ONE wrap instead of two
-    (round 3: a wrong table element, or - first element of the buffer - a read in front of it; found with the guard allocator)."""
+    (round 3: a wrong table element, or - first element of the buffer - a read in front of it; found with the guard allocator).
+    Checker: the CPU oracle (bit-pinned to the reference) on the SAME shifted coordinates.  The reference's numbers are not translation
+    invariant to rounding: .gro-quantised coordinates put pairs exactly on r_c, and which side they fall is decided by the last bit (the oracle
+    and the GPU both move by -0.19879676938 kJ/mol on evb_n6_d8_s1 at half a box); at zero shift the oracle equals the fixture."""
+    import dataclasses
     g = golden(name)
     spec = system.from_golden(g)
     L = np.diag(spec.box) if np.ndim(spec.box) == 2 else np.asarray(spec.box)
-    for frac in (0.5, 0.47):
+    for frac in (0.5, 0.25):
         xyz = spec.xyz + frac * L
         for m in range(spec.n_mole):      # wrap molecule by molecule (first atom decides): molecules stay whole
             a0, n = spec.mol_first[m], spec.mol_natom[m]
             xyz[a0:a0 + n] -= L * np.floor(xyz[a0] / L)
-        h = api.MsEvbHip(spec)
-        h.set_positions(xyz)
+        sp = dataclasses.replace(spec, xyz=xyz)
+        o = oracle_lib.Oracle(sp)
+        o.verlet_build()
+        r = o.evb()
+        h = api.MsEvbHip(sp)
         e, F = h.ms_evb_calculate_total_force_energy()
         st = h.evb_state()
-        assert st["D"] == int(g["n_diabat"][0])
-        assert np.abs(st["H"] - g["evb_hamiltonian"]).max() < 1e-10 * np.abs(g["evb_hamiltonian"]).max(), frac
-        assert rel(e, g["E_adiabatic"][0]) < 1e-10 and np.abs(F - g["F_adiabatic"]).max() < 1e-8, frac
+        assert st["D"] == r["D"] == int(g["n_diabat"][0])
+        Ho = np.triu(np.array(r["H"]))
+        assert np.abs(st["H"] - Ho).max() < 1e-10 * np.abs(Ho).max(), frac
+        assert rel(e, r["E"]) < 1e-10 and np.abs(F - r["F"]).max() < 1e-8, frac
+        assert abs(r["E"] - g["E_adiabatic"][0]) < 0.5      # (the shifted system is the fixture's system)
         h.close()
 
 

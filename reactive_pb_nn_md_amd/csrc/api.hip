@@ -797,7 +797,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "pme_tile_threads") { c->pme_tile_threads = v >= 512 ? 512 : 256; c->pme_graph_key[0] = 0; if (c->pme_graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)c->pme_graph_exec); c->pme_graph_exec = nullptr; } return MSEVB_OK; }
   if (s == "fft_own") { c->fft_own = v != 0.0; return MSEVB_OK; }
   if (s == "spread_bricks") { c->spread_bricks = v != 0.0; return MSEVB_OK; }
-  if (s == "evb_device_solve") { c->evb_device_solve = v != 0.0; return MSEVB_OK; }
+  if (s == "evb_device_solve") { c->evb_device_solve = v != 0.0; c->evb_device_solve_method = v == 2.0 ? 0 : 1; return MSEVB_OK; }      // 1: squaring (+ Jacobi when needed), 2: Jacobi always, 0: host
   if (s == "pair_threads") { c->pair_threads = v == 512.0 ? 512 : 1024; return MSEVB_OK; }
   if (s == "evb_recip_linear") { c->evb_recip_linear = v != 0.0; return MSEVB_OK; }
   if (s == "ensemble_nvt") { c->nvt = v != 0.0; return MSEVB_OK; }
@@ -822,7 +822,10 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   }
   if (s == "prune_freeze") { c->prune_freeze = v != 0.0; return MSEVB_OK; }
   if (s == "pair_taylor") { c->pair_taylor = v != 0.0; return MSEVB_OK; }
+  if (s == "evb_fuse_blend") { c->evb_fuse_blend = v != 0.0; return MSEVB_OK; }
   if (s == "pair_pipe") { c->pair_pipe = v != 0.0; return MSEVB_OK; }
+  if (s == "comm_timeout_ms") { if (!(v >= 1.0)) return MSEVB_ERR_ARG; c->comm_timeout_ms = (int)v; return MSEVB_OK; }
+  if (s == "comm_stall_ms") { c->comm_stall_ms = (int)v; return MSEVB_OK; }
   if (s == "pair_tiles") { c->pair_tiles_opt = (int)v; c->list_valid = false; return MSEVB_OK; }
   c->err = "unknown option " + s;
   return MSEVB_ERR_ARG;

@@ -4,6 +4,8 @@
 // communicator are never in flight together.  Force stores never travel.
 #include <rccl/rccl.h>
 
+#include <chrono>
+
 #include "ctx.hpp"
 
 
@@ -21,14 +23,28 @@ __global__ void k_comm_publish(const double* __restrict__ src, double* __restric
   __syncthreads();
   if (threadIdx.x == 0) *flag = seq;
 }
+// (diagnostic / test) holds the stream for `ticks` of the 100 MHz wall clock, then ends: what a collective with a missing peer looks like to
+// the host, for a bounded time (test_comm_wait_gives_up_on_a_missing_peer)
+__global__ void k_comm_stall(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+// The host's wait for the gathered payload.  It ENDS: when the sequence number arrives, when the stream reports an error, when the stream
+// is idle without the number - or after comm_timeout_ms (option, default 30 s) of wall clock, because a peer that died or never entered
+// the collective leaves hipStreamQuery at hipErrorNotReady for ever (the round-3 loop spun on that without a limit).
 int comm_wait(msevb_ctx* c, long long seq) {
   volatile long long* flag = c->h_comm_flag;
+  const auto t0 = std::chrono::steady_clock::now();
   for (long spins = 1;; ++spins) {
     if (*flag >= seq) return MSEVB_OK;
     if ((spins & 0x3fff) == 0) {      // a collective that failed never publishes: ask the stream now and then
       const hipError_t e = hipStreamQuery(c->aux2);
       if (e == hipSuccess) { if (*flag >= seq) return MSEVB_OK; FAIL(MSEVB_ERR_COMM, "all-gather finished without publishing its result"); }
       if (e != hipErrorNotReady) FAIL(MSEVB_ERR_HIP, std::string("HIP error behind the EVB all-gather: ") + hipGetErrorString(e));
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(c->comm_timeout_ms)) {
+        char b[160]; snprintf(b, sizeof b, "EVB all-gather: no result after %d ms (a peer rank is missing or has stopped); rank %d of %d", c->comm_timeout_ms, c->rank, c->n_ranks);
+        FAIL(MSEVB_ERR_COMM, b);
+      }
     }
   }
 }
@@ -104,6 +120,7 @@ int msevb_comm_allgather_evb(msevb_ctx* c, int with_energies) {
   double* all = c->h_comm;
   double* mine = c->h_comm + (size_t)R * P;
   if (msevb_evb_payload_pack(D, R, c->rank, Hm.data(), c->parent, with_energies ? c->h_energies + S_ELEC_PAIR : nullptr, mine) != MSEVB_OK) FAIL(MSEVB_ERR_ARG, "EVB payload");      // S_ELEC_PAIR .. S_RECIP are contiguous
+  if (c->comm_stall_ms > 0) { hipLaunchKernelGGL(k_comm_stall, dim3(1), dim3(1), 0, c->aux2, 100000LL * c->comm_stall_ms); c->comm_stall_ms = 0; }      // (one-shot test hook)
   hipLaunchKernelGGL(k_comm_stage, dim3(1), dim3(128), 0, c->aux2, mine, d_h.p + (size_t)c->rank * P, P);
   if (ncclAllGather(d_h.p + (size_t)c->rank * P, d_h.p, (size_t)P, ncclDouble, comm, c->aux2) != ncclSuccess) FAIL(MSEVB_ERR_COMM, "ncclAllGather failed");
   hipLaunchKernelGGL(k_comm_publish, dim3(1), dim3(256), 0, c->aux2, d_h.p, all, R * P, (volatile long long*)c->h_comm_flag, ++c->comm_seq);

@@ -351,7 +351,7 @@ struct msevb_ctx {
   bool spread_tiles = true;
   bool pme_weightless = true;       // tiled spread / gather recompute the B-spline weights from (uscale, nearpt) and the tables: no 288 B/atom weight store
   bool weights_needed_now = false;  // this call has another reader of d_w / d_dw (set by the MS-EVB call for its per-diabat-transform paths)
-  int attr_gather_wl = 0;           // dynamic LDS the weight-free gather has been allowed so far
+  int attr_gather_wl = 0, attr_gather_wl_b = 0;      // dynamic LDS the weight-free gather (plain / blending instantiation) has been allowed so far
   bool pme_side_weights = false; bool weights_side = false; hipEvent_t ev_weights = nullptr;      // MS-EVB fast path: stored weights computed on a side stream for the blend phase's gather (pme_side_weights)
   bool weights_valid = false;       // d_w / d_dw hold this step's weights (k_pme_prep ran, not k_pme_prep_light)
   int pme_tile_threads = 512;    // workgroup size of the LDS-tile spread / gather kernels (option pme_tile_threads: 256 or 512)
@@ -386,6 +386,7 @@ struct msevb_ctx {
   DBuf<double> d_Fdiag, d_Foff;     // [D][N][3]
   int evb_cap = 0;
   int rank = 0, n_ranks = 1;
+  int comm_timeout_ms = 30000, comm_stall_ms = 0;      // options: wall-clock limit of the host's wait for the per-step all-gather / one-shot artificial stall in front of it (test)
   void* nccl_comm = nullptr;
   // per-context scratch that used to be process-wide (two contexts on different GPUs / host threads must not share it)
   // principal-diabat switches since the log was last read: {EVB force call number (1-based, counted over the context's life), old hydronium, new hydronium}
@@ -407,6 +408,8 @@ struct msevb_ctx {
   bool evb_recip_linear = true;      // diabats' reciprocal space through the linear response of theta to the charge differences (evb.hip): no transform per diabat
   bool evb_speculate = true;         // MS-EVB step without a host wait for the neighbourhood record while the diabat tree stays the same (evb.hip, SpecPlan); 0 = enumerate every step
   long topo_epoch = 0;               // bumped by everything that can change what a recorded diabat tree means (topology upload, box, options)
+  bool evb_fuse_blend = true;        // MS-EVB fast path: the Hellmann-Feynman blend inside the gather of the blended potential (no k_evb_blend launch)
+  int evb_device_solve_method = 1;   // k_evb_solve: 1 = ground state by repeated squaring (<= 16 diabats; Jacobi decides when it does not converge), 0 = round-robin Jacobi always
   bool evb_device_solve = true;      // single rank, no element stores: H' assembly + round-robin Jacobi + blend coefficients in a kernel on the main stream, the blend phase behind it (no host turn on the critical path); 0 = host Jacobi
   bool nvt = false; double friction = 0.1 /* 1/ps, the reference's default */, temperature = 300.0; unsigned long long langevin_seed = 0, langevin_tick = 0;
 };
@@ -468,11 +471,22 @@ int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part
 int pme_prepare_atoms(msevb_ctx* c, bool with_indices);
 bool pme_weightless_now(const msevb_ctx* c);
 bool pme_tiles_ok(const msevb_ctx* c);
+bool pme_gather_can_blend(const msevb_ctx* c);      // the next pme_gather call will be the weight-free tiled kernel (which can apply a GatherBlend)
 int pme_side_weights(msevb_ctx* c, hipStream_t st, hipEvent_t after);
 bool fft_lds_usable(const msevb_ctx* c);                              // fft_lds.hip
 int fft_lds_setup(msevb_ctx* c);
 int fft_lds_solve(msevb_ctx* c, const double* Q, double2* work, double* theta, double* part, int* nblocks, hipStream_t st);
-int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic = false, const double* theta = nullptr);
+// the Hellmann-Feynman blend as the weight-free tiled gather applies it per atom (pme.hip: k_pme_gather_tiles_wl<true>; evb.hip: k_evb_blend is the stand-alone kernel)
+struct GatherBlend {
+  int n, N;                                  // terms; atoms (pitch of Fs)
+  int slot[2 * MAX_DIABATS];                 // >= 0: slot of the delta store (consumed: re-zeroed), < 0: off-diagonal store -slot - 1
+  double coef[2 * MAX_DIABATS];              // coefficients as kernel arguments ...
+  const double* dc;                          // ... or in device memory (k_evb_solve); nullptr: coef
+  double w11;                                // weight of F11 (+ the pair loop's accumulator) already in F
+  double* Fdiag; const double* Foff; size_t fstride;
+  double* Fs;                                // pair loop's sorted-order accumulator [3][N], consumed; nullptr: already folded
+};
+int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic = false, const double* theta = nullptr, const GatherBlend* blend = nullptr, bool* blended = nullptr);
 
 constexpr int MAX_BLOCKS = 65536;
 enum Slot { S_ELEC_PAIR = 0, S_VDW_PAIR, S_ELEC_INTRA, S_VDW_INTRA, S_BOND, S_ANGLE, S_DIH, S_RECIP, S_KE, S_PX, S_PY, S_PZ, S_VX, S_VY, S_VZ /* sum of velocities: KE after the momentum removal */, S_MAXD1, S_MAXD2, S_PRD1, S_PRD2 /* two largest displacements since the pair list was last pruned */, S_EVB0,

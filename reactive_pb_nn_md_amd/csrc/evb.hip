@@ -921,7 +921,7 @@ struct SolveDesc {
 // behind the pair loop and must not start reading E before that one is done; no cross-stream event hop (~10 us each)
 __global__ __launch_bounds__(256) void k_evb_solve(const SolveDesc* __restrict__ sd, const int* __restrict__ unit_idx, const double* __restrict__ unit_sign,
                                                    const double* __restrict__ E, const double* __restrict__ e_recip1, double* __restrict__ dcoef, double* __restrict__ out_host,
-                                                   const long long* wait_mark, long long wait_seq, volatile long long* done_flag, long long done_seq, double* fault) {
+                                                   const long long* wait_mark, long long wait_seq, volatile long long* done_flag, long long done_seq, double* fault, int method) {
 #pragma clang fp contract(off)
   extern __shared__ double sh[];      // A[n*n], V[n*n], cplA[n], per pair of a round: c, s, d_p - t a_pq, d_q + t a_pq (n/2 each) and p, q (ints)
   const int n = sd->D, tid = threadIdx.x, nth = blockDim.x;
@@ -960,7 +960,63 @@ __global__ __launch_bounds__(256) void k_evb_solve(const SolveDesc* __restrict__
   __syncthreads();
   for (int k = tid; k < n * n; k += nth) out_host[2 + 2 * n + k] = (k / n <= k % n) ? A[k] : 0.0;      // H' as the host assembles it (upper triangle)
   int status = -1;
-  for (int it = 1; it <= 50; ++it) {
+  int gfast = -1; double efast = 0.0;
+  // ---- ground state by REPEATED SQUARING (n <= 16): P = sigma I - H' (sigma = Gershgorin's upper bound: P is positive semi-definite, its top
+  // eigenvector the ground state of H'), P <- P^2 / tr(P^2) converges to the projector v v^T like rho^(2^k), rho = second / top eigenvalue of P -
+  // a dozen 8 x 8 products where the Jacobi sweeps below are ~40 dependent rounds of divisions and square roots (35 us on the main stream behind the
+  // pair loop, measured; this: ~3 us).  Accepted only when the residual |H' v - e v| says it converged (a near-degenerate ground state does
+  // not within 48 squarings: the Jacobi below then decides, as the reference's would); v agrees with Jacobi's vector to rounding / gap.
+  if (n <= 16 && n > 1 && method == 1) {
+    double* Pm = V; double* Tm = rdq + hp + 2 * hp;      // (V is rebuilt below if Jacobi has to run; Tm: n*n doubles behind the round tables)
+    __shared__ double s_sig, s_tr; __shared__ int s_done;
+    if (tid == 0) {
+      double sg = -1e300;
+      for (int i = 0; i < n; ++i) { double r = A[i * n + i]; for (int j = 0; j < n; ++j) if (j != i) r += fabs(A[i * n + j]); sg = fmax(sg, r); }
+      double tr = 0.0; for (int i = 0; i < n; ++i) tr += sg - A[i * n + i];
+      s_sig = sg; s_tr = tr; s_done = 0;
+    }
+    __syncthreads();
+    const double sg = s_sig, tr0 = s_tr;
+    if (tr0 > 0.0) {
+      for (int k = tid; k < n * n; k += nth) Pm[k] = ((k / n == k % n ? sg : 0.0) - A[k]) / tr0;
+      __syncthreads();
+      int extra = 0;
+      for (int it = 0; it < 48; ++it) {
+        for (int k = tid; k < n * n; k += nth) { const int i = k / n, j = k % n; double t = 0.0; for (int l = 0; l < n; ++l) t += Pm[i * n + l] * Pm[l * n + j]; Tm[k] = t; }
+        __syncthreads();
+        if (tid == 0) { double tr = 0.0; for (int i = 0; i < n; ++i) tr += Tm[i * n + i]; s_tr = tr; if (1.0 - tr < 1e-15) s_done = 1; }      // tr(P^2) -> 1 for a projector of trace 1
+        __syncthreads();
+        const double tr = s_tr;
+        for (int k = tid; k < n * n; k += nth) Pm[k] = Tm[k] / tr;
+        __syncthreads();
+        if (s_done && ++extra == 2) break;
+      }
+      if (s_done) {      // v = the column of the projector with the largest diagonal element, normalised; e = v^T H' v; residual test
+        int jm = 0; for (int j = 1; j < n; ++j) if (Pm[j * n + j] > Pm[jm * n + jm]) jm = j;
+        double nrm = 0.0; for (int i = 0; i < n; ++i) nrm += Pm[i * n + jm] * Pm[i * n + jm];
+        nrm = 1.0 / sqrt(nrm);
+        __syncthreads();
+        for (int i = tid; i < n; i += nth) Tm[i] = Pm[i * n + jm] * nrm;      // v
+        __syncthreads();
+        for (int i = tid; i < n; i += nth) { double t = 0.0; for (int j = 0; j < n; ++j) t += A[i * n + j] * Tm[j]; Tm[n + i] = t; }      // H' v
+        __syncthreads();
+        double e = 0.0, amax = 0.0, res = 0.0;
+        for (int i = 0; i < n; ++i) e += Tm[i] * Tm[n + i];
+        for (int k = 0; k < n * n; ++k) amax = fmax(amax, fabs(A[k]));
+        for (int i = 0; i < n; ++i) res = fmax(res, fabs(Tm[n + i] - e * Tm[i]));
+        if (res <= 1e-13 * fmax(amax, 1e-300)) { gfast = 0; efast = e; status = 0; }
+      }
+    }
+    __syncthreads();
+    if (gfast == 0) {      // hand the vector over in column 0 of V (what the epilogue reads), and stop here
+      for (int i = tid; i < n; i += nth) V[i * n] = Tm[i];
+      __syncthreads();
+    } else {
+      for (int k = tid; k < n * n; k += nth) V[k] = (k / n == k % n) ? 1.0 : 0.0;
+      __syncthreads();
+    }
+  }
+  for (int it = 1; it <= 50 && gfast < 0; ++it) {
     if (tid == 0) s_nonzero = 0;
     __syncthreads();
     { int nz = 0; for (int k = tid; k < n * n; k += nth) if (k / n < k % n && A[k] != 0.0) nz = 1; if (nz) s_nonzero = 1; }
@@ -1016,7 +1072,8 @@ __global__ __launch_bounds__(256) void k_evb_solve(const SolveDesc* __restrict__
   }
   // ground state, blend coefficients
   int gidx = 0; double eg = A[0];
-  for (int i = 1; i < n; ++i) if (A[i * n + i] < eg) { eg = A[i * n + i]; gidx = i; }
+  if (gfast == 0) eg = efast;
+  else for (int i = 1; i < n; ++i) if (A[i * n + i] < eg) { eg = A[i * n + i]; gidx = i; }
   if (tid == 0) { out_host[0] = (double)status; out_host[1] = eg; dcoef[0] = V[gidx] * V[gidx]; }
   for (int k = tid; k < n; k += nth) { out_host[2 + k] = V[k * n + gidx]; out_host[2 + n + k] = cA[k]; }
   for (int d = 1 + tid; d < n; d += nth) if (sd->grid_of[d] >= 0) { const double ev = V[d * n + gidx]; dcoef[1 + sd->grid_of[d]] = ev * ev; }
@@ -1589,6 +1646,21 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   GridCoefs gc; gc.n = ngrid; gc.c0 = 0.0;
   if (ev) { gc.c0 = c->rank == 0 ? ev[0] * ev[0] : 0.0; for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gc.c[grid_of[d]] = ev[d] * ev[d]; }
   const bool one_wait = c->overlap && w->side_valid;      // every side chain of this force call behind ONE event
+  // the blend itself rides in the gather of the blended potential when that is the weight-free tiled kernel (pme.hip, k_pme_gather_tiles_wl<true>)
+  const bool fuse = c->evb_fuse_blend && pme_gather_can_blend(c) && (w->last_linear ? (ngrid > 0 || c->rank == 0) : true);
+  GatherBlend gb; bool blended = false;
+  if (fuse) {
+    gb.n = bt.n; gb.N = c->N;
+    for (int t = 0; t < bt.n; ++t) { gb.slot[t] = bt.slot[t]; gb.coef[t] = bt.coef[t]; }
+    gb.dc = dcoef ? dcoef + 1 + ngrid : (const double*)nullptr; gb.w11 = w11;
+    gb.Fdiag = w->d_Fdelta.p; gb.Foff = c->d_Foff.p; gb.fstride = n3; gb.Fs = c->fsorted_pending ? c->d_fsorted.p : (double*)nullptr;
+  }
+  auto join_before_blend = [&]() -> int {      // everything else that adds to the force array has to be in before the kernel that blends (k_evb_blend, or the fused gather)
+    if (c->overlap && !one_wait) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0)); if (ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_rs, 0)); }
+    if (c->overlap && !one_wait && w->mol_deferred) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // the principal diabat's per-molecule forces (aux3, behind the coupling chain)
+    if (one_wait && w->side_wo_mol) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // ... which the ONE event left out: patch, solve and gather of the blend phase run beside that kernel
+    return MSEVB_OK;
+  };
   if (one_wait && !w->side_by_A && !w->side_by_mark) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0));      // (side_by_A: whoever enqueues this phase has seen fetch A, or has put k_evb_wait_coef in front of it)
   else if (c->overlap && ngrid && !one_wait) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // convolved diabat grids / grid energies (aux)
   stamp(c, 8, c->stream);
@@ -1597,7 +1669,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
     // blended CHARGE grid Q_1 (rank 0) + sum_d c_d^2 DQ_d -> one transform pair -> blended potential theta_1 + sum_d c_d^2 G * DQ_d
     // (sum_d c_d^2 = 1 over all ranks, so the principal potential enters once, on rank 0)
     if (!ngrid) {
-      if (c->rank == 0) CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, c->d_theta.p));
+      if (c->rank == 0) { if (fuse) CHK(join_before_blend()); CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, c->d_theta.p, fuse ? &gb : nullptr, &blended)); }
     } else {
       if (w->d_grids.alloc_room(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended charge grid)");
       if (fft_lds_usable(c)) {      // real grid in, real potential out, in place in d_pack (d_grids is the transform's complex work space)
@@ -1620,20 +1692,22 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
         CHK(rc_conv);
         hipLaunchKernelGGL(k_grid_real, dim3(1024), dim3(256), 0, c->stream, K3, w->d_grids.p, w->d_pack.p);
       }
-      CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p));
+      if (fuse) CHK(join_before_blend());
+      CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p, fuse ? &gb : nullptr, &blended));
     }
   } else {
     hipLaunchKernelGGL(k_evb_blend_grids, dim3(1024), dim3(256), 0, c->stream, K3, gc, dcoef, c->d_theta.p, w->d_grids.p, w->d_pack.p);
-    CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p));
+    if (fuse) CHK(join_before_blend());
+    CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p, fuse ? &gb : nullptr, &blended));
   }
   // ... the special atoms' own-stencil corrections per diabat are in the delta store already (k_evb_recip_special ran at the end of the
   // diabat grid chain, before the host's turn); the blend consumes the store and re-zeroes it
-  if (c->overlap && !one_wait) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0)); if (ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_rs, 0)); }
-  if (c->overlap && !one_wait && w->mol_deferred) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // the principal diabat's per-molecule forces (aux3, behind the coupling chain)
-  if (one_wait && w->side_wo_mol) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // ... which the ONE event left out: patch, solve and gather of the blend phase run beside that kernel
   (void)nra; (void)d_ra;
+  if (!blended) {
+  if (!fuse) CHK(join_before_blend());
   hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, dcoef ? dcoef + 1 + ngrid : (const double*)nullptr, w11, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p, 1,
                      c->fsorted_pending ? c->d_fsorted.p : (double*)nullptr, c->d_inv_perm.p, c->N);
+  }
   c->fsorted_pending = false;
   stamp(c, 9, c->stream);
   HIPCHK(hipGetLastError());
@@ -2257,13 +2331,13 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     }
     if (w->d_coef.alloc(1 + MAX_DIABATS + 2 * MAX_DIABATS)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blend coefficients)");
     const int hp = (D + 1) / 2;
-    const size_t lds = ((size_t)2 * D * D + D + 4 * hp) * 8 + 2 * hp * 4 + 16;
-    if (!c->attr_evb_solve) { const int Dm = MAX_DIABATS, hm = Dm / 2; HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * Dm * Dm + Dm + 4 * hm) * 8 + 2 * hm * 4 + 16)); c->attr_evb_solve = true; }
+    const size_t lds = ((size_t)2 * D * D + D + 6 * hp + (D <= 16 ? D * D + 2 * D : 0)) * 8 + 16;      // A, V, cplA, round tables (4 hp doubles + 2 hp ints), squaring scratch
+    if (!c->attr_evb_solve) { const int Dm = MAX_DIABATS, hm = Dm / 2; HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * Dm * Dm + Dm + 6 * hm + 16 * 16 + 32) * 8 + 16)); c->attr_evb_solve = true; }
     if (c->overlap && !pub_spin) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_fetchA, 0));      // (without the marks: one event hop)
     phase_begin(c, PH_EVB_BLEND);
     hipLaunchKernelGGL(k_evb_solve, dim3(1), dim3(D <= 16 ? 64 : 256), lds, c->stream, (const SolveDesc*)(w->d_desc.p + off_s), (const int*)(w->d_desc.p + off_si),
                        (const double*)(w->d_desc.p + off_ss), w->d_E.p, linear ? w->d_Elq.p + 2 * MAX_DIABATS /* zero: the grid energies are differences already */ : c->d_energies.p + S_RECIP, w->d_coef.p, w->h_solve,
-                       pub_spin ? (const long long*)(w->d_chain_done.p + 2) : (const long long*)nullptr, w->seq_A, (volatile long long*)(w->h_flag + 6), ++w->seq_S, c->d_energies.p + S_FAULT);
+                       pub_spin ? (const long long*)(w->d_chain_done.p + 2) : (const long long*)nullptr, w->seq_A, (volatile long long*)(w->h_flag + 6), ++w->seq_S, c->d_energies.p + S_FAULT, c->evb_device_solve_method);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(w->ev_solve, c->stream));
     w->side_by_mark = pub_spin;      // the mark this kernel waited for follows every side chain (and the Q_1 copy) of this call: no event waits in the phase

@@ -1026,6 +1026,31 @@ def test_rccl_communicator_of_one_rank():
     assert np.abs(en1 - en0).max() < 1e-9 * np.abs(en0).max() and np.abs(x1 - x0).max() < 1e-10
 
 
+def test_comm_wait_gives_up_on_a_missing_peer():
+    """The host's wait for the per-step all-gather has a wall-clock limit (option comm_timeout_ms, default 30 s): a peer that died or never entered
+    the collective must end the force call with MSEVB_ERR_COMM, not hang every rank (round 3's loop spun on hipErrorNotReady for ever).
+    One rank, real communicator; the missing peer is played by a kernel that holds the collective's stream for 1.5 s (option comm_stall_ms,
+    one-shot) against a limit of 200 ms.  The stream drains by itself, and the context works again afterwards."""
+    import time
+    g = golden("evb_n6_d4_s2")
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    h.comm_init(api.MsEvbHip.comm_unique_id(h.L), 0, 1)
+    e0, F0 = h.ms_evb_calculate_total_force_energy()
+    h.set_option("comm_timeout_ms", 200)
+    h.set_option("comm_stall_ms", 1500)
+    t0 = time.time()
+    with pytest.raises(api.MsevbError) as ei:
+        h.ms_evb_calculate_total_force_energy()
+    dt = time.time() - t0
+    assert "peer rank is missing" in str(ei.value) and 0.15 < dt < 1.4, (str(ei.value), dt)
+    h.synchronize()
+    h.set_option("comm_timeout_ms", 30000)
+    e1, F1 = h.ms_evb_calculate_total_force_energy()
+    assert rel(e1, e0) < 1e-13 and np.abs(F1 - F0).max() < 1e-10
+    h.close()
+
+
 def _synthetic(n_side, n_diabat, seed, K, rc=9.0, rv=10.5):
     s = synth.make_system(n_side, n_diabat=n_diabat, seed=seed)
     p = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"])

@@ -6,7 +6,7 @@ switches on) runs the MS-EVB force call of BASELINE.json configs[2] (98 220 atom
 fixed ground-state vector - everything a rank does between the two collectives of a step, nothing of the collectives themselves (the
 all-gather carries 2S + 9 doubles, the all-reduce 24 B/atom = 2.4 MB).  Reported: the slowest rank's time over the one-rank time.
 
-    python tools/virtual_rank_times.py [calls] [B|C]      (C = configs[4]'s size: 985 527 atoms, 16 diabats, 128^3)
+    python tools/virtual_rank_times.py [calls] [B|C] [R,R,...]      (C = configs[4]'s size: 985 527 atoms, 16 diabats, 128^3; default ranks 1,2,4,8)
 """
 import json
 import os
@@ -53,12 +53,12 @@ def main():
     h.close()
     out = {}
     t1 = None
-    for R in (1, 2, 4, 8):
+    for R in ([int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else (1, 2, 4, 8)):
         ts = []
         for r in range(R):
             dt, D = rank_time(spec, r, R, ev, calls)
             ts.append(dt * 1e6)
-        if R == 1:
+        if t1 is None:
             t1 = ts[0]
         out[R] = {"us_per_rank": [round(t, 1) for t in ts], "slowest_over_one_rank": round(max(ts) / t1, 3), "n_diabats": int(D)}
         print("R=%d  slowest %.1f us  (x%.3f of one rank)  per rank: %s" % (R, max(ts), max(ts) / t1, " ".join("%.0f" % t for t in ts)), flush=True)

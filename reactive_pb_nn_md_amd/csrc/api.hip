@@ -699,7 +699,20 @@ int total_force_collect(msevb_ctx* c, double* en) {
   const double* h = c->h_energies;
   // the index arithmetic of the reference (and ours) covers atoms at most one box image away; a blown-up trajectory is reported, not run
   if (h[S_FAULT] == 2.0) FAIL(MSEVB_ERR_NUMERIC, "the energy-fetch kernel gave up waiting for the side chains of the MS-EVB call (2 s): a kernel of those chains never finished");
-  if (h[S_FAULT] != 0.0) FAIL(MSEVB_ERR_NUMERIC, "atom coordinates are not finite or more than one box length outside the cell (unstable trajectory?)");
+  if (h[S_FAULT] == 5.0) FAIL(MSEVB_ERR_NUMERIC, "the blend phase gave up waiting for the host's coefficients (5 s)");
+  if (h[S_FAULT] != 0.0) {      // code + 16 x (atom + 1) of the LAST kernel that met such a coordinate (k_pme_prep: 1; special atoms of the MS-EVB call: 3 / 4)
+    const long v = (long)h[S_FAULT]; const int code = (int)(v % 16); const long atom = v / 16 - 1;
+    char b[512]; double xv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (atom >= 0 && atom < c->N) {      // its position, velocity and force as they are now (diagnostic; synchronous copies on an error path)
+      (void)hipDeviceSynchronize();
+      (void)hipMemcpy(xv, c->d_xyz.p + 3 * atom, 24, hipMemcpyDeviceToHost);
+      if (c->d_vel.p) (void)hipMemcpy(xv + 3, c->d_vel.p + 3 * atom, 24, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(xv + 6, c->d_force.p + 3 * atom, 24, hipMemcpyDeviceToHost);
+    }
+    snprintf(b, sizeof b, "atom coordinates are not finite or more than one box length outside the cell (unstable trajectory?): atom %ld (0-based; kernel code %d) x = %.6g %.6g %.6g  v = %.6g %.6g %.6g  F = %.6g %.6g %.6g, EVB force call %ld",
+             atom, code, xv[0], xv[1], xv[2], xv[3], xv[4], xv[5], xv[6], xv[7], xv[8], c->evb_calls);
+    FAIL(MSEVB_ERR_NUMERIC, b);
+  }
   if (c->list_valid) {   // flag for the NEXT call (src/general_routines.f90:1320-1326)
     const double skin = 1.2 * (c->rv - c->rc);
     if ((h[S_MAXD1] + h[S_MAXD2]) > skin) c->flag_verlet_list = 1;

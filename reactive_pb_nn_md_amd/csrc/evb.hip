@@ -361,7 +361,7 @@ __global__ void k_evb_spec_prep(int n, const RecipAtom* __restrict__ ra, int K, 
   const double ka = l == 0 ? k00 : l == 1 ? k10 : k20, kb = l == 0 ? k01 : l == 1 ? k11 : k21, kc = l == 0 ? k02 : l == 1 ? k12 : k22;
   double u = (double)K * ((ka * x + kb * y) + kc * z);
   if (u < 0.0) u = u + (double)K; else if (u >= (double)K) u = u - (double)K;
-  if (!(u >= 0.0 && u < (double)K)) { *fault = 1.0; u = 0.5; }      // see k_pme_prep
+  if (!(u >= 0.0 && u < (double)K)) { *fault = 16.0 * (double)(ra[e].idx + 1) + (old_state ? 3.0 : 4.0); u = 0.5; }      // see k_pme_prep (codes 3 / 4: a special atom in its principal / diabat state)
   if (fabs(fmod(u, 1.0)) < 1e-6) u = u + 1e-6;
   const int np = (int)floor(u);
   int* ob = old_state ? obase : sbase; double* w_ = old_state ? ow : sw; double* dw_ = old_state ? odw : sdw;
@@ -1343,7 +1343,7 @@ __global__ void k_evb_wait_coef(const double* h_coef, volatile long long* flag, 
     for (;;) {
       const long long f = __hip_atomic_load((const long long*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (fine-grained host memory: see the allocation)
       if (f == seq || f == -seq) break;
-      if (wall_clock64() - t0 > 500000000LL) { *fault = 1.0; break; }
+      if (wall_clock64() - t0 > 500000000LL) { *fault = 5.0; break; }
       __builtin_amdgcn_s_sleep(4);
     }
   }

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_pme_prep(int N, int K, int G, const dou
   const double ka = l == 0 ? k00 : l == 1 ? k10 : k20, kb = l == 0 ? k01 : l == 1 ? k11 : k21, kc = l == 0 ? k02 : l == 1 ? k12 : k22;
   double u = (double)K * ((ka * x + kb * y) + kc * z);
   if (u < 0.0) u = u + (double)K; else if (u >= (double)K) u = u - (double)K;
-  if (!(u >= 0.0 && u < (double)K)) { *fault = 1.0; u = 0.5; }      // more than one box away, or not a number: flag it, stay inside the grid
+  if (!(u >= 0.0 && u < (double)K)) { *fault = 16.0 * (double)(i + 1) + 1.0; u = 0.5; }      // more than one box away, or not a number: flag it (code 1 + 16 x (atom + 1): total_force_collect names the atom), stay inside the grid
   if (fabs(fmod(u, 1.0)) < 1e-6) u = u + 1e-6;
   const int np = (int)floor(u);
   if (k == 0 && uscale) { uscale[3 * i + l] = u; base[3 * i + l] = np; }      // (uscale == nullptr: weights only, beside k_pme_prep_light - pme_side_weights)
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_pme_prep_light(int N, int K, const doub
   const double ka = l == 0 ? k00 : l == 1 ? k10 : k20, kb = l == 0 ? k01 : l == 1 ? k11 : k21, kc = l == 0 ? k02 : l == 1 ? k12 : k22;
   double u = (double)K * ((ka * x + kb * y) + kc * z);
   if (u < 0.0) u = u + (double)K; else if (u >= (double)K) u = u - (double)K;
-  if (!(u >= 0.0 && u < (double)K)) { *fault = 1.0; u = 0.5; }
+  if (!(u >= 0.0 && u < (double)K)) { *fault = 16.0 * (double)(i + 1) + 1.0; u = 0.5; }
   if (fabs(fmod(u, 1.0)) < 1e-6) u = u + 1e-6;
   const int np = (int)floor(u);
   uscale[t] = u; base[t] = np;
@@ -738,6 +738,15 @@ __global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, 
     const bool live = ia < e;
     const int i = ni, b1 = nb1, b2 = nb2, b3 = nb3;
     const double q = nq;
+    double bx = 0.0, by = 0.0, bz = 0.0;
+    if (BLEND && live) {      // this atom's share of the blend terms, lane `sub` takes terms sub, sub + 8, ...: the loads go out HERE, at the top of the trip, and meet
+      for (int t = sub; t < gb.n; t += 8) {      // the reciprocal force at its end (at the end of the trip their latency was the trip's tail: +25 us on the kernel)
+        const int sl = gb.slot[t];
+        const double cf = gb.dc ? gb.dc[t] : gb.coef[t];
+        if (sl < 0) { const double* p = gb.Foff + (size_t)(-sl - 1) * gb.fstride + 3 * (size_t)i; bx += cf * p[0]; by += cf * p[1]; bz += cf * p[2]; }
+        else { double* p = gb.Fdiag + (size_t)sl * gb.fstride + 3 * (size_t)i; bx += cf * p[0]; by += cf * p[1]; bz += cf * p[2]; p[0] = 0.0; p[1] = 0.0; p[2] = 0.0; }      // (the delta store is consumed)
+      }
+    }
     double tw[3], td[3];
     pme_taps3_finish(nt, tw, td);      // (first use of the table values that went out one trip ago)
     const double w3 = tw[2], d3 = td[2];
@@ -793,15 +802,6 @@ __global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();      // (the next trip's taps overwrite xw)
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); f3 += __shfl_xor(f3, o, 64); }
-    double bx = 0.0, by = 0.0, bz = 0.0;
-    if (BLEND && live) {      // this atom's share of the blend terms: lane `sub` takes terms sub, sub + 8, ...
-      for (int t = sub; t < gb.n; t += 8) {
-        const int sl = gb.slot[t];
-        const double cf = gb.dc ? gb.dc[t] : gb.coef[t];
-        if (sl < 0) { const double* p = gb.Foff + (size_t)(-sl - 1) * gb.fstride + 3 * (size_t)i; bx += cf * p[0]; by += cf * p[1]; bz += cf * p[2]; }
-        else { double* p = gb.Fdiag + (size_t)sl * gb.fstride + 3 * (size_t)i; bx += cf * p[0]; by += cf * p[1]; bz += cf * p[2]; p[0] = 0.0; p[1] = 0.0; p[2] = 0.0; }      // (the delta store is consumed)
-      }
-    }
     if (BLEND) {
 #pragma unroll
       for (int o = 4; o > 0; o >>= 1) { bx += __shfl_xor(bx, o, 64); by += __shfl_xor(by, o, 64); bz += __shfl_xor(bz, o, 64); }

@@ -211,25 +211,34 @@ def test_pme_without_the_weight_store_changes_nothing():
     assert rel(a[7], b[7]) < 1e-14 and np.abs(a[8] - b[8]).max() < 1e-11
 
 
-@pytest.mark.parametrize("opts", [{"evb_defer_fold": 0}, {"evb_prelaunch_blend": 1}, {"evb_defer_molecules": 1}, {"evb_region_main": 1},
-                                  {"evb_coupling_blocks": 96}, {"evb_recip_linear": 0}, {"fft_own": 0, "evb_defer_fold": 0, "evb_prelaunch_blend": 1},
-                                  {"overlap": 0, "graphs": 0}])
+_SCHED_DEFAULT = {}
+
+
+def _schedule_run(spec, opts):
+    h = api.MsEvbHip(spec)
+    for k, v in opts.items():
+        h.set_option(k, v)
+    e, F = h.ms_evb_calculate_total_force_energy()
+    H = h.evb_state()["H"].copy()
+    h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 7))
+    tr = h.md_integrate_atomic(12, spec.delta_t, use_evb=True)
+    out = (e, F, H, tr, h.get_positions())
+    h.close()
+    return out
+
+
+@pytest.mark.parametrize("opts", [{"evb_defer_fold": 0}, {"evb_prelaunch_blend": 1, "evb_device_solve": 0}, {"evb_defer_molecules": 1}, {"evb_region_main": 1},
+                                  {"evb_coupling_blocks": 96}, {"evb_recip_linear": 0}, {"fft_own": 0, "evb_defer_fold": 0, "evb_prelaunch_blend": 1, "evb_device_solve": 0},
+                                  {"overlap": 0, "graphs": 0}, {"evb_device_solve": 0}, {"evb_device_solve": 2}, {"evb_fuse_blend": 0}, {"pair_pipe": 0},
+                                  {"evb_device_solve": 0, "evb_fuse_blend": 0}])
 def test_schedule_options_leave_the_forces_alone(opts):
     """the switchable pieces of the step schedule at BASELINE.json configs[2]: same Hamiltonian, same Hellmann-Feynman
-    force, same 12-step trajectory as the default schedule"""
+    force, same 12-step trajectory as the default schedule (device-side solve by repeated squaring, blend inside the gather); among them the
+    host's Jacobi (evb_device_solve = 0, the reference's row-cyclic sweep) and the device's round-robin Jacobi (= 2)"""
     spec = _synthetic(32, 8, 11, 64)
-    res = []
-    for o in ({}, opts):
-        h = api.MsEvbHip(spec)
-        for k, v in o.items():
-            h.set_option(k, v)
-        e, F = h.ms_evb_calculate_total_force_energy()
-        H = h.evb_state()["H"].copy()
-        h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 7))
-        tr = h.md_integrate_atomic(12, spec.delta_t, use_evb=True)
-        res.append((e, F, H, tr, h.get_positions()))
-        h.close()
-    a, b = res
+    if "default" not in _SCHED_DEFAULT:
+        _SCHED_DEFAULT["default"] = _schedule_run(spec, {})
+    a, b = _SCHED_DEFAULT["default"], _schedule_run(spec, opts)
     assert rel(b[0], a[0]) < 1e-13 and np.abs(b[1] - a[1]).max() < 1e-9 and np.abs(b[2] - a[2]).max() < 1e-9 * np.abs(a[2]).max()
     assert np.abs(b[3] - a[3]).max() < 1e-8 * np.abs(a[3]).max() and np.abs(b[4] - a[4]).max() < 1e-8
 

@@ -408,7 +408,7 @@ struct msevb_ctx {
   bool evb_recip_linear = true;      // diabats' reciprocal space through the linear response of theta to the charge differences (evb.hip): no transform per diabat
   bool evb_speculate = true;         // MS-EVB step without a host wait for the neighbourhood record while the diabat tree stays the same (evb.hip, SpecPlan); 0 = enumerate every step
   long topo_epoch = 0;               // bumped by everything that can change what a recorded diabat tree means (topology upload, box, options)
-  bool evb_fuse_blend = true;        // MS-EVB fast path: the Hellmann-Feynman blend inside the gather of the blended potential (no k_evb_blend launch)
+  bool evb_fuse_blend = false;       // option (measured, off): the Hellmann-Feynman blend inside the gather of the blended potential - 68 us against 40 + 15: the stores it reads are in atom order, the gather walks the atoms in cell order (scattered 24-byte reads where k_evb_blend streams)
   int evb_device_solve_method = 1;   // k_evb_solve: 1 = ground state by repeated squaring (<= 16 diabats; Jacobi decides when it does not converge), 0 = round-robin Jacobi always
   bool evb_device_solve = true;      // single rank, no element stores: H' assembly + round-robin Jacobi + blend coefficients in a kernel on the main stream, the blend phase behind it (no host turn on the critical path); 0 = host Jacobi
   bool nvt = false; double friction = 0.1 /* 1/ps, the reference's default */, temperature = 300.0; unsigned long long langevin_seed = 0, langevin_tick = 0;

@@ -944,11 +944,16 @@ __global__ __launch_bounds__(256) void k_evb_solve(const SolveDesc* __restrict__
   for (int k = tid; k < n; k += nth) cA[k] = 0.0;
   __syncthreads();
   const double Er1 = *e_recip1;
+  // the units' energies (two dependent global loads each) are fetched by all lanes at once and summed per diabat in their fixed order afterwards
+  double* contrib = rdq + hp + 2 * hp;      // scratch behind the round tables: [unit references] now, the squaring's product later
+  const int nref = sd->unit_off[n];
+  for (int q = tid; q < nref; q += nth) { const int iu = unit_idx[q]; contrib[q] = unit_sign[q] * (E[iu] + E[nu + iu]); }
+  __syncthreads();
   for (int d = tid; d < n; d += nth) {
     if (d == 0) { const int iu = sd->unit00; A[0] = sd->Hp_norep + sd->once * (E[iu] + E[nu + iu]); }
     else {
       double e = sd->e_hyd + sd->eref_delta[d];
-      for (int q = sd->unit_off[d]; q < sd->unit_off[d + 1]; ++q) { const int iu = unit_idx[q]; e += unit_sign[q] * (E[iu] + E[nu + iu]); }
+      for (int q = sd->unit_off[d]; q < sd->unit_off[d + 1]; ++q) e += contrib[q];
       e += E[2 * nu + ncp + sd->grid_of[d]] - Er1;
       A[d * n + d] = e;
       const double hpd = E[2 * nu + ncp + ngrid + 3 * sd->cp_of[d] + 2];
@@ -968,30 +973,35 @@ __global__ __launch_bounds__(256) void k_evb_solve(const SolveDesc* __restrict__
   // not within 48 squarings: the Jacobi below then decides, as the reference's would); v agrees with Jacobi's vector to rounding / gap.
   if (n <= 16 && n > 1 && method == 1) {
     double* Pm = V; double* Tm = rdq + hp + 2 * hp;      // (V is rebuilt below if Jacobi has to run; Tm: n*n doubles behind the round tables)
-    __shared__ double s_sig, s_tr; __shared__ int s_done;
+    __shared__ double s_sig, s_tr, s_row[16], s_nrm;
+    __syncthreads();      // (contrib, which Tm overlays, has been consumed)
+    if (tid < n) { double r = 0.0; for (int j = 0; j < n; ++j) r += j == tid ? A[tid * n + j] : fabs(A[tid * n + j]); s_row[tid] = r; }      // Gershgorin: a_ii + sum_{j != i} |a_ij|
+    __syncthreads();
     if (tid == 0) {
-      double sg = -1e300;
-      for (int i = 0; i < n; ++i) { double r = A[i * n + i]; for (int j = 0; j < n; ++j) if (j != i) r += fabs(A[i * n + j]); sg = fmax(sg, r); }
+      double sg = -1e300, an = 0.0;
+      for (int i = 0; i < n; ++i) { sg = fmax(sg, s_row[i]); an = fmax(an, fabs(s_row[i])); }
       double tr = 0.0; for (int i = 0; i < n; ++i) tr += sg - A[i * n + i];
-      s_sig = sg; s_tr = tr; s_done = 0;
+      s_sig = sg; s_tr = tr; s_nrm = an;      // an: a scale of H' for the residual test
     }
     __syncthreads();
     const double sg = s_sig, tr0 = s_tr;
     if (tr0 > 0.0) {
-      for (int k = tid; k < n * n; k += nth) Pm[k] = ((k / n == k % n ? sg : 0.0) - A[k]) / tr0;
+      { const double inv = 1.0 / tr0; for (int k = tid; k < n * n; k += nth) Pm[k] = ((k / n == k % n ? sg : 0.0) - A[k]) * inv; }
       __syncthreads();
       int extra = 0;
       for (int it = 0; it < 48; ++it) {
         for (int k = tid; k < n * n; k += nth) { const int i = k / n, j = k % n; double t = 0.0; for (int l = 0; l < n; ++l) t += Pm[i * n + l] * Pm[l * n + j]; Tm[k] = t; }
         __syncthreads();
-        if (tid == 0) { double tr = 0.0; for (int i = 0; i < n; ++i) tr += Tm[i * n + i]; s_tr = tr; if (1.0 - tr < 1e-15) s_done = 1; }      // tr(P^2) -> 1 for a projector of trace 1
+        double tr = 0.0; for (int i = 0; i < n; ++i) tr += Tm[i * n + i];      // every lane the same sum: tr(P^2) -> 1 for a projector of trace 1
+        const bool done = 1.0 - tr < 1e-15;
+        const double inv = 1.0 / tr;
         __syncthreads();
-        const double tr = s_tr;
-        for (int k = tid; k < n * n; k += nth) Pm[k] = Tm[k] / tr;
+        for (int k = tid; k < n * n; k += nth) Pm[k] = Tm[k] * inv;
         __syncthreads();
-        if (s_done && ++extra == 2) break;
+        if (done && ++extra == 2) break;
+        if (!done) extra = 0;
       }
-      if (s_done) {      // v = the column of the projector with the largest diagonal element, normalised; e = v^T H' v; residual test
+      if (extra == 2) {      // v = the column of the projector with the largest diagonal element, normalised; e = v^T H' v; residual test
         int jm = 0; for (int j = 1; j < n; ++j) if (Pm[j * n + j] > Pm[jm * n + jm]) jm = j;
         double nrm = 0.0; for (int i = 0; i < n; ++i) nrm += Pm[i * n + jm] * Pm[i * n + jm];
         nrm = 1.0 / sqrt(nrm);
@@ -1000,11 +1010,10 @@ __global__ __launch_bounds__(256) void k_evb_solve(const SolveDesc* __restrict__
         __syncthreads();
         for (int i = tid; i < n; i += nth) { double t = 0.0; for (int j = 0; j < n; ++j) t += A[i * n + j] * Tm[j]; Tm[n + i] = t; }      // H' v
         __syncthreads();
-        double e = 0.0, amax = 0.0, res = 0.0;
+        double e = 0.0, res = 0.0;
         for (int i = 0; i < n; ++i) e += Tm[i] * Tm[n + i];
-        for (int k = 0; k < n * n; ++k) amax = fmax(amax, fabs(A[k]));
         for (int i = 0; i < n; ++i) res = fmax(res, fabs(Tm[n + i] - e * Tm[i]));
-        if (res <= 1e-13 * fmax(amax, 1e-300)) { gfast = 0; efast = e; status = 0; }
+        if (res <= 1e-13 * fmax(s_nrm, 1e-300)) { gfast = 0; efast = e; status = 0; }
       }
     }
     __syncthreads();
@@ -2331,8 +2340,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     }
     if (w->d_coef.alloc(1 + MAX_DIABATS + 2 * MAX_DIABATS)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blend coefficients)");
     const int hp = (D + 1) / 2;
-    const size_t lds = ((size_t)2 * D * D + D + 6 * hp + (D <= 16 ? D * D + 2 * D : 0)) * 8 + 16;      // A, V, cplA, round tables (4 hp doubles + 2 hp ints), squaring scratch
-    if (!c->attr_evb_solve) { const int Dm = MAX_DIABATS, hm = Dm / 2; HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * Dm * Dm + Dm + 6 * hm + 16 * 16 + 32) * 8 + 16)); c->attr_evb_solve = true; }
+    const size_t lds = ((size_t)2 * D * D + D + 6 * hp + std::max(D <= 16 ? D * D + 2 * D : 0, n_unit_refs)) * 8 + 16;      // A, V, cplA, round tables (4 hp doubles + 2 hp ints), squaring scratch
+    if (!c->attr_evb_solve) { const int Dm = MAX_DIABATS, hm = Dm / 2; HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * Dm * Dm + Dm + 6 * hm + std::max(16 * 16 + 32, MAX_UNITS)) * 8 + 16)); c->attr_evb_solve = true; }
     if (c->overlap && !pub_spin) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_fetchA, 0));      // (without the marks: one event hop)
     phase_begin(c, PH_EVB_BLEND);
     hipLaunchKernelGGL(k_evb_solve, dim3(1), dim3(D <= 16 ? 64 : 256), lds, c->stream, (const SolveDesc*)(w->d_desc.p + off_s), (const int*)(w->d_desc.p + off_si),

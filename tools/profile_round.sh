@@ -20,8 +20,10 @@ python3 $R/tools/summarize_prof.py $OUT > $OUT/serial_kernel_stats.txt 2>&1 || t
 python3 $R/tools/pair_modes.py $OUT > $OUT/pair_modes.txt 2>&1 || true      # pair kernel: launches that read their list / that rewrite it
 rm -rf $OUT/kt
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in their own passes (MI355X_MICROARCH.md: they do not fit one pass), default schedule
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o f -- $B --steps 10 --warmup 2 > $OUT/fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o w -- $B --steps 10 --warmup 2 > $OUT/write.log 2>&1
+# (with counters the profiler runs ONE kernel at a time, in the order they become ready: a kernel that waits on the device for a mark another queue's
+#  kernel sets would wait until its 2 s limit - evb_publish_spin=0 orders those kernels with events instead; same kernels, same bytes)
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o f -- $B --steps 10 --warmup 2 --opt evb_publish_spin=0 > $OUT/fetch.log 2>&1 || true
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o w -- $B --steps 10 --warmup 2 --opt evb_publish_spin=0 > $OUT/write.log 2>&1 || true
 python3 $R/tools/summarize_prof.py $OUT > $OUT/traffic_summary.txt 2>&1 || true
 python3 $R/tools/make_traffic_json.py $OUT $OUT/traffic.json > /dev/null 2>&1 || true
 rm -rf $OUT/fetch $OUT/write

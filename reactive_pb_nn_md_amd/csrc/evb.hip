@@ -856,7 +856,23 @@ __global__ __launch_bounds__(256) void k_evb_recip_pairs(GridRanges gr, const St
 
 // blended charge grid: grid += sum over the stencils of c_d^2 q S (the grid holds Q_1 on rank 0, zero on the others); coefficients as kernel
 // arguments, or from device memory behind k_evb_solve
-__global__ __launch_bounds__(256) void k_evb_blend_patch(int nst, const Stencil* __restrict__ st, GridCoefs gc, const double* __restrict__ dc, int K, double* __restrict__ grid, int gs) {
+// first kernel of a chain that starts on a mark of another stream (2 s limit, then the sticky fault flag, as k_evb_publish)
+__device__ __forceinline__ void evb_wait_mark(const long long* mark, long long seq, double* fault) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(mark, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+      if (wall_clock64() - t0 > 200000000LL) { if (fault) *fault = 2.0; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+}
+__global__ void k_evb_wait_mark(const long long* mark, long long seq, double* fault) { evb_wait_mark(mark, seq, fault); }
+// wait_mark: the coefficients in dc come from k_evb_solve on ANOTHER stream (the grid stream, right behind the energy fetch): this kernel, first of the
+// blend phase on the main stream, starts on that kernel's mark instead of behind a cross-stream event (~10 us) or behind the solve itself
+__global__ __launch_bounds__(256) void k_evb_blend_patch(int nst, const Stencil* __restrict__ st, GridCoefs gc, const double* __restrict__ dc, int K, double* __restrict__ grid, int gs,
+                                                         const long long* wait_mark = nullptr, long long wait_seq = 0, double* fault = nullptr) {
+  if (wait_mark) evb_wait_mark(wait_mark, wait_seq, fault);
   const int lane = threadIdx.x & 63;
   const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (e >= nst) return;
@@ -875,6 +891,9 @@ __global__ void k_grid_real(size_t K3, const double2* __restrict__ grid, double*
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K3; k += (size_t)gridDim.x * blockDim.x) out[k] = grid[k].x;
 }
 
+__global__ void k_copy_grid(size_t n, const double* __restrict__ src, double* __restrict__ dst) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) dst[k] = src[k];
+}
 struct BlendTerms { int n; int slot[2 * MAX_DIABATS]; double coef[2 * MAX_DIABATS]; };   // slot < 0: off-diagonal store, index -slot-1 (kernel argument, no upload)
 // The diagonal store holds differences to the principal force F11 (F_dd = F11 + store_d) and sum_d c_d^2 = 1, so
 // F = w11 F11 + sum_d c_d^2 store_d + 2 sum c_p c_d F_pd with w11 = 1 (w11 < 1 only for a rank's PARTIAL blend, see evb_partial terms);
@@ -921,7 +940,7 @@ struct SolveDesc {
 // behind the pair loop and must not start reading E before that one is done; no cross-stream event hop (~10 us each)
 __global__ __launch_bounds__(256) void k_evb_solve(const SolveDesc* __restrict__ sd, const int* __restrict__ unit_idx, const double* __restrict__ unit_sign,
                                                    const double* __restrict__ E, const double* __restrict__ e_recip1, double* __restrict__ dcoef, double* __restrict__ out_host,
-                                                   const long long* wait_mark, long long wait_seq, volatile long long* done_flag, long long done_seq, double* fault, int method) {
+                                                   const long long* wait_mark, long long wait_seq, volatile long long* done_flag, long long done_seq, double* fault, int method, long long* done_mark) {
 #pragma clang fp contract(off)
   extern __shared__ double sh[];      // A[n*n], V[n*n], cplA[n], per pair of a round: c, s, d_p - t a_pq, d_q + t a_pq (n/2 each) and p, q (ints)
   const int n = sd->D, tid = threadIdx.x, nth = blockDim.x;
@@ -1091,6 +1110,7 @@ __global__ __launch_bounds__(256) void k_evb_solve(const SolveDesc* __restrict__
     const double ei = V[i * n + gidx], ej = V[j * n + gidx];
     dcoef[1 + ngrid + t] = i == j ? ei * ej : 2.0 * ei * ej * -cA[j];
   }
+  if (done_mark) { __syncthreads(); if (tid == 0) __hip_atomic_store(done_mark, wait_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }      // the blend phase (main stream) starts on this
   if (done_flag) { __threadfence_system(); __syncthreads(); if (tid == 0) *done_flag = done_seq; }
 }
 
@@ -1300,7 +1320,7 @@ __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ 
 __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, const double* b, int nb, double* __restrict__ hb,
                               volatile long long* flag = nullptr, long long seq = 0, int ng = 0, double* E_lin = nullptr, double* E_quad = nullptr,
                               double conv = 0.0, double* E_grid = nullptr, const double* __restrict__ slot_part = nullptr, int n_part = 0, double* slot_out = nullptr,
-                              const long long* chain_done = nullptr, long long chain_seq = 0, int n_chains = 0, double* fault = nullptr, long long* done_mark = nullptr) {      // (a and E_grid alias: no __restrict__ on them)
+                              const long long* chain_done = nullptr, long long chain_seq = 0, int n_chains = 0, double* fault = nullptr) {      // (a and E_grid alias: no __restrict__ on them)
   // n_chains > 0: the kernels on OTHER streams whose energies this kernel publishes end with k_evb_mark(chain_done + k, chain_seq); wait for
   // those marks here instead of through two cross-stream event hops in front of this kernel (~10 us each on the way to the host's turn).
   // The marks are enqueued before this kernel in host order, so streams that share a hardware queue cannot deadlock; after 2 s of wall
@@ -1335,7 +1355,6 @@ __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, 
   for (int k = threadIdx.x; k < na; k += blockDim.x) ha[k] = a[k];
   for (int k = threadIdx.x; k < nb; k += blockDim.x) hb[k] = b[k];
   if (flag) { __threadfence_system(); __syncthreads(); if (threadIdx.x == 0) *flag = seq; }
-  if (done_mark) { __syncthreads(); if (threadIdx.x == 0) __hip_atomic_store(done_mark, chain_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }      // everything the device-side solve reads is in place
 }
 
 // The blend phase is enqueued BEFORE the host has the ground-state vector: this kernel, first of the phase on the main stream, waits until
@@ -1412,7 +1431,7 @@ struct EvbWork {   // persistent device scratch of one context
   hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
   RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
   long long* h_flag = nullptr; long long seq_A = 0, seq_R = 0, seq_B = 0;      // pinned: sequence number of the last published fetch A
-  DBuf<double> d_coef; double* h_solve = nullptr; size_t h_solve_cap = 0; hipEvent_t ev_solve = nullptr; long long seq_S = 0; bool side_by_mark = false;      // device-side Hamiltonian solve (k_evb_solve)
+  DBuf<double> d_coef; double* h_solve = nullptr; size_t h_solve_cap = 0; hipEvent_t ev_solve = nullptr; long long seq_S = 0; bool side_by_mark = false; const long long* blend_mark = nullptr; long long blend_mark_seq = 0;      // device-side Hamiltonian solve (k_evb_solve)
   char* h_desc = nullptr; DBuf<char> d_desc; size_t desc_cap = 0;   // units | couplings | recip atoms, one pinned block -> one upload
   double* h_E = nullptr; size_t hE_cap = 0;                         // pinned
   int grids_cap = 0;
@@ -1674,6 +1693,8 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   else if (c->overlap && ngrid && !one_wait) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // convolved diabat grids / grid energies (aux)
   stamp(c, 8, c->stream);
   if (w->d_pack.alloc(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended potential)");
+  const bool patch_waits = w->blend_mark && w->last_linear && ngrid > 0 && fft_lds_usable(c);      // k_evb_blend_patch is the phase's first kernel and waits itself
+  if (w->blend_mark && !patch_waits) hipLaunchKernelGGL(k_evb_wait_mark, dim3(1), dim3(64), 0, c->stream, w->blend_mark, w->blend_mark_seq, c->d_energies.p + S_FAULT);
   if (w->last_linear) {
     // blended CHARGE grid Q_1 (rank 0) + sum_d c_d^2 DQ_d -> one transform pair -> blended potential theta_1 + sum_d c_d^2 G * DQ_d
     // (sum_d c_d^2 = 1 over all ranks, so the principal potential enters once, on rank 0)
@@ -1683,10 +1704,11 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
       if (w->d_grids.alloc_room(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended charge grid)");
       if (fft_lds_usable(c)) {      // real grid in, real potential out, in place in d_pack (d_grids is the transform's complex work space)
         if (w->pack_prefilled) { if (c->overlap && (!one_wait || w->side_by_A) && !w->side_by_mark) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_prefill, 0)); }      // (went out before the host's turn)
-        else if (c->rank == 0) HIPCHK(hipMemcpyAsync(w->d_pack.p, c->d_Q.p, K3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        else if (c->rank == 0) hipLaunchKernelGGL(k_copy_grid, dim3(256), dim3(256), 0, c->stream, K3, (const double*)c->d_Q.p, w->d_pack.p);
         else HIPCHK(hipMemsetAsync(w->d_pack.p, 0, K3 * sizeof(double), c->stream));
         w->pack_prefilled = false;
-        hipLaunchKernelGGL(k_evb_blend_patch, dim3((w->last_nst + 3) / 4), dim3(256), 0, c->stream, w->last_nst, w->d_stencils.p, gc, dcoef, K, w->d_pack.p, 1);
+        hipLaunchKernelGGL(k_evb_blend_patch, dim3((w->last_nst + 3) / 4), dim3(256), 0, c->stream, w->last_nst, w->d_stencils.p, gc, dcoef, K, w->d_pack.p, 1,
+                           patch_waits ? w->blend_mark : (const long long*)nullptr, w->blend_mark_seq, c->d_energies.p + S_FAULT);
         HIPCHK(hipGetLastError());
         CHK(fft_lds_solve(c, w->d_pack.p, w->d_grids.p, w->d_pack.p, nullptr, nullptr, c->stream));
       } else {
@@ -2214,11 +2236,28 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, seqA,
                        lin_e ? ngrid : 0, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid,
                        (const double*)(c->d_partials.p + (size_t)S_RECIP * MAX_BLOCKS), n_recip_part, c->d_energies.p + S_RECIP,
-                       pub_spin ? (const long long*)w->d_chain_done.p : (const long long*)nullptr, seqA, pub_spin ? (ncp ? 2 : 1) : 0, c->d_energies.p + S_FAULT,
-                       dev_solve && pub_spin ? w->d_chain_done.p + 2 : (long long*)nullptr);      // device solve: k_evb_solve (main stream) starts on this mark
+                       pub_spin ? (const long long*)w->d_chain_done.p : (const long long*)nullptr, seqA, pub_spin ? (ncp ? 2 : 1) : 0, c->d_energies.p + S_FAULT);
     HIPCHK(hipGetLastError());
     stamp(c, 10, sg);
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, sg));
+    if (dev_solve) {      // Hamiltonian, ground state and blend coefficients: HERE, on the stream that has just completed the energies - beside the pair loop's tail, not behind it
+      const size_t need = 2 + 2 * (size_t)D + (size_t)D * D;
+      if (need > w->h_solve_cap) {
+        if (w->h_solve) HIPCHK(hipHostFree(w->h_solve));
+        w->h_solve_cap = 2 * need + 64;
+        HIPCHK(hipHostMalloc((void**)&w->h_solve, w->h_solve_cap * sizeof(double), hipHostMallocDefault));
+      }
+      if (w->d_coef.alloc(1 + MAX_DIABATS + 2 * MAX_DIABATS)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blend coefficients)");
+      const int hp = (D + 1) / 2;
+      const size_t lds = ((size_t)2 * D * D + D + 6 * hp + std::max(D <= 16 ? D * D + 2 * D : 0, n_unit_refs)) * 8 + 16;      // A, V, cplA, round tables (4 hp doubles + 2 hp ints), scratch
+      if (!c->attr_evb_solve) { const int Dm = MAX_DIABATS, hm = Dm / 2; HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * Dm * Dm + Dm + 6 * hm + std::max(16 * 16 + 32, MAX_UNITS)) * 8 + 16)); c->attr_evb_solve = true; }
+      hipLaunchKernelGGL(k_evb_solve, dim3(1), dim3(D <= 16 ? 64 : 256), lds, sg, (const SolveDesc*)(w->d_desc.p + off_s), (const int*)(w->d_desc.p + off_si),
+                         (const double*)(w->d_desc.p + off_ss), w->d_E.p, linear ? w->d_Elq.p + 2 * MAX_DIABATS /* zero: the grid energies are differences already */ : c->d_energies.p + S_RECIP, w->d_coef.p, w->h_solve,
+                         (const long long*)nullptr, seqA, (volatile long long*)(w->h_flag + 6), ++w->seq_S, c->d_energies.p + S_FAULT, c->evb_device_solve_method,
+                         pub_spin ? w->d_chain_done.p + 3 : (long long*)nullptr);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(w->ev_solve, sg));
+    }
     return MSEVB_OK;
   };
   auto fetch_B = [&]() -> int {      // principal energy slots + Verlet displacement flag (behind the pair loop)
@@ -2281,7 +2320,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   w->pack_prefilled = false;
   if (fast && ngrid && linear && fft_lds_usable(c)) {      // start value of the blended charge grid (Q_1 on rank 0): needs no coefficient, so it goes out in front of the energy fetch (the stream idles there until the other chains have ended)
     if (!w->ev_prefill) HIPCHK(hipEventCreateWithFlags(&w->ev_prefill, hipEventDisableTiming));
-    if (c->rank == 0) HIPCHK(hipMemcpyAsync(w->d_pack.p, c->d_Q.p, K3 * sizeof(double), hipMemcpyDeviceToDevice, sg));
+    if (c->rank == 0) hipLaunchKernelGGL(k_copy_grid, dim3(256), dim3(256), 0, sg, K3, (const double*)c->d_Q.p, w->d_pack.p);      // (a kernel, not a copy command: those cost ~15 us of queue time around their 4 us in front of the energy fetch)
     else HIPCHK(hipMemsetAsync(w->d_pack.p, 0, K3 * sizeof(double), sg));
     HIPCHK(hipEventRecord(w->ev_prefill, sg));
     w->pack_prefilled = true;
@@ -2331,27 +2370,14 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   //         and the diagonal real-space deltas (forked in step 5b, joined here)
   HIPCHK(hipGetLastError());
   if (ncp && c->overlap && !single_join) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_cpl, 0));      // off-diagonal force stores complete
-  if (dev_solve) {      // the blend phase goes out NOW, on the main stream behind the device-side solve: no host round trip between the energies and the blend
-    const size_t need = 2 + 2 * (size_t)D + (size_t)D * D;
-    if (need > w->h_solve_cap) {
-      if (w->h_solve) HIPCHK(hipHostFree(w->h_solve));
-      w->h_solve_cap = 2 * need + 64;
-      HIPCHK(hipHostMalloc((void**)&w->h_solve, w->h_solve_cap * sizeof(double), hipHostMallocDefault));
-    }
-    if (w->d_coef.alloc(1 + MAX_DIABATS + 2 * MAX_DIABATS)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blend coefficients)");
-    const int hp = (D + 1) / 2;
-    const size_t lds = ((size_t)2 * D * D + D + 6 * hp + std::max(D <= 16 ? D * D + 2 * D : 0, n_unit_refs)) * 8 + 16;      // A, V, cplA, round tables (4 hp doubles + 2 hp ints), squaring scratch
-    if (!c->attr_evb_solve) { const int Dm = MAX_DIABATS, hm = Dm / 2; HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * Dm * Dm + Dm + 6 * hm + std::max(16 * 16 + 32, MAX_UNITS)) * 8 + 16)); c->attr_evb_solve = true; }
-    if (c->overlap && !pub_spin) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_fetchA, 0));      // (without the marks: one event hop)
+  if (dev_solve) {      // the blend phase goes out NOW on the main stream, pre-enqueued behind the pair loop: its first kernel starts on the solve kernel's mark - no host turn, no event hop
+    if (c->overlap && !pub_spin) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_solve, 0));      // (without device-side marks: one event hop)
     phase_begin(c, PH_EVB_BLEND);
-    hipLaunchKernelGGL(k_evb_solve, dim3(1), dim3(D <= 16 ? 64 : 256), lds, c->stream, (const SolveDesc*)(w->d_desc.p + off_s), (const int*)(w->d_desc.p + off_si),
-                       (const double*)(w->d_desc.p + off_ss), w->d_E.p, linear ? w->d_Elq.p + 2 * MAX_DIABATS /* zero: the grid energies are differences already */ : c->d_energies.p + S_RECIP, w->d_coef.p, w->h_solve,
-                       pub_spin ? (const long long*)(w->d_chain_done.p + 2) : (const long long*)nullptr, w->seq_A, (volatile long long*)(w->h_flag + 6), ++w->seq_S, c->d_energies.p + S_FAULT, c->evb_device_solve_method);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(w->ev_solve, c->stream));
-    w->side_by_mark = pub_spin;      // the mark this kernel waited for follows every side chain (and the Q_1 copy) of this call: no event waits in the phase
-    CHK(fast_blend_phase(c, w, D, nullptr, grid_of.data(), ngrid, nra, d_ra, w->d_coef.p));
-    w->side_by_mark = false;
+    w->blend_mark = pub_spin ? w->d_chain_done.p + 3 : nullptr; w->blend_mark_seq = w->seq_A;
+    w->side_by_mark = pub_spin;      // that mark follows every side chain (and the Q_1 copy) of this call on the grid stream: no event waits in the phase
+    const int rc_b = fast_blend_phase(c, w, D, nullptr, grid_of.data(), ngrid, nra, d_ra, w->d_coef.p);
+    w->side_by_mark = false; w->blend_mark = nullptr;
+    CHK(rc_b);
     phase_end(c, PH_EVB_BLEND);
   }
   // host-side solve, blend phase enqueued ahead of it: the phase's kernels wait on the main stream behind k_evb_wait_coef for the

@@ -653,6 +653,7 @@ int total_force_enqueue(msevb_ctx* c) {
   CHK(nb_settle(c));
   stamp(c, 0, c->stream);
   const bool rebuild = c->flag_verlet_list == 1 || !c->list_valid;
+  const int fused_nb = c->refresh_fused_nb; c->refresh_fused_nb = 0;      // one-shot: a repeated force call (MSEVB_RETRY) refreshes the ordinary way (idempotent, and it zeroes the force array again)
   // A step that keeps its list: the PME front end (stencils, spreading, FFTs) needs the NEW POSITIONS only - not the refreshed sorted arrays,
   // not the zeroed force array - and is the longest chain beside the pair loop: it leaves for the side stream before the refresh kernels
   const bool early_pme = c->overlap && !rebuild && c->cells_valid;
@@ -670,7 +671,8 @@ int total_force_enqueue(msevb_ctx* c) {
     CHK(nb_step_refresh(c, c->aux3));
     HIPCHK(hipEventRecord(c->ev_refresh, c->aux3));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_refresh, 0));
-  } else CHK(nb_step_refresh(c));
+  } else if (fused_nb > 0) CHK(nb_step_top2(c, fused_nb));      // the integrator's first kernel did the refresh
+  else CHK(nb_step_refresh(c));
   if (c->overlap) {     // independent chains, all adding to the force with fp64 atomics
     HIPCHK(aux_fork(c));
     if (rebuild) CHK(nb_build_finish(c, true));                      // main: list rows first (the longest chain of a rebuild step: rows, then the pair loop)
@@ -836,6 +838,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "prune_freeze") { c->prune_freeze = v != 0.0; return MSEVB_OK; }
   if (s == "pair_taylor") { c->pair_taylor = v != 0.0; return MSEVB_OK; }
   if (s == "evb_fuse_blend") { c->evb_fuse_blend = v != 0.0; return MSEVB_OK; }
+  if (s == "step_fuse_refresh") { c->step_fuse_refresh = v != 0.0; return MSEVB_OK; }
   if (s == "pair_pipe") { c->pair_pipe = v != 0.0; return MSEVB_OK; }
   if (s == "comm_timeout_ms") { if (!(v >= 1.0)) return MSEVB_ERR_ARG; c->comm_timeout_ms = (int)v; return MSEVB_OK; }
   if (s == "comm_stall_ms") { c->comm_stall_ms = (int)v; return MSEVB_OK; }

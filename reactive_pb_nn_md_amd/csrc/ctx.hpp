@@ -332,6 +332,7 @@ struct msevb_ctx {
   bool nbr_check_pending = false;      // a deferred rebuild's row statistics have not been looked at yet
   int* h_nbr_stats = nullptr;          // pinned: {tile_max, pad, count_max, pad, count_sum lo, hi}
   int flag_verlet_list = 0;
+  bool step_fuse_refresh = true; int refresh_fused_nb = 0;      // option step_fuse_refresh: k_step_first_half does k_step_refresh's work on steps that keep their list (integrate.hip); > 0: blocks whose displacement partial sums await k_top2_final
   DBuf<double4> d_posq;        // sorted {x,y,z,q}
   DBuf<double> d_fsorted;      // [N][3] force accumulator of the half-list pair kernel in SORTED order (coalesced atomics), folded into d_force and re-zeroed by k_pair_fold
   DBuf<int> d_type_sorted, d_mol_sorted;
@@ -434,7 +435,8 @@ extern "C" int msevb_comm_allreduce_forces(msevb_ctx* c);   // comm.hip
 void evb_release(msevb_ctx* c);        // evb.hip: per-context EVB scratch
 extern "C" void msevb_comm_release(msevb_ctx* c);   // comm.hip: destroys the RCCL communicator, if any
 int flush_one(msevb_ctx* c, int slot, hipStream_t st);      // api.hip
-int nb_step_refresh(msevb_ctx* c, hipStream_t st = nullptr);      // refresh + displacement check + zero forces (neighbor.hip)
+int nb_step_refresh(msevb_ctx* c, hipStream_t st = nullptr);
+int nb_step_top2(msevb_ctx* c, int nb, hipStream_t st = nullptr);      // k_top2_final alone, over nb per-block partial results (the integrator's first kernel left them)      // refresh + displacement check + zero forces (neighbor.hip)
 int nb_check_displacements(msevb_ctx* c, int initialize, int* flag);
 int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw);              // pair.hip
 bool pair_flat_usable(const msevb_ctx* c);                                // pair_flat.hip

@@ -60,10 +60,15 @@ __global__ void k_remove_momentum(int N, double n_free, const double* __restrict
 // remove == 2: the momentum is summed HERE from the per-block partial sums the previous step's second kernel left (every block sums them
 // again - 3 x nb numbers - which takes the reduction kernel and the 56-byte download out of the chain in front of the pair loop); block 0
 // also finishes the kinetic-energy / velocity sums of that step and posts all seven to `post` (pinned host memory) and to the energy slots.
+// REFRESH (option step_fuse_refresh, steps that keep their Verlet list): the kernel also does what k_step_refresh (neighbor.hip) does for the atom it
+// has just moved - cell-sorted copy {x,y,z,q} (a scattered 32-byte store where the refresh kernel gathers), accumulated displacement since the list
+// build and since the pair list was pruned with the per-block top-2 norms (update_verlet_displacements, src/general_routines.f90:1259), force
+// accumulator zeroed - so that the pair loop starts one kernel and one launch gap (~15 us) earlier; k_top2_final follows as before.
+struct StepRefresh { int on; const int* inv_perm; const double* chg; double4* posq; double* store; double* disp; double* part1; double* part2; const double4* posq_prune; double* part3; double* part4; };
 __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt, int remove, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms,
-                                                         const double* __restrict__ mass, const double* __restrict__ F, double* __restrict__ en,
+                                                         const double* __restrict__ mass, double* __restrict__ F, double* __restrict__ en,
                                                          double* __restrict__ v, double* __restrict__ x, BoxDev box, Langevin L,
-                                                         const double* __restrict__ part, int nb, double* __restrict__ post, const int* __restrict__ frozen, double n_free) {
+                                                         const double* __restrict__ part, int nb, double* __restrict__ post, const int* __restrict__ frozen, double n_free, StepRefresh R) {
   static_assert(MAX_MOL_ATOMS == 8, "eight lanes per molecule");
   __shared__ double red[7][4];
   double P[3] = {0.0, 0.0, 0.0};
@@ -118,12 +123,53 @@ __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt
     const double p0 = __shfl(c0, lane0 + j, 64), p1 = __shfl(c1, lane0 + j, 64), p2 = __shfl(c2, lane0 + j, 64), pm = __shfl(ma, lane0 + j, 64);
     if (j < n) { com[0] += p0; com[1] += p1; com[2] += p2; mt += pm; }
   }
-  if (!live) return;
-  double sh[3];
-  for (int d = 0; d < 3; ++d) { const double f = com[d] / mt * box.invL[d]; sh[d] = f < 0.0 ? box.L[d] : (f > 1.0 ? -box.L[d] : 0.0); }
-  const bool any = sh[0] != 0.0 || sh[1] != 0.0 || sh[2] != 0.0;
-  if (moved) for (int d = 0; d < 3; ++d) v[3 * a + d] = vn[d];
-  if (moved || any) for (int d = 0; d < 3; ++d) x[3 * a + d] = any ? xn[d] + sh[d] : xn[d];
+  if (!live && !R.on) return;
+  double nrm = 0.0, nrm_p = 0.0;
+  if (live) {
+    double sh[3];
+    for (int d = 0; d < 3; ++d) { const double f = com[d] / mt * box.invL[d]; sh[d] = f < 0.0 ? box.L[d] : (f > 1.0 ? -box.L[d] : 0.0); }
+    const bool any = sh[0] != 0.0 || sh[1] != 0.0 || sh[2] != 0.0;
+    if (moved) for (int d = 0; d < 3; ++d) v[3 * a + d] = vn[d];
+    double xf[3];
+    for (int d = 0; d < 3; ++d) xf[d] = any ? xn[d] + sh[d] : xn[d];
+    if (moved || any) for (int d = 0; d < 3; ++d) x[3 * a + d] = xf[d];
+    if (R.on) {      // k_step_refresh's work for this atom, same expressions (neighbor.hip)
+      const int ks = R.inv_perm[a];
+      if (R.posq_prune) {
+        const double4 q = R.posq_prune[ks];
+        double e[3] = {xf[0] - q.x, xf[1] - q.y, xf[2] - q.z};
+        for (int d = 0; d < 3; ++d) e[d] -= box.L[d] * floor(e[d] * box.invL[d] + 0.5);
+        nrm_p = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+      }
+      R.posq[ks] = make_double4(xf[0], xf[1], xf[2], R.chg[a]);
+      double ad[3];
+      for (int d = 0; d < 3; ++d) {
+        const double dc = xf[d] - R.store[3 * a + d];
+        const double shd = floor(dc * box.invL[d] + 0.5) * box.L[d];
+        ad[d] = R.disp[3 * a + d] + (dc - shd);
+        R.disp[3 * a + d] = ad[d];
+        R.store[3 * a + d] = xf[d];
+        F[3 * a + d] = 0.0;
+      }
+      nrm = sqrt(ad[0] * ad[0] + ad[1] * ad[1] + ad[2] * ad[2]);
+    }
+  }
+  if (!R.on) return;
+  // per-block top-2 of both displacement norms (the order of a maximum does not matter: same bits as k_step_refresh's blocks give k_top2_final)
+  __shared__ double s1[256], s2[256];
+  for (int pass = 0; pass < (R.posq_prune ? 2 : 1); ++pass) {
+    s1[threadIdx.x] = pass ? nrm_p : nrm; s2[threadIdx.x] = 0.0;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) {
+        const double a1 = s1[threadIdx.x], a2 = s2[threadIdx.x], b1 = s1[threadIdx.x + st], b2 = s2[threadIdx.x + st];
+        s1[threadIdx.x] = fmax(a1, b1); s2[threadIdx.x] = fmax(fmin(a1, b1), fmax(a2, b2));
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { (pass ? R.part3 : R.part1)[blockIdx.x] = s1[0]; (pass ? R.part4 : R.part2)[blockIdx.x] = s2[0]; }
+    __syncthreads();
+  }
 }
 // second half: one thread per atom - half kick with the |F| > 1e5 guard (:508-529) and the per-block partial sums of momentum and
 // kinetic energy of the kicked velocities (calculate_kinetic_energy, src/total_energy_forces.f90:106)
@@ -216,8 +262,19 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
     L.kick = c->langevin_tick++;
     // EVB loop (no host synchronisation of its own): from the second step on the kernel reduces the previous step's partial sums itself
     const bool self_reduce = use_evb && s > 0;
+    StepRefresh R{};
+    // the refresh of the sorted arrays rides in this kernel on steps that keep their list (decided exactly as total_force_enqueue will: the flag the previous
+    // force call raised); a call that finds it has to rebuild after all (nb_settle) rebuilds from the positions, which are complete either way
+    const bool fuse = c->step_fuse_refresh && c->list_valid && c->cells_valid && c->flag_verlet_list != 1 && !c->nbr_check_pending && !(use_evb && c->evb_region_main) && c->d_posq.p && c->d_xyz_store.p && c->d_inv_perm.p;
+    if (fuse) {
+      const bool pr = c->prune && c->d_posq_prune.p && c->d_prune_mode.p;
+      R.on = 1; R.inv_perm = c->d_inv_perm.p; R.chg = c->d_chg.p; R.posq = c->d_posq.p; R.store = c->d_xyz_store.p; R.disp = c->d_disp.p;
+      R.part1 = c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS; R.part2 = c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS;
+      R.posq_prune = pr ? c->d_posq_prune.p : (const double4*)nullptr; R.part3 = c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS; R.part4 = c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS;
+    }
     hipLaunchKernelGGL(k_step_first_half, dim3(nbm8), dim3(256), 0, c->stream, M, N, dt, self_reduce ? 2 : (s > 0 ? 1 : 0), c->d_mol_natom.p, c->d_mol_atoms.p, c->d_mass.p,
-                       c->d_force.p, c->d_energies.p, c->d_vel.p, c->d_xyz.p, box, L, c->d_partials.p, nba, self_reduce ? h_ke + 7 * (size_t)(s - 1) : (double*)nullptr, frz, c->n_free);
+                       c->d_force.p, c->d_energies.p, c->d_vel.p, c->d_xyz.p, box, L, c->d_partials.p, nba, self_reduce ? h_ke + 7 * (size_t)(s - 1) : (double*)nullptr, frz, c->n_free, R);
+    c->refresh_fused_nb = fuse ? nbm8 : 0;      // consumed (once) by the force call that follows
     phase_end(c, PH_INTEGRATE);
     double epot = 0.0;
     if (use_evb) { CHK(evb_force_energy(c, &epot)); }
@@ -229,6 +286,7 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
         CHK(total_force_enqueue(c));
       }
     }
+    c->refresh_fused_nb = 0;
     L.kick = c->langevin_tick++;
     hipLaunchKernelGGL(k_step_second_half, dim3(nba), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p, c->d_partials.p, L, frz);
     HIPCHK(hipGetLastError());

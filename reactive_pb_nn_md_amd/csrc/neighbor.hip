@@ -540,6 +540,16 @@ int nb_step_refresh(msevb_ctx* c, hipStream_t st) {
   return MSEVB_OK;
 }
 
+int nb_step_top2(msevb_ctx* c, int nb, hipStream_t st) {
+  if (!st) st = c->stream;
+  const bool pr = c->prune && c->d_posq_prune.p && c->d_prune_mode.p;
+  hipLaunchKernelGGL(k_top2_final, dim3(pr ? 2 : 1), dim3(256), 0, st, nb, c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS,
+                     c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS, c->d_energies.p + S_MAXD1,
+                     c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS, c->prune_delta, c->d_prune_mode.p);
+  HIPCHK(hipGetLastError());
+  return MSEVB_OK;
+}
+
 // A (re)build in two halves so that the caller can start everything that only needs the CELL structure (PME spreading, per-molecule
 // terms) on the side streams while the rows are still being filled: nb_build_begin = cell sort + sorted arrays, nb_build_finish = rows
 // (+ the one host synchronisation of a build).  nb_build = both.

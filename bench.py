@@ -357,6 +357,8 @@ def main():
             "blocks_ms_per_step": [round(b[0] / args.steps * 1e3, 4) for b in blocks],      # every timed block; `value` is the median one
             "verlet_rebuilds": rebuilds,      # inside the reported (median) block
             "energy_first_last": [float(en[0, 0] + en[0, 1]), float(en[-1, 0] + en[-1, 1])],
+            "library_sha256": hashlib.sha256(open(os.path.join(ROOT, "reactive_pb_nn_md_amd", "libmsevb_hip.so"), "rb").read()).hexdigest()[:16],      # which build this line is about
+            "options": list(args.opt),
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(spec, args.steps / max(out["verlet_rebuilds"], 1))

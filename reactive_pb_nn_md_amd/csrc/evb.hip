@@ -938,26 +938,25 @@ struct SolveDesc {
 // out_host: {status, lowest eigenvalue of H', eigvec[D], cpl_A[D], H'[D*D] row-major (upper triangle filled)}, then done_flag = done_seq (pinned memory, the host spins on it)
 // wait_mark: device-side mark of the kernel that completes the energies (k_evb_publish on the grid stream) - this kernel sits on the MAIN stream
 // behind the pair loop and must not start reading E before that one is done; no cross-stream event hop (~10 us each)
-__global__ __launch_bounds__(256) void k_evb_solve(const SolveDesc* __restrict__ sd, const int* __restrict__ unit_idx, const double* __restrict__ unit_sign,
-                                                   const double* __restrict__ E, const double* __restrict__ e_recip1, double* __restrict__ dcoef, double* __restrict__ out_host,
-                                                   const long long* wait_mark, long long wait_seq, volatile long long* done_flag, long long done_seq, double* fault, int method, long long* done_mark) {
+struct SolveArgs {
+  int on, method;
+  const SolveDesc* sd; const int* unit_idx; const double* unit_sign; const double* E; const double* e_recip1;
+  double* dcoef; double* out_host;
+  long long mark_seq; long long* done_mark;               // device mark the blend phase (main stream) starts on
+  volatile long long* done_flag; long long done_seq;      // pinned flag the host spins on
+  double* fault;
+};
+__device__ __forceinline__ void evb_solve_body(const SolveArgs& sa) {
 #pragma clang fp contract(off)
+  const SolveDesc* __restrict__ sd = sa.sd; const int* __restrict__ unit_idx = sa.unit_idx; const double* __restrict__ unit_sign = sa.unit_sign;
+  const double* __restrict__ E = sa.E; const double* __restrict__ e_recip1 = sa.e_recip1; double* __restrict__ dcoef = sa.dcoef; double* __restrict__ out_host = sa.out_host;
+  const int method = sa.method; long long* done_mark = sa.done_mark; const long long wait_seq = sa.mark_seq; volatile long long* done_flag = sa.done_flag; const long long done_seq = sa.done_seq;
   extern __shared__ double sh[];      // A[n*n], V[n*n], cplA[n], per pair of a round: c, s, d_p - t a_pq, d_q + t a_pq (n/2 each) and p, q (ints)
   const int n = sd->D, tid = threadIdx.x, nth = blockDim.x;
   const int m = (n + 1) & ~1, hp = m / 2;      // tournament over m players (an odd n plays with a dummy that sits out)
   double* A = sh; double* V = A + n * n; double* cA = V + n * n; double* rc = cA + n; double* rs = rc + hp; double* rdp = rs + hp; double* rdq = rdp + hp;
   int* rp = (int*)(rdq + hp); int* rq = rp + hp;
   __shared__ int s_nonzero;
-  if (wait_mark) {
-    if (tid == 0) {
-      const long long t0 = wall_clock64();      // 100 MHz
-      while (__hip_atomic_load(wait_mark, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != wait_seq) {
-        if (wall_clock64() - t0 > 200000000LL) { if (fault) *fault = 2.0; break; }      // 2 s, as k_evb_publish
-        __builtin_amdgcn_s_sleep(2);
-      }
-    }
-    __syncthreads();
-  }
   const int nu = sd->nu, ncp = sd->ncp, ngrid = sd->ngrid;
   for (int k = tid; k < n * n; k += nth) { A[k] = 0.0; V[k] = (k / n == k % n) ? 1.0 : 0.0; }
   for (int k = tid; k < n; k += nth) cA[k] = 0.0;
@@ -1113,6 +1112,9 @@ __global__ __launch_bounds__(256) void k_evb_solve(const SolveDesc* __restrict__
   if (done_mark) { __syncthreads(); if (tid == 0) __hip_atomic_store(done_mark, wait_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }      // the blend phase (main stream) starts on this
   if (done_flag) { __threadfence_system(); __syncthreads(); if (tid == 0) *done_flag = done_seq; }
 }
+// stand-alone launch (single-stream schedule); in the four-stream schedule the body runs at the end of the energy-fetch kernel (k_evb_publish)
+__global__ __launch_bounds__(256) void k_evb_solve(const SolveArgs sa) { evb_solve_body(sa); }
+
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // SPECULATIVE EVB STEP (f2): the diabat tree (which protons can hop where) changes every few dozen steps, the positions every step.
@@ -1320,7 +1322,7 @@ __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ 
 __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, const double* b, int nb, double* __restrict__ hb,
                               volatile long long* flag = nullptr, long long seq = 0, int ng = 0, double* E_lin = nullptr, double* E_quad = nullptr,
                               double conv = 0.0, double* E_grid = nullptr, const double* __restrict__ slot_part = nullptr, int n_part = 0, double* slot_out = nullptr,
-                              const long long* chain_done = nullptr, long long chain_seq = 0, int n_chains = 0, double* fault = nullptr) {      // (a and E_grid alias: no __restrict__ on them)
+                              const long long* chain_done = nullptr, long long chain_seq = 0, int n_chains = 0, double* fault = nullptr, const SolveArgs sa = SolveArgs()) {      // (a and E_grid alias: no __restrict__ on them)
   // n_chains > 0: the kernels on OTHER streams whose energies this kernel publishes end with k_evb_mark(chain_done + k, chain_seq); wait for
   // those marks here instead of through two cross-stream event hops in front of this kernel (~10 us each on the way to the host's turn).
   // The marks are enqueued before this kernel in host order, so streams that share a hardware queue cannot deadlock; after 2 s of wall
@@ -1355,6 +1357,9 @@ __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, 
   for (int k = threadIdx.x; k < na; k += blockDim.x) ha[k] = a[k];
   for (int k = threadIdx.x; k < nb; k += blockDim.x) hb[k] = b[k];
   if (flag) { __threadfence_system(); __syncthreads(); if (threadIdx.x == 0) *flag = seq; }
+  // sa.on: the energies this kernel has just completed are all the Hamiltonian needs - H' assembly, ground state and blend coefficients right here
+  // (a launch of its own behind this kernel cost a gap and a minimum kernel duration, ~7 us, on the way to the blend phase's start)
+  if (sa.on) { __threadfence_block(); __syncthreads(); evb_solve_body(sa); }
 }
 
 // The blend phase is enqueued BEFORE the host has the ground-state vector: this kernel, first of the phase on the main stream, waits until
@@ -2233,14 +2238,9 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     }
     const bool lin_e = linear && ngrid > 0;
     const long long seqA = ++w->seq_A;      // (the chains' marks carry this number)
-    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, seqA,
-                       lin_e ? ngrid : 0, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid,
-                       (const double*)(c->d_partials.p + (size_t)S_RECIP * MAX_BLOCKS), n_recip_part, c->d_energies.p + S_RECIP,
-                       pub_spin ? (const long long*)w->d_chain_done.p : (const long long*)nullptr, seqA, pub_spin ? (ncp ? 2 : 1) : 0, c->d_energies.p + S_FAULT);
-    HIPCHK(hipGetLastError());
-    stamp(c, 10, sg);
-    if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, sg));
-    if (dev_solve) {      // Hamiltonian, ground state and blend coefficients: HERE, on the stream that has just completed the energies - beside the pair loop's tail, not behind it
+    SolveArgs sa = SolveArgs();
+    size_t lds = 0;
+    if (dev_solve) {      // Hamiltonian, ground state and blend coefficients at the end of the kernel that completes the energies - beside the pair loop's tail, not behind it
       const size_t need = 2 + 2 * (size_t)D + (size_t)D * D;
       if (need > w->h_solve_cap) {
         if (w->h_solve) HIPCHK(hipHostFree(w->h_solve));
@@ -2249,15 +2249,27 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       }
       if (w->d_coef.alloc(1 + MAX_DIABATS + 2 * MAX_DIABATS)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blend coefficients)");
       const int hp = (D + 1) / 2;
-      const size_t lds = ((size_t)2 * D * D + D + 6 * hp + std::max(D <= 16 ? D * D + 2 * D : 0, n_unit_refs)) * 8 + 16;      // A, V, cplA, round tables (4 hp doubles + 2 hp ints), scratch
-      if (!c->attr_evb_solve) { const int Dm = MAX_DIABATS, hm = Dm / 2; HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * Dm * Dm + Dm + 6 * hm + std::max(16 * 16 + 32, MAX_UNITS)) * 8 + 16)); c->attr_evb_solve = true; }
-      hipLaunchKernelGGL(k_evb_solve, dim3(1), dim3(D <= 16 ? 64 : 256), lds, sg, (const SolveDesc*)(w->d_desc.p + off_s), (const int*)(w->d_desc.p + off_si),
-                         (const double*)(w->d_desc.p + off_ss), w->d_E.p, linear ? w->d_Elq.p + 2 * MAX_DIABATS /* zero: the grid energies are differences already */ : c->d_energies.p + S_RECIP, w->d_coef.p, w->h_solve,
-                         (const long long*)nullptr, seqA, (volatile long long*)(w->h_flag + 6), ++w->seq_S, c->d_energies.p + S_FAULT, c->evb_device_solve_method,
-                         pub_spin ? w->d_chain_done.p + 3 : (long long*)nullptr);
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipEventRecord(w->ev_solve, sg));
+      lds = ((size_t)2 * D * D + D + 6 * hp + std::max(D <= 16 ? D * D + 2 * D : 0, n_unit_refs)) * 8 + 16;      // A, V, cplA, round tables (4 hp doubles + 2 hp ints), scratch
+      if (!c->attr_evb_solve) {
+        const int Dm = MAX_DIABATS, hm = Dm / 2, most = (2 * Dm * Dm + Dm + 6 * hm + std::max(16 * 16 + 32, MAX_UNITS)) * 8 + 16;
+        HIPCHK(hipFuncSetAttribute((const void*)k_evb_publish, hipFuncAttributeMaxDynamicSharedMemorySize, most));
+        HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, most));
+        c->attr_evb_solve = true;
+      }
+      sa.on = 1; sa.method = c->evb_device_solve_method;
+      sa.sd = (const SolveDesc*)(w->d_desc.p + off_s); sa.unit_idx = (const int*)(w->d_desc.p + off_si); sa.unit_sign = (const double*)(w->d_desc.p + off_ss);
+      sa.E = w->d_E.p; sa.e_recip1 = linear ? w->d_Elq.p + 2 * MAX_DIABATS /* zero: the grid energies are differences already */ : c->d_energies.p + S_RECIP;
+      sa.dcoef = w->d_coef.p; sa.out_host = w->h_solve; sa.mark_seq = seqA; sa.done_mark = pub_spin ? w->d_chain_done.p + 3 : (long long*)nullptr;
+      sa.done_flag = (volatile long long*)(w->h_flag + 6); sa.done_seq = ++w->seq_S; sa.fault = c->d_energies.p + S_FAULT;
     }
+    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), lds, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, seqA,
+                       lin_e ? ngrid : 0, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid,
+                       (const double*)(c->d_partials.p + (size_t)S_RECIP * MAX_BLOCKS), n_recip_part, c->d_energies.p + S_RECIP,
+                       pub_spin ? (const long long*)w->d_chain_done.p : (const long long*)nullptr, seqA, pub_spin ? (ncp ? 2 : 1) : 0, c->d_energies.p + S_FAULT, sa);
+    HIPCHK(hipGetLastError());
+    stamp(c, 10, sg);
+    if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, sg));
+    if (dev_solve) HIPCHK(hipEventRecord(w->ev_solve, sg));
     return MSEVB_OK;
   };
   auto fetch_B = [&]() -> int {      // principal energy slots + Verlet displacement flag (behind the pair loop)

@@ -409,6 +409,7 @@ struct msevb_ctx {
   bool evb_recip_linear = true;      // diabats' reciprocal space through the linear response of theta to the charge differences (evb.hip): no transform per diabat
   bool evb_speculate = true;         // MS-EVB step without a host wait for the neighbourhood record while the diabat tree stays the same (evb.hip, SpecPlan); 0 = enumerate every step
   long topo_epoch = 0;               // bumped by everything that can change what a recorded diabat tree means (topology upload, box, options)
+  bool evb_fft_patch = true;         // 64^3: the blended charge grid is formed inside the forward transform (fft_lds.hip, FftPatch); 0 = copy of Q_1 + k_evb_blend_patch in front of it
   bool evb_fuse_blend = false;       // option (measured, off): the Hellmann-Feynman blend inside the gather of the blended potential - 68 us against 40 + 15: the stores it reads are in atom order, the gather walks the atoms in cell order (scattered 24-byte reads where k_evb_blend streams)
   int evb_device_solve_method = 1;   // k_evb_solve: 1 = ground state by repeated squaring (<= 16 diabats; Jacobi decides when it does not converge), 0 = round-robin Jacobi always
   bool evb_device_solve = true;      // single rank, no element stores: H' assembly + round-robin Jacobi + blend coefficients in a kernel on the main stream, the blend phase behind it (no host turn on the critical path); 0 = host Jacobi
@@ -477,7 +478,18 @@ bool pme_gather_can_blend(const msevb_ctx* c);      // the next pme_gather call 
 int pme_side_weights(msevb_ctx* c, hipStream_t st, hipEvent_t after);
 bool fft_lds_usable(const msevb_ctx* c);                              // fft_lds.hip
 int fft_lds_setup(msevb_ctx* c);
-int fft_lds_solve(msevb_ctx* c, const double* Q, double2* work, double* theta, double* part, int* nblocks, hipStream_t st);
+// B-spline stencil of one special atom in one state (MS-EVB reciprocal space by linear response, evb.hip): nearest grid points, charge, tap weights
+struct Stencil { int base[3]; int grid, slot, idx; double q; double w[18], dw[18]; };
+// charge-grid patch applied by the forward transform itself (64^3, fft_lds.hip): plane += sum over the stencils of coefficient[grid] q S.  The blended
+// charge grid of the Hellmann-Feynman force then needs neither a copy of Q_1 nor a patch kernel in front of its transform.
+struct FftPatch {
+  int nst; const Stencil* st;
+  const double* dc;                       // coefficients in device memory: dc[1 + grid] (written by the solve body) ...
+  double c[MAX_DIABATS];                  // ... or as kernel arguments (dc == nullptr)
+  const long long* wait_mark; long long wait_seq; double* fault;      // the coefficients' kernel runs on another stream: start on its mark
+};
+bool fft_lds_can_patch(const msevb_ctx* c);      // the 64^3 transform (its forward kernel applies an FftPatch)
+int fft_lds_solve(msevb_ctx* c, const double* Q, double2* work, double* theta, double* part, int* nblocks, hipStream_t st, const FftPatch* patch = nullptr);
 // the Hellmann-Feynman blend as the weight-free tiled gather applies it per atom (pme.hip: k_pme_gather_tiles_wl<true>; evb.hip: k_evb_blend is the stand-alone kernel)
 struct GatherBlend {
   int n, N;                                  // terms; atoms (pitch of Fs)

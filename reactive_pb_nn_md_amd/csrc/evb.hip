@@ -721,7 +721,6 @@ __global__ void k_evb_blend_grids(size_t K3, GridCoefs gc, const double* __restr
 // instead of D - 1 transform pairs of dense grids (7 x 4 MB x 4 passes per step at 98 k atoms).  A stencil pair (T, S) interacts through
 //   sum_{i in T, j in S} wT_i wS_j G(x_T,i - x_S,j) = sum_{o in [-5,5]^3} W(o) G(b_T - b_S - o),  W = separable cross-correlation of the
 // two stencils' tap weights (11 values per axis): 1331 table reads per pair.
-struct Stencil { int base[3]; int grid, slot, idx; double q; double w[18], dw[18]; };
 
 // two stencils per recip entry: 2 e = the atom as the principal diabat has it (charge -q_old), 2 e + 1 = its new state (charge +q_new).
 // Charges modify_Q_grid would skip (|q| <= 1e-6, src/pme.f90:296) and entries whose two states are identical get q = 0.
@@ -1707,7 +1706,13 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
       if (c->rank == 0) { if (fuse) CHK(join_before_blend()); CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, c->d_theta.p, fuse ? &gb : nullptr, &blended)); }
     } else {
       if (w->d_grids.alloc_room(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended charge grid)");
-      if (fft_lds_usable(c)) {      // real grid in, real potential out, in place in d_pack (d_grids is the transform's complex work space)
+      if (fft_lds_can_patch(c) && c->evb_fft_patch) {      // 64^3: the forward transform applies the stencils to the planes of Q_1 itself - no copy of Q_1, no patch kernel
+        FftPatch P; P.nst = w->last_nst; P.st = w->d_stencils.p; P.dc = dcoef;
+        for (int g = 0; g < MAX_DIABATS; ++g) P.c[g] = (!dcoef && g < ngrid) ? gc.c[g] : 0.0;
+        P.wait_mark = patch_waits ? w->blend_mark : (const long long*)nullptr; P.wait_seq = w->blend_mark_seq; P.fault = c->d_energies.p + S_FAULT;
+        CHK(fft_lds_solve(c, c->rank == 0 ? c->d_Q.p : (const double*)nullptr, w->d_grids.p, w->d_pack.p, nullptr, nullptr, c->stream, &P));
+        w->pack_prefilled = false;
+      } else if (fft_lds_usable(c)) {      // real grid in, real potential out, in place in d_pack (d_grids is the transform's complex work space)
         if (w->pack_prefilled) { if (c->overlap && (!one_wait || w->side_by_A) && !w->side_by_mark) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_prefill, 0)); }      // (went out before the host's turn)
         else if (c->rank == 0) hipLaunchKernelGGL(k_copy_grid, dim3(256), dim3(256), 0, c->stream, K3, (const double*)c->d_Q.p, w->d_pack.p);
         else HIPCHK(hipMemsetAsync(w->d_pack.p, 0, K3 * sizeof(double), c->stream));
@@ -2330,7 +2335,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   phase_end(c, PH_EVB_RECIP, sg);
   stamp(c, 6, sg);
   w->pack_prefilled = false;
-  if (fast && ngrid && linear && fft_lds_usable(c)) {      // start value of the blended charge grid (Q_1 on rank 0): needs no coefficient, so it goes out in front of the energy fetch (the stream idles there until the other chains have ended)
+  if (fast && ngrid && linear && fft_lds_usable(c) && !(fft_lds_can_patch(c) && c->evb_fft_patch)) {      // start value of the blended charge grid (Q_1 on rank 0): needs no coefficient, so it goes out in front of the energy fetch (the stream idles there until the other chains have ended)
     if (!w->ev_prefill) HIPCHK(hipEventCreateWithFlags(&w->ev_prefill, hipEventDisableTiming));
     if (c->rank == 0) hipLaunchKernelGGL(k_copy_grid, dim3(256), dim3(256), 0, sg, K3, (const double*)c->d_Q.p, w->d_pack.p);      // (a kernel, not a copy command: those cost ~15 us of queue time around their 4 us in front of the energy fetch)
     else HIPCHK(hipMemsetAsync(w->d_pack.p, 0, K3 * sizeof(double), sg));

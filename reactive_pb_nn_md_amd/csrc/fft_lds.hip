@@ -66,19 +66,63 @@ __device__ __forceinline__ void load_tw(int j, double2 (&tw)[8]) {
 }
 
 // ---- x then y, forward, real input ----
-__global__ __launch_bounds__(512) void k_fft_xy_fwd(const double* __restrict__ Q, double2* __restrict__ grid) {
+// PATCH: the plane is staged in LDS first and the stencils of P that touch it are added there (coefficient x charge x tap weights, one thread per
+// stencil, 36 LDS atomics each) - the blended charge grid Q_1 + sum_d c_d^2 DQ_d of the MS-EVB step exists only inside this kernel (round 3:
+// a 2 MB copy of Q_1 in front of the energy fetch + k_evb_blend_patch in front of the transform).  Q == nullptr: a zero plane (ranks other than 0).
+template <bool PATCH>
+__global__ __launch_bounds__(512) void k_fft_xy_fwd(const double* __restrict__ Q, double2* __restrict__ grid, const FftPatch P) {
   extern __shared__ double lds[];
   double* pr = lds;                 // [64][LS] real parts
   double* pi = lds + FK * LS;       // imaginary parts
   const int z = blockIdx.x, t = threadIdx.x;
   double re[8], im[8];
   double2 tw[8];
+  if (PATCH) {
+    if (P.wait_mark) {      // (as evb_wait_mark, evb.hip: 2 s limit, then the sticky fault flag)
+      if (t == 0) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(P.wait_mark, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != P.wait_seq) {
+          if (wall_clock64() - t0 > 200000000LL) { if (P.fault) *P.fault = 2.0; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      __syncthreads();
+    }
+    const double* plane = Q ? Q + (size_t)FK * FK * z : nullptr;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { const int k = t + 512 * m, y = k >> 6, x = k & 63; pr[y * LS + x] = plane ? plane[k] : 0.0; }
+    __syncthreads();
+    for (int s0 = 0; s0 < P.nst; s0 += 512) {
+      const int si = s0 + t;
+      if (si < P.nst) {
+        const Stencil& S = P.st[si];
+        int k3 = S.base[2] - z; if (k3 < 0) k3 += FK;
+        if (k3 < 6 && S.q != 0.0) {
+          const double q = S.q * (P.dc ? P.dc[1 + S.grid] : P.c[S.grid]) * S.w[12 + k3];
+          if (q != 0.0) {
+            for (int k2 = 0; k2 < 6; ++k2) {
+              int n2 = S.base[1] - k2; if (n2 < 0) n2 += FK;
+              const double q2 = q * S.w[6 + k2];
+              for (int k1 = 0; k1 < 6; ++k1) { int n1 = S.base[0] - k1; if (n1 < 0) n1 += FK; atomicAdd(&pr[n2 * LS + n1], q2 * S.w[k1]); }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
   {      // x lines: 8 threads per line y
     const int y = t >> 3, j = t & 7;
     load_tw(j, tw);
-    const double* row = Q + (size_t)FK * (y + (size_t)FK * z);
+    if (PATCH) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) { re[m] = row[j + 8 * m]; im[m] = 0.0; }
+      for (int m = 0; m < 8; ++m) { re[m] = pr[y * LS + j + 8 * m]; im[m] = 0.0; }
+      __syncthreads();      // (the exchange below overwrites the staged plane)
+    } else {
+      const double* row = Q + (size_t)FK * (y + (size_t)FK * z);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) { re[m] = row[j + 8 * m]; im[m] = 0.0; }
+    }
     dft8<-1>(re, im);
     twiddle<-1>(re, im, tw);
     double* rr = pr + y * LS + j * 9; double* ri = pi + y * LS + j * 9;
@@ -346,13 +390,16 @@ int fft_lds_setup(msevb_ctx* c) {
   tw[0] = make_double2(1, 0); tw[16] = make_double2(0, 1); tw[32] = make_double2(-1, 0); tw[48] = make_double2(0, -1);
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tw64), tw, sizeof tw));
   const int lds = 2 * FK * LS * (int)sizeof(double);
-  HIPCHK(hipFuncSetAttribute((const void*)k_fft_xy_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fft_xy_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fft_xy_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   HIPCHK(hipFuncSetAttribute((const void*)k_fft_xy_inv, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   return MSEVB_OK;
 }
 
 // theta = Re IFFT(CB FFT(Q)); Q and theta real [64^3] (may be the same buffer), work complex [64^3]; part (optional): 256 energy partials
-int fft_lds_solve(msevb_ctx* c, const double* Q, double2* work, double* theta, double* part, int* nblocks, hipStream_t st) {
+bool fft_lds_can_patch(const msevb_ctx* c) { return fft_lds_usable(c) && c->K == FK; }
+int fft_lds_solve(msevb_ctx* c, const double* Q, double2* work, double* theta, double* part, int* nblocks, hipStream_t st, const FftPatch* patch) {
+  if (patch && c->K != FK) FAIL(MSEVB_ERR_STATE, "fft_lds_solve: a charge-grid patch needs the 64^3 transform");
   if (c->K == FN) {      // five kernels, 1024 workgroups of 128 threads each
     hipLaunchKernelGGL(k_fft128_x<-1>, dim3(FN * 8), dim3(128), 0, st, Q, work, (double*)nullptr);
     hipLaunchKernelGGL(k_fft128_y<-1>, dim3(FN * 8), dim3(128), 0, st, work);
@@ -364,7 +411,9 @@ int fft_lds_solve(msevb_ctx* c, const double* Q, double2* work, double* theta, d
     return MSEVB_OK;
   }
   const int lds = 2 * FK * LS * (int)sizeof(double);
-  hipLaunchKernelGGL(k_fft_xy_fwd, dim3(FK), dim3(512), lds, st, Q, work);
+  static const FftPatch no_patch = {};
+  if (patch) hipLaunchKernelGGL(k_fft_xy_fwd<true>, dim3(FK), dim3(512), lds, st, Q, work, *patch);
+  else hipLaunchKernelGGL(k_fft_xy_fwd<false>, dim3(FK), dim3(512), lds, st, Q, work, no_patch);
   hipLaunchKernelGGL(k_fft_z_conv, dim3(FK * 4), dim3(128), 0, st, work, c->d_CB.p, part, 0.5 * c->conv);
   hipLaunchKernelGGL(k_fft_xy_inv, dim3(FK), dim3(512), lds, st, work, theta);
   HIPCHK(hipGetLastError());

@@ -838,7 +838,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "prune_freeze") { c->prune_freeze = v != 0.0; return MSEVB_OK; }
   if (s == "pair_taylor") { c->pair_taylor = v != 0.0; return MSEVB_OK; }
   if (s == "evb_fft_patch") { c->evb_fft_patch = v != 0.0; return MSEVB_OK; }
-  if (s == "evb_fuse_blend") { c->evb_fuse_blend = v != 0.0; return MSEVB_OK; }
+  if (s == "evb_blend_aside") { c->evb_blend_aside = v != 0.0; return MSEVB_OK; }
   if (s == "step_fuse_refresh") { c->step_fuse_refresh = v != 0.0; return MSEVB_OK; }
   if (s == "pair_pipe") { c->pair_pipe = v != 0.0; return MSEVB_OK; }
   if (s == "comm_timeout_ms") { if (!(v >= 1.0)) return MSEVB_ERR_ARG; c->comm_timeout_ms = (int)v; return MSEVB_OK; }

@@ -410,7 +410,7 @@ struct msevb_ctx {
   bool evb_speculate = true;         // MS-EVB step without a host wait for the neighbourhood record while the diabat tree stays the same (evb.hip, SpecPlan); 0 = enumerate every step
   long topo_epoch = 0;               // bumped by everything that can change what a recorded diabat tree means (topology upload, box, options)
   bool evb_fft_patch = true;         // 64^3: the blended charge grid is formed inside the forward transform (fft_lds.hip, FftPatch); 0 = copy of Q_1 + k_evb_blend_patch in front of it
-  bool evb_fuse_blend = false;       // option (measured, off): the Hellmann-Feynman blend inside the gather of the blended potential - 68 us against 40 + 15: the stores it reads are in atom order, the gather walks the atoms in cell order (scattered 24-byte reads where k_evb_blend streams)
+  bool evb_blend_aside = true;       // MS-EVB fast path: blend terms added from a side stream beside the transform and the gather (k_evb_blend_terms), pair accumulator folded by the gather; 0 = k_evb_blend behind the gather
   int evb_device_solve_method = 1;   // k_evb_solve: 1 = ground state by repeated squaring (<= 16 diabats; Jacobi decides when it does not converge), 0 = round-robin Jacobi always
   bool evb_device_solve = true;      // single rank, no element stores: H' assembly + round-robin Jacobi + blend coefficients in a kernel on the main stream, the blend phase behind it (no host turn on the critical path); 0 = host Jacobi
   bool nvt = false; double friction = 0.1 /* 1/ps, the reference's default */, temperature = 300.0; unsigned long long langevin_seed = 0, langevin_tick = 0;
@@ -474,7 +474,7 @@ int pme_convolve(msevb_ctx* c, double2* grids, int batch, double* part, int part
 int pme_prepare_atoms(msevb_ctx* c, bool with_indices);
 bool pme_weightless_now(const msevb_ctx* c);
 bool pme_tiles_ok(const msevb_ctx* c);
-bool pme_gather_can_blend(const msevb_ctx* c);      // the next pme_gather call will be the weight-free tiled kernel (which can apply a GatherBlend)
+bool pme_gather_can_fold(const msevb_ctx* c);      // the next pme_gather call will be the weight-free tiled kernel (which can fold the pair loop's accumulator in)
 int pme_side_weights(msevb_ctx* c, hipStream_t st, hipEvent_t after);
 bool fft_lds_usable(const msevb_ctx* c);                              // fft_lds.hip
 int fft_lds_setup(msevb_ctx* c);
@@ -490,17 +490,7 @@ struct FftPatch {
 };
 bool fft_lds_can_patch(const msevb_ctx* c);      // the 64^3 transform (its forward kernel applies an FftPatch)
 int fft_lds_solve(msevb_ctx* c, const double* Q, double2* work, double* theta, double* part, int* nblocks, hipStream_t st, const FftPatch* patch = nullptr);
-// the Hellmann-Feynman blend as the weight-free tiled gather applies it per atom (pme.hip: k_pme_gather_tiles_wl<true>; evb.hip: k_evb_blend is the stand-alone kernel)
-struct GatherBlend {
-  int n, N;                                  // terms; atoms (pitch of Fs)
-  int slot[2 * MAX_DIABATS];                 // >= 0: slot of the delta store (consumed: re-zeroed), < 0: off-diagonal store -slot - 1
-  double coef[2 * MAX_DIABATS];              // coefficients as kernel arguments ...
-  const double* dc;                          // ... or in device memory (k_evb_solve); nullptr: coef
-  double w11;                                // weight of F11 (+ the pair loop's accumulator) already in F
-  double* Fdiag; const double* Foff; size_t fstride;
-  double* Fs;                                // pair loop's sorted-order accumulator [3][N], consumed; nullptr: already folded
-};
-int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic = false, const double* theta = nullptr, const GatherBlend* blend = nullptr, bool* blended = nullptr);
+int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic = false, const double* theta = nullptr, double* Fs_fold = nullptr, bool* folded = nullptr);      // Fs_fold: the pair loop's sorted-order accumulator joins the atomic add and is re-zeroed (weight-free tiled kernel only; *folded says whether)
 
 constexpr int MAX_BLOCKS = 65536;
 enum Slot { S_ELEC_PAIR = 0, S_VDW_PAIR, S_ELEC_INTRA, S_VDW_INTRA, S_BOND, S_ANGLE, S_DIH, S_RECIP, S_KE, S_PX, S_PY, S_PZ, S_VX, S_VY, S_VZ /* sum of velocities: KE after the momentum removal */, S_MAXD1, S_MAXD2, S_PRD1, S_PRD2 /* two largest displacements since the pair list was last pruned */, S_EVB0,

@@ -917,6 +917,22 @@ __global__ void k_evb_blend(size_t n3, BlendTerms bt, const double* __restrict__
   }
 }
 
+// The same sum WITHOUT the force array's own value: F += sum of coefficient x store, added with atomics, so that it can run on a side stream while the
+// main stream transforms and gathers the blended potential (whose kernel also folds the pair loop's accumulator in, pme.hip) - every contribution
+// to the force array of an MS-EVB step is then an atomic add, their order does not matter, and no pass over the array is left behind the gather.
+__global__ void k_evb_blend_terms(size_t n3, BlendTerms bt, const double* __restrict__ dc, double* __restrict__ Fdiag, const double* __restrict__ Foff, size_t fstride, double* __restrict__ F) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += (size_t)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int t = 0; t < bt.n; ++t) {
+      const int sl = bt.slot[t];
+      const double cf = dc ? dc[t] : bt.coef[t];
+      if (sl < 0) s += cf * Foff[(size_t)(-sl - 1) * fstride + k];
+      else { double* p = Fdiag + (size_t)sl * fstride + k; s += cf * *p; *p = 0.0; }      // (the delta store is consumed)
+    }
+    if (s != 0.0) atomicAdd(&F[k], s);
+  }
+}
+
 // ---- Hamiltonian assembly + Jacobi + blend coefficients ON THE DEVICE (single rank, fast path): the blend phase is enqueued behind this
 // kernel on the main stream without a host round trip (fetch -> host Jacobi -> launch cost 27-35 us of the step's critical path, and kept
 // the host from enqueueing ahead).  diagonalize_evb_hamiltonian + jacobi (src/ms_evb.f90:242-330, src/general_routines.f90:2013-2088): the
@@ -1435,7 +1451,7 @@ struct EvbWork {   // persistent device scratch of one context
   hipStream_t stream2 = nullptr; hipEvent_t ev_in = nullptr, ev_region = nullptr;
   RegionRec* h_region = nullptr; int* h_count = nullptr;          // pinned
   long long* h_flag = nullptr; long long seq_A = 0, seq_R = 0, seq_B = 0;      // pinned: sequence number of the last published fetch A
-  DBuf<double> d_coef; double* h_solve = nullptr; size_t h_solve_cap = 0; hipEvent_t ev_solve = nullptr; long long seq_S = 0; bool side_by_mark = false; const long long* blend_mark = nullptr; long long blend_mark_seq = 0;      // device-side Hamiltonian solve (k_evb_solve)
+  DBuf<double> d_coef; double* h_solve = nullptr; size_t h_solve_cap = 0; hipEvent_t ev_solve = nullptr; long long seq_S = 0; hipEvent_t ev_bterms = nullptr; bool side_by_mark = false; const long long* blend_mark = nullptr; long long blend_mark_seq = 0;      // device-side Hamiltonian solve (k_evb_solve)
   char* h_desc = nullptr; DBuf<char> d_desc; size_t desc_cap = 0;   // units | couplings | recip atoms, one pinned block -> one upload
   double* h_E = nullptr; size_t hE_cap = 0;                         // pinned
   int grids_cap = 0;
@@ -1667,6 +1683,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   const size_t K3 = (size_t)K * K * K, n3 = 3 * (size_t)c->N;
   BlendTerms bt;
   double w11 = blend_terms(c, D, ev, bt);
+  const bool w11_was_one = w11 != 0.0;
   if (w11 == 0.0) {      // replicated (not sharded) principal diabat on a rank other than 0: F11 counts on rank 0 only, the gather below adds to zero
     if (c->overlap && w->side_valid) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0)); if (w->side_wo_mol) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0)); }      // (the per-molecule kernel still adds to it)
     else if (c->overlap && w->mol_deferred) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
@@ -1678,15 +1695,21 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   GridCoefs gc; gc.n = ngrid; gc.c0 = 0.0;
   if (ev) { gc.c0 = c->rank == 0 ? ev[0] * ev[0] : 0.0; for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gc.c[grid_of[d]] = ev[d] * ev[d]; }
   const bool one_wait = c->overlap && w->side_valid;      // every side chain of this force call behind ONE event
-  // the blend itself rides in the gather of the blended potential when that is the weight-free tiled kernel (pme.hip, k_pme_gather_tiles_wl<true>)
-  const bool fuse = c->evb_fuse_blend && pme_gather_can_blend(c) && (w->last_linear ? (ngrid > 0 || c->rank == 0) : true);
-  GatherBlend gb; bool blended = false;
-  if (fuse) {
-    gb.n = bt.n; gb.N = c->N;
-    for (int t = 0; t < bt.n; ++t) { gb.slot[t] = bt.slot[t]; gb.coef[t] = bt.coef[t]; }
-    gb.dc = dcoef ? dcoef + 1 + ngrid : (const double*)nullptr; gb.w11 = w11;
-    gb.Fdiag = w->d_Fdelta.p; gb.Foff = c->d_Foff.p; gb.fstride = n3; gb.Fs = c->fsorted_pending ? c->d_fsorted.p : (double*)nullptr;
+  // ASIDE (default): the blend terms are added from the grid stream (k_evb_blend_terms: atomics) while this stream transforms and gathers; the gather folds the
+  // pair loop's accumulator in; the main stream joins behind the gather.  Needs: the single-join schedule, a gather call on this rank, and - when the
+  // pair force still sits in the sorted-order accumulator - the gather kernel that can fold it.
+  const bool gather_here = w->last_linear ? (ngrid > 0 || c->rank == 0) : true;
+  const bool aside = c->evb_blend_aside && one_wait && w11_was_one && (c->fsorted_pending ? (gather_here && pme_gather_can_fold(c)) : true);
+  bool folded = false;
+  if (aside) {
+    if (!w->ev_bterms) HIPCHK(hipEventCreateWithFlags(&w->ev_bterms, hipEventDisableTiming));
+    const hipStream_t sb = c->aux;      // the grid stream: the energy fetch (and the device-side solve, whose coefficients this kernel reads) precede it there
+    if (!w->side_by_A && !w->side_by_mark) HIPCHK(hipStreamWaitEvent(sb, w->ev_side, 0));
+    hipLaunchKernelGGL(k_evb_blend_terms, dim3(std::min<size_t>(1024, (n3 + 255) / 256)), dim3(256), 0, sb, n3, bt, dcoef ? dcoef + 1 + ngrid : (const double*)nullptr, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(w->ev_bterms, sb));
   }
+  double* const fold = (aside && c->fsorted_pending) ? c->d_fsorted.p : (double*)nullptr;
   auto join_before_blend = [&]() -> int {      // everything else that adds to the force array has to be in before the kernel that blends (k_evb_blend, or the fused gather)
     if (c->overlap && !one_wait) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0)); if (ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_rs, 0)); }
     if (c->overlap && !one_wait && w->mol_deferred) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // the principal diabat's per-molecule forces (aux3, behind the coupling chain)
@@ -1703,7 +1726,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
     // blended CHARGE grid Q_1 (rank 0) + sum_d c_d^2 DQ_d -> one transform pair -> blended potential theta_1 + sum_d c_d^2 G * DQ_d
     // (sum_d c_d^2 = 1 over all ranks, so the principal potential enters once, on rank 0)
     if (!ngrid) {
-      if (c->rank == 0) { if (fuse) CHK(join_before_blend()); CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, c->d_theta.p, fuse ? &gb : nullptr, &blended)); }
+      if (c->rank == 0) CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, c->d_theta.p, fold, &folded));
     } else {
       if (w->d_grids.alloc_room(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended charge grid)");
       if (fft_lds_can_patch(c) && c->evb_fft_patch) {      // 64^3: the forward transform applies the stencils to the planes of Q_1 itself - no copy of Q_1, no patch kernel
@@ -1733,19 +1756,20 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
         CHK(rc_conv);
         hipLaunchKernelGGL(k_grid_real, dim3(1024), dim3(256), 0, c->stream, K3, w->d_grids.p, w->d_pack.p);
       }
-      if (fuse) CHK(join_before_blend());
-      CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p, fuse ? &gb : nullptr, &blended));
+      CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p, fold, &folded));
     }
   } else {
     hipLaunchKernelGGL(k_evb_blend_grids, dim3(1024), dim3(256), 0, c->stream, K3, gc, dcoef, c->d_theta.p, w->d_grids.p, w->d_pack.p);
-    if (fuse) CHK(join_before_blend());
-    CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p, fuse ? &gb : nullptr, &blended));
+    CHK(pme_gather(c, nullptr, c->d_chg.p, c->d_force_recip.p, c->d_force.p, true, w->d_pack.p, fold, &folded));
   }
   // ... the special atoms' own-stencil corrections per diabat are in the delta store already (k_evb_recip_special ran at the end of the
   // diabat grid chain, before the host's turn); the blend consumes the store and re-zeroes it
   (void)nra; (void)d_ra;
-  if (!blended) {
-  if (!fuse) CHK(join_before_blend());
+  CHK(join_before_blend());
+  if (aside) {
+    if (fold && !folded) FAIL(MSEVB_ERR_STATE, "blend phase: the gather that was to fold the pair loop's accumulator in did not run");
+    HIPCHK(hipStreamWaitEvent(c->stream, w->ev_bterms, 0));      // the terms went in long ago (15 us of streaming beside 60 us of transform + gather)
+  } else {
   hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, dcoef ? dcoef + 1 + ngrid : (const double*)nullptr, w11, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p, 1,
                      c->fsorted_pending ? c->d_fsorted.p : (double*)nullptr, c->d_inv_perm.p, c->N);
   }
@@ -2579,7 +2603,7 @@ void evb_release(msevb_ctx* c) {
     DBuf<double>* db[] = {&w->d_exch, &w->d_part, &w->d_E, &w->d_dVspec, &w->d_sw, &w->d_sdw, &w->d_Fdelta, &w->d_F11, &w->d_pack, &w->d_com_atom};
     for (auto b : db) b->release();
     w->d_stencils.release(); w->d_Elq.release(); w->d_ow.release(); w->d_odw.release(); w->d_obase.release(); w->d_tabs.release(); w->d_sbase.release(); w->d_counter.release(); w->d_grids.release(); w->d_region.release(); w->d_cand.release(); w->d_desc.release();
-    hipEvent_t* ev[] = {&w->ev_chains, &w->ev_side, &w->ev_prefill, &w->ev_pairs, &w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA, &w->ev_solve, &w->ev_rs};
+    hipEvent_t* ev[] = {&w->ev_chains, &w->ev_side, &w->ev_prefill, &w->ev_pairs, &w->ev_fork2, &w->ev_join2, &w->ev_E, &w->ev_fetch, &w->ev_in, &w->ev_region, &w->ev_cpl, &w->ev_flush, &w->ev_fetchA, &w->ev_solve, &w->ev_rs, &w->ev_bterms};
     for (auto e : ev) if (*e) (void)hipEventDestroy(*e);
     if (w->h_region) (void)hipHostFree(w->h_region);
     if (w->h_count) (void)hipHostFree(w->h_count);

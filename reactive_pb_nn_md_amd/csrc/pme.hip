@@ -662,17 +662,17 @@ __global__ __launch_bounds__(512) void k_pme_gather_tiles(int K, int3 nc, int3 T
 // lane.  The table loads of an atom go out one trip ahead: trip 0's before the tile fill, from global (u, nearpt); the later ones before the
 // stencil sums of the trip in front of them, from the cell's (u, nearpt) staged in LDS beside the tile - no global load waits inside the loop.
 // Same sums in the same order as k_pme_gather_tiles: bit-identical forces.
-// BLEND (MS-EVB fast path): the gather of the blended potential is the last kernel that adds to the force of an atom, so the group that has just
-// finished an atom's reciprocal force also does that atom's Hellmann-Feynman blend (k_evb_blend's arithmetic, evb.hip): its eight lanes share the
-// terms (coefficient x delta / off-diagonal store, 24 B each), the pair loop's sorted-order accumulator is folded in and re-zeroed, the delta store
-// re-zeroed - one kernel and one pass over the force array less on the step's critical path (15 us + a launch gap at 98 k atoms).
-template <bool BLEND>
+// FOLD (MS-EVB fast path): the pair loop's force accumulator in cell-sorted order (d_fsorted, [3][N]) joins the atom's reciprocal force in the ONE
+// atomic add this kernel makes per component anyway and is re-zeroed - the atoms are walked in that order here, so the read is coalesced; with the
+// blend terms added from a side stream (k_evb_blend_terms, evb.hip) no k_evb_blend pass over the force array is left on the step's critical path.
+// (Round 4 also tried the whole blend in here: 68 us against 40 + 15 - the force STORES are in atom order, scattered 24-byte reads from this kernel.)
+template <bool FOLD>
 __global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, int3 T, const int* __restrict__ cell_start, const int* __restrict__ perm,
                                                              const double* __restrict__ chg, const int* __restrict__ base_s, const double* __restrict__ uscale_s, const int2* __restrict__ rows_s,
                                                              const double* __restrict__ B6, const double* __restrict__ B5, int G, int cap,
                                                              const double* __restrict__ theta, double conv, double k00, double k01,
                                                              double k02, double k10, double k11, double k12, double k20, double k21, double k22,
-                                                             double* __restrict__ F_recip, double* __restrict__ F, int atomic, int add_lo, int add_hi, const GatherBlend gb) {
+                                                             double* __restrict__ F_recip, double* __restrict__ F, int atomic, int add_lo, int add_hi, double* __restrict__ Fs, int NFs) {
   extern __shared__ double tile[];
   const int cidx = blockIdx.x;
   const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
@@ -738,15 +738,6 @@ __global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, 
     const bool live = ia < e;
     const int i = ni, b1 = nb1, b2 = nb2, b3 = nb3;
     const double q = nq;
-    double bx = 0.0, by = 0.0, bz = 0.0;
-    if (BLEND && live) {      // this atom's share of the blend terms, lane `sub` takes terms sub, sub + 8, ...: the loads go out HERE, at the top of the trip, and meet
-      for (int t = sub; t < gb.n; t += 8) {      // the reciprocal force at its end (at the end of the trip their latency was the trip's tail: +25 us on the kernel)
-        const int sl = gb.slot[t];
-        const double cf = gb.dc ? gb.dc[t] : gb.coef[t];
-        if (sl < 0) { const double* p = gb.Foff + (size_t)(-sl - 1) * gb.fstride + 3 * (size_t)i; bx += cf * p[0]; by += cf * p[1]; bz += cf * p[2]; }
-        else { double* p = gb.Fdiag + (size_t)sl * gb.fstride + 3 * (size_t)i; bx += cf * p[0]; by += cf * p[1]; bz += cf * p[2]; p[0] = 0.0; p[1] = 0.0; p[2] = 0.0; }      // (the delta store is consumed)
-      }
-    }
     double tw[3], td[3];
     pme_taps3_finish(nt, tw, td);      // (first use of the table values that went out one trip ago)
     const double w3 = tw[2], d3 = td[2];
@@ -802,10 +793,6 @@ __global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();      // (the next trip's taps overwrite xw)
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); f3 += __shfl_xor(f3, o, 64); }
-    if (BLEND) {
-#pragma unroll
-      for (int o = 4; o > 0; o >>= 1) { bx += __shfl_xor(bx, o, 64); by += __shfl_xor(by, o, 64); bz += __shfl_xor(bz, o, 64); }
-    }
     if (live && sub == 0) {
       const double sc = q * conv;
       f1 *= sc; f2 *= sc; f3 *= sc;
@@ -814,11 +801,12 @@ __global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, 
       const double fy = -Kd * (k01 * f1 + k11 * f2 + k21 * f3);
       const double fz = -Kd * (k02 * f1 + k12 * f2 + k22 * f3);
       F_recip[3 * i] = fx; F_recip[3 * i + 1] = fy; F_recip[3 * i + 2] = fz;
-      if (BLEND) {      // F = w11 (F11 + pair loop's accumulator) + reciprocal force of the blended potential + sum of the terms
-        double g1 = F[3 * i], g2 = F[3 * i + 1], g3 = F[3 * i + 2];
-        if (gb.Fs) { double* a = gb.Fs + ia; g1 += a[0]; g2 += a[gb.N]; g3 += a[2 * (size_t)gb.N]; a[0] = 0.0; a[gb.N] = 0.0; a[2 * (size_t)gb.N] = 0.0; }
+      if (FOLD) {      // + the pair loop's accumulator of this atom (sorted position ia), consumed
+        double* a = Fs + ia;
+        const double g1 = a[0], g2 = a[NFs], g3 = a[2 * (size_t)NFs];
+        a[0] = 0.0; a[NFs] = 0.0; a[2 * (size_t)NFs] = 0.0;
         const bool add = i >= add_lo && i < add_hi;
-        F[3 * i] = gb.w11 * g1 + (add ? fx : 0.0) + bx; F[3 * i + 1] = gb.w11 * g2 + (add ? fy : 0.0) + by; F[3 * i + 2] = gb.w11 * g3 + (add ? fz : 0.0) + bz;
+        atomicAdd(&F[3 * i], g1 + (add ? fx : 0.0)); atomicAdd(&F[3 * i + 1], g2 + (add ? fy : 0.0)); atomicAdd(&F[3 * i + 2], g3 + (add ? fz : 0.0));
       } else
       if (F && i >= add_lo && i < add_hi) {
         if (atomic) { atomicAdd(&F[3 * i], fx); atomicAdd(&F[3 * i + 1], fy); atomicAdd(&F[3 * i + 2], fz); }
@@ -1100,7 +1088,7 @@ bool pme_tiles_ok(const msevb_ctx* c) {
   const size_t tile_bytes = (size_t)spread_plane_stride(T) * T.z * sizeof(double) + (size_t)SPREAD_CHUNK * (18 * 8 + 8 + 12);
   return c->cells_valid && c->spread_tiles && tile_bytes <= 64 * 1024 && T.x <= c->K && T.y <= c->K && T.z <= c->K;
 }
-bool pme_gather_can_blend(const msevb_ctx* c) {      // mirrors the dispatch of pme_gather below
+bool pme_gather_can_fold(const msevb_ctx* c) {      // mirrors the dispatch of pme_gather below
   const bool mfma = c->gather_mfma && c->cells_valid && c->weights_valid;
   return !mfma && pme_tiles_ok(c) && !c->weights_valid && !c->weights_side;
 }
@@ -1145,8 +1133,8 @@ int pme_prepare_atoms(msevb_ctx* c, bool with_indices) {
   return MSEVB_OK;
 }
 
-int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic, const double* theta, const GatherBlend* blend, bool* blended) {
-  if (blended) *blended = false;
+int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_recip, double* F_add, bool atomic, const double* theta, double* Fs_fold, bool* folded) {
+  if (folded) *folded = false;
   const int N = c->N;
   int add_lo, add_hi;
   shard_range(c, N, add_lo, add_hi);
@@ -1170,15 +1158,14 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
         const int cap = std::min(std::max((int)(c->cell_atoms_max * 1.05) + 1, 16), 1024);      // (the largest cell of the last build whose statistics the host has seen)
         const size_t lds = tile_bytes + (size_t)c->pme_tile_threads * 24 + (size_t)cap * 48 + 16;
         if (lds > 160 * 1024) FAIL(MSEVB_ERR_LIMIT, "pme_gather: cell too large for the weight-free gather (set option pme_weightless=0)");
-        static const GatherBlend no_blend = {};
-        const bool fuse = blend && blended && F_add;
+        const bool fuse = Fs_fold && folded && F_add && atomic;
         auto kern = fuse ? k_pme_gather_tiles_wl<true> : k_pme_gather_tiles_wl<false>;
         int& attr = fuse ? c->attr_gather_wl_b : c->attr_gather_wl;
         if (lds > 64 * 1024 && attr < (int)lds) { HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = (int)lds; }
         hipLaunchKernelGGL(kern, dim3(ncell), dim3(c->pme_tile_threads), lds, c->stream, c->K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T, c->d_cell_start.p, c->d_perm.p,
                            chg, c->d_base_s.p, c->d_uscale_s.p, c->d_rows_s.p, c->d_B6.p, c->d_B5.p, c->spline_grid, cap, theta ? theta : c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
-                           c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, atomic ? 1 : 0, add_lo, add_hi, fuse ? *blend : no_blend);
-        if (fuse) *blended = true;
+                           c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, atomic ? 1 : 0, add_lo, add_hi, fuse ? Fs_fold : (double*)nullptr, c->N);
+        if (fuse) *folded = true;
       } else
       hipLaunchKernelGGL(k_pme_gather_tiles, dim3(ncell), dim3(c->pme_tile_threads), tile_bytes, c->stream, c->K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T, c->d_cell_start.p, c->d_perm.p,
                          chg, c->d_base.p, c->d_w.p, c->d_dw.p, theta ? theta : c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2],

@@ -229,11 +229,11 @@ def _schedule_run(spec, opts):
 
 @pytest.mark.parametrize("opts", [{"evb_defer_fold": 0}, {"evb_prelaunch_blend": 1, "evb_device_solve": 0}, {"evb_defer_molecules": 1}, {"evb_region_main": 1},
                                   {"evb_coupling_blocks": 96}, {"evb_recip_linear": 0}, {"fft_own": 0, "evb_defer_fold": 0, "evb_prelaunch_blend": 1, "evb_device_solve": 0},
-                                  {"overlap": 0, "graphs": 0}, {"evb_device_solve": 0}, {"evb_device_solve": 2}, {"evb_fuse_blend": 1}, {"pair_pipe": 0},
-                                  {"evb_device_solve": 0, "evb_fuse_blend": 1}, {"step_fuse_refresh": 0}, {"evb_fft_patch": 0}, {"evb_fft_patch": 0, "evb_device_solve": 0}])
+                                  {"overlap": 0, "graphs": 0}, {"evb_device_solve": 0}, {"evb_device_solve": 2}, {"evb_blend_aside": 0}, {"pair_pipe": 0},
+                                  {"evb_device_solve": 0, "evb_blend_aside": 0}, {"step_fuse_refresh": 0}, {"evb_fft_patch": 0}, {"evb_fft_patch": 0, "evb_device_solve": 0}])
 def test_schedule_options_leave_the_forces_alone(opts):
     """the switchable pieces of the step schedule at BASELINE.json configs[2]: same Hamiltonian, same Hellmann-Feynman
-    force, same 12-step trajectory as the default schedule (device-side solve by repeated squaring); among them the blend inside the gather, the
+    force, same 12-step trajectory as the default schedule (device-side solve by repeated squaring); among them the blend as one kernel behind the gather, the
     host's Jacobi (evb_device_solve = 0, the reference's row-cyclic sweep) and the device's round-robin Jacobi (= 2)"""
     spec = _synthetic(32, 8, 11, 64)
     if "default" not in _SCHED_DEFAULT:

@@ -194,7 +194,7 @@ int msevb_reset_phase_times(msevb_ctx* ctx);
                             pme_side_weights (0), spread_mfma (0), spread_bricks (0), gather_mfma (0), pme_tile_threads (512), fft_batch
      schedule             : overlap (1: four streams), graphs (1: front end replayed as a hipGraph), evb_speculate (1), evb_publish_spin (1),
                             evb_late_mol_join (1), evb_single_join (1), evb_defer_fold (1), evb_pme_split (1), evb_defer_molecules (0),
-                            evb_prelaunch_blend (0), evb_region_main (0), evb_region_aside (0), evb_pair_first (0), evb_device_solve (0),
+                            evb_blend_aside (1), evb_fft_patch (1), step_fuse_refresh (1), evb_region_main (0), evb_region_aside (0), evb_pair_first (0), evb_device_solve (1: squaring + Jacobi fallback on the device, 2: Jacobi on the device, 0: host),
                             evb_coupling_blocks (0 = auto), pin_host_arrays (0)
      multi-GPU            : shard_principal (set by msevb_comm_init)
      measurement          : phase_timing (0), phase_timing_stride (8) */

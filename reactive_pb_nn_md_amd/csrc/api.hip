@@ -679,7 +679,7 @@ int total_force_enqueue(msevb_ctx* c) {
     stamp(c, 1, c->stream);
     CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));                    // main: the pair loop (longest) goes out first
     stamp(c, 2, c->stream);
-    if (c->evb_pair_first) { if (!c->ev_pair_done) HIPCHK(hipEventCreateWithFlags(&c->ev_pair_done, hipEventDisableTiming)); HIPCHK(hipEventRecord(c->ev_pair_done, c->stream)); }
+    if (c->evb_pair_first || c->molecules_after_pair_now) { if (!c->ev_pair_done) HIPCHK(hipEventCreateWithFlags(&c->ev_pair_done, hipEventDisableTiming)); HIPCHK(hipEventRecord(c->ev_pair_done, c->stream)); }
     if (!c->defer_molecules_now)                                     // (the MS-EVB call sends them out itself, behind its coupling chain on the same stream)
       CHK(molecule_forces(c, S_ELEC_INTRA, true, true, c->aux3));    // aux3: per-molecule terms (few, long threads); aux2 stays free for the
                                                                      // EVB descriptors + environment chain, which the host enqueues next
@@ -805,10 +805,9 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "evb_late_mol_join") { c->evb_late_mol_join = v != 0.0; return MSEVB_OK; }
   if (s == "evb_single_join") { c->evb_single_join = v != 0.0; return MSEVB_OK; }
   if (s == "evb_defer_fold") { c->evb_defer_fold = v != 0.0; return MSEVB_OK; }
-  if (s == "evb_prelaunch_blend") { c->evb_prelaunch_blend = v != 0.0; return MSEVB_OK; }
   if (s == "evb_coupling_blocks") { c->evb_coupling_blocks = (int)v; return MSEVB_OK; }
   if (s == "evb_region_main") { c->evb_region_main = v != 0.0; return MSEVB_OK; }
-  if (s == "evb_defer_molecules") { c->evb_defer_molecules = v != 0.0; return MSEVB_OK; }
+  if (s == "evb_defer_molecules") { c->evb_defer_molecules = v != 0.0; c->evb_molecules_after_pair = v == 2.0; return MSEVB_OK; }      // 1: behind the coupling chain; 2: behind the PAIR LOOP (in the blend phase's window)
   if (s == "pme_tile_threads") { c->pme_tile_threads = v >= 512 ? 512 : 256; c->pme_graph_key[0] = 0; if (c->pme_graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)c->pme_graph_exec); c->pme_graph_exec = nullptr; } return MSEVB_OK; }
   if (s == "fft_own") { c->fft_own = v != 0.0; return MSEVB_OK; }
   if (s == "spread_bricks") { c->spread_bricks = v != 0.0; return MSEVB_OK; }

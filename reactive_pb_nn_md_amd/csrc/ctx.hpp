@@ -240,9 +240,9 @@ struct msevb_ctx {
   bool pme_split_now = false, pme_split_pending = false, evb_pme_split = true; int pme_split_slot = 0;      // MS-EVB fast path: spread now, solve later (behind the stencil-pair kernels on aux)
   bool skip_side_joins_now = false, evb_single_join = true;      // MS-EVB fast path: the main stream waits ONCE for the side streams (a barrier packet behind the pair loop costs several us each)
   bool defer_fold_now = false, fsorted_pending = false, evb_defer_fold = true;      // MS-EVB fast path: k_pair_fold's work is done by k_evb_blend
-  bool evb_prelaunch_blend = false;        // option: the blend phase is enqueued before the host's Jacobi and waits on the device for its coefficients (evb.hip, k_evb_wait_coef)
   int evb_coupling_blocks = 0;            // option: workgroups per coupling in k_evb_coupling (0: the built-in choice)
   bool evb_region_main = false;           // option: the neighbourhood kernel on the main stream (see evb.hip, step 1)
+  bool molecules_after_pair_now = false, evb_molecules_after_pair = false;      // evb_defer_molecules = 2: the per-molecule kernel waits for the pair loop's end and runs beside the blend phase's transform and gather (an otherwise idle GPU)
   bool defer_molecules_now = false, evb_defer_molecules = false;      // MS-EVB call: the per-molecule kernel goes out BEHIND the coupling chain on aux3 (the host's
                                                                      // turn waits for that chain, only the blend for the per-molecule terms)
   bool shard_now = false;        // true while the EVB force call enqueues the principal diabat

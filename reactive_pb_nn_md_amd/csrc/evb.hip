@@ -859,10 +859,11 @@ __global__ __launch_bounds__(256) void k_evb_recip_pairs(GridRanges gr, const St
 __device__ __forceinline__ void evb_wait_mark(const long long* mark, long long seq, double* fault) {
   if (threadIdx.x == 0) {
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(mark, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+    while (__hip_atomic_load(mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {      // (relaxed polls: an acquire per poll is a cache invalidation per poll, from every waiting workgroup)
       if (wall_clock64() - t0 > 200000000LL) { if (fault) *fault = 2.0; break; }
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(8);
     }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
   }
   __syncthreads();
 }
@@ -1377,28 +1378,8 @@ __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, 
   if (sa.on) { __threadfence_block(); __syncthreads(); evb_solve_body(sa); }
 }
 
-// The blend phase is enqueued BEFORE the host has the ground-state vector: this kernel, first of the phase on the main stream, waits until
-// the host has written the blend coefficients to pinned memory (sequence number behind them), then copies them to device memory for
-// the kernels behind it.  What it saves is the launch latency of the phase (~6 launches, 25-35 us) between the host's Jacobi and the
-// first blend kernel.  It always terminates: the host writes -seq on every error path (CoefGuard), and after ~5 s of wall clock the
-// kernel raises the sticky fault flag and goes on (the force call then ends in MSEVB_ERR_NUMERIC).
 // last kernel of a side chain: its stream has finished everything in front of it
 __global__ void k_evb_mark(long long* p, long long seq) { __hip_atomic_store(p, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-
-__global__ void k_evb_wait_coef(const double* h_coef, volatile long long* flag, long long seq, int n, double* __restrict__ d_coef, double* __restrict__ fault) {
-  if (threadIdx.x == 0) {
-    const long long t0 = wall_clock64();      // 100 MHz
-    for (;;) {
-      const long long f = __hip_atomic_load((const long long*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (fine-grained host memory: see the allocation)
-      if (f == seq || f == -seq) break;
-      if (wall_clock64() - t0 > 500000000LL) { *fault = 5.0; break; }
-      __builtin_amdgcn_s_sleep(4);
-    }
-  }
-  __syncthreads();
-  __threadfence_system();
-  for (int k = threadIdx.x; k < n; k += blockDim.x) d_coef[k] = ((const volatile double*)h_coef)[k];
-}
 
 __global__ void k_sum_rows(int nrow, int ncol, int stride, const double* __restrict__ part, double* __restrict__ out) {
   const int r = blockIdx.x;
@@ -1460,7 +1441,6 @@ struct EvbWork {   // persistent device scratch of one context
   // what the last force call left behind, for msevb_evb_partial_blend on the fast path (virtual-rank tests)
   int last_ngrid = 0, last_nra = 0, last_grid_of[MAX_DIABATS]; const RecipAtom* last_d_ra = nullptr; bool last_fast = false;
   bool counters_dirty = true, dv_dirty = true, mol_deferred = false;
-  double* h_coef = nullptr; long long seq_C = 0;      // pinned, coherent: blend coefficients for k_evb_wait_coef + its flag behind them
   hipEvent_t ev_chains = nullptr;      // environment chain + couplings done (recorded on the descriptor stream)
   bool side_by_A = false;        // every side chain the blend phase needs has ended once fetch A is published (spinning publish kernel, prefill in front of it,
                                  // no kernel behind it): the host, which has seen fetch A, enqueues the blend phase without a GPU-side wait for ev_side
@@ -1716,7 +1696,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
     if (one_wait && w->side_wo_mol) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0));      // ... which the ONE event left out: patch, solve and gather of the blend phase run beside that kernel
     return MSEVB_OK;
   };
-  if (one_wait && !w->side_by_A && !w->side_by_mark) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0));      // (side_by_A: whoever enqueues this phase has seen fetch A, or has put k_evb_wait_coef in front of it)
+  if (one_wait && !w->side_by_A && !w->side_by_mark) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0));      // (side_by_A: whoever enqueues this phase has seen fetch A)
   else if (c->overlap && ngrid && !one_wait) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_E, 0));           // convolved diabat grids / grid energies (aux)
   stamp(c, 8, c->stream);
   if (w->d_pack.alloc(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended potential)");
@@ -1856,6 +1836,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   c->skip_gather_now = fast;
   const bool defer_mol = c->overlap && c->evb_defer_molecules;
   c->defer_molecules_now = defer_mol;
+  c->molecules_after_pair_now = defer_mol && c->evb_molecules_after_pair;
   c->ev_pos_ready = w->ev_in;      // new positions: what the PME front end waits for (not for the neighbourhood kernels behind them)
   c->defer_fold_now = fast && c->evb_defer_fold;      // the blend kernel folds the pair loop's sorted-order accumulator in (k_evb_blend)
   const bool single_join = fast && c->overlap && c->evb_single_join;      // the main stream does not wait for the side streams one by one behind the pair loop
@@ -1868,7 +1849,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   if (side_w) CHK(pme_side_weights(c, c->aux3, w->ev_in));
   const int rc_tfe = total_force_enqueue(c);
   c->weights_needed_now = false;
-  c->shard_now = false; c->skip_gather_now = false; c->defer_molecules_now = false; c->ev_pos_ready = nullptr; c->defer_fold_now = false; c->skip_side_joins_now = false; c->pme_split_now = false; c->refresh_side_now = false;
+  c->shard_now = false; c->skip_gather_now = false; c->defer_molecules_now = false; c->molecules_after_pair_now = false; c->ev_pos_ready = nullptr; c->defer_fold_now = false; c->skip_side_joins_now = false; c->pme_split_now = false; c->refresh_side_now = false;
   CHK(rc_tfe);
   if (side_w) c->weights_side = true;      // (total_force_enqueue cleared it)
   HT(2);
@@ -2226,6 +2207,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_cpl, so));
   }
   if (defer_mol) {      // the principal diabat's per-molecule terms: behind the coupling chain on aux3 (they ran in front of it and held it up by ~80 us)
+    if (c->evb_molecules_after_pair && c->ev_pair_done) HIPCHK(hipStreamWaitEvent(c->aux3, c->ev_pair_done, 0));      // ... and behind the pair loop: they fill the blend phase's window instead of taking CUs from the pair loop
     c->shard_now = c->shard_principal && c->n_ranks > 1;
     const int rc_mol = molecule_forces(c, S_ELEC_INTRA, true, true, c->aux3);
     c->shard_now = false;
@@ -2421,28 +2403,6 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     CHK(rc_b);
     phase_end(c, PH_EVB_BLEND);
   }
-  // host-side solve, blend phase enqueued ahead of it: the phase's kernels wait on the main stream behind k_evb_wait_coef for the
-  // coefficients the host writes to pinned memory after its Jacobi (single rank, fast path)
-  const bool prelaunch = !dev_solve && fast && c->overlap && c->n_ranks == 1 && !c->nccl_comm && c->evb_prelaunch_blend;
-  struct CoefGuard { volatile long long* flag = nullptr; long long seq = 0; ~CoefGuard() { if (flag) *flag = -seq; } } coef_guard;      // any early return releases the waiting kernel
-  int n_coef = 0;
-  if (prelaunch) {
-    BlendTerms bt0;
-    (void)blend_terms(c, D, nullptr, bt0);
-    n_coef = 1 + ngrid + bt0.n;
-    if (w->d_coef.alloc(1 + MAX_DIABATS + 2 * MAX_DIABATS)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blend coefficients)");
-    // COHERENT (fine-grained) pinned memory: a running kernel reads it uncached.  Default pinned memory may sit in the GPU's L2 until a
-    // kernel boundary - the waiting kernel then saw the host's flag ~30 us late (measured)
-    if (!w->h_coef) { HIPCHK(hipHostMalloc((void**)&w->h_coef, (2 + 3 * MAX_DIABATS) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped)); memset(w->h_coef, 0, (2 + 3 * MAX_DIABATS) * sizeof(double)); }
-    volatile long long* cflag = (volatile long long*)(w->h_coef + 1 + 3 * MAX_DIABATS);
-    const long long seq = ++w->seq_C;
-    hipLaunchKernelGGL(k_evb_wait_coef, dim3(1), dim3(64), 0, c->stream, (const double*)w->h_coef, cflag, seq, n_coef, w->d_coef.p, c->d_energies.p + S_FAULT);
-    HIPCHK(hipGetLastError());
-    coef_guard.flag = cflag; coef_guard.seq = seq;
-    phase_begin(c, PH_EVB_BLEND);
-    CHK(fast_blend_phase(c, w, D, nullptr, grid_of.data(), ngrid, nra, d_ra, w->d_coef.p));
-    phase_end(c, PH_EVB_BLEND);
-  }
   HT(8);
   // ---- 9. Hamiltonian without the principal diabat's energy (H' = H - E0 I), from fetch A (or from the device-side solve)
   if (c->overlap) {
@@ -2520,18 +2480,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     for (int i = 1; i < D; ++i) if (ev[i] < eg) { eg = ev[i]; g = i; }
     for (int i = 0; i < D; ++i) c->eigvec[i] = v[(size_t)i * D + g];
   }
-  if (!dev_solve && !prelaunch) phase_begin(c, PH_EVB_BLEND);
+  if (!dev_solve) phase_begin(c, PH_EVB_BLEND);
   if (dev_solve) {
-  } else if (prelaunch) {      // the phase is waiting on the main stream: coefficients {c_0^2, c_d^2 per grid, blend terms} in the order k_evb_solve writes them
-    BlendTerms bt;
-    (void)blend_terms(c, D, c->eigvec, bt);
-    w->h_coef[0] = c->eigvec[0] * c->eigvec[0];
-    for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) w->h_coef[1 + grid_of[d]] = c->eigvec[d] * c->eigvec[d];
-    for (int t = 0; t < bt.n; ++t) w->h_coef[1 + ngrid + t] = bt.coef[t];
-    if (1 + ngrid + bt.n != n_coef) FAIL(MSEVB_ERR_STATE, "blend coefficient count changed between the enqueue and the solve");
-    std::atomic_thread_fence(std::memory_order_seq_cst);
-    *coef_guard.flag = coef_guard.seq;
-    coef_guard.flag = nullptr;      // released
   } else if (fast) {
     CHK(fast_blend_phase(c, w, D, c->eigvec, grid_of.data(), ngrid, nra, d_ra));
   } else {
@@ -2541,7 +2491,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   }
   HIPCHK(hipGetLastError());
   if (c->nccl_comm) CHK(msevb_comm_allreduce_forces(c));
-  if (!dev_solve && !prelaunch) phase_end(c, PH_EVB_BLEND);
+  if (!dev_solve) phase_end(c, PH_EVB_BLEND);
   HT(10);
   {   // the blend is enqueued: now the principal energy (it shifts the whole diagonal, not the ground-state vector)
     double E0 = 0.0;
@@ -2610,7 +2560,6 @@ void evb_release(msevb_ctx* c) {
     if (w->h_desc) (void)hipHostFree(w->h_desc);
     if (w->h_solve) (void)hipHostFree(w->h_solve);
     if (w->h_flag) (void)hipHostFree(w->h_flag);
-    if (w->h_coef) (void)hipHostFree(w->h_coef);
     w->d_coef.release(); w->d_plan.release(); w->d_sphere.release(); w->d_check.release(); w->d_refresh_scratch.release(); w->d_chain_done.release();
     if (w->h_E) (void)hipHostFree(w->h_E);
     delete w;

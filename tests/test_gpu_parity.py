@@ -227,8 +227,8 @@ def _schedule_run(spec, opts):
     return out
 
 
-@pytest.mark.parametrize("opts", [{"evb_defer_fold": 0}, {"evb_prelaunch_blend": 1, "evb_device_solve": 0}, {"evb_defer_molecules": 1}, {"evb_region_main": 1},
-                                  {"evb_coupling_blocks": 96}, {"evb_recip_linear": 0}, {"fft_own": 0, "evb_defer_fold": 0, "evb_prelaunch_blend": 1, "evb_device_solve": 0},
+@pytest.mark.parametrize("opts", [{"evb_defer_fold": 0}, {"evb_defer_molecules": 1}, {"evb_defer_molecules": 2}, {"evb_region_main": 1},
+                                  {"evb_coupling_blocks": 96}, {"evb_recip_linear": 0}, {"fft_own": 0, "evb_defer_fold": 0, "evb_device_solve": 0},
                                   {"overlap": 0, "graphs": 0}, {"evb_device_solve": 0}, {"evb_device_solve": 2}, {"evb_blend_aside": 0}, {"pair_pipe": 0},
                                   {"evb_device_solve": 0, "evb_blend_aside": 0}, {"step_fuse_refresh": 0}, {"evb_fft_patch": 0}, {"evb_fft_patch": 0, "evb_device_solve": 0}])
 def test_schedule_options_leave_the_forces_alone(opts):

@@ -89,9 +89,11 @@ int msevb_create(msevb_ctx** out, int device_id) {
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     // the side chains feed the host's turn (Hamiltonian, blend coefficients), the pair loop only has to be done when the blend starts:
     // side streams above the main one (+1 % measured; the opposite order lost 10 %)
-    HIPCHK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi));
-    HIPCHK(hipStreamCreateWithPriority(&c->aux2, hipStreamNonBlocking, hi));
-    HIPCHK(hipStreamCreateWithPriority(&c->aux3, hipStreamNonBlocking, hi));
+    const char* sp = getenv("MSEVB_SIDE_PRIORITY");      // (diagnostic) "normal" / "low": side streams at the main stream's priority / below it
+    const int pr = !sp ? hi : (sp[0] == 'l' ? lo : 0);
+    HIPCHK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, pr));
+    HIPCHK(hipStreamCreateWithPriority(&c->aux2, hipStreamNonBlocking, pr));
+    HIPCHK(hipStreamCreateWithPriority(&c->aux3, hipStreamNonBlocking, pr));
   }
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork0, hipEventDisableTiming));
@@ -663,8 +665,12 @@ int total_force_enqueue(msevb_ctx* c) {
     CHK(pme_front(c, S_RECIP, true));
   }
   if (rebuild) {      // cells + sorted arrays now; the rows are filled below, beside what only needs the cells
-    CHK(nb_build_begin(c)); c->flag_verlet_list = 0;
-    HIPCHK(hipMemsetAsync(c->d_force.p, 0, 3 * (size_t)c->N * 8, c->stream));
+    c->rebuild_zero_force_now = true;      // (k_gather_sorted zeroes the force array on its way: no fill command)
+    const int rc_b = nb_build_begin(c);
+    const bool zeroed = c->rebuild_zero_force_now == false;
+    c->rebuild_zero_force_now = false;
+    CHK(rc_b); c->flag_verlet_list = 0;
+    if (!zeroed) HIPCHK(hipMemsetAsync(c->d_force.p, 0, 3 * (size_t)c->N * 8, c->stream));
   } else if (c->refresh_side_now && c->overlap && c->ev_pos_ready) {      // beside the neighbourhood kernel, which holds the main stream right now
     if (!c->ev_refresh) HIPCHK(hipEventCreateWithFlags(&c->ev_refresh, hipEventDisableTiming));
     HIPCHK(hipStreamWaitEvent(c->aux3, c->ev_pos_ready, 0));

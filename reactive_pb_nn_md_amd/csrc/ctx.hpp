@@ -332,6 +332,7 @@ struct msevb_ctx {
   bool nbr_check_pending = false;      // a deferred rebuild's row statistics have not been looked at yet
   int* h_nbr_stats = nullptr;          // pinned: {tile_max, pad, count_max, pad, count_sum lo, hi}
   int flag_verlet_list = 0;
+  bool rebuild_zero_force_now = false, stats_zeroed_now = false;      // list rebuild inside a force call: k_gather_sorted zeroes the force array (and clears the flag) / has zeroed the row statistics
   bool step_fuse_refresh = true; int refresh_fused_nb = 0;      // option step_fuse_refresh: k_step_first_half does k_step_refresh's work on steps that keep their list (integrate.hip); > 0: blocks whose displacement partial sums await k_top2_final
   DBuf<double4> d_posq;        // sorted {x,y,z,q}
   DBuf<double> d_fsorted;      // [N][3] force accumulator of the half-list pair kernel in SORTED order (coalesced atomics), folded into d_force and re-zeroed by k_pair_fold

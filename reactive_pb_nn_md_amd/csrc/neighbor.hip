@@ -125,14 +125,20 @@ __global__ void k_cell_bounds(int N, int ncell, const int* __restrict__ keys, in
 
 __global__ void k_gather_sorted(int N, const int* __restrict__ perm, const double* __restrict__ xyz, const double* __restrict__ chg,
                                 const int* __restrict__ atype, const int* __restrict__ mol_of, double4* __restrict__ posq,
-                                int* __restrict__ type_s, int* __restrict__ mol_s, int* __restrict__ inv_perm) {
+                                int* __restrict__ type_s, int* __restrict__ mol_s, int* __restrict__ inv_perm,
+                                double* __restrict__ F_zero = nullptr, int* __restrict__ prune_mode = nullptr, int* __restrict__ stats_zero = nullptr) {
+  // the small resets of a list rebuild ride along (each was a fill COMMAND of its own on the stream, 7-17 us apiece in front of the row kernel):
+  // force accumulator zeroed (rebuild inside a force call), pair loop told to prune (nb_prune_reset), row statistics zeroed
   int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0 && prune_mode) { prune_mode[0] = 1; prune_mode[2] = 0; }
+  if (k < 8 && stats_zero) stats_zero[k] = 0;
   if (k >= N) return;
   int i = perm[k];
   posq[k] = make_double4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], chg[i]);
   type_s[k] = atype[i];
   mol_s[k] = mol_of[i];
   if (inv_perm) inv_perm[i] = k;
+  if (F_zero) { F_zero[3 * i] = 0.0; F_zero[3 * i + 1] = 0.0; F_zero[3 * i + 2] = 0.0; }
 }
 
 // out[0]: largest number of atoms in the neighbourhood (distinct neighbour cells) of any cell = LDS tile of the full-list build;
@@ -505,10 +511,15 @@ static BoxDev make_box(const msevb_ctx* c) {
 
 int nb_refresh_sorted(msevb_ctx* c) {
   const int N = c->N;
+  const bool reset_here = !c->prune_freeze && c->prune && c->d_prune_mode.p;      // nb_prune_reset's two stores, by the kernel
+  c->stats_zeroed_now = c->d_tile_max.p != nullptr;
   hipLaunchKernelGGL(k_gather_sorted, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, c->d_perm.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p,
-                     c->d_mol_of.p, c->d_posq.p, c->d_type_sorted.p, c->d_mol_sorted.p, c->d_inv_perm.p);
+                     c->d_mol_of.p, c->d_posq.p, c->d_type_sorted.p, c->d_mol_sorted.p, c->d_inv_perm.p,
+                     c->rebuild_zero_force_now ? c->d_force.p : (double*)nullptr, reset_here ? c->d_prune_mode.p : (int*)nullptr, c->d_tile_max.p);
   HIPCHK(hipGetLastError());
-  return c->prune_freeze ? MSEVB_OK : nb_prune_reset(c);      // positions were replaced wholesale: whatever pruned rows exist are not known to cover them
+  c->rebuild_zero_force_now = false;      // done (the caller looks)
+  if (reset_here || c->prune_freeze) return MSEVB_OK;
+  return nb_prune_reset(c);      // positions were replaced wholesale: whatever pruned rows exist are not known to cover them
 }
 
 // the next pair loop runs on the full rows and writes fresh pruned ones
@@ -641,7 +652,7 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
       int tile_cap = NBR_TILE_CAP2;
       const int seen = c->pair_tiles ? c->half_tile_max : c->tile_atoms_max;
       if (seen > 0 && seen * 1.03 > NBR_TILE_CAP2) tile_cap = std::min(NBR_TILE_CAP, ((int)(seen * 1.08) + 63) & ~63);
-      if (want_inline) { HIPCHK(hipMemsetAsync(d_stats, 0, 8 * sizeof(int), c->stream)); inline_stats = true; }
+      if (want_inline) { if (!c->stats_zeroed_now) HIPCHK(hipMemsetAsync(d_stats, 0, 8 * sizeof(int), c->stream)); c->stats_zeroed_now = false; inline_stats = true; }      // (k_gather_sorted of this rebuild has zeroed them already; a repeated fill zeroes them itself)
       hipLaunchKernelGGL(kern, dim3(ncell), dim3(1024), (size_t)tile_cap * NBR_TILE_BYTES + 64, c->stream, nc, c->d_cell_start.p, c->d_posq.p, c->d_mol_sorted.p, c->d_type_sorted.p, box, rv2,
                          c->nbr_cap, tile_cap, c->d_nbr_count.p, c->d_nbr_start.p, c->d_nbr.p, want_inline ? d_stats : (int*)nullptr, c->d_nbr_split.p);
     } else

@@ -29,7 +29,7 @@ def main():
     e_ref, F_ref = h.ms_evb_calculate_total_force_energy()
     ev = h.evb_state()["eigvec"].copy()
     h.close()
-    modes = ["default + 12 MD steps", "spread_mfma", "virtual rank of 8", "gather_mfma + stored weights"]
+    modes = ["default + 12 MD steps", "spread_mfma", "virtual rank of 8", "gather_mfma + stored weights"]      # spread_mfma: + 12 MD steps as well
     errors, counts, t0 = [], {m: 0 for m in modes}, time.time()
     for it in range(n_it):
         mode = modes[it % len(modes)]
@@ -50,7 +50,7 @@ def main():
                     h.evb_partial_blend(ev, download=False)
                 elif abs(e - e_ref) > 1e-9 * abs(e_ref) or not np.all(np.isfinite(F)) or np.abs(F - F_ref).max() > 1e-7:
                     errors.append({"iteration": it, "mode": mode, "error": "result differs: dE %.3e max dF %.3e" % (e - e_ref, np.abs(F - F_ref).max())})
-            if mode == "default + 12 MD steps":
+            if mode in ("default + 12 MD steps", "spread_mfma"):      # (the round-3 failure of the spread_mfma test came in its 25-step trajectory)
                 h.set_velocities(vel)
                 en = h.md_integrate_atomic(12, spec.delta_t, use_evb=True)
                 if not np.all(np.isfinite(en)):

@@ -409,6 +409,7 @@ int msevb_finalize(msevb_ctx* c) {
   HIPCHK(hipMemset(c->d_vel.p, 0, 3 * (size_t)N * 8));
   HIPCHK(hipMemset(c->d_force.p, 0, 3 * (size_t)N * 8));
   HIPCHK(hipMemset(c->d_energies.p, 0, N_SLOTS * 8));
+  HIPCHK(hipDeviceSynchronize());      // (hipMemset may return early; the library's non-blocking streams do not wait for the null stream)
   CHK(pme_setup(c));
   c->list_valid = false;
   c->flag_verlet_list = 1;

@@ -2181,7 +2181,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   stamp(c, 4, sr);
   const bool pub_spin = c->overlap && c->evb_publish_spin;      // fetch A's publish kernel waits for the chains' marks, not for their events
   if (pub_spin) {
-    if (!w->d_chain_done.p) { if (w->d_chain_done.alloc(4)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (chain marks)"); HIPCHK(hipMemset(w->d_chain_done.p, 0, 32)); }      // (synchronous, once per context: the two marks come from different streams)
+    if (!w->d_chain_done.p) { if (w->d_chain_done.alloc(4)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (chain marks)"); HIPCHK(hipMemset(w->d_chain_done.p, 0, 32)); HIPCHK(hipDeviceSynchronize()); }      // (once per context.  hipMemset of device memory may RETURN EARLY and the library's streams do not wait for the null stream: without the synchronisation the fill could land BEHIND the first mark and wipe it - the energy-fetch kernel then sat out its 2 s limit: the intermittent MSEVB_ERR_NUMERIC of round 3, HISTORY.md E; the marks come from different streams)
     hipLaunchKernelGGL(k_evb_mark, dim3(1), dim3(1), 0, sr, w->d_chain_done.p, w->seq_A + 1);
   }
   if (c->overlap) HIPCHK(hipEventRecord(w->ev_join2, w->stream2));

@@ -322,7 +322,7 @@ struct msevb_ctx {
   int pair_flat_opt = 1;         // option pair_flat: 0 = k_pair_half on per-atom rows (round 2's kernel; still what force fields with a live SAPT term run)
   bool prune_freeze = false;     // diagnostics (tools/time_stage.py): stage calls on unchanged positions keep the pair list of the first call instead of rewriting it every time
   bool pair_taylor = true;       // option pair_taylor (default on): one Ewald-table row per pair, the other one from the table's own derivatives (pair_flat.hip); 0 = both rows gathered
-  bool attr_pair_flat[16] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};
+  bool attr_pair_flat[20] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};
   bool pair_pipe = true;         // option pair_pipe: 1 = two trips in flight per wave (128 registers), 0 = one trip at a time (80)
   int pair_split_opt = 0;        // option pair_split (measured slower, off): 1 = two workgroups per cell when the sub-tiles fit (2 x 12 waves per CU), 2 = the same with 2 x 8 waves and the pipelined loop, 0 = one workgroup per cell
   bool pair_split_now = false;

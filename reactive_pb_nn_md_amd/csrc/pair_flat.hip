@@ -1,5 +1,5 @@
 // Real-space pair loop on a FLAT per-cell pair list (replaces pairwise_real_space_verlet, src/pair_int_real_space.f90:135-321, with
-// the Ewald table interpolation :698-760 and Lennard-Jones :621-645, for force fields without a live SAPT term; those run k_pair_half).
+// the Ewald table interpolation :698-760, Lennard-Jones :621-645 and - SAPT instantiation - the Buckingham / Tang-Toennies term :651-690; k_pair_half serves > 16 atom types or pruning off).
 //
 // One 1024-thread workgroup per cell of the neighbour grid, as k_pair_half (pair.hip), but the list the force loop reads is not a set of
 // per-atom rows any more:
@@ -79,6 +79,7 @@ struct PairFlatArgs {
   double* Fs; double* part_el; double* part_vdw;
   int* prune_state; int* flat; uint2* cell_trips; unsigned stride;
   double4* posq_prune; double rp2; int N_all;
+  const double* tt; const double* dtt;      // Tang-Toennies damping tables (SAPT instantiation)
 };
 
 struct PfTrip {      // what stage A leaves for stage B (per lane)
@@ -152,7 +153,7 @@ __device__ __forceinline__ double pf_exact_r2(const double4& pi, const double4& 
   return (dx * dx + dy * dy) + dz * dz;
 }
 
-struct PfSmall { double red[2][16]; int lo[HALF_SLOTS], off[HALF_SLOTS + 1], full, off7; unsigned tt0, tt; unsigned ljm[16] /* per atom type: bit t set = the pair with type t has a Lennard-Jones term */; unsigned char typ[PAIR_CELL_MAX]; };
+struct PfSmall { double red[2][16]; int lo[HALF_SLOTS], off[HALF_SLOTS + 1], full, off7; unsigned tt0, tt; unsigned ljm[16] /* per atom type: bit t set = the pair with type t has a van der Waals term (Lennard-Jones, or SAPT with a non-zero coefficient) */; unsigned char vkind[256] /* per pair type: 1 = SAPT */; unsigned char typ[PAIR_CELL_MAX]; };
 struct PfRows { unsigned off2[PAIR_CELL_MAX], cnt[PAIR_CELL_MAX], beg[PAIR_CELL_MAX]; };      // per-row scratch of the pruning pass: in the third force array, behind the single-precision copy of the tile
 
 struct PfAcc { double fx, fy, fz, e_el, e_vdw; unsigned a_prev;
@@ -166,9 +167,10 @@ __device__ __forceinline__ void pf_flush_row(PfAcc& acc, int lane) {      // eve
 }
 
 // Stage B: interaction arithmetic of a trip whose table rows were requested a trip ago; LDS force adds.
-template <int P, bool TAYLOR>
+template <int P, bool TAYLOR, bool SAPT>
 __device__ __forceinline__ void pf_stage_b(const PfTrip& s, int lane, double rc2, double rc2_lo, double rc2_hi, double dxg, double delta, const BoxDev& box,
-                                           const double4* __restrict__ posq, int cs, const int* s_lo, const int* s_off, int ns, PfAcc& acc) {
+                                           const double4* __restrict__ posq, int cs, const int* s_lo, const int* s_off, int ns, PfAcc& acc,
+                                           const unsigned char* vkind, const PairParam* __restrict__ pairpar, const double* __restrict__ tt, const double* __restrict__ dtt) {
 #pragma clang fp contract(fast)
   if (__ballot(s.aa != acc.a_prev)) {      // (wave-uniform test) some DPP row has moved on to its next atom: its owner's force joins the tile
     if (s.aa != acc.a_prev) { pf_flush_row<P>(acc, lane); acc.a_prev = s.aa; }
@@ -200,6 +202,24 @@ __device__ __forceinline__ void pf_stage_b(const PfTrip& s, int lane, double rc2
     const double r6i = inv_r2 * inv_r2 * inv_r2;
     evdw = __builtin_fma(C12, r6i, -C6) * r6i;                                  // C12/r^12 - C6/r^6
     flj = __builtin_fma(C12x12, r6i, -C6x6) * r6i * inv_r2;
+    if (SAPT) {      // Buckingham + Tang-Toennies damped dispersion (pairwise_real_space_sapt, src/pair_int_real_space.f90:651-690; vdw_interaction of devmath.hpp): pair types of kind 1,
+      const bool sp = vkind[pa >> 5] == 1;      // whose Lennard-Jones row is zero; their six coefficients come from the parameter table in global memory (a handful of 64-byte rows: cache hits)
+      if (__ballot(sp)) {
+        if (sp) {
+          const PairParam& pp = pairpar[pa >> 5];
+          const double r = s.r2 * s.inv_r, A = pp.p[0], B = pp.p[1];      // (r^2 < r_c^2 for every lane that accumulates: inv_r is 1/r there)
+          const int ti = min(max((int)ceil(B * r / TT_MAX * (double)TT_GRID), 1), TT_GRID);
+          const double* t = tt + 4 * (ti - 1);
+          const double* dt = dtt + 4 * (ti - 1);
+          const double r8i = r6i * inv_r2, r10i = r8i * inv_r2, r12i = r10i * inv_r2;
+          const double ex = exp(-B * r);
+          evdw = A * ex - t[0] * pp.p[2] * r6i - t[1] * pp.p[3] * r8i - t[2] * pp.p[4] * r10i - t[3] * pp.p[5] * r12i;
+          const double fac = r * A * B * ex + (r * B * dt[0] - 6.0 * t[0]) * pp.p[2] * r6i + (r * B * dt[1] - 8.0 * t[1]) * pp.p[3] * r8i +
+                             (r * B * dt[2] - 10.0 * t[2]) * pp.p[4] * r10i + (r * B * dt[3] - 12.0 * t[3]) * pp.p[5] * r12i;
+          flj = inv_r2 * fac;
+        }
+      }
+    }
   }
   const double fs = __builtin_fma(qr * inv_r2, sv, flj);      // force on i = fs * dr
   bool in = s.r2 < rc2_lo;
@@ -225,7 +245,7 @@ __device__ __forceinline__ void pf_stage_b(const PfTrip& s, int lane, double rc2
 // SPLIT: TWO workgroups per cell - workgroup h = 0 works on the pairs whose partner lies in the cell itself or in the first 6 forward cells, h = 1 on the
 // last 7 forward cells (the builder's rows are in tile order and carry the position of the cut, d_nbr_split) - so that a sub-tile (the cell + 6 or 7 cells,
 // ~1 100 atoms) needs < 80 KB and two workgroups share a CU: 24 waves per CU instead of 16, and one workgroup stages or flushes while the other computes.
-template <int P, bool TAYLOR, bool SPLIT, int THREADS, int MINW, bool PIPE>
+template <int P, bool TAYLOR, bool SPLIT, int THREADS, int MINW, bool PIPE, bool SAPT = false>
 __global__ __launch_bounds__(THREADS, MINW) void k_pair_flat(const PairFlatArgs A) {
   constexpr int NS = SPLIT ? 8 : HALF_SLOTS;      // cells in the (sub-)tile
   constexpr int LJB = pf_lj_bytes(P);
@@ -311,9 +331,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_pair_flat(const PairFlatArgs 
     }
     if (mode != 2 && (int)threadIdx.x < A.nt) {
       unsigned m = 0;
-      for (int t = 0; t < A.nt; ++t) { const PairParam q = A.pairpar[threadIdx.x * A.nt + t]; if (q.type == 0 && (q.p[0] != 0.0 || q.p[1] != 0.0)) m |= 1u << t; }
+      for (int t = 0; t < A.nt; ++t) { const PairParam q = A.pairpar[threadIdx.x * A.nt + t]; if ((q.type == 0 && (q.p[0] != 0.0 || q.p[1] != 0.0)) || (SAPT && q.type == 1 && q.nonzero)) m |= 1u << t; }
       sm.ljm[threadIdx.x] = m;
     }
+    if (SAPT) for (int k = threadIdx.x; k < A.nt * A.nt; k += blockDim.x) { const PairParam q = A.pairpar[k]; sm.vkind[k] = (q.type == 1 && q.nonzero) ? 1 : 0; }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -457,13 +478,13 @@ __global__ __launch_bounds__(THREADS, MINW) void k_pair_flat(const PairFlatArgs 
         eb = pf_ld_entry(src + 128);                                                                                  // entries of trip t + 2
         pf_stage_a_read<P>(ea, w);
         pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sb);                                               // trip t + 1: geometry, table rows requested (behind the last trip: padding)
-        pf_stage_b<P, TAYLOR>(sa, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, NS, acc);      // trip t: arithmetic
+        pf_stage_b<P, TAYLOR, SAPT>(sa, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, NS, acc, sm.vkind, A.pairpar, A.tt, A.dtt);      // trip t: arithmetic
         eb = t + 2 < t1 ? eb : e_none;
         if (t + 1 >= t1) break;
         ea = pf_ld_entry(src + 192);
         pf_stage_a_read<P>(eb, w);
         pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sa);
-        pf_stage_b<P, TAYLOR>(sb, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, NS, acc);
+        pf_stage_b<P, TAYLOR, SAPT>(sb, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, NS, acc, sm.vkind, A.pairpar, A.tt, A.dtt);
         ea = t + 3 < t1 ? ea : e_none;
         src += 128;
       }
@@ -476,7 +497,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_pair_flat(const PairFlatArgs 
         pf_stage_a_read<P>(e, w);
         pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sa);
         if (first) { acc.a_prev = sa.aa; first = false; }
-        pf_stage_b<P, TAYLOR>(sa, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, NS, acc);
+        pf_stage_b<P, TAYLOR, SAPT>(sa, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, NS, acc, sm.vkind, A.pairpar, A.tt, A.dtt);
         e = en; src += 64;
       }
     }
@@ -513,9 +534,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_pair_flat(const PairFlatArgs 
 #endif
 }
 
-template <int P, bool TAYLOR, bool SPLIT, int THREADS, int MINW, bool PIPE>
+template <int P, bool TAYLOR, bool SPLIT, int THREADS, int MINW, bool PIPE, bool SAPT = false>
 int pf_launch(msevb_ctx* c, const PairFlatArgs& A, int nblocks, bool& attr_done) {
-  auto kern = k_pair_flat<P, TAYLOR, SPLIT, THREADS, MINW, PIPE>;
+  auto kern = k_pair_flat<P, TAYLOR, SPLIT, THREADS, MINW, PIPE, SAPT>;
   constexpr int lds = pf_lj_bytes(P) + 56 * P + (int)sizeof(PfSmall);
   if (!attr_done) {
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -530,11 +551,11 @@ int pf_launch(msevb_ctx* c, const PairFlatArgs& A, int nblocks, bool& attr_done)
 
 // the flat-list kernel serves: half list on tiles, rolling pruning on, no live SAPT term, <= 16 atom types, tile + dummy slot within the largest pitch
 bool pair_flat_usable(const msevb_ctx* c) {
-  return c->pair_flat_opt != 0 && c->pair_tiles && !c->has_sapt && c->nt <= 16 && c->half_tile_cap + 1 <= 2560 && c->prune && c->rc + c->prune_delta < c->rv;
+  return c->pair_flat_opt != 0 && c->pair_tiles && (!c->has_sapt || c->pair_taylor) && c->nt <= 16 && c->half_tile_cap + 1 <= 2560 && c->prune && c->rc + c->prune_delta < c->rv;
 }
 // two workgroups per cell: the sub-tiles the last build saw (+ 3 %) fit the 1344-atom pitch, and the Lennard-Jones table 4.5 KB
 bool pair_flat_split(const msevb_ctx* c) {
-  return c->pair_split_opt != 0 && c->nt <= 12 && c->sub_tile_max > 0 && (int)(c->sub_tile_max * 1.03) + 1 < 1344;
+  return c->pair_split_opt != 0 && !c->has_sapt && c->nt <= 12 && c->sub_tile_max > 0 && (int)(c->sub_tile_max * 1.03) + 1 < 1344;
 }
 
 // called by pair_forces (pair.hip) in place of the k_pair_half launch; the caller has sized the pruning state and the sorted-order accumulator
@@ -561,6 +582,7 @@ int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int slot_elec, int slot_v
   A.Fs = c->d_fsorted.p; A.part_el = c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS; A.part_vdw = c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS;
   A.prune_state = c->d_prune_mode.p; A.flat = c->d_flat.p; A.cell_trips = c->d_cell_trips.p; A.stride = c->nbr_cap;
   A.posq_prune = c->d_posq_prune.p;
+  A.tt = c->d_tt.p; A.dtt = c->d_dtt.p;
   const double rp = c->rc + c->prune_delta;
   A.rp2 = rp * rp; A.N_all = N;
   const bool ty = c->pair_taylor;
@@ -570,6 +592,11 @@ int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int slot_elec, int slot_v
     return ty ? pf_launch<1344, true, true, 768, 6, false>(c, A, nblocks, at[10]) : pf_launch<1344, false, true, 768, 6, false>(c, A, nblocks, at[11]);      // 2 x 12 waves, 80 registers
   }
   const int need_slots = c->half_tile_cap + 1;
+  if (c->has_sapt) {      // a live SAPT term: the same kernel with the Buckingham / Tang-Toennies branch (one-row Ewald table, one workgroup per cell, one trip at a time: with two in flight the branch spills 22 registers)
+    if (need_slots <= 2048) return pf_launch<2048, true, false, 1024, 4, false, true>(c, A, nblocks, at[16]);
+    if (need_slots <= 2304) return pf_launch<2304, true, false, 1024, 4, false, true>(c, A, nblocks, at[17]);
+    return pf_launch<2560, true, false, 1024, 4, false, true>(c, A, nblocks, at[18]);
+  }
   if (!c->pair_pipe) {      // option pair_pipe = 0: one trip at a time in <= 80 registers - the four waves per SIMD of a tile's workgroup then leave 192 registers per lane for waves of the side chains
     if (need_slots <= 2048) return ty ? pf_launch<2048, true, false, 1024, 6, false>(c, A, nblocks, at[12]) : pf_launch<2048, false, false, 1024, 6, false>(c, A, nblocks, at[13]);
     return ty ? pf_launch<2560, true, false, 1024, 6, false>(c, A, nblocks, at[14]) : pf_launch<2560, false, false, 1024, 6, false>(c, A, nblocks, at[15]);

@@ -414,6 +414,8 @@ def test_half_list_lds_pair_kernel_against_oracle(oracle_lib, sapt):
             e = h.real_space_energy_force()
             assert np.abs(h.get_forces() - (Fo + Fi)).max() < F_TOL, (tiles, prune)
             assert rel(e[0], Eo[0]) < E_RTOL and abs(e[1] - Eo[1]) < E_RTOL * max(abs(Eo[1]), 1.0), (tiles, prune, e, Eo)
+        if tiles:      # with the pruned list on, the flat-list kernel serves both force fields (round 4: the SAPT / Tang-Toennies branch lives in k_pair_flat too)
+            assert h.info("pair_kernel") == 2
         # the full force call three times at the same positions: the first writes the rolling pruned rows, the others run on them
         for rep in range(3):
             en, F = h.calculate_total_force_energy()

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-thermal --n-side 69 --diabats 16 --pme-grid 128"
+B="python3 $R/bench.py --no-cpu-baseline --no-thermal --repeats 1 --n-side 69 --diabats 16 --pme-grid 128"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $B --steps 10 --warmup 3 > $OUT/kt.log 2>&1
 python3 $R/tools/summarize_prof.py $OUT > $OUT/rocprof_summary.txt 2>&1 || true
 python3 $R/tools/timeline.py $OUT > $OUT/timeline.txt 2>&1 || true

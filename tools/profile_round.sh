@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-thermal"
+B="python3 $R/bench.py --no-cpu-baseline --no-thermal --repeats 1"
 # 1. kernel trace of the overlapped (default) schedule + timelines of a step without / with a list rebuild
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $B --steps 30 --warmup 5 > $OUT/kt.log 2>&1
 python3 $R/tools/summarize_prof.py $OUT > $OUT/rocprof_summary.txt 2>&1 || true

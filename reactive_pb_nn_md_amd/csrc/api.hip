@@ -127,6 +127,7 @@ int msevb_destroy(msevb_ctx* c) {
   if (c->ev_fork0) (void)hipEventDestroy(c->ev_fork0);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_refresh) (void)hipEventDestroy(c->ev_refresh);
+  if (c->ev_top2) (void)hipEventDestroy(c->ev_top2);
   if (c->ev_weights) (void)hipEventDestroy(c->ev_weights);
   pme_teardown(c);
   DBuf<int>* ib[] = {&c->d_atype, &c->d_mol_type, &c->d_mol_natom, &c->d_mol_atoms, &c->d_mol_of, &c->d_cell_of, &c->d_perm, &c->d_cell_keys_tmp,
@@ -656,6 +657,7 @@ int total_force_enqueue(msevb_ctx* c) {
   CHK(nb_settle(c));
   stamp(c, 0, c->stream);
   const bool rebuild = c->flag_verlet_list == 1 || !c->list_valid;
+  int self_nb = 0;
   const int fused_nb = c->refresh_fused_nb; c->refresh_fused_nb = 0;      // one-shot: a repeated force call (MSEVB_RETRY) refreshes the ordinary way (idempotent, and it zeroes the force array again)
   // A step that keeps its list: the PME front end (stencils, spreading, FFTs) needs the NEW POSITIONS only - not the refreshed sorted arrays,
   // not the zeroed force array - and is the longest chain beside the pair loop: it leaves for the side stream before the refresh kernels
@@ -678,13 +680,25 @@ int total_force_enqueue(msevb_ctx* c) {
     CHK(nb_step_refresh(c, c->aux3));
     HIPCHK(hipEventRecord(c->ev_refresh, c->aux3));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_refresh, 0));
-  } else if (fused_nb > 0) CHK(nb_step_top2(c, fused_nb));      // the integrator's first kernel did the refresh
-  else CHK(nb_step_refresh(c));
+  } else {
+    // the pair kernel can take the "does my list still cover r_c" decision itself: k_top2_final then only serves the host's rebuild flag and runs beside the pair loop
+    self_nb = (c->overlap && c->pair_self_mode && !c->prune_freeze && c->d_prune_mode.p && c->d_posq_prune.p && pair_flat_usable(c)) ? (fused_nb > 0 ? fused_nb : (c->N + 255) / 256) : 0;
+    if (fused_nb > 0) { if (!self_nb) CHK(nb_step_top2(c, fused_nb)); }      // the integrator's first kernel did the refresh
+    else CHK(nb_step_refresh(c, nullptr, self_nb == 0));
+  }
   if (c->overlap) {     // independent chains, all adding to the force with fp64 atomics
     HIPCHK(aux_fork(c));
+    if (self_nb) {
+      if (!c->ev_top2) HIPCHK(hipEventCreateWithFlags(&c->ev_top2, hipEventDisableTiming));
+      CHK(nb_step_top2(c, self_nb, c->aux3, false));
+      HIPCHK(hipEventRecord(c->ev_top2, c->aux3));
+      c->pair_self_nb = self_nb;
+    }
     if (rebuild) CHK(nb_build_finish(c, true));                      // main: list rows first (the longest chain of a rebuild step: rows, then the pair loop)
     stamp(c, 1, c->stream);
     CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));                    // main: the pair loop (longest) goes out first
+    c->pair_self_nb = 0;
+    if (self_nb) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_top2, 0));      // (the displacement maxima are part of what the main stream publishes)
     stamp(c, 2, c->stream);
     if (c->evb_pair_first || c->molecules_after_pair_now) { if (!c->ev_pair_done) HIPCHK(hipEventCreateWithFlags(&c->ev_pair_done, hipEventDisableTiming)); HIPCHK(hipEventRecord(c->ev_pair_done, c->stream)); }
     if (!c->defer_molecules_now)                                     // (the MS-EVB call sends them out itself, behind its coupling chain on the same stream)
@@ -841,6 +855,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
     if (!was && c->pair_split_opt != 0 && c->list_valid) CHK(nb_build(c));
     return MSEVB_OK;
   }
+  if (s == "pair_self_mode") { c->pair_self_mode = v != 0.0; return MSEVB_OK; }
   if (s == "prune_freeze") { c->prune_freeze = v != 0.0; return MSEVB_OK; }
   if (s == "pair_taylor") { c->pair_taylor = v != 0.0; return MSEVB_OK; }
   if (s == "evb_fft_patch") { c->evb_fft_patch = v != 0.0; return MSEVB_OK; }

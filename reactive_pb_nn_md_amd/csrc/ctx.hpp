@@ -320,6 +320,7 @@ struct msevb_ctx {
   // cell's workgroup; cell c's list starts at cell_start[c] * (nbr_cap + 96) + 3584 c, d_cell_trips[32 c + 16 h + w] = {offset, length in 64-entry trips} of the segment of wave w of workgroup h
   DBuf<int> d_flat; DBuf<uint2> d_cell_trips;
   int pair_flat_opt = 1;         // option pair_flat: 0 = k_pair_half on per-atom rows (round 2's kernel; still what force fields with a live SAPT term run)
+  bool pair_self_mode = true; int pair_self_nb = 0, pair_epoch = 0; hipEvent_t ev_top2 = nullptr;      // option pair_self_mode: k_pair_flat decides itself whether its list still covers r_c (pair_flat.hip); pair_self_nb > 0: for the next launch, over that many per-block partial maxima
   bool prune_freeze = false;     // diagnostics (tools/time_stage.py): stage calls on unchanged positions keep the pair list of the first call instead of rewriting it every time
   bool pair_taylor = true;       // option pair_taylor (default on): one Ewald-table row per pair, the other one from the table's own derivatives (pair_flat.hip); 0 = both rows gathered
   bool attr_pair_flat[20] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};
@@ -437,8 +438,8 @@ extern "C" int msevb_comm_allreduce_forces(msevb_ctx* c);   // comm.hip
 void evb_release(msevb_ctx* c);        // evb.hip: per-context EVB scratch
 extern "C" void msevb_comm_release(msevb_ctx* c);   // comm.hip: destroys the RCCL communicator, if any
 int flush_one(msevb_ctx* c, int slot, hipStream_t st);      // api.hip
-int nb_step_refresh(msevb_ctx* c, hipStream_t st = nullptr);
-int nb_step_top2(msevb_ctx* c, int nb, hipStream_t st = nullptr);      // k_top2_final alone, over nb per-block partial results (the integrator's first kernel left them)      // refresh + displacement check + zero forces (neighbor.hip)
+int nb_step_refresh(msevb_ctx* c, hipStream_t st = nullptr, bool with_top2 = true);
+int nb_step_top2(msevb_ctx* c, int nb, hipStream_t st = nullptr, bool decide = true);      // k_top2_final alone, over nb per-block partial results (the integrator's first kernel left them)      // refresh + displacement check + zero forces (neighbor.hip)
 int nb_check_displacements(msevb_ctx* c, int initialize, int* flag);
 int pair_forces(msevb_ctx* c, int slot_elec, int slot_vdw);              // pair.hip
 bool pair_flat_usable(const msevb_ctx* c);                                // pair_flat.hip

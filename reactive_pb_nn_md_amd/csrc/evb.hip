@@ -471,62 +471,40 @@ __device__ __forceinline__ double evb_row_sum16(double v) {
   return v;
 }
 
-// ONE THREAD PER ATOM: the thread takes the minimum image and the "special molecule" test once per atom (round 2's first version, a lane per
-// (atom, Zundel atom) pair, repeated them on every lane: 52 us alone against 47), then walks the coupling's Zundel atoms (positions and exchange charges broadcast from LDS) with the
-// loop unrolled, so that the QL x 3 Zundel-force accumulators are registers; they are reduced over the workgroup once, at the end.
+// ONE PASS OVER THE ATOMS FOR ALL COUPLINGS of the step (round 4; rounds 2-3 walked the atoms once per coupling: D - 1 reads of the 60 B an
+// atom brings, D - 1 descriptor copies per workgroup).  A thread holds CPA atoms in registers (position, centre of mass of the molecule,
+// charge, molecule), then walks the couplings of its workgroup's group (<= CPG, their Zundel atoms staged in LDS once): per coupling the
+// minimum image per molecule relative to the Zundel centre, the "special molecule" test, the Zundel atoms with the loop unrolled (the QL x 3
+// Zundel-force accumulators are registers; a runtime bound sends them to scratch memory: 400 B per thread, 45 us), DPP row sums and one LDS
+// add per 16-lane row and value.  The per-atom sums run over the Zundel atoms in the same order as before: same bits in the element stores.
+constexpr int CPA = 4, CPG = 16;
+struct CplStage { double zx[16][3], zq[16], zc[3]; int nz, n_mols, slot, mols[MAX_CHAIN + 1], zspec[16]; };
 template <int QL>
-__device__ __forceinline__ void evb_coupling_body_atoms(int N, int n_cp, const CouplingDesc* __restrict__ cps, const int* __restrict__ mol_of,
-                                                        const double* __restrict__ com_atom, const double* __restrict__ xyz, const double* __restrict__ chg,
-                                                        const double* __restrict__ exch_atomic,
-                                                        BoxDev box, double conv, double* __restrict__ Foff, size_t fstride, double* __restrict__ part,
-                                                        int part_stride, double* __restrict__ dVspec, int ic0, int nbx) {
-  __shared__ CouplingDesc cp;
-  __shared__ double zx[QL][3], zq[QL];
-  __shared__ int zspec[QL];
-  __shared__ double red[QL * 3 + 1];
-  const int ic = ic0 + blockIdx.y;
-  {
-    const int* src = (const int*)&cps[ic]; int* dst = (int*)&cp;
-    for (int k = threadIdx.x; k < (int)(sizeof(CouplingDesc) / 4); k += blockDim.x) dst[k] = src[k];
-    for (int k = threadIdx.x; k < QL * 3 + 1; k += blockDim.x) red[k] = 0.0;
-  }
-  __syncthreads();
-  const int nz = cp.nD + cp.nA;
-  if ((int)threadIdx.x < QL) {
-    const int q = threadIdx.x;
-    if (q < nz) {
-      const bool acc = q >= cp.nD;
-      const int sp = acc ? cp.A_at[q - cp.nD] : cp.D_at[q];
-      const SpecAtom& a = cp.spec[sp];
-      const double* shm = acc ? cp.shifta : cp.shiftd;
-      for (int d = 0; d < 3; ++d) zx[q][d] = cp.zc[d] + (a.x[d] - cp.zc[d] - shm[d]);
-      zq[q] = (acc && q == nz - 1) ? cp.q_transfer : exch_atomic[a.type];
-      zspec[q] = sp;
-    } else { zx[q][0] = zx[q][1] = zx[q][2] = 0.0; zq[q] = 0.0; zspec[q] = 0; }      // a zero charge: the padded q contribute exact zeros
-  }
-  __syncthreads();
-  double* F = Foff + (size_t)cp.slot * fstride;
+__device__ __forceinline__ void evb_coupling_one(const CplStage& z, const double (&x)[CPA][3], const double (&cm)[CPA][3], const double (&qc)[CPA], const int (&m)[CPA],
+                                                 const int (&ja)[CPA], int N, const BoxDev& box, double* __restrict__ F, double* __restrict__ red) {
+  const int nz = z.nz;
   double fz[QL][3];
 #pragma unroll
   for (int q = 0; q < QL; ++q) fz[q][0] = fz[q][1] = fz[q][2] = 0.0;
   double vex = 0.0;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += nbx * blockDim.x) {
-    const int m = mol_of[j];
-    bool special = false;
-    for (int k = 0; k < cp.n_mols; ++k) special |= (cp.mols[k] == m);
+#pragma unroll
+  for (int a = 0; a < CPA; ++a) {
+    const int j = ja[a];
+    bool special = j >= N;
+    for (int k = 0; k < z.n_mols; ++k) special |= (z.mols[k] == m[a]);
     double fx = 0.0, fy = 0.0, fz_ = 0.0;
     if (!special) {
       double xs[3];
-      for (int d = 0; d < 3; ++d) xs[d] = xyz[3 * j + d] - floor((com_atom[3 * j + d] - cp.zc[d]) * box.invL[d] + 0.5) * box.L[d];
-      const double qj = chg[j] * conv;
+      for (int d = 0; d < 3; ++d) xs[d] = x[a][d] - floor((cm[a][d] - z.zc[d]) * box.invL[d] + 0.5) * box.L[d];
+      const double qj = qc[a];
 #pragma unroll
       for (int q = 0; q < QL; ++q) {
-        if (q < nz) {      // (uniform; no break: the loop must unroll completely, or fz[][] goes to scratch memory - 400 B per thread and 45 us with it)
-          const double r0 = -(xs[0] - zx[q][0]), r1 = -(xs[1] - zx[q][1]), r2c = -(xs[2] - zx[q][2]);
+        if (q < nz) {      // (uniform; no break: the loop must unroll completely)
+          const double r0 = -(xs[0] - z.zx[q][0]), r1 = -(xs[1] - z.zx[q][1]), r2c = -(xs[2] - z.zx[q][2]);
           const double r2 = r0 * r0 + r1 * r1 + r2c * r2c;
           double r, inv_r;
           sqrt_rsqrt(r2, r, inv_r);
-          const double qq = zq[q] * qj * inv_r;
+          const double qq = z.zq[q] * qj * inv_r;
           vex += qq;
           const double g = qq * inv_r * inv_r;      // = -(-qq / r^2)
           const double f0 = g * r0, f1 = g * r1, f2 = g * r2c;
@@ -535,9 +513,8 @@ __device__ __forceinline__ void evb_coupling_body_atoms(int N, int n_cp, const C
         }
       }
     }
-    F[3 * (size_t)j] = fx; F[3 * (size_t)j + 1] = fy; F[3 * (size_t)j + 2] = fz_;      // dVex of atom j (0 for special atoms: k_evb_coupling_finish assigns them)
+    if (j < N) { F[3 * (size_t)j] = fx; F[3 * (size_t)j + 1] = fy; F[3 * (size_t)j + 2] = fz_; }      // dVex of atom j (0 for special atoms: k_evb_coupling_finish assigns them)
   }
-  // workgroup sums of the Zundel forces and of Vex: DPP row sums, then one LDS add per 16-lane row
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int q = 0; q < QL; ++q)
@@ -548,28 +525,65 @@ __device__ __forceinline__ void evb_coupling_body_atoms(int N, int n_cp, const C
     }
   {
     const double v = evb_row_sum16(vex);
-    if ((lane & 15) == 0) atomicAdd(&red[QL * 3], v);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) part[(size_t)ic * part_stride + blockIdx.x] = red[QL * 3];
-  for (int k = threadIdx.x; k < nz * 3; k += blockDim.x) {
-    const double v = red[k];
-    if (v != 0.0) atomicAdd(&dVspec[((size_t)ic * CPL_BINS + (blockIdx.x % CPL_BINS)) * MAX_SPEC * 3 + 3 * zspec[k / 3] + k % 3], v);
+    if ((lane & 15) == 0) atomicAdd(&red[48], v);
   }
 }
-// ONE launch for all couplings of a step: blockIdx.y < n_big -> the 16-lane body (the acid's coupling), else the 8-lane one; launched one
-// behind the other they cost 15 + 36 us of a latency-bound chain the host's turn waits for.  nb_big / nb_small workgroups per coupling.
+// gridDim.x workgroups share the atoms (256 CPA per trip), gridDim.y = groups of cpg couplings (one group = one pass over the atoms: 96 workgroups of a
+// 98 k-atom box with all seven couplings each were 77 us alone - one wave per SIMD walking 12 k dependent instructions; four groups: see DESIGN.md 4.6); part[ic][blockIdx.x] = the workgroup's share of
+// Vex, Zundel forces into copy blockIdx.x % CPL_BINS of dVspec (k_evb_coupling_finish sums both)
 __global__ __launch_bounds__(256) void k_evb_coupling(int N, int n_cp, const CouplingDesc* __restrict__ cps, const int* __restrict__ mol_of,
                                                       const double* __restrict__ com_atom, const double* __restrict__ xyz, const double* __restrict__ chg,
                                                       const double* __restrict__ exch_atomic,
                                                       BoxDev box, double conv, double* __restrict__ Foff, size_t fstride, double* __restrict__ part,
-                                                      int part_stride, double* __restrict__ dVspec, int n_big, int nb_big, int nb_small) {
-  if ((int)blockIdx.y < n_big) {
-    if ((int)blockIdx.x >= nb_big) return;
-    evb_coupling_body_atoms<16>(N, n_cp, cps, mol_of, com_atom, xyz, chg, exch_atomic, box, conv, Foff, fstride, part, part_stride, dVspec, 0, nb_big);
-  } else {
-    if ((int)blockIdx.x >= nb_small) return;
-    evb_coupling_body_atoms<8>(N, n_cp, cps, mol_of, com_atom, xyz, chg, exch_atomic, box, conv, Foff, fstride, part, part_stride, dVspec, 0, nb_small);
+                                                      int part_stride, double* __restrict__ dVspec, int cpg) {
+  __shared__ CplStage zs[CPG];
+  __shared__ double red[CPG][49];
+  const int g0 = blockIdx.y * cpg, ng = min(cpg, n_cp - g0);      // cpg <= CPG couplings per workgroup (host: as many groups as it takes to fill the GPU with ~500 workgroups)
+  {
+    const int l = threadIdx.x >> 4, q = threadIdx.x & 15;      // 16 threads per coupling
+    if (l < ng) {
+      const CouplingDesc& cp = cps[g0 + l];
+      CplStage& z = zs[l];
+      const int nz = cp.nD + cp.nA;
+      if (q < nz) {
+        const bool acc = q >= cp.nD;
+        const int sp = acc ? cp.A_at[q - cp.nD] : cp.D_at[q];
+        const SpecAtom& a = cp.spec[sp];
+        const double* shm = acc ? cp.shifta : cp.shiftd;
+        for (int d = 0; d < 3; ++d) z.zx[q][d] = cp.zc[d] + (a.x[d] - cp.zc[d] - shm[d]);
+        z.zq[q] = (acc && q == nz - 1) ? cp.q_transfer : exch_atomic[a.type];
+        z.zspec[q] = sp;
+      } else { z.zx[q][0] = z.zx[q][1] = z.zx[q][2] = 0.0; z.zq[q] = 0.0; z.zspec[q] = 0; }      // a zero charge: the padded q contribute exact zeros
+      if (q < 3) z.zc[q] = cp.zc[q];
+      if (q <= MAX_CHAIN) z.mols[q] = cp.mols[q];
+      if (q == 0) { z.nz = nz; z.n_mols = cp.n_mols; z.slot = cp.slot; }
+    }
+    for (int k = threadIdx.x; k < CPG * 49; k += blockDim.x) (&red[0][0])[k] = 0.0;
+  }
+  __syncthreads();
+  for (int base = blockIdx.x * (256 * CPA); base < N; base += gridDim.x * (256 * CPA)) {
+    double x[CPA][3], cm[CPA][3], qc[CPA];
+    int m[CPA], ja[CPA];
+#pragma unroll
+    for (int a = 0; a < CPA; ++a) {
+      const int j = base + a * 256 + (int)threadIdx.x, jc = min(j, N - 1);
+      ja[a] = j; m[a] = mol_of[jc]; qc[a] = chg[jc] * conv;
+      for (int d = 0; d < 3; ++d) { x[a][d] = xyz[3 * (size_t)jc + d]; cm[a][d] = com_atom[3 * (size_t)jc + d]; }
+    }
+    for (int l = 0; l < ng; ++l) {
+      const CplStage& z = zs[l];
+      double* F = Foff + (size_t)z.slot * fstride;
+      if (z.nz > 8) evb_coupling_one<16>(z, x, cm, qc, m, ja, N, box, F, red[l]);
+      else evb_coupling_one<8>(z, x, cm, qc, m, ja, N, box, F, red[l]);
+    }
+  }
+  __syncthreads();
+  for (int l = threadIdx.x; l < ng; l += blockDim.x) part[(size_t)(g0 + l) * part_stride + blockIdx.x] = red[l][48];
+  for (int k = threadIdx.x; k < ng * 48; k += blockDim.x) {
+    const int l = k / 48, r = k - l * 48;
+    if (r >= zs[l].nz * 3) continue;
+    const double v = red[l][r];
+    if (v != 0.0) atomicAdd(&dVspec[((size_t)(g0 + l) * CPL_BINS + (blockIdx.x % CPL_BINS)) * MAX_SPEC * 3 + 3 * zs[l].zspec[r / 3] + r % 3], v);
   }
 }
 
@@ -955,18 +969,28 @@ struct SolveDesc {
 // wait_mark: device-side mark of the kernel that completes the energies (k_evb_publish on the grid stream) - this kernel sits on the MAIN stream
 // behind the pair loop and must not start reading E before that one is done; no cross-stream event hop (~10 us each)
 struct SolveArgs {
-  int on, method;
+  int on, method, nref /* unit references (= sd->unit_off[D]) */;
   const SolveDesc* sd; const int* unit_idx; const double* unit_sign; const double* E; const double* e_recip1;
   double* dcoef; double* out_host;
   long long mark_seq; long long* done_mark;               // device mark the blend phase (main stream) starts on
   volatile long long* done_flag; long long done_seq;      // pinned flag the host spins on
   double* fault;
 };
-__device__ __forceinline__ void evb_solve_body(const SolveArgs& sa) {
+// the descriptor is static for the call: the kernels stage it in LDS BEFORE they wait for the energies (a dozen dependent global loads, ~1 us each, used to sit
+// between the last energy and the blend phase's start)
+constexpr int SOLVE_PRE = 256;      // unit references staged with the descriptor (the rest, if any, is read from global memory)
+struct SolveStage { SolveDesc sd; int ui[SOLVE_PRE]; double us[SOLVE_PRE]; };
+__device__ __forceinline__ void evb_solve_stage(const SolveArgs& sa, SolveStage* st) {
+  const int* src = (const int*)sa.sd; int* dst = (int*)&st->sd;
+  for (int k = threadIdx.x; k < (int)(sizeof(SolveDesc) / 4); k += blockDim.x) dst[k] = src[k];
+  for (int k = threadIdx.x; k < min(sa.nref, SOLVE_PRE); k += blockDim.x) { st->ui[k] = sa.unit_idx[k]; st->us[k] = sa.unit_sign[k]; }
+}
+__device__ __forceinline__ void evb_solve_body(const SolveArgs& sa, const SolveStage* stg) {
 #pragma clang fp contract(off)
-  const SolveDesc* __restrict__ sd = sa.sd; const int* __restrict__ unit_idx = sa.unit_idx; const double* __restrict__ unit_sign = sa.unit_sign;
+  const SolveDesc* sd = &stg->sd;
+  const int* __restrict__ unit_idx = sa.unit_idx; const double* __restrict__ unit_sign = sa.unit_sign;
   const double* __restrict__ E = sa.E; const double* __restrict__ e_recip1 = sa.e_recip1; double* __restrict__ dcoef = sa.dcoef; double* __restrict__ out_host = sa.out_host;
-  const int method = sa.method; long long* done_mark = sa.done_mark; const long long wait_seq = sa.mark_seq; volatile long long* done_flag = sa.done_flag; const long long done_seq = sa.done_seq;
+  const int method = sa.method; long long* done_mark = sa.done_mark; const long long wait_seq = sa.mark_seq; 
   extern __shared__ double sh[];      // A[n*n], V[n*n], cplA[n], per pair of a round: c, s, d_p - t a_pq, d_q + t a_pq (n/2 each) and p, q (ints)
   const int n = sd->D, tid = threadIdx.x, nth = blockDim.x;
   const int m = (n + 1) & ~1, hp = m / 2;      // tournament over m players (an odd n plays with a dummy that sits out)
@@ -981,7 +1005,7 @@ __device__ __forceinline__ void evb_solve_body(const SolveArgs& sa) {
   // the units' energies (two dependent global loads each) are fetched by all lanes at once and summed per diabat in their fixed order afterwards
   double* contrib = rdq + hp + 2 * hp;      // scratch behind the round tables: [unit references] now, the squaring's product later
   const int nref = sd->unit_off[n];
-  for (int q = tid; q < nref; q += nth) { const int iu = unit_idx[q]; contrib[q] = unit_sign[q] * (E[iu] + E[nu + iu]); }
+  for (int q = tid; q < nref; q += nth) { const int iu = q < SOLVE_PRE ? stg->ui[q] : unit_idx[q]; contrib[q] = (q < SOLVE_PRE ? stg->us[q] : unit_sign[q]) * (E[iu] + E[nu + iu]); }
   __syncthreads();
   for (int d = tid; d < n; d += nth) {
     if (d == 0) { const int iu = sd->unit00; A[0] = sd->Hp_norep + sd->once * (E[iu] + E[nu + iu]); }
@@ -1126,10 +1150,8 @@ __device__ __forceinline__ void evb_solve_body(const SolveArgs& sa) {
     dcoef[1 + ngrid + t] = i == j ? ei * ej : 2.0 * ei * ej * -cA[j];
   }
   if (done_mark) { __syncthreads(); if (tid == 0) __hip_atomic_store(done_mark, wait_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }      // the blend phase (main stream) starts on this
-  if (done_flag) { __threadfence_system(); __syncthreads(); if (tid == 0) *done_flag = done_seq; }
+  // (k_evb_publish raises sa.done_flag for the host together with its own flag, behind the copies)
 }
-// stand-alone launch (single-stream schedule); in the four-stream schedule the body runs at the end of the energy-fetch kernel (k_evb_publish)
-__global__ __launch_bounds__(256) void k_evb_solve(const SolveArgs sa) { evb_solve_body(sa); }
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -1343,6 +1365,8 @@ __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, 
   // those marks here instead of through two cross-stream event hops in front of this kernel (~10 us each on the way to the host's turn).
   // The marks are enqueued before this kernel in host order, so streams that share a hardware queue cannot deadlock; after 2 s of wall
   // clock the sticky fault flag is raised and the kernel goes on (the force call then ends in MSEVB_ERR_NUMERIC).
+  __shared__ SolveStage s_sd;
+  if (sa.on) evb_solve_stage(sa, &s_sd);      // (in flight while thread 0 waits for the chains)
   if (n_chains > 0) {
     if (threadIdx.x == 0) {
       const long long t0 = wall_clock64();      // 100 MHz
@@ -1370,12 +1394,16 @@ __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, 
     __threadfence_block();
     __syncthreads();
   }
+  // sa.on: the energies this kernel has just completed are all the Hamiltonian needs - H' assembly, ground state and blend coefficients right here
+  // (a launch of its own behind this kernel cost a gap and a minimum kernel duration, ~7 us, on the way to the blend phase's start), and BEFORE the copies
+  // for the host: the blend phase waits for the solve's mark, the host only for its bookkeeping
+  if (sa.on) { __threadfence_block(); __syncthreads(); evb_solve_body(sa, &s_sd); }
   for (int k = threadIdx.x; k < na; k += blockDim.x) ha[k] = a[k];
   for (int k = threadIdx.x; k < nb; k += blockDim.x) hb[k] = b[k];
-  if (flag) { __threadfence_system(); __syncthreads(); if (threadIdx.x == 0) *flag = seq; }
-  // sa.on: the energies this kernel has just completed are all the Hamiltonian needs - H' assembly, ground state and blend coefficients right here
-  // (a launch of its own behind this kernel cost a gap and a minimum kernel duration, ~7 us, on the way to the blend phase's start)
-  if (sa.on) { __threadfence_block(); __syncthreads(); evb_solve_body(sa); }
+  if (flag || (sa.on && sa.done_flag)) {
+    __threadfence_system(); __syncthreads();
+    if (threadIdx.x == 0) { if (flag) *flag = seq; if (sa.on && sa.done_flag) *sa.done_flag = sa.done_seq; }
+  }
 }
 
 // last kernel of a side chain: its stream has finished everything in front of it
@@ -2192,13 +2220,13 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     hipStream_t so = c->overlap ? c->aux3 : c->stream;
     hipLaunchKernelGGL(k_mol_com, dim3((M + 255) / 256), dim3(256), 0, so, M, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p, c->d_mass.p, w->d_com_atom.p);      // positions only
     if (c->overlap) HIPCHK(hipStreamWaitEvent(so, w->ev_fork2, 0));
-    // ~1000 workgroups per launch in all: every block pays a descriptor copy, two barriers and the Zundel reductions
-    int cpb_big = cpb, cpb_small = std::min(cpb, std::max(256, 6144 / std::max(ncp - ncp_big, 1)));      // few trips per wave: the kernels are latency-bound
-    cpb_big = cpb_small = std::min(cpb, std::min(128, std::max(32, (N + 1023) / 1024)));      // thread per atom: >= 4 atoms per thread, so that the final workgroup reductions are amortised; never more than 128 workgroups
-                                                                                               // per coupling (985 k atoms, 15 couplings: 962 each were 14 430 descriptor copies and reductions - 3.67 ms per step against 3.34 with 96-128)
-    if (c->evb_coupling_blocks > 0) { cpb_big = std::min(cpb, c->evb_coupling_blocks); cpb_small = std::min(cpb, c->evb_coupling_blocks); }
-    hipLaunchKernelGGL(k_evb_coupling, dim3(std::max(cpb_big, cpb_small), ncp), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, w->d_com_atom.p, c->d_xyz.p, c->d_chg.p,
-                       w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p, ncp_big, cpb_big, cpb_small);
+    // one pass over the atoms for up to CPG couplings: 1024 atoms per workgroup and trip, never more than `cpb` workgroups (the row length of the partial sums)
+    int cpb_big = std::min(cpb, std::max(1, (N + 256 * CPA - 1) / (256 * CPA)));
+    if (c->evb_coupling_blocks > 0) cpb_big = std::min(cpb, c->evb_coupling_blocks);
+    const int cpb_small = cpb_big;
+    const int cgroups = std::min(ncp, std::max(1, (512 + cpb_big - 1) / cpb_big)), cpg = std::min(CPG, (ncp + cgroups - 1) / cgroups);
+    hipLaunchKernelGGL(k_evb_coupling, dim3(cpb_big, (ncp + cpg - 1) / cpg), dim3(256), 0, so, N, ncp, d_cps, c->d_mol_of.p, w->d_com_atom.p, c->d_xyz.p, c->d_chg.p,
+                       w->d_exch.p, box, c->conv, c->d_Foff.p, n3, part_cp, part_stride, w->d_dVspec.p, cpg);
     hipLaunchKernelGGL(k_evb_coupling_finish, dim3(ncp), dim3(64), 0, so, ncp, d_cps, w->d_exch.p, c->d_mass.p, box, c->conv, (const double*)part_cp, part_stride, ncp_big, cpb_big, cpb_small,
                        E_cp_env, w->d_dVspec.p, c->d_Foff.p, n3, d_cpout);
     HIPCHK(hipGetLastError());
@@ -2264,10 +2292,9 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       if (!c->attr_evb_solve) {
         const int Dm = MAX_DIABATS, hm = Dm / 2, most = (2 * Dm * Dm + Dm + 6 * hm + std::max(16 * 16 + 32, MAX_UNITS)) * 8 + 16;
         HIPCHK(hipFuncSetAttribute((const void*)k_evb_publish, hipFuncAttributeMaxDynamicSharedMemorySize, most));
-        HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, most));
         c->attr_evb_solve = true;
       }
-      sa.on = 1; sa.method = c->evb_device_solve_method;
+      sa.on = 1; sa.method = c->evb_device_solve_method; sa.nref = n_unit_refs;
       sa.sd = (const SolveDesc*)(w->d_desc.p + off_s); sa.unit_idx = (const int*)(w->d_desc.p + off_si); sa.unit_sign = (const double*)(w->d_desc.p + off_ss);
       sa.E = w->d_E.p; sa.e_recip1 = linear ? w->d_Elq.p + 2 * MAX_DIABATS /* zero: the grid energies are differences already */ : c->d_energies.p + S_RECIP;
       sa.dcoef = w->d_coef.p; sa.out_host = w->h_solve; sa.mark_seq = seqA; sa.done_mark = pub_spin ? w->d_chain_done.p + 3 : (long long*)nullptr;

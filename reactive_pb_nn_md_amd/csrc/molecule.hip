@@ -1,7 +1,7 @@
 // Per-molecule terms: bonded (bond / angle / dihedral; replaces intra_molecular_energy_force,
 // src/intra_bonded_interactions.f90:17-552) and intra-molecular non-bonded with exclusions (replaces
 // intra_molecular_pairwise_energy_force, src/pair_int_real_space.f90:386-588, and intra_pme_exclusion :781).
-// Eight lanes per molecule (forces are added with fp64 atomics because the kernel may overlap the pair loop); all parameters of a
+// Four lanes per molecule (forces are added with fp64 atomics because the kernel may overlap the pair loop); all parameters of a
 // molecule type are pre-resolved into one MolTypeDev record (L2 / scalar-cache resident, <= 10 types).
 #include "ctx.hpp"
 #include "devmath.hpp"
@@ -10,15 +10,16 @@
 
 namespace {
 
-constexpr int MOL_LANES = 8;        // lanes per molecule (= MAX_MOL_ATOMS: lane k also owns atom k for the loads and the force write-out)
-constexpr int MOL_TPB = 256;       // 32 molecules per workgroup
-static_assert(MOL_LANES == MAX_MOL_ATOMS, "lane k of a molecule's group handles atom k");
+constexpr int MOL_LANES = 4;        // lanes per molecule (lane k owns atoms k, k + 4 for the loads and the force write-out).  Eight lanes (rounds 2-3) left five of them idle
+                                    // on a water - three pairs, two bonds, one angle - and the kernel is instruction-bound: half the waves, same work per busy lane
+constexpr int MOL_TPB = 256;       // 64 molecules per workgroup
+static_assert(MAX_MOL_ATOMS % MOL_LANES == 0, "lane k of a molecule's group handles atoms k, k + MOL_LANES, ...");
 
 // a molecule's [atom][3] / [atom] arrays in LDS, shared by the lanes of its group (x[i][d] / q[i] syntax of the molecule functions)
 struct MolRows { double* p; __device__ __forceinline__ double* operator[](int i) const { return p + 3 * i; } };
 struct MolVec { double* p; __device__ __forceinline__ double& operator[](int i) const { return p[i]; } };
 
-// EIGHT LANES PER MOLECULE: the pairs, bonds, angles and dihedrals of a molecule are dealt to the lanes of its group (molecule_dev.hpp, SHARED),
+// FOUR LANES PER MOLECULE: the pairs, bonds, angles and dihedrals of a molecule are dealt to the lanes of its group (molecule_dev.hpp, SHARED),
 // forces meet in LDS.  One thread per molecule was 512 waves for 32 k molecules - two per CU, each walking a water's three erfc pairs, two bonds
 // and an angle one after the other: 47 us of pure latency (77 us beside the pair loop).
 __global__ __launch_bounds__(MOL_TPB) void k_molecules(int m_lo, int M, const int* __restrict__ mol_type, const int* __restrict__ mol_natom,
@@ -35,11 +36,16 @@ __global__ __launch_bounds__(MOL_TPB) void k_molecules(int m_lo, int M, const in
   double e[5] = {0, 0, 0, 0, 0};
   const bool live = m < M;
   const int n = live ? mol_natom[m] : 0;
-  int a = -1;
-  if (k < n) {
-    a = mol_atoms[m * MAX_MOL_ATOMS + k];
-    sq[g][k] = chg[a];
-    for (int d = 0; d < 3; ++d) { sx[g][3 * k + d] = xyz[3 * a + d]; sf[g][3 * k + d] = 0.0; }
+  int a[MAX_MOL_ATOMS / MOL_LANES];
+#pragma unroll
+  for (int u = 0; u < MAX_MOL_ATOMS / MOL_LANES; ++u) {
+    const int kk = k + u * MOL_LANES;
+    a[u] = -1;
+    if (kk < n) {
+      a[u] = mol_atoms[m * MAX_MOL_ATOMS + kk];
+      sq[g][kk] = chg[a[u]];
+      for (int d = 0; d < 3; ++d) { sx[g][3 * kk + d] = xyz[3 * a[u] + d]; sf[g][3 * kk + d] = 0.0; }
+    }
   }
   __syncthreads();
   if (live) {
@@ -50,7 +56,9 @@ __global__ __launch_bounds__(MOL_TPB) void k_molecules(int m_lo, int M, const in
     if (do_bonded) molecule_bonded<true>(mt, x, f, pi_ref, e[2], e[3], e[4], k, MOL_LANES);
   }
   __syncthreads();
-  if (k < n) for (int d = 0; d < 3; ++d) atomicAdd(&F[3 * a + d], sf[g][3 * k + d]);   // may run beside the pair loop
+#pragma unroll
+  for (int u = 0; u < MAX_MOL_ATOMS / MOL_LANES; ++u)
+    if (a[u] >= 0) for (int d = 0; d < 3; ++d) atomicAdd(&F[3 * a[u] + d], sf[g][3 * (k + u * MOL_LANES) + d]);   // may run beside the pair loop
   for (int s = 0; s < 5; ++s) { double v = e[s]; for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); if ((threadIdx.x & 63) == 0) red[s][threadIdx.x >> 6] = v; }
   __syncthreads();
   if (threadIdx.x < 5) { double v = 0.0; for (int w = 0; w < MOL_TPB / 64; ++w) v += red[threadIdx.x][w]; partials[(size_t)(slot0 + threadIdx.x) * MAX_BLOCKS + blockIdx.x] = v; }

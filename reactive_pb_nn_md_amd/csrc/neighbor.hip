@@ -497,7 +497,7 @@ __global__ void k_top2_final(int nb, const double* __restrict__ part1, const dou
   if (threadIdx.x == 0) {
     out[0] = s1[0]; out[1] = s2[0];
     // prune_mode[2]: pruned rows exist for the CURRENT full rows (cleared by nb_prune_reset, set by a pair loop that wrote them)
-    if (blockIdx.x == 1) { const int use = prune_mode[2] != 0 && (s1[0] + s2[0]) < prune_delta; prune_mode[0] = use ? 2 : 1; prune_mode[1] += use ? 0 : 1; }
+    if (blockIdx.x == 1 && prune_mode) { const int use = prune_mode[2] != 0 && (s1[0] + s2[0]) < prune_delta; prune_mode[0] = use ? 2 : 1; prune_mode[1] += use ? 0 : 1; }      // (prune_mode == nullptr: the pair kernel decides for itself)
   }
 }
 
@@ -535,7 +535,7 @@ int nb_prune_reset(msevb_ctx* c) {
 }
 
 // displacement check + sorted-array refresh + force zeroing of a step that keeps the current list (one kernel + the tiny top-2 finish)
-int nb_step_refresh(msevb_ctx* c, hipStream_t st) {
+int nb_step_refresh(msevb_ctx* c, hipStream_t st, bool with_top2) {
   if (!st) st = c->stream;
   const int N = c->N, nb = (N + 255) / 256;
   const bool pr = c->prune && c->d_posq_prune.p && c->d_prune_mode.p;
@@ -544,6 +544,7 @@ int nb_step_refresh(msevb_ctx* c, hipStream_t st) {
                      c->d_type_sorted.p, c->d_mol_sorted.p, c->d_xyz_store.p, c->d_disp.p, make_box(c), c->d_force.p,
                      c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS,
                      pr ? c->d_posq_prune.p : (const double4*)nullptr, c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS);
+  if (with_top2)
   hipLaunchKernelGGL(k_top2_final, dim3(pr ? 2 : 1), dim3(256), 0, st, nb, c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS,
                      c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS, c->d_energies.p + S_MAXD1,
                      c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS, c->prune_delta, c->d_prune_mode.p);
@@ -551,12 +552,12 @@ int nb_step_refresh(msevb_ctx* c, hipStream_t st) {
   return MSEVB_OK;
 }
 
-int nb_step_top2(msevb_ctx* c, int nb, hipStream_t st) {
+int nb_step_top2(msevb_ctx* c, int nb, hipStream_t st, bool decide) {
   if (!st) st = c->stream;
   const bool pr = c->prune && c->d_posq_prune.p && c->d_prune_mode.p;
   hipLaunchKernelGGL(k_top2_final, dim3(pr ? 2 : 1), dim3(256), 0, st, nb, c->d_partials.p + (size_t)S_MAXD1 * MAX_BLOCKS,
                      c->d_partials.p + (size_t)S_MAXD2 * MAX_BLOCKS, c->d_energies.p + S_MAXD1,
-                     c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS, c->prune_delta, c->d_prune_mode.p);
+                     c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS, c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS, c->prune_delta, decide ? c->d_prune_mode.p : (int*)nullptr);
   HIPCHK(hipGetLastError());
   return MSEVB_OK;
 }

@@ -79,6 +79,10 @@ struct PairFlatArgs {
   double* Fs; double* part_el; double* part_vdw;
   int* prune_state; int* flat; uint2* cell_trips; unsigned stride;
   double4* posq_prune; double rp2; int N_all;
+  // self_nb > 0: the kernel takes k_top2_final's decision itself (a launch and a gap less in front of the pair loop): every workgroup reduces the self_nb
+  // per-block top-2 displacements since the last rewrite and compares with prune_delta; prune_state[2] carries the NUMBER (epoch) of the launch that wrote
+  // the list, so that workgroups starting after workgroup 0 has stamped it still agree with it
+  int self_nb, epoch; const double* prd1; const double* prd2; double prune_delta;
   const double* tt; const double* dtt;      // Tang-Toennies damping tables (SAPT instantiation)
 };
 
@@ -260,11 +264,37 @@ __global__ __launch_bounds__(THREADS, MINW) void k_pair_flat(const PairFlatArgs 
 #if PF_EXP & 256
   const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-  const int mode = __builtin_amdgcn_readfirstlane(A.prune_state[0]);      // 2: the flat list still covers r_c; otherwise it is rewritten first
+  int mode;
+  if (A.self_nb > 0) {
+    const int w = A.prune_state[2];
+    double m1 = 0.0, m2 = 0.0;      // same top-2 merge as k_top2_final (maxima: the order does not matter, same bits)
+    for (int k = threadIdx.x; k < A.self_nb; k += THREADS) {
+      const double b1 = A.prd1[k], b2 = A.prd2[k];
+      const double n1 = fmax(m1, b1), n2 = fmax(fmin(m1, b1), fmax(m2, b2));
+      m1 = n1; m2 = n2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double b1 = __shfl_xor(m1, o, 64), b2 = __shfl_xor(m2, o, 64);
+      const double n1 = fmax(m1, b1), n2 = fmax(fmin(m1, b1), fmax(m2, b2));
+      m1 = n1; m2 = n2;
+    }
+    if ((threadIdx.x & 63) == 0) { sm.red[0][threadIdx.x >> 6] = m1; sm.red[1][threadIdx.x >> 6] = m2; }
+    __syncthreads();
+    m1 = sm.red[0][0]; m2 = sm.red[1][0];
+#pragma unroll
+    for (int k = 1; k < THREADS / 64; ++k) {
+      const double b1 = sm.red[0][k], b2 = sm.red[1][k];
+      const double n1 = fmax(m1, b1), n2 = fmax(fmin(m1, b1), fmax(m2, b2));
+      m1 = n1; m2 = n2;
+    }
+    __syncthreads();      // (sm.red is the energy reduction's scratch later on)
+    mode = __builtin_amdgcn_readfirstlane((w != 0 && w != A.epoch && (m1 + m2) < A.prune_delta) ? 2 : 1);
+  } else mode = __builtin_amdgcn_readfirstlane(A.prune_state[0]);      // 2: the flat list still covers r_c; otherwise it is rewritten first
   if (mode != 2) {      // snapshot of ALL positions (the displacement check runs over every atom, also when the cells are sharded over ranks)
     const int chunk = (A.N_all + gridDim.x - 1) / gridDim.x, k0 = blockIdx.x * chunk, k1 = min(A.N_all, k0 + chunk);
     for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x) A.posq_prune[k] = A.posq[k];
-    if (blockIdx.x == 0 && threadIdx.x == 0) A.prune_state[2] = 1;      // seen by the NEXT step's k_top2_final: a list exists for the current rows
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.prune_state[2] = A.epoch;      // a list exists for the current rows (k_top2_final / the next launches look), written by launch `epoch`
   }
   const int lb = xcd_block(blockIdx.x, gridDim.x);      // one XCD works on one contiguous eighth of the cells (a slab)
   const int cidx = A.c_lo + (SPLIT ? lb >> 1 : lb), h = SPLIT ? (lb & 1) : 0;
@@ -585,6 +615,9 @@ int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int slot_elec, int slot_v
   A.tt = c->d_tt.p; A.dtt = c->d_dtt.p;
   const double rp = c->rc + c->prune_delta;
   A.rp2 = rp * rp; A.N_all = N;
+  if (++c->pair_epoch <= 0) c->pair_epoch = 1;
+  A.epoch = c->pair_epoch; A.self_nb = c->pair_self_nb; c->pair_self_nb = 0;      // (one-shot: set by total_force_enqueue for the launch it is about to make)
+  A.prd1 = c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS; A.prd2 = c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS; A.prune_delta = c->prune_delta;
   const bool ty = c->pair_taylor;
   bool* at = c->attr_pair_flat;
   if (split) {

@@ -192,6 +192,14 @@ __global__ __launch_bounds__(256) void k_pme_spread(int N, int K, const double* 
 __host__ __device__ inline int spread_plane_stride(int3 T) { const int rows = (T.x | 1) * T.y; return rows + (6 - rows % 16 + 16) % 16; }
 constexpr int SPREAD_CHUNK = 64;      // atoms of a cell staged in LDS at a time (10.5 KB)
 
+// n = q d + r for 0 <= n < 2^23 and a divisor known only at run time: the quotient estimated with a single-precision reciprocal (off by at
+// most one at these sizes) and corrected by the remainder - eight instructions where the compiler's 32-bit division takes ~35; the tile loops
+// below did two to five of those per grid point
+__device__ __forceinline__ void divmod_small(int n, int d, float inv_d, int& q, int& r) {
+  q = (int)((float)n * inv_d); r = n - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) { ++q; r -= d; }
+}
 // LDS-tiled spread: one workgroup per neighbour cell (atoms are cell-sorted).  The cell's atoms scatter
 // their 216-point stencils into an LDS tile with ds_add_f64, the tile is flushed once with global fp64 atomics
 // (non-zero points only): ~20x fewer HBM atomics than one per stencil point.  Atoms that drifted out of the tile since the
@@ -261,13 +269,15 @@ __global__ __launch_bounds__(512) void k_pme_spread_tiles(int K, int3 nc, int3 T
     }
   }
   __syncthreads();
+  const float inv_P2 = __builtin_amdgcn_rcpf((float)P2), inv_P = __builtin_amdgcn_rcpf((float)P);
   for (int k = threadIdx.x; k < ntile; k += blockDim.x) {
     const double v = tile[k];
     if (v != 0.0) {      // padding points stay zero
-      const int r = k % P2;
-      int n1 = (ox + r % P) % K; if (n1 < 0) n1 += K;
-      int n2 = (oy + r / P) % K; if (n2 < 0) n2 += K;
-      int n3 = (oz + k / P2) % K; if (n3 < 0) n3 += K;
+      int cc, r, b, a;
+      divmod_small(k, P2, inv_P2, cc, r); divmod_small(r, P, inv_P, b, a);
+      int n1 = ox + a; n1 += n1 < 0 ? K : 0; n1 -= n1 >= K ? K : 0;      // (origin + offset lies in (-K, 2 K): the tile is no wider than the grid)
+      int n2 = oy + b; n2 += n2 < 0 ? K : 0; n2 -= n2 >= K ? K : 0;
+      int n3 = oz + cc; n3 += n3 < 0 ? K : 0; n3 -= n3 >= K ? K : 0;
       atomicAdd(&grid[gs * (n1 + (size_t)K * (n2 + (size_t)K * n3))], v);
     }
   }
@@ -570,6 +580,7 @@ __global__ __launch_bounds__(512) void k_pme_gather_tiles(int K, int3 nc, int3 T
   const int P = T.x | 1, P2 = spread_plane_stride(T);
   {      // stage: x fastest (coalesced rows of T.x points); four loads in flight per thread (one per trip left the fill latency-bound: 16 dependent trips)
     const int ntile = T.x * T.y * T.z, txy = T.x * T.y;
+    const float inv_txy = __builtin_amdgcn_rcpf((float)txy), inv_tx = __builtin_amdgcn_rcpf((float)T.x);
     for (int r0 = threadIdx.x; r0 < ntile; r0 += 4 * blockDim.x) {
       double v[4]; int dst[4];
 #pragma unroll
@@ -577,7 +588,8 @@ __global__ __launch_bounds__(512) void k_pme_gather_tiles(int K, int3 nc, int3 T
         const int r = r0 + u * blockDim.x;
         dst[u] = -1;
         if (r < ntile) {
-          const int cc = r / txy, rem = r - cc * txy, b = rem / T.x, a = rem - b * T.x;
+          int cc, rem, b, a;
+          divmod_small(r, txy, inv_txy, cc, rem); divmod_small(rem, T.x, inv_tx, b, a);
           int n1 = ox + a; n1 += n1 < 0 ? K : 0; n1 -= n1 >= K ? K : 0;
           int n2 = oy + b; n2 += n2 < 0 ? K : 0; n2 -= n2 >= K ? K : 0;
           int n3 = oz + cc; n3 += n3 < 0 ? K : 0; n3 -= n3 >= K ? K : 0;
@@ -707,16 +719,18 @@ __global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, 
   pme_taps3_issue_rows(tr1, tr2, tr3, rt, sub < 6 ? sub : 0, G, B6, B5, uscale_s, base_s, 3 * iac, nt);
   nq = chg[ni];
   const double sq = chg[si];
-  {      // stage the potential: x fastest (coalesced rows of T.x points); four loads in flight per thread
+  {      // stage the potential: x fastest (coalesced rows of T.x points); ten loads in flight per thread (a 17^3 tile is 9.6 per thread: one round of memory latency instead of three)
     const int ntile = T.x * T.y * T.z, txy = T.x * T.y;
-    for (int r0 = threadIdx.x; r0 < ntile; r0 += 4 * blockDim.x) {
-      double v[4]; int dst[4];
+    const float inv_txy = __builtin_amdgcn_rcpf((float)txy), inv_tx = __builtin_amdgcn_rcpf((float)T.x);
+    for (int r0 = threadIdx.x; r0 < ntile; r0 += 10 * blockDim.x) {
+      double v[10]; int dst[10];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 10; ++u) {
         const int r = r0 + u * blockDim.x;
         dst[u] = -1;
         if (r < ntile) {
-          const int cc = r / txy, rem = r - cc * txy, b = rem / T.x, a = rem - b * T.x;
+          int cc, rem, b, a;
+          divmod_small(r, txy, inv_txy, cc, rem); divmod_small(rem, T.x, inv_tx, b, a);
           int n1 = ox + a; n1 += n1 < 0 ? K : 0; n1 -= n1 >= K ? K : 0;
           int n2 = oy + b; n2 += n2 < 0 ? K : 0; n2 -= n2 >= K ? K : 0;
           int n3 = oz + cc; n3 += n3 < 0 ? K : 0; n3 -= n3 >= K ? K : 0;
@@ -725,7 +739,7 @@ __global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, 
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) if (dst[u] >= 0) tile[dst[u]] = v[u];
+      for (int u = 0; u < 10; ++u) if (dst[u] >= 0) tile[dst[u]] = v[u];
     }
   }
   if (st_on) {

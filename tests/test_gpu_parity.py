@@ -229,7 +229,7 @@ def _schedule_run(spec, opts):
 
 @pytest.mark.parametrize("opts", [{"evb_defer_fold": 0}, {"evb_defer_molecules": 1}, {"evb_defer_molecules": 2}, {"evb_region_main": 1},
                                   {"evb_coupling_blocks": 96}, {"evb_recip_linear": 0}, {"fft_own": 0, "evb_defer_fold": 0, "evb_device_solve": 0},
-                                  {"overlap": 0, "graphs": 0}, {"evb_device_solve": 0}, {"evb_device_solve": 2}, {"evb_blend_aside": 0}, {"pair_pipe": 0},
+                                  {"overlap": 0, "graphs": 0}, {"evb_device_solve": 0}, {"evb_device_solve": 2}, {"evb_blend_aside": 0}, {"pair_pipe": 0}, {"pair_self_mode": 0},
                                   {"evb_device_solve": 0, "evb_blend_aside": 0}, {"step_fuse_refresh": 0}, {"evb_fft_patch": 0}, {"evb_fft_patch": 0, "evb_device_solve": 0}])
 def test_schedule_options_leave_the_forces_alone(opts):
     """the switchable pieces of the step schedule at BASELINE.json configs[2]: same Hamiltonian, same Hellmann-Feynman
@@ -384,10 +384,12 @@ def test_evb_translated_across_the_periodic_boundary(oracle_lib, name):
 @pytest.mark.parametrize("sapt", [False, True])
 def test_half_list_lds_pair_kernel_against_oracle(oracle_lib, sapt):
     """The half-list LDS pair kernel (one workgroup per cell, tile-local list entries; the default whenever the box has >= 4 cells per
-    axis - the small reference fixtures do not, they run the full-list kernel) at the size of BASELINE.json configs[1]: its list decodes
+    axis - the small reference fixtures do not, they run the full-list kernel) at 1.5 x the size of BASELINE.json configs[1] (17^3 sites: five
+    cells of 10.6 A per axis, so that the 14-cell half neighbourhood fits the flat-list kernel's 2560-atom tile; at 15^3 sites the four cells of
+    11.7 A per axis do not and the full-list kernel runs): its list decodes
     to the oracle's pair set, forces / energies equal the oracle's AND the full-list kernel's, with and without the rolling pruned rows,
     also with a live SAPT (Buckingham + Tang-Toennies) term."""
-    s = synth.make_system(15, n_diabat=2, seed=7)
+    s = synth.make_system(17, n_diabat=2, seed=7)
     ff = forcefield.ch3so3h_water_forcefield()
     if sapt:
         ff = forcefield.with_test_sapt(ff)

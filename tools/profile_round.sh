@@ -19,6 +19,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $B --step
 python3 $R/tools/summarize_prof.py $OUT > $OUT/serial_kernel_stats.txt 2>&1 || true
 python3 $R/tools/pair_modes.py $OUT > $OUT/pair_modes.txt 2>&1 || true      # pair kernel: launches that read their list / that rewrite it
 rm -rf $OUT/kt
+if [ -n "$QUICK" ]; then rm -f $OUT/*.log; ls -la $OUT; exit 0; fi      # QUICK=1: the two kernel traces only
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in their own passes (MI355X_MICROARCH.md: they do not fit one pass), default schedule
 # (with counters the profiler runs ONE kernel at a time, in the order they become ready: a kernel that waits on the device for a mark another queue's
 #  kernel sets would wait until its 2 s limit - evb_publish_spin=0 orders those kernels with events instead; same kernels, same bytes)

@@ -195,7 +195,8 @@ int msevb_reset_phase_times(msevb_ctx* ctx);
      schedule             : overlap (1: four streams), graphs (1: front end replayed as a hipGraph), evb_speculate (1), evb_publish_spin (1),
                             evb_late_mol_join (1), evb_single_join (1), evb_defer_fold (1), evb_pme_split (1), evb_defer_molecules (0),
                             evb_blend_aside (1), evb_fft_patch (1), step_fuse_refresh (1), evb_region_main (0), evb_region_aside (0), evb_pair_first (0), evb_device_solve (1: squaring + Jacobi fallback on the device, 2: Jacobi on the device, 0: host),
-                            evb_coupling_blocks (0 = auto), pin_host_arrays (0)
+                            evb_coupling_blocks (0 = auto), pin_host_arrays (0),
+                            pair_self_mode (1), pme_gather_threads (0 = auto: 256 while no cell holds more atoms, else pme_tile_threads)
      multi-GPU            : shard_principal (set by msevb_comm_init)
      measurement          : phase_timing (0), phase_timing_stride (8) */
 int msevb_set_option(msevb_ctx* ctx, const char* name, double value);

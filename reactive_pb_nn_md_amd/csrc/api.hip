@@ -829,6 +829,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "evb_coupling_blocks") { c->evb_coupling_blocks = (int)v; return MSEVB_OK; }
   if (s == "evb_region_main") { c->evb_region_main = v != 0.0; return MSEVB_OK; }
   if (s == "evb_defer_molecules") { c->evb_defer_molecules = v != 0.0; c->evb_molecules_after_pair = v == 2.0; return MSEVB_OK; }      // 1: behind the coupling chain; 2: behind the PAIR LOOP (in the blend phase's window)
+  if (s == "pme_gather_threads") { const int t = (int)v; if (t < 0 || t > 512 || (t & 63)) return MSEVB_ERR_ARG; c->pme_gather_threads = t; return MSEVB_OK; }
   if (s == "pme_tile_threads") { c->pme_tile_threads = v >= 512 ? 512 : 256; c->pme_graph_key[0] = 0; if (c->pme_graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)c->pme_graph_exec); c->pme_graph_exec = nullptr; } return MSEVB_OK; }
   if (s == "fft_own") { c->fft_own = v != 0.0; return MSEVB_OK; }
   if (s == "spread_bricks") { c->spread_bricks = v != 0.0; return MSEVB_OK; }

@@ -321,6 +321,7 @@ struct msevb_ctx {
   DBuf<int> d_flat; DBuf<uint2> d_cell_trips;
   int pair_flat_opt = 1;         // option pair_flat: 0 = k_pair_half on per-atom rows (round 2's kernel; still what force fields with a live SAPT term run)
   bool pair_self_mode = true; int pair_self_nb = 0, pair_epoch = 0; hipEvent_t ev_top2 = nullptr;      // option pair_self_mode: k_pair_flat decides itself whether its list still covers r_c (pair_flat.hip); pair_self_nb > 0: for the next launch, over that many per-block partial maxima
+  bool md_defer_join = false; const long long* step_marks = nullptr; long long step_mark_seq = 0; int step_n_marks = 0;      // MD loop: the blend phase's side kernels are joined by device marks k_step_second_half waits for (evb.hip fast_blend_phase), not by stream events
   bool prune_freeze = false;     // diagnostics (tools/time_stage.py): stage calls on unchanged positions keep the pair list of the first call instead of rewriting it every time
   bool pair_taylor = true;       // option pair_taylor (default on): one Ewald-table row per pair, the other one from the table's own derivatives (pair_flat.hip); 0 = both rows gathered
   bool attr_pair_flat[20] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};
@@ -357,6 +358,7 @@ struct msevb_ctx {
   int attr_gather_wl = 0, attr_gather_wl_b = 0;      // dynamic LDS the weight-free gather (plain / blending instantiation) has been allowed so far
   bool pme_side_weights = false; bool weights_side = false; hipEvent_t ev_weights = nullptr;      // MS-EVB fast path: stored weights computed on a side stream for the blend phase's gather (pme_side_weights)
   bool weights_valid = false;       // d_w / d_dw hold this step's weights (k_pme_prep ran, not k_pme_prep_light)
+  int pme_gather_threads = 0;    // option: workgroup size of the weight-free gather alone (multiple of 64, <= 512; 0 = 256 while no cell holds more atoms than that, else pme_tile_threads)
   int pme_tile_threads = 512;    // workgroup size of the LDS-tile spread / gather kernels (option pme_tile_threads: 256 or 512)
   bool spread_bricks = false;    // option: owner-computes charge spreading on the matrix cores (k_pme_spread_bricks): every cell's workgroup writes ITS brick of the grid, no atomics, no zero-fill
                                  // (needs bricks of <= 8 points per axis, K >= 16).  Measured 63 us alone against 55 + 4 + 5 for the LDS-atomic tiles with fill and copy, 2-3 % slower in the overlapped step: off

@@ -98,6 +98,15 @@ __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt
   const int a = live ? mol_atoms[m * MAX_MOL_ATOMS + k] : 0;
   double ma = 0.0, xn[3] = {0.0, 0.0, 0.0}, vn[3] = {0.0, 0.0, 0.0};
   bool moved = false;
+  // what the refresh part needs of this atom is requested NOW (it depends on the atom's index alone): in flight during the kick, the drift and the centre-of-mass
+  // shuffles instead of two more dependent rounds behind them (sorted position -> snapshot row)
+  int ks = 0; double4 qpr = make_double4(0.0, 0.0, 0.0, 0.0); double sto[3] = {0.0, 0.0, 0.0}, dsp[3] = {0.0, 0.0, 0.0}, chg_a = 0.0;
+  if (live && R.on) {
+    ks = R.inv_perm[a];
+    for (int d = 0; d < 3; ++d) { sto[d] = R.store[3 * a + d]; dsp[d] = R.disp[3 * a + d]; }
+    chg_a = R.chg[a];
+    if (R.posq_prune) qpr = R.posq_prune[ks];
+  }
   if (live) {
     ma = mass[a];
     if (frozen && frozen[a]) { for (int d = 0; d < 3; ++d) xn[d] = x[3 * a + d]; }      // neither kicked nor moved
@@ -134,19 +143,18 @@ __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt
     for (int d = 0; d < 3; ++d) xf[d] = any ? xn[d] + sh[d] : xn[d];
     if (moved || any) for (int d = 0; d < 3; ++d) x[3 * a + d] = xf[d];
     if (R.on) {      // k_step_refresh's work for this atom, same expressions (neighbor.hip)
-      const int ks = R.inv_perm[a];
       if (R.posq_prune) {
-        const double4 q = R.posq_prune[ks];
+        const double4 q = qpr;
         double e[3] = {xf[0] - q.x, xf[1] - q.y, xf[2] - q.z};
         for (int d = 0; d < 3; ++d) e[d] -= box.L[d] * floor(e[d] * box.invL[d] + 0.5);
         nrm_p = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
       }
-      R.posq[ks] = make_double4(xf[0], xf[1], xf[2], R.chg[a]);
+      R.posq[ks] = make_double4(xf[0], xf[1], xf[2], chg_a);
       double ad[3];
       for (int d = 0; d < 3; ++d) {
-        const double dc = xf[d] - R.store[3 * a + d];
+        const double dc = xf[d] - sto[d];
         const double shd = floor(dc * box.invL[d] + 0.5) * box.L[d];
-        ad[d] = R.disp[3 * a + d] + (dc - shd);
+        ad[d] = dsp[d] + (dc - shd);
         R.disp[3 * a + d] = ad[d];
         R.store[3 * a + d] = xf[d];
         F[3 * a + d] = 0.0;
@@ -155,27 +163,47 @@ __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt
     }
   }
   if (!R.on) return;
-  // per-block top-2 of both displacement norms (the order of a maximum does not matter: same bits as k_step_refresh's blocks give k_top2_final)
-  __shared__ double s1[256], s2[256];
-  for (int pass = 0; pass < (R.posq_prune ? 2 : 1); ++pass) {
-    s1[threadIdx.x] = pass ? nrm_p : nrm; s2[threadIdx.x] = 0.0;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-      if ((int)threadIdx.x < st) {
-        const double a1 = s1[threadIdx.x], a2 = s2[threadIdx.x], b1 = s1[threadIdx.x + st], b2 = s2[threadIdx.x + st];
-        s1[threadIdx.x] = fmax(a1, b1); s2[threadIdx.x] = fmax(fmin(a1, b1), fmax(a2, b2));
-      }
-      __syncthreads();
+  // per-block top-2 of both displacement norms (the order of a maximum does not matter: same bits as k_step_refresh's blocks give k_top2_final): butterfly
+  // over the wave, then the four waves' pairs through LDS - one barrier (the 256-wide LDS tree took eight per norm, ~4 us of this kernel)
+  __shared__ double s12[4][4];
+  double a1 = nrm, a2 = 0.0, p1 = nrm_p, p2 = 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double b1 = __shfl_xor(a1, o, 64), b2 = __shfl_xor(a2, o, 64), q1 = __shfl_xor(p1, o, 64), q2 = __shfl_xor(p2, o, 64);
+    const double n1 = fmax(a1, b1), n2 = fmax(fmin(a1, b1), fmax(a2, b2)), m1 = fmax(p1, q1), m2 = fmax(fmin(p1, q1), fmax(p2, q2));
+    a1 = n1; a2 = n2; p1 = m1; p2 = m2;
+  }
+  if ((threadIdx.x & 63) == 0) { double* w = s12[threadIdx.x >> 6]; w[0] = a1; w[1] = a2; w[2] = p1; w[3] = p2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a1 = s12[0][0]; a2 = s12[0][1]; p1 = s12[0][2]; p2 = s12[0][3];
+    for (int w = 1; w < 4; ++w) {
+      const double b1 = s12[w][0], b2 = s12[w][1], q1 = s12[w][2], q2 = s12[w][3];
+      const double n1 = fmax(a1, b1), n2 = fmax(fmin(a1, b1), fmax(a2, b2)), m1 = fmax(p1, q1), m2 = fmax(fmin(p1, q1), fmax(p2, q2));
+      a1 = n1; a2 = n2; p1 = m1; p2 = m2;
     }
-    if (threadIdx.x == 0) { (pass ? R.part3 : R.part1)[blockIdx.x] = s1[0]; (pass ? R.part4 : R.part2)[blockIdx.x] = s2[0]; }
-    __syncthreads();
+    R.part1[blockIdx.x] = a1; R.part2[blockIdx.x] = a2;
+    if (R.posq_prune) { R.part3[blockIdx.x] = p1; R.part4[blockIdx.x] = p2; }
   }
 }
 // second half: one thread per atom - half kick with the |F| > 1e5 guard (:508-529) and the per-block partial sums of momentum and
 // kinetic energy of the kicked velocities (calculate_kinetic_energy, src/total_energy_forces.f90:106)
 __global__ __launch_bounds__(256) void k_step_second_half(int N, double dt, const double* __restrict__ mass, const double* __restrict__ F, double* __restrict__ v,
-                                                          int* __restrict__ bad, double* __restrict__ part, Langevin L, const int* __restrict__ frozen) {
-  __shared__ double red[7][256];
+                                                          int* __restrict__ bad, double* __restrict__ part, Langevin L, const int* __restrict__ frozen,
+                                                          const long long* marks, int n_marks, long long mark_seq, double* __restrict__ fault) {
+  __shared__ double red[7][4];
+  if (n_marks > 0) {      // MS-EVB step: the side streams' last additions to the force array are marked on the device (evb.hip, fast_blend_phase); 2 s limit -> sticky fault flag
+    if (threadIdx.x == 0) {
+      const long long t0 = wall_clock64();
+      for (int k = 0; k < n_marks; ++k)
+        while (__hip_atomic_load(marks + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mark_seq) {
+          if (wall_clock64() - t0 > 200000000LL) { if (fault) *fault = 2.0; break; }
+          __builtin_amdgcn_s_sleep(4);
+        }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    __syncthreads();
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double p[7] = {0, 0, 0, 0, 0, 0, 0};
   if (i < N && frozen && frozen[i]) {      // frozen: velocity untouched, kinetic energy counted, no momentum
@@ -193,12 +221,18 @@ __global__ __launch_bounds__(256) void k_step_second_half(int N, double dt, cons
       p[d] = m * vv; p[3] += 0.5 * m * vv * vv / 100.0; p[4 + d] = vv;
     }
   }
-  for (int s = 0; s < 7; ++s) red[s][threadIdx.x] = p[s];
+  // workgroup sums: butterfly over the wave, the four waves' sums through LDS (one barrier; the 256-wide LDS tree took eight)
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    double v = p[s];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[s][threadIdx.x >> 6] = v;
+  }
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) for (int s = 0; s < 7; ++s) red[s][threadIdx.x] += red[s][threadIdx.x + st]; __syncthreads(); }
   if (threadIdx.x < 7) {
     const int slot[7] = {S_PX, S_PY, S_PZ, S_KE, S_VX, S_VY, S_VZ};
-    part[(size_t)slot[threadIdx.x] * MAX_BLOCKS + blockIdx.x] = red[threadIdx.x][0];
+    part[(size_t)slot[threadIdx.x] * MAX_BLOCKS + blockIdx.x] = ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
   }
 }
 
@@ -277,7 +311,8 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
     c->refresh_fused_nb = fuse ? nbm8 : 0;      // consumed (once) by the force call that follows
     phase_end(c, PH_INTEGRATE);
     double epot = 0.0;
-    if (use_evb) { CHK(evb_force_energy(c, &epot)); }
+    c->step_marks = nullptr; c->step_n_marks = 0;
+    if (use_evb) { c->md_defer_join = c->overlap; const int rc_f = evb_force_energy(c, &epot); c->md_defer_join = false; CHK(rc_f); }
     else {
       CHK(total_force_enqueue(c));
       while (c->nbr_check_pending) {      // rebuild step: the half kick below must not run on forces from a list with a cut row
@@ -288,7 +323,9 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
     }
     c->refresh_fused_nb = 0;
     L.kick = c->langevin_tick++;
-    hipLaunchKernelGGL(k_step_second_half, dim3(nba), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p, c->d_partials.p, L, frz);
+    hipLaunchKernelGGL(k_step_second_half, dim3(nba), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p, c->d_partials.p, L, frz,
+                       c->step_marks, c->step_marks ? c->step_n_marks : 0, c->step_mark_seq, c->d_energies.p + S_FAULT);
+    c->step_marks = nullptr; c->step_n_marks = 0;
     HIPCHK(hipGetLastError());
     if (!use_evb || s == n_steps - 1) {      // (inside the EVB loop the next step's first kernel does this)
       CHK(reduce_partials(c, S_PX, nba)); CHK(reduce_partials(c, S_PY, nba)); CHK(reduce_partials(c, S_PZ, nba)); CHK(reduce_partials(c, S_KE, nba));

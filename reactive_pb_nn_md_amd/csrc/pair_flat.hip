@@ -171,6 +171,13 @@ __device__ __forceinline__ void pf_flush_row(PfAcc& acc, int lane) {      // eve
 }
 
 // Stage B: interaction arithmetic of a trip whose table rows were requested a trip ago; LDS force adds.
+// argument of the Tang-Toennies row lookup in the reference's arithmetic (vdw_interaction, devmath.hpp: r = sqrt(r^2) of the raw coordinates)
+__device__ __forceinline__ double pf_exact_tt_arg(const double4& pi, const double4& pj, const BoxDev& box, double B) {
+#pragma clang fp contract(off)
+  const double r = sqrt(pf_exact_r2(pi, pj, box));
+  return B * r / TT_MAX * (double)TT_GRID;
+}
+
 template <int P, bool TAYLOR, bool SAPT>
 __device__ __forceinline__ void pf_stage_b(const PfTrip& s, int lane, double rc2, double rc2_lo, double rc2_hi, double dxg, double delta, const BoxDev& box,
                                            const double4* __restrict__ posq, int cs, const int* s_lo, const int* s_off, int ns, PfAcc& acc,
@@ -212,7 +219,13 @@ __device__ __forceinline__ void pf_stage_b(const PfTrip& s, int lane, double rc2
         if (sp) {
           const PairParam& pp = pairpar[pa >> 5];
           const double r = s.r2 * s.inv_r, A = pp.p[0], B = pp.p[1];      // (r^2 < r_c^2 for every lane that accumulates: inv_r is 1/r there)
-          const int ti = min(max((int)ceil(B * r / TT_MAX * (double)TT_GRID), 1), TT_GRID);
+          // The damping table is a STEP function of B r (row = ceil(B r / 50 * 1000), no interpolation: the reference's): a pair whose B r sits on a row
+          // boundary to within rounding - lattice-like distances, 3.5 A at B = 3.5 - takes the row the REFERENCE's arithmetic on the raw coordinates
+          // gives (as the cutoff test above does); the tile coordinates differ from those in the last bits
+          double xi = B * r / TT_MAX * (double)TT_GRID;
+          const bool tie = fabs(xi - rint(xi)) <= 1e-9 * fmax(xi, 1.0);
+          if (__builtin_expect(tie, 0)) xi = pf_exact_tt_arg(posq[cs + (int)(s.aa >> 3)], posq[pf_tile_to_sorted((int)(s.ja >> 3), s_lo, s_off, ns)], box, B);
+          const int ti = min(max((int)ceil(xi), 1), TT_GRID);
           const double* t = tt + 4 * (ti - 1);
           const double* dt = dtt + 4 * (ti - 1);
           const double r8i = r6i * inv_r2, r10i = r8i * inv_r2, r12i = r10i * inv_r2;
@@ -588,6 +601,25 @@ bool pair_flat_split(const msevb_ctx* c) {
   return c->pair_split_opt != 0 && !c->has_sapt && c->nt <= 12 && c->sub_tile_max > 0 && (int)(c->sub_tile_max * 1.03) + 1 < 1344;
 }
 
+static void pf_args(msevb_ctx* c, int c_lo, int c_hi, int slot_elec, int slot_vdw, PairFlatArgs& A) {
+  const int N = c->N;
+  A.c_lo = c_lo; A.c_hi = c_hi; A.nc = make_int3(c->ncell[0], c->ncell[1], c->ncell[2]); A.tile_cap = c->half_tile_cap;
+  A.cell_start = c->d_cell_start.p; A.posq = c->d_posq.p; A.type_s = c->d_type_sorted.p;
+  A.nbr_count = c->d_nbr_count.p; A.nbr_split = c->d_nbr_split.p; A.nbr = c->d_nbr.p;
+  A.pairpar = c->d_pair_par.p; A.nt = c->nt;
+  A.etab = c->pair_taylor ? c->d_ewald_tay.p : c->d_ewald_tab.p; A.inv_dx = 1.0 / c->erfc_dx; A.dx = c->erfc_dx; A.delta = c->alpha * c->erfc_dx;
+  for (int d = 0; d < 3; ++d) { A.box.L[d] = c->box[d]; A.box.invL[d] = 1.0 / c->box[d]; }
+  A.rc2 = c->rc * c->rc;
+  A.Fs = c->d_fsorted.p; A.part_el = c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS; A.part_vdw = c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS;
+  A.prune_state = c->d_prune_mode.p; A.flat = c->d_flat.p; A.cell_trips = c->d_cell_trips.p; A.stride = c->nbr_cap;
+  A.posq_prune = c->d_posq_prune.p;
+  A.tt = c->d_tt.p; A.dtt = c->d_dtt.p;
+  const double rp = c->rc + c->prune_delta;
+  A.rp2 = rp * rp; A.N_all = N;
+  A.prd1 = c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS; A.prd2 = c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS; A.prune_delta = c->prune_delta;
+  A.self_nb = 0; A.epoch = 0;
+}
+
 // called by pair_forces (pair.hip) in place of the k_pair_half launch; the caller has sized the pruning state and the sorted-order accumulator
 int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int slot_elec, int slot_vdw, int* nblocks_out) {
   const int N = c->N, ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
@@ -602,22 +634,9 @@ int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int slot_elec, int slot_v
   if (nblocks > MAX_BLOCKS) FAIL(MSEVB_ERR_LIMIT, "pair_forces: too many cells");
   *nblocks_out = nblocks;
   PairFlatArgs A;
-  A.c_lo = c_lo; A.c_hi = c_hi; A.nc = make_int3(c->ncell[0], c->ncell[1], c->ncell[2]); A.tile_cap = c->half_tile_cap;
-  A.cell_start = c->d_cell_start.p; A.posq = c->d_posq.p; A.type_s = c->d_type_sorted.p;
-  A.nbr_count = c->d_nbr_count.p; A.nbr_split = c->d_nbr_split.p; A.nbr = c->d_nbr.p;
-  A.pairpar = c->d_pair_par.p; A.nt = c->nt;
-  A.etab = c->pair_taylor ? c->d_ewald_tay.p : c->d_ewald_tab.p; A.inv_dx = 1.0 / c->erfc_dx; A.dx = c->erfc_dx; A.delta = c->alpha * c->erfc_dx;
-  for (int d = 0; d < 3; ++d) { A.box.L[d] = c->box[d]; A.box.invL[d] = 1.0 / c->box[d]; }
-  A.rc2 = c->rc * c->rc;
-  A.Fs = c->d_fsorted.p; A.part_el = c->d_partials.p + (size_t)slot_elec * MAX_BLOCKS; A.part_vdw = c->d_partials.p + (size_t)slot_vdw * MAX_BLOCKS;
-  A.prune_state = c->d_prune_mode.p; A.flat = c->d_flat.p; A.cell_trips = c->d_cell_trips.p; A.stride = c->nbr_cap;
-  A.posq_prune = c->d_posq_prune.p;
-  A.tt = c->d_tt.p; A.dtt = c->d_dtt.p;
-  const double rp = c->rc + c->prune_delta;
-  A.rp2 = rp * rp; A.N_all = N;
+  pf_args(c, c_lo, c_hi, slot_elec, slot_vdw, A);
   if (++c->pair_epoch <= 0) c->pair_epoch = 1;
   A.epoch = c->pair_epoch; A.self_nb = c->pair_self_nb; c->pair_self_nb = 0;      // (one-shot: set by total_force_enqueue for the launch it is about to make)
-  A.prd1 = c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS; A.prd2 = c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS; A.prune_delta = c->prune_delta;
   const bool ty = c->pair_taylor;
   bool* at = c->attr_pair_flat;
   if (split) {

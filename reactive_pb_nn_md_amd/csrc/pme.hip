@@ -218,6 +218,9 @@ __global__ __launch_bounds__(512) void k_pme_spread_tiles(int K, int3 nc, int3 T
   // ... and the plane stride to 6 (mod 16) doubles, which spreads the 6 x 6 taps of an atom evenly over the 16 double-wide bank pairs
   const int P = T.x | 1, P2 = spread_plane_stride(T);
   const int ntile = P2 * T.z;
+#ifdef PME_GATHER_DIAG
+  const unsigned long long sd0 = __builtin_amdgcn_s_memtime();
+#endif
   for (int k = threadIdx.x; k < ntile; k += blockDim.x) tile[k] = 0.0;
   // per-atom inputs of a chunk of the cell's atoms are staged in LDS first: the scatter loop then has no global loads (it used to wait
   // for six dependent weight loads per item at < 3 waves per SIMD - latency bound, 90 us)
@@ -269,6 +272,9 @@ __global__ __launch_bounds__(512) void k_pme_spread_tiles(int K, int3 nc, int3 T
     }
   }
   __syncthreads();
+#ifdef PME_GATHER_DIAG
+  const unsigned long long sd1 = __builtin_amdgcn_s_memtime();
+#endif
   const float inv_P2 = __builtin_amdgcn_rcpf((float)P2), inv_P = __builtin_amdgcn_rcpf((float)P);
   for (int k = threadIdx.x; k < ntile; k += blockDim.x) {
     const double v = tile[k];
@@ -281,6 +287,12 @@ __global__ __launch_bounds__(512) void k_pme_spread_tiles(int K, int3 nc, int3 T
       atomicAdd(&grid[gs * (n1 + (size_t)K * (n2 + (size_t)K * n3))], v);
     }
   }
+#ifdef PME_GATHER_DIAG
+  const unsigned long long sd2 = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0 && (blockIdx.x % 61) == 5)
+    printf("spread diag block %d atoms %d: zero + atoms %llu clk (100 MHz), flush issue %llu, flush drain %llu\n", blockIdx.x, e - s, sd1 - sd0, sd2 - sd1, __builtin_amdgcn_s_memtime() - sd2);
+#endif
 }
 
 // MFMA spread (north_star: "MFMA used only for the B-spline -> charge-grid spreading/gathering contraction").  One workgroup (4 waves) per
@@ -686,6 +698,9 @@ __global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, 
                                                              double k02, double k10, double k11, double k12, double k20, double k21, double k22,
                                                              double* __restrict__ F_recip, double* __restrict__ F, int atomic, int add_lo, int add_hi, double* __restrict__ Fs, int NFs) {
   extern __shared__ double tile[];
+#ifdef PME_GATHER_DIAG
+  const unsigned long long gd0 = __builtin_amdgcn_s_memtime();
+#endif
   const int cidx = blockIdx.x;
   const int cx = cidx % nc.x, cy = (cidx / nc.x) % nc.y, cz = cidx / (nc.x * nc.y);
   const int ox = (int)floor((double)cx * K / nc.x) - 6, oy = (int)floor((double)cy * K / nc.y) - 6, oz = (int)floor((double)cz * K / nc.z) - 6;
@@ -716,37 +731,57 @@ __global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, 
   const int ks = st_on ? s + (int)threadIdx.x : iac;
   const int2 su1 = rows_s[3 * ks], su2 = rows_s[3 * ks + 1], su3 = rows_s[3 * ks + 2];
   const int sb1 = base_s[3 * ks], sb2 = base_s[3 * ks + 1], sb3 = base_s[3 * ks + 2], si = perm[ks];
+  // the tile's loads go out BEHIND the loads above and IN FRONT of the loads that wait for them (table rows, charges): the counter retires in order, so
+  // the wait for trip 0's coordinates leaves the tile loads in flight - one round of memory latency for both (they were two: 2-5 + 4-9 us per workgroup, measured)
+  const int ntile = T.x * T.y * T.z, txy = T.x * T.y;
+  const float inv_txy = __builtin_amdgcn_rcpf((float)txy), inv_tx = __builtin_amdgcn_rcpf((float)T.x);
+  auto tile_index = [&](int r, size_t& src, int& dst) {      // point r of the tile (x fastest: coalesced rows of T.x points) -> grid point, LDS slot
+    int cc, rem, b, a;
+    divmod_small(r, txy, inv_txy, cc, rem); divmod_small(rem, T.x, inv_tx, b, a);
+    int n1 = ox + a; n1 += n1 < 0 ? K : 0; n1 -= n1 >= K ? K : 0;
+    int n2 = oy + b; n2 += n2 < 0 ? K : 0; n2 -= n2 >= K ? K : 0;
+    int n3 = oz + cc; n3 += n3 < 0 ? K : 0; n3 -= n3 >= K ? K : 0;
+    src = n1 + (size_t)K * (n2 + (size_t)K * n3);
+    dst = a + P * b + P2 * cc;
+  };
+  constexpr int FILL = 13;      // loads in flight per thread (a 16^3 tile is 8 per thread at 512 threads, 12.8 at 320)
+  double v0[FILL];
+#pragma unroll
+  for (int u = 0; u < FILL; ++u) {
+    const int r = (int)threadIdx.x + u * (int)blockDim.x;
+    v0[u] = 0.0;
+    if (r < ntile) { size_t src; int dst; tile_index(r, src, dst); v0[u] = theta[src]; }
+  }
   pme_taps3_issue_rows(tr1, tr2, tr3, rt, sub < 6 ? sub : 0, G, B6, B5, uscale_s, base_s, 3 * iac, nt);
   nq = chg[ni];
   const double sq = chg[si];
-  {      // stage the potential: x fastest (coalesced rows of T.x points); ten loads in flight per thread (a 17^3 tile is 9.6 per thread: one round of memory latency instead of three)
-    const int ntile = T.x * T.y * T.z, txy = T.x * T.y;
-    const float inv_txy = __builtin_amdgcn_rcpf((float)txy), inv_tx = __builtin_amdgcn_rcpf((float)T.x);
-    for (int r0 = threadIdx.x; r0 < ntile; r0 += 10 * blockDim.x) {
-      double v[10]; int dst[10];
+#ifdef PME_GATHER_DIAG
+  const unsigned long long gd1 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
-      for (int u = 0; u < 10; ++u) {
-        const int r = r0 + u * blockDim.x;
-        dst[u] = -1;
-        if (r < ntile) {
-          int cc, rem, b, a;
-          divmod_small(r, txy, inv_txy, cc, rem); divmod_small(rem, T.x, inv_tx, b, a);
-          int n1 = ox + a; n1 += n1 < 0 ? K : 0; n1 -= n1 >= K ? K : 0;
-          int n2 = oy + b; n2 += n2 < 0 ? K : 0; n2 -= n2 >= K ? K : 0;
-          int n3 = oz + cc; n3 += n3 < 0 ? K : 0; n3 -= n3 >= K ? K : 0;
-          v[u] = theta[n1 + (size_t)K * (n2 + (size_t)K * n3)];
-          dst[u] = a + P * b + P2 * cc;
-        }
-      }
+  for (int u = 0; u < FILL; ++u) {
+    const int r = (int)threadIdx.x + u * (int)blockDim.x;
+    if (r < ntile) { size_t src; int dst; tile_index(r, src, dst); tile[dst] = v0[u]; }
+  }
+  for (int r0 = (int)threadIdx.x + FILL * (int)blockDim.x; r0 < ntile; r0 += FILL * blockDim.x) {      // (larger tiles: the rest, FILL at a time)
+    double v[FILL]; int dst[FILL];
 #pragma unroll
-      for (int u = 0; u < 10; ++u) if (dst[u] >= 0) tile[dst[u]] = v[u];
+    for (int u = 0; u < FILL; ++u) {
+      const int r = r0 + u * blockDim.x;
+      dst[u] = -1;
+      if (r < ntile) { size_t src; tile_index(r, src, dst[u]); v[u] = theta[src]; }
     }
+#pragma unroll
+    for (int u = 0; u < FILL; ++u) if (dst[u] >= 0) tile[dst[u]] = v[u];
   }
   if (st_on) {
     const int k = threadIdx.x;
     cu[3 * k] = su1; cu[3 * k + 1] = su2; cu[3 * k + 2] = su3; cb[3 * k] = sb1; cb[3 * k + 1] = sb2; cb[3 * k + 2] = sb3; ci[k] = si; cq[k] = sq;
   }
   __syncthreads();
+#ifdef PME_GATHER_DIAG
+  const unsigned long long gd2 = __builtin_amdgcn_s_memtime();
+#endif
   for (int a0 = s; a0 < e; a0 += ngrp) {      // uniform trip count per wave (shuffles below)
     const int ia = a0 + grp;
     const bool live = ia < e;
@@ -828,6 +863,12 @@ __global__ __launch_bounds__(512, 2) void k_pme_gather_tiles_wl(int K, int3 nc, 
       }
     }
   }
+#ifdef PME_GATHER_DIAG
+  const unsigned long long gd3 = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0 && (blockIdx.x % 61) == 5)
+    printf("gather diag block %d atoms %d: prologue %llu clk (100 MHz), fill %llu, atom loop %llu, drain %llu\n", blockIdx.x, e - s, gd1 - gd0, gd2 - gd1, gd3 - gd2, __builtin_amdgcn_s_memtime() - gd3);
+#endif
 }
 
 // MFMA gather (option gather_mfma; north_star: "... spreading/GATHERING contraction"): the transpose of k_pme_spread_mfma.  One workgroup
@@ -1170,13 +1211,16 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
       if (!c->weights_valid && c->weights_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_weights, 0));      // (k_pme_weights filled them in on a side stream meanwhile)
       if (!c->weights_valid && !c->weights_side) {      // k_pme_prep_light ran: per workgroup 192 B of LDS per 8-lane group + 48 B per atom of the largest cell
         const int cap = std::min(std::max((int)(c->cell_atoms_max * 1.05) + 1, 16), 1024);      // (the largest cell of the last build whose statistics the host has seen)
-        const size_t lds = tile_bytes + (size_t)c->pme_tile_threads * 24 + (size_t)cap * 48 + 16;
+        // 256 threads (32 atoms per trip) when the cells hold <= 256 atoms: 49 KB of LDS per workgroup, three per CU - all 729 workgroups of configs[2] resident at once instead of
+        // 1.4 rounds of two 512-thread ones (0.4021 against 0.4121 ms per step; 320 and 384 threads: 0.4209 / 0.4170 - HISTORY.md E)
+        const int gthreads = c->pme_gather_threads > 0 ? c->pme_gather_threads : (c->cell_atoms_max <= 256 ? 256 : c->pme_tile_threads);
+        const size_t lds = tile_bytes + (size_t)gthreads * 24 + (size_t)cap * 48 + 16;
         if (lds > 160 * 1024) FAIL(MSEVB_ERR_LIMIT, "pme_gather: cell too large for the weight-free gather (set option pme_weightless=0)");
         const bool fuse = Fs_fold && folded && F_add && atomic;
         auto kern = fuse ? k_pme_gather_tiles_wl<true> : k_pme_gather_tiles_wl<false>;
         int& attr = fuse ? c->attr_gather_wl_b : c->attr_gather_wl;
         if (lds > 64 * 1024 && attr < (int)lds) { HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = (int)lds; }
-        hipLaunchKernelGGL(kern, dim3(ncell), dim3(c->pme_tile_threads), lds, c->stream, c->K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T, c->d_cell_start.p, c->d_perm.p,
+        hipLaunchKernelGGL(kern, dim3(ncell), dim3(gthreads), lds, c->stream, c->K, make_int3(c->ncell[0], c->ncell[1], c->ncell[2]), T, c->d_cell_start.p, c->d_perm.p,
                            chg, c->d_base_s.p, c->d_uscale_s.p, c->d_rows_s.p, c->d_B6.p, c->d_B5.p, c->spline_grid, cap, theta ? theta : c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
                            c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], F_recip, F_add, atomic ? 1 : 0, add_lo, add_hi, fuse ? Fs_fold : (double*)nullptr, c->N);
         if (fuse) *folded = true;

@@ -321,7 +321,6 @@ struct msevb_ctx {
   DBuf<int> d_flat; DBuf<uint2> d_cell_trips;
   int pair_flat_opt = 1;         // option pair_flat: 0 = k_pair_half on per-atom rows (round 2's kernel; still what force fields with a live SAPT term run)
   bool pair_self_mode = true; int pair_self_nb = 0, pair_epoch = 0; hipEvent_t ev_top2 = nullptr;      // option pair_self_mode: k_pair_flat decides itself whether its list still covers r_c (pair_flat.hip); pair_self_nb > 0: for the next launch, over that many per-block partial maxima
-  bool md_defer_join = false; const long long* step_marks = nullptr; long long step_mark_seq = 0; int step_n_marks = 0;      // MD loop: the blend phase's side kernels are joined by device marks k_step_second_half waits for (evb.hip fast_blend_phase), not by stream events
   bool prune_freeze = false;     // diagnostics (tools/time_stage.py): stage calls on unchanged positions keep the pair list of the first call instead of rewriting it every time
   bool pair_taylor = true;       // option pair_taylor (default on): one Ewald-table row per pair, the other one from the table's own derivatives (pair_flat.hip); 0 = both rows gathered
   bool attr_pair_flat[20] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};

@@ -1717,19 +1717,6 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(w->ev_bterms, sb));
   }
-  // MD loop (c->md_defer_join): what the main stream would wait for behind the gather - the blend terms, and the per-molecule kernel when the ONE side event left it
-  // out - is marked on the device instead (k_evb_mark behind each on its own stream); the integrator's second kernel, the first reader of the force array, starts on
-  // the marks (both set ~100 us earlier): two barrier packets (a cross-stream hop is ~6-10 us even when its event has long fired) off the step's tail
-  static const bool no_mark_join = getenv("MSEVB_NO_MARK_JOIN") != nullptr;      // (diagnostic: the event waits instead)
-  const bool mark_join = !no_mark_join && aside && c->md_defer_join && w->side_by_mark && w->d_chain_done.p && !c->nccl_comm && c->n_ranks == 1;
-  if (mark_join) {
-    hipLaunchKernelGGL(k_evb_mark, dim3(1), dim3(1), 0, c->aux, w->d_chain_done.p + 4, w->blend_mark_seq);
-    int nm = 1;
-    if (one_wait && w->side_wo_mol) { hipLaunchKernelGGL(k_evb_mark, dim3(1), dim3(1), 0, c->aux3, w->d_chain_done.p + 5, w->blend_mark_seq); nm = 2; }
-    else hipLaunchKernelGGL(k_evb_mark, dim3(1), dim3(1), 0, c->aux, w->d_chain_done.p + 5, w->blend_mark_seq);      // (one slot count for the kernel: both are always set)
-    (void)nm;
-    c->step_marks = w->d_chain_done.p + 4; c->step_mark_seq = w->blend_mark_seq; c->step_n_marks = 2;
-  }
   double* const fold = (aside && c->fsorted_pending) ? c->d_fsorted.p : (double*)nullptr;
   auto join_before_blend = [&]() -> int {      // everything else that adds to the force array has to be in before the kernel that blends (k_evb_blend, or the fused gather)
     if (c->overlap && !one_wait) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_join2, 0)); if (ngrid) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_rs, 0)); }
@@ -1786,10 +1773,10 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   // ... the special atoms' own-stencil corrections per diabat are in the delta store already (k_evb_recip_special ran at the end of the
   // diabat grid chain, before the host's turn); the blend consumes the store and re-zeroes it
   (void)nra; (void)d_ra;
-  if (!mark_join) CHK(join_before_blend());
+  CHK(join_before_blend());
   if (aside) {
     if (fold && !folded) FAIL(MSEVB_ERR_STATE, "blend phase: the gather that was to fold the pair loop's accumulator in did not run");
-    if (!mark_join) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_bterms, 0));      // the terms went in long ago (15 us of streaming beside 60 us of transform + gather)
+    HIPCHK(hipStreamWaitEvent(c->stream, w->ev_bterms, 0));      // the terms went in long ago (15 us of streaming beside 60 us of transform + gather)
   } else {
   hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, dcoef ? dcoef + 1 + ngrid : (const double*)nullptr, w11, w->d_Fdelta.p, c->d_Foff.p, n3, c->d_force.p, 1,
                      c->fsorted_pending ? c->d_fsorted.p : (double*)nullptr, c->d_inv_perm.p, c->N);
@@ -2222,7 +2209,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   stamp(c, 4, sr);
   const bool pub_spin = c->overlap && c->evb_publish_spin;      // fetch A's publish kernel waits for the chains' marks, not for their events
   if (pub_spin) {
-    if (!w->d_chain_done.p) { if (w->d_chain_done.alloc(8)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (chain marks)"); HIPCHK(hipMemset(w->d_chain_done.p, 0, 64)); HIPCHK(hipDeviceSynchronize()); }      // (once per context.  hipMemset of device memory may RETURN EARLY and the library's streams do not wait for the null stream: without the synchronisation the fill could land BEHIND the first mark and wipe it - the energy-fetch kernel then sat out its 2 s limit: the intermittent MSEVB_ERR_NUMERIC of round 3, HISTORY.md E; the marks come from different streams)
+    if (!w->d_chain_done.p) { if (w->d_chain_done.alloc(4)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (chain marks)"); HIPCHK(hipMemset(w->d_chain_done.p, 0, 32)); HIPCHK(hipDeviceSynchronize()); }      // (once per context.  hipMemset of device memory may RETURN EARLY and the library's streams do not wait for the null stream: without the synchronisation the fill could land BEHIND the first mark and wipe it - the energy-fetch kernel then sat out its 2 s limit: the intermittent MSEVB_ERR_NUMERIC of round 3, HISTORY.md E; the marks come from different streams)
     hipLaunchKernelGGL(k_evb_mark, dim3(1), dim3(1), 0, sr, w->d_chain_done.p, w->seq_A + 1);
   }
   if (c->overlap) HIPCHK(hipEventRecord(w->ev_join2, w->stream2));

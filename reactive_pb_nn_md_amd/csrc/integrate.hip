@@ -189,21 +189,8 @@ __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt
 // second half: one thread per atom - half kick with the |F| > 1e5 guard (:508-529) and the per-block partial sums of momentum and
 // kinetic energy of the kicked velocities (calculate_kinetic_energy, src/total_energy_forces.f90:106)
 __global__ __launch_bounds__(256) void k_step_second_half(int N, double dt, const double* __restrict__ mass, const double* __restrict__ F, double* __restrict__ v,
-                                                          int* __restrict__ bad, double* __restrict__ part, Langevin L, const int* __restrict__ frozen,
-                                                          const long long* marks, int n_marks, long long mark_seq, double* __restrict__ fault) {
+                                                          int* __restrict__ bad, double* __restrict__ part, Langevin L, const int* __restrict__ frozen) {
   __shared__ double red[7][4];
-  if (n_marks > 0) {      // MS-EVB step: the side streams' last additions to the force array are marked on the device (evb.hip, fast_blend_phase); 2 s limit -> sticky fault flag
-    if (threadIdx.x == 0) {
-      const long long t0 = wall_clock64();
-      for (int k = 0; k < n_marks; ++k)
-        while (__hip_atomic_load(marks + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mark_seq) {
-          if (wall_clock64() - t0 > 200000000LL) { if (fault) *fault = 2.0; break; }
-          __builtin_amdgcn_s_sleep(4);
-        }
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    }
-    __syncthreads();
-  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double p[7] = {0, 0, 0, 0, 0, 0, 0};
   if (i < N && frozen && frozen[i]) {      // frozen: velocity untouched, kinetic energy counted, no momentum
@@ -311,8 +298,7 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
     c->refresh_fused_nb = fuse ? nbm8 : 0;      // consumed (once) by the force call that follows
     phase_end(c, PH_INTEGRATE);
     double epot = 0.0;
-    c->step_marks = nullptr; c->step_n_marks = 0;
-    if (use_evb) { c->md_defer_join = c->overlap; const int rc_f = evb_force_energy(c, &epot); c->md_defer_join = false; CHK(rc_f); }
+    if (use_evb) { CHK(evb_force_energy(c, &epot)); }
     else {
       CHK(total_force_enqueue(c));
       while (c->nbr_check_pending) {      // rebuild step: the half kick below must not run on forces from a list with a cut row
@@ -323,9 +309,7 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
     }
     c->refresh_fused_nb = 0;
     L.kick = c->langevin_tick++;
-    hipLaunchKernelGGL(k_step_second_half, dim3(nba), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p, c->d_partials.p, L, frz,
-                       c->step_marks, c->step_marks ? c->step_n_marks : 0, c->step_mark_seq, c->d_energies.p + S_FAULT);
-    c->step_marks = nullptr; c->step_n_marks = 0;
+    hipLaunchKernelGGL(k_step_second_half, dim3(nba), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p, c->d_partials.p, L, frz);
     HIPCHK(hipGetLastError());
     if (!use_evb || s == n_steps - 1) {      // (inside the EVB loop the next step's first kernel does this)
       CHK(reduce_partials(c, S_PX, nba)); CHK(reduce_partials(c, S_PY, nba)); CHK(reduce_partials(c, S_PZ, nba)); CHK(reduce_partials(c, S_KE, nba));

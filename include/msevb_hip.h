@@ -189,7 +189,7 @@ int msevb_reset_phase_times(msevb_ctx* ctx);
                             Hamiltonian element as the reference's evb_forces_store does), evb_recip_linear (1: diabats' reciprocal space by linear
                             response, 0: one transform pair per diabat as src/ms_evb.f90:1962 does)
      pair loop            : pair_tiles (-1 auto), pair_flat (1: flat per-cell list, pair_flat.hip), pair_taylor (1: one-row Ewald table), pair_prune (1),
-                            prune_delta (0.6 A), pair_split (0), pair_threads (1024), prune_freeze (diagnostic), nbr_tiles (1), nbr_cap (row stride)
+                            prune_delta (min(0.75 A, (verlet_cutoff - real_space_cutoff) / 2)), pair_split (0), pair_threads (1024), prune_freeze (diagnostic), nbr_tiles (1), nbr_cap (row stride)
      PME                  : fft_own (1: own 64^3 / 128^3 transforms, 0: rocFFT), spread_tiles (1), pme_weightless (1: no per-atom weight store),
                             pme_side_weights (0), spread_mfma (0), spread_bricks (0), gather_mfma (0), pme_tile_threads (512), fft_batch
      schedule             : overlap (1: four streams), graphs (1: front end replayed as a hipGraph), evb_speculate (1), evb_publish_spin (1),

@@ -175,6 +175,7 @@ int msevb_set_system(msevb_ctx* c, int N, int M, const double* box, double rc, d
     if (rv >= 0.5 * c->box[d]) FAIL(MSEVB_ERR_ARG, "verlet skin width is too big for this box");
   }
   c->N = N; c->M = M; c->rc = rc; c->rv = rv; c->alpha = alpha; c->K = K; c->order = order; c->spline_grid = spline_grid; c->erfc_grid = erfc_grid;
+  c->prune_delta = std::min(0.75, 0.5 * (rv - rc));      // margin of the rolling pair list: half the Verlet skin, at most 0.75 A (0.45 / 0.6 / 0.75 / 0.9 A at r_v - r_c = 1.5: 0.411 / 0.402 / 0.399 / 0.399 ms per step; option prune_delta overrides)
   c->finalized = false;
   return MSEVB_OK;
 }
@@ -683,6 +684,7 @@ int total_force_enqueue(msevb_ctx* c) {
   } else {
     // the pair kernel can take the "does my list still cover r_c" decision itself: k_top2_final then only serves the host's rebuild flag and runs beside the pair loop
     self_nb = (c->overlap && c->pair_self_mode && !c->prune_freeze && c->d_prune_mode.p && c->d_posq_prune.p && pair_flat_usable(c)) ? (fused_nb > 0 ? fused_nb : (c->N + 255) / 256) : 0;
+    if (self_nb > 2048) self_nb = 0;      // (every pair workgroup reads all the partial maxima: 16 B x self_nb each - at configs[4] size 10 264 blocks x 7 900 workgroups; k_top2_final decides there)
     if (fused_nb > 0) { if (!self_nb) CHK(nb_step_top2(c, fused_nb)); }      // the integrator's first kernel did the refresh
     else CHK(nb_step_refresh(c, nullptr, self_nb == 0));
   }

@@ -314,7 +314,7 @@ struct msevb_ctx {
   bool list_valid = false;
   // rolling pruned pair list (pair.hip): rows of the pairs within rc + prune_delta, rewritten by the pair loop itself whenever the two
   // largest displacements since the last pruning add up to prune_delta; d_prune_mode[0]: 1 = this step prunes, 2 = this step uses the rows
-  bool prune = true; double prune_delta = 0.6; int prune_lo = -1, prune_hi = -1;
+  bool prune = true; double prune_delta = 0.6 /* msevb_create sets min(0.75, (r_v - r_c) / 2) */; int prune_lo = -1, prune_hi = -1;
   DBuf<int> d_nbr2, d_prune_mode; DBuf<unsigned> d_nbr2_count; DBuf<double4> d_posq_prune;
   // flat per-cell pair list of k_pair_flat (pair_flat.hip): the cell's pairs within rc + prune_delta, rows padded to 16 entries, one segment per wave of the
   // cell's workgroup; cell c's list starts at cell_start[c] * (nbr_cap + 96) + 3584 c, d_cell_trips[32 c + 16 h + w] = {offset, length in 64-entry trips} of the segment of wave w of workgroup h

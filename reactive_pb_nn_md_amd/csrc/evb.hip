@@ -2481,9 +2481,15 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     E0 = en[MSEVB_E_POTENTIAL] - (1.0 - once) * c->ewald_self;
     return MSEVB_OK;
   };
+  auto remember_plan = [&]() {      // what the next steps start from (speculative step)
+    w->pl_D = D; memcpy(w->pl_plog, c->plog, sizeof c->plog); memcpy(w->pl_parent, c->parent, sizeof c->parent);
+    w->pl_units_of = units_of; w->pl_grid_of = grid_of; w->pl_cp_of = cp_of; w->pl_eref_delta = eref_delta; w->pl_ngrid = ngrid; w->pl_ncp_big = ncp_big;
+    w->plan_valid = true; w->plan_epoch = c->topo_epoch;
+  };
   if (c->n_ranks > 1 && !c->nccl_comm) {   // virtual sharding (tests): leave foreign diabats empty; caller merges
     double E0 = 0.0;
     CHK(principal_energy(E0));
+    if (!spec && w->plan_fits && c->evb_speculate) remember_plan();      // (round 4: this return used to skip it - virtual ranks never speculated, and tools/virtual_rank_times.py timed the long way round every call)
     for (int d = 0; d < D; ++d) if (d == 0 || owned(c, d)) c->H[d][d] += E0;
     if (epot_out) *epot_out = c->H[0][0];
     if (fast) w->delta_dirty = true;      // no blend consumed the delta store: msevb_evb_partial_blend may still, the next call re-zeroes it
@@ -2553,11 +2559,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     CHK(nb_build(c));
     c->flag_verlet_list = 0;
   }
-  if (!spec && w->plan_fits && c->evb_speculate && c->new_hydronium == c->hydronium) {      // what the next steps start from
-    w->pl_D = D; memcpy(w->pl_plog, c->plog, sizeof c->plog); memcpy(w->pl_parent, c->parent, sizeof c->parent);
-    w->pl_units_of = units_of; w->pl_grid_of = grid_of; w->pl_cp_of = cp_of; w->pl_eref_delta = eref_delta; w->pl_ngrid = ngrid; w->pl_ncp_big = ncp_big;
-    w->plan_valid = true; w->plan_epoch = c->topo_epoch;
-  }
+  if (!spec && w->plan_fits && c->evb_speculate && c->new_hydronium == c->hydronium) remember_plan();
   rearm.ok = true;
   HT(11); g_ht.n++;
   if (ht_on && (g_ht.n % 100) == 0) fprintf(stderr, "[msevb] speculative steps %ld, of which the tree had changed %ld\n", w->spec_steps, w->spec_misses);

@@ -420,6 +420,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_pair_flat(const PairFlatArgs 
       }
     }
     __syncthreads();
+#if PF_EXP & 256
+    const unsigned long long tsA = __builtin_amdgcn_s_memtime();
+#endif
     const unsigned TT = sm.tt;
     unsigned ft = (unsigned)(((unsigned long long)TT * (unsigned)wave) / (unsigned)wpb);
     const unsigned ft1 = (unsigned)(((unsigned long long)TT * (unsigned)(wave + 1)) / (unsigned)wpb);
@@ -488,9 +491,16 @@ __global__ __launch_bounds__(THREADS, MINW) void k_pair_flat(const PairFlatArgs 
     seg_trips = (o + 63u) >> 6;
     if (o + lane < (seg_trips << 6)) out[o + lane] = (int)(((unsigned)a_last << PF_A_SHIFT) + (unsigned)ntile);
     if (lane == 0) *meta = make_uint2(seg_off, seg_trips);
+#if PF_EXP & 256
+    const unsigned long long tsB = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();      // (the stores of the wave's segment have left it, which is all its own reads of the segment need: same CU, write-through L1)
     for (int p = threadIdx.x; p <= ntile; p += blockDim.x) { tf[p] = 0.0; tf[P + p] = 0.0; tf[2 * P + p] = 0.0; }      // the force tile held the single-precision copy
     __syncthreads();
+#if PF_EXP & 256
+    if (lane == 0 && (wave == 0 || wave == 15) && (blockIdx.x % 97) == 5)
+      printf("pf diag REWRITE block %d wave %d pieces %u: row prefix %llu clk, pieces %llu, wait + zero the force tile %llu\n", blockIdx.x, wave, ft1 - ft, tsA - ts1, tsB - tsA, __builtin_amdgcn_s_memtime() - tsB);
+#endif
   } else {
     const uint2 sg = *meta;
     seg_off = sg.x; seg_trips = sg.y;
@@ -572,8 +582,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_pair_flat(const PairFlatArgs 
   }
 #if PF_EXP & 256
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0 && (wave == 0 || wave == wpb - 1) && (blockIdx.x % 97) == 5 && mode == 2)
-    printf("pf diag block %d wave %d trips %u: staging %llu clk, loop %llu, wait for the other waves %llu, flush %llu\n", blockIdx.x, wave, t1, ts1 - ts0, ts2 - ts1, ts3 - ts2, __builtin_amdgcn_s_memtime() - ts3);
+  if (lane == 0 && (wave == 0 || wave == wpb - 1) && (blockIdx.x % 97) == 5)
+    printf("pf diag block %d mode %d wave %d trips %u: staging %llu clk, loop %llu, wait for the other waves %llu, flush %llu\n", blockIdx.x, mode, wave, t1, ts1 - ts0, ts2 - ts1, ts3 - ts2, __builtin_amdgcn_s_memtime() - ts3);
 #endif
 }
 

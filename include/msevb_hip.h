@@ -23,7 +23,8 @@ extern "C" {
 typedef struct msevb_ctx msevb_ctx;
 
 enum { MSEVB_OK = 0, MSEVB_ERR_ARG = -1, MSEVB_ERR_HIP = -2, MSEVB_ERR_STATE = -3, MSEVB_ERR_FFT = -4, MSEVB_ERR_LIMIT = -5,
-       MSEVB_ERR_NUMERIC = -6, MSEVB_ERR_COMM = -7 };
+       MSEVB_ERR_NUMERIC = -6, MSEVB_ERR_COMM = -7,
+       MSEVB_ERR_TIMEOUT = -8 /* a device-side wait of the MS-EVB call ran into its wall-clock limit (not a statement about the coordinates) */ };
 
 /* energies[] layout of msevb_calculate_total_force_energy (system_data%E_* of src/glob_v.f90:137-142) */
 enum { MSEVB_E_POTENTIAL = 0, MSEVB_E_ELEC = 1, MSEVB_E_VDW = 2, MSEVB_E_BOND = 3, MSEVB_E_ANGLE = 4, MSEVB_E_DIHEDRAL = 5,

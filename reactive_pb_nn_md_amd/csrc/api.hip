@@ -175,7 +175,11 @@ int msevb_set_system(msevb_ctx* c, int N, int M, const double* box, double rc, d
     if (rv >= 0.5 * c->box[d]) FAIL(MSEVB_ERR_ARG, "verlet skin width is too big for this box");
   }
   c->N = N; c->M = M; c->rc = rc; c->rv = rv; c->alpha = alpha; c->K = K; c->order = order; c->spline_grid = spline_grid; c->erfc_grid = erfc_grid;
-  c->prune_delta = std::min(0.75, 0.5 * (rv - rc));      // margin of the rolling pair list: half the Verlet skin, at most 0.75 A (0.45 / 0.6 / 0.75 / 0.9 A at r_v - r_c = 1.5: 0.411 / 0.402 / 0.399 / 0.399 ms per step; option prune_delta overrides)
+  // the weight-free PME kernels pack floor(f G / 6) and floor(f G / 5) into 16-bit fields of a row seed (pme_row_seed, pme.hip): G / 5 must stay below 65 536
+  // (the reference's tables have 100 000 rows, src/glob_v.f90); larger tables would silently read wrong rows
+  if (spline_grid < 12 || spline_grid > 5 * 65535) FAIL(MSEVB_ERR_LIMIT, "spline_grid outside 12 ... 327 675 (row seeds of the PME kernels hold 16-bit table offsets)");
+  if (erfc_grid < 2) FAIL(MSEVB_ERR_ARG, "erfc_grid must be at least 2");
+  if (!c->prune_delta_user) c->prune_delta = std::min(0.75, 0.5 * (rv - rc));      // margin of the rolling pair list: half the Verlet skin, at most 0.75 A (0.45 / 0.6 / 0.75 / 0.9 A at r_v - r_c = 1.5: 0.411 / 0.402 / 0.399 / 0.399 ms per step; option prune_delta overrides)
   c->finalized = false;
   return MSEVB_OK;
 }
@@ -504,7 +508,8 @@ int msevb_set_positions(msevb_ctx* c, const double* xyz) {
   pin_user_buffer(c, xyz, 3 * (size_t)c->N * 8);
   CHK(upload_atoms3(c, c->d_xyz.p, xyz));
   HIPCHK(hipMemsetAsync(c->d_energies.p + S_FAULT, 0, 8, c->stream));      // new coordinates: the sticky bad-coordinate flag starts over
-  c->h_energies[S_FAULT] = 0.0;
+  HIPCHK(hipMemsetAsync(c->d_energies.p + S_TIMEOUT, 0, 8, c->stream));
+  c->h_energies[S_FAULT] = 0.0; c->h_energies[S_TIMEOUT] = 0.0;
   HIPCHK(hipStreamSynchronize(c->stream));
   return MSEVB_OK;
 }
@@ -723,8 +728,7 @@ int total_force_enqueue(msevb_ctx* c) {
 int total_force_collect(msevb_ctx* c, double* en) {
   const double* h = c->h_energies;
   // the index arithmetic of the reference (and ours) covers atoms at most one box image away; a blown-up trajectory is reported, not run
-  if (h[S_FAULT] == 2.0) FAIL(MSEVB_ERR_NUMERIC, "the energy-fetch kernel gave up waiting for the side chains of the MS-EVB call (2 s): a kernel of those chains never finished");
-  if (h[S_FAULT] == 5.0) FAIL(MSEVB_ERR_NUMERIC, "the blend phase gave up waiting for the host's coefficients (5 s)");
+  if (h[S_TIMEOUT] != 0.0) FAIL(MSEVB_ERR_TIMEOUT, "a kernel of the MS-EVB call gave up waiting for a mark of another stream (2 s): a kernel of the side chains never finished, or the waiting kernel and the one it waits for could not run at the same time (profilers that serialise kernels: option evb_publish_spin=0)");
   if (h[S_FAULT] != 0.0) {      // code + 16 x (atom + 1) of the LAST kernel that met such a coordinate (k_pme_prep: 1; special atoms of the MS-EVB call: 3 / 4)
     const long v = (long)h[S_FAULT]; const int code = (int)(v % 16); const long atom = v / 16 - 1;
     char b[512]; double xv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -844,7 +848,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "langevin_seed") { c->langevin_seed = (unsigned long long)v; c->langevin_tick = 0; return MSEVB_OK; }
   if (s == "overlap") { c->overlap = v != 0.0; return MSEVB_OK; }
   if (s == "pair_prune") { c->prune = v != 0.0; if (c->prune && c->finalized) (void)nb_prune_reset(c); return MSEVB_OK; }
-  if (s == "prune_delta") { if (!(v > 0.0)) return MSEVB_ERR_ARG; c->prune_delta = v; if (c->prune && c->finalized) (void)nb_prune_reset(c); return MSEVB_OK; }
+  if (s == "prune_delta") { if (!(v > 0.0)) return MSEVB_ERR_ARG; c->prune_delta = v; c->prune_delta_user = true;      /* (kept across msevb_set_system / box changes) */ if (c->prune && c->finalized) (void)nb_prune_reset(c); return MSEVB_OK; }
   if (s == "pin_host_arrays") { c->pin_host_arrays = v != 0.0; return MSEVB_OK; }
   if (s == "nbr_cap") { if (v < 64.0) return MSEVB_ERR_ARG; c->nbr_cap = ((unsigned)v + 63u) & ~63u; c->list_valid = false; return MSEVB_OK; }      // row stride (tests: force the overflow path)
   if (s == "nbr_tiles") { c->nbr_tiles = v != 0.0; c->list_valid = false; return MSEVB_OK; }

@@ -314,7 +314,7 @@ struct msevb_ctx {
   bool list_valid = false;
   // rolling pruned pair list (pair.hip): rows of the pairs within rc + prune_delta, rewritten by the pair loop itself whenever the two
   // largest displacements since the last pruning add up to prune_delta; d_prune_mode[0]: 1 = this step prunes, 2 = this step uses the rows
-  bool prune = true; double prune_delta = 0.6 /* msevb_create sets min(0.75, (r_v - r_c) / 2) */; int prune_lo = -1, prune_hi = -1;
+  bool prune = true; double prune_delta = 0.6 /* msevb_set_system sets min(0.75, (r_v - r_c) / 2) unless the option prune_delta was given */; bool prune_delta_user = false; int prune_lo = -1, prune_hi = -1;
   DBuf<int> d_nbr2, d_prune_mode; DBuf<unsigned> d_nbr2_count; DBuf<double4> d_posq_prune;
   // flat per-cell pair list of k_pair_flat (pair_flat.hip): the cell's pairs within rc + prune_delta, rows padded to 16 entries, one segment per wave of the
   // cell's workgroup; cell c's list starts at cell_start[c] * (nbr_cap + 96) + 3584 c, d_cell_trips[32 c + 16 h + w] = {offset, length in 64-entry trips} of the segment of wave w of workgroup h
@@ -497,6 +497,8 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
 
 constexpr int MAX_BLOCKS = 65536;
 enum Slot { S_ELEC_PAIR = 0, S_VDW_PAIR, S_ELEC_INTRA, S_VDW_INTRA, S_BOND, S_ANGLE, S_DIH, S_RECIP, S_KE, S_PX, S_PY, S_PZ, S_VX, S_VY, S_VZ /* sum of velocities: KE after the momentum removal */, S_MAXD1, S_MAXD2, S_PRD1, S_PRD2 /* two largest displacements since the pair list was last pruned */, S_EVB0,
+            S_TIMEOUT = 29,    // sticky: a device-side wait (chain marks, blend mark) ran into its wall-clock limit -> MSEVB_ERR_TIMEOUT; a slot of its own, so that a coordinate code
+                               // written to S_FAULT afterwards cannot hide it
             S_BRICK = 30,      // sticky: a brick of the owner-computes spread met more atoms than it can take (nb_check_overflow switches to the tile kernel and has the force call repeated)
             S_FAULT = 31,      // sticky: a kernel met a coordinate outside what its index arithmetic covers (non-finite, or more than one box away)
             N_SLOTS = 32 };

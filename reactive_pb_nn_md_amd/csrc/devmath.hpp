@@ -66,9 +66,19 @@ __device__ __forceinline__ void ewald_fetch(double r2, double inv_dx, int emax, 
   const int row = min(max(w.idx, 1), emax);
   w.t0 = etab[row - 1]; w.t1 = etab[row];
 }
-template <bool SAPT = true>
+// Row of the Tang-Toennies table for a pair whose B r sits on a row boundary to within rounding.  The table is a STEP function of B r
+// (row = ceil(B r / 50 * 1000), no interpolation: src/pair_int_real_space.f90:674), so the last bit of r picks the row; the kernels' r (v_rsq_f64 seed + Newton
+// steps, tile-relative coordinates) differs from the reference's sqrt(dot_product(dr, dr)) in that bit.  Such pairs take the reference's own expression on the
+// raw coordinates: tt_arg_exact(r2, B) with r2 from min_image_r2 (pair.hip) / pf_exact_r2 (pair_flat.hip).  NoTieFix: callers whose r IS the reference's.
+__device__ __forceinline__ double tt_arg_exact(double r2_exact, double B) {
+#pragma clang fp contract(off)
+  const double r = sqrt(r2_exact);
+  return B * r / TT_MAX * (double)TT_GRID;
+}
+struct NoTieFix { static constexpr bool on = false; __device__ __forceinline__ double operator()(double) const { return 0.0; } };
+template <bool SAPT = true, class TieFix = NoTieFix>
 __device__ __forceinline__ void pair_interaction_rows(double r2, double qq, const PairParam& pp, const EwaldRows& w, const double* __restrict__ tt,
-                                                      const double* __restrict__ dtt, double& fs, double& e_el, double& e_vdw) {
+                                                      const double* __restrict__ dtt, double& fs, double& e_el, double& e_vdw, const TieFix& tie_fix = TieFix()) {
 #pragma clang fp contract(fast)
   const double r = w.r;
   const double inv_r = w.inv_r;
@@ -85,7 +95,9 @@ __device__ __forceinline__ void pair_interaction_rows(double r2, double qq, cons
     fs += inv_r2 * (12.0 * pp.p[0] * r12i - 6.0 * pp.p[1] * r6i);
   } else if (SAPT && pp.type == 1 && pp.nonzero) {
     const double A = pp.p[0], B = pp.p[1];
-    const int ti = min(max((int)ceil(B * r / TT_MAX * (double)TT_GRID), 1), TT_GRID);
+    double xi = B * r / TT_MAX * (double)TT_GRID;
+    if (TieFix::on) { if (__builtin_expect(fabs(xi - rint(xi)) <= 1e-9 * fmax(xi, 1.0), 0)) xi = tie_fix(B); }      // on a row boundary to within rounding: the reference's arithmetic decides
+    const int ti = min(max((int)ceil(xi), 1), TT_GRID);
     const double* t = tt + 4 * (ti - 1);
     const double* dt = dtt + 4 * (ti - 1);
     const double r6i = inv_r2 * inv_r2 * inv_r2, r8i = r6i * inv_r2, r10i = r8i * inv_r2, r12i = r10i * inv_r2;

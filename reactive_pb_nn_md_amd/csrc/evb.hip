@@ -1364,7 +1364,7 @@ __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, 
   // n_chains > 0: the kernels on OTHER streams whose energies this kernel publishes end with k_evb_mark(chain_done + k, chain_seq); wait for
   // those marks here instead of through two cross-stream event hops in front of this kernel (~10 us each on the way to the host's turn).
   // The marks are enqueued before this kernel in host order, so streams that share a hardware queue cannot deadlock; after 2 s of wall
-  // clock the sticky fault flag is raised and the kernel goes on (the force call then ends in MSEVB_ERR_NUMERIC).
+  // clock the sticky time-out flag (energy slot S_TIMEOUT) is raised and the kernel goes on (the force call then ends in MSEVB_ERR_TIMEOUT).
   __shared__ SolveStage s_sd;
   if (sa.on) evb_solve_stage(sa, &s_sd);      // (in flight while thread 0 waits for the chains)
   if (n_chains > 0) {
@@ -1729,7 +1729,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   stamp(c, 8, c->stream);
   if (w->d_pack.alloc(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended potential)");
   const bool patch_waits = w->blend_mark && w->last_linear && ngrid > 0 && fft_lds_usable(c);      // k_evb_blend_patch is the phase's first kernel and waits itself
-  if (w->blend_mark && !patch_waits) hipLaunchKernelGGL(k_evb_wait_mark, dim3(1), dim3(64), 0, c->stream, w->blend_mark, w->blend_mark_seq, c->d_energies.p + S_FAULT);
+  if (w->blend_mark && !patch_waits) hipLaunchKernelGGL(k_evb_wait_mark, dim3(1), dim3(64), 0, c->stream, w->blend_mark, w->blend_mark_seq, c->d_energies.p + S_TIMEOUT);
   if (w->last_linear) {
     // blended CHARGE grid Q_1 (rank 0) + sum_d c_d^2 DQ_d -> one transform pair -> blended potential theta_1 + sum_d c_d^2 G * DQ_d
     // (sum_d c_d^2 = 1 over all ranks, so the principal potential enters once, on rank 0)
@@ -1740,7 +1740,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
       if (fft_lds_can_patch(c) && c->evb_fft_patch) {      // 64^3: the forward transform applies the stencils to the planes of Q_1 itself - no copy of Q_1, no patch kernel
         FftPatch P; P.nst = w->last_nst; P.st = w->d_stencils.p; P.dc = dcoef;
         for (int g = 0; g < MAX_DIABATS; ++g) P.c[g] = (!dcoef && g < ngrid) ? gc.c[g] : 0.0;
-        P.wait_mark = patch_waits ? w->blend_mark : (const long long*)nullptr; P.wait_seq = w->blend_mark_seq; P.fault = c->d_energies.p + S_FAULT;
+        P.wait_mark = patch_waits ? w->blend_mark : (const long long*)nullptr; P.wait_seq = w->blend_mark_seq; P.fault = c->d_energies.p + S_TIMEOUT;
         CHK(fft_lds_solve(c, c->rank == 0 ? c->d_Q.p : (const double*)nullptr, w->d_grids.p, w->d_pack.p, nullptr, nullptr, c->stream, &P));
         w->pack_prefilled = false;
       } else if (fft_lds_usable(c)) {      // real grid in, real potential out, in place in d_pack (d_grids is the transform's complex work space)
@@ -1749,7 +1749,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
         else HIPCHK(hipMemsetAsync(w->d_pack.p, 0, K3 * sizeof(double), c->stream));
         w->pack_prefilled = false;
         hipLaunchKernelGGL(k_evb_blend_patch, dim3((w->last_nst + 3) / 4), dim3(256), 0, c->stream, w->last_nst, w->d_stencils.p, gc, dcoef, K, w->d_pack.p, 1,
-                           patch_waits ? w->blend_mark : (const long long*)nullptr, w->blend_mark_seq, c->d_energies.p + S_FAULT);
+                           patch_waits ? w->blend_mark : (const long long*)nullptr, w->blend_mark_seq, c->d_energies.p + S_TIMEOUT);
         HIPCHK(hipGetLastError());
         CHK(fft_lds_solve(c, w->d_pack.p, w->d_grids.p, w->d_pack.p, nullptr, nullptr, c->stream));
       } else {
@@ -2298,12 +2298,12 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       sa.sd = (const SolveDesc*)(w->d_desc.p + off_s); sa.unit_idx = (const int*)(w->d_desc.p + off_si); sa.unit_sign = (const double*)(w->d_desc.p + off_ss);
       sa.E = w->d_E.p; sa.e_recip1 = linear ? w->d_Elq.p + 2 * MAX_DIABATS /* zero: the grid energies are differences already */ : c->d_energies.p + S_RECIP;
       sa.dcoef = w->d_coef.p; sa.out_host = w->h_solve; sa.mark_seq = seqA; sa.done_mark = pub_spin ? w->d_chain_done.p + 3 : (long long*)nullptr;
-      sa.done_flag = (volatile long long*)(w->h_flag + 6); sa.done_seq = ++w->seq_S; sa.fault = c->d_energies.p + S_FAULT;
+      sa.done_flag = (volatile long long*)(w->h_flag + 6); sa.done_seq = ++w->seq_S; sa.fault = c->d_energies.p + S_TIMEOUT;
     }
     hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), lds, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, seqA,
                        lin_e ? ngrid : 0, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid,
                        (const double*)(c->d_partials.p + (size_t)S_RECIP * MAX_BLOCKS), n_recip_part, c->d_energies.p + S_RECIP,
-                       pub_spin ? (const long long*)w->d_chain_done.p : (const long long*)nullptr, seqA, pub_spin ? (ncp ? 2 : 1) : 0, c->d_energies.p + S_FAULT, sa);
+                       pub_spin ? (const long long*)w->d_chain_done.p : (const long long*)nullptr, seqA, pub_spin ? (ncp ? 2 : 1) : 0, c->d_energies.p + S_TIMEOUT, sa);
     HIPCHK(hipGetLastError());
     stamp(c, 10, sg);
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, sg));

@@ -50,6 +50,19 @@ __device__ __forceinline__ double min_image_r2(const double4& pi, const double4&
   return (dx * dx + dy * dy) + dz * dz;
 }
 
+// Tang-Toennies rows of pairs on a row boundary (devmath.hpp: tt_arg_exact): the reference's r from its own r^2.  k_pair's r^2 is min_image_r2 already;
+// the tile kernels (coordinates relative to the cell centre) go back to the raw positions of the two atoms, as they do for pairs on the cutoff.
+__device__ __forceinline__ int tile_to_sorted(int p, const int* s_lo, const int* s_off);
+struct TieFixR2 { static constexpr bool on = true; double r2; __device__ __forceinline__ double operator()(double B) const { return tt_arg_exact(r2, B); } };
+struct TieFixTile {
+  static constexpr bool on = true;
+  const double4* __restrict__ posq; int i_sorted, j_tile; const int* s_lo; const int* s_off; const BoxDev* box;
+  __device__ __forceinline__ double operator()(double B) const {
+    double ux, uy, uz;
+    return tt_arg_exact(min_image_r2(posq[i_sorted], posq[tile_to_sorted(j_tile, s_lo, s_off)], *box, ux, uy, uz), B);
+  }
+};
+
 // One atom's list row, 64 lanes x 2 entries per trip; the entries of the NEXT trip are loaded before the current trip is evaluated
 // and the Ewald table rows of both entries of a trip are fetched before either pair is finished.  `src` is the {x,y,z,q} array the
 // entries index: the cell-sorted array in HBM (k_pair) or the cell-neighbourhood tile in LDS (k_pair_tiles).
@@ -85,12 +98,12 @@ __device__ __forceinline__ void pair_row(PosPtr src, const double4 pi, int ti, u
     ewald_fetch(inb ? r2b : rc2, inv_dx, emax, etab, wb);
     if (ina) {
       double fs, ee, ev;
-      pair_interaction_rows<SAPT>(r2a, pi.w * pa.w, sp[ti * nt + (int)(e0 >> NBR_IDX_BITS)], wa, tt, dtt, fs, ee, ev);
+      pair_interaction_rows<SAPT>(r2a, pi.w * pa.w, sp[ti * nt + (int)(e0 >> NBR_IDX_BITS)], wa, tt, dtt, fs, ee, ev, TieFixR2{r2a});
       fx += fs * dxa; fy += fs * dya; fz += fs * dza; e_el += ee; e_vdw += ev;
     }
     if (inb) {
       double fs, ee, ev;
-      pair_interaction_rows<SAPT>(r2b, pi.w * pb.w, sp[ti * nt + (int)(e1 >> NBR_IDX_BITS)], wb, tt, dtt, fs, ee, ev);
+      pair_interaction_rows<SAPT>(r2b, pi.w * pb.w, sp[ti * nt + (int)(e1 >> NBR_IDX_BITS)], wb, tt, dtt, fs, ee, ev, TieFixR2{r2b});
       fx += fs * dxb; fy += fs * dyb; fz += fs * dzb; e_el += ee; e_vdw += ev;
     }
     e0 = n0; e1 = n1; k = kn;
@@ -219,14 +232,14 @@ __device__ __forceinline__ void pair_row_half(const double4* tile, double* tfx, 
     ewald_fetch(inb ? r2b : rc2, inv_dx, emax, etab, wb);
     if (ina) {
       double fs, ee, ev;
-      pair_interaction_rows<SAPT>(r2a, pi.w * pa.w, sp[ti * nt + (int)(e0 >> NBR_IDX_BITS)], wa, tt, dtt, fs, ee, ev);
+      pair_interaction_rows<SAPT>(r2a, pi.w * pa.w, sp[ti * nt + (int)(e0 >> NBR_IDX_BITS)], wa, tt, dtt, fs, ee, ev, TieFixTile{posq, i_sorted, (int)ja, s_lo, s_off, &box});
       const double gx = fs * dxa, gy = fs * dya, gz = fs * dza;
       fx += gx; fy += gy; fz += gz; e_el += ee; e_vdw += ev;
       atomicAdd(&tfx[ja], -gx); atomicAdd(&tfy[ja], -gy); atomicAdd(&tfz[ja], -gz);
     }
     if (inb) {
       double fs, ee, ev;
-      pair_interaction_rows<SAPT>(r2b, pi.w * pb.w, sp[ti * nt + (int)(e1 >> NBR_IDX_BITS)], wb, tt, dtt, fs, ee, ev);
+      pair_interaction_rows<SAPT>(r2b, pi.w * pb.w, sp[ti * nt + (int)(e1 >> NBR_IDX_BITS)], wb, tt, dtt, fs, ee, ev, TieFixTile{posq, i_sorted, (int)jb, s_lo, s_off, &box});
       const double gx = fs * dxb, gy = fs * dyb, gz = fs * dzb;
       fx += gx; fy += gy; fz += gz; e_el += ee; e_vdw += ev;
       atomicAdd(&tfx[jb], -gx); atomicAdd(&tfy[jb], -gy); atomicAdd(&tfz[jb], -gz);
@@ -272,7 +285,7 @@ __device__ __forceinline__ void trip_stage_b(const TripState& st, int a, int cs,
   const unsigned j = st.e & NBR_IDX_MASK;
   const PairParam& pp = sp[ti * nt + (st.in ? (int)(st.e >> NBR_IDX_BITS) : 0)];
   double fs, ee, ev;
-  if (SAPT) pair_interaction_rows<true>(fmin(st.r2, rc2), st.qq, pp, st.w, tt, dtt, fs, ee, ev);
+  if (SAPT) pair_interaction_rows<true>(fmin(st.r2, rc2), st.qq, pp, st.w, tt, dtt, fs, ee, ev, TieFixTile{posq, cs + a, (int)j, s_lo, s_off, &box});
   else {      // Ewald + LJ without a branch (pair_interaction_rows' arithmetic; a pair type without LJ gets the factor 0)
     const double inv_r = st.w.inv_r, inv_r2 = inv_r * inv_r;
     const double c2 = (st.w.x1 + 1.0) - (double)st.w.idx, c1 = 1.0 - c2;

@@ -3,8 +3,10 @@ linked into it) feeds the arrays of the committed fixtures through the iso_c_bin
 numbers the real reference computed for them: a plain force call, an MS-EVB force call, the same call with the host arrays in another atom
 order (msevb_set_host_order: the host side of a proton hop), and a block of md_integrate_atomic.
 
-The tests further down run executables that contain REFERENCE objects (oracle/_ref/, built by `make link_check` in the dev container).  oracle/_ref/
-does not travel to the GPU box (.gpurunignore), so they skip there by construction; they run where a GPU and the reference are both present."""
+The tests further down run executables that contain REFERENCE objects (oracle/_ref/, built by `make link_check` in the dev container).  They
+skip wherever /root/reference/src is absent - whether or not oracle/_ref/ happens to be in the tree that was pushed to the box (the driver's push
+does not read .gpurunignore) - so nothing derived from the reference is executed on a GPU box; they run where a GPU and the reference are both
+present."""
 import os
 import subprocess
 
@@ -15,6 +17,18 @@ from conftest import ROOT, golden      # conftest puts oracle/ on sys.path (test
 from reactive_pb_nn_md_amd import system
 
 pytestmark = pytest.mark.gpu
+
+REFERENCE_SRC = "/root/reference/src"
+
+
+def ref_exe(name):
+    """path of an executable under oracle/_ref/ that contains reference objects; skips the test unless the reference tree itself is present"""
+    if not os.path.isdir(REFERENCE_SRC):
+        pytest.skip("executables with reference objects only run where %s exists (dev container), never on a GPU box" % REFERENCE_SRC)
+    exe = os.path.join(ROOT, "oracle", "_ref", name)
+    if not os.path.exists(exe):
+        pytest.skip(name + " not built (oracle/build_ref.sh / make link_check)")
+    return exe
 
 SMOKE = os.path.join(ROOT, "reactive_pb_nn_md_amd", "fortran", "fortran_smoke")
 
@@ -152,9 +166,7 @@ def test_unchanged_reference_main_program_on_the_gpu_library(tmp_path, name, evb
     path.  It is run on the input files of a golden fixture, with the reference's own command line, for a few MD steps; its step-0 log
     block (velocity independent) must show the energies the real reference computed for that fixture (print_step writes 6 digits), and the
     steps after it must stay on the energy shell as well as the reference's own integrator does on this box."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "main_ms_evb_hip_" + ("evb" if evb else "std"))
-    if not os.path.exists(exe):
-        pytest.skip("main_ms_evb_hip_* not built (needs the reference sources: dev container only)")
+    exe = ref_exe("main_ms_evb_hip_" + ("evb" if evb else "std"))
     import ref_inputs      # oracle/: writes the four input files in the formats the reference's parsers accept
     from reactive_pb_nn_md_amd import forcefield, synth
     g = golden(name)
@@ -194,9 +206,7 @@ def test_fortran_stage_procedures_against_the_reference_on_the_cpu(tmp_path):
     CPU against the procedures of the same names and argument lists in module msevb_hip_stages (GPU): real_space_energy_force after
     construct_verlet_list, pme_reciprocal_space_energy_force (forces, E_recip, Q_grid, theta_conv_Q), grid_Q / derivative_grid_Q,
     intra_molecular_energy_force, and one step of md_integrate_atomic."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "stages_check")
-    if not os.path.exists(exe):
-        pytest.skip("stages_check not built (needs the reference sources: dev container only)")
+    exe = ref_exe("stages_check")
     import ref_inputs
     from reactive_pb_nn_md_amd import forcefield, synth
     g = golden("std_n6_s3")
@@ -224,9 +234,7 @@ def test_unchanged_reference_main_program_across_a_proton_hop(tmp_path):
     the drop-in module hands the new atom order to the library (msevb_set_host_order: no context tear-down, no re-upload of tables) and the run
     goes on.  Checked: the hop is logged at step 0 with the molecules the real reference hopped between, the step-0 energy is the reference's
     adiabatic energy, and the steps AFTER the hop stay on the energy shell (a wrong permutation of positions or forces does not)."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "main_ms_evb_hip_evb")
-    if not os.path.exists(exe):
-        pytest.skip("main_ms_evb_hip_evb not built (needs the reference sources: dev container only)")
+    exe = ref_exe("main_ms_evb_hip_evb")
     import dataclasses
     import ref_inputs
     from reactive_pb_nn_md_amd import forcefield, synth
@@ -264,9 +272,7 @@ def test_fortran_evb_force_call_against_the_reference_routine(tmp_path):
     (linked beside the drop-in as ms_evb_calculate_total_force_energy_cpu: its diabat enumeration, topology hand-overs, per-diabat real-space and
     reciprocal-space updates, couplings and Jacobi all run on the CPU) against the drop-in's nine-argument procedure of the same name, on fixture
     evb_n6_d4_s2's input files: forces to 1e-9 kJ/mol/A, the adiabatic energy and every Hamiltonian entry to 1e-10 relative."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "stages_check_evb")
-    if not os.path.exists(exe):
-        pytest.skip("stages_check_evb not built (needs the reference sources: dev container only)")
+    exe = ref_exe("stages_check_evb")
     import ref_inputs
     from reactive_pb_nn_md_amd import forcefield, synth
     g = golden("evb_n6_d4_s2")

@@ -427,6 +427,48 @@ def test_half_list_lds_pair_kernel_against_oracle(oracle_lib, sapt):
     assert np.abs(Fk[1] - Fk[0]).max() < F_TOL
 
 
+def test_tang_toennies_rows_on_table_boundaries(oracle_lib):
+    """The Tang-Toennies damping table is a STEP function of B r (row = ceil(B r / 50 * 1000), no interpolation: src/pair_int_real_space.f90:674), so a
+    pair whose B r lies on a row boundary takes the row the last bit of r picks.  Coordinates quantised to 0.01 A (what a .gro holds) put dozens of
+    pairs exactly there (H...H at multiples of 0.1 A with B = 3.5).  All three pair kernels - k_pair (full list), k_pair_half (tile rows) and
+    k_pair_flat - must take the row the reference's arithmetic on the raw coordinates gives (oracle = reference, bit-identical on the fixtures):
+    a wrong row is an error of 1e-4 kJ/mol/A, five orders above the tolerance (VERDICT r04 'weak' 2)."""
+    s = synth.make_system(17, n_diabat=2, seed=11)
+    s.xyz = np.round(s.xyz, 2)
+    p = forcefield.build_params(forcefield.with_test_sapt(forcefield.ch3so3h_water_forcefield()), moltype_order=["h2o", "so3h"])
+    spec = system.from_synth(s, p, rc=9.0, rv=10.5, pme_grid=32)
+    o = oracle_lib.Oracle(spec, threads=8)
+    o.verlet_build()
+    vpo, nlo = o.verlet_get()
+    # how many pairs inside the cutoff sit on a row boundary (the test must not pass for lack of them)
+    i_of = np.repeat(np.arange(spec.n_atom), np.diff(vpo))
+    d = spec.xyz[i_of] - spec.xyz[nlo]
+    L = np.diag(spec.box) if np.ndim(spec.box) == 2 else np.asarray(spec.box)
+    d -= L * np.floor(d / L + 0.5)
+    r = np.sqrt((d * d).sum(1))
+    ti, tj = spec.atype[i_of], spec.atype[nlo]
+    live = (p.vdw_type[ti, tj] == 1) & (r < spec.rc)
+    xi = p.vdw_param[ti, tj, 1] * r / 50.0 * 1000.0
+    n_tie = int((live & (np.abs(xi - np.rint(xi)) <= 1e-9 * np.maximum(xi, 1.0))).sum())
+    assert n_tie >= 20, n_tie
+    Eo, Fo = o.pair()
+    Ei, Fi = o.intra_nonbonded()
+    seen = set()
+    for opts in ({"pair_tiles": 0}, {"pair_flat": 0}, {"pair_flat": 0, "pair_prune": 0}, {}):
+        h = api.MsEvbHip(spec)
+        for k, v in opts.items():
+            h.set_option(k, v)
+        h.construct_verlet_list()
+        for rep in range(2):      # (the second call of the pruning kernels runs on the list the first one wrote)
+            h.zero_forces()
+            e = h.real_space_energy_force()
+            assert np.abs(h.get_forces() - (Fo + Fi)).max() < F_TOL, (opts, rep, np.abs(h.get_forces() - (Fo + Fi)).max())
+            assert rel(e[0], Eo[0]) < E_RTOL and abs(e[1] - Eo[1]) < E_RTOL * max(abs(Eo[1]), 1.0), (opts, rep)
+        seen.add(int(h.info("pair_kernel")))
+        h.close()
+    assert seen == {0, 1, 2}      # every kernel was in the comparison
+
+
 @pytest.mark.parametrize("name,evb", [("md_std_n6_s4", False), ("md_evb_n6_d2_s5", True), ("md_std_n6_frz_s14", False), ("md_evb_n12_d4_s29", True)])
 def test_md_trajectory_against_reference(name, evb):
     g = golden(name)

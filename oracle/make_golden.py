@@ -180,6 +180,10 @@ def main():
     # 16 diabats with the reference's compile-time evb_max_chain = 3 (src/glob_v.f90:65): the acid proton and one third-shell hydrogen
     # have TWO acceptors each (synth.py: bifurcate) - 1 + 2 + 4 + 9 states
     case("evb_n12_d16_bif_s31", 12, 16, 31, evb=True, keep_store=False, pme_grid=32, bifurcate=(0, 5), **big)
+    # live Buckingham / Tang-Toennies terms on boxes with >= 4 neighbour cells per axis: the SAPT branch of k_pair_flat (the production pair kernel) against the
+    # reference's pairwise_real_space_sapt (src/pair_int_real_space.f90:651-690) itself (round 5; the n6 SAPT fixtures run k_pair)
+    case("std_n12_sapt_s32", 12, 1, 32, evb=False, sapt=True, pme_grid=32, **big)
+    case("evb_n12_d4_sapt_s33", 12, 4, 33, evb=True, keep_store=False, sapt=True, pme_grid=32, **big)
     # principal-diabat switch (src/ms_evb.f90:218-227).  Acid proton started next to its acceptor and the acid's reference energy
     # raised by 850 kJ/mol (the unrelaxed lattice otherwise keeps the acid diabat ~800 kJ/mol below): the reference's FIRST EVB force
     # call (during its initialisation) hands the proton to the water, so everything this fixture holds - 'xyz', topology, Hamiltonian,

@@ -5,6 +5,9 @@
 
 #include "ctx.hpp"
 
+thread_local StepRec* t_step_rec = nullptr;      // capture / replay of a force call (ctx.hpp)
+long g_alloc_epoch = 0;
+
 
 struct SlotCounts { int n[N_SLOTS]; };
 __global__ __launch_bounds__(1024) void k_reduce_slots(SlotCounts cnt, const double* __restrict__ part, double* __restrict__ out) {
@@ -816,6 +819,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   const std::string s(name);
   c->topo_epoch++;
   if (s == "evb_speculate") { c->evb_speculate = v != 0.0; return MSEVB_OK; }
+  if (s == "step_graph") { c->evb_step_graph = v != 0.0; return MSEVB_OK; }      // the enqueue part of a speculative MS-EVB call as one captured hipGraph (evb.hip)
   if (s == "phase_timing") { c->timing = v != 0.0; c->timing_now = false; return MSEVB_OK; }
   if (s == "phase_timing_stride") { c->timing_stride = v < 1.0 ? 1 : (int)v; return MSEVB_OK; }
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }
@@ -886,6 +890,13 @@ int msevb_get_info(msevb_ctx* c, const char* name, double* value) {
   if (s == "cells_per_axis_min") { *value = (double)std::min(c->ncell[0], std::min(c->ncell[1], c->ncell[2])); return MSEVB_OK; }
   if (s == "fft_own") { *value = fft_lds_usable(c) ? 1.0 : 0.0; return MSEVB_OK; }
   if (s == "n_diabat") { *value = (double)c->D; return MSEVB_OK; }
+  if (s == "spec_steps") { *value = (double)c->evb_spec_steps; return MSEVB_OK; }      // MS-EVB calls that started from the recorded diabat tree
+  if (s == "spec_misses") { *value = (double)c->evb_spec_misses; return MSEVB_OK; }    // ... of which the device found the tree changed (call repeated with a fresh enumeration)
+  if (s == "host_dfs_calls") { *value = (double)c->evb_host_dfs_calls; return MSEVB_OK; }      // enumerations (DFS + descriptor build) done on the host
+  if (s == "evb_calls") { *value = (double)c->evb_calls; return MSEVB_OK; }
+  if (s == "graph_launches") { *value = (double)c->evb_graph_launches; return MSEVB_OK; }      // MS-EVB calls that went out as ONE hipGraphLaunch
+  if (s == "graph_captures") { *value = (double)c->evb_graph_captures; return MSEVB_OK; }      // ... how often the call was captured (once per diabat tree and refresh mode)
+  if (s == "graph_mismatches") { *value = (double)c->evb_graph_mismatches; return MSEVB_OK; }  // replays whose launches would have differed from the captured ones (call repeated the ordinary way): 0 unless the library has a bug
   c->err = "unknown info " + s;
   return MSEVB_ERR_ARG;
 }

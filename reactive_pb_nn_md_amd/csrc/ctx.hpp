@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -37,6 +38,61 @@ constexpr int WAVE = 64;
   } while (0)
 #define FAIL(code, msg) do { c->err = (msg); return (code); } while (0)
 #define CHK(call) do { int r_ = (call); if (r_ != MSEVB_OK) return r_; } while (0)
+
+// ---- capture / replay of a whole MS-EVB force call as ONE hipGraph ("step graph", evb.hip) ------------------------------------
+// Between two changes of the diabat tree a force call enqueues the same ~35 kernels, event records / waits and fills with the same arguments (what changes from
+// call to call - sequence numbers, the pair list's epoch - is read from a device-resident step block).  The call's host code is therefore run in one of three modes:
+//   0 direct   every launch / event operation goes to its stream (rebuild steps, calls that re-enumerate the tree, timed calls, step_graph = 0);
+//   1 capture  the main stream is in stream capture: the same calls build the graph; every launch is also hashed (function, geometry, stream, argument bytes);
+//   2 replay   the same host code runs again for its bookkeeping, launches and event operations are NOT issued but hashed; if the hash equals the capture's,
+//              the call is ONE hipGraphLaunch - otherwise the call is repeated in mode 0 (nothing had been issued) and the graph is dropped.
+// All device work of the library goes through the wrappers below (the HIP names are redirected to them at the end of this block).
+enum StepBlockSlot { SB_R = 0, SB_A, SB_S, SB_B, SB_EPOCH, SB_N = 8 };      // device-resident step block: what changes between two launches of a captured force call
+struct StepRec { int mode = 0; unsigned long long hash = 0xcbf29ce484222325ull; int n = 0; };
+extern thread_local StepRec* t_step_rec;      // non-null only inside a captured / replayed force call of the calling thread (api.hip)
+extern long g_alloc_epoch;                    // bumped by every (re)allocation or release of a device buffer: addresses baked into a captured graph may be stale
+inline void step_hash_bytes(StepRec& r, const void* p, size_t n) {
+  const unsigned char* b = (const unsigned char*)p;
+  unsigned long long h = r.hash;
+  size_t k = 0;
+  for (; k + 8 <= n; k += 8) { unsigned long long w; memcpy(&w, b + k, 8); h = (h ^ w) * 0x100000001b3ull; h ^= h >> 29; }
+  for (; k < n; ++k) h = (h ^ b[k]) * 0x100000001b3ull;
+  r.hash = h;
+}
+template <class T> inline void step_hash_one(StepRec& r, const T& v) { step_hash_bytes(r, &v, sizeof(T)); }
+inline void step_hash_one(StepRec& r, std::nullptr_t) { const void* z = nullptr; step_hash_bytes(r, &z, sizeof z); }
+#ifdef __HIPCC__
+template <class K, class... A>
+inline void step_launch(K kern, dim3 grid, dim3 block, size_t shm, hipStream_t st, A&&... a) {
+  StepRec* r = t_step_rec;
+  if (r) {
+    const void* fn = (const void*)kern;
+    step_hash_one(*r, fn); step_hash_one(*r, grid.x); step_hash_one(*r, grid.y); step_hash_one(*r, grid.z); step_hash_one(*r, block.x); step_hash_one(*r, shm); step_hash_one(*r, st);
+    (step_hash_one(*r, a), ...);
+    r->n++;
+    if (r->mode == 2) return;
+  }
+  kern<<<grid, block, shm, st>>>(std::forward<A>(a)...);
+}
+#endif
+inline bool step_skip(int tag, const void* a, const void* b, size_t n) {      // event / fill operations: hashed like launches, skipped on replay
+  StepRec* r = t_step_rec;
+  if (!r) return false;
+  step_hash_one(*r, tag); step_hash_one(*r, a); step_hash_one(*r, b); step_hash_one(*r, n); r->n++;
+  return r->mode == 2;
+}
+inline hipError_t step_event_record(hipEvent_t e, hipStream_t s) { return step_skip(1, e, s, 0) ? hipSuccess : (hipEventRecord)(e, s); }
+inline hipError_t step_stream_wait(hipStream_t s, hipEvent_t e, unsigned f) { return step_skip(2, e, s, f) ? hipSuccess : (hipStreamWaitEvent)(s, e, f); }
+inline hipError_t step_memset_async(void* p, int v, size_t n, hipStream_t s) { return step_skip(3 + 16 * (v & 0xff), p, s, n) ? hipSuccess : (hipMemsetAsync)(p, v, n, s); }
+inline hipError_t step_memset_d32_async(hipDeviceptr_t p, int v, size_t n, hipStream_t s) { return step_skip(4 + 16 * v, (const void*)p, s, n) ? hipSuccess : (hipMemsetD32Async)(p, v, n, s); }
+inline hipError_t step_memcpy_async(void* d, const void* src, size_t n, hipMemcpyKind k, hipStream_t s) { return step_skip(5 + 16 * (int)k, d, src, n) ? hipSuccess : (hipMemcpyAsync)(d, src, n, k, s); }
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kern, grid, block, shm, st, ...) step_launch(kern, dim3(grid), dim3(block), (size_t)(shm), (st), ##__VA_ARGS__)
+#define hipEventRecord(e, s) step_event_record((e), (s))
+#define hipStreamWaitEvent(s, e, f) step_stream_wait((s), (e), (f))
+#define hipMemsetAsync(p, v, n, s) step_memset_async((p), (v), (n), (s))
+#define hipMemsetD32Async(p, v, n, s) step_memset_d32_async((p), (v), (n), (s))
+#define hipMemcpyAsync(d, src, n, k, s) step_memcpy_async((d), (src), (n), (k), (s))
 
 // ---- device-side parameter blocks -------------------------------------------------------------------
 struct PairParam {  // one (type_i,type_j) entry of atype_vdw_type / atype_vdw_parameter, 64 B
@@ -194,7 +250,7 @@ struct DBuf {  // device buffer, exactly `count` elements: no kernel of this lib
     static const size_t tail = getenv("MSEVB_DBUF_TAIL") ? (size_t)atol(getenv("MSEVB_DBUF_TAIL")) : 0;
     if (guard_mode()) { p = (T*)guard_alloc(bytes, file, line); if (!p) return -1; }
     else if (hipMalloc((void**)&p, bytes + tail) != hipSuccess) { p = nullptr; return -1; }
-    n = count;
+    n = count; ++g_alloc_epoch;
     // MSEVB_POISON=1 (diagnostic): fresh device memory reads as NaN / -1 instead of whatever the allocator hands back (zeros in a young process,
     // another context's data later), so that a read of something nobody wrote shows in the first test that does it, not in the fortieth
     static const bool poison = getenv("MSEVB_POISON") != nullptr;
@@ -204,7 +260,7 @@ struct DBuf {  // device buffer, exactly `count` elements: no kernel of this lib
   // for buffers whose size follows the diabat count: grow with half as much again, so that a tree gaining a diabat or two during a run
   // does not free + allocate (a device synchronisation and milliseconds) every time
   int alloc_room(size_t count, const char* file = __builtin_FILE(), int line = __builtin_LINE()) { return (count <= n && p) ? 0 : alloc(count + count / 2, file, line); }
-  void release() { if (p && !(guard_mode() && guard_free(p))) (void)hipFree(p); p = nullptr; n = 0; }
+  void release() { if (p) ++g_alloc_epoch; if (p && !(guard_mode() && guard_free(p))) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
 struct EvbHop { int donor_mol, proton_local, heavy_local, acceptor_mol, acceptor_heavy_local; };
@@ -396,6 +452,11 @@ struct msevb_ctx {
   // principal-diabat switches since the log was last read: {EVB force call number (1-based, counted over the context's life), old hydronium, new hydronium}
   // (1-based molecules) - the reference writes every hop at its own step (src/ms_evb.f90:331-335)
   std::vector<int> hop_log; long evb_calls = 0;
+  // counters behind msevb_get_info: speculative MS-EVB calls, how many of them found the diabat tree changed (the call is repeated the long way), enumerations (DFS + descriptor build) done by the HOST
+  long evb_spec_steps = 0, evb_spec_misses = 0, evb_host_dfs_calls = 0;
+  // step graph (StepRec above): option step_graph; step_sb is non-null while a force call is being captured / replayed (kernels then read their per-call numbers from it);
+  // opt_epoch counts msevb_set_option / box / communicator changes (a captured graph bakes the options in)
+  bool evb_step_graph = true; const long long* step_sb = nullptr; long opt_epoch = 0, evb_graph_launches = 0, evb_graph_captures = 0, evb_graph_mismatches = 0;
   void* evb_work = nullptr;            // EvbWork of evb.hip (created by the first EVB force call, freed by evb_release)
   DBuf<double> d_comm_h, d_comm_e;     // staging of the Hamiltonian all-gather / the energy all-reduce (comm.hip)
   double* h_comm = nullptr; size_t h_comm_cap = 0; long long* h_comm_flag = nullptr; long long comm_seq = 0;      // pinned staging of the per-step all-gather (comm.hip)

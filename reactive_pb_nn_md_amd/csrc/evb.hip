@@ -1309,7 +1309,7 @@ __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ 
                              int* __restrict__ cand_counter, RegionRec* __restrict__ out_host, int cap_host,
                              int* __restrict__ ticket, int* __restrict__ host_count, volatile long long* flag, long long seq,
                              const SpecPlan* __restrict__ plan = nullptr, const EvbTablesDev* __restrict__ tabs = nullptr, const int* __restrict__ mol_type = nullptr, int* __restrict__ check = nullptr,
-                             int* __restrict__ verdict_host = nullptr) {      // verdict_host: this kernel runs BESIDE the descriptor chain (own stream): it delivers the verdict of the tree check and re-arms its own counter
+                             int* __restrict__ verdict_host = nullptr, const long long* __restrict__ sb = nullptr) {      // sb: step graph - the sequence number comes from the device-resident step block.  verdict_host: this kernel runs BESIDE the descriptor chain (own stream): it delivers the verdict of the tree check and re-arms its own counter
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   double com_m[3] = {0, 0, 0};
   if (m == 0 && !verdict_host) *cand_counter = 0;      // re-arm k_evb_candidates (which in turn re-arms `counter` for the next step)
@@ -1351,7 +1351,7 @@ __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ 
     *verdict_host = ok ? 1 : -1;
   }
   __threadfence_system();
-  *flag = seq;
+  *flag = sb ? sb[SB_R] : seq;
 }
 
 // copies two small device arrays into pinned host memory (zero-copy stores): the energy downloads, without copy commands
@@ -1360,7 +1360,8 @@ __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ 
 __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, const double* b, int nb, double* __restrict__ hb,
                               volatile long long* flag = nullptr, long long seq = 0, int ng = 0, double* E_lin = nullptr, double* E_quad = nullptr,
                               double conv = 0.0, double* E_grid = nullptr, const double* __restrict__ slot_part = nullptr, int n_part = 0, double* slot_out = nullptr,
-                              const long long* chain_done = nullptr, long long chain_seq = 0, int n_chains = 0, double* fault = nullptr, const SolveArgs sa = SolveArgs()) {      // (a and E_grid alias: no __restrict__ on them)
+                              const long long* chain_done = nullptr, long long chain_seq = 0, int n_chains = 0, double* fault = nullptr, const SolveArgs sa = SolveArgs(),
+                              const long long* __restrict__ sb = nullptr, int sb_flag = 0) {      // sb: step graph - `seq` is sb[sb_flag], the solve's done_seq sb[SB_S] (a and E_grid alias: no __restrict__ on them)
   // n_chains > 0: the kernels on OTHER streams whose energies this kernel publishes end with k_evb_mark(chain_done + k, chain_seq); wait for
   // those marks here instead of through two cross-stream event hops in front of this kernel (~10 us each on the way to the host's turn).
   // The marks are enqueued before this kernel in host order, so streams that share a hardware queue cannot deadlock; after 2 s of wall
@@ -1402,10 +1403,13 @@ __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, 
   for (int k = threadIdx.x; k < nb; k += blockDim.x) hb[k] = b[k];
   if (flag || (sa.on && sa.done_flag)) {
     __threadfence_system(); __syncthreads();
-    if (threadIdx.x == 0) { if (flag) *flag = seq; if (sa.on && sa.done_flag) *sa.done_flag = sa.done_seq; }
+    if (threadIdx.x == 0) { if (flag) *flag = sb ? sb[sb_flag] : seq; if (sa.on && sa.done_flag) *sa.done_flag = sb ? sb[SB_S] : sa.done_seq; }
   }
 }
 
+// step graph: the numbers of THIS call, set on the main stream right in front of the graph launch (by-value arguments of an ordinary launch)
+struct StepBlockVals { long long v[SB_N]; };
+__global__ void k_set_step_block(long long* sb, StepBlockVals v) { if (threadIdx.x < SB_N) sb[threadIdx.x] = v.v[threadIdx.x]; }
 // last kernel of a side chain: its stream has finished everything in front of it
 __global__ void k_evb_mark(long long* p, long long seq) { __hip_atomic_store(p, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -1483,6 +1487,10 @@ struct EvbWork {   // persistent device scratch of one context
   int pl_D = 0, pl_plog[MAX_DIABATS][MAX_CHAIN][5], pl_parent[MAX_DIABATS], pl_ngrid = 0, pl_ncp_big = 0;
   std::vector<std::vector<int>> pl_units_of; std::vector<int> pl_grid_of, pl_cp_of; std::vector<double> pl_eref_delta;
   long spec_steps = 0, spec_misses = 0;
+  // step graph (ctx.hpp: StepRec): the enqueue part of a speculative call captured once per diabat tree and replayed with ONE launch; two entries: calls whose refresh of the
+  // sorted arrays rode in the integrator's first kernel (MD loop) and calls that refresh themselves (force calls through the host-array entry points)
+  struct StepGraph { hipGraphExec_t exec = nullptr; unsigned long long hash = 0; int n = 0; long plan_serial = -1, topo_epoch = -1, alloc_epoch = -1; };
+  StepGraph sg[2]; hipEvent_t ev_gjoin[3] = {nullptr, nullptr, nullptr}; DBuf<long long> d_sb; long plan_serial = 0; bool graph_broken = false, graph_skip_once = false;
 };
 // host-side section timing (MSEVB_HOST_TIMING=1): where the CPU thread spends the step
 struct HostTimes { double t[12] = {0}; long n = 0; };
@@ -1665,13 +1673,14 @@ static double blend_terms(const msevb_ctx* c, int D, const double* ev, BlendTerm
 // The host waits for small results (neighbourhood record, energies) by spinning on a sequence number the producing kernel writes to
 // pinned memory behind its data: hipEventSynchronize sleeps on an interrupt and needs 50-100 us to wake up, a spin sees the store in
 // ~2 us.  The event stays the fallback (a kernel that failed never writes; the event reports the error).
-static int spin_wait(volatile long long* flag, long long seq, hipEvent_t ev) {
+static int spin_wait(volatile long long* flag, long long seq, hipEvent_t ev, hipStream_t graph_stream = nullptr) {      // graph_stream: the producer ran inside a launched graph - `ev` was only captured, the stream is what can be waited for
   const auto t0 = std::chrono::steady_clock::now();
   long spins = 0;
   while (*flag != seq) {
     __builtin_ia32_pause();
     if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
   }
+  if (*flag != seq && graph_stream) return (hipStreamSynchronize(graph_stream) == hipSuccess && *flag == seq) ? 0 : -1;
   if (*flag != seq && hipEventSynchronize(ev) != hipSuccess) return -1;
   return 0;
 }
@@ -1689,7 +1698,7 @@ extern "C" int msevb_comm_allgather_evb(msevb_ctx* c, int with_energies);   // c
 static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, const int* grid_of, int ngrid, int nra, const RecipAtom* d_ra, const double* dcoef) {
   const int K = c->K;
   const size_t K3 = (size_t)K * K * K, n3 = 3 * (size_t)c->N;
-  BlendTerms bt;
+  BlendTerms bt; memset(&bt, 0, sizeof bt);      // (by-value kernel arguments are zero-filled, padding and unused tails included: captured / replayed launches are compared by their bytes)
   double w11 = blend_terms(c, D, ev, bt);
   const bool w11_was_one = w11 != 0.0;
   if (w11 == 0.0) {      // replicated (not sharded) principal diabat on a rank other than 0: F11 counts on rank 0 only, the gather below adds to zero
@@ -1700,7 +1709,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
     w11 = 1.0;
   }
   // reciprocal space of the blend in ONE gather: blended potential of this rank's diabats (+ the principal one on rank 0) ...
-  GridCoefs gc; gc.n = ngrid; gc.c0 = 0.0;
+  GridCoefs gc; memset(&gc, 0, sizeof gc); gc.n = ngrid; gc.c0 = 0.0;
   if (ev) { gc.c0 = c->rank == 0 ? ev[0] * ev[0] : 0.0; for (int d = 1; d < D; ++d) if (grid_of[d] >= 0) gc.c[grid_of[d]] = ev[d] * ev[d]; }
   const bool one_wait = c->overlap && w->side_valid;      // every side chain of this force call behind ONE event
   // ASIDE (default): the blend terms are added from the grid stream (k_evb_blend_terms: atomics) while this stream transforms and gathers; the gather folds the
@@ -1738,7 +1747,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
     } else {
       if (w->d_grids.alloc_room(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended charge grid)");
       if (fft_lds_can_patch(c) && c->evb_fft_patch) {      // 64^3: the forward transform applies the stencils to the planes of Q_1 itself - no copy of Q_1, no patch kernel
-        FftPatch P; P.nst = w->last_nst; P.st = w->d_stencils.p; P.dc = dcoef;
+        FftPatch P; memset(&P, 0, sizeof P); P.nst = w->last_nst; P.st = w->d_stencils.p; P.dc = dcoef;
         for (int g = 0; g < MAX_DIABATS; ++g) P.c[g] = (!dcoef && g < ngrid) ? gc.c[g] : 0.0;
         P.wait_mark = patch_waits ? w->blend_mark : (const long long*)nullptr; P.wait_seq = w->blend_mark_seq; P.fault = c->d_energies.p + S_TIMEOUT;
         CHK(fft_lds_solve(c, c->rank == 0 ? c->d_Q.p : (const double*)nullptr, w->d_grids.p, w->d_pack.p, nullptr, nullptr, c->stream, &P));
@@ -1755,7 +1764,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
       } else {
         if (c->rank == 0) hipLaunchKernelGGL(k_evb_grid_init, dim3(2048), dim3(256), 0, c->stream, K3, 1, c->d_Q.p, w->d_grids.p);
         else HIPCHK(hipMemsetAsync(w->d_grids.p, 0, K3 * sizeof(double2), c->stream));
-        hipLaunchKernelGGL(k_evb_blend_patch, dim3((w->last_nst + 3) / 4), dim3(256), 0, c->stream, w->last_nst, w->d_stencils.p, gc, dcoef, K, (double*)w->d_grids.p, 2);
+        hipLaunchKernelGGL(k_evb_blend_patch, dim3((w->last_nst + 3) / 4), dim3(256), 0, c->stream, w->last_nst, w->d_stencils.p, gc, dcoef, K, (double*)w->d_grids.p, 2, (const long long*)nullptr, 0LL, (double*)nullptr);
         HIPCHK(hipGetLastError());
         int nbk = 0;
         hipStream_t keep = c->pme_st; c->pme_st = nullptr;      // on the main stream
@@ -1831,8 +1840,6 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   // a hop goes to a molecule whose centre of mass is within 5 A of the donor's (evb_first_solvation_cutoff): a chain of max_chain hops
   // stays inside 5 max_chain of the hydronium's
   const double Rreg = 5.0 * c->max_chain + 0.25;
-  HIPCHK(hipEventRecord(w->ev_in, c->stream));
-  HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_in, 0));
   // The neighbourhood record is the first thing the host's turn needs, and everything the side chains do starts behind that turn: it goes
   // out on the MAIN stream, directly behind the integrator's first kernel (on a side stream it started one cross-queue event hop,
   // ~15 us, later; the pair loop, which it now precedes, has that much slack before the blend needs it)
@@ -1846,16 +1853,52 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   }
   int* h_verdict = (int*)(w->h_flag + 4);
   *h_verdict = 0;
+  // STEP GRAPH (ctx.hpp: StepRec).  A speculative call that neither rebuilds its list nor samples the phase timers enqueues the same operations with the same arguments
+  // as the last such call on this tree: its enqueue part (down to the host's first wait) is captured once and replayed with one hipGraphLaunch.
+  // gmode 1 = this call captures, 2 = this call replays (the host code below runs for its bookkeeping, the wrappers of ctx.hpp issue nothing).
+  // Device-side waits on marks of other streams do not exist inside the graph (its branches are ordered by the captured events' edges).
+  if (c->stamps_on < 0) c->stamps_on = getenv("MSEVB_STAMPS") ? 1 : 0;
+  const int gslot = c->refresh_fused_nb > 0 ? 1 : 0;
+  EvbWork::StepGraph& G = w->sg[gslot];
+  int gmode = 0;
+  StepRec grec;
+  const long alloc_epoch0 = g_alloc_epoch;
+  if (c->evb_step_graph && !w->graph_broken && spec && !c->stamps_on && !c->nbr_check_pending && c->flag_verlet_list != 1 && c->list_valid && c->cells_valid &&
+      !(c->timing && (c->timing_tick % c->timing_stride) == 0) && !w->delta_dirty && !w->dv_dirty && w->d_check.p && c->stream && !c->evb_pair_first) {
+    if (w->graph_skip_once) w->graph_skip_once = false;      // (the call that repeats a mismatched replay)
+    else {
+      if (w->d_sb.alloc(SB_N)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (step block)");
+      const bool have = G.exec && G.plan_serial == w->plan_serial && G.topo_epoch == c->topo_epoch && G.alloc_epoch == g_alloc_epoch;
+      gmode = have ? 2 : 1;
+      if (gmode == 1) {
+        if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); w->graph_broken = true; gmode = 0; }
+      }
+    }
+  }
+  grec.mode = gmode;
+  struct StepScope {      // leaves capture / replay mode on every way out of this function
+    msevb_ctx* c; EvbWork* w; int* gmode;
+    ~StepScope() {
+      if (t_step_rec && t_step_rec->mode == 1) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(c->stream, &g); if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); w->graph_broken = true; }      // an error inside the capture
+      t_step_rec = nullptr; c->step_sb = nullptr;
+    }
+  } step_scope{c, w, &gmode};
+  if (gmode) { t_step_rec = &grec; c->step_sb = w->d_sb.p; }
+  const long long* const sb = gmode ? w->d_sb.p : (const long long*)nullptr;
+  const hipStream_t gsync = gmode ? c->stream : (hipStream_t)nullptr;
+  HIPCHK(hipEventRecord(w->ev_in, c->stream));      // (the first operation of a captured call: every side stream joins the capture through this event)
+  HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_in, 0));
   // speculative step with couplings: nothing on the device needs the neighbourhood record, only the host's verdict does - the kernel goes to the
   // coupling stream (idle until the descriptors are refreshed; its chain ends with a mark the energy fetch waits for, so the verdict is
   // in pinned memory before the host looks), and the descriptor chain starts with k_evb_refresh instead of behind 24-37 us of scanning
-  const bool region_aside = spec && !c->evb_region_main && c->evb_region_aside && c->evb_publish_spin && w->plan.n_cps > 0;
+  const bool region_aside = spec && !c->evb_region_main && c->evb_region_aside && c->evb_publish_spin && !gmode && w->plan.n_cps > 0;
   if (region_aside) { s_reg = c->aux3; HIPCHK(hipStreamWaitEvent(c->aux3, w->ev_in, 0)); }
   hipLaunchKernelGGL(k_evb_region, dim3((M + 1023) / 1024), dim3(1024), 0, s_reg, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
                      c->d_mass.p, box, w->d_counter.p, w->d_region.p, REGION_CAP, w->d_counter.p + 1, w->h_region, REGION_FAST,
-                     w->d_counter.p + 2, w->h_count, (volatile long long*)(w->h_flag + 1), ++w->seq_R,
+                     w->d_counter.p + 2, w->h_count, (volatile long long*)(w->h_flag + 1), (++w->seq_R, gmode ? 0LL : w->seq_R),
                      spec ? (const SpecPlan*)w->d_plan.p : (const SpecPlan*)nullptr, (const EvbTablesDev*)w->d_tabs.p, (const int*)c->d_mol_type.p, w->d_check.p,
-                     region_aside ? h_verdict : (int*)nullptr);
+                     region_aside ? h_verdict : (int*)nullptr, sb);
   HIPCHK(hipEventRecord(w->ev_region, s_reg));
   HT(1);
   // ---- 2. principal diabat (calculate_total_force_energy, src/ms_evb.f90:411) - enqueued, not waited for
@@ -1882,7 +1925,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   if (side_w) c->weights_side = true;      // (total_force_enqueue cleared it)
   HT(2);
   auto fetch_region = [&]() -> int {
-  if (spin_wait((volatile long long*)(w->h_flag + 1), w->seq_R, w->ev_region)) HIPCHK(hipErrorUnknown);
+  if (spin_wait((volatile long long*)(w->h_flag + 1), w->seq_R, w->ev_region, gsync)) HIPCHK(hipErrorUnknown);
   const int nreg = *w->h_count;
   if (nreg > REGION_CAP) FAIL(MSEVB_ERR_LIMIT, "EVB neighbourhood buffer too small");
   w->region.resize(nreg);
@@ -1910,7 +1953,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     c->D = w->pl_D;
     memcpy(c->plog, w->pl_plog, sizeof c->plog); memcpy(c->parent, w->pl_parent, sizeof c->parent);
   } else {
-    w->plan_valid = false; w->plan_fits = true;
+    w->plan_valid = false; w->plan_fits = true; c->evb_host_dfs_calls++;
     plan.n_donors = 0; plan.n_pairs_total = 0; plan.hyd = c->hydronium;
     struct Frame { int mol, diabat; };
     // recursion implemented with an explicit lambda to keep the reference's DFS order
@@ -2109,7 +2152,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   if (ncp) memcpy(w->h_desc + off_c, cps.data(), (size_t)ncp * sizeof(CouplingDesc));
   if (nra) memcpy(w->h_desc + off_r, ras.data(), (size_t)nra * sizeof(RecipAtom));
   }
-  BlendTerms bt_dev;      // slots of the blend terms (the coefficients will come from the device)
+  BlendTerms bt_dev; memset(&bt_dev, 0, sizeof bt_dev);      // slots of the blend terms (the coefficients will come from the device)
   if (dev_solve) {
     SolveDesc* sd = (SolveDesc*)(w->h_desc + off_s);
     int* ui = (int*)(w->h_desc + off_si); double* us = (double*)(w->h_desc + off_ss);
@@ -2138,7 +2181,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
                        (const double*)c->d_xyz.p, (const double*)c->d_mass.p, (const int*)c->d_mol_natom.p, (const int*)c->d_mol_atoms.p, box, std::max(c->rc, w->screen_r) + 0.5, w->d_sphere.p, w->d_check.p, region_aside ? (int*)nullptr : h_verdict, w->d_refresh_scratch.p,
                        region_aside ? w->d_counter.p + 1 : (int*)nullptr);
     HIPCHK(hipGetLastError());
-    w->spec_steps++;
+    w->spec_steps++; c->evb_spec_steps++;
   }
   const UnitDesc* d_units = (const UnitDesc*)(w->d_desc.p + off_u);
   const CouplingDesc* d_cps = (const CouplingDesc*)(w->d_desc.p + off_c);
@@ -2197,7 +2240,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     }
     const double Renv = std::sqrt(far2) + std::max(c->rc, w->screen_r) + 0.5;
     hipLaunchKernelGGL(k_evb_candidates, dim3((N + 255) / 256), dim3(256), 0, sr, N, rh->com[0], rh->com[1], rh->com[2], Renv * Renv, c->d_xyz.p, box,
-                       w->d_counter.p + 1, w->d_cand.p, w->d_counter.p);
+                       w->d_counter.p + 1, w->d_cand.p, w->d_counter.p, (const double*)nullptr);
   }
   hipLaunchKernelGGL(k_evb_env, dim3(envb, nu), dim3(256), 0, sr, w->d_counter.p + 1, w->d_cand.p, nu, d_units, w->d_tabs.p, c->d_xyz.p, c->d_chg.p, c->d_atype.p, c->d_mol_of.p,
                      c->d_pair_par.p, c->nt, c->d_ewald_tab.p, 1.0 / c->erfc_dx, c->d_tt.p, c->d_dtt.p, box, c->rc * c->rc, w->d_Fdelta.p, n3, part_units, part_stride);
@@ -2207,7 +2250,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   HIPCHK(hipGetLastError());
   phase_end(c, PH_EVB_REAL, sr);
   stamp(c, 4, sr);
-  const bool pub_spin = c->overlap && c->evb_publish_spin;      // fetch A's publish kernel waits for the chains' marks, not for their events
+  const bool pub_spin = c->overlap && c->evb_publish_spin && !gmode;      // fetch A's publish kernel waits for the chains' marks, not for their events
   if (pub_spin) {
     if (!w->d_chain_done.p) { if (w->d_chain_done.alloc(4)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (chain marks)"); HIPCHK(hipMemset(w->d_chain_done.p, 0, 32)); HIPCHK(hipDeviceSynchronize()); }      // (once per context.  hipMemset of device memory may RETURN EARLY and the library's streams do not wait for the null stream: without the synchronisation the fill could land BEHIND the first mark and wipe it - the energy-fetch kernel then sat out its 2 s limit: the intermittent MSEVB_ERR_NUMERIC of round 3, HISTORY.md E; the marks come from different streams)
     hipLaunchKernelGGL(k_evb_mark, dim3(1), dim3(1), 0, sr, w->d_chain_done.p, w->seq_A + 1);
@@ -2277,7 +2320,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     }
     const bool lin_e = linear && ngrid > 0;
     const long long seqA = ++w->seq_A;      // (the chains' marks carry this number)
-    SolveArgs sa = SolveArgs();
+    SolveArgs sa; memset(&sa, 0, sizeof sa);      // (padding bytes too: a captured / replayed launch is compared by its argument bytes)
     size_t lds = 0;
     if (dev_solve) {      // Hamiltonian, ground state and blend coefficients at the end of the kernel that completes the energies - beside the pair loop's tail, not behind it
       const size_t need = 2 + 2 * (size_t)D + (size_t)D * D;
@@ -2297,19 +2340,20 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       sa.on = 1; sa.method = c->evb_device_solve_method; sa.nref = n_unit_refs;
       sa.sd = (const SolveDesc*)(w->d_desc.p + off_s); sa.unit_idx = (const int*)(w->d_desc.p + off_si); sa.unit_sign = (const double*)(w->d_desc.p + off_ss);
       sa.E = w->d_E.p; sa.e_recip1 = linear ? w->d_Elq.p + 2 * MAX_DIABATS /* zero: the grid energies are differences already */ : c->d_energies.p + S_RECIP;
-      sa.dcoef = w->d_coef.p; sa.out_host = w->h_solve; sa.mark_seq = seqA; sa.done_mark = pub_spin ? w->d_chain_done.p + 3 : (long long*)nullptr;
-      sa.done_flag = (volatile long long*)(w->h_flag + 6); sa.done_seq = ++w->seq_S; sa.fault = c->d_energies.p + S_TIMEOUT;
+      sa.dcoef = w->d_coef.p; sa.out_host = w->h_solve; sa.mark_seq = gmode ? 0 : seqA; sa.done_mark = pub_spin ? w->d_chain_done.p + 3 : (long long*)nullptr;
+      sa.done_flag = (volatile long long*)(w->h_flag + 6); sa.done_seq = (++w->seq_S, gmode ? 0LL : w->seq_S); sa.fault = c->d_energies.p + S_TIMEOUT;
     }
-    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), lds, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, seqA,
+    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), lds, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, gmode ? 0LL : seqA,
                        lin_e ? ngrid : 0, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid,
                        (const double*)(c->d_partials.p + (size_t)S_RECIP * MAX_BLOCKS), n_recip_part, c->d_energies.p + S_RECIP,
-                       pub_spin ? (const long long*)w->d_chain_done.p : (const long long*)nullptr, seqA, pub_spin ? (ncp ? 2 : 1) : 0, c->d_energies.p + S_TIMEOUT, sa);
+                       pub_spin ? (const long long*)w->d_chain_done.p : (const long long*)nullptr, gmode ? 0LL : seqA, pub_spin ? (ncp ? 2 : 1) : 0, c->d_energies.p + S_TIMEOUT, sa, sb, (int)SB_A);
     HIPCHK(hipGetLastError());
     stamp(c, 10, sg);
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, sg));
     if (dev_solve) HIPCHK(hipEventRecord(w->ev_solve, sg));
     return MSEVB_OK;
   };
+  SolveArgs sa_none; memset(&sa_none, 0, sizeof sa_none);
   auto fetch_B = [&]() -> int {      // principal energy slots + Verlet displacement flag (behind the pair loop)
     if (!c->overlap) CHK(flush_reductions(c));
     if (c->overlap) {      // the reduction of the partial sums goes to the side stream too: the main stream runs from the pair loop straight into the blend phase
@@ -2320,7 +2364,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       if (defer_mol || single_join) HIPCHK(hipStreamWaitEvent(w->stream2, c->ev_join2, 0));      // per-molecule energies (aux3)
     }
     hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, ss, c->d_energies.p, (int)N_SLOTS, c->h_energies, (const double*)nullptr, 0, (double*)nullptr,
-                       (volatile long long*)(w->h_flag + 2), ++w->seq_B);
+                       (volatile long long*)(w->h_flag + 2), (++w->seq_B, gmode ? 0LL : w->seq_B), 0, (double*)nullptr, (double*)nullptr, 0.0, (double*)nullptr, (const double*)nullptr, 0, (double*)nullptr,
+                       (const long long*)nullptr, 0LL, 0, (double*)nullptr, sa_none, sb, (int)SB_B);
     HIPCHK(hipGetLastError());
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetch, ss));
     return MSEVB_OK;
@@ -2339,7 +2384,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     // run HERE, on the stream of the principal front end right behind it, with the dots against theta_1 - no event hop in between, and not
     // behind the environment chain of the descriptor stream, where they used to wait ~100 us for kernels they do not depend on
     {
-      GridRanges granges;
+      GridRanges granges; memset(&granges, 0, sizeof granges);
       { int g = 0; granges.start[0] = 0; for (int e = 0; e < nra; ++e) { while (g < ras[e].grid) granges.start[++g] = 2 * e; } while (g < ngrid) granges.start[++g] = nst; }
       int max_ns = 0;
       for (int g = 0; g < ngrid; ++g) max_ns = std::max(max_ns, granges.start[g + 1] - granges.start[g]);
@@ -2430,13 +2475,46 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     CHK(rc_b);
     phase_end(c, PH_EVB_BLEND);
   }
+  if (gmode) {
+    // every stream the capture spread to has to be back on the main stream before it can end; in the launched graph these are its last edges
+    if (!w->ev_gjoin[0]) for (int k = 0; k < 3; ++k) HIPCHK(hipEventCreateWithFlags(&w->ev_gjoin[k], hipEventDisableTiming));
+    { const hipStream_t side[3] = {c->aux, w->stream2, c->aux3}; for (int k = 0; k < 3; ++k) { HIPCHK(hipEventRecord(w->ev_gjoin[k], side[k])); HIPCHK(hipStreamWaitEvent(c->stream, w->ev_gjoin[k], 0)); } }
+    t_step_rec = nullptr; c->step_sb = nullptr;
+    if (gmode == 1) {
+      hipGraph_t g = nullptr; hipGraphExec_t ex = nullptr;
+      hipError_t e = hipStreamEndCapture(c->stream, &g);
+      if (e == hipSuccess && g) e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+      if (g) (void)hipGraphDestroy(g);
+      if (e != hipSuccess || !ex) {      // this runtime cannot capture the call: nothing has been issued - the call again, the ordinary way, and no further attempts
+        (void)hipGetLastError(); w->graph_broken = true;
+        fprintf(stderr, "[msevb] hipGraph capture of the MS-EVB force call failed (%s): option step_graph is off for this context\n", hipGetErrorString(e));
+        return MSEVB_RETRY;
+      }
+      G.exec = ex; G.hash = grec.hash; G.n = grec.n; G.plan_serial = w->plan_serial; G.topo_epoch = c->topo_epoch; G.alloc_epoch = g_alloc_epoch; c->evb_graph_captures++;
+    } else if (grec.hash != G.hash || grec.n != G.n || g_alloc_epoch != alloc_epoch0) {
+      // this call would NOT have enqueued what the graph holds (an argument, a launch geometry or a buffer changed): nothing has been issued - drop the graph, repeat the call the ordinary way
+      (void)hipGraphExecDestroy(G.exec); G.exec = nullptr;
+      w->graph_skip_once = true;
+      if (++c->evb_graph_mismatches >= 8) w->graph_broken = true;
+      return MSEVB_RETRY;
+    }
+    StepBlockVals sv; memset(&sv, 0, sizeof sv);
+    sv.v[SB_R] = w->seq_R; sv.v[SB_A] = w->seq_A; sv.v[SB_S] = w->seq_S; sv.v[SB_B] = w->seq_B; sv.v[SB_EPOCH] = c->pair_epoch;
+    hipLaunchKernelGGL(k_set_step_block, dim3(1), dim3(64), 0, c->stream, w->d_sb.p, sv);
+    HIPCHK(hipGraphLaunch(G.exec, c->stream));
+    c->evb_graph_launches++;
+    if (!dev_solve) {      // the host's turn follows (Jacobi, blend phase enqueued the ordinary way): the events that phase waits for were only captured - they all lie behind the graph now
+      hipEvent_t evs[] = {w->ev_side, c->ev_join2, w->ev_join2, w->ev_rs, w->ev_E, w->ev_prefill, w->ev_cpl, w->ev_fetchA, w->ev_fetch, c->ev_join};
+      for (hipEvent_t e : evs) if (e) HIPCHK(hipEventRecord(e, c->stream));
+    }
+  }
   HT(8);
   // ---- 9. Hamiltonian without the principal diabat's energy (H' = H - E0 I), from fetch A (or from the device-side solve)
   if (c->overlap) {
-    if (spin_wait((volatile long long*)w->h_flag, w->seq_A, w->ev_fetchA)) HIPCHK(hipErrorUnknown);
+    if (spin_wait((volatile long long*)w->h_flag, w->seq_A, w->ev_fetchA, gsync)) HIPCHK(hipErrorUnknown);
   } else HIPCHK(hipStreamSynchronize(c->stream));
   if (spec && *h_verdict != 1) {      // the tree has changed (or the check never ran): this call's side chains worked on a stale topology - the whole call again, the long way
-    w->plan_valid = false; w->spec_misses++;
+    w->plan_valid = false; w->spec_misses++; c->evb_spec_misses++;
     if (c->overlap && w->side_valid) { HIPCHK(hipStreamWaitEvent(c->stream, w->ev_side, 0)); if (w->side_wo_mol) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join2, 0)); }
     return MSEVB_RETRY;
   }
@@ -2465,7 +2543,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   bool energies_in = false;
   if (c->nccl_comm) {
     if (sharded) {      // the ranks' partial principal energies travel with the Hamiltonian entries
-      if (c->overlap) { if (spin_wait((volatile long long*)(w->h_flag + 2), w->seq_B, w->ev_fetch)) HIPCHK(hipErrorUnknown); } else HIPCHK(hipStreamSynchronize(c->stream));
+      if (c->overlap) { if (spin_wait((volatile long long*)(w->h_flag + 2), w->seq_B, w->ev_fetch, gsync)) HIPCHK(hipErrorUnknown); } else HIPCHK(hipStreamSynchronize(c->stream));
       if (c->rank != 0) c->h_energies[S_RECIP] = 0.0;      // replicated term: counts once
       energies_in = true;
     }
@@ -2473,7 +2551,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   }
   // E0 = potential energy of the principal diabat (fetch B); added to the diagonal and to the eigenvalue
   auto principal_energy = [&](double& E0) -> int {
-    if (c->overlap) { if (spin_wait((volatile long long*)(w->h_flag + 2), w->seq_B, w->ev_fetch)) HIPCHK(hipErrorUnknown); } else HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->overlap) { if (spin_wait((volatile long long*)(w->h_flag + 2), w->seq_B, w->ev_fetch, gsync)) HIPCHK(hipErrorUnknown); } else HIPCHK(hipStreamSynchronize(c->stream));
     if (nb_check_overflow(c)) return MSEVB_RETRY;      // a list row outgrew its stride in this call's rebuild: the whole force call is repeated
     if (sharded && !energies_in && c->rank != 0) c->h_energies[S_RECIP] = 0.0;      // sharded principal diabat: replicated terms count once (rank 0)
     double en[MSEVB_N_ENERGY];
@@ -2484,7 +2562,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   auto remember_plan = [&]() {      // what the next steps start from (speculative step)
     w->pl_D = D; memcpy(w->pl_plog, c->plog, sizeof c->plog); memcpy(w->pl_parent, c->parent, sizeof c->parent);
     w->pl_units_of = units_of; w->pl_grid_of = grid_of; w->pl_cp_of = cp_of; w->pl_eref_delta = eref_delta; w->pl_ngrid = ngrid; w->pl_ncp_big = ncp_big;
-    w->plan_valid = true; w->plan_epoch = c->topo_epoch;
+    w->plan_valid = true; w->plan_epoch = c->topo_epoch; w->plan_serial++;
   };
   if (c->n_ranks > 1 && !c->nccl_comm) {   // virtual sharding (tests): leave foreign diabats empty; caller merges
     double E0 = 0.0;
@@ -2500,7 +2578,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   // ---- 11. diagonalise H', blend (diagonalize_evb_hamiltonian, :242)
   double eg = 0.0;
   if (dev_solve) {      // eigenvalue and ground-state vector of the device's Jacobi (the blend behind it is running already)
-    if (c->overlap) { if (spin_wait((volatile long long*)(w->h_flag + 6), w->seq_S, w->ev_solve)) HIPCHK(hipErrorUnknown); } else HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->overlap) { if (spin_wait((volatile long long*)(w->h_flag + 6), w->seq_S, w->ev_solve, gsync)) HIPCHK(hipErrorUnknown); } else HIPCHK(hipStreamSynchronize(c->stream));
     const double* hs = w->h_solve;
     if (hs[0] != 0.0) FAIL(MSEVB_ERR_NUMERIC, "too many iterations in jacobi");
     eg = hs[1];
@@ -2520,7 +2598,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   } else {
     BlendTerms bt;
     const double w11 = blend_terms(c, D, c->eigvec, bt);
-    hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, (const double*)nullptr, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0);
+    hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, (const double*)nullptr, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0, (double*)nullptr, (const int*)nullptr, 0);
   }
   HIPCHK(hipGetLastError());
   if (c->nccl_comm) CHK(msevb_comm_allreduce_forces(c));
@@ -2589,6 +2667,9 @@ void evb_release(msevb_ctx* c) {
     if (w->h_desc) (void)hipHostFree(w->h_desc);
     if (w->h_solve) (void)hipHostFree(w->h_solve);
     if (w->h_flag) (void)hipHostFree(w->h_flag);
+    for (auto& g : w->sg) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    for (hipEvent_t e : w->ev_gjoin) if (e) (void)hipEventDestroy(e);
+    w->d_sb.release();
     w->d_coef.release(); w->d_plan.release(); w->d_sphere.release(); w->d_check.release(); w->d_refresh_scratch.release(); w->d_chain_done.release();
     if (w->h_E) (void)hipHostFree(w->h_E);
     delete w;
@@ -2635,7 +2716,7 @@ int msevb_evb_partial_blend(msevb_ctx* c, const double* eigvec, double* force) {
     BlendTerms bt;
     const double w11 = blend_terms(c, c->D, eigvec, bt);
     HIPCHK(hipMemcpyAsync(c->d_force.p, w->d_F11.p, n3 * 8, hipMemcpyDeviceToDevice, c->stream));
-    hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, (const double*)nullptr, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0);
+    hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, (const double*)nullptr, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0, (double*)nullptr, (const int*)nullptr, 0);
   }
   if (force) HIPCHK(hipMemcpyAsync(force, c->d_force.p, n3 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));

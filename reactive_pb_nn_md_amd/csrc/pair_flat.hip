@@ -83,6 +83,7 @@ struct PairFlatArgs {
   // per-block top-2 displacements since the last rewrite and compares with prune_delta; prune_state[2] carries the NUMBER (epoch) of the launch that wrote
   // the list, so that workgroups starting after workgroup 0 has stamped it still agree with it
   int self_nb, epoch; const double* prd1; const double* prd2; double prune_delta;
+  const long long* sb;      // step graph (ctx.hpp): the launch number comes from the device-resident step block (sb[SB_EPOCH]) instead of `epoch` - a captured launch's arguments never change
   const double* tt; const double* dtt;      // Tang-Toennies damping tables (SAPT instantiation)
 };
 
@@ -302,12 +303,12 @@ __global__ __launch_bounds__(THREADS, MINW) void k_pair_flat(const PairFlatArgs 
       m1 = n1; m2 = n2;
     }
     __syncthreads();      // (sm.red is the energy reduction's scratch later on)
-    mode = __builtin_amdgcn_readfirstlane((w != 0 && w != A.epoch && (m1 + m2) < A.prune_delta) ? 2 : 1);
+    mode = __builtin_amdgcn_readfirstlane((w != 0 && w != (A.sb ? (int)A.sb[SB_EPOCH] : A.epoch) && (m1 + m2) < A.prune_delta) ? 2 : 1);
   } else mode = __builtin_amdgcn_readfirstlane(A.prune_state[0]);      // 2: the flat list still covers r_c; otherwise it is rewritten first
   if (mode != 2) {      // snapshot of ALL positions (the displacement check runs over every atom, also when the cells are sharded over ranks)
     const int chunk = (A.N_all + gridDim.x - 1) / gridDim.x, k0 = blockIdx.x * chunk, k1 = min(A.N_all, k0 + chunk);
     for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x) A.posq_prune[k] = A.posq[k];
-    if (blockIdx.x == 0 && threadIdx.x == 0) A.prune_state[2] = A.epoch;      // a list exists for the current rows (k_top2_final / the next launches look), written by launch `epoch`
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.prune_state[2] = A.sb ? (int)A.sb[SB_EPOCH] : A.epoch;      // a list exists for the current rows (k_top2_final / the next launches look), written by launch `epoch`
   }
   const int lb = xcd_block(blockIdx.x, gridDim.x);      // one XCD works on one contiguous eighth of the cells (a slab)
   const int cidx = A.c_lo + (SPLIT ? lb >> 1 : lb), h = SPLIT ? (lb & 1) : 0;
@@ -627,7 +628,7 @@ static void pf_args(msevb_ctx* c, int c_lo, int c_hi, int slot_elec, int slot_vd
   const double rp = c->rc + c->prune_delta;
   A.rp2 = rp * rp; A.N_all = N;
   A.prd1 = c->d_partials.p + (size_t)S_PRD1 * MAX_BLOCKS; A.prd2 = c->d_partials.p + (size_t)S_PRD2 * MAX_BLOCKS; A.prune_delta = c->prune_delta;
-  A.self_nb = 0; A.epoch = 0;
+  A.self_nb = 0; A.epoch = 0; A.sb = nullptr;
 }
 
 // called by pair_forces (pair.hip) in place of the k_pair_half launch; the caller has sized the pruning state and the sorted-order accumulator
@@ -644,9 +645,10 @@ int pair_flat_launch(msevb_ctx* c, int c_lo, int c_hi, int slot_elec, int slot_v
   if (nblocks > MAX_BLOCKS) FAIL(MSEVB_ERR_LIMIT, "pair_forces: too many cells");
   *nblocks_out = nblocks;
   PairFlatArgs A;
+  memset(&A, 0, sizeof A);      // (padding bytes too: captured / replayed launches are compared by their argument bytes)
   pf_args(c, c_lo, c_hi, slot_elec, slot_vdw, A);
   if (++c->pair_epoch <= 0) c->pair_epoch = 1;
-  A.epoch = c->pair_epoch; A.self_nb = c->pair_self_nb; c->pair_self_nb = 0;      // (one-shot: set by total_force_enqueue for the launch it is about to make)
+  A.epoch = c->step_sb ? 0 : c->pair_epoch; A.sb = c->step_sb; A.self_nb = c->pair_self_nb; c->pair_self_nb = 0;      // (one-shot: set by total_force_enqueue for the launch it is about to make)
   const bool ty = c->pair_taylor;
   bool* at = c->attr_pair_flat;
   if (split) {

@@ -1255,7 +1255,7 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
   // the host is what decides when the EVB chains behind them can start).  Steps that sample the phase timers launch directly.
   struct Key { const void* p[9]; int v[8]; } key = {{c->d_grid.p, c->d_Q.p, c->d_theta.p, c->d_w.p, c->d_base.p, c->d_cell_start.p, c->d_perm.p, c->d_chg.p, c->d_fft_work.p},
                                                {N, K, c->ncell[0], c->ncell[1], c->ncell[2], c->cells_valid ? 1 : 0, (c->spread_tiles ? 1 : 0) + (c->spread_mfma ? 2 : 0) + (c->spread_bricks ? 4 : 0) + (fft_lds_usable(c) ? 8 : 0) + (c->pme_split_now ? 16 : 0) + (pme_weightless_now(c) ? 32 : 0), slot_recip}};
-  const bool use_graph = join_aux && c->graphs && !c->timing_now;
+  const bool use_graph = join_aux && c->graphs && !c->timing_now && !t_step_rec;      // (inside a captured / replayed force call the launches go into THAT graph)
   bool capturing = false;
   int nbk = 0;
   if (use_graph && c->pme_graph_exec && memcmp(&key, c->pme_graph_key, sizeof key) == 0) {

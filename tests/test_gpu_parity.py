@@ -65,7 +65,7 @@ def test_verlet_pair_set_identical(name):
     h.close()
 
 
-@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3", "std_n6_sapt_s6", "std_n6_lb_s9", "std_n6_rb_s10", "std_n6_ex3_s12", "std_n6_k20_s13", "std_n6_k64_s17", "std_n6_ortho_s19", "std_n12_k32_s26"])
+@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3", "std_n6_sapt_s6", "std_n6_lb_s9", "std_n6_rb_s10", "std_n6_ex3_s12", "std_n6_k20_s13", "std_n6_k64_s17", "std_n6_ortho_s19", "std_n12_k32_s26", "std_n12_sapt_s32"])
 def test_stages_against_reference(name):
     g = golden(name)
     h = api.MsEvbHip(system.from_golden(g))
@@ -230,7 +230,8 @@ def _schedule_run(spec, opts):
 @pytest.mark.parametrize("opts", [{"evb_defer_fold": 0}, {"evb_defer_molecules": 1}, {"evb_defer_molecules": 2}, {"evb_region_main": 1},
                                   {"evb_coupling_blocks": 96}, {"evb_recip_linear": 0}, {"fft_own": 0, "evb_defer_fold": 0, "evb_device_solve": 0},
                                   {"overlap": 0, "graphs": 0}, {"evb_device_solve": 0}, {"evb_device_solve": 2}, {"evb_blend_aside": 0}, {"pair_pipe": 0}, {"pair_self_mode": 0},
-                                  {"evb_device_solve": 0, "evb_blend_aside": 0}, {"step_fuse_refresh": 0}, {"evb_fft_patch": 0}, {"evb_fft_patch": 0, "evb_device_solve": 0}])
+                                  {"evb_device_solve": 0, "evb_blend_aside": 0}, {"step_fuse_refresh": 0}, {"evb_fft_patch": 0}, {"evb_fft_patch": 0, "evb_device_solve": 0},
+                                  {"step_graph": 0}, {"step_graph": 0, "evb_publish_spin": 0}, {"evb_device_solve": 0, "step_graph": 1}])
 def test_schedule_options_leave_the_forces_alone(opts):
     """the switchable pieces of the step schedule at BASELINE.json configs[2]: same Hamiltonian, same Hellmann-Feynman
     force, same 12-step trajectory as the default schedule (device-side solve by repeated squaring); among them the blend as one kernel behind the gather, the
@@ -241,6 +242,31 @@ def test_schedule_options_leave_the_forces_alone(opts):
     a, b = _SCHED_DEFAULT["default"], _schedule_run(spec, opts)
     assert rel(b[0], a[0]) < 1e-13 and np.abs(b[1] - a[1]).max() < 1e-9 and np.abs(b[2] - a[2]).max() < 1e-9 * np.abs(a[2]).max()
     assert np.abs(b[3] - a[3]).max() < 1e-8 * np.abs(a[3]).max() and np.abs(b[4] - a[4]).max() < 1e-8
+
+
+def test_step_graph_replays_the_force_call():
+    """The enqueue part of a speculative MS-EVB call as ONE captured hipGraph (option step_graph, default).  At BASELINE.json configs[2] size:
+    30 MD steps + host-array force calls; nearly every call must have gone out as a graph launch, NO replay may have differed from what the direct enqueue
+    would have issued (the library compares a hash of every launch's arguments), and energies / end state must equal the run without the graph."""
+    spec = _synthetic(32, 8, 11, 64)
+    out = {}
+    for g in (1, 0):
+        h = api.MsEvbHip(spec)
+        h.set_option("step_graph", g)
+        h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 77))
+        e0, F0 = h.ms_evb_calculate_total_force_energy()
+        e1, F1 = h.ms_evb_calculate_total_force_energy()      # (the second host-array call replays or captures the non-fused variant)
+        e2, F2 = h.ms_evb_calculate_total_force_energy()
+        en = h.md_integrate_atomic(30, spec.delta_t, use_evb=True)
+        out[g] = (e0, e1, e2, F2, en, h.get_positions(), int(h.info("graph_launches")), int(h.info("graph_captures")), int(h.info("graph_mismatches")), int(h.info("spec_misses")), int(h.info("evb_calls")))
+        h.close()
+    a, b = out[1], out[0]
+    assert b[6] == 0 and b[7] == 0      # off means off
+    assert a[8] == 0, "replays differed from the direct enqueue: %d" % a[8]
+    assert a[6] >= a[10] - 3 * (a[9] + 1) - 8 and a[7] <= 2 * (a[9] + 2), (a[6:], "graph launches / captures / mismatches / speculation misses / calls")
+    assert rel(a[0], b[0]) < 1e-13 and rel(a[1], a[0]) < 1e-13 and rel(a[2], a[0]) < 1e-13
+    assert np.abs(a[3] - b[3]).max() < 1e-9
+    assert np.abs(a[4][:, 0] - b[4][:, 0]).max() < 1e-9 * np.abs(b[4][:, 0]).max() and np.abs(a[5] - b[5]).max() < 1e-8
 
 
 @pytest.mark.parametrize("stores", [0, 1])
@@ -518,6 +544,9 @@ def test_md_trajectory_across_rebuilds_against_reference(name, evb):
     assert np.abs(h.get_positions() - g["md_xyz"]).max() < 1e-10
     assert np.abs(h.get_velocities() - g["md_velocity"]).max() < 1e-9
     assert np.abs(h.get_forces() - g["md_force"]).max() < 1e-7
+    if evb:      # the DEFAULT schedule (speculative step, device-side solve, blend phase enqueued before the host has seen the verdict) went through tree changes:
+        # calls that started from a stale tree were noticed and repeated, and the trajectory above is still the reference's
+        assert h.info("spec_steps") > 0 and h.info("spec_misses") >= len(set(nd)) - 1, (h.info("spec_steps"), h.info("spec_misses"))
     h.close()
     # the same trajectory in ONE call (device-resident loop, no host look at the flag between steps)
     h = api.MsEvbHip(spec)

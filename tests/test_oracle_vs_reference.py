@@ -43,7 +43,7 @@ def test_verlet_list_identical(oracle_lib, name):
     assert h.hexdigest() == str(g["neighbor_pairs_sha256"])
 
 
-@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3", "std_n6_sapt_s6", "std_n6_lb_s9", "std_n6_rb_s10", "std_n6_ex3_s12", "std_n6_k20_s13", "std_n6_k64_s17", "std_n6_ortho_s19", "std_n12_k32_s26"])
+@pytest.mark.parametrize("name", ["std_n8_s0", "std_n6_s3", "std_n6_sapt_s6", "std_n6_lb_s9", "std_n6_rb_s10", "std_n6_ex3_s12", "std_n6_k20_s13", "std_n6_k64_s17", "std_n6_ortho_s19", "std_n12_k32_s26", "std_n12_sapt_s32"])
 def test_stages(oracle_lib, name):
     g = golden(name)
     o = oracle_lib.Oracle(system.from_golden(g))

@@ -23,10 +23,11 @@ if [ -n "$QUICK" ]; then rm -f $OUT/*.log; ls -la $OUT; exit 0; fi      # QUICK=
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in their own passes (MI355X_MICROARCH.md: they do not fit one pass), default schedule
 # (with counters the profiler runs ONE kernel at a time, in the order they become ready: a kernel that waits on the device for a mark another queue's
 #  kernel sets would wait until its 2 s limit - evb_publish_spin=0 orders those kernels with events instead; same kernels, same bytes)
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o f -- $B --steps 10 --warmup 2 --opt evb_publish_spin=0 > $OUT/fetch.log 2>&1 || true
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o w -- $B --steps 10 --warmup 2 --opt evb_publish_spin=0 > $OUT/write.log 2>&1 || true
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o f -- $B --steps 10 --warmup 2 --opt evb_publish_spin=0 > $OUT/fetch.log 2>&1 && rcf=0 || rcf=$?; echo "fetch pass rc=$rcf" >> $OUT/pmc_exit_codes.txt
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o w -- $B --steps 10 --warmup 2 --opt evb_publish_spin=0 > $OUT/write.log 2>&1 && rcw=0 || rcw=$?; echo "write pass rc=$rcw" >> $OUT/pmc_exit_codes.txt
 python3 $R/tools/summarize_prof.py $OUT > $OUT/traffic_summary.txt 2>&1 || true
-python3 $R/tools/make_traffic_json.py $OUT $OUT/traffic.json > /dev/null 2>&1 || true
+# (a failed counter pass leaves NO traffic.json behind - a stale one from an earlier round must not pass for this build's)
+if [ "$rcf" = "0" ] && [ "$rcw" = "0" ]; then python3 $R/tools/make_traffic_json.py $OUT $OUT/traffic.json > /dev/null 2> $OUT/traffic_json.err || echo "make_traffic_json failed" >> $OUT/pmc_exit_codes.txt; else echo "traffic.json not made: a counter pass failed" >> $OUT/pmc_exit_codes.txt; fi
 rm -rf $OUT/fetch $OUT/write
 # 4. SQ / TCP counters of the dominant kernels, stand-alone
 PMC_ONLY="k_pair k_pme_spread k_pme_gather" BENCH_ARGS="--no-thermal --opt overlap=0 --opt graphs=0" bash $R/tools/pmc_gpu.sh ${TAG}_sq \

@@ -52,13 +52,17 @@ def main():
     ev = h.evb_state()["eigvec"].copy()
     h.close()
     out = {}
+    ranks = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 4, 8]
+    if 1 not in ranks:      # the ratios are over ONE rank's time, whatever the list asks for (a list starting with 4 used to take rank 0 of R = 4 as the baseline)
+        ranks = [1] + ranks
+    ranks = [1] + [R for R in ranks if R != 1]
     t1 = None
-    for R in ([int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else (1, 2, 4, 8)):
+    for R in ranks:
         ts = []
         for r in range(R):
             dt, D = rank_time(spec, r, R, ev, calls)
             ts.append(dt * 1e6)
-        if t1 is None:
+        if R == 1:
             t1 = ts[0]
         out[R] = {"us_per_rank": [round(t, 1) for t in ts], "slowest_over_one_rank": round(max(ts) / t1, 3), "n_diabats": int(D)}
         print("R=%d  slowest %.1f us  (x%.3f of one rank)  per rank: %s" % (R, max(ts), max(ts) / t1, " ".join("%.0f" % t for t in ts)), flush=True)

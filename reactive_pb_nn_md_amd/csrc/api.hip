@@ -3,10 +3,15 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include "ctx.hpp"
 
 thread_local StepRec* t_step_rec = nullptr;      // capture / replay of a force call (ctx.hpp)
 long g_alloc_epoch = 0;
+thread_local StepEventTable t_step_events;
 
 
 struct SlotCounts { int n[N_SLOTS]; };
@@ -77,7 +82,24 @@ __global__ void k_permute3(int N, const int* __restrict__ perm, const double* __
 
 extern "C" {
 
+// MSEVB_SEGV_TRACE=1 (diagnostic): a fault inside the runtime (no debugger on the GPU boxes) prints the native call stack before the process dies
+static void segv_trace(int sig) {
+  void* frames[64];
+  const int n = backtrace(frames, 48);
+  const char msg[] = "[msevb] fatal signal, native stack:\n";
+  (void)!write(2, msg, sizeof msg - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
 int msevb_create(msevb_ctx** out, int device_id) {
+  { static const bool tr = getenv("MSEVB_SEGV_TRACE") != nullptr; static bool installed = false; if (tr && !installed) {
+      installed = true;
+      static char alt[1 << 16];      // (its own stack: a stack overflow inside the runtime must still get its trace out)
+      stack_t ss; ss.ss_sp = alt; ss.ss_size = sizeof alt; ss.ss_flags = 0; (void)sigaltstack(&ss, nullptr);
+      struct sigaction sa; memset(&sa, 0, sizeof sa); sa.sa_handler = segv_trace; sa.sa_flags = SA_ONSTACK; sigemptyset(&sa.sa_mask);
+      (void)sigaction(SIGSEGV, &sa, nullptr); (void)sigaction(SIGABRT, &sa, nullptr); (void)sigaction(SIGBUS, &sa, nullptr);
+    } }
   if (!out) return MSEVB_ERR_ARG;
   msevb_ctx* c = new msevb_ctx();
   *out = c;

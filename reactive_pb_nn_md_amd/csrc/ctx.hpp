@@ -81,8 +81,20 @@ inline bool step_skip(int tag, const void* a, const void* b, size_t n) {      //
   step_hash_one(*r, tag); step_hash_one(*r, a); step_hash_one(*r, b); step_hash_one(*r, n); r->n++;
   return r->mode == 2;
 }
-inline hipError_t step_event_record(hipEvent_t e, hipStream_t s) { return step_skip(1, e, s, 0) ? hipSuccess : (hipEventRecord)(e, s); }
-inline hipError_t step_stream_wait(hipStream_t s, hipEvent_t e, unsigned f) { return step_skip(2, e, s, f) ? hipSuccess : (hipStreamWaitEvent)(s, e, f); }
+// (while capturing, a stream must not wait for an event of its OWN: this runtime's hipStreamEndCapture recurses without end on the edge such a wait adds - found with the
+//  blend-terms kernel, profiles/r05_graph_probe.txt; in stream order the wait is a no-op anyway.  The record streams of a capture's events are kept in a small table.)
+struct StepEventTable { int n = 0; hipEvent_t ev[64]; hipStream_t st[64]; };
+extern thread_local StepEventTable t_step_events;
+inline hipError_t step_event_record(hipEvent_t e, hipStream_t s) {
+  if (step_skip(1, e, s, 0)) return hipSuccess;
+  if (t_step_rec) { StepEventTable& T = t_step_events; int k = 0; while (k < T.n && T.ev[k] != e) ++k; if (k < 64) { T.ev[k] = e; T.st[k] = s; if (k == T.n) T.n++; } }
+  return (hipEventRecord)(e, s);
+}
+inline hipError_t step_stream_wait(hipStream_t s, hipEvent_t e, unsigned f) {
+  if (step_skip(2, e, s, f)) return hipSuccess;
+  if (t_step_rec) { const StepEventTable& T = t_step_events; for (int k = 0; k < T.n; ++k) if (T.ev[k] == e && T.st[k] == s) return hipSuccess; }
+  return (hipStreamWaitEvent)(s, e, f);
+}
 inline hipError_t step_memset_async(void* p, int v, size_t n, hipStream_t s) { return step_skip(3 + 16 * (v & 0xff), p, s, n) ? hipSuccess : (hipMemsetAsync)(p, v, n, s); }
 inline hipError_t step_memset_d32_async(hipDeviceptr_t p, int v, size_t n, hipStream_t s) { return step_skip(4 + 16 * v, (const void*)p, s, n) ? hipSuccess : (hipMemsetD32Async)(p, v, n, s); }
 inline hipError_t step_memcpy_async(void* d, const void* src, size_t n, hipMemcpyKind k, hipStream_t s) { return step_skip(5 + 16 * (int)k, d, src, n) ? hipSuccess : (hipMemcpyAsync)(d, src, n, k, s); }
@@ -456,7 +468,9 @@ struct msevb_ctx {
   long evb_spec_steps = 0, evb_spec_misses = 0, evb_host_dfs_calls = 0;
   // step graph (StepRec above): option step_graph; step_sb is non-null while a force call is being captured / replayed (kernels then read their per-call numbers from it);
   // opt_epoch counts msevb_set_option / box / communicator changes (a captured graph bakes the options in)
-  bool evb_step_graph = true; const long long* step_sb = nullptr; long opt_epoch = 0, evb_graph_launches = 0, evb_graph_captures = 0, evb_graph_mismatches = 0;
+  // OFF by default: on this runtime (ROCm 7.2) hipGraphLaunch enqueues its nodes one by one on the calling thread - 3.1 us per node against 3.3 us per stream launch
+  // (profiles/r05_graph_probe.txt) - so the replay saves no host time, and the graph's branches cannot use the device-side marks (3 % of the step)
+  bool evb_step_graph = false; const long long* step_sb = nullptr; long evb_graph_launches = 0, evb_graph_captures = 0, evb_graph_mismatches = 0;
   void* evb_work = nullptr;            // EvbWork of evb.hip (created by the first EVB force call, freed by evb_release)
   DBuf<double> d_comm_h, d_comm_e;     // staging of the Hamiltonian all-gather / the energy all-reduce (comm.hip)
   double* h_comm = nullptr; size_t h_comm_cap = 0; long long* h_comm_flag = nullptr; long long comm_seq = 0;      // pinned staging of the per-step all-gather (comm.hip)

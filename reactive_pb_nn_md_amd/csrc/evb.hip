@@ -1864,7 +1864,10 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   StepRec grec;
   const long alloc_epoch0 = g_alloc_epoch;
   if (c->evb_step_graph && !w->graph_broken && spec && !c->stamps_on && !c->nbr_check_pending && c->flag_verlet_list != 1 && c->list_valid && c->cells_valid &&
-      !(c->timing && (c->timing_tick % c->timing_stride) == 0) && !w->delta_dirty && !w->dv_dirty && w->d_check.p && c->stream && !c->evb_pair_first) {
+      !(c->timing && (c->timing_tick % c->timing_stride) == 0) && !w->delta_dirty && !w->dv_dirty && w->d_check.p && c->stream && !c->evb_pair_first && !c->evb_molecules_after_pair /* (evb_defer_molecules = 2 in a capture: hipStreamEndCapture crashes, as with the same-stream wait of ctx.hpp) */ &&
+      // (a blend phase that transforms with rocFFT stays out of the graph: hipStreamEndCapture of this runtime crashes on a capture that holds rocFFT launches on the origin stream
+      //  behind launches of the same plan on a side stream - grids other than 64^3 / 128^3 with the device-side solve; profiles/r05_graph_probe.txt)
+      (fft_lds_usable(c) || !(!c->evb_element_stores && c->n_ranks == 1 && !c->nccl_comm && c->evb_device_solve))) {
     if (w->graph_skip_once) w->graph_skip_once = false;      // (the call that repeats a mismatched replay)
     else {
       if (w->d_sb.alloc(SB_N)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (step block)");
@@ -1884,7 +1887,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       t_step_rec = nullptr; c->step_sb = nullptr;
     }
   } step_scope{c, w, &gmode};
-  if (gmode) { t_step_rec = &grec; c->step_sb = w->d_sb.p; }
+  if (gmode) { t_step_rec = &grec; c->step_sb = w->d_sb.p; t_step_events.n = 0; }
   const long long* const sb = gmode ? w->d_sb.p : (const long long*)nullptr;
   const hipStream_t gsync = gmode ? c->stream : (hipStream_t)nullptr;
   HIPCHK(hipEventRecord(w->ev_in, c->stream));      // (the first operation of a captured call: every side stream joins the capture through this event)
@@ -2468,7 +2471,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   if (dev_solve) {      // the blend phase goes out NOW on the main stream, pre-enqueued behind the pair loop: its first kernel starts on the solve kernel's mark - no host turn, no event hop
     if (c->overlap && !pub_spin) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_solve, 0));      // (without device-side marks: one event hop)
     phase_begin(c, PH_EVB_BLEND);
-    w->blend_mark = pub_spin ? w->d_chain_done.p + 3 : nullptr; w->blend_mark_seq = w->seq_A;
+    w->blend_mark = pub_spin ? w->d_chain_done.p + 3 : nullptr; w->blend_mark_seq = pub_spin ? w->seq_A : 0;      // (no mark, no number: a captured launch's arguments must not change from call to call)
     w->side_by_mark = pub_spin;      // that mark follows every side chain (and the Q_1 copy) of this call on the grid stream: no event waits in the phase
     const int rc_b = fast_blend_phase(c, w, D, nullptr, grid_of.data(), ngrid, nra, d_ra, w->d_coef.p);
     w->side_by_mark = false; w->blend_mark = nullptr;

@@ -231,7 +231,7 @@ def _schedule_run(spec, opts):
                                   {"evb_coupling_blocks": 96}, {"evb_recip_linear": 0}, {"fft_own": 0, "evb_defer_fold": 0, "evb_device_solve": 0},
                                   {"overlap": 0, "graphs": 0}, {"evb_device_solve": 0}, {"evb_device_solve": 2}, {"evb_blend_aside": 0}, {"pair_pipe": 0}, {"pair_self_mode": 0},
                                   {"evb_device_solve": 0, "evb_blend_aside": 0}, {"step_fuse_refresh": 0}, {"evb_fft_patch": 0}, {"evb_fft_patch": 0, "evb_device_solve": 0},
-                                  {"step_graph": 0}, {"step_graph": 0, "evb_publish_spin": 0}, {"evb_device_solve": 0, "step_graph": 1}])
+                                  {"step_graph": 1}, {"evb_publish_spin": 0}, {"evb_device_solve": 0, "step_graph": 1}, {"step_graph": 1, "evb_defer_molecules": 2}])
 def test_schedule_options_leave_the_forces_alone(opts):
     """the switchable pieces of the step schedule at BASELINE.json configs[2]: same Hamiltonian, same Hellmann-Feynman
     force, same 12-step trajectory as the default schedule (device-side solve by repeated squaring); among them the blend as one kernel behind the gather, the
@@ -245,7 +245,7 @@ def test_schedule_options_leave_the_forces_alone(opts):
 
 
 def test_step_graph_replays_the_force_call():
-    """The enqueue part of a speculative MS-EVB call as ONE captured hipGraph (option step_graph, default).  At BASELINE.json configs[2] size:
+    """The enqueue part of a speculative MS-EVB call as ONE captured hipGraph (option step_graph; off by default - on ROCm 7.2 it saves no host time).  At BASELINE.json configs[2] size:
     30 MD steps + host-array force calls; nearly every call must have gone out as a graph launch, NO replay may have differed from what the direct enqueue
     would have issued (the library compares a hash of every launch's arguments), and energies / end state must equal the run without the graph."""
     spec = _synthetic(32, 8, 11, 64)

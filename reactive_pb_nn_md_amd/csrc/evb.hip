@@ -1172,6 +1172,8 @@ struct SpecPlan {
   int donor_mol[SPEC_MAX_DONORS], donor_np[SPEC_MAX_DONORS], donor_pair[SPEC_MAX_DONORS][SPEC_MAX_PAIRS][3];   // {proton (local), acceptor molecule, basic atom (local)}
 };
 
+#include "evb_plan.hpp"      // enumeration + descriptor construction, one source for host and device
+
 // the tree check inside k_evb_region: thread = molecule j, against every expanded donor (their centres of mass and proton positions once per workgroup in LDS)
 __device__ __forceinline__ void spec_check_molecule(const SpecPlan* __restrict__ pl, const EvbTablesDev* __restrict__ tb, const int* __restrict__ mol_type, int m, int M,
                                                     const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms, const double* __restrict__ xyz, const double* __restrict__ mass,
@@ -1425,33 +1427,6 @@ __global__ void k_sum_rows(int nrow, int ncol, int stride, const double* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------- host side
-struct HMol { int id, type, natom; int atoms[MAX_MOL_ATOMS]; double com[3]; };
-struct HAtom { int type; double q; double x[3]; int mol; };
-// Small flat containers with the few std::map / std::vector operations the host side of a force call uses: a hop chain touches at most
-// MAX_CHAIN + 1 molecules (MAX_SPEC atoms), and the topologies are copied once per diabat - node-based maps and heap vectors made the
-// descriptor construction 25 us of the host's turn, which is on the step's critical path (the side chains start behind it).
-template <class V, int CAP> struct FlatMap {
-  int n = 0; int key[CAP]; V val[CAP];
-  V* find(int k) { for (int i = 0; i < n; ++i) if (key[i] == k) return &val[i]; return nullptr; }
-  V& operator[](int k) { if (V* v = find(k)) return *v; if (n >= CAP) throw std::length_error("EVB: more special atoms than MAX_SPEC"); key[n] = k; val[n] = V(); return val[n++]; }
-  const V& at(int k) const { for (int i = 0; i < n; ++i) if (key[i] == k) return val[i]; throw std::out_of_range("EVB: atom not in the hop-chain topology"); }
-};
-template <class V, int CAP> struct FlatVec {
-  int n = 0; V v[CAP];
-  size_t size() const { return (size_t)n; }
-  V& operator[](size_t k) { return v[k]; }
-  const V& operator[](size_t k) const { return v[k]; }
-  void push_back(const V& x) { if (n >= CAP) throw std::length_error("EVB: more molecules in a hop chain than MAX_CHAIN + 1"); v[n++] = x; }
-  V* begin() { return v; } V* end() { return v + n; }
-  const V* begin() const { return v; } const V* end() const { return v + n; }
-};
-struct HTopo {   // the molecules touched so far by a hop chain, in the topology reached so far
-  FlatVec<HMol, MAX_CHAIN + 1> mols;
-  FlatMap<HAtom, MAX_SPEC> atoms;
-  int hydronium;
-};
-typedef FlatMap<int, MAX_SPEC> WhereMap;
-
 struct EvbWork {   // persistent device scratch of one context
   DBuf<EvbTablesDev> d_tabs; DBuf<double> d_exch;
   DBuf<double> d_part, d_E, d_dVspec; DBuf<int> d_sbase, d_counter; DBuf<double> d_sw, d_sdw;
@@ -1490,6 +1465,8 @@ struct EvbWork {   // persistent device scratch of one context
   // step graph (ctx.hpp: StepRec): the enqueue part of a speculative call captured once per diabat tree and replayed with ONE launch; two entries: calls whose refresh of the
   // sorted arrays rode in the integrator's first kernel (MD loop) and calls that refresh themselves (force calls through the host-array entry points)
   struct StepGraph { hipGraphExec_t exec = nullptr; unsigned long long hash = 0; int n = 0; long plan_serial = -1, topo_epoch = -1, alloc_epoch = -1; };
+  // diabat enumeration / descriptor construction (evb_plan.hpp): static tables, the region's molecule order, scratch frames of the search
+  PlanTables ptab; std::vector<int> region_order; std::vector<PlanFrame> plan_frames;
   StepGraph sg[2]; hipEvent_t ev_gjoin[3] = {nullptr, nullptr, nullptr}; DBuf<long long> d_sb; long plan_serial = 0; bool graph_broken = false, graph_skip_once = false;
 };
 // host-side section timing (MSEVB_HOST_TIMING=1): where the CPU thread spends the step
@@ -1497,122 +1474,38 @@ struct HostTimes { double t[12] = {0}; long n = 0; };
 HostTimes g_ht;
 inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-void pbc_shift_h(const msevb_ctx* c, const double* ri, const double* rj, double* sh) { for (int d = 0; d < 3; ++d) sh[d] = std::floor((rj[d] - ri[d]) * (1.0 / c->box[d]) + 0.5) * c->box[d]; }
 
 const RegionRec* find_region(const EvbWork* w, int mol) {
   auto it = std::lower_bound(w->region.begin(), w->region.end(), mol, [](const RegionRec& r, int m) { return r.mol < m; });
   return (it != w->region.end() && it->mol == mol) ? &*it : nullptr;
 }
 
-int ensure_mol(msevb_ctx* c, const EvbWork* w, HTopo& t, int m) {   // returns index in t.mols
-  for (size_t k = 0; k < t.mols.size(); ++k) if (t.mols[k].id == m) return (int)k;
-  const RegionRec* r = find_region(w, m);
-  if (!r) return -1;
-  HMol hm; hm.id = m; hm.type = c->h_mol_type[m]; hm.natom = c->h_mol_natom[m];
-  for (int k = 0; k < hm.natom; ++k) {
-    const int a = c->h_mol_atoms[(size_t)m * MAX_MOL_ATOMS + k];
-    hm.atoms[k] = a;
-    HAtom ha; ha.type = c->h_atype[a]; ha.q = c->h_chg[a]; ha.mol = m;
-    for (int d = 0; d < 3; ++d) ha.x[d] = r->x[k][d];
-    t.atoms[a] = ha;
-  }
-  for (int d = 0; d < 3; ++d) hm.com[d] = r->com[d];
-  t.mols.push_back(hm);
-  return (int)t.mols.size() - 1;
-}
-
-void mol_com_h(const msevb_ctx* c, const HTopo& t, HMol& m) {
-  double s[3] = {0, 0, 0}, mt = 0;
-  for (int k = 0; k < m.natom; ++k) { const HAtom& a = t.atoms.at(m.atoms[k]); const double ma = c->h_mass[m.atoms[k]]; for (int d = 0; d < 3; ++d) s[d] = s[d] + a.x[d] * ma; mt = mt + ma; }
-  for (int d = 0; d < 3; ++d) m.com[d] = s[d] / mt;
-}
-
-// evb_change_data_structures_proton_transfer (src/ms_evb.f90:843-932) on the compact topology
-int apply_hop_h(msevb_ctx* c, const EvbWork* w, HTopo& t, int md, int ip_local, int ma, int iheavy_local, int* mw_atoms = nullptr, int* mw_n = nullptr) {
-  const int kd = ensure_mol(c, w, t, md), ka0 = ensure_mol(c, w, t, ma);
-  if (kd < 0 || ka0 < 0) FAIL(MSEVB_ERR_LIMIT, "EVB: proton-hop molecule outside the gathered neighbourhood");
-  HMol& D = t.mols[kd];
-  HMol& A = t.mols[ka0];
-  const int gp = D.atoms[ip_local];
-  for (int k = ip_local; k < D.natom - 1; ++k) D.atoms[k] = D.atoms[k + 1];
-  D.natom -= 1;
-  if (A.natom >= MAX_MOL_ATOMS) FAIL(MSEVB_ERR_LIMIT, "EVB: acceptor molecule too large");
-  A.atoms[A.natom] = gp; A.natom += 1;
-  t.atoms[gp].mol = ma;
-  t.hydronium = ma;
-  if (mw_atoms) { *mw_n = A.natom; for (int i = 0; i < A.natom; ++i) mw_atoms[i] = A.atoms[i]; }      // (what k_evb_refresh replays on the next steps' positions)
-  for (int i = 1; i < A.natom; ++i) {    // make_molecule_whole (src/general_routines.f90:1065)
-    HAtom& prev = t.atoms[A.atoms[i - 1]];
-    HAtom& cur = t.atoms[A.atoms[i]];
-    double sh[3]; pbc_shift_h(c, prev.x, cur.x, sh);
-    if (std::fabs(sh[0]) > 1e-6 || std::fabs(sh[1]) > 1e-6 || std::fabs(sh[2]) > 1e-6) for (int d = 0; d < 3; ++d) cur.x[d] = prev.x[d] + (cur.x[d] - prev.x[d] - sh[d]);
-  }
-  mol_com_h(c, t, D); mol_com_h(c, t, A);
-  const int base_type = A.type, acid_type = c->e_conj_mol[base_type];
-  if (acid_type < 0) FAIL(MSEVB_ERR_ARG, "EVB: acceptor molecule type has no conjugate acid");
-  t.atoms[gp].type = c->e_proton_type[acid_type];
-  for (int i = 0; i < A.natom; ++i) {
-    HAtom& a = t.atoms[A.atoms[i]];
-    const int tn = (i != A.natom - 1) ? c->e_conj_atype[a.type] : a.type;
-    a.type = tn; a.q = c->h_atype_chg[tn];
-  }
-  t.atoms[A.atoms[iheavy_local]].type = c->e_heavy_type[acid_type];
-  for (int i = 0; i < D.natom; ++i) { HAtom& a = t.atoms[D.atoms[i]]; const int tn = c->e_conj_atype[a.type]; a.type = tn; a.q = c->h_atype_chg[tn]; }
-  D.type = c->e_conj_mol[D.type];
-  A.type = acid_type;
-  const MolTypeHost& mt = c->h_mt[acid_type];    // reorder_molecule_data_structures (src/ms_evb.f90:941)
-  for (int i = 0; i < mt.natom; ++i) {
-    if (mt.atype[i] != t.atoms[A.atoms[i]].type) {
-      int idx = -1;
-      for (int j = i + 1; j < A.natom; ++j) if (mt.atype[i] == t.atoms[A.atoms[j]].type) { idx = j; break; }
-      if (idx < 0) FAIL(MSEVB_ERR_ARG, "error in reorder_molecule_data_structures");
-      const int keep = A.atoms[idx];
-      for (int j = idx; j > i; --j) A.atoms[j] = A.atoms[j - 1];
-      A.atoms[i] = keep;
+static int plan_err_code(int pe) { return (pe == PE_NO_CONJUGATE || pe == PE_REORDER || pe == PE_NO_HEAVY || pe == PE_NO_COUPLING_INDEX) ? MSEVB_ERR_ARG : MSEVB_ERR_LIMIT; }
+// the enumeration's static tables from the context (PlanTables, evb_plan.hpp)
+int fill_plan_tables(const msevb_ctx* c, PlanTables& tb) {
+  memset(&tb, 0, sizeof tb);
+  tb.nmt = c->nmt; tb.max_chain = c->max_chain; tb.rank = c->rank; tb.n_ranks = c->n_ranks;
+  if (c->nmt > MAX_MOLTYPES) return -1;
+  for (int t = 0; t < c->nmt; ++t) {
+    const MolTypeHost& mt = c->h_mt[t];
+    tb.mt_natom[t] = mt.natom;
+    for (int k = 0; k < MAX_MOL_ATOMS; ++k) {
+      tb.mt_atype[t][k] = k < (int)mt.atype.size() ? mt.atype[k] : -1;
+      tb.reactive_p[t][k] = k < (int)mt.reactive_protons.size() ? mt.reactive_protons[k] : 0;
+      tb.reactive_b[t][k] = k < (int)mt.reactive_basic.size() ? mt.reactive_basic[k] : 0;
     }
+    const int nb = (int)mt.bonds.size() / 2;
+    if (nb > MAX_BONDED) return -1;
+    tb.mt_nbond[t] = nb;
+    for (int b = 0; b < nb; ++b) { tb.mt_bond[t][b][0] = mt.bonds[2 * b]; tb.mt_bond[t][b][1] = mt.bonds[2 * b + 1]; }
   }
-  return MSEVB_OK;
-}
-
-int heavy_local_acid(const msevb_ctx* c, int acid_type) {   // get_heavy_atom_transfer_acid (src/ms_evb.f90:2917)
-  const MolTypeHost& mt = c->h_mt[acid_type];
-  for (int i = 0; i < mt.natom; ++i) if (mt.atype[i] == c->e_heavy_type[acid_type]) return i;
-  return -1;
-}
-
-int fill_spec(const HTopo& t, SpecAtom* spec, int* mols, int& n_spec, int& n_mols, WhereMap& where) {
-  n_spec = 0; n_mols = 0;
-  for (const HMol& m : t.mols) {
-    mols[n_mols++] = m.id;
-    for (int k = 0; k < m.natom; ++k) {
-      const HAtom& a = t.atoms.at(m.atoms[k]);
-      SpecAtom& s = spec[n_spec];
-      s.idx = m.atoms[k]; s.type = a.type; s.mol = m.id; s.q = a.q; s.pad = 0;
-      for (int d = 0; d < 3; ++d) s.x[d] = a.x[d];
-      where[m.atoms[k]] = n_spec++;
-    }
-  }
+  memcpy(tb.conj_mol, c->e_conj_mol, sizeof tb.conj_mol); memcpy(tb.proton_type, c->e_proton_type, sizeof tb.proton_type); memcpy(tb.heavy_type, c->e_heavy_type, sizeof tb.heavy_type);
+  memcpy(tb.conj_atype, c->e_conj_atype, sizeof tb.conj_atype);
+  for (int t = 0; t < MAX_TYPES; ++t) tb.atype_chg[t] = t < (int)c->h_atype_chg.size() ? c->h_atype_chg[t] : 0.0;
+  memcpy(tb.e_ref, c->e_ref, sizeof tb.e_ref); memcpy(tb.exch_proton, c->e_exch_proton, sizeof tb.exch_proton);
+  tb.n_cp = c->n_cp; memcpy(tb.cp_types, c->cp_types, sizeof tb.cp_types); memcpy(tb.cp_func, c->cp_func, sizeof tb.cp_func); memcpy(tb.cp_par, c->cp_par, sizeof tb.cp_par);
+  for (int d = 0; d < 3; ++d) tb.box[d] = c->box[d];
   return 0;
-}
-
-int make_unit(msevb_ctx* c, const HTopo& t, int donor, int acceptor, double sign, int slot, int do_rs, int do_rep, UnitDesc& u) {
-  memset(&u, 0, sizeof(u));
-  u.sign = sign; u.slot = slot; u.do_rs = do_rs; u.do_rep = do_rep; u.donor = donor; u.acceptor = acceptor; u.hyd = t.hydronium;
-  WhereMap where;
-  fill_spec(t, u.spec, u.mols, u.n_spec, u.n_mols, where);
-  for (const HMol& m : t.mols) {
-    if (do_rs && m.id == donor) { u.nD = m.natom; u.mt_D = m.type; for (int k = 0; k < m.natom; ++k) u.D_at[k] = where[m.atoms[k]]; }
-    if (do_rs && m.id == acceptor) { u.nA = m.natom; u.mt_A = m.type; for (int k = 0; k < m.natom; ++k) u.A_at[k] = where[m.atoms[k]]; }
-    if (m.id == t.hydronium) {
-      u.nH = m.natom;
-      for (int k = 0; k < m.natom; ++k) u.H_at[k] = where[m.atoms[k]];
-      const int hl = heavy_local_acid(c, m.type);
-      if (hl < 0) FAIL(MSEVB_ERR_ARG, "couldn't find atom type in subroutine get_heavy_atom_transfer_acid");
-      u.heavy = u.H_at[hl];
-      u.type_H = t.atoms.at(m.atoms[m.natom - 1]).type;
-    }
-  }
-  return MSEVB_OK;
 }
 
 // symmetric Jacobi diagonalisation (jacobi, src/general_routines.f90:2013-2088)
@@ -1952,62 +1845,22 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   for (int d = 0; d < MAX_DIABATS; ++d) { c->parent[d] = -1; for (int h = 0; h < MAX_CHAIN; ++h) for (int q = 0; q < 5; ++q) c->plog[d][h][q] = -1; }
   c->D = 1;
   SpecPlan& plan = w->plan;
+  PlanEnv penv; memset(&penv, 0, sizeof penv);
   if (spec) {      // the recorded tree
     c->D = w->pl_D;
     memcpy(c->plog, w->pl_plog, sizeof c->plog); memcpy(c->parent, w->pl_parent, sizeof c->parent);
-  } else {
+  } else {      // plan_enumerate (evb_plan.hpp): the reference's depth-first search on the neighbourhood record
     w->plan_valid = false; w->plan_fits = true; c->evb_host_dfs_calls++;
-    plan.n_donors = 0; plan.n_pairs_total = 0; plan.hyd = c->hydronium;
-    struct Frame { int mol, diabat; };
-    // recursion implemented with an explicit lambda to keep the reference's DFS order
-    std::function<int(int, int)> rec = [&](int im_donor, int d_donor) -> int {
-      int count = 0;
-      for (int h = 0; h < c->max_chain; ++h) { if (c->plog[d_donor][h][0] < 0) break; count++; }
-      if (count >= c->max_chain) return MSEVB_OK;
-      const RegionRec* ri = find_region(w, im_donor);
-      if (!ri) FAIL(MSEVB_ERR_LIMIT, "EVB: donor outside the gathered neighbourhood");
-      const MolTypeHost& mt = c->h_mt[c->h_mol_type[im_donor]];
-      int dq = -1; bool dnew = false;      // this molecule's entry among the expanded donors of the plan (its pairs are recorded once)
-      for (int q = 0; q < plan.n_donors; ++q) if (plan.donor_mol[q] == im_donor) dq = q;
-      if (dq < 0) { if (plan.n_donors < SPEC_MAX_DONORS) { dq = plan.n_donors++; plan.donor_mol[dq] = im_donor; plan.donor_np[dq] = 0; dnew = true; } else w->plan_fits = false; }
-      // molecules of the donor's first solvation shell, once per donor (not once per proton), in ascending molecule index
-      struct Near { int k; double sh[3]; };
-      Near near[64]; int n_near = 0;
-      for (int k = 0; k < (int)w->region.size(); ++k) {
-        const RegionRec& rj = w->region[k];
-        if (rj.mol == im_donor) continue;
-        double sh[3], dc[3]; pbc_shift_h(c, ri->com, rj.com, sh);
-        for (int d = 0; d < 3; ++d) dc[d] = rj.com[d] - ri->com[d] - sh[d];
-        if (dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2] >= 25.0) continue;       // evb_first_solvation_cutoff = 5 (src/glob_v.f90:54)
-        if (n_near >= 64) FAIL(MSEVB_ERR_LIMIT, "EVB: more than 64 molecules in a first solvation shell");
-        near[n_near].k = k; for (int d = 0; d < 3; ++d) near[n_near].sh[d] = sh[d];
-        ++n_near;
-      }
-      for (int ia = 0; ia < c->h_mol_natom[im_donor]; ++ia) {
-        if (mt.reactive_protons[ia] != 1) continue;
-        for (int q = 0; q < n_near; ++q) {      // ascending molecule index == the reference's j_mole loop
-          const RegionRec& rj = w->region[near[q].k];
-          const double* sh = near[q].sh;
-          const MolTypeHost& mj = c->h_mt[c->h_mol_type[rj.mol]];
-          for (int ja = 0; ja < rj.natom; ++ja) {
-            if (mj.reactive_basic[ja] != 1) continue;
-            double r[3]; for (int d = 0; d < 3; ++d) r[d] = rj.x[ja][d] - ri->x[ia][d] - sh[d];
-            if (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] >= 6.25) continue;           // evb_reactive_pair_distance = 2.5 (src/glob_v.f90:55)
-            if (dnew) { if (plan.donor_np[dq] < SPEC_MAX_PAIRS) { int* pp = plan.donor_pair[dq][plan.donor_np[dq]++]; pp[0] = ia; pp[1] = rj.mol; pp[2] = ja; plan.n_pairs_total++; } else w->plan_fits = false; }
-            if (c->D >= MAX_DIABATS) FAIL(MSEVB_ERR_LIMIT, "Found more diabat states than evb_max_states");
-            const int d = c->D++;
-            c->parent[d] = d_donor;
-            for (int h = 0; h < count; ++h) for (int q5 = 0; q5 < 5; ++q5) c->plog[d][h][q5] = c->plog[d_donor][h][q5];
-            int heavy = -1;
-            for (size_t b = 0; b < mt.bonds.size() / 2; ++b) { if (mt.bonds[2 * b] == ia) heavy = mt.bonds[2 * b + 1]; else if (mt.bonds[2 * b + 1] == ia) heavy = mt.bonds[2 * b]; }
-            c->plog[d][count][0] = im_donor; c->plog[d][count][1] = ia; c->plog[d][count][2] = heavy; c->plog[d][count][3] = rj.mol; c->plog[d][count][4] = ja;
-            if (rj.mol != c->hydronium) CHK(rec(rj.mol, d));
-          }
-        }
-      }
-      return MSEVB_OK;
-    };
-    CHK(rec(c->hydronium, 0));
+    if (fill_plan_tables(c, w->ptab)) FAIL(MSEVB_ERR_LIMIT, "EVB: molecule-type tables exceed the fixed sizes of the enumeration");
+    w->region_order.resize(w->region.size());
+    for (size_t k = 0; k < w->region.size(); ++k) w->region_order[k] = (int)k;      // (fetch_region sorted the records by molecule)
+    w->plan_frames.resize(MAX_CHAIN + 2);
+    penv.tb = &w->ptab; penv.mol_type = c->h_mol_type.data(); penv.mol_natom = c->h_mol_natom.data(); penv.mol_atoms = c->h_mol_atoms.data(); penv.atype = c->h_atype.data();
+    penv.chg = c->h_chg.data(); penv.mass = c->h_mass.data(); penv.rec = w->region.data(); penv.order = w->region_order.data(); penv.n_region = (int)w->region.size(); penv.hydronium = c->hydronium;
+    int fits = 1;
+    const int pe = plan_enumerate(penv, w->plan_frames.data(), c->plog, c->parent, &c->D, plan, &fits);
+    if (pe) FAIL(plan_err_code(pe), plan_error_text(pe));
+    if (!fits) w->plan_fits = false;
   }
   const int D = c->D, S = slots_per_rank(c, D), n_off = c->n_ranks * S, n_diag = 1 + n_off;
   HT(4);
@@ -2018,69 +1871,30 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   std::vector<int> grid_of(D, -1), cp_of(D, -1);
   std::vector<double> eref_delta(D, 0.0);
   std::vector<std::vector<int>> units_of(D);
-  HTopo P; P.hydronium = c->hydronium;
   int ngrid = 0, ncp_big = 0;
   if (spec) { units_of = w->pl_units_of; grid_of = w->pl_grid_of; cp_of = w->pl_cp_of; eref_delta = w->pl_eref_delta; ngrid = w->pl_ngrid; ncp_big = w->pl_ncp_big; }
-  else {
-  units.clear(); cps.clear(); ras.clear();
-  if (ensure_mol(c, w, P, c->hydronium) < 0) FAIL(MSEVB_ERR_LIMIT, "EVB: hydronium outside region");
-  auto push_unit = [&](const UnitDesc& u, int d, int k) { if ((int)units.size() < MAX_UNITS) { plan.unit_d[units.size()] = d; plan.unit_k[units.size()] = k; } units_of[d].push_back((int)units.size()); units.push_back(u); };
-  { UnitDesc u; CHK(make_unit(c, P, -1, -1, +1.0, 0, 0, 1, u)); push_unit(u, 0, 0); }
+  else {      // plan_build_diabat (evb_plan.hpp): units, reciprocal-space atoms and coupling of every owned diabat
+  int nu_need = 1, ncp_need = 0;
+  for (int d = 1; d < D; ++d) if (owned(c, d)) { int nhop = 0; for (int h = 0; h < c->max_chain; ++h) if (c->plog[d][h][0] >= 0) nhop = h + 1; nu_need += 2 * nhop; ++ncp_need; }
+  if (nu_need > MAX_UNITS) FAIL(MSEVB_ERR_LIMIT, "EVB descriptor staging too small");
+  units.resize(nu_need); cps.resize(ncp_need); ras.resize((size_t)ncp_need * MAX_SPEC);
+  PTopo Pt; Pt.n_mols = 0; Pt.n_atoms = 0; Pt.hydronium = c->hydronium;
+  { int perr = PE_OK; if (plan_ensure_mol(penv, Pt, c->hydronium, &perr) < 0) FAIL(MSEVB_ERR_LIMIT, "EVB: hydronium outside region"); }
+  { const int pe = plan_make_unit(penv, Pt, -1, -1, +1.0, 0, 0, 1, units[0]); if (pe) FAIL(plan_err_code(pe), plan_error_text(pe)); plan.unit_d[0] = 0; plan.unit_k[0] = 0; units_of[0].push_back(0); }
   std::vector<int> cp_d_unsorted, cp_nhop_unsorted;
+  int iu = 1, ir = 0, icp = 0;
   for (int d = 1; d < D; ++d) {
     if (!owned(c, d)) continue;
-    HTopo T = P;
-    const int slot = diag_slot(c, D, d);
-    int md = c->hydronium, ma = c->hydronium, nhop = 0;
-    for (int h = 0; h < c->max_chain; ++h) if (c->plog[d][h][0] >= 0) nhop = h + 1;
-    for (int h = 0; h < c->max_chain; ++h) {
-      if (c->plog[d][h][0] < 0) break;
-      md = T.hydronium; ma = c->plog[d][h][3];
-      if (ensure_mol(c, w, T, md) < 0 || ensure_mol(c, w, T, ma) < 0) FAIL(MSEVB_ERR_LIMIT, "EVB: hop molecule outside region");
-      { UnitDesc u; CHK(make_unit(c, T, md, ma, -1.0, slot, 1, 0, u)); push_unit(u, d, h); }
-      int typ_old = -1; for (const HMol& m : T.mols) if (m.id == T.hydronium) typ_old = m.type;
-      CHK(apply_hop_h(c, w, T, md, c->plog[d][h][1], ma, c->plog[d][h][4], plan.mw_atoms[d][h], &plan.mw_n[d][h]));
-      { UnitDesc u; CHK(make_unit(c, T, md, ma, +1.0, slot, 1, h == nhop - 1 ? 1 : 0, u)); push_unit(u, d, h + 1); }
-      int typ_new = -1; for (const HMol& m : T.mols) if (m.id == T.hydronium) typ_new = m.type;
-      eref_delta[d] += c->e_ref[typ_new] - c->e_ref[typ_old];
-    }
-    // reciprocal-space patches: every atom of a touched molecule
-    grid_of[d] = ngrid++;
-    for (const HMol& m : T.mols) for (int k = 0; k < m.natom; ++k) {
-      const int a = m.atoms[k]; const HAtom& ha = T.atoms.at(a);
-      RecipAtom r; r.grid = grid_of[d]; r.slot = slot; r.idx = a; r.pad = 0; r.q_new = ha.q; r.q_old = c->h_chg[a];
-      for (int q = 0; q < 3; ++q) r.x_new[q] = ha.x[q];
-      ras.push_back(r);
-    }
-    // off-diagonal element with the parent diabat, in this (acceptor) topology (evb_diabatic_coupling, :1021)
-    CouplingDesc cp; memset(&cp, 0, sizeof(cp));
-    cp.slot = off_slot(c, D, d);
-    WhereMap where;
-    fill_spec(T, cp.spec, cp.mols, cp.n_spec, cp.n_mols, where);
-    const HMol *Dm = nullptr, *Am = nullptr;
-    for (size_t k = 0; k < T.mols.size(); ++k) { if (T.mols[k].id == md) Dm = &T.mols[k]; if (T.mols[k].id == ma) Am = &T.mols[k]; for (int q = 0; q < 3; ++q) cp.mol_com[k][q] = T.mols[k].com[q]; }
-    cp.nD = Dm->natom; cp.nA = Am->natom;
-    for (int k = 0; k < Dm->natom; ++k) cp.D_at[k] = where[Dm->atoms[k]];
-    for (int k = 0; k < Am->natom; ++k) cp.A_at[k] = where[Am->atoms[k]];
-    double mdt = 0, mat = 0;
-    for (int k = 0; k < Dm->natom; ++k) mdt = mdt + c->h_mass[Dm->atoms[k]];
-    for (int k = 0; k < Am->natom; ++k) mat = mat + c->h_mass[Am->atoms[k]];
-    double sha[3]; pbc_shift_h(c, Dm->com, Am->com, sha);      // zundel_r_com (src/ms_evb.f90:2946)
-    for (int q = 0; q < 3; ++q) { const double rca = Dm->com[q] + (Am->com[q] - Dm->com[q] - sha[q]); cp.zc[q] = (mdt * Dm->com[q] + mat * rca) / (mdt + mat); cp.shiftd[q] = 0.0; cp.shifta[q] = sha[q]; }
-    cp.q_transfer = c->e_exch_proton[Am->type][Dm->type];
-    const int i_don = heavy_local_acid(c, c->e_conj_mol[Dm->type]), i_acc = heavy_local_acid(c, Am->type);
-    if (i_don < 0 || i_acc < 0) FAIL(MSEVB_ERR_ARG, "couldn't find heavy atom for the diabatic coupling");
-    cp.gO1 = where[Dm->atoms[i_don]]; cp.gO2 = where[Am->atoms[i_acc]]; cp.gH = where[Am->atoms[Am->natom - 1]];
-    const int t1 = cp.spec[cp.gO1].type, t2 = cp.spec[cp.gO2].type, t3 = cp.spec[cp.gH].type;
-    int ic = -1;
-    for (int k = 0; k < c->n_cp; ++k) if (c->cp_types[k][0] == t1 && c->cp_types[k][1] == t2 && c->cp_types[k][2] == t3) { ic = k; break; }
-    if (ic < 0) FAIL(MSEVB_ERR_ARG, "couldn't find index in subroutine 'get_index_atom_set' (diabat coupling parameters)");
-    cp.ftype = c->cp_func[ic];
-    for (int k = 0; k < 10; ++k) cp.par[k] = c->cp_par[ic][k];
-    cp_of[d] = (int)cps.size();
-    cps.push_back(cp);
+    int nr = 0, nhop = 0;
+    grid_of[d] = ngrid;
+    const int pe = plan_build_diabat(penv, Pt, d, D, c->plog, units.data(), iu, ras.data(), ir, ngrid, cps[icp], plan, &eref_delta[d], &nr, &nhop);
+    if (pe) FAIL(plan_err_code(pe), plan_error_text(pe));
+    for (int k = 0; k < 2 * nhop; ++k) units_of[d].push_back(iu + k);
+    iu += 2 * nhop; ir += nr; ++ngrid;
+    cp_of[d] = icp++;
     cp_d_unsorted.push_back(d); cp_nhop_unsorted.push_back(nhop);
   }
+  ras.resize(ir);
   // couplings with more than 8 Zundel atoms first: they take the 16-lane instantiation of k_evb_coupling, the rest the 8-lane one
   {
     std::vector<int> order(cps.size());
@@ -2621,18 +2435,28 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   // ---- 12. principal-diabat switch (src/ms_evb.f90:218-227): adopt the new topology, rebuild the Verlet list
   if (c->new_hydronium != c->hydronium) {
     c->hop_log.push_back((int)c->evb_calls); c->hop_log.push_back(c->hydronium + 1); c->hop_log.push_back(c->new_hydronium + 1);
-    if (spec) { CHK(fetch_region()); if (ensure_mol(c, w, P, c->hydronium) < 0) FAIL(MSEVB_ERR_LIMIT, "EVB: hydronium outside region"); }      // (the host has not looked at the neighbourhood record yet)
+    // the new principal topology from the neighbourhood record as it is NOW on the host (a call that started from the recorded tree has not looked at it yet)
+    if (spec || !penv.tb) {
+      CHK(fetch_region());
+      if (fill_plan_tables(c, w->ptab)) FAIL(MSEVB_ERR_LIMIT, "EVB: molecule-type tables exceed the fixed sizes of the enumeration");
+      w->region_order.resize(w->region.size());
+      for (size_t k = 0; k < w->region.size(); ++k) w->region_order[k] = (int)k;
+      penv.tb = &w->ptab; penv.mol_type = c->h_mol_type.data(); penv.mol_natom = c->h_mol_natom.data(); penv.mol_atoms = c->h_mol_atoms.data(); penv.atype = c->h_atype.data();
+      penv.chg = c->h_chg.data(); penv.mass = c->h_mass.data(); penv.rec = w->region.data(); penv.order = w->region_order.data(); penv.n_region = (int)w->region.size(); penv.hydronium = c->hydronium;
+    }
     w->plan_valid = false;
-    HTopo T = P;
-    for (int h = 0; h < c->max_chain; ++h) { if (c->plog[pr][h][0] < 0) break; CHK(apply_hop_h(c, w, T, T.hydronium, c->plog[pr][h][1], c->plog[pr][h][3], c->plog[pr][h][4])); }
+    PTopo T; T.n_mols = 0; T.n_atoms = 0; T.hydronium = c->hydronium;
+    { int perr = PE_OK; if (plan_ensure_mol(penv, T, c->hydronium, &perr) < 0) FAIL(MSEVB_ERR_LIMIT, "EVB: hydronium outside region"); }
+    for (int h = 0; h < c->max_chain; ++h) { if (c->plog[pr][h][0] < 0) break; const int pe = plan_apply_hop(penv, T, T.hydronium, c->plog[pr][h][1], c->plog[pr][h][3], c->plog[pr][h][4]); if (pe) FAIL(plan_err_code(pe), plan_error_text(pe)); }
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (const HMol& m : T.mols) {
+    for (int im = 0; im < T.n_mols; ++im) {
+      const PMol& m = T.mols[im];
       c->h_mol_type[m.id] = m.type; c->h_mol_natom[m.id] = m.natom;
       for (int k = 0; k < MAX_MOL_ATOMS; ++k) c->h_mol_atoms[(size_t)m.id * MAX_MOL_ATOMS + k] = k < m.natom ? m.atoms[k] : -1;
       for (int k = 0; k < m.natom; ++k) {
-        const int a = m.atoms[k]; const HAtom& ha = T.atoms.at(a);
-        c->h_atype[a] = ha.type; c->h_chg[a] = ha.q; c->h_mol_of[a] = m.id;
-        HIPCHK(hipMemcpy(c->d_xyz.p + 3 * (size_t)a, ha.x, 24, hipMemcpyHostToDevice));
+        const int a = m.atoms[k]; const PAtom* ha = T.find(a);
+        c->h_atype[a] = ha->type; c->h_chg[a] = ha->q; c->h_mol_of[a] = m.id;
+        HIPCHK(hipMemcpy(c->d_xyz.p + 3 * (size_t)a, ha->x, 24, hipMemcpyHostToDevice));
       }
     }
     c->hydronium = T.hydronium;

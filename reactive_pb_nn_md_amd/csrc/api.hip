@@ -841,6 +841,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   const std::string s(name);
   c->topo_epoch++;
   if (s == "evb_speculate") { c->evb_speculate = v != 0.0; return MSEVB_OK; }
+  if (s == "evb_device_plan") { c->evb_device_plan = v != 0.0; return MSEVB_OK; }      // 0: enumeration + descriptor build on the host (evb_plan.hpp, the same source the device runs)
   if (s == "step_graph") { c->evb_step_graph = v != 0.0; return MSEVB_OK; }      // the enqueue part of a speculative MS-EVB call as one captured hipGraph (evb.hip)
   if (s == "phase_timing") { c->timing = v != 0.0; c->timing_now = false; return MSEVB_OK; }
   if (s == "phase_timing_stride") { c->timing_stride = v < 1.0 ? 1 : (int)v; return MSEVB_OK; }
@@ -915,6 +916,7 @@ int msevb_get_info(msevb_ctx* c, const char* name, double* value) {
   if (s == "spec_steps") { *value = (double)c->evb_spec_steps; return MSEVB_OK; }      // MS-EVB calls that started from the recorded diabat tree
   if (s == "spec_misses") { *value = (double)c->evb_spec_misses; return MSEVB_OK; }    // ... of which the device found the tree changed (call repeated with a fresh enumeration)
   if (s == "host_dfs_calls") { *value = (double)c->evb_host_dfs_calls; return MSEVB_OK; }      // enumerations (DFS + descriptor build) done on the host
+  if (s == "device_plans") { *value = (double)c->evb_device_plans; return MSEVB_OK; }      // ... and on the device (k_evb_plan)
   if (s == "evb_calls") { *value = (double)c->evb_calls; return MSEVB_OK; }
   if (s == "graph_launches") { *value = (double)c->evb_graph_launches; return MSEVB_OK; }      // MS-EVB calls that went out as ONE hipGraphLaunch
   if (s == "graph_captures") { *value = (double)c->evb_graph_captures; return MSEVB_OK; }      // ... how often the call was captured (once per diabat tree and refresh mode)

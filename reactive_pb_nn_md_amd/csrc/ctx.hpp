@@ -465,7 +465,8 @@ struct msevb_ctx {
   // (1-based molecules) - the reference writes every hop at its own step (src/ms_evb.f90:331-335)
   std::vector<int> hop_log; long evb_calls = 0;
   // counters behind msevb_get_info: speculative MS-EVB calls, how many of them found the diabat tree changed (the call is repeated the long way), enumerations (DFS + descriptor build) done by the HOST
-  long evb_spec_steps = 0, evb_spec_misses = 0, evb_host_dfs_calls = 0;
+  long evb_spec_steps = 0, evb_spec_misses = 0, evb_host_dfs_calls = 0, evb_device_plans = 0;
+  bool evb_device_plan = true;      // f2: a call that has to enumerate the diabat tree does so on the device (k_evb_plan); 0 = on the host (the same source, evb_plan.hpp: the checker)
   // step graph (StepRec above): option step_graph; step_sb is non-null while a force call is being captured / replayed (kernels then read their per-call numbers from it);
   // opt_epoch counts msevb_set_option / box / communicator changes (a captured graph bakes the options in)
   // OFF by default: on this runtime (ROCm 7.2) hipGraphLaunch enqueues its nodes one by one on the calling thread - 3.1 us per node against 3.3 us per stream launch

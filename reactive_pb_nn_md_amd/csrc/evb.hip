@@ -1306,6 +1306,123 @@ __global__ __launch_bounds__(64) void k_evb_refresh(const SpecPlan* __restrict__
   *verdict_host = ok ? 1 : -1;
 }
 
+// ---- f2: the enumeration and the descriptors of a step whose diabat tree CHANGED, on the device (one workgroup; evb_plan.hpp holds the logic, the host runs the same source as the checker) ----
+// what the host needs back (pinned memory): sizes for its launches, the tree for the Hamiltonian it reports; seq is written last
+struct PlanSummary {
+  int err, fits, D, nu, ncp, nra, ngrid, ncp_big, n_region, n_donors;
+  unsigned long long need_bytes;
+  int plog[MAX_DIABATS][MAX_CHAIN][5], parent[MAX_DIABATS], nhop[MAX_DIABATS], grid_of[MAX_DIABATS], cp_of[MAX_DIABATS], unit0[MAX_DIABATS], nras[MAX_DIABATS];
+  double eref_delta[MAX_DIABATS];
+  long long seq;
+};
+struct PlanArgs {
+  const PlanTables* tb; const int* mol_type; const int* mol_natom; const int* mol_atoms; const int* atype; const double* chg; const double* mass;
+  const RegionRec* region; const int* region_count; int region_cap; int hydronium;
+  int* order; int* near_tab; int* near_cnt;      // scratch: REGION_CAP, 64 REGION_CAP, REGION_CAP ints
+  char* desc; unsigned long long desc_cap;      // units | couplings | reciprocal-space atoms (the layout of the host path: offsets from the counts)
+  CouplingDesc* cps_tmp;                        // MAX_DIABATS couplings in diabat order (sorted into desc at the end)
+  PlanWork* work;                               // MAX_DIABATS work spaces (one per thread of the construction phase)
+  SpecPlan* plan; PlanSummary* out; long long seq;
+};
+__global__ __launch_bounds__(256) void k_evb_plan(const PlanArgs A) {
+  __shared__ PlanFrame s_frames[MAX_CHAIN + 2];
+  __shared__ int s_plog[MAX_DIABATS][MAX_CHAIN][5], s_parent[MAX_DIABATS], s_nhop[MAX_DIABATS], s_unit0[MAX_DIABATS], s_r0[MAX_DIABATS], s_nras[MAX_DIABATS], s_grid[MAX_DIABATS], s_cp[MAX_DIABATS], s_own[MAX_DIABATS];
+  __shared__ double s_eref[MAX_DIABATS];
+  __shared__ int s_err, s_fits, s_D, s_nu, s_ncp, s_nra, s_n, s_ncp_big, s_pos[MAX_DIABATS];
+  __shared__ unsigned long long s_off_c, s_off_r;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  if (tid == 0) { s_err = PE_OK; s_fits = 1; s_n = min(*A.region_count, A.region_cap); if (*A.region_count > A.region_cap) s_err = PE_REGION_FULL; }
+  for (int k = tid; k < MAX_DIABATS * MAX_CHAIN * 5; k += nt) (&s_plog[0][0][0])[k] = -1;
+  for (int k = tid; k < MAX_DIABATS; k += nt) { s_parent[k] = -1; s_nhop[k] = 0; s_unit0[k] = 0; s_r0[k] = 0; s_nras[k] = 0; s_grid[k] = -1; s_cp[k] = -1; s_own[k] = 0; s_eref[k] = 0.0; }
+  __syncthreads();
+  const int n = s_n;
+  PlanEnv E;
+  E.tb = A.tb; E.mol_type = A.mol_type; E.mol_natom = A.mol_natom; E.mol_atoms = A.mol_atoms; E.atype = A.atype; E.chg = A.chg; E.mass = A.mass;
+  E.rec = A.region; E.order = A.order; E.n_region = n; E.hydronium = A.hydronium; E.near_tab = A.near_tab; E.near_cnt = A.near_cnt;
+  // A. molecule order of the record (the reference's j_mole loops run in ascending molecule index): rank by counting, the ids are distinct
+  for (int k = tid; k < n; k += nt) { const int mk = A.region[k].mol; int r = 0; for (int j = 0; j < n; ++j) r += A.region[j].mol < mk ? 1 : 0; A.order[r] = k; }
+  __threadfence_block(); __syncthreads();
+  //    first solvation shell of every record molecule (plan_in_shell: the search's own predicate), ascending
+  for (int a = tid; a < n; a += nt) {
+    const RegionRec& ri = A.region[A.order[a]];
+    int cnt = 0;
+    for (int b = 0; b < n; ++b) {
+      if (b == a) continue;
+      double sh[3];
+      if (!plan_in_shell(A.tb, ri, A.region[A.order[b]], sh)) continue;
+      if (cnt < 64) A.near_tab[64 * a + cnt] = b;
+      ++cnt;
+    }
+    A.near_cnt[a] = cnt;
+  }
+  __threadfence_block(); __syncthreads();
+  // B. the tree (one thread: a depth-first search over a few dozen short lists), then sizes and offsets
+  if (tid == 0 && s_err == PE_OK) {
+    int D = 1, fits = 1;
+    const int pe = plan_enumerate(E, s_frames, s_plog, s_parent, &D, *A.plan, &fits);
+    s_err = pe; s_fits = fits; s_D = D;
+    if (pe == PE_OK) {
+      int nu = 1, nra = 0, ncp = 0;
+      for (int d = 1; d < D; ++d) {
+        if (!plan_owned(A.tb, d)) continue;
+        int nhop = 0;
+        const int na = plan_chain_atoms(E, d, s_plog, &nhop);
+        s_own[d] = 1; s_nhop[d] = nhop; s_unit0[d] = nu; s_r0[d] = nra; s_nras[d] = na; s_grid[d] = ncp; s_cp[d] = ncp;
+        nu += 2 * nhop; nra += na; ++ncp;
+      }
+      s_nu = nu; s_nra = nra; s_ncp = ncp;
+      s_off_c = (unsigned long long)nu * sizeof(UnitDesc); s_off_r = s_off_c + (unsigned long long)ncp * sizeof(CouplingDesc);
+      if (nu > MAX_UNITS || ncp > MAX_DIABATS || nra > MAX_DIABATS * MAX_SPEC) s_err = PE_STAGING;
+      else if (s_off_r + (unsigned long long)nra * sizeof(RecipAtom) > A.desc_cap) s_err = PE_DESC_ROOM;
+    }
+  }
+  __syncthreads();
+  if (s_err == PE_OK) {
+    // C. descriptors: one thread per owned diabat (+ thread 0: the principal diabat's unit), each on a private copy of the principal topology
+    UnitDesc* units = (UnitDesc*)A.desc; RecipAtom* ras = (RecipAtom*)(A.desc + s_off_r);
+    const int D = s_D;
+    for (int d = tid; d < D; d += nt) {
+      if (d != 0 && !s_own[d]) continue;
+      PlanWork& W = A.work[d]; PTopo& P = W.P;
+      P.n_mols = 0; P.n_atoms = 0; P.hydronium = A.hydronium;
+      int perr = PE_OK;
+      if (plan_ensure_mol(E, P, A.hydronium, &perr) < 0) { atomicMax(&s_err, perr != PE_OK ? perr : (int)PE_HYD_OUTSIDE); continue; }
+      if (d == 0) { const int pe = plan_make_unit(E, P, -1, -1, +1.0, 0, 0, 1, units[0], W.where); if (pe) atomicMax(&s_err, pe); A.plan->unit_d[0] = 0; A.plan->unit_k[0] = 0; continue; }
+      int nr = 0, nhop = 0; double er = 0.0;
+      const int pe = plan_build_diabat(E, W, d, D, s_plog, units, s_unit0[d], ras, s_r0[d], s_grid[d], A.cps_tmp[s_cp[d]], *A.plan, &er, &nr, &nhop);
+      if (pe) atomicMax(&s_err, pe);
+      else if (nr != s_nras[d] || nhop != s_nhop[d]) atomicMax(&s_err, (int)PE_STAGING);
+      s_eref[d] = er;
+    }
+  }
+  __threadfence(); __syncthreads();
+  if (s_err == PE_OK) {
+    // D. couplings with more than 8 Zundel atoms first (they take the 16-lane instantiation of k_evb_coupling), otherwise diabat order: a stable partition
+    if (tid == 0) {
+      int pos = 0, big = 0;
+      for (int pass = 0; pass < 2; ++pass) for (int d = 1; d < s_D; ++d) if (s_own[d]) { const CouplingDesc& cp = A.cps_tmp[s_cp[d]]; const bool isbig = cp.nD + cp.nA > 8; if (isbig == (pass == 0)) { s_pos[s_cp[d]] = pos++; big += isbig ? 1 : 0; } }
+      s_ncp_big = big;
+      SpecPlan& pl = *A.plan;
+      for (int d = 1; d < s_D; ++d) if (s_own[d]) { const int k = s_pos[s_cp[d]]; pl.cp_d[k] = d; pl.cp_nhop[k] = s_nhop[d]; pl.cp_ra0[k] = s_r0[d]; pl.cp_ra1[k] = s_r0[d] + s_nras[d]; s_cp[d] = k; }
+      pl.n_units = s_nu; pl.n_cps = s_ncp; pl.n_ras = s_nra;
+    }
+    __syncthreads();
+    CouplingDesc* cps = (CouplingDesc*)(A.desc + s_off_c);
+    const int words = (int)(sizeof(CouplingDesc) / 8);
+    for (int k = 0; k < s_ncp; ++k) { const unsigned long long* src = (const unsigned long long*)&A.cps_tmp[k]; unsigned long long* dst = (unsigned long long*)&cps[s_pos[k]]; for (int q = tid; q < words; q += nt) dst[q] = src[q]; }
+  }
+  __threadfence_system(); __syncthreads();
+  PlanSummary* o = A.out;
+  for (int k = tid; k < MAX_DIABATS * MAX_CHAIN * 5; k += nt) (&o->plog[0][0][0])[k] = (&s_plog[0][0][0])[k];
+  for (int k = tid; k < MAX_DIABATS; k += nt) { o->parent[k] = s_parent[k]; o->nhop[k] = s_nhop[k]; o->grid_of[k] = s_own[k] ? s_grid[k] : -1; o->cp_of[k] = s_own[k] ? s_cp[k] : -1; o->unit0[k] = s_unit0[k]; o->nras[k] = s_nras[k]; o->eref_delta[k] = s_eref[k]; }
+  if (tid == 0) {
+    o->err = s_err; o->fits = s_fits; o->D = s_D; o->nu = s_nu; o->ncp = s_ncp; o->nra = s_nra; o->ngrid = s_ncp; o->ncp_big = s_ncp_big; o->n_region = n; o->n_donors = A.plan->n_donors;
+    o->need_bytes = s_off_r + (unsigned long long)s_nra * sizeof(RecipAtom);
+  }
+  __threadfence_system(); __syncthreads();
+  if (tid == 0) { o->seq = A.seq; }
+}
+
 __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms, const double* __restrict__ xyz,
                              const double* __restrict__ mass, BoxDev box, int* __restrict__ counter, RegionRec* __restrict__ out, int cap,
                              int* __restrict__ cand_counter, RegionRec* __restrict__ out_host, int cap_host,
@@ -1466,7 +1583,10 @@ struct EvbWork {   // persistent device scratch of one context
   // sorted arrays rode in the integrator's first kernel (MD loop) and calls that refresh themselves (force calls through the host-array entry points)
   struct StepGraph { hipGraphExec_t exec = nullptr; unsigned long long hash = 0; int n = 0; long plan_serial = -1, topo_epoch = -1, alloc_epoch = -1; };
   // diabat enumeration / descriptor construction (evb_plan.hpp): static tables, the region's molecule order, scratch frames of the search
-  PlanTables ptab; std::vector<int> region_order; std::vector<PlanFrame> plan_frames;
+  PlanTables ptab; std::vector<int> region_order; std::vector<PlanFrame> plan_frames; PlanWork plan_work;
+  // ... on the device (k_evb_plan): tables, scratch, the summary in pinned memory; solve_desc_dirty: the host-built part of the descriptor block (SolveDesc) has to follow the device-built one
+  DBuf<PlanWork> d_plan_work; DBuf<PlanTables> d_ptab; PlanTables ptab_dev; bool ptab_dev_valid = false; DBuf<int> d_plan_order, d_plan_near, d_plan_cnt; DBuf<CouplingDesc> d_cps_tmp;
+  PlanSummary* h_plan_sum = nullptr; long long seq_P = 0; hipEvent_t ev_plan = nullptr; bool solve_desc_dirty = false, device_plan_off_once = false;
   StepGraph sg[2]; hipEvent_t ev_gjoin[3] = {nullptr, nullptr, nullptr}; DBuf<long long> d_sb; long plan_serial = 0; bool graph_broken = false, graph_skip_once = false;
 };
 // host-side section timing (MSEVB_HOST_TIMING=1): where the CPU thread spends the step
@@ -1689,6 +1809,32 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   return MSEVB_OK;
 }
 
+// the MS-EVB parameter tables of the device kernels (once per context / msevb_set_evb)
+static int upload_evb_tables(msevb_ctx* c, EvbWork* w) {
+  if (w->tabs_uploaded) return MSEVB_OK;
+  if (w->d_tabs.alloc(1) || w->d_exch.alloc(MAX_TYPES)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB tables)");
+  {
+    EvbTablesDev tb; memset(&tb, 0, sizeof tb);
+    tb.n_da = c->n_da; tb.n_pa = c->n_pa;
+    memcpy(tb.da_types, c->da_types, sizeof tb.da_types); memcpy(tb.da_par, c->da_par, sizeof tb.da_par);
+    memcpy(tb.pa_types, c->pa_types, sizeof tb.pa_types); memcpy(tb.pa_par, c->pa_par, sizeof tb.pa_par);
+    memcpy(tb.exch_atomic, c->e_exch_atomic, sizeof tb.exch_atomic);
+    for (int t = 0; t < c->nmt && t < MAX_MOLTYPES; ++t) for (int k = 0; k < MAX_MOL_ATOMS; ++k) {
+      tb.reactive_p[t][k] = k < (int)c->h_mt[t].reactive_protons.size() ? c->h_mt[t].reactive_protons[k] : 0;
+      tb.reactive_b[t][k] = k < (int)c->h_mt[t].reactive_basic.size() ? c->h_mt[t].reactive_basic[k] : 0;
+    }
+    double rmax = 0.0;
+    for (int k = 0; k < c->n_da; ++k) rmax = std::max(rmax, c->da_par[k][5]);
+    for (int k = 0; k < c->n_pa; ++k) rmax = std::max(rmax, c->pa_par[k][4] + 3.0);
+    tb.screen2 = (rmax + 0.5) * (rmax + 0.5);
+    w->screen_r = rmax + 0.5;
+    HIPCHK(hipMemcpy(w->d_tabs.p, &tb, sizeof tb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(w->d_exch.p, c->e_exch_atomic, sizeof(double) * MAX_TYPES, hipMemcpyHostToDevice));
+    w->tabs_uploaded = true;
+  }
+  return MSEVB_OK;
+}
+
 static int evb_force_energy_body(msevb_ctx* c, double* epot_out);
 static int evb_force_energy_once(msevb_ctx* c, double* epot_out) {
   try { return evb_force_energy_body(c, epot_out); }
@@ -1757,7 +1903,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   StepRec grec;
   const long alloc_epoch0 = g_alloc_epoch;
   if (c->evb_step_graph && !w->graph_broken && spec && !c->stamps_on && !c->nbr_check_pending && c->flag_verlet_list != 1 && c->list_valid && c->cells_valid &&
-      !(c->timing && (c->timing_tick % c->timing_stride) == 0) && !w->delta_dirty && !w->dv_dirty && w->d_check.p && c->stream && !c->evb_pair_first && !c->evb_molecules_after_pair /* (evb_defer_molecules = 2 in a capture: hipStreamEndCapture crashes, as with the same-stream wait of ctx.hpp) */ &&
+      !(c->timing && (c->timing_tick % c->timing_stride) == 0) && !w->solve_desc_dirty && !w->delta_dirty && !w->dv_dirty && w->d_check.p && c->stream && !c->evb_pair_first && !c->evb_molecules_after_pair /* (evb_defer_molecules = 2 in a capture: hipStreamEndCapture crashes, as with the same-stream wait of ctx.hpp) */ &&
       // (a blend phase that transforms with rocFFT stays out of the graph: hipStreamEndCapture of this runtime crashes on a capture that holds rocFFT launches on the origin stream
       //  behind launches of the same plan on a side stream - grids other than 64^3 / 128^3 with the device-side solve; profiles/r05_graph_probe.txt)
       (fft_lds_usable(c) || !(!c->evb_element_stores && c->n_ranks == 1 && !c->nccl_comm && c->evb_device_solve))) {
@@ -1796,6 +1942,73 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
                      spec ? (const SpecPlan*)w->d_plan.p : (const SpecPlan*)nullptr, (const EvbTablesDev*)w->d_tabs.p, (const int*)c->d_mol_type.p, w->d_check.p,
                      region_aside ? h_verdict : (int*)nullptr, sb);
   HIPCHK(hipEventRecord(w->ev_region, s_reg));
+  // ---- 1b. f2: a call that has to enumerate the tree does so ON THE DEVICE (k_evb_plan: search, descriptors, the plan of the speculative steps) and is then repeated as a
+  //          speculative call - the descriptors are on the device already, the host has only read the summary (sizes for its launches, the tree for the Hamiltonian it reports).
+  //          evb_device_plan = 0: the host runs the same source (evb_plan.hpp) on the neighbourhood record, as rounds 1-4 did.
+  if (!spec && c->evb_device_plan && c->evb_speculate && c->overlap && !w->device_plan_off_once && !c->evb_element_stores) {
+    CHK(upload_evb_tables(c, w));
+    PlanTables& tbh = w->ptab;
+    if (fill_plan_tables(c, tbh)) FAIL(MSEVB_ERR_LIMIT, "EVB: molecule-type tables exceed the fixed sizes of the enumeration");
+    if (w->d_ptab.alloc(1) || w->d_plan_order.alloc(REGION_CAP) || w->d_plan_near.alloc((size_t)64 * REGION_CAP) || w->d_plan_cnt.alloc(REGION_CAP) || w->d_cps_tmp.alloc(MAX_DIABATS) || w->d_plan_work.alloc(MAX_DIABATS))
+      FAIL(MSEVB_ERR_HIP, "hipMalloc failed (device-side plan)");
+    if (!w->h_plan_sum) { HIPCHK(hipHostMalloc((void**)&w->h_plan_sum, sizeof(PlanSummary), hipHostMallocDefault)); memset(w->h_plan_sum, 0, sizeof(PlanSummary)); HIPCHK(hipEventCreateWithFlags(&w->ev_plan, hipEventDisableTiming)); }
+    if (!w->ptab_dev_valid || memcmp(&w->ptab_dev, &tbh, sizeof tbh) != 0) {      // (rank layout, box or tables changed)
+      HIPCHK(hipMemcpyAsync(w->d_ptab.p, &tbh, sizeof tbh, hipMemcpyHostToDevice, s_reg)); HIPCHK(hipStreamSynchronize(s_reg));
+      w->ptab_dev = tbh; w->ptab_dev_valid = true;
+    }
+    if (w->desc_cap < (size_t)512 * 1024) {      // room for a few dozen descriptors to start with; k_evb_plan says when it needs more
+      HIPCHK(hipDeviceSynchronize());
+      if (w->h_desc) HIPCHK(hipHostFree(w->h_desc));
+      w->desc_cap = (size_t)512 * 1024;
+      HIPCHK(hipHostMalloc((void**)&w->h_desc, w->desc_cap, hipHostMallocDefault));
+      if (w->d_desc.alloc(w->desc_cap)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB descriptors)");
+    }
+    const PlanSummary* ps = w->h_plan_sum;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+      PlanArgs pa; memset(&pa, 0, sizeof pa);
+      pa.tb = w->d_ptab.p; pa.mol_type = c->d_mol_type.p; pa.mol_natom = c->d_mol_natom.p; pa.mol_atoms = c->d_mol_atoms.p; pa.atype = c->d_atype.p; pa.chg = c->d_chg.p; pa.mass = c->d_mass.p;
+      pa.region = w->d_region.p; pa.region_count = w->d_counter.p; pa.region_cap = REGION_CAP; pa.hydronium = c->hydronium;
+      pa.order = w->d_plan_order.p; pa.near_tab = w->d_plan_near.p; pa.near_cnt = w->d_plan_cnt.p;
+      const size_t reserve = sizeof(SolveDesc) + 16 * (size_t)MAX_UNITS + 64;      // the host-built tail of the block (SolveDesc + unit references) must fit behind what the kernel writes
+      pa.desc = w->d_desc.p; pa.desc_cap = w->desc_cap - reserve; pa.cps_tmp = w->d_cps_tmp.p; pa.work = w->d_plan_work.p; pa.plan = w->d_plan.p; pa.out = w->h_plan_sum; pa.seq = ++w->seq_P;
+      hipLaunchKernelGGL(k_evb_plan, dim3(1), dim3(256), 0, s_reg, pa);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(w->ev_plan, s_reg));
+      if (spin_wait((volatile long long*)&w->h_plan_sum->seq, w->seq_P, w->ev_plan)) HIPCHK(hipErrorUnknown);
+      if (ps->err != PE_DESC_ROOM) break;
+      HIPCHK(hipDeviceSynchronize());      // the descriptor block grows: nothing else of this call is in flight yet
+      if (w->h_desc) HIPCHK(hipHostFree(w->h_desc));
+      w->desc_cap = 2 * (size_t)ps->need_bytes + 65536 + sizeof(SolveDesc) + 16 * (size_t)MAX_UNITS;
+      HIPCHK(hipHostMalloc((void**)&w->h_desc, w->desc_cap, hipHostMallocDefault));
+      if (w->d_desc.alloc(w->desc_cap)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB descriptors)");
+    }
+    if (ps->err != PE_OK) FAIL(plan_err_code(ps->err), plan_error_text(ps->err));
+    c->evb_device_plans++;
+    if (!ps->fits) w->device_plan_off_once = true;      // a tree too large for the fixed tables of the speculative step: this call goes the host's way (no plan, no speculation)
+    else {
+      // what the speculative calls start from (remember_plan's part): the tree, unit / grid / coupling indices, host-side mirrors of the descriptor counts
+      const int D = ps->D;
+      c->D = D; memcpy(c->plog, ps->plog, sizeof c->plog); memcpy(c->parent, ps->parent, sizeof c->parent);
+      w->pl_D = D; memcpy(w->pl_plog, ps->plog, sizeof w->pl_plog); memcpy(w->pl_parent, ps->parent, sizeof w->pl_parent);
+      w->pl_units_of.assign(D, std::vector<int>()); w->pl_grid_of.assign(D, -1); w->pl_cp_of.assign(D, -1); w->pl_eref_delta.assign(D, 0.0);
+      w->units.assign(ps->nu, UnitDesc()); w->cps.assign(ps->ncp, CouplingDesc()); w->ras.assign(ps->nra, RecipAtom());
+      w->pl_units_of[0].push_back(0); w->units[0].sign = +1.0;
+      int r0 = 0;
+      for (int d = 1; d < D; ++d) {
+        if (ps->grid_of[d] < 0) continue;      // (another rank's diabat)
+        for (int k = 0; k < 2 * ps->nhop[d]; ++k) { w->pl_units_of[d].push_back(ps->unit0[d] + k); w->units[ps->unit0[d] + k].sign = (k & 1) ? +1.0 : -1.0; }
+        w->pl_grid_of[d] = ps->grid_of[d]; w->pl_cp_of[d] = ps->cp_of[d]; w->pl_eref_delta[d] = ps->eref_delta[d];
+        for (int k = 0; k < ps->nras[d]; ++k) w->ras[r0 + k].grid = ps->grid_of[d];
+        r0 += ps->nras[d];
+      }
+      w->pl_ngrid = ps->ngrid; w->pl_ncp_big = ps->ncp_big;
+      w->plan.hyd = c->hydronium; w->plan.n_units = ps->nu; w->plan.n_cps = ps->ncp; w->plan.n_ras = ps->nra; w->plan.n_donors = ps->n_donors;
+      w->plan_valid = true; w->plan_fits = true; w->plan_epoch = c->topo_epoch; w->plan_serial++;
+      w->solve_desc_dirty = true;
+      return MSEVB_RETRY;      // the same call again, from the recorded tree (its check passes: the positions are the ones the tree was made from)
+    }
+  }
+  w->device_plan_off_once = false;
   HT(1);
   // ---- 2. principal diabat (calculate_total_force_energy, src/ms_evb.f90:411) - enqueued, not waited for
   const bool fast = !c->evb_element_stores;      // no per-element force stores: one gather of the blended potential (k_evb_blend_grids)
@@ -1878,16 +2091,17 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   for (int d = 1; d < D; ++d) if (owned(c, d)) { int nhop = 0; for (int h = 0; h < c->max_chain; ++h) if (c->plog[d][h][0] >= 0) nhop = h + 1; nu_need += 2 * nhop; ++ncp_need; }
   if (nu_need > MAX_UNITS) FAIL(MSEVB_ERR_LIMIT, "EVB descriptor staging too small");
   units.resize(nu_need); cps.resize(ncp_need); ras.resize((size_t)ncp_need * MAX_SPEC);
-  PTopo Pt; Pt.n_mols = 0; Pt.n_atoms = 0; Pt.hydronium = c->hydronium;
+  PlanWork& PW = w->plan_work; PTopo& Pt = PW.P;
+  Pt.n_mols = 0; Pt.n_atoms = 0; Pt.hydronium = c->hydronium;
   { int perr = PE_OK; if (plan_ensure_mol(penv, Pt, c->hydronium, &perr) < 0) FAIL(MSEVB_ERR_LIMIT, "EVB: hydronium outside region"); }
-  { const int pe = plan_make_unit(penv, Pt, -1, -1, +1.0, 0, 0, 1, units[0]); if (pe) FAIL(plan_err_code(pe), plan_error_text(pe)); plan.unit_d[0] = 0; plan.unit_k[0] = 0; units_of[0].push_back(0); }
+  { const int pe = plan_make_unit(penv, Pt, -1, -1, +1.0, 0, 0, 1, units[0], PW.where); if (pe) FAIL(plan_err_code(pe), plan_error_text(pe)); plan.unit_d[0] = 0; plan.unit_k[0] = 0; units_of[0].push_back(0); }
   std::vector<int> cp_d_unsorted, cp_nhop_unsorted;
   int iu = 1, ir = 0, icp = 0;
   for (int d = 1; d < D; ++d) {
     if (!owned(c, d)) continue;
     int nr = 0, nhop = 0;
     grid_of[d] = ngrid;
-    const int pe = plan_build_diabat(penv, Pt, d, D, c->plog, units.data(), iu, ras.data(), ir, ngrid, cps[icp], plan, &eref_delta[d], &nr, &nhop);
+    const int pe = plan_build_diabat(penv, PW, d, D, c->plog, units.data(), iu, ras.data(), ir, ngrid, cps[icp], plan, &eref_delta[d], &nr, &nhop);
     if (pe) FAIL(plan_err_code(pe), plan_error_text(pe));
     for (int k = 0; k < 2 * nhop; ++k) units_of[d].push_back(iu + k);
     iu += 2 * nhop; ir += nr; ++ngrid;
@@ -1927,25 +2141,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       w->d_grids.alloc_room(K3 * std::max(ngrid, 1)) || w->d_pack.alloc_room(fast ? K3 : K3 * std::max(ngrid, 1)) /* (fast path: one blended grid; it may hold the prefilled Q_1 already: no re-allocation) */ || w->d_F11.alloc(n3) || w->d_com_atom.alloc(n3))
     FAIL(MSEVB_ERR_HIP, "hipMalloc failed (EVB work buffers)");
   c->evb_cap = D;
-  if (!w->tabs_uploaded) {
-    EvbTablesDev tb; memset(&tb, 0, sizeof tb);
-    tb.n_da = c->n_da; tb.n_pa = c->n_pa;
-    memcpy(tb.da_types, c->da_types, sizeof tb.da_types); memcpy(tb.da_par, c->da_par, sizeof tb.da_par);
-    memcpy(tb.pa_types, c->pa_types, sizeof tb.pa_types); memcpy(tb.pa_par, c->pa_par, sizeof tb.pa_par);
-    memcpy(tb.exch_atomic, c->e_exch_atomic, sizeof tb.exch_atomic);
-    for (int t = 0; t < c->nmt && t < MAX_MOLTYPES; ++t) for (int k = 0; k < MAX_MOL_ATOMS; ++k) {
-      tb.reactive_p[t][k] = k < (int)c->h_mt[t].reactive_protons.size() ? c->h_mt[t].reactive_protons[k] : 0;
-      tb.reactive_b[t][k] = k < (int)c->h_mt[t].reactive_basic.size() ? c->h_mt[t].reactive_basic[k] : 0;
-    }
-    double rmax = 0.0;
-    for (int k = 0; k < c->n_da; ++k) rmax = std::max(rmax, c->da_par[k][5]);
-    for (int k = 0; k < c->n_pa; ++k) rmax = std::max(rmax, c->pa_par[k][4] + 3.0);
-    tb.screen2 = (rmax + 0.5) * (rmax + 0.5);
-    w->screen_r = rmax + 0.5;
-    HIPCHK(hipMemcpy(w->d_tabs.p, &tb, sizeof tb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(w->d_exch.p, c->e_exch_atomic, sizeof(double) * MAX_TYPES, hipMemcpyHostToDevice));
-    w->tabs_uploaded = true;
-  }
+  CHK(upload_evb_tables(c, w));
   if (nu > MAX_UNITS || ncp > MAX_DIABATS || nra > MAX_DIABATS * MAX_SPEC) FAIL(MSEVB_ERR_LIMIT, "EVB descriptor staging too small");
   // single rank, no per-element stores: the Hamiltonian is assembled and diagonalised on the device (k_evb_solve), its descriptor rides along
   const bool dev_solve = !c->evb_element_stores && c->n_ranks == 1 && !c->nccl_comm && c->evb_device_solve;
@@ -1987,6 +2183,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     (void)blend_terms(c, D, nullptr, bt_dev, sd->term_i, sd->term_j);
     sd->nterm = bt_dev.n;
   }
+  if (spec && w->solve_desc_dirty && dev_solve) HIPCHK(hipMemcpyAsync(w->d_desc.p + off_s, w->h_desc + off_s, desc_bytes - off_s, hipMemcpyHostToDevice, ss));      // (units / couplings / reciprocal-space atoms were written by k_evb_plan)
+  w->solve_desc_dirty = false;
   if (!spec) {
     HIPCHK(hipMemcpyAsync(w->d_desc.p, w->h_desc, desc_bytes, hipMemcpyHostToDevice, ss));
     // the plan for the steps that follow (they start from these descriptors): only when everything fitted its fixed-size tables
@@ -2474,7 +2672,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
 int evb_force_energy(msevb_ctx* c, double* epot_out) {
   c->evb_calls++;
   int rc = evb_force_energy_once(c, epot_out);
-  for (int k = 0; k < 3 && rc == MSEVB_RETRY; ++k) rc = evb_force_energy_once(c, epot_out);
+  for (int k = 0; k < 6 && rc == MSEVB_RETRY; ++k) rc = evb_force_energy_once(c, epot_out);      // (tree changed -> planned on the device -> speculative call; list overflow; a dropped step graph)
   if (rc == MSEVB_RETRY) FAIL(MSEVB_ERR_LIMIT, "Verlet list rows keep overflowing");
   return rc;
 }
@@ -2496,7 +2694,9 @@ void evb_release(msevb_ctx* c) {
     if (w->h_flag) (void)hipHostFree(w->h_flag);
     for (auto& g : w->sg) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : w->ev_gjoin) if (e) (void)hipEventDestroy(e);
-    w->d_sb.release();
+    w->d_sb.release(); w->d_ptab.release(); w->d_plan_order.release(); w->d_plan_near.release(); w->d_plan_cnt.release(); w->d_cps_tmp.release(); w->d_plan_work.release();
+    if (w->h_plan_sum) (void)hipHostFree(w->h_plan_sum);
+    if (w->ev_plan) (void)hipEventDestroy(w->ev_plan);
     w->d_coef.release(); w->d_plan.release(); w->d_sphere.release(); w->d_check.release(); w->d_refresh_scratch.release(); w->d_chain_done.release();
     if (w->h_E) (void)hipHostFree(w->h_E);
     delete w;

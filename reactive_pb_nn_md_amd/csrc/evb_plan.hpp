@@ -55,6 +55,9 @@ struct PlanEnv {
   const int* mol_type; const int* mol_natom; const int* mol_atoms; const int* atype; const double* chg; const double* mass;
   const RegionRec* rec; const int* order; int n_region;      // rec[order[k]].mol ascending in k
   int hydronium;
+  // device: the first solvation shells of ALL record molecules, made by the whole workgroup before one thread walks the tree (near_cnt[a] molecules near_tab[64 a ..], sorted
+  // indices, ascending; near_cnt > 64 = overflow).  nullptr: plan_enumerate scans the record itself (host)
+  const int* near_tab; const int* near_cnt;
 };
 
 struct PMol { int id, type, natom; int atoms[MAX_MOL_ATOMS]; double com[3]; };
@@ -67,12 +70,20 @@ struct PTopo {      // the molecules touched so far by a hop chain, in the topol
   PLAN_HD const PAtom* find(int a) const { for (int i = 0; i < n_atoms; ++i) if (akey[i] == a) return &aval[i]; return nullptr; }
 };
 struct PWhere { int n; int key[MAX_SPEC], val[MAX_SPEC]; PLAN_HD int at(int a) const { for (int i = 0; i < n; ++i) if (key[i] == a) return val[i]; return -1; } };
+struct PlanWork { PTopo P, T; PWhere where; };      // work space of one diabat's construction (device: global memory, one per thread - not 5 KB of private memory per lane)
 
 PLAN_HD void plan_pbc_shift(const PlanTables* tb, const double* ri, const double* rj, double* sh) { for (int d = 0; d < 3; ++d) sh[d] = floor((rj[d] - ri[d]) * (1.0 / tb->box[d]) + 0.5) * tb->box[d]; }
-PLAN_HD const RegionRec* plan_find_region(const PlanEnv& E, int mol) {
+PLAN_HD int plan_find_region_index(const PlanEnv& E, int mol) {      // position in the molecule order, -1: not in the record
   int lo = 0, hi = E.n_region;
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (E.rec[E.order[mid]].mol < mol) lo = mid + 1; else hi = mid; }
-  return (lo < E.n_region && E.rec[E.order[lo]].mol == mol) ? &E.rec[E.order[lo]] : nullptr;
+  return (lo < E.n_region && E.rec[E.order[lo]].mol == mol) ? lo : -1;
+}
+PLAN_HD const RegionRec* plan_find_region(const PlanEnv& E, int mol) { const int k = plan_find_region_index(E, mol); return k < 0 ? nullptr : &E.rec[E.order[k]]; }
+// is molecule j (record rj) in the first solvation shell of molecule i (record ri)?  evb_first_solvation_cutoff = 5 (src/glob_v.f90:54); sh = the periodic shift used
+PLAN_HD bool plan_in_shell(const PlanTables* tb, const RegionRec& ri, const RegionRec& rj, double* sh) {
+  double dc[3]; plan_pbc_shift(tb, ri.com, rj.com, sh);
+  for (int d = 0; d < 3; ++d) dc[d] = rj.com[d] - ri.com[d] - sh[d];
+  return !(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2] >= 25.0);
 }
 PLAN_HD int plan_ensure_mol(const PlanEnv& E, PTopo& t, int m, int* err) {      // index in t.mols, -1: molecule outside the record (err untouched), -2: container full
   for (int k = 0; k < t.n_mols; ++k) if (t.mols[k].id == m) return k;
@@ -162,11 +173,13 @@ PLAN_HD void plan_fill_spec(const PTopo& t, SpecAtom* spec, int* mols, int& n_sp
     }
   }
 }
-PLAN_HD void plan_zero(void* p, size_t n) { unsigned char* b = (unsigned char*)p; for (size_t k = 0; k < n; ++k) b[k] = 0; }
-PLAN_HD int plan_make_unit(const PlanEnv& E, const PTopo& t, int donor, int acceptor, double sign, int slot, int do_rs, int do_rep, UnitDesc& u) {
+PLAN_HD void plan_zero(void* p, size_t n) {      // (descriptors are multiples of 8 bytes, 8-byte aligned)
+  if ((((size_t)p | n) & 7) == 0) { unsigned long long* w = (unsigned long long*)p; for (size_t k = 0; k < n / 8; ++k) w[k] = 0ull; }
+  else { unsigned char* b = (unsigned char*)p; for (size_t k = 0; k < n; ++k) b[k] = 0; }
+}
+PLAN_HD int plan_make_unit(const PlanEnv& E, const PTopo& t, int donor, int acceptor, double sign, int slot, int do_rs, int do_rep, UnitDesc& u, PWhere& where) {
   plan_zero(&u, sizeof(u));
   u.sign = sign; u.slot = slot; u.do_rs = do_rs; u.do_rep = do_rep; u.donor = donor; u.acceptor = acceptor; u.hyd = t.hydronium;
-  PWhere where;
   plan_fill_spec(t, u.spec, u.mols, u.n_spec, u.n_mols, where);
   for (int im = 0; im < t.n_mols; ++im) {
     const PMol& m = t.mols[im];
@@ -215,12 +228,17 @@ PLAN_HD int plan_enumerate(const PlanEnv& E, PlanFrame* st, int (*plog)[MAX_CHAI
       if (f.dq < 0) { if (plan.n_donors < SPEC_MAX_DONORS) { f.dq = plan.n_donors++; plan.donor_mol[f.dq] = f.mol; plan.donor_np[f.dq] = 0; f.dnew = 1; } else *fits = 0; }
       // molecules of the donor's first solvation shell, once per donor (not once per proton), in ascending molecule index
       f.n_near = 0;
+      if (E.near_cnt) {      // the shell was tabulated (same predicate, same order)
+        const int a = plan_find_region_index(E, f.mol), cnt = E.near_cnt[a];
+        if (cnt > 64) return PE_SHELL_FULL;
+        for (int q = 0; q < cnt; ++q) { const int k = E.near_tab[64 * a + q]; double sh[3]; (void)plan_in_shell(tb, *ri, E.rec[E.order[k]], sh); f.near_k[q] = k; for (int d = 0; d < 3; ++d) f.near_sh[q][d] = sh[d]; }
+        f.n_near = cnt;
+      } else
       for (int k = 0; k < E.n_region; ++k) {
         const RegionRec& rj = E.rec[E.order[k]];
         if (rj.mol == f.mol) continue;
-        double sh[3], dc[3]; plan_pbc_shift(tb, ri->com, rj.com, sh);
-        for (int d = 0; d < 3; ++d) dc[d] = rj.com[d] - ri->com[d] - sh[d];
-        if (dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2] >= 25.0) continue;       // evb_first_solvation_cutoff = 5 (src/glob_v.f90:54)
+        double sh[3];
+        if (!plan_in_shell(tb, *ri, rj, sh)) continue;
         if (f.n_near >= 64) return PE_SHELL_FULL;
         f.near_k[f.n_near] = k; for (int d = 0; d < 3; ++d) f.near_sh[f.n_near][d] = sh[d];
         ++f.n_near;
@@ -265,13 +283,31 @@ PLAN_HD int plan_enumerate(const PlanEnv& E, PlanFrame* st, int (*plog)[MAX_CHAI
   return PE_OK;
 }
 
+// atoms of the molecules diabat d's hop chain touches (hops move atoms between them, the total stays): its number of reciprocal-space atoms
+PLAN_HD int plan_chain_atoms(const PlanEnv& E, int d, const int (*plog)[MAX_CHAIN][5], int* nhop_out) {
+  int mols[MAX_CHAIN + 1], nm = 0, n = 0, nhop = 0;
+  mols[nm++] = E.hydronium;
+  for (int h = 0; h < E.tb->max_chain; ++h) {
+    if (plog[d][h][0] < 0) break;
+    nhop = h + 1;
+    const int ma = plog[d][h][3];
+    bool seen = false;
+    for (int k = 0; k < nm; ++k) seen = seen || mols[k] == ma;
+    if (!seen) mols[nm++] = ma;
+  }
+  for (int k = 0; k < nm; ++k) n += E.mol_natom[mols[k]];
+  *nhop_out = nhop;
+  return n;
+}
+
 // ---- one diabat's descriptors ---------------------------------------------------------------------------------------------------------------
-// P: the principal topology with the hydronium in it (plan_ensure_mol).  Writes units[u0 .. u0 + 2 nhop), ras[r0 ..) (returns their number in *n_ras), the coupling cp
+// W.P: the principal topology with the hydronium in it (plan_ensure_mol); W.T, W.where: scratch.  Writes units[u0 .. u0 + 2 nhop), ras[r0 ..) (returns their number in *n_ras), the coupling cp
 // (slot, geometry, parameters), the plan's unit_d / unit_k / mw_atoms / mw_n of this diabat, and the reference-energy difference.
-PLAN_HD int plan_build_diabat(const PlanEnv& E, const PTopo& P, int d, int D, const int (*plog)[MAX_CHAIN][5], UnitDesc* units, int u0, RecipAtom* ras, int r0, int grid, CouplingDesc& cp,
+PLAN_HD int plan_build_diabat(const PlanEnv& E, PlanWork& W, int d, int D, const int (*plog)[MAX_CHAIN][5], UnitDesc* units, int u0, RecipAtom* ras, int r0, int grid, CouplingDesc& cp,
                               SpecPlan& plan, double* eref_delta, int* n_ras, int* nhop_out) {
   const PlanTables* tb = E.tb;
-  PTopo T = P;
+  PTopo& T = W.T; PWhere& where = W.where;
+  T = W.P;
   const int slot = plan_diag_slot(tb, D, d);
   int md = E.hydronium, ma = E.hydronium, nhop = 0, err = PE_OK;
   for (int h = 0; h < tb->max_chain; ++h) if (plog[d][h][0] >= 0) nhop = h + 1;
@@ -282,10 +318,10 @@ PLAN_HD int plan_build_diabat(const PlanEnv& E, const PTopo& P, int d, int D, co
     md = T.hydronium; ma = plog[d][h][3];
     if (plan_ensure_mol(E, T, md, &err) < 0 || plan_ensure_mol(E, T, ma, &err) < 0) return err != PE_OK ? err : PE_HOP_OUTSIDE;
     if (iu + 1 >= MAX_UNITS) return PE_STAGING;
-    { const int rc = plan_make_unit(E, T, md, ma, -1.0, slot, 1, 0, units[iu]); if (rc) return rc; plan.unit_d[iu] = d; plan.unit_k[iu] = h; ++iu; }
+    { const int rc = plan_make_unit(E, T, md, ma, -1.0, slot, 1, 0, units[iu], where); if (rc) return rc; plan.unit_d[iu] = d; plan.unit_k[iu] = h; ++iu; }
     int typ_old = -1; for (int k = 0; k < T.n_mols; ++k) if (T.mols[k].id == T.hydronium) typ_old = T.mols[k].type;
     { const int rc = plan_apply_hop(E, T, md, plog[d][h][1], ma, plog[d][h][4], plan.mw_atoms[d][h], &plan.mw_n[d][h]); if (rc) return rc; }
-    { const int rc = plan_make_unit(E, T, md, ma, +1.0, slot, 1, h == nhop - 1 ? 1 : 0, units[iu]); if (rc) return rc; plan.unit_d[iu] = d; plan.unit_k[iu] = h + 1; ++iu; }
+    { const int rc = plan_make_unit(E, T, md, ma, +1.0, slot, 1, h == nhop - 1 ? 1 : 0, units[iu], where); if (rc) return rc; plan.unit_d[iu] = d; plan.unit_k[iu] = h + 1; ++iu; }
     int typ_new = -1; for (int k = 0; k < T.n_mols; ++k) if (T.mols[k].id == T.hydronium) typ_new = T.mols[k].type;
     er += tb->e_ref[typ_new] - tb->e_ref[typ_old];
   }
@@ -302,7 +338,6 @@ PLAN_HD int plan_build_diabat(const PlanEnv& E, const PTopo& P, int d, int D, co
   // off-diagonal element with the parent diabat, in this (acceptor) topology (evb_diabatic_coupling, :1021)
   plan_zero(&cp, sizeof(cp));
   cp.slot = plan_off_slot(tb, D, d);
-  PWhere where;
   plan_fill_spec(T, cp.spec, cp.mols, cp.n_spec, cp.n_mols, where);
   const PMol *Dm = nullptr, *Am = nullptr;
   for (int k = 0; k < T.n_mols; ++k) { if (T.mols[k].id == md) Dm = &T.mols[k]; if (T.mols[k].id == ma) Am = &T.mols[k]; for (int q = 0; q < 3; ++q) cp.mol_com[k][q] = T.mols[k].com[q]; }

@@ -244,6 +244,34 @@ def test_schedule_options_leave_the_forces_alone(opts):
     assert np.abs(b[3] - a[3]).max() < 1e-8 * np.abs(a[3]).max() and np.abs(b[4] - a[4]).max() < 1e-8
 
 
+@pytest.mark.parametrize("name", all_golden("evb_") + ["md_evb_n6_d4_switch_s8"])
+def test_device_side_enumeration_against_the_host(name):
+    """f2: evb_conduct_proton_transfer_recursive / find_evb_reactive_neighbors (src/ms_evb.f90:498-620, :702-764) and the descriptor build behind
+    them (:843-932) as ONE workgroup on the device (k_evb_plan) against the host running the same source (evb_device_plan = 0, the checker): diabat count,
+    proton_log and coupling_matrix integer-equal, Hamiltonian and Hellmann-Feynman force to rounding of the atomics - on every EVB fixture of the real reference
+    (whose own proton_log / coupling_matrix test_evb_against_reference compares with the default = device path) and, with three virtual ranks, on the rank layout."""
+    g = golden(name)
+    spec = system.from_golden(g)
+    for ranks in (1, 3):
+        res = {}
+        for dev in (1, 0):
+            h = api.MsEvbHip(spec)
+            h.set_option("evb_device_plan", dev)
+            if ranks > 1:
+                h.set_option("shard_principal", 1)
+                h.comm_set_virtual(1, ranks)
+            e, F = h.ms_evb_calculate_total_force_energy()
+            e2, F2 = h.ms_evb_calculate_total_force_energy()      # (a speculative call on the tree the first one left)
+            st = h.evb_state()
+            res[dev] = (e, F, st, e2, F2, h.info("host_dfs_calls"), h.info("device_plans"), h.info("spec_steps"))
+            h.close()
+        a, b = res[1], res[0]
+        assert a[5] == 0 and a[6] >= 1 and b[5] >= 1 and b[6] == 0, (a[5:], b[5:])
+        assert a[2]["D"] == b[2]["D"] and np.array_equal(a[2]["proton_log"], b[2]["proton_log"]) and np.array_equal(a[2]["coupling_matrix"], b[2]["coupling_matrix"])
+        assert np.abs(a[2]["H"] - b[2]["H"]).max() < 1e-10 * max(np.abs(b[2]["H"]).max(), 1.0)
+        assert rel(a[0], b[0]) < 1e-13 and np.abs(a[1] - b[1]).max() < 1e-9 and rel(a[3], a[0]) < 1e-13 and np.abs(a[4] - a[1]).max() < 1e-9
+
+
 def test_step_graph_replays_the_force_call():
     """The enqueue part of a speculative MS-EVB call as ONE captured hipGraph (option step_graph; off by default - on ROCm 7.2 it saves no host time).  At BASELINE.json configs[2] size:
     30 MD steps + host-array force calls; nearly every call must have gone out as a graph launch, NO replay may have differed from what the direct enqueue
@@ -547,6 +575,8 @@ def test_md_trajectory_across_rebuilds_against_reference(name, evb):
     if evb:      # the DEFAULT schedule (speculative step, device-side solve, blend phase enqueued before the host has seen the verdict) went through tree changes:
         # calls that started from a stale tree were noticed and repeated, and the trajectory above is still the reference's
         assert h.info("spec_steps") > 0 and h.info("spec_misses") >= len(set(nd)) - 1, (h.info("spec_steps"), h.info("spec_misses"))
+        # f2: every enumeration of this trajectory (first call, every tree change) ran on the device - no depth-first search, no descriptor build on the host
+        assert h.info("host_dfs_calls") == 0 and h.info("device_plans") >= len(set(nd)), (h.info("host_dfs_calls"), h.info("device_plans"))
     h.close()
     # the same trajectory in ONE call (device-resident loop, no host look at the flag between steps)
     h = api.MsEvbHip(spec)

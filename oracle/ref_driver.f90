@@ -104,7 +104,7 @@ program ref_dump
   type(single_molecule_data_type) :: smd
 
   character(300) :: dumpfile, velfile, arg
-  integer :: nsteps, N, M, K, i, j, k2, l, nargs_cli, i_mole, n_nz, it, nt, na, nb, nang, ndih, D, ns
+  integer :: nsteps, N, M, K, i, j, k2, l, nargs_cli, i_mole, n_nz, it, nt, na, nb, nang, ndih, D, ns, i_hyd_trace
   integer :: principle_diabat, new_h, i_step
   integer, allocatable :: itmp(:), itmp2(:,:)
   real*8, allocatable :: rtmp(:,:), vel(:,:), etraj(:,:)
@@ -416,6 +416,8 @@ program ref_dump
         call calculate_total_force_energy( system_data, molecule_data, atom_data, verlet_list_data, PME_data )
      end if
      call dump_r8('md_F0', atom_data%force, (/3,N/))
+     ! one line per step, flushed at once: a run the reference itself ends (its 'stop' on a force that is too big, src/md_integration.f90:523) leaves its history behind
+     open(unit=79, file='md_trace.txt', status='replace')
      do i_step=1,nsteps
         trajectory_step = i_step
         call md_integrate_atomic( system_data, molecule_data, atom_data, integrator_data, verlet_list_data, PME_data, file_io_data )
@@ -427,7 +429,12 @@ program ref_dump
         vflag(i_step) = verlet_list_data%flag_verlet_list
         ndia(i_step) = 1
         if (ms_evb_simulation == "yes") ndia(i_step) = diabat_index
+        i_hyd_trace = 0
+        if (ms_evb_simulation == "yes") i_hyd_trace = hydronium_molecule_index(1)
+        write(79,'(I7,2ES26.17E3,2I4,ES26.17E3,I8)') i_step, etraj(1,i_step), etraj(2,i_step), vflag(i_step), ndia(i_step), sqrt(maxval(sum(atom_data%force**2, dim=1))), i_hyd_trace
+        flush(79)
      end do
+     close(79)
      call dump_i4('md_verlet_flag', vflag, (/nsteps/))
      call dump_i4('md_n_diabat', ndia, (/nsteps/))
      call dump_is('md_nsteps', nsteps)

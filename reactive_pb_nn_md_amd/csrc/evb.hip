@@ -1313,63 +1313,95 @@ struct PlanSummary {
   unsigned long long need_bytes;
   int plog[MAX_DIABATS][MAX_CHAIN][5], parent[MAX_DIABATS], nhop[MAX_DIABATS], grid_of[MAX_DIABATS], cp_of[MAX_DIABATS], unit0[MAX_DIABATS], nras[MAX_DIABATS];
   double eref_delta[MAX_DIABATS];
+  long long t[8];      // 100 MHz clock at the kernel's phase boundaries (diagnostic: MSEVB_HOST_TIMING prints them)
   long long seq;
 };
 struct PlanArgs {
   const PlanTables* tb; const int* mol_type; const int* mol_natom; const int* mol_atoms; const int* atype; const double* chg; const double* mass;
   const RegionRec* region; const int* region_count; int region_cap; int hydronium;
-  int* order; int* near_tab; int* near_cnt;      // scratch: REGION_CAP, 64 REGION_CAP, REGION_CAP ints
+  int* order; int* pair_tab; int* pair_cnt; int* near_tab; int* near_cnt;      // scratch: REGION_CAP, 3 PLAN_MAX_PAIRS REGION_CAP, REGION_CAP, 64 REGION_CAP, REGION_CAP ints
   char* desc; unsigned long long desc_cap;      // units | couplings | reciprocal-space atoms (the layout of the host path: offsets from the counts)
   CouplingDesc* cps_tmp;                        // MAX_DIABATS couplings in diabat order (sorted into desc at the end)
-  PlanWork* work;                               // MAX_DIABATS work spaces (one per thread of the construction phase)
   SpecPlan* plan; PlanSummary* out; long long seq;
 };
-__global__ __launch_bounds__(256) void k_evb_plan(const PlanArgs A) {
+constexpr int PLAN_LDS_REC = 1024;      // records whose molecule ids / centres of mass are staged in LDS (larger neighbourhoods - chains of four hops - read them from global memory)
+constexpr int PLAN_BATCH = 8;           // diabats constructed at a time: one per wave, work spaces in LDS
+__global__ __launch_bounds__(512) void k_evb_plan(const PlanArgs A) {
   __shared__ PlanFrame s_frames[MAX_CHAIN + 2];
   __shared__ int s_plog[MAX_DIABATS][MAX_CHAIN][5], s_parent[MAX_DIABATS], s_nhop[MAX_DIABATS], s_unit0[MAX_DIABATS], s_r0[MAX_DIABATS], s_nras[MAX_DIABATS], s_grid[MAX_DIABATS], s_cp[MAX_DIABATS], s_own[MAX_DIABATS];
   __shared__ double s_eref[MAX_DIABATS];
-  __shared__ int s_err, s_fits, s_D, s_nu, s_ncp, s_nra, s_n, s_ncp_big, s_pos[MAX_DIABATS];
+  __shared__ int s_err, s_fits, s_D, s_nu, s_ncp, s_nra, s_n, s_ncp_big, s_pos[MAX_DIABATS], s_list[MAX_DIABATS], s_nlist;
   __shared__ unsigned long long s_off_c, s_off_r;
+  __shared__ int s_mol[PLAN_LDS_REC];
+  __shared__ PlanTables s_tb;      // (the search reads the box and the reactive-atom flags in its innermost loops: from global memory that was 1 us per iteration)
+  // the tabulation phase keeps the records' centres of mass here, the construction phase its work spaces (one phase at a time)
+  constexpr size_t UNION_BYTES = sizeof(PlanWork) * PLAN_BATCH > sizeof(double) * 3 * PLAN_LDS_REC ? sizeof(PlanWork) * PLAN_BATCH : sizeof(double) * 3 * PLAN_LDS_REC;
+  __shared__ __attribute__((aligned(16))) unsigned char s_union[UNION_BYTES];
+  double* s_com = (double*)s_union;
+  PlanWork* s_work = (PlanWork*)s_union;
   const int tid = threadIdx.x, nt = blockDim.x;
-  if (tid == 0) { s_err = PE_OK; s_fits = 1; s_n = min(*A.region_count, A.region_cap); if (*A.region_count > A.region_cap) s_err = PE_REGION_FULL; }
+  if (tid == 0) A.out->t[0] = wall_clock64();
+  if (tid == 0) { s_err = PE_OK; s_fits = 1; s_n = min(*A.region_count, A.region_cap); if (*A.region_count > A.region_cap) s_err = PE_REGION_FULL; s_D = 1; s_nu = 1; s_ncp = 0; s_nra = 0; s_ncp_big = 0; s_off_c = 0; s_off_r = 0; s_nlist = 0; }
+  for (int k = tid; k < (int)(sizeof(PlanTables) / 4); k += nt) ((int*)&s_tb)[k] = ((const int*)A.tb)[k];
   for (int k = tid; k < MAX_DIABATS * MAX_CHAIN * 5; k += nt) (&s_plog[0][0][0])[k] = -1;
   for (int k = tid; k < MAX_DIABATS; k += nt) { s_parent[k] = -1; s_nhop[k] = 0; s_unit0[k] = 0; s_r0[k] = 0; s_nras[k] = 0; s_grid[k] = -1; s_cp[k] = -1; s_own[k] = 0; s_eref[k] = 0.0; }
   __syncthreads();
   const int n = s_n;
+  const bool lds_rec = n <= PLAN_LDS_REC;
   PlanEnv E;
-  E.tb = A.tb; E.mol_type = A.mol_type; E.mol_natom = A.mol_natom; E.mol_atoms = A.mol_atoms; E.atype = A.atype; E.chg = A.chg; E.mass = A.mass;
-  E.rec = A.region; E.order = A.order; E.n_region = n; E.hydronium = A.hydronium; E.near_tab = A.near_tab; E.near_cnt = A.near_cnt;
+  E.tb = &s_tb; E.mol_type = A.mol_type; E.mol_natom = A.mol_natom; E.mol_atoms = A.mol_atoms; E.atype = A.atype; E.chg = A.chg; E.mass = A.mass;
+  E.rec = A.region; E.order = A.order; E.n_region = n; E.hydronium = A.hydronium;
+  E.sorted_mol = lds_rec ? s_mol : (const int*)nullptr; E.sorted_com = lds_rec ? s_com : (const double*)nullptr; E.pair_tab = A.pair_tab; E.pair_cnt = A.pair_cnt;
   // A. molecule order of the record (the reference's j_mole loops run in ascending molecule index): rank by counting, the ids are distinct
-  for (int k = tid; k < n; k += nt) { const int mk = A.region[k].mol; int r = 0; for (int j = 0; j < n; ++j) r += A.region[j].mol < mk ? 1 : 0; A.order[r] = k; }
-  __threadfence_block(); __syncthreads();
-  //    first solvation shell of every record molecule (plan_in_shell: the search's own predicate), ascending
-  for (int a = tid; a < n; a += nt) {
-    const RegionRec& ri = A.region[A.order[a]];
-    int cnt = 0;
-    for (int b = 0; b < n; ++b) {
-      if (b == a) continue;
-      double sh[3];
-      if (!plan_in_shell(A.tb, ri, A.region[A.order[b]], sh)) continue;
-      if (cnt < 64) A.near_tab[64 * a + cnt] = b;
-      ++cnt;
-    }
-    A.near_cnt[a] = cnt;
+  for (int k = tid; k < n; k += nt) {
+    const int mk = A.region[k].mol; int r = 0;
+    for (int j = 0; j < n; ++j) r += A.region[j].mol < mk ? 1 : 0;
+    A.order[r] = k;
+    if (lds_rec) { s_mol[r] = mk; for (int d = 0; d < 3; ++d) s_com[3 * r + d] = A.region[k].com[d]; }
   }
   __threadfence_block(); __syncthreads();
-  // B. the tree (one thread: a depth-first search over a few dozen short lists), then sizes and offsets
+  if (tid == 0) A.out->t[1] = wall_clock64();
+  //    reactive pairs of EVERY record molecule (plan_donor_pairs: the search's own loops), one molecule per thread
+  //    in two passes: the shells (centres of mass from LDS, nothing else: every lane of a wave walks the same loop), then the pairs inside them (a dozen molecules each)
+  //    Only molecules the search can EXPAND: a donor reached through k hops (k <= max_chain - 1, src/ms_evb.f90:531) lies within 5 k A of the hydronium, every hop
+  //    joining two molecules of one first solvation shell (centres of mass within 5 A) - the rest of the record (three quarters of it) can only accept.
+  const int a_hyd = plan_find_region_index(E, A.hydronium);
+  const double reach = 5.0 * (s_tb.max_chain - 1) + 0.5;
+  for (int a = tid; a < n; a += nt) {
+    bool cand = a_hyd >= 0;
+    if (cand) {
+      const double* ch = lds_rec ? s_com + 3 * a_hyd : A.region[A.order[a_hyd]].com; const double* ca = lds_rec ? s_com + 3 * a : A.region[A.order[a]].com;
+      double sh[3], d2 = 0.0; plan_pbc_shift(&s_tb, ch, ca, sh);
+      for (int d = 0; d < 3; ++d) { const double dc = ca[d] - ch[d] - sh[d]; d2 += dc * dc; }
+      cand = d2 <= reach * reach;
+    }
+    A.near_cnt[a] = cand ? plan_shell(E, a, A.near_tab + 64 * a) : -1;
+  }
+  __threadfence_block(); __syncthreads();
+  for (int a = tid; a < n; a += nt) {
+    int cnt = 0;
+    const int pe = A.near_cnt[a] < 0 ? (int)PE_DONOR_OUTSIDE : plan_donor_pairs(E, a, A.near_tab + 64 * a, A.near_cnt[a], (int(*)[3])(A.pair_tab + 3 * PLAN_MAX_PAIRS * a), &cnt);
+    A.pair_cnt[a] = pe ? -pe : cnt;
+  }
+  __threadfence_block(); __syncthreads();
+  if (tid == 0) A.out->t[2] = wall_clock64();
+  // B. the tree (one thread walks the short pair lists), then sizes and offsets
   if (tid == 0 && s_err == PE_OK) {
     int D = 1, fits = 1;
     const int pe = plan_enumerate(E, s_frames, s_plog, s_parent, &D, *A.plan, &fits);
     s_err = pe; s_fits = fits; s_D = D;
     if (pe == PE_OK) {
-      int nu = 1, nra = 0, ncp = 0;
+      int nu = 1, nra = 0, ncp = 0, nl = 0;
+      s_list[nl++] = 0;      // (the principal diabat's unit is constructed with the others)
       for (int d = 1; d < D; ++d) {
-        if (!plan_owned(A.tb, d)) continue;
+        if (!plan_owned(&s_tb, d)) continue;
         int nhop = 0;
         const int na = plan_chain_atoms(E, d, s_plog, &nhop);
         s_own[d] = 1; s_nhop[d] = nhop; s_unit0[d] = nu; s_r0[d] = nra; s_nras[d] = na; s_grid[d] = ncp; s_cp[d] = ncp;
         nu += 2 * nhop; nra += na; ++ncp;
+        s_list[nl++] = d;
       }
+      s_nlist = nl;
       s_nu = nu; s_nra = nra; s_ncp = ncp;
       s_off_c = (unsigned long long)nu * sizeof(UnitDesc); s_off_r = s_off_c + (unsigned long long)ncp * sizeof(CouplingDesc);
       if (nu > MAX_UNITS || ncp > MAX_DIABATS || nra > MAX_DIABATS * MAX_SPEC) s_err = PE_STAGING;
@@ -1377,25 +1409,45 @@ __global__ __launch_bounds__(256) void k_evb_plan(const PlanArgs A) {
     }
   }
   __syncthreads();
+  if (tid == 0) A.out->t[3] = wall_clock64();
+  E.sorted_com = nullptr;      // (its storage becomes the work spaces now; the molecule ids stay)
   if (s_err == PE_OK) {
-    // C. descriptors: one thread per owned diabat (+ thread 0: the principal diabat's unit), each on a private copy of the principal topology
+    // C. descriptors: one diabat per WAVE (its lane 0 - lanes of one wave on different diabats would take turns), PLAN_BATCH at a time, each on a private copy of the principal topology
     UnitDesc* units = (UnitDesc*)A.desc; RecipAtom* ras = (RecipAtom*)(A.desc + s_off_r);
-    const int D = s_D;
-    for (int d = tid; d < D; d += nt) {
-      if (d != 0 && !s_own[d]) continue;
-      PlanWork& W = A.work[d]; PTopo& P = W.P;
-      P.n_mols = 0; P.n_atoms = 0; P.hydronium = A.hydronium;
-      int perr = PE_OK;
-      if (plan_ensure_mol(E, P, A.hydronium, &perr) < 0) { atomicMax(&s_err, perr != PE_OK ? perr : (int)PE_HYD_OUTSIDE); continue; }
-      if (d == 0) { const int pe = plan_make_unit(E, P, -1, -1, +1.0, 0, 0, 1, units[0], W.where); if (pe) atomicMax(&s_err, pe); A.plan->unit_d[0] = 0; A.plan->unit_k[0] = 0; continue; }
-      int nr = 0, nhop = 0; double er = 0.0;
-      const int pe = plan_build_diabat(E, W, d, D, s_plog, units, s_unit0[d], ras, s_r0[d], s_grid[d], A.cps_tmp[s_cp[d]], *A.plan, &er, &nr, &nhop);
-      if (pe) atomicMax(&s_err, pe);
-      else if (nr != s_nras[d] || nhop != s_nhop[d]) atomicMax(&s_err, (int)PE_STAGING);
-      s_eref[d] = er;
+    const int D = s_D, wave = tid >> 6, lane = tid & 63, nl = s_nlist;
+    {      // zero-fill of every descriptor by the whole workgroup (coalesced), not by the one lane that constructs it
+      unsigned long long* z = (unsigned long long*)A.desc; const size_t nz = (size_t)s_off_c / 8;
+      for (size_t k = tid; k < nz; k += nt) z[k] = 0ull;
+      unsigned long long* zc = (unsigned long long*)A.cps_tmp; const size_t nzc = (size_t)s_ncp * sizeof(CouplingDesc) / 8;
+      for (size_t k = tid; k < nzc; k += nt) zc[k] = 0ull;
+      __threadfence_block(); __syncthreads();
+    }
+    for (int base = 0; base < nl; base += PLAN_BATCH) {
+      const int q = base + wave;
+      if (lane == 0 && wave < PLAN_BATCH && q < nl) {
+        const int d = s_list[q];
+        PlanWork& W = s_work[wave]; PTopo& P = W.P;
+        P.n_mols = 0; P.n_atoms = 0; P.hydronium = A.hydronium;
+        int perr = PE_OK;
+        const long long tc0 = wall_clock64();
+        const int em = plan_ensure_mol(E, P, A.hydronium, &perr);
+        if (q == nl - 1) A.out->t[7] = wall_clock64() - tc0;
+        if (em < 0) atomicMax(&s_err, perr != PE_OK ? perr : (int)PE_HYD_OUTSIDE);
+        else if (d == 0) { const int pe = plan_make_unit(E, P, -1, -1, +1.0, 0, 0, 1, units[0], W.where, true); if (pe) atomicMax(&s_err, pe); A.plan->unit_d[0] = 0; A.plan->unit_k[0] = 0; }
+        else {
+          int nr = 0, nhop = 0; double er = 0.0;
+          const int pe = plan_build_diabat(E, W, d, D, s_plog, units, s_unit0[d], ras, s_r0[d], s_grid[d], A.cps_tmp[s_cp[d]], *A.plan, &er, &nr, &nhop, true);
+          if (pe) atomicMax(&s_err, pe);
+          else if (nr != s_nras[d] || nhop != s_nhop[d]) atomicMax(&s_err, (int)PE_STAGING);
+          s_eref[d] = er;
+        }
+        if (q == nl - 1) A.out->t[6] = wall_clock64() - tc0;
+      }
+      __syncthreads();
     }
   }
   __threadfence(); __syncthreads();
+  if (tid == 0) A.out->t[4] = wall_clock64();
   if (s_err == PE_OK) {
     // D. couplings with more than 8 Zundel atoms first (they take the 16-lane instantiation of k_evb_coupling), otherwise diabat order: a stable partition
     if (tid == 0) {
@@ -1420,7 +1472,7 @@ __global__ __launch_bounds__(256) void k_evb_plan(const PlanArgs A) {
     o->need_bytes = s_off_r + (unsigned long long)s_nra * sizeof(RecipAtom);
   }
   __threadfence_system(); __syncthreads();
-  if (tid == 0) { o->seq = A.seq; }
+  if (tid == 0) { o->t[5] = wall_clock64(); __threadfence_system(); o->seq = A.seq; }
 }
 
 __global__ void k_evb_region(int M, int hyd, double R2, const int* __restrict__ mol_natom, const int* __restrict__ mol_atoms, const double* __restrict__ xyz,
@@ -1585,7 +1637,7 @@ struct EvbWork {   // persistent device scratch of one context
   // diabat enumeration / descriptor construction (evb_plan.hpp): static tables, the region's molecule order, scratch frames of the search
   PlanTables ptab; std::vector<int> region_order; std::vector<PlanFrame> plan_frames; PlanWork plan_work;
   // ... on the device (k_evb_plan): tables, scratch, the summary in pinned memory; solve_desc_dirty: the host-built part of the descriptor block (SolveDesc) has to follow the device-built one
-  DBuf<PlanWork> d_plan_work; DBuf<PlanTables> d_ptab; PlanTables ptab_dev; bool ptab_dev_valid = false; DBuf<int> d_plan_order, d_plan_near, d_plan_cnt; DBuf<CouplingDesc> d_cps_tmp;
+  DBuf<PlanTables> d_ptab; PlanTables ptab_dev; bool ptab_dev_valid = false; DBuf<int> d_plan_order, d_plan_near, d_plan_cnt, d_plan_shell; DBuf<CouplingDesc> d_cps_tmp;
   PlanSummary* h_plan_sum = nullptr; long long seq_P = 0; hipEvent_t ev_plan = nullptr; bool solve_desc_dirty = false, device_plan_off_once = false;
   StepGraph sg[2]; hipEvent_t ev_gjoin[3] = {nullptr, nullptr, nullptr}; DBuf<long long> d_sb; long plan_serial = 0; bool graph_broken = false, graph_skip_once = false;
 };
@@ -1624,7 +1676,7 @@ int fill_plan_tables(const msevb_ctx* c, PlanTables& tb) {
   for (int t = 0; t < MAX_TYPES; ++t) tb.atype_chg[t] = t < (int)c->h_atype_chg.size() ? c->h_atype_chg[t] : 0.0;
   memcpy(tb.e_ref, c->e_ref, sizeof tb.e_ref); memcpy(tb.exch_proton, c->e_exch_proton, sizeof tb.exch_proton);
   tb.n_cp = c->n_cp; memcpy(tb.cp_types, c->cp_types, sizeof tb.cp_types); memcpy(tb.cp_func, c->cp_func, sizeof tb.cp_func); memcpy(tb.cp_par, c->cp_par, sizeof tb.cp_par);
-  for (int d = 0; d < 3; ++d) tb.box[d] = c->box[d];
+  for (int d = 0; d < 3; ++d) { tb.box[d] = c->box[d]; tb.inv_box[d] = 1.0 / c->box[d]; }
   return 0;
 }
 
@@ -1949,7 +2001,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     CHK(upload_evb_tables(c, w));
     PlanTables& tbh = w->ptab;
     if (fill_plan_tables(c, tbh)) FAIL(MSEVB_ERR_LIMIT, "EVB: molecule-type tables exceed the fixed sizes of the enumeration");
-    if (w->d_ptab.alloc(1) || w->d_plan_order.alloc(REGION_CAP) || w->d_plan_near.alloc((size_t)64 * REGION_CAP) || w->d_plan_cnt.alloc(REGION_CAP) || w->d_cps_tmp.alloc(MAX_DIABATS) || w->d_plan_work.alloc(MAX_DIABATS))
+    if (w->d_ptab.alloc(1) || w->d_plan_order.alloc(REGION_CAP) || w->d_plan_near.alloc((size_t)3 * PLAN_MAX_PAIRS * REGION_CAP) || w->d_plan_cnt.alloc(REGION_CAP) || w->d_cps_tmp.alloc(MAX_DIABATS) || w->d_plan_shell.alloc((size_t)65 * REGION_CAP))
       FAIL(MSEVB_ERR_HIP, "hipMalloc failed (device-side plan)");
     if (!w->h_plan_sum) { HIPCHK(hipHostMalloc((void**)&w->h_plan_sum, sizeof(PlanSummary), hipHostMallocDefault)); memset(w->h_plan_sum, 0, sizeof(PlanSummary)); HIPCHK(hipEventCreateWithFlags(&w->ev_plan, hipEventDisableTiming)); }
     if (!w->ptab_dev_valid || memcmp(&w->ptab_dev, &tbh, sizeof tbh) != 0) {      // (rank layout, box or tables changed)
@@ -1968,10 +2020,10 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       PlanArgs pa; memset(&pa, 0, sizeof pa);
       pa.tb = w->d_ptab.p; pa.mol_type = c->d_mol_type.p; pa.mol_natom = c->d_mol_natom.p; pa.mol_atoms = c->d_mol_atoms.p; pa.atype = c->d_atype.p; pa.chg = c->d_chg.p; pa.mass = c->d_mass.p;
       pa.region = w->d_region.p; pa.region_count = w->d_counter.p; pa.region_cap = REGION_CAP; pa.hydronium = c->hydronium;
-      pa.order = w->d_plan_order.p; pa.near_tab = w->d_plan_near.p; pa.near_cnt = w->d_plan_cnt.p;
+      pa.order = w->d_plan_order.p; pa.pair_tab = w->d_plan_near.p; pa.pair_cnt = w->d_plan_cnt.p; pa.near_tab = w->d_plan_shell.p; pa.near_cnt = w->d_plan_shell.p + (size_t)64 * REGION_CAP;
       const size_t reserve = sizeof(SolveDesc) + 16 * (size_t)MAX_UNITS + 64;      // the host-built tail of the block (SolveDesc + unit references) must fit behind what the kernel writes
-      pa.desc = w->d_desc.p; pa.desc_cap = w->desc_cap - reserve; pa.cps_tmp = w->d_cps_tmp.p; pa.work = w->d_plan_work.p; pa.plan = w->d_plan.p; pa.out = w->h_plan_sum; pa.seq = ++w->seq_P;
-      hipLaunchKernelGGL(k_evb_plan, dim3(1), dim3(256), 0, s_reg, pa);
+      pa.desc = w->d_desc.p; pa.desc_cap = w->desc_cap - reserve; pa.cps_tmp = w->d_cps_tmp.p; pa.plan = w->d_plan.p; pa.out = w->h_plan_sum; pa.seq = ++w->seq_P;
+      hipLaunchKernelGGL(k_evb_plan, dim3(1), dim3(512), 0, s_reg, pa);
       HIPCHK(hipGetLastError());
       HIPCHK(hipEventRecord(w->ev_plan, s_reg));
       if (spin_wait((volatile long long*)&w->h_plan_sum->seq, w->seq_P, w->ev_plan)) HIPCHK(hipErrorUnknown);
@@ -1984,6 +2036,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     }
     if (ps->err != PE_OK) FAIL(plan_err_code(ps->err), plan_error_text(ps->err));
     c->evb_device_plans++;
+    if (ht_on) fprintf(stderr, "[msevb] k_evb_plan phases (us): order %.1f, pairs %.1f, tree %.1f, descriptors %.1f, couplings + summary %.1f; records %d, diabats %d; last diabat alone %.1f (its first ensure_mol %.1f)\n", (ps->t[1] - ps->t[0]) * 0.01, (ps->t[2] - ps->t[1]) * 0.01, (ps->t[3] - ps->t[2]) * 0.01, (ps->t[4] - ps->t[3]) * 0.01, (ps->t[5] - ps->t[4]) * 0.01, ps->n_region, ps->D, ps->t[6] * 0.01, ps->t[7] * 0.01);
     if (!ps->fits) w->device_plan_off_once = true;      // a tree too large for the fixed tables of the speculative step: this call goes the host's way (no plan, no speculation)
     else {
       // what the speculative calls start from (remember_plan's part): the tree, unit / grid / coupling indices, host-side mirrors of the descriptor counts
@@ -2005,6 +2058,10 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       w->plan.hyd = c->hydronium; w->plan.n_units = ps->nu; w->plan.n_cps = ps->ncp; w->plan.n_ras = ps->nra; w->plan.n_donors = ps->n_donors;
       w->plan_valid = true; w->plan_fits = true; w->plan_epoch = c->topo_epoch; w->plan_serial++;
       w->solve_desc_dirty = true;
+      // nothing of this attempt is in flight except the neighbourhood kernel, whose record counter nobody has re-armed: zero it on that kernel's stream (the repeated call's
+      // kernel follows there) - no "previous call failed half-way" clean-up with its stream synchronisation
+      HIPCHK(hipMemsetAsync(w->d_counter.p, 0, sizeof(int), s_reg));
+      rearm.ok = true;
       return MSEVB_RETRY;      // the same call again, from the recorded tree (its check passes: the positions are the ones the tree was made from)
     }
   }
@@ -2694,7 +2751,7 @@ void evb_release(msevb_ctx* c) {
     if (w->h_flag) (void)hipHostFree(w->h_flag);
     for (auto& g : w->sg) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : w->ev_gjoin) if (e) (void)hipEventDestroy(e);
-    w->d_sb.release(); w->d_ptab.release(); w->d_plan_order.release(); w->d_plan_near.release(); w->d_plan_cnt.release(); w->d_cps_tmp.release(); w->d_plan_work.release();
+    w->d_sb.release(); w->d_ptab.release(); w->d_plan_order.release(); w->d_plan_near.release(); w->d_plan_cnt.release(); w->d_cps_tmp.release(); w->d_plan_shell.release();
     if (w->h_plan_sum) (void)hipHostFree(w->h_plan_sum);
     if (w->ev_plan) (void)hipEventDestroy(w->ev_plan);
     w->d_coef.release(); w->d_plan.release(); w->d_sphere.release(); w->d_check.release(); w->d_refresh_scratch.release(); w->d_chain_done.release();

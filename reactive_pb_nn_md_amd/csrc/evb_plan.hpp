@@ -15,7 +15,7 @@
 #define PLAN_HD __host__ __device__ inline
 
 enum PlanErr { PE_OK = 0, PE_DONOR_OUTSIDE, PE_SHELL_FULL, PE_MAX_STATES, PE_HOP_OUTSIDE, PE_ACCEPTOR_LARGE, PE_NO_CONJUGATE, PE_REORDER, PE_NO_HEAVY, PE_NO_COUPLING_INDEX, PE_SPEC_FULL,
-               PE_HYD_OUTSIDE, PE_CHAIN_FULL, PE_NOT_IN_TOPOLOGY, PE_STAGING, PE_REGION_FULL, PE_DESC_ROOM };
+               PE_HYD_OUTSIDE, PE_CHAIN_FULL, PE_NOT_IN_TOPOLOGY, PE_STAGING, PE_REGION_FULL, PE_DESC_ROOM, PE_PAIRS_FULL };
 inline const char* plan_error_text(int e) {
   switch (e) {
     case PE_DONOR_OUTSIDE: return "EVB: donor outside the gathered neighbourhood";
@@ -34,6 +34,7 @@ inline const char* plan_error_text(int e) {
     case PE_STAGING: return "EVB descriptor staging too small";
     case PE_REGION_FULL: return "EVB neighbourhood buffer too small";
     case PE_DESC_ROOM: return "EVB: descriptor buffer too small for the device-side plan";
+    case PE_PAIRS_FULL: return "EVB: more than 32 reactive pairs around one donor molecule";
     default: return "EVB plan: unknown error";
   }
 }
@@ -47,7 +48,7 @@ struct PlanTables {
   double atype_chg[MAX_TYPES], e_ref[MAX_MOLTYPES], exch_proton[MAX_MOLTYPES][MAX_MOLTYPES];
   int n_cp, cp_types[MAX_INTERACTION][3], cp_func[MAX_INTERACTION];
   double cp_par[MAX_INTERACTION][10];
-  double box[3];
+  double box[3], inv_box[3];      // inv_box = 1 / box, rounded once on the host (the same bits the division in the loop gave)
 };
 // what a call works on: the principal topology (arrays of the context) and the neighbourhood record of the hydronium, addressed in ascending molecule order
 struct PlanEnv {
@@ -55,9 +56,10 @@ struct PlanEnv {
   const int* mol_type; const int* mol_natom; const int* mol_atoms; const int* atype; const double* chg; const double* mass;
   const RegionRec* rec; const int* order; int n_region;      // rec[order[k]].mol ascending in k
   int hydronium;
-  // device: the first solvation shells of ALL record molecules, made by the whole workgroup before one thread walks the tree (near_cnt[a] molecules near_tab[64 a ..], sorted
-  // indices, ascending; near_cnt > 64 = overflow).  nullptr: plan_enumerate scans the record itself (host)
-  const int* near_tab; const int* near_cnt;
+  // device only (nullptr on the host): fast copies of the records' molecule ids and centres of mass in molecule order (LDS), and the reactive pairs of ALL record
+  // molecules, tabulated by the whole workgroup before one thread walks the tree: pair_cnt[a] pairs {proton, acceptor molecule, basic atom} at pair_tab[3 PLAN_MAX_PAIRS a ..],
+  // pair_cnt[a] < 0: - error code of plan_donor_pairs (raised only if the search expands that molecule)
+  const int* sorted_mol; const double* sorted_com; const int* pair_tab; const int* pair_cnt;
 };
 
 struct PMol { int id, type, natom; int atoms[MAX_MOL_ATOMS]; double com[3]; };
@@ -72,17 +74,21 @@ struct PTopo {      // the molecules touched so far by a hop chain, in the topol
 struct PWhere { int n; int key[MAX_SPEC], val[MAX_SPEC]; PLAN_HD int at(int a) const { for (int i = 0; i < n; ++i) if (key[i] == a) return val[i]; return -1; } };
 struct PlanWork { PTopo P, T; PWhere where; };      // work space of one diabat's construction (device: global memory, one per thread - not 5 KB of private memory per lane)
 
-PLAN_HD void plan_pbc_shift(const PlanTables* tb, const double* ri, const double* rj, double* sh) { for (int d = 0; d < 3; ++d) sh[d] = floor((rj[d] - ri[d]) * (1.0 / tb->box[d]) + 0.5) * tb->box[d]; }
+PLAN_HD void plan_pbc_shift(const PlanTables* tb, const double* ri, const double* rj, double* sh) { for (int d = 0; d < 3; ++d) sh[d] = floor((rj[d] - ri[d]) * tb->inv_box[d] + 0.5) * tb->box[d]; }
 PLAN_HD int plan_find_region_index(const PlanEnv& E, int mol) {      // position in the molecule order, -1: not in the record
   int lo = 0, hi = E.n_region;
+  if (E.sorted_mol) {
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (E.sorted_mol[mid] < mol) lo = mid + 1; else hi = mid; }
+    return (lo < E.n_region && E.sorted_mol[lo] == mol) ? lo : -1;
+  }
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (E.rec[E.order[mid]].mol < mol) lo = mid + 1; else hi = mid; }
   return (lo < E.n_region && E.rec[E.order[lo]].mol == mol) ? lo : -1;
 }
 PLAN_HD const RegionRec* plan_find_region(const PlanEnv& E, int mol) { const int k = plan_find_region_index(E, mol); return k < 0 ? nullptr : &E.rec[E.order[k]]; }
 // is molecule j (record rj) in the first solvation shell of molecule i (record ri)?  evb_first_solvation_cutoff = 5 (src/glob_v.f90:54); sh = the periodic shift used
-PLAN_HD bool plan_in_shell(const PlanTables* tb, const RegionRec& ri, const RegionRec& rj, double* sh) {
-  double dc[3]; plan_pbc_shift(tb, ri.com, rj.com, sh);
-  for (int d = 0; d < 3; ++d) dc[d] = rj.com[d] - ri.com[d] - sh[d];
+PLAN_HD bool plan_in_shell(const PlanTables* tb, const double* ci, const double* cj, double* sh) {
+  double dc[3]; plan_pbc_shift(tb, ci, cj, sh);
+  for (int d = 0; d < 3; ++d) dc[d] = cj[d] - ci[d] - sh[d];
   return !(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2] >= 25.0);
 }
 PLAN_HD int plan_ensure_mol(const PlanEnv& E, PTopo& t, int m, int* err) {      // index in t.mols, -1: molecule outside the record (err untouched), -2: container full
@@ -177,8 +183,8 @@ PLAN_HD void plan_zero(void* p, size_t n) {      // (descriptors are multiples o
   if ((((size_t)p | n) & 7) == 0) { unsigned long long* w = (unsigned long long*)p; for (size_t k = 0; k < n / 8; ++k) w[k] = 0ull; }
   else { unsigned char* b = (unsigned char*)p; for (size_t k = 0; k < n; ++k) b[k] = 0; }
 }
-PLAN_HD int plan_make_unit(const PlanEnv& E, const PTopo& t, int donor, int acceptor, double sign, int slot, int do_rs, int do_rep, UnitDesc& u, PWhere& where) {
-  plan_zero(&u, sizeof(u));
+PLAN_HD int plan_make_unit(const PlanEnv& E, const PTopo& t, int donor, int acceptor, double sign, int slot, int do_rs, int do_rep, UnitDesc& u, PWhere& where, bool zeroed = false) {
+  if (!zeroed) plan_zero(&u, sizeof(u));      // (device: the whole descriptor block was zero-filled by the workgroup - 270 eight-byte stores from ONE lane cost 27 us per descriptor)
   u.sign = sign; u.slot = slot; u.do_rs = do_rs; u.do_rep = do_rep; u.donor = donor; u.acceptor = acceptor; u.hyd = t.hydronium;
   plan_fill_spec(t, u.spec, u.mols, u.n_spec, u.n_mols, where);
   for (int im = 0; im < t.n_mols; ++im) {
@@ -204,9 +210,52 @@ PLAN_HD int plan_diag_slot(const PlanTables* tb, int D, int d) { return d == 0 ?
 PLAN_HD bool plan_owned(const PlanTables* tb, int d) { return d == 0 || ((d - 1) % tb->n_ranks) == tb->rank; }
 
 // ---- enumeration ----------------------------------------------------------------------------------------------------------------------------
-struct PlanFrame {      // one level of evb_conduct_proton_transfer_recursive: the donor, the diabat it was reached in, its first solvation shell, and how far the loops have got
-  int mol, diabat, count, dq, dnew, n_near, ia, q, ja, ready;
-  int near_k[64]; double near_sh[64][3];
+constexpr int PLAN_MAX_PAIRS = 32;
+// find_evb_reactive_neighbors (src/ms_evb.f90:702-764) for EVERY reactive proton of the record molecule at position a of the molecule order: the pairs
+// {proton ia, acceptor molecule, basic atom ja} within evb_reactive_pair_distance, acceptors from the first solvation shell (centres of mass within
+// evb_first_solvation_cutoff), in the reference's loop order (protons in atom order, molecules ascending, basic atoms in atom order).
+// the first solvation shell of the record molecule at position a of the molecule order: positions (ascending) of the molecules whose centre of mass lies within
+// evb_first_solvation_cutoff = 5 A (src/glob_v.f90:54); returns their number (more than 64: the reference's own limit, only the first 64 are stored)
+PLAN_HD int plan_shell(const PlanEnv& E, int a, int* near) {
+  const double* ci = E.sorted_com ? E.sorted_com + 3 * a : E.rec[E.order[a]].com;
+  int n = 0;
+  for (int k = 0; k < E.n_region; ++k) {
+    if (k == a) continue;
+    const double* cj = E.sorted_com ? E.sorted_com + 3 * k : E.rec[E.order[k]].com;
+    double sh[3];
+    if (!plan_in_shell(E.tb, ci, cj, sh)) continue;
+    if (n < 64) near[n] = k;
+    ++n;
+  }
+  return n;
+}
+PLAN_HD int plan_donor_pairs(const PlanEnv& E, int a, const int* near, int n_near, int (*pairs)[3], int* n_out) {
+  const PlanTables* tb = E.tb;
+  if (n_near > 64) return PE_SHELL_FULL;
+  const RegionRec& ri = E.rec[E.order[a]];
+  const int mt = E.mol_type[ri.mol], na = E.mol_natom[ri.mol];
+  int n = 0;
+  for (int ia = 0; ia < na; ++ia) {
+    if (tb->reactive_p[mt][ia] != 1) continue;
+    for (int q = 0; q < n_near; ++q) {      // ascending molecule index == the reference's j_mole loop
+      const RegionRec& rj = E.rec[E.order[near[q]]];
+      double sh[3]; plan_pbc_shift(tb, ri.com, rj.com, sh);
+      const int mj = E.mol_type[rj.mol];
+      for (int ja = 0; ja < rj.natom; ++ja) {
+        if (tb->reactive_b[mj][ja] != 1) continue;
+        double r[3]; for (int d = 0; d < 3; ++d) r[d] = rj.x[ja][d] - ri.x[ia][d] - sh[d];
+        if (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] >= 6.25) continue;           // evb_reactive_pair_distance = 2.5 (src/glob_v.f90:55)
+        if (n >= PLAN_MAX_PAIRS) return PE_PAIRS_FULL;
+        pairs[n][0] = ia; pairs[n][1] = rj.mol; pairs[n][2] = ja; ++n;
+      }
+    }
+  }
+  *n_out = n;
+  return PE_OK;
+}
+struct PlanFrame {      // one level of evb_conduct_proton_transfer_recursive: the donor, the diabat it was reached in, its reactive pairs, and how far the loop over them has got
+  int mol, diabat, count, dq, dnew, n_pairs, ip, ready;
+  int pairs[PLAN_MAX_PAIRS][3];
 };
 // st: MAX_CHAIN + 2 frames of scratch.  plog / parent / D: the tree; plan: donors and pairs of the speculative step's tree check (fits: everything fitted its fixed tables)
 PLAN_HD int plan_enumerate(const PlanEnv& E, PlanFrame* st, int (*plog)[MAX_CHAIN][5], int* parent, int* D_out, SpecPlan& plan, int* fits) {
@@ -216,66 +265,41 @@ PLAN_HD int plan_enumerate(const PlanEnv& E, PlanFrame* st, int (*plog)[MAX_CHAI
   st[sp].mol = E.hydronium; st[sp].diabat = 0; st[sp].ready = 0; ++sp;
   while (sp > 0) {
     PlanFrame& f = st[sp - 1];
-    const RegionRec* ri = nullptr;
     if (!f.ready) {
       int count = 0;
       for (int h = 0; h < tb->max_chain; ++h) { if (plog[f.diabat][h][0] < 0) break; count++; }
       if (count >= tb->max_chain) { --sp; continue; }
-      ri = plan_find_region(E, f.mol);
-      if (!ri) return PE_DONOR_OUTSIDE;
+      const int a = plan_find_region_index(E, f.mol);
+      if (a < 0) return PE_DONOR_OUTSIDE;
       f.count = count; f.dq = -1; f.dnew = 0;      // this molecule's entry among the expanded donors of the plan (its pairs are recorded once)
       for (int q = 0; q < plan.n_donors; ++q) if (plan.donor_mol[q] == f.mol) f.dq = q;
       if (f.dq < 0) { if (plan.n_donors < SPEC_MAX_DONORS) { f.dq = plan.n_donors++; plan.donor_mol[f.dq] = f.mol; plan.donor_np[f.dq] = 0; f.dnew = 1; } else *fits = 0; }
-      // molecules of the donor's first solvation shell, once per donor (not once per proton), in ascending molecule index
-      f.n_near = 0;
-      if (E.near_cnt) {      // the shell was tabulated (same predicate, same order)
-        const int a = plan_find_region_index(E, f.mol), cnt = E.near_cnt[a];
-        if (cnt > 64) return PE_SHELL_FULL;
-        for (int q = 0; q < cnt; ++q) { const int k = E.near_tab[64 * a + q]; double sh[3]; (void)plan_in_shell(tb, *ri, E.rec[E.order[k]], sh); f.near_k[q] = k; for (int d = 0; d < 3; ++d) f.near_sh[q][d] = sh[d]; }
-        f.n_near = cnt;
-      } else
-      for (int k = 0; k < E.n_region; ++k) {
-        const RegionRec& rj = E.rec[E.order[k]];
-        if (rj.mol == f.mol) continue;
-        double sh[3];
-        if (!plan_in_shell(tb, *ri, rj, sh)) continue;
-        if (f.n_near >= 64) return PE_SHELL_FULL;
-        f.near_k[f.n_near] = k; for (int d = 0; d < 3; ++d) f.near_sh[f.n_near][d] = sh[d];
-        ++f.n_near;
-      }
-      f.ia = 0; f.q = 0; f.ja = 0; f.ready = 1;
-    } else ri = plan_find_region(E, f.mol);
-    const int mt = E.mol_type[f.mol], na = E.mol_natom[f.mol];
+      if (E.pair_cnt) {      // tabulated (device)
+        const int cnt = E.pair_cnt[a];
+        if (cnt < 0) return -cnt;
+        for (int q = 0; q < cnt; ++q) for (int z = 0; z < 3; ++z) f.pairs[q][z] = E.pair_tab[3 * (PLAN_MAX_PAIRS * a + q) + z];
+        f.n_pairs = cnt;
+      } else { int near[64]; const int nn = plan_shell(E, a, near); const int pe = plan_donor_pairs(E, a, near, nn, f.pairs, &f.n_pairs); if (pe) return pe; }
+      f.ip = 0; f.ready = 1;
+    }
+    const int mt = E.mol_type[f.mol];
     bool pushed = false;
-    for (; f.ia < na && !pushed; ++f.ia, f.q = 0, f.ja = 0) {
-      if (tb->reactive_p[mt][f.ia] != 1) continue;
-      for (; f.q < f.n_near && !pushed; ++f.q, f.ja = 0) {      // ascending molecule index == the reference's j_mole loop
-        const RegionRec& rj = E.rec[E.order[f.near_k[f.q]]];
-        const double* sh = f.near_sh[f.q];
-        const int mj = E.mol_type[rj.mol];
-        for (; f.ja < rj.natom; ++f.ja) {
-          const int ia = f.ia, ja = f.ja;
-          if (tb->reactive_b[mj][ja] != 1) continue;
-          double r[3]; for (int d = 0; d < 3; ++d) r[d] = rj.x[ja][d] - ri->x[ia][d] - sh[d];
-          if (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] >= 6.25) continue;           // evb_reactive_pair_distance = 2.5 (src/glob_v.f90:55)
-          if (f.dnew) { if (plan.donor_np[f.dq] < SPEC_MAX_PAIRS) { int* pp = plan.donor_pair[f.dq][plan.donor_np[f.dq]++]; pp[0] = ia; pp[1] = rj.mol; pp[2] = ja; plan.n_pairs_total++; } else *fits = 0; }
-          if (D >= MAX_DIABATS) return PE_MAX_STATES;
-          const int d = D++;
-          parent[d] = f.diabat;
-          for (int h = 0; h < f.count; ++h) for (int q5 = 0; q5 < 5; ++q5) plog[d][h][q5] = plog[f.diabat][h][q5];
-          int heavy = -1;
-          for (int b = 0; b < tb->mt_nbond[mt]; ++b) { if (tb->mt_bond[mt][b][0] == ia) heavy = tb->mt_bond[mt][b][1]; else if (tb->mt_bond[mt][b][1] == ia) heavy = tb->mt_bond[mt][b][0]; }
-          plog[d][f.count][0] = f.mol; plog[d][f.count][1] = ia; plog[d][f.count][2] = heavy; plog[d][f.count][3] = rj.mol; plog[d][f.count][4] = ja;
-          if (rj.mol != E.hydronium) {      // descend; the loops of this level go on behind the pair just taken
-            ++f.ja;
-            st[sp].mol = rj.mol; st[sp].diabat = d; st[sp].ready = 0; ++sp;
-            pushed = true;
-            break;
-          }
-        }
-        if (pushed) break;
+    while (f.ip < f.n_pairs) {
+      const int ia = f.pairs[f.ip][0], mj = f.pairs[f.ip][1], ja = f.pairs[f.ip][2];
+      ++f.ip;
+      if (f.dnew) { if (plan.donor_np[f.dq] < SPEC_MAX_PAIRS) { int* pp = plan.donor_pair[f.dq][plan.donor_np[f.dq]++]; pp[0] = ia; pp[1] = mj; pp[2] = ja; plan.n_pairs_total++; } else *fits = 0; }
+      if (D >= MAX_DIABATS) return PE_MAX_STATES;
+      const int d = D++;
+      parent[d] = f.diabat;
+      for (int h = 0; h < f.count; ++h) for (int q5 = 0; q5 < 5; ++q5) plog[d][h][q5] = plog[f.diabat][h][q5];
+      int heavy = -1;
+      for (int b = 0; b < tb->mt_nbond[mt]; ++b) { if (tb->mt_bond[mt][b][0] == ia) heavy = tb->mt_bond[mt][b][1]; else if (tb->mt_bond[mt][b][1] == ia) heavy = tb->mt_bond[mt][b][0]; }
+      plog[d][f.count][0] = f.mol; plog[d][f.count][1] = ia; plog[d][f.count][2] = heavy; plog[d][f.count][3] = mj; plog[d][f.count][4] = ja;
+      if (mj != E.hydronium) {      // descend; this level's loop goes on behind the pair just taken (a transfer onto the current hydronium ends the branch, flag_cycle :573)
+        st[sp].mol = mj; st[sp].diabat = d; st[sp].ready = 0; ++sp;
+        pushed = true;
+        break;
       }
-      if (pushed) break;
     }
     if (!pushed) --sp;
   }
@@ -304,7 +328,7 @@ PLAN_HD int plan_chain_atoms(const PlanEnv& E, int d, const int (*plog)[MAX_CHAI
 // W.P: the principal topology with the hydronium in it (plan_ensure_mol); W.T, W.where: scratch.  Writes units[u0 .. u0 + 2 nhop), ras[r0 ..) (returns their number in *n_ras), the coupling cp
 // (slot, geometry, parameters), the plan's unit_d / unit_k / mw_atoms / mw_n of this diabat, and the reference-energy difference.
 PLAN_HD int plan_build_diabat(const PlanEnv& E, PlanWork& W, int d, int D, const int (*plog)[MAX_CHAIN][5], UnitDesc* units, int u0, RecipAtom* ras, int r0, int grid, CouplingDesc& cp,
-                              SpecPlan& plan, double* eref_delta, int* n_ras, int* nhop_out) {
+                              SpecPlan& plan, double* eref_delta, int* n_ras, int* nhop_out, bool zeroed = false) {
   const PlanTables* tb = E.tb;
   PTopo& T = W.T; PWhere& where = W.where;
   T = W.P;
@@ -318,10 +342,10 @@ PLAN_HD int plan_build_diabat(const PlanEnv& E, PlanWork& W, int d, int D, const
     md = T.hydronium; ma = plog[d][h][3];
     if (plan_ensure_mol(E, T, md, &err) < 0 || plan_ensure_mol(E, T, ma, &err) < 0) return err != PE_OK ? err : PE_HOP_OUTSIDE;
     if (iu + 1 >= MAX_UNITS) return PE_STAGING;
-    { const int rc = plan_make_unit(E, T, md, ma, -1.0, slot, 1, 0, units[iu], where); if (rc) return rc; plan.unit_d[iu] = d; plan.unit_k[iu] = h; ++iu; }
+    { const int rc = plan_make_unit(E, T, md, ma, -1.0, slot, 1, 0, units[iu], where, zeroed); if (rc) return rc; plan.unit_d[iu] = d; plan.unit_k[iu] = h; ++iu; }
     int typ_old = -1; for (int k = 0; k < T.n_mols; ++k) if (T.mols[k].id == T.hydronium) typ_old = T.mols[k].type;
     { const int rc = plan_apply_hop(E, T, md, plog[d][h][1], ma, plog[d][h][4], plan.mw_atoms[d][h], &plan.mw_n[d][h]); if (rc) return rc; }
-    { const int rc = plan_make_unit(E, T, md, ma, +1.0, slot, 1, h == nhop - 1 ? 1 : 0, units[iu], where); if (rc) return rc; plan.unit_d[iu] = d; plan.unit_k[iu] = h + 1; ++iu; }
+    { const int rc = plan_make_unit(E, T, md, ma, +1.0, slot, 1, h == nhop - 1 ? 1 : 0, units[iu], where, zeroed); if (rc) return rc; plan.unit_d[iu] = d; plan.unit_k[iu] = h + 1; ++iu; }
     int typ_new = -1; for (int k = 0; k < T.n_mols; ++k) if (T.mols[k].id == T.hydronium) typ_new = T.mols[k].type;
     er += tb->e_ref[typ_new] - tb->e_ref[typ_old];
   }
@@ -336,7 +360,7 @@ PLAN_HD int plan_build_diabat(const PlanEnv& E, PlanWork& W, int d, int D, const
   }
   *n_ras = nr;
   // off-diagonal element with the parent diabat, in this (acceptor) topology (evb_diabatic_coupling, :1021)
-  plan_zero(&cp, sizeof(cp));
+  if (!zeroed) plan_zero(&cp, sizeof(cp));
   cp.slot = plan_off_slot(tb, D, d);
   plan_fill_spec(T, cp.spec, cp.mols, cp.n_spec, cp.n_mols, where);
   const PMol *Dm = nullptr, *Am = nullptr;

@@ -588,6 +588,43 @@ def test_md_trajectory_across_rebuilds_against_reference(name, evb):
     h.close()
 
 
+def test_long_trajectory_to_the_references_own_stop():
+    """tests/golden/long_evb_n12_liquid_s40 (oracle/make_collapse_trace.py): the REAL reference on a liquid-like 12^3-site box, 4 planted diabats, 300 K start -
+    it runs 319 steps and then STOPS ITSELF ('force on atom 2568 is too big', src/md_integration.f90:523): the diabat tree dissolves (D = 4 -> 5 -> 1 around
+    step 305) and the acid proton, which has no Lennard-Jones wall outside the EVB complex, falls onto an oxygen of its own molecule (|F|max 470 -> 4 000
+    kJ/mol/A within six steps).  The same collapse ends bench.py's box after ~ 300 steps: it is the force field's, not the library's.
+    Here the GPU path walks the reference's history step by step - potential and kinetic energy, Verlet flag, diabat count, largest force - up to the
+    collapse and then ends the run the way the reference does."""
+    g = golden("long_evb_n12_liquid_s40")
+    s = synth.make_system(int(g["gen_n_side"]), n_diabat=int(g["gen_n_diabat"]), seed=int(g["gen_seed"]), liquid_like=True)
+    assert np.array_equal(s.xyz, g["gen_xyz"])
+    p = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"])
+    spec = system.from_synth(s, p, rc=float(g["rc"]), rv=float(g["rv"]), pme_grid=int(g["pme_grid"]), nslist=int(g["nslist"]))
+    assert not bool(g["reference_finished"]) and "is too big" in str(g["reference_last_output"])
+    h = api.MsEvbHip(spec)
+    h.set_velocities(g["md_velocity0"])
+    h.ms_evb_calculate_total_force_energy(want_force=False)
+    n = len(g["trace_step"])
+    worst = 0.0
+    for k in range(n):
+        en = h.md_integrate_atomic(1, spec.delta_t, use_evb=True)
+        tol = 1e-9 if k < 100 else 1e-7 if k < 250 else 1e-5      # (fp64 atomics sum in another order than the reference's loops: the difference grows with the trajectory's own instability)
+        de = abs(en[0, 0] - g["trace_epot"][k]) / abs(g["trace_epot"][k])
+        dk = abs(en[0, 1] - g["trace_ekin"][k]) / abs(g["trace_ekin"][k])
+        worst = max(worst, de / tol, dk / tol)
+        assert de < tol and dk < tol, (k, de, dk)
+        assert h.verlet_flag() == g["trace_verlet_flag"][k], k
+        assert h.evb_state()["D"] == g["trace_n_diabat"][k], k
+        fmax = np.sqrt((h.get_forces() ** 2).sum(1).max())
+        assert abs(fmax - g["trace_fmax"][k]) < (1e-6 if k < 250 else 1e-3) * g["trace_fmax"][k], (k, fmax, g["trace_fmax"][k])
+    assert g["trace_fmax"][-1] > 5 * g["trace_fmax"][-8] and g["trace_n_diabat"][-1] == 1      # the fixture ends in the collapse
+    with pytest.raises(api.MsevbError, match="too big|not finite"):      # ... and so does the run: the reference stopped in its step 320
+        for _k in range(4):
+            h.md_integrate_atomic(1, spec.delta_t, use_evb=True)
+    assert h.info("host_dfs_calls") == 0
+    h.close()
+
+
 @pytest.mark.parametrize("n_ranks", [2, 3, 8])
 def test_diabat_sharding_is_a_partition(n_ranks):
     """virtual ranks: every Hamiltonian element is produced by exactly one rank and equals the single-rank result, and the ranks'

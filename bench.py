@@ -72,8 +72,9 @@ def cpu_baseline(spec, steps_per_rebuild):
       * thread sweep of the principal-diabat force call (calculate_total_force_energy restatement) - the oracle keeps the reference's
         OpenMP structure (per-thread force replicas summed serially, src/pair_int_real_space.f90:146-147,:319-327; serial spread), so it
         stops scaling long before the host runs out of cores; the best thread count is used for the rest;
-      * value: the reference's delta-update step assembled from timed oracle stages (principal force call + (D - 1) reciprocal-space passes);
-      * from_scratch_steps_per_s: FULL EVB steps of the oracle's own formulation (every diabat from scratch in its own topology - more work than
+      * value: TIMED velocity-Verlet steps of the reference's delta-update formulation (orc_evb_force_energy_delta: principal diabat in full, every further
+        diabat as the change of its donor / acceptor molecules + one reciprocal-space pass of its own - src/ms_evb.f90:1421-1560, :1962-2090);
+      * from_scratch_steps_per_s: a step of the oracle's other formulation (every diabat from scratch in its own topology - more work than
         the reference's delta update: a lower bound of CPU steps/s); principal_only_steps_per_s: an upper bound.  The Verlet build is amortised
         over the bench's own rebuild interval."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -101,31 +102,33 @@ def cpu_baseline(spec, steps_per_rebuild):
             best = (th, dt)
     th = best[0]
     o.L.orc_set_threads(o.h, th)
-    # what the REFERENCE does per step (src/ms_evb.f90:375-470): the principal diabat's full force call, then per further diabat a DELTA update - the
-    # donor / acceptor molecules against their surroundings (a few dozen atoms: left out here) and one reciprocal-space pass of its own
-    # (modify_Q_grid, transform, convolution, back-transform, force update over all atoms: calculate_reciprocal_space_pme, :1962-2090), which is what
-    # the oracle's orc_pme_recip costs.  Timed: total() and pme() at the best thread count, three calls each, the fastest taken.
+    # what the REFERENCE does per step (src/ms_evb.f90:375-470): the principal diabat's full force call, then per further diabat a DELTA update - the donor /
+    # acceptor molecules against all atoms in both topologies, their stencils on a copy of the principal charge grid (modify_Q_grid), and one reciprocal-space pass of
+    # its own (transform, convolution, back-transform, force update over all atoms: calculate_reciprocal_space_pme, :1962-2090).  The oracle has that formulation
+    # (orc_evb_force_energy_delta, pinned against the real reference's Hamiltonians and force stores in tests/test_oracle_vs_reference.py) and it is TIMED here,
+    # whole velocity-Verlet steps of it, not assembled from stages.
     t_tot = min(_timeit(o.total) for _k in range(3))
-    t_pme = min(_timeit(o.pme) for _k in range(3))
     vel = synth.maxwell_boltzmann(spec.mass, 300.0, 12345)
-    F = o.evb()["F"].copy()
+    F = o.evb(delta=True)["F"].copy()
     D = o.n_diabat()
     n_evb, t0 = 0, time.time()
-    while n_evb < 1 or (time.time() - t0 < 8.0 and n_evb < 2):
-        o.md_step(vel, F, spec.delta_t, True)
+    while n_evb < 3 or (time.time() - t0 < 12.0 and n_evb < 12):
+        o.md_step(vel, F, spec.delta_t, 2)      # evb = 2: the delta-update formulation
         n_evb += 1
     t_evb = (time.time() - t0) / n_evb
-    t_delta = t_tot + (D - 1) * t_pme + t_list / max(steps_per_rebuild, 1.0)
-    t_scratch = t_evb + t_list / max(steps_per_rebuild, 1.0)
+    t_delta = t_evb + t_list / max(steps_per_rebuild, 1.0)
+    t0 = time.time()
+    o.md_step(vel, F, spec.delta_t, 1)      # one step of the from-scratch formulation (every diabat in its own topology with its own Verlet list), for the record
+    t_scratch = time.time() - t0 + t_list / max(steps_per_rebuild, 1.0)
     return {"value": 1.0 / t_delta, "unit": "steps/s", "cores": th, "kind": "port",
             "sample": "CPU oracle on the same %d-atom box, %d diabats, %d OpenMP threads (%s, %d hardware threads visible, no pinning; fastest of a sweep %s s at %s threads for the "
-                      "principal force call): the reference's DELTA-UPDATE step = principal-diabat force call %.3f s + %d x one reciprocal-space pass per further diabat %.3f s "
-                      "(spread, transforms, convolution, all-atom force update; the donor / acceptor real-space deltas and the couplings touch a few dozen atoms and are left out) "
-                      "+ Verlet build %.2f s amortised over %.0f steps = %.2f s per step.  from_scratch_steps_per_s: %d full MS-EVB steps of the oracle's own formulation "
-                      "(every diabat evaluated from scratch, %.2f s per step) - more work than the reference does.  The oracle keeps the reference's per-thread force replicas "
-                      "with a serial sum and its serial charge spreading, so it stops scaling long before the host runs out of cores"
-                      % (spec.n_atom, D, th, cpu, cores, "/".join("%.2f" % d for _t, d in sweep), "/".join(str(t) for t, _d in sweep), t_tot, D - 1, t_pme, t_list,
-                         steps_per_rebuild, t_delta, n_evb, t_evb),
+                      "principal force call): %d TIMED velocity-Verlet steps of the reference's DELTA-UPDATE formulation (principal-diabat force call %.3f s of it; per further diabat the "
+                      "donor / acceptor real-space and intra-molecular deltas by all-atom scans, modify_Q_grid, one transform pair + convolution and the all-atom reciprocal force "
+                      "update; couplings, Jacobi, Hellmann-Feynman blend, integrator) = %.3f s per step, + Verlet build %.2f s amortised over %.0f steps.  "
+                      "from_scratch_steps_per_s: one step of the oracle's other formulation (every diabat from scratch, %.2f s) - more work than the reference does.  The oracle keeps "
+                      "the reference's per-thread force replicas with a serial sum and its serial charge spreading, so it stops scaling long before the host runs out of cores"
+                      % (spec.n_atom, D, th, cpu, cores, "/".join("%.2f" % d for _t, d in sweep), "/".join(str(t) for t, _d in sweep), n_evb, t_tot, t_evb, t_list,
+                         steps_per_rebuild, t_scratch),
             "from_scratch_steps_per_s": 1.0 / t_scratch,
             "principal_only_steps_per_s": 1.0 / best[1]}
 
@@ -379,6 +382,7 @@ def main():
             "energy_first_last": [float(en[0, 0] + en[0, 1]), float(en[-1, 0] + en[-1, 1])],
             "library_sha256": hashlib.sha256(open(os.path.join(ROOT, "reactive_pb_nn_md_amd", "libmsevb_hip.so"), "rb").read()).hexdigest()[:16],      # which build this line is about
             "options": list(args.opt),
+            "step_graph": {k: int(h.info(k)) for k in ("evb_calls", "spec_steps", "spec_misses", "graph_launches", "graph_captures", "graph_mismatches", "device_plans")},      # MS-EVB calls of the whole run (warm-ups and all blocks): how many went out as four linear graph launches
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(spec, args.steps / max(out["verlet_rebuilds"], 1))

@@ -775,7 +775,7 @@ double orc_md_step(OrcSys* s, double* vel, double* F, double dt, int evb) {
   orc_update_com(s); shift_into_box(s);
   if (s->verlet_flag == 1) { orc_verlet_build(s, s->nslist); orc_verlet_check(s, 1); s->verlet_flag = 0; }
   else s->verlet_flag = orc_verlet_check(s, 0);
-  if (evb) { epot = orc_evb_force_energy_noverlet(s, F); orc_evb_apply_principal(s); } else epot = orc_total(s, E, F);
+  if (evb) { epot = evb == 2 ? orc_evb_force_energy_delta_noverlet(s, F) : orc_evb_force_energy_noverlet(s, F); orc_evb_apply_principal(s); } else epot = orc_total(s, E, F);      /* evb = 2: the reference's delta-update formulation */
   for (int a = 0; a < N; ++a) { if (frozen_atom(s, a)) continue;      /* :512 */
     for (int d = 0; d < 3; ++d) vel[3 * a + d] = vel[3 * a + d] + dt / 2.0 / s->mass[a] * F[3 * a + d] * 100.0; }
   remove_com_momentum(s, vel);

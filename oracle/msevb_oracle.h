@@ -80,6 +80,10 @@ void orc_set_evb(OrcSys*, const int* acid, const int* base, const int* conj_mol,
 /* full EVB force call (src/ms_evb.f90:181): returns adiabatic energy, fills F (principal atom order).
    Every diabat is evaluated FROM SCRATCH in its own topology (independent of the product's delta scheme). */
 double orc_evb_force_energy(OrcSys*, double* F);
+/* the same call in the reference's DELTA-UPDATE formulation (ms_evb_diabat_force_energy, src/ms_evb.f90:1421-1560; calculate_reciprocal_space_pme :1962-2090):
+   principal diabat in full, every further diabat as the change of its donor / acceptor molecules + one reciprocal-space pass of its own.  Same results as
+   orc_evb_force_energy to rounding (tests); what bench.py times as the CPU baseline. */
+double orc_evb_force_energy_delta(OrcSys*, double* F);
 double orc_evb_repulsion_principal(OrcSys*, double* F);      /* src/ms_evb.f90:2259-2478 on the principal topology */
 void orc_evb_rep_switch(double r, double rs, double rc, double* sw, double* dsw);      /* :2484 */
 int  orc_evb_n_diabat(OrcSys*);

@@ -344,6 +344,31 @@ static int jacobi(int n, double* a /*[n][n] row-major, a[i][j]*/, double* d, dou
 double orc_evb_repulsion_principal(OrcSys* s, double* F) { OrcTopo P = orc_principal_topo(s); return evb_repulsion(s, &P, F); }
 void orc_evb_rep_switch(double r, double rs, double rc, double* sw, double* dsw) { rep_switch(r, rs, rc, sw, dsw); }
 
+/* diagonalize_evb_hamiltonian (src/ms_evb.f90:242-351): ground state, Hellmann-Feynman blend of the stored diabat / coupling forces, principal diabat */
+static double evb_diag_blend(OrcSys* s, double* F) {
+  int N = s->N, D = s->D;
+  double *a = malloc(D * D * 8), *v = malloc(D * D * 8), ev[ORC_MAX_DIABATS];
+  for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) { a[i * D + j] = s->H[i][j]; a[j * D + i] = s->H[i][j]; }
+  jacobi(D, a, ev, v);
+  int g = 0; double eg = ev[0];
+  for (int i = 1; i < D; ++i) if (ev[i] < eg) { eg = ev[i]; g = i; }
+  for (int i = 0; i < D; ++i) s->eigvec[i] = v[i * D + g];
+  memset(F, 0, 24 * (size_t)N);
+  for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) {
+    const double* Fs = NULL; double fac;
+    if (i == j) { Fs = s->evb_Fdiag + (size_t)i * 3 * N; fac = s->eigvec[i] * s->eigvec[j]; }
+    else if (s->parent[j] == i) { Fs = s->evb_Foff + (size_t)j * 3 * N; fac = 2.0 * s->eigvec[i] * s->eigvec[j]; }
+    else continue;
+    for (size_t k = 0; k < 3 * (size_t)N; ++k) F[k] = F[k] + fac * Fs[k];
+  }
+  int pr = 0; double sc = fabs(s->eigvec[0]);
+  for (int i = 0; i < D; ++i) if (sc < fabs(s->eigvec[i])) { sc = fabs(s->eigvec[i]); pr = i; }
+  s->principal = pr; s->new_hydronium = s->hydronium;
+  for (int h = 0; h < s->max_chain; ++h) { if (s->plog[pr][h][0] < 0) break; s->new_hydronium = s->plog[pr][h][3]; }
+  free(a); free(v);
+  return eg;
+}
+
 /* ---------------------------------------------------------------- the EVB force call */
 /* construct_evb_hamiltonian (src/ms_evb.f90:375-489) + diagonalize_evb_hamiltonian (:242-351) */
 double orc_evb_force_energy_noverlet(OrcSys* s, double* F) {
@@ -383,31 +408,92 @@ double orc_evb_force_energy_noverlet(OrcSys* s, double* F) {
   }
   memcpy(s->Q, Q1, K3 * 8); memcpy(s->theta, th1, K3 * 8); memcpy(s->force_recip, fr1, 24 * (size_t)N); memcpy(s->xyz_scale, us1, 24 * (size_t)N); s->E_recip = er1;
   free(Q1); free(th1); free(fr1); free(us1);
-  /* diagonalise */
-  double *a = malloc(D * D * 8), *v = malloc(D * D * 8), ev[ORC_MAX_DIABATS];
-  for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) { a[i * D + j] = s->H[i][j]; a[j * D + i] = s->H[i][j]; }
-  jacobi(D, a, ev, v);
-  int g = 0; double eg = ev[0];
-  for (int i = 1; i < D; ++i) if (ev[i] < eg) { eg = ev[i]; g = i; }
-  for (int i = 0; i < D; ++i) s->eigvec[i] = v[i * D + g];
-  memset(F, 0, 24 * (size_t)N);
-  for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) {
-    const double* Fs = NULL; double fac;
-    if (i == j) { Fs = s->evb_Fdiag + (size_t)i * 3 * N; fac = s->eigvec[i] * s->eigvec[j]; }
-    else if (s->parent[j] == i) { Fs = s->evb_Foff + (size_t)j * 3 * N; fac = 2.0 * s->eigvec[i] * s->eigvec[j]; }
-    else continue;
-    for (size_t k = 0; k < 3 * (size_t)N; ++k) F[k] = F[k] + fac * Fs[k];
-  }
-  int pr = 0; double sc = fabs(s->eigvec[0]);
-  for (int i = 0; i < D; ++i) if (sc < fabs(s->eigvec[i])) { sc = fabs(s->eigvec[i]); pr = i; }
-  s->principal = pr; s->new_hydronium = s->hydronium;
-  for (int h = 0; h < s->max_chain; ++h) { if (s->plog[pr][h][0] < 0) break; s->new_hydronium = s->plog[pr][h][3]; }
-  free(a); free(v);
-  return eg;
+  return evb_diag_blend(s, F);
 }
 double orc_evb_force_energy(OrcSys* s, double* F) {
   if (s->verlet_flag == 1 || !s->neighbor_list) { orc_verlet_build(s, s->nslist); orc_verlet_check(s, 1); s->verlet_flag = 0; }
   return orc_evb_force_energy_noverlet(s, F);
+}
+/* The same call in the reference's DELTA-UPDATE formulation (ms_evb_diabat_force_energy, src/ms_evb.f90:1421-1560, with its real-space part
+   ms_evb_diabat_force_energy_update_real_space :1566-1860 and the per-diabat reciprocal space calculate_reciprocal_space_pme :1962-2090): a diabat's
+   energy and force START from the principal diabat's.  The molecules the hops of its chain changed (every donor / acceptor) are taken out in the
+   principal topology and put back in the diabat's own: their intra-molecular terms, their real-space pairs with ALL atoms inside the cutoff (one
+   all-atom scan per changed atom - no Verlet list, :1629-1732), their stencils on a copy of the principal charge grid (modify_Q_grid, src/pme.f90:275);
+   then ONE reciprocal-space pass per diabat on the patched grid - transform, convolution, back-transform, force update of ALL atoms.  The reference
+   walks the chain hop by hop; the intermediate topologies cancel, so this takes principal -> diabat d in one step (same scans, same grid, same sums).
+   Two users: the delta-vs-full known-answer test (tests/test_oracle_vs_reference.py: equal to orc_evb_force_energy, which evaluates every diabat from
+   scratch) and bench.py's timed CPU baseline (what the reference does per MD step). */
+static void evb_changed_terms(const OrcSys* s, const OrcTopo* X, int nchg, const int* mols, double sign, double* e_acc, double* Fd, double* Ftmp,
+                              unsigned char* screen, double* Q, const double kk[3][3], OrcScratch* w) {
+  int N = s->N;
+  memset(Ftmp, 0, 24 * (size_t)N);
+  memset(screen, 1, (size_t)N);
+  double e_el = 0.0, e_vdw = 0.0, eb = 0.0, ea = 0.0, ed = 0.0;
+  for (int k = 0; k < nchg; ++k) {
+    int m = mols[k], n = X->mol_natom[m]; const int* at = &X->mol_atoms[m * ORC_MAX_MOL_ATOMS];
+    for (int q = 0; q < n; ++q) screen[at[q]] = 0;      /* own molecule (intra-molecular terms below) and the changed molecules already done (pairs count once) */
+    for (int q = 0; q < n; ++q) orc_atom_vs_list(s, X, at[q], N, NULL, screen, &e_el, &e_vdw, Ftmp, w);
+    if (n > 1) orc_intra_nb_mol(s, X, m, &e_el, &e_vdw, Ftmp);
+    { double b, a, d; orc_bonded_mol(s, X, m, &b, &a, &d, Ftmp); eb = eb + b; ea = ea + a; ed = ed + d; }
+    for (int q = 0; q < n; ++q) { double u[3]; orc_scaled_coords(kk, s->K, 1, &X->xyz[3 * at[q]], u); orc_spread_atom(s, Q, X->chg[at[q]], u, sign); }
+  }
+  *e_acc = *e_acc + sign * (e_el + e_vdw + eb + ea + ed);
+  for (size_t k = 0; k < 3 * (size_t)N; ++k) Fd[k] = Fd[k] + sign * Ftmp[k];
+}
+double orc_evb_force_energy_delta_noverlet(OrcSys* s, double* F) {
+  int N = s->N, K = s->K; double E[5];
+  size_t K3 = (size_t)K * K * K, n3 = 3 * (size_t)N;
+  OrcTopo P = orc_principal_topo(s);
+  orc_update_com(s);
+  for (int d = 0; d < ORC_MAX_DIABATS; ++d) { s->parent[d] = -1; for (int h = 0; h < ORC_MAX_CHAIN; ++h) for (int q = 0; q < 5; ++q) s->plog[d][h][q] = -1; }
+  memset(s->H, 0, sizeof s->H);
+  s->D = 1;
+  enumerate(s, &P, s->hydronium, 0);
+  int D = s->D;
+  if (s->evb_cap < D) { free(s->evb_Fdiag); free(s->evb_Foff); s->evb_Fdiag = malloc((size_t)D * n3 * 8); s->evb_Foff = malloc((size_t)D * n3 * 8); s->evb_cap = D; }
+  memset(s->evb_Foff, 0, (size_t)D * n3 * 8);
+  /* principal diabat: the full force call (src/ms_evb.f90:411) */
+  double* F1 = s->evb_Fdiag;
+  double e1_terms = orc_total_topo(s, &P, s->verlet_point, s->neighbor_list, E, F1);      /* F1: without the repulsion terms */
+  double *Q1 = malloc(K3 * 8), *th1 = malloc(K3 * 8), *fr1 = malloc(8 * n3), *us1 = malloc(8 * n3), *Ftmp = malloc(8 * n3), *Qd = malloc(K3 * 8), *thd = malloc(K3 * 8), *usd = malloc(8 * n3);
+  unsigned char* screen = malloc((size_t)N);
+  double er1 = s->E_recip; double kk[3][3]; memcpy(kk, s->kk, sizeof kk);
+  memcpy(Q1, s->Q, K3 * 8); memcpy(th1, s->theta, K3 * 8); memcpy(fr1, s->force_recip, 8 * n3); memcpy(us1, s->xyz_scale, 8 * n3);
+  OrcScratch w; memset(&w, 0, sizeof w);
+  for (int d = 1; d < D; ++d) {
+    OrcTopo T; build_diabat_topo(s, &P, d, &T);
+    int mols[ORC_MAX_CHAIN + 1], nchg = 0, md = s->hydronium, ma = s->hydronium, md_last = s->hydronium;
+    mols[nchg++] = s->hydronium;
+    for (int h = 0; h < s->max_chain; ++h) { if (s->plog[d][h][0] < 0) break; md_last = ma; ma = s->plog[d][h][3]; int seen = 0; for (int q = 0; q < nchg; ++q) if (mols[q] == ma) seen = 1; if (!seen) mols[nchg++] = ma; }
+    md = md_last;
+    double* Fd = s->evb_Fdiag + (size_t)d * n3;
+    for (size_t k = 0; k < n3; ++k) Fd[k] = F1[k] - fr1[k];      /* everything but the reciprocal-space force, which is the diabat's own below */
+    double ed = e1_terms - er1;
+    memcpy(Qd, Q1, K3 * 8);
+    evb_changed_terms(s, &P, nchg, mols, -1.0, &ed, Fd, Ftmp, screen, Qd, kk, &w);      /* out, in the principal topology */
+    evb_changed_terms(s, &T, nchg, mols, +1.0, &ed, Fd, Ftmp, screen, Qd, kk, &w);      /* in, in the diabat's */
+    /* calculate_reciprocal_space_pme: the diabat's grid through the transforms, then the force on every atom */
+    double er_d = orc_convolve(s, Qd, thd);
+    orc_scaled_coords(kk, K, N, T.xyz, usd);
+#pragma omp parallel for num_threads(s->nthreads) schedule(static)
+    for (int i = 0; i < N; ++i) { double f[3]; orc_gather_atom(s, thd, T.chg[i], &usd[3 * i], kk, f); for (int q = 0; q < 3; ++q) Fd[3 * i + q] = Fd[3 * i + q] + f[q]; }
+    ed = ed + er_d;
+    ed = ed + evb_repulsion(s, &T, Fd);
+    ed = ed + s->ref_energy[T.mol_type[T.hydronium]];
+    s->H[d][d] = ed;
+    s->H[s->parent[d]][d] = evb_coupling(s, &T, md, ma, s->evb_Foff + (size_t)d * n3);
+    topo_free(&T);
+  }
+  orc_scratch_free(&w);
+  double e1 = e1_terms + evb_repulsion(s, &P, F1);
+  e1 = e1 + s->ref_energy[P.mol_type[P.hydronium]];
+  s->H[0][0] = e1;
+  free(Q1); free(th1); free(fr1); free(us1); free(Ftmp); free(Qd); free(thd); free(usd); free(screen);
+  return evb_diag_blend(s, F);
+}
+double orc_evb_force_energy_delta(OrcSys* s, double* F) {
+  if (s->verlet_flag == 1 || !s->neighbor_list) { orc_verlet_build(s, s->nslist); orc_verlet_check(s, 1); s->verlet_flag = 0; }
+  return orc_evb_force_energy_delta_noverlet(s, F);
 }
 int orc_evb_n_diabat(OrcSys* s) { return s->D; }
 void orc_evb_get(OrcSys* s, int* plog, int* parent, double* H, double* eig, double* Fd, double* Fo) {

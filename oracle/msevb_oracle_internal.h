@@ -83,6 +83,7 @@ void orc_bonded_topo(OrcSys* s, const OrcTopo* tp, double* E, double* F);
 double orc_total_topo(OrcSys* s, const OrcTopo* tp, const int* vp, const int* nl, double* E, double* F);
 void orc_update_com(OrcSys* s);
 double orc_evb_force_energy_noverlet(OrcSys* s, double* F);
+double orc_evb_force_energy_delta_noverlet(OrcSys* s, double* F);
 void orc_set_atype_chg(OrcSys* s, const double* atype_chg);
 void orc_set_atype_freeze(OrcSys* s, const int* atype_freeze);
 #endif

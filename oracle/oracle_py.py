@@ -24,7 +24,7 @@ def lib():
             build()
         L = C.CDLL(path)
         L.orc_create.restype = C.c_void_p
-        for f in ("orc_total", "orc_ewald_self", "orc_md_step", "orc_kinetic_energy", "orc_evb_force_energy", "orc_evb_repulsion_principal"):
+        for f in ("orc_total", "orc_ewald_self", "orc_md_step", "orc_kinetic_energy", "orc_evb_force_energy", "orc_evb_force_energy_delta", "orc_evb_repulsion_principal"):
             getattr(L, f).restype = C.c_double
         _LIB = L
     return _LIB
@@ -194,9 +194,10 @@ class Oracle:
         self.L.orc_evb_rep_switch(C.c_double(r), C.c_double(rs), C.c_double(rc), C.byref(sw), C.byref(dsw))
         return sw.value, dsw.value
 
-    def evb(self):
+    def evb(self, delta=False):
+        """delta=True: the reference's delta-update formulation (orc_evb_force_energy_delta) instead of every diabat from scratch"""
         F = np.zeros((self.N, 3))
-        e = self.L.orc_evb_force_energy(self.h, _p(F, C.c_double))
+        e = (self.L.orc_evb_force_energy_delta if delta else self.L.orc_evb_force_energy)(self.h, _p(F, C.c_double))
         D = self.L.orc_evb_n_diabat(self.h)
         mc = self.spec.max_chain
         plog = np.zeros((D, mc, 5), dtype=np.int32)

@@ -22,7 +22,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsevb_hip.so")
+LIB_PATH = os.environ.get("MSEVB_LIB") or os.path.join(_HERE, "libmsevb_hip.so")      # MSEVB_LIB: a variant build (tools/variant.sh) for A/B runs on one box
 _LIB = None
 
 N_ENERGY = 8

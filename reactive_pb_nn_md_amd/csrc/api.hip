@@ -7,11 +7,18 @@
 #include <signal.h>
 #include <unistd.h>
 
+#include <atomic>
 #include "ctx.hpp"
 
 thread_local StepRec* t_step_rec = nullptr;      // capture / replay of a force call (ctx.hpp)
 long g_alloc_epoch = 0;
-thread_local StepEventTable t_step_events;
+ApiProf g_api_prof;
+std::atomic<int> g_live_contexts{0};      // contexts alive in this process (the linear step graphs need their four streams on hardware queues of their own: one context at a time)
+// Room for every stream's own hardware queue (the runtime's default is four per process, shared round-robin beyond that): the library's four streams order themselves by
+// kernels that wait on the device for kernels of the other three - two of them on one queue could wait for each other.  Read by the runtime when it initialises, i.e. at the
+// first HIP call after this library was loaded; a value the user has set is left alone.
+__attribute__((constructor)) static void msevb_queue_room() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+thread_local LinCap* t_lin = nullptr;      // learn / capture pass of a call as four linear graphs (ctx.hpp)
 
 
 struct SlotCounts { int n[N_SLOTS]; };
@@ -103,6 +110,7 @@ int msevb_create(msevb_ctx** out, int device_id) {
   if (!out) return MSEVB_ERR_ARG;
   msevb_ctx* c = new msevb_ctx();
   *out = c;
+  g_live_contexts++;
   c->device = device_id;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { c->err = "no HIP device visible: libmsevb_hip has no CPU fallback"; return MSEVB_ERR_HIP; }
@@ -136,6 +144,7 @@ int msevb_create(msevb_ctx** out, int device_id) {
 
 int msevb_destroy(msevb_ctx* c) {
   if (!c) return MSEVB_OK;
+  g_live_contexts--;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->aux2) (void)hipStreamSynchronize(c->aux2);
@@ -730,7 +739,9 @@ int total_force_enqueue(msevb_ctx* c) {
     stamp(c, 1, c->stream);
     CHK(pair_forces(c, S_ELEC_PAIR, S_VDW_PAIR));                    // main: the pair loop (longest) goes out first
     c->pair_self_nb = 0;
-    if (self_nb) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_top2, 0));      // (the displacement maxima are part of what the main stream publishes)
+    c->top2_join_pending = false;
+    if (self_nb) { if (c->skip_side_joins_now) c->top2_join_pending = true;      /* (MS-EVB fast path: the stream that publishes the energies waits for it itself - nothing on the main stream between the pair loop and the blend phase) */
+                   else HIPCHK(hipStreamWaitEvent(c->stream, c->ev_top2, 0)); }      // (the displacement maxima are part of what the main stream publishes)
     stamp(c, 2, c->stream);
     if (c->evb_pair_first || c->molecules_after_pair_now) { if (!c->ev_pair_done) HIPCHK(hipEventCreateWithFlags(&c->ev_pair_done, hipEventDisableTiming)); HIPCHK(hipEventRecord(c->ev_pair_done, c->stream)); }
     if (!c->defer_molecules_now)                                     // (the MS-EVB call sends them out itself, behind its coupling chain on the same stream)
@@ -842,7 +853,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   c->topo_epoch++;
   if (s == "evb_speculate") { c->evb_speculate = v != 0.0; return MSEVB_OK; }
   if (s == "evb_device_plan") { c->evb_device_plan = v != 0.0; return MSEVB_OK; }      // 0: enumeration + descriptor build on the host (evb_plan.hpp, the same source the device runs)
-  if (s == "step_graph") { c->evb_step_graph = v != 0.0; return MSEVB_OK; }      // the enqueue part of a speculative MS-EVB call as one captured hipGraph (evb.hip)
+  if (s == "step_graph") { c->evb_step_graph = (int)v; return MSEVB_OK; }      // the enqueue part of a speculative MS-EVB call as four captured linear hipGraphs (evb.hip): 0 off, 1 on except with a real communicator, 2 on
   if (s == "phase_timing") { c->timing = v != 0.0; c->timing_now = false; return MSEVB_OK; }
   if (s == "phase_timing_stride") { c->timing_stride = v < 1.0 ? 1 : (int)v; return MSEVB_OK; }
   if (s == "fft_batch") { c->fft_batch = (int)v; return MSEVB_OK; }

@@ -6,7 +6,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <utility>
 #include <map>
@@ -48,8 +50,9 @@ constexpr int WAVE = 64;
 //              the call is ONE hipGraphLaunch - otherwise the call is repeated in mode 0 (nothing had been issued) and the graph is dropped.
 // All device work of the library goes through the wrappers below (the HIP names are redirected to them at the end of this block).
 enum StepBlockSlot { SB_R = 0, SB_A, SB_S, SB_B, SB_EPOCH, SB_N = 8 };      // device-resident step block: what changes between two launches of a captured force call
-struct StepRec { int mode = 0; unsigned long long hash = 0xcbf29ce484222325ull; int n = 0; };
+struct StepRec { int mode = 0; unsigned long long hash = 0xcbf29ce484222325ull; int n = 0; std::vector<std::pair<const void*, unsigned long long>>* trace = nullptr; /* MSEVB_GRAPH_DEBUG: (kernel or operation tag, running hash) per operation */ };
 extern thread_local StepRec* t_step_rec;      // non-null only inside a captured / replayed force call of the calling thread (api.hip)
+extern std::atomic<int> g_live_contexts;
 extern long g_alloc_epoch;                    // bumped by every (re)allocation or release of a device buffer: addresses baked into a captured graph may be stale
 inline void step_hash_bytes(StepRec& r, const void* p, size_t n) {
   const unsigned char* b = (const unsigned char*)p;
@@ -61,7 +64,76 @@ inline void step_hash_bytes(StepRec& r, const void* p, size_t n) {
 }
 template <class T> inline void step_hash_one(StepRec& r, const T& v) { step_hash_bytes(r, &v, sizeof(T)); }
 inline void step_hash_one(StepRec& r, std::nullptr_t) { const void* z = nullptr; step_hash_bytes(r, &z, sizeof z); }
+// MSEVB_API_TIMING=1 (diagnostic): host time and call count per kind of runtime call the library's wrappers issue (0 kernel launch, 1 event record, 2 stream wait,
+// 3 fill / copy command, 4 graph launch), printed per MS-EVB call when the context is released - where the host's enqueue time of a step goes
+struct ApiProf { int on = -1; double us[5] = {0, 0, 0, 0, 0}; long n[5] = {0, 0, 0, 0, 0}; };
+extern ApiProf g_api_prof;
+inline bool api_prof_on() { if (g_api_prof.on < 0) g_api_prof.on = getenv("MSEVB_API_TIMING") ? 1 : 0; return g_api_prof.on == 1; }
+inline double api_now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+struct ApiScope { int k; double t0; explicit ApiScope(int kind) : k(api_prof_on() ? kind : -1), t0(k >= 0 ? api_now_us() : 0.0) {} ~ApiScope() { if (k >= 0) { g_api_prof.us[k] += api_now_us() - t0; g_api_prof.n[k]++; } } };
+// ---- the captured call as FOUR LINEAR graphs, one per stream (round 5; tools/graph_probe.hip, profiles/r05_graph_probe.txt) ---------------------------------------
+// One hipGraph that holds the call's four branches costs the calling thread ~3 us per node on this runtime (it is enqueued node by node, like the stream launches
+// it replaces); a graph that is ONE chain of kernel nodes costs ~3 us for the whole chain (14 nodes: 3.0 us; four chains of 14-19 nodes: 10.7 us).  So every stream of
+// the call is captured on its own (four captures, no edges between them) and what used to order the streams - event record on one, wait on another - becomes a pair
+// of operations of one-thread kernels inside the chains (k_lg_ops): a mark stores {step number of the producing stream} x 64 + {ordinal of this record of the event in
+// the call}, a wait polls for that value; what a stream does between two of its kernels is ONE such kernel.  The step number lives on the device, one counter per
+// stream, advanced by the first operation of the stream's chain: no node's arguments change from launch to launch.  Records nobody waits for on another
+// stream emit nothing (found by a dry "learn" pass over the call, mode 3, before the capture pass).
+// what a stream does between two of its kernels, in order: up to 8 operations {kind, slot, ordinal} in ONE one-thread kernel (kind 0 = advance the stream's step counter,
+// 1 = store a mark, 2 = wait for a mark).  Order matters (a record in front of a wait must stay in front of it: two streams that each mark first and wait second would
+// wait for each other otherwise), so the list is kept as issued.
+struct LinOps { int n = 0; int kind[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int slot[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int ord[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
+struct LinCap {
+  hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
+  long long* cnt = nullptr; long long* marks = nullptr; double* fault = nullptr;      // device: cnt[4], marks[64]; the sticky time-out flag (S_TIMEOUT)
+  int nev = 0; hipEvent_t ev[60]; int ev_stream[60]; int ev_ord[60];
+  unsigned long long need[60];      // bit `ord` of need[slot]: that record of the event is waited for by another stream (learn pass -> capture pass)
+  LinOps pend[4];                   // operations a stream has collected since its last kernel
+  bool head_open = true; LinOps head;      // the main stream's operations in front of its first kernel: not captured - the step-block kernel, launched in front of the main chain at every replay, performs them
+  bool bad = false, verbose = false; const char* why = nullptr; int n_marks = 0, n_waits = 0, n_op_kernels = 0;
+  int stream_index(hipStream_t s) const { for (int b = 0; b < 4; ++b) if (st[b] == s) return b; return -1; }
+  int slot_of(hipEvent_t e) const { for (int k = 0; k < nev; ++k) if (ev[k] == e) return k; return -1; }
+};
+extern thread_local LinCap* t_lin;      // non-null during the learn (mode 3) and capture (mode 1) passes of a call (evb.hip)
 #ifdef __HIPCC__
+__device__ __forceinline__ void lin_run_ops(const LinOps& a, long long* cnt, long long* marks, double* fault) {
+  const long long t0 = wall_clock64();
+  bool waited = false;
+  for (int k = 0; k < a.n; ++k) {
+    if (a.kind[k] == 0) *cnt = *cnt + 1;
+    else if (a.kind[k] == 1) __hip_atomic_store(marks + a.slot[k], *cnt * 64 + a.ord[k], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    else {
+      const long long want = *cnt * 64 + a.ord[k];
+      while (__hip_atomic_load(marks + a.slot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {      // (relaxed polls, one acquire at the end)
+        if (wall_clock64() - t0 > 200000000LL) { if (fault) *fault = 2.0; break; }      // 2 s of the 100 MHz clock: the sticky flag the host reports as MSEVB_ERR_TIMEOUT
+        __builtin_amdgcn_s_sleep(8);
+      }
+      waited = true;
+    }
+  }
+  if (waited) __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+[[maybe_unused]] static __global__ void k_lg_ops(long long* cnt, long long* marks, LinOps a, double* fault) { if (threadIdx.x == 0) lin_run_ops(a, cnt, marks, fault); }
+inline void lin_flush(LinCap& L, int b) {      // what a stream has collected, as ONE kernel in front of whatever it does next
+  if (L.pend[b].n == 0) return;
+  if (b == 0 && L.head_open) { L.head = L.pend[0]; L.head_open = false; L.pend[0].n = 0; return; }      // (performed by the step-block kernel)
+  LinOps a = L.pend[b];
+  L.pend[b].n = 0; L.n_op_kernels++;
+  k_lg_ops<<<dim3(1), dim3(64), 0, L.st[b]>>>(L.cnt + b, L.marks, a, L.fault);
+}
+inline void lin_add_op(LinCap& L, int b, int kind, int slot, int ord) {
+  if (L.pend[b].n == 8) lin_flush(L, b);
+  LinOps& p = L.pend[b];
+  p.kind[p.n] = kind; p.slot[p.n] = slot; p.ord[p.n] = ord; p.n++;
+}
+inline void lin_before_op(hipStream_t s) {      // capture pass: anything issued to a stream comes behind its pending operations
+  LinCap* L = t_lin;
+  if (!L) return;
+  const int b = L->stream_index(s);
+  if (b < 0) { L->bad = true; L->why = "an operation on a stream outside the call's four"; return; }
+  lin_flush(*L, b);
+  if (b == 0) L->head_open = false;
+}
 template <class K, class... A>
 inline void step_launch(K kern, dim3 grid, dim3 block, size_t shm, hipStream_t st, A&&... a) {
   StepRec* r = t_step_rec;
@@ -70,34 +142,67 @@ inline void step_launch(K kern, dim3 grid, dim3 block, size_t shm, hipStream_t s
     step_hash_one(*r, fn); step_hash_one(*r, grid.x); step_hash_one(*r, grid.y); step_hash_one(*r, grid.z); step_hash_one(*r, block.x); step_hash_one(*r, shm); step_hash_one(*r, st);
     (step_hash_one(*r, a), ...);
     r->n++;
-    if (r->mode == 2) return;
+    if (r->trace) r->trace->push_back({fn, r->hash});
+    if (r->mode >= 2) return;
+    if (r->mode == 1) lin_before_op(st);
   }
+  ApiScope aps(0);
   kern<<<grid, block, shm, st>>>(std::forward<A>(a)...);
 }
 #endif
-inline bool step_skip(int tag, const void* a, const void* b, size_t n) {      // event / fill operations: hashed like launches, skipped on replay
+inline bool step_skip(int tag, const void* a, const void* b, size_t n) {      // event / fill operations: hashed like launches, skipped on replay (mode 2) and in the learn pass (mode 3)
   StepRec* r = t_step_rec;
   if (!r) return false;
   step_hash_one(*r, tag); step_hash_one(*r, a); step_hash_one(*r, b); step_hash_one(*r, n); r->n++;
-  return r->mode == 2;
+  if (r->trace) r->trace->push_back({(const void*)(size_t)tag, r->hash});
+  return r->mode >= 2;
 }
-// (while capturing, a stream must not wait for an event of its OWN: this runtime's hipStreamEndCapture recurses without end on the edge such a wait adds - found with the
-//  blend-terms kernel, profiles/r05_graph_probe.txt; in stream order the wait is a no-op anyway.  The record streams of a capture's events are kept in a small table.)
-struct StepEventTable { int n = 0; hipEvent_t ev[64]; hipStream_t st[64]; };
-extern thread_local StepEventTable t_step_events;
 inline hipError_t step_event_record(hipEvent_t e, hipStream_t s) {
-  if (step_skip(1, e, s, 0)) return hipSuccess;
-  if (t_step_rec) { StepEventTable& T = t_step_events; int k = 0; while (k < T.n && T.ev[k] != e) ++k; if (k < 64) { T.ev[k] = e; T.st[k] = s; if (k == T.n) T.n++; } }
+  const bool skip = step_skip(1, e, s, 0);
+  LinCap* L = t_lin;
+  if (L && t_step_rec) {      // learn / capture pass: the record gets its slot and ordinal; the capture pass emits a mark where the learn pass saw a cross-stream wait
+    const int b = L->stream_index(s);
+    int k = L->slot_of(e);
+    if (k < 0 && L->nev < 60) { k = L->nev++; L->ev[k] = e; L->ev_ord[k] = 0; if (t_step_rec->mode == 3) L->need[k] = 0; }
+    if (b < 0 || k < 0 || L->ev_ord[k] >= 62) { L->bad = true; L->why = "event table of the linear capture"; return hipSuccess; }
+    L->ev_stream[k] = b; L->ev_ord[k]++;
+#ifdef __HIPCC__
+    if (t_step_rec->mode == 1 && ((L->need[k] >> L->ev_ord[k]) & 1ull)) { L->n_marks++; lin_add_op(*L, b, 1, k, L->ev_ord[k]); }
+#endif
+    return hipSuccess;
+  }
+  if (skip) return hipSuccess;
+  ApiScope aps(1);
   return (hipEventRecord)(e, s);
 }
 inline hipError_t step_stream_wait(hipStream_t s, hipEvent_t e, unsigned f) {
-  if (step_skip(2, e, s, f)) return hipSuccess;
-  if (t_step_rec) { const StepEventTable& T = t_step_events; for (int k = 0; k < T.n; ++k) if (T.ev[k] == e && T.st[k] == s) return hipSuccess; }
+  const bool skip = step_skip(2, e, s, f);
+  LinCap* L = t_lin;
+  if (L && t_step_rec) {
+    const int b = L->stream_index(s), k = L->slot_of(e);
+    if (b < 0) { L->bad = true; L->why = "a wait on a stream outside the call's four"; return hipSuccess; }
+    if (k < 0) { L->bad = true; L->why = "a wait for an event that was not recorded inside the call"; return hipSuccess; }
+    if (L->ev_stream[k] == b) return hipSuccess;      // same stream: stream order
+    if (t_step_rec->mode == 3) { L->need[k] |= 1ull << L->ev_ord[k]; return hipSuccess; }
+#ifdef __HIPCC__
+    lin_add_op(*L, b, 2, k, L->ev_ord[k]); L->n_waits++;
+#endif
+    if (L->verbose) fprintf(stderr, "[msevb]   stream %d waits for event %d (record %d, made on stream %d)\n", b, k, L->ev_ord[k], L->ev_stream[k]);
+    return hipSuccess;
+  }
+  if (skip) return hipSuccess;
+  ApiScope aps(2);
   return (hipStreamWaitEvent)(s, e, f);
 }
-inline hipError_t step_memset_async(void* p, int v, size_t n, hipStream_t s) { return step_skip(3 + 16 * (v & 0xff), p, s, n) ? hipSuccess : (hipMemsetAsync)(p, v, n, s); }
-inline hipError_t step_memset_d32_async(hipDeviceptr_t p, int v, size_t n, hipStream_t s) { return step_skip(4 + 16 * v, (const void*)p, s, n) ? hipSuccess : (hipMemsetD32Async)(p, v, n, s); }
-inline hipError_t step_memcpy_async(void* d, const void* src, size_t n, hipMemcpyKind k, hipStream_t s) { return step_skip(5 + 16 * (int)k, d, src, n) ? hipSuccess : (hipMemcpyAsync)(d, src, n, k, s); }
+#ifdef __HIPCC__
+inline hipError_t step_memset_async(void* p, int v, size_t n, hipStream_t s) { if (step_skip(3 + 16 * (v & 0xff), p, s, n)) return hipSuccess; lin_before_op(s); ApiScope aps(3); return (hipMemsetAsync)(p, v, n, s); }
+inline hipError_t step_memset_d32_async(hipDeviceptr_t p, int v, size_t n, hipStream_t s) { if (step_skip(4 + 16 * v, (const void*)p, s, n)) return hipSuccess; lin_before_op(s); ApiScope aps(3); return (hipMemsetD32Async)(p, v, n, s); }
+inline hipError_t step_memcpy_async(void* d, const void* src, size_t n, hipMemcpyKind k, hipStream_t s) { if (step_skip(5 + 16 * (int)k, d, src, n)) return hipSuccess; lin_before_op(s); ApiScope aps(3); return (hipMemcpyAsync)(d, src, n, k, s); }
+#else
+inline hipError_t step_memset_async(void* p, int v, size_t n, hipStream_t s) { if (step_skip(3 + 16 * (v & 0xff), p, s, n)) return hipSuccess; return (hipMemsetAsync)(p, v, n, s); }
+inline hipError_t step_memset_d32_async(hipDeviceptr_t p, int v, size_t n, hipStream_t s) { if (step_skip(4 + 16 * v, (const void*)p, s, n)) return hipSuccess; return (hipMemsetD32Async)(p, v, n, s); }
+inline hipError_t step_memcpy_async(void* d, const void* src, size_t n, hipMemcpyKind k, hipStream_t s) { if (step_skip(5 + 16 * (int)k, d, src, n)) return hipSuccess; return (hipMemcpyAsync)(d, src, n, k, s); }
+#endif
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kern, grid, block, shm, st, ...) step_launch(kern, dim3(grid), dim3(block), (size_t)(shm), (st), ##__VA_ARGS__)
 #define hipEventRecord(e, s) step_event_record((e), (s))
@@ -317,6 +422,7 @@ struct msevb_ctx {
   int pair_tiles_opt = -1;       // half-list LDS pair kernel: -1 / 1 = whenever the box has >= 4 cells per axis and the tile fits in LDS (default), 0 = never
   bool pair_tiles = false;       // format of the current list
   int tile_atoms_max = 0;        // largest 27-cell neighbourhood (atoms) the last build saw
+  int half_tile_cap_seen = 0, gather_cap_seen = 0;      // largest tile capacity / per-cell staging capacity used so far: launch parameters that follow the list statistics only upwards (a captured force call stays valid across rebuilds)
   int half_tile_max = 0, half_tile_cap = 0;      // largest half neighbourhood the last build saw / tile size (atoms) the current half list was built for
   bool finalized = false;
   bool attr_pair_half[8] = {false, false, false, false, false, false, false, false};
@@ -471,7 +577,9 @@ struct msevb_ctx {
   // opt_epoch counts msevb_set_option / box / communicator changes (a captured graph bakes the options in)
   // OFF by default: on this runtime (ROCm 7.2) hipGraphLaunch enqueues its nodes one by one on the calling thread - 3.1 us per node against 3.3 us per stream launch
   // (profiles/r05_graph_probe.txt) - so the replay saves no host time, and the graph's branches cannot use the device-side marks (3 % of the step)
-  bool evb_step_graph = false; const long long* step_sb = nullptr; long evb_graph_launches = 0, evb_graph_captures = 0, evb_graph_mismatches = 0;
+  bool top2_join_pending = false;      // k_top2_final ran on aux3 and the main stream did not wait for it: whoever publishes the displacement maxima does
+  LinOps lin_tail; long long* lin_cnt = nullptr; long long* lin_marks = nullptr; bool lin_tail_defer = false;      // closing waits of a force call that went out as linear graphs: performed by the integrator's second kernel (MD loop: lin_tail_defer) or by a one-thread kernel at the end of the call
+  int evb_step_graph = 1; const long long* step_sb = nullptr; long evb_graph_launches = 0, evb_graph_captures = 0, evb_graph_mismatches = 0;
   void* evb_work = nullptr;            // EvbWork of evb.hip (created by the first EVB force call, freed by evb_release)
   DBuf<double> d_comm_h, d_comm_e;     // staging of the Hamiltonian all-gather / the energy all-reduce (comm.hip)
   double* h_comm = nullptr; size_t h_comm_cap = 0; long long* h_comm_flag = nullptr; long long comm_seq = 0;      // pinned staging of the per-step all-gather (comm.hip)
@@ -566,6 +674,7 @@ struct FftPatch {
   const double* dc;                       // coefficients in device memory: dc[1 + grid] (written by the solve body) ...
   double c[MAX_DIABATS];                  // ... or as kernel arguments (dc == nullptr)
   const long long* wait_mark; long long wait_seq; double* fault;      // the coefficients' kernel runs on another stream: start on its mark
+  const long long* wait_sb;                                           // (a captured launch: the mark's number is wait_sb[SB_A])
 };
 bool fft_lds_can_patch(const msevb_ctx* c);      // the 64^3 transform (its forward kernel applies an FftPatch)
 int fft_lds_solve(msevb_ctx* c, const double* Q, double2* work, double* theta, double* part, int* nblocks, hipStream_t st, const FftPatch* patch = nullptr);

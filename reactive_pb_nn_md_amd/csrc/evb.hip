@@ -178,7 +178,13 @@ __global__ __launch_bounds__(256) void k_evb_candidates(int N, double cx, double
 // sum over its q-lanes (one atomic triple per candidate), the force on special atom q accumulates per lane and meets in LDS at the end.
 // The MS-EVB3 repulsion (rare: candidates within the screening radius of the hydronium) is done by the q = 0 lane and adds straight into
 // the LDS table.  No private arrays (the thread-per-candidate version kept the hydronium force block in scratch memory).
-__global__ __launch_bounds__(256) void k_evb_env(const int* __restrict__ n_cand, const int* __restrict__ cand, int n_units, const UnitDesc* __restrict__ units, const EvbTablesDev* __restrict__ tabs,
+// EVB_ENV_CAP (variant build): at most 64 vector registers per lane, the most that fits beside a pair-loop workgroup on its CU (4 waves x 112 registers per SIMD) - spills to scratch
+#ifdef EVB_ENV_CAP
+#define EVB_ENV_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define EVB_ENV_ATTR
+#endif
+__global__ __launch_bounds__(256) EVB_ENV_ATTR void k_evb_env(const int* __restrict__ n_cand, const int* __restrict__ cand, int n_units, const UnitDesc* __restrict__ units, const EvbTablesDev* __restrict__ tabs,
                                                  const double* __restrict__ xyz, const double* __restrict__ chg, const int* __restrict__ atype,
                                                  const int* __restrict__ mol_of, const PairParam* __restrict__ pairpar, int nt,
                                                  const double2* __restrict__ etab, double inv_dx, const double* __restrict__ tt,
@@ -870,8 +876,9 @@ __global__ __launch_bounds__(256) void k_evb_recip_pairs(GridRanges gr, const St
 // blended charge grid: grid += sum over the stencils of c_d^2 q S (the grid holds Q_1 on rank 0, zero on the others); coefficients as kernel
 // arguments, or from device memory behind k_evb_solve
 // first kernel of a chain that starts on a mark of another stream (2 s limit, then the sticky fault flag, as k_evb_publish)
-__device__ __forceinline__ void evb_wait_mark(const long long* mark, long long seq, double* fault) {
+__device__ __forceinline__ void evb_wait_mark(const long long* mark, long long seq, double* fault, const long long* sb = nullptr) {      // sb: a captured launch - the number is the step block's SB_A
   if (threadIdx.x == 0) {
+    if (sb) seq = sb[SB_A];
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {      // (relaxed polls: an acquire per poll is a cache invalidation per poll, from every waiting workgroup)
       if (wall_clock64() - t0 > 200000000LL) { if (fault) *fault = 2.0; break; }
@@ -881,12 +888,12 @@ __device__ __forceinline__ void evb_wait_mark(const long long* mark, long long s
   }
   __syncthreads();
 }
-__global__ void k_evb_wait_mark(const long long* mark, long long seq, double* fault) { evb_wait_mark(mark, seq, fault); }
+__global__ void k_evb_wait_mark(const long long* mark, long long seq, double* fault, const long long* sb = nullptr) { evb_wait_mark(mark, seq, fault, sb); }
 // wait_mark: the coefficients in dc come from k_evb_solve on ANOTHER stream (the grid stream, right behind the energy fetch): this kernel, first of the
 // blend phase on the main stream, starts on that kernel's mark instead of behind a cross-stream event (~10 us) or behind the solve itself
 __global__ __launch_bounds__(256) void k_evb_blend_patch(int nst, const Stencil* __restrict__ st, GridCoefs gc, const double* __restrict__ dc, int K, double* __restrict__ grid, int gs,
-                                                         const long long* wait_mark = nullptr, long long wait_seq = 0, double* fault = nullptr) {
-  if (wait_mark) evb_wait_mark(wait_mark, wait_seq, fault);
+                                                         const long long* wait_mark = nullptr, long long wait_seq = 0, double* fault = nullptr, const long long* wait_sb = nullptr) {
+  if (wait_mark) evb_wait_mark(wait_mark, wait_seq, fault, wait_sb);
   const int lane = threadIdx.x & 63;
   const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (e >= nst) return;
@@ -973,6 +980,7 @@ struct SolveArgs {
   const SolveDesc* sd; const int* unit_idx; const double* unit_sign; const double* E; const double* e_recip1;
   double* dcoef; double* out_host;
   long long mark_seq; long long* done_mark;               // device mark the blend phase (main stream) starts on
+  const long long* sb;                                    // a captured launch: the mark's number is sb[SB_A]
   volatile long long* done_flag; long long done_seq;      // pinned flag the host spins on
   double* fault;
 };
@@ -990,7 +998,7 @@ __device__ __forceinline__ void evb_solve_body(const SolveArgs& sa, const SolveS
   const SolveDesc* sd = &stg->sd;
   const int* __restrict__ unit_idx = sa.unit_idx; const double* __restrict__ unit_sign = sa.unit_sign;
   const double* __restrict__ E = sa.E; const double* __restrict__ e_recip1 = sa.e_recip1; double* __restrict__ dcoef = sa.dcoef; double* __restrict__ out_host = sa.out_host;
-  const int method = sa.method; long long* done_mark = sa.done_mark; const long long wait_seq = sa.mark_seq; 
+  const int method = sa.method; long long* done_mark = sa.done_mark; const long long wait_seq = sa.sb ? sa.sb[SB_A] : sa.mark_seq; 
   extern __shared__ double sh[];      // A[n*n], V[n*n], cplA[n], per pair of a round: c, s, d_p - t a_pq, d_q + t a_pq (n/2 each) and p, q (ints)
   const int n = sd->D, tid = threadIdx.x, nth = blockDim.x;
   const int m = (n + 1) & ~1, hp = m / 2;      // tournament over m players (an odd n plays with a dummy that sits out)
@@ -1543,7 +1551,7 @@ __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, 
     if (threadIdx.x == 0) {
       const long long t0 = wall_clock64();      // 100 MHz
       for (int k = 0; k < n_chains; ++k)
-        while (__hip_atomic_load(chain_done + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != chain_seq) {
+        while (__hip_atomic_load(chain_done + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (sb ? sb[SB_A] : chain_seq)) {
           if (wall_clock64() - t0 > 200000000LL) { if (fault) *fault = 2.0; break; }      // 2 s (the first launch of a kernel in a process can take milliseconds to load)
           __builtin_amdgcn_s_sleep(2);
         }
@@ -1580,9 +1588,13 @@ __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, 
 
 // step graph: the numbers of THIS call, set on the main stream right in front of the graph launch (by-value arguments of an ordinary launch)
 struct StepBlockVals { long long v[SB_N]; };
-__global__ void k_set_step_block(long long* sb, StepBlockVals v) { if (threadIdx.x < SB_N) sb[threadIdx.x] = v.v[threadIdx.x]; }
+__global__ void k_set_step_block(long long* sb, StepBlockVals v, long long* cnt, long long* marks, LinOps head, double* fault) {
+  if (threadIdx.x < SB_N) sb[threadIdx.x] = v.v[threadIdx.x];
+  __threadfence(); __syncthreads();
+  if (threadIdx.x == 0 && cnt) lin_run_ops(head, cnt, marks, fault);      // ... and the head of the main chain: its step counter, the marks the side chains start on
+}
 // last kernel of a side chain: its stream has finished everything in front of it
-__global__ void k_evb_mark(long long* p, long long seq) { __hip_atomic_store(p, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void k_evb_mark(long long* p, long long seq, const long long* sb = nullptr) { __hip_atomic_store(p, sb ? sb[SB_A] : seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }      // sb: a captured launch - the number is the step block's
 
 __global__ void k_sum_rows(int nrow, int ncol, int stride, const double* __restrict__ part, double* __restrict__ out) {
   const int r = blockIdx.x;
@@ -1633,13 +1645,22 @@ struct EvbWork {   // persistent device scratch of one context
   long spec_steps = 0, spec_misses = 0;
   // step graph (ctx.hpp: StepRec): the enqueue part of a speculative call captured once per diabat tree and replayed with ONE launch; two entries: calls whose refresh of the
   // sorted arrays rode in the integrator's first kernel (MD loop) and calls that refresh themselves (force calls through the host-array entry points)
-  struct StepGraph { hipGraphExec_t exec = nullptr; unsigned long long hash = 0; int n = 0; long plan_serial = -1, topo_epoch = -1, alloc_epoch = -1; };
+  struct StepGraph {      // four linear graphs, one per stream (ctx.hpp: LinCap); `need` is what the learn pass found (which event records another stream waits for)
+    hipGraphExec_t exec[4] = {nullptr, nullptr, nullptr, nullptr}; unsigned long long hash = 0; int n = 0; long plan_serial = -1, topo_epoch = -1, alloc_epoch = -1;
+    bool learned = false; long learn_serial = -1, learn_topo = -1; unsigned long long need[60]; int nev = 0;
+    std::vector<std::pair<const void*, unsigned long long>> trace;      // (MSEVB_GRAPH_DEBUG)
+    LinOps tail;      // ... and its closing waits (integrator's second kernel / a kernel of their own)
+    LinOps head;      // the main chain's operations in front of its first kernel (step counter, the marks everything else starts on): done by the step-block kernel
+    bool have() const { return exec[0] != nullptr; }
+    void drop() { for (auto& e : exec) if (e) { (void)hipGraphExecDestroy(e); e = nullptr; } }
+  };
   // diabat enumeration / descriptor construction (evb_plan.hpp): static tables, the region's molecule order, scratch frames of the search
   PlanTables ptab; std::vector<int> region_order; std::vector<PlanFrame> plan_frames; PlanWork plan_work;
   // ... on the device (k_evb_plan): tables, scratch, the summary in pinned memory; solve_desc_dirty: the host-built part of the descriptor block (SolveDesc) has to follow the device-built one
   DBuf<PlanTables> d_ptab; PlanTables ptab_dev; bool ptab_dev_valid = false; DBuf<int> d_plan_order, d_plan_near, d_plan_cnt, d_plan_shell; DBuf<CouplingDesc> d_cps_tmp;
   PlanSummary* h_plan_sum = nullptr; long long seq_P = 0; hipEvent_t ev_plan = nullptr; bool solve_desc_dirty = false, device_plan_off_once = false;
-  StepGraph sg[2]; hipEvent_t ev_gjoin[3] = {nullptr, nullptr, nullptr}; DBuf<long long> d_sb; long plan_serial = 0; bool graph_broken = false, graph_skip_once = false;
+  StepGraph sg[2]; hipEvent_t ev_gjoin[3] = {nullptr, nullptr, nullptr}; DBuf<long long> d_sb, d_lin;      // d_lin: the linear graphs' step counters [4] and marks [64]
+  LinCap lin; long plan_serial = 0; bool graph_broken = false, graph_skip_once = false; int graph_mismatch_run = 0;
 };
 // host-side section timing (MSEVB_HOST_TIMING=1): where the CPU thread spends the step
 struct HostTimes { double t[12] = {0}; long n = 0; };
@@ -1738,14 +1759,14 @@ static double blend_terms(const msevb_ctx* c, int D, const double* ev, BlendTerm
 // The host waits for small results (neighbourhood record, energies) by spinning on a sequence number the producing kernel writes to
 // pinned memory behind its data: hipEventSynchronize sleeps on an interrupt and needs 50-100 us to wake up, a spin sees the store in
 // ~2 us.  The event stays the fallback (a kernel that failed never writes; the event reports the error).
-static int spin_wait(volatile long long* flag, long long seq, hipEvent_t ev, hipStream_t graph_stream = nullptr) {      // graph_stream: the producer ran inside a launched graph - `ev` was only captured, the stream is what can be waited for
+static int spin_wait(volatile long long* flag, long long seq, hipEvent_t ev, hipStream_t graph_stream = nullptr) {      // graph_stream != null: the producer ran inside a launched graph - `ev` was never recorded, the device is what can be waited for
   const auto t0 = std::chrono::steady_clock::now();
   long spins = 0;
   while (*flag != seq) {
     __builtin_ia32_pause();
     if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
   }
-  if (*flag != seq && graph_stream) return (hipStreamSynchronize(graph_stream) == hipSuccess && *flag == seq) ? 0 : -1;
+  if (*flag != seq && graph_stream) return (hipDeviceSynchronize() == hipSuccess && *flag == seq) ? 0 : -1;
   if (*flag != seq && hipEventSynchronize(ev) != hipSuccess) return -1;
   return 0;
 }
@@ -1803,7 +1824,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
   stamp(c, 8, c->stream);
   if (w->d_pack.alloc(K3)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (blended potential)");
   const bool patch_waits = w->blend_mark && w->last_linear && ngrid > 0 && fft_lds_usable(c);      // k_evb_blend_patch is the phase's first kernel and waits itself
-  if (w->blend_mark && !patch_waits) hipLaunchKernelGGL(k_evb_wait_mark, dim3(1), dim3(64), 0, c->stream, w->blend_mark, w->blend_mark_seq, c->d_energies.p + S_TIMEOUT);
+  if (w->blend_mark && !patch_waits) hipLaunchKernelGGL(k_evb_wait_mark, dim3(1), dim3(64), 0, c->stream, w->blend_mark, w->blend_mark_seq, c->d_energies.p + S_TIMEOUT, (const long long*)c->step_sb);
   if (w->last_linear) {
     // blended CHARGE grid Q_1 (rank 0) + sum_d c_d^2 DQ_d -> one transform pair -> blended potential theta_1 + sum_d c_d^2 G * DQ_d
     // (sum_d c_d^2 = 1 over all ranks, so the principal potential enters once, on rank 0)
@@ -1814,7 +1835,7 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
       if (fft_lds_can_patch(c) && c->evb_fft_patch) {      // 64^3: the forward transform applies the stencils to the planes of Q_1 itself - no copy of Q_1, no patch kernel
         FftPatch P; memset(&P, 0, sizeof P); P.nst = w->last_nst; P.st = w->d_stencils.p; P.dc = dcoef;
         for (int g = 0; g < MAX_DIABATS; ++g) P.c[g] = (!dcoef && g < ngrid) ? gc.c[g] : 0.0;
-        P.wait_mark = patch_waits ? w->blend_mark : (const long long*)nullptr; P.wait_seq = w->blend_mark_seq; P.fault = c->d_energies.p + S_TIMEOUT;
+        P.wait_mark = patch_waits ? w->blend_mark : (const long long*)nullptr; P.wait_seq = w->blend_mark_seq; P.wait_sb = patch_waits ? (const long long*)c->step_sb : (const long long*)nullptr; P.fault = c->d_energies.p + S_TIMEOUT;
         CHK(fft_lds_solve(c, c->rank == 0 ? c->d_Q.p : (const double*)nullptr, w->d_grids.p, w->d_pack.p, nullptr, nullptr, c->stream, &P));
         w->pack_prefilled = false;
       } else if (fft_lds_usable(c)) {      // real grid in, real potential out, in place in d_pack (d_grids is the transform's complex work space)
@@ -1823,13 +1844,13 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
         else HIPCHK(hipMemsetAsync(w->d_pack.p, 0, K3 * sizeof(double), c->stream));
         w->pack_prefilled = false;
         hipLaunchKernelGGL(k_evb_blend_patch, dim3((w->last_nst + 3) / 4), dim3(256), 0, c->stream, w->last_nst, w->d_stencils.p, gc, dcoef, K, w->d_pack.p, 1,
-                           patch_waits ? w->blend_mark : (const long long*)nullptr, w->blend_mark_seq, c->d_energies.p + S_TIMEOUT);
+                           patch_waits ? w->blend_mark : (const long long*)nullptr, w->blend_mark_seq, c->d_energies.p + S_TIMEOUT, patch_waits ? (const long long*)c->step_sb : (const long long*)nullptr);
         HIPCHK(hipGetLastError());
         CHK(fft_lds_solve(c, w->d_pack.p, w->d_grids.p, w->d_pack.p, nullptr, nullptr, c->stream));
       } else {
         if (c->rank == 0) hipLaunchKernelGGL(k_evb_grid_init, dim3(2048), dim3(256), 0, c->stream, K3, 1, c->d_Q.p, w->d_grids.p);
         else HIPCHK(hipMemsetAsync(w->d_grids.p, 0, K3 * sizeof(double2), c->stream));
-        hipLaunchKernelGGL(k_evb_blend_patch, dim3((w->last_nst + 3) / 4), dim3(256), 0, c->stream, w->last_nst, w->d_stencils.p, gc, dcoef, K, (double*)w->d_grids.p, 2, (const long long*)nullptr, 0LL, (double*)nullptr);
+        hipLaunchKernelGGL(k_evb_blend_patch, dim3((w->last_nst + 3) / 4), dim3(256), 0, c->stream, w->last_nst, w->d_stencils.p, gc, dcoef, K, (double*)w->d_grids.p, 2, (const long long*)nullptr, 0LL, (double*)nullptr, (const long long*)nullptr);
         HIPCHK(hipGetLastError());
         int nbk = 0;
         hipStream_t keep = c->pme_st; c->pme_st = nullptr;      // on the main stream
@@ -1944,48 +1965,67 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   }
   int* h_verdict = (int*)(w->h_flag + 4);
   *h_verdict = 0;
-  // STEP GRAPH (ctx.hpp: StepRec).  A speculative call that neither rebuilds its list nor samples the phase timers enqueues the same operations with the same arguments
-  // as the last such call on this tree: its enqueue part (down to the host's first wait) is captured once and replayed with one hipGraphLaunch.
-  // gmode 1 = this call captures, 2 = this call replays (the host code below runs for its bookkeeping, the wrappers of ctx.hpp issue nothing).
-  // Device-side waits on marks of other streams do not exist inside the graph (its branches are ordered by the captured events' edges).
+  // STEP GRAPH (ctx.hpp: StepRec, LinCap).  A speculative call that neither rebuilds its list nor samples the phase timers enqueues the same operations with the same arguments
+  // as the last such call on this tree: its enqueue part is captured once - every stream as a linear graph of its own, the streams ordered by device-side marks -
+  // and replayed with four hipGraphLaunch calls (~3 us each, profiles/r05_graph_probe.txt).
+  // gmode 3 = this call learns which event records are waited for across streams (nothing issued, the call is repeated), 1 = this call captures (and launches),
+  // 2 = this call replays (the host code below runs for its bookkeeping, the wrappers of ctx.hpp issue nothing and hash what they would have issued).
   if (c->stamps_on < 0) c->stamps_on = getenv("MSEVB_STAMPS") ? 1 : 0;
+  const int fused_nb_in = c->refresh_fused_nb;
   const int gslot = c->refresh_fused_nb > 0 ? 1 : 0;
   EvbWork::StepGraph& G = w->sg[gslot];
   int gmode = 0;
   StepRec grec;
+  LinCap& LC = w->lin;
   const long alloc_epoch0 = g_alloc_epoch;
-  if (c->evb_step_graph && !w->graph_broken && spec && !c->stamps_on && !c->nbr_check_pending && c->flag_verlet_list != 1 && c->list_valid && c->cells_valid &&
-      !(c->timing && (c->timing_tick % c->timing_stride) == 0) && !w->solve_desc_dirty && !w->delta_dirty && !w->dv_dirty && w->d_check.p && c->stream && !c->evb_pair_first && !c->evb_molecules_after_pair /* (evb_defer_molecules = 2 in a capture: hipStreamEndCapture crashes, as with the same-stream wait of ctx.hpp) */ &&
-      // (a blend phase that transforms with rocFFT stays out of the graph: hipStreamEndCapture of this runtime crashes on a capture that holds rocFFT launches on the origin stream
-      //  behind launches of the same plan on a side stream - grids other than 64^3 / 128^3 with the device-side solve; profiles/r05_graph_probe.txt)
-      (fft_lds_usable(c) || !(!c->evb_element_stores && c->n_ranks == 1 && !c->nccl_comm && c->evb_device_solve))) {
+  if (c->evb_step_graph && (c->evb_step_graph >= 2 || !c->nccl_comm) && g_live_contexts.load() == 1 && !w->graph_broken && spec && !c->stamps_on && !c->nbr_check_pending && c->flag_verlet_list != 1 && c->list_valid && c->cells_valid &&
+      !(c->timing && (c->timing_tick % c->timing_stride) == 0) && !w->solve_desc_dirty && !w->delta_dirty && !w->dv_dirty && !w->counters_dirty && w->d_check.p && c->stream && !c->evb_pair_first && !c->evb_molecules_after_pair &&
+      fft_lds_usable(c) /* (rocFFT launches on streams of their own: not inside these captures) */ && w->d_Fdelta.p && w->tabs_uploaded) {
     if (w->graph_skip_once) w->graph_skip_once = false;      // (the call that repeats a mismatched replay)
     else {
       if (w->d_sb.alloc(SB_N)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (step block)");
-      const bool have = G.exec && G.plan_serial == w->plan_serial && G.topo_epoch == c->topo_epoch && G.alloc_epoch == g_alloc_epoch;
-      gmode = have ? 2 : 1;
+      if (!w->d_lin.p) { if (w->d_lin.alloc(4 + 64)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (marks of the linear graphs)"); HIPCHK((hipMemset)(w->d_lin.p, 0, (4 + 64) * sizeof(long long))); HIPCHK(hipDeviceSynchronize()); }
+      const bool have = G.have() && G.plan_serial == w->plan_serial && G.topo_epoch == c->topo_epoch && G.alloc_epoch == g_alloc_epoch;
+      gmode = have ? 2 : (G.learned && G.learn_serial == w->plan_serial && G.learn_topo == c->topo_epoch) ? 1 : 3;
+      if (gmode != 2) {
+        G.drop();
+        LC = LinCap();
+        LC.st[0] = c->stream; LC.st[1] = c->aux; LC.st[2] = w->stream2; LC.st[3] = c->aux3;
+        LC.cnt = w->d_lin.p; LC.marks = w->d_lin.p + 4; LC.fault = c->d_energies.p + S_TIMEOUT;
+        if (gmode == 1) { LC.nev = 0; memcpy(LC.need, G.need, sizeof LC.need); LC.verbose = getenv("MSEVB_GRAPH_DEBUG") && c->evb_graph_captures == 0; }
+      }
       if (gmode == 1) {
-        if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
-        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); w->graph_broken = true; gmode = 0; }
+        int nb = 0;
+        for (; nb < 4; ++nb) if (hipStreamBeginCapture(LC.st[nb], hipStreamCaptureModeRelaxed) != hipSuccess) break;
+        if (nb < 4) {      // this runtime cannot capture here: end what has begun, no further attempts
+          for (int b = 0; b < nb; ++b) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(LC.st[b], &g); if (g) (void)hipGraphDestroy(g); }
+          (void)hipGetLastError(); w->graph_broken = true; gmode = 0;
+        } else for (int b = 0; b < 4; ++b) lin_add_op(LC, b, 0, 0, 0);      // first operation of every chain: the stream's step number advances
       }
     }
   }
   grec.mode = gmode;
-  struct StepScope {      // leaves capture / replay mode on every way out of this function
-    msevb_ctx* c; EvbWork* w; int* gmode;
+  std::vector<std::pair<const void*, unsigned long long>> gtrace;
+  if (gmode && getenv("MSEVB_GRAPH_DEBUG")) grec.trace = &gtrace;
+  struct StepScope {      // leaves learn / capture / replay mode on every way out of this function
+    msevb_ctx* c; EvbWork* w;
     ~StepScope() {
-      if (t_step_rec && t_step_rec->mode == 1) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(c->stream, &g); if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); w->graph_broken = true; }      // an error inside the capture
-      t_step_rec = nullptr; c->step_sb = nullptr;
+      if (t_step_rec && t_step_rec->mode == 1) {      // an error inside the capture
+        for (int b = 0; b < 4; ++b) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(w->lin.st[b], &g); if (g) (void)hipGraphDestroy(g); }
+        (void)hipGetLastError(); w->graph_broken = true;
+      }
+      t_step_rec = nullptr; t_lin = nullptr; c->step_sb = nullptr;
     }
-  } step_scope{c, w, &gmode};
-  if (gmode) { t_step_rec = &grec; c->step_sb = w->d_sb.p; t_step_events.n = 0; }
+  } step_scope{c, w};
+  if (gmode) { t_step_rec = &grec; c->step_sb = w->d_sb.p; t_lin = (gmode == 1 || gmode == 3) ? &LC : nullptr; }
   const long long* const sb = gmode ? w->d_sb.p : (const long long*)nullptr;
-  const hipStream_t gsync = gmode ? c->stream : (hipStream_t)nullptr;
+  const hipStream_t gsync = gmode ? (hipStream_t)-1 : (hipStream_t)nullptr;      // (spin_wait's fall-back when the flag does not come: the whole device - the producers sit in graphs of several streams)
   HIPCHK(hipEventRecord(w->ev_in, c->stream));      // (the first operation of a captured call: every side stream joins the capture through this event)
   HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_in, 0));
   // speculative step with couplings: nothing on the device needs the neighbourhood record, only the host's verdict does - the kernel goes to the
   // coupling stream (idle until the descriptors are refreshed; its chain ends with a mark the energy fetch waits for, so the verdict is
   // in pinned memory before the host looks), and the descriptor chain starts with k_evb_refresh instead of behind 24-37 us of scanning
+  const bool dev_solve_early = !c->evb_element_stores && c->n_ranks == 1 && !c->nccl_comm && c->evb_device_solve, pub_spin_early = c->overlap && c->evb_publish_spin;
   const bool region_aside = spec && !c->evb_region_main && c->evb_region_aside && c->evb_publish_spin && !gmode && w->plan.n_cps > 0;
   if (region_aside) { s_reg = c->aux3; HIPCHK(hipStreamWaitEvent(c->aux3, w->ev_in, 0)); }
   hipLaunchKernelGGL(k_evb_region, dim3((M + 1023) / 1024), dim3(1024), 0, s_reg, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
@@ -2292,7 +2332,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   if (c->overlap) {      // descriptors + special stencils are on the device: the main stream and the off-diagonal chain may use them
     if (c->evb_pair_first && c->ev_pair_done) HIPCHK(hipStreamWaitEvent(ss, c->ev_pair_done, 0));      // (schedule experiment: the diabat chains start behind the pair loop instead of beside it)
     HIPCHK(hipEventRecord(w->ev_fork2, ss));
-    HIPCHK(hipStreamWaitEvent(c->stream, w->ev_fork2, 0));
+    if (!(gmode && dev_solve_early && pub_spin_early)) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_fork2, 0));      // (linear graphs with the device-side solve: all the main chain takes from the descriptors it takes behind the solve's mark, which follows them)
     HIPCHK(hipStreamWaitEvent(c->aux, w->ev_fork2, 0));
   }
   HT(6);
@@ -2322,10 +2362,10 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   HIPCHK(hipGetLastError());
   phase_end(c, PH_EVB_REAL, sr);
   stamp(c, 4, sr);
-  const bool pub_spin = c->overlap && c->evb_publish_spin && !gmode;      // fetch A's publish kernel waits for the chains' marks, not for their events
+  const bool pub_spin = c->overlap && c->evb_publish_spin;      // fetch A's publish kernel waits for the chains' marks, not for their events (inside the linear graphs too: the numbers then come from the step block)
   if (pub_spin) {
     if (!w->d_chain_done.p) { if (w->d_chain_done.alloc(4)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (chain marks)"); HIPCHK(hipMemset(w->d_chain_done.p, 0, 32)); HIPCHK(hipDeviceSynchronize()); }      // (once per context.  hipMemset of device memory may RETURN EARLY and the library's streams do not wait for the null stream: without the synchronisation the fill could land BEHIND the first mark and wipe it - the energy-fetch kernel then sat out its 2 s limit: the intermittent MSEVB_ERR_NUMERIC of round 3, HISTORY.md E; the marks come from different streams)
-    hipLaunchKernelGGL(k_evb_mark, dim3(1), dim3(1), 0, sr, w->d_chain_done.p, w->seq_A + 1);
+    hipLaunchKernelGGL(k_evb_mark, dim3(1), dim3(1), 0, sr, w->d_chain_done.p, gmode ? 0LL : w->seq_A + 1, sb);
   }
   if (c->overlap) HIPCHK(hipEventRecord(w->ev_join2, w->stream2));
   // ---- 6a'. off-diagonal elements (evb_diabatic_coupling, :1021): few, latency-bound kernels writing only d_Foff; on aux2 behind the
@@ -2346,7 +2386,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
                        E_cp_env, w->d_dVspec.p, c->d_Foff.p, n3, d_cpout);
     HIPCHK(hipGetLastError());
     stamp(c, 7, so);
-    if (pub_spin) hipLaunchKernelGGL(k_evb_mark, dim3(1), dim3(1), 0, so, w->d_chain_done.p + 1, w->seq_A + 1);
+    if (pub_spin) hipLaunchKernelGGL(k_evb_mark, dim3(1), dim3(1), 0, so, w->d_chain_done.p + 1, gmode ? 0LL : w->seq_A + 1, sb);
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_cpl, so));
   }
   if (defer_mol) {      // the principal diabat's per-molecule terms: behind the coupling chain on aux3 (they ran in front of it and held it up by ~80 us)
@@ -2412,7 +2452,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       sa.on = 1; sa.method = c->evb_device_solve_method; sa.nref = n_unit_refs;
       sa.sd = (const SolveDesc*)(w->d_desc.p + off_s); sa.unit_idx = (const int*)(w->d_desc.p + off_si); sa.unit_sign = (const double*)(w->d_desc.p + off_ss);
       sa.E = w->d_E.p; sa.e_recip1 = linear ? w->d_Elq.p + 2 * MAX_DIABATS /* zero: the grid energies are differences already */ : c->d_energies.p + S_RECIP;
-      sa.dcoef = w->d_coef.p; sa.out_host = w->h_solve; sa.mark_seq = gmode ? 0 : seqA; sa.done_mark = pub_spin ? w->d_chain_done.p + 3 : (long long*)nullptr;
+      sa.dcoef = w->d_coef.p; sa.out_host = w->h_solve; sa.mark_seq = gmode ? 0 : seqA; sa.sb = sb; sa.done_mark = pub_spin ? w->d_chain_done.p + 3 : (long long*)nullptr;
       sa.done_flag = (volatile long long*)(w->h_flag + 6); sa.done_seq = (++w->seq_S, gmode ? 0LL : w->seq_S); sa.fault = c->d_energies.p + S_TIMEOUT;
     }
     hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), lds, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, gmode ? 0LL : seqA,
@@ -2430,6 +2470,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     if (!c->overlap) CHK(flush_reductions(c));
     if (c->overlap) {      // the reduction of the partial sums goes to the side stream too: the main stream runs from the pair loop straight into the blend phase
       HIPCHK(hipEventRecord(w->ev_flush, c->stream)); HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_flush, 0));
+      if (c->top2_join_pending) { HIPCHK(hipStreamWaitEvent(w->stream2, c->ev_top2, 0)); c->top2_join_pending = false; }
       CHK(flush_range(c, 0, N_SLOTS - 1, w->stream2));
       HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0));      // the principal reciprocal energy slot is reduced on the diabat grid stream (fetch A) ...
       HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_fetchA, 0));      // ... by its publish kernel
@@ -2540,7 +2581,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   if (dev_solve) {      // the blend phase goes out NOW on the main stream, pre-enqueued behind the pair loop: its first kernel starts on the solve kernel's mark - no host turn, no event hop
     if (c->overlap && !pub_spin) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_solve, 0));      // (without device-side marks: one event hop)
     phase_begin(c, PH_EVB_BLEND);
-    w->blend_mark = pub_spin ? w->d_chain_done.p + 3 : nullptr; w->blend_mark_seq = pub_spin ? w->seq_A : 0;      // (no mark, no number: a captured launch's arguments must not change from call to call)
+    w->blend_mark = pub_spin ? w->d_chain_done.p + 3 : nullptr; w->blend_mark_seq = (pub_spin && !gmode) ? w->seq_A : 0;      // (no mark, no number: a captured launch's arguments must not change from call to call)
     w->side_by_mark = pub_spin;      // that mark follows every side chain (and the Q_1 copy) of this call on the grid stream: no event waits in the phase
     const int rc_b = fast_blend_phase(c, w, D, nullptr, grid_of.data(), ngrid, nra, d_ra, w->d_coef.p);
     w->side_by_mark = false; w->blend_mark = nullptr;
@@ -2548,34 +2589,71 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     phase_end(c, PH_EVB_BLEND);
   }
   if (gmode) {
-    // every stream the capture spread to has to be back on the main stream before it can end; in the launched graph these are its last edges
-    if (!w->ev_gjoin[0]) for (int k = 0; k < 3; ++k) HIPCHK(hipEventCreateWithFlags(&w->ev_gjoin[k], hipEventDisableTiming));
-    { const hipStream_t side[3] = {c->aux, w->stream2, c->aux3}; for (int k = 0; k < 3; ++k) { HIPCHK(hipEventRecord(w->ev_gjoin[k], side[k])); HIPCHK(hipStreamWaitEvent(c->stream, w->ev_gjoin[k], 0)); } }
-    t_step_rec = nullptr; c->step_sb = nullptr;
-    if (gmode == 1) {
-      hipGraph_t g = nullptr; hipGraphExec_t ex = nullptr;
-      hipError_t e = hipStreamEndCapture(c->stream, &g);
-      if (e == hipSuccess && g) e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-      if (g) (void)hipGraphDestroy(g);
-      if (e != hipSuccess || !ex) {      // this runtime cannot capture the call: nothing has been issued - the call again, the ordinary way, and no further attempts
-        (void)hipGetLastError(); w->graph_broken = true;
-        fprintf(stderr, "[msevb] hipGraph capture of the MS-EVB force call failed (%s): option step_graph is off for this context\n", hipGetErrorString(e));
-        return MSEVB_RETRY;
-      }
-      G.exec = ex; G.hash = grec.hash; G.n = grec.n; G.plan_serial = w->plan_serial; G.topo_epoch = c->topo_epoch; G.alloc_epoch = g_alloc_epoch; c->evb_graph_captures++;
-    } else if (grec.hash != G.hash || grec.n != G.n || g_alloc_epoch != alloc_epoch0) {
-      // this call would NOT have enqueued what the graph holds (an argument, a launch geometry or a buffer changed): nothing has been issued - drop the graph, repeat the call the ordinary way
-      (void)hipGraphExecDestroy(G.exec); G.exec = nullptr;
-      w->graph_skip_once = true;
-      if (++c->evb_graph_mismatches >= 8) w->graph_broken = true;
+    if (gmode == 3) {      // learn pass: nothing has been issued and the device has not been touched; keep what was learnt, give the one-shot state back, the call again
+      t_step_rec = nullptr; t_lin = nullptr; c->step_sb = nullptr;
+      if (LC.bad) { w->graph_broken = true; if (getenv("MSEVB_GRAPH_DEBUG")) fprintf(stderr, "[msevb] linear capture not possible: %s\n", LC.why ? LC.why : "?"); }
+      else { memcpy(G.need, LC.need, sizeof G.need); G.nev = LC.nev; G.learned = true; G.learn_serial = w->plan_serial; G.learn_topo = c->topo_epoch; }
+      c->refresh_fused_nb = fused_nb_in;
+      rearm.ok = true;
       return MSEVB_RETRY;
     }
+    if (gmode == 1) {
+      // the end of every chain: the side streams leave a final mark each, the main stream waits for the three - whatever follows the call on the main stream
+      // (the integrator's second kernel, the next call's step block) follows all of the call
+      for (int b = 1; b < 4; ++b) { lin_add_op(LC, b, 1, 60 + b, 1); lin_flush(LC, b); }
+      for (int b = 1; b < 4; ++b) lin_add_op(LC, 0, 2, 60 + b, 1);
+      LC.head_open = false;
+      LinOps tail = LC.pend[0]; LC.pend[0].n = 0;      // the main chain's closing waits are NOT captured: the integrator's second kernel performs them (MD loop), or a kernel of their own behind the chain
+      for (int k = 0; k < tail.n; ++k) if (tail.kind[k] != 2) { LC.bad = true; LC.why = "the main chain ends with something other than waits"; }
+      t_step_rec = nullptr; t_lin = nullptr; c->step_sb = nullptr;
+      hipGraph_t g[4] = {nullptr, nullptr, nullptr, nullptr}; hipGraphExec_t ex[4] = {nullptr, nullptr, nullptr, nullptr};
+      const double t_inst0 = now_us();
+      hipError_t e = hipSuccess;
+      for (int b = 0; b < 4; ++b) { const hipError_t eb = hipStreamEndCapture(LC.st[b], &g[b]); if (eb != hipSuccess && e == hipSuccess) e = eb; }
+      size_t nn[4] = {0, 0, 0, 0};
+      for (int b = 0; b < 4 && e == hipSuccess && !LC.bad; ++b) { if (!g[b]) { e = hipErrorUnknown; break; } (void)hipGraphGetNodes(g[b], nullptr, &nn[b]); e = hipGraphInstantiate(&ex[b], g[b], nullptr, nullptr, 0); }
+      for (int b = 0; b < 4; ++b) if (g[b]) (void)hipGraphDestroy(g[b]);
+      if (e != hipSuccess || LC.bad || !ex[3]) {      // this runtime cannot capture the call: nothing has been issued - the call again, the ordinary way, and no further attempts
+        for (int b = 0; b < 4; ++b) if (ex[b]) (void)hipGraphExecDestroy(ex[b]);
+        (void)hipGetLastError(); w->graph_broken = true;
+        fprintf(stderr, "[msevb] hipGraph capture of the MS-EVB force call failed (%s): option step_graph is off for this context\n", LC.bad ? (LC.why ? LC.why : "?") : hipGetErrorString(e));
+        c->refresh_fused_nb = fused_nb_in;
+        return MSEVB_RETRY;
+      }
+      for (int b = 0; b < 4; ++b) G.exec[b] = ex[b];
+      G.head = LC.head; G.tail = tail;
+      G.trace = gtrace;
+      G.hash = grec.hash; G.n = grec.n; G.plan_serial = w->plan_serial; G.topo_epoch = c->topo_epoch; G.alloc_epoch = g_alloc_epoch; c->evb_graph_captures++;
+      if (getenv("MSEVB_GRAPH_DEBUG")) fprintf(stderr, "[msevb] MS-EVB call captured as four linear graphs: nodes %zu %zu %zu %zu (main, grid, descriptor, coupling stream); %d events, %d marks and %d waits in %d one-thread kernels (+ the step-block kernel); end of capture + instantiation %.0f us\n", nn[0], nn[1], nn[2], nn[3], LC.nev, LC.n_marks + 3, LC.n_waits + 3, LC.n_op_kernels, now_us() - t_inst0);
+    } else if (grec.hash != G.hash || grec.n != G.n || g_alloc_epoch != alloc_epoch0) {
+      // this call would NOT have enqueued what the graphs hold (an argument, a launch geometry or a buffer changed): nothing has been issued - drop them, repeat the call the ordinary way
+      t_step_rec = nullptr; t_lin = nullptr; c->step_sb = nullptr;
+      if (getenv("MSEVB_GRAPH_DEBUG")) fprintf(stderr, "[msevb] replay of the captured call differs from the capture (launches %d / %d, allocations %s): call repeated the ordinary way\n", grec.n, G.n, g_alloc_epoch != alloc_epoch0 ? "changed" : "same");
+      if (grec.trace) for (size_t k = 0; k < gtrace.size() && k < G.trace.size(); ++k) if (gtrace[k] != G.trace[k]) {
+        const size_t tag = (size_t)gtrace[k].first;
+        fprintf(stderr, "[msevb]   first difference at operation %zu: %s\n", k, tag < 4096 ? (tag % 16 == 1 ? "event record" : tag % 16 == 2 ? "stream wait" : "fill / copy") : hipKernelNameRefByPtr(gtrace[k].first, c->stream));
+        break;
+      }
+      G.drop(); G.learned = false;
+      w->graph_skip_once = true;
+      ++c->evb_graph_mismatches;
+      if (++w->graph_mismatch_run >= 8) w->graph_broken = true;      // (eight in a row: something in the call changes every time - not worth the dry passes)
+      c->refresh_fused_nb = fused_nb_in;
+      rearm.ok = true;      // (nothing was issued)
+      return MSEVB_RETRY;
+    }
+    t_step_rec = nullptr; t_lin = nullptr; c->step_sb = nullptr;
     StepBlockVals sv; memset(&sv, 0, sizeof sv);
     sv.v[SB_R] = w->seq_R; sv.v[SB_A] = w->seq_A; sv.v[SB_S] = w->seq_S; sv.v[SB_B] = w->seq_B; sv.v[SB_EPOCH] = c->pair_epoch;
-    hipLaunchKernelGGL(k_set_step_block, dim3(1), dim3(64), 0, c->stream, w->d_sb.p, sv);
-    HIPCHK(hipGraphLaunch(G.exec, c->stream));
-    c->evb_graph_launches++;
-    if (!dev_solve) {      // the host's turn follows (Jacobi, blend phase enqueued the ordinary way): the events that phase waits for were only captured - they all lie behind the graph now
+    hipLaunchKernelGGL(k_set_step_block, dim3(1), dim3(64), 0, c->stream, w->d_sb.p, sv, LC.cnt, LC.marks, G.head, LC.fault);      // (every kernel of a side chain that reads the block sits behind a wait for a mark of the main chain)
+    { ApiScope aps(4); for (int b = 0; b < 4; ++b) HIPCHK(hipGraphLaunch(G.exec[b], LC.st[b])); }
+    c->evb_graph_launches++; if (gmode == 2) w->graph_mismatch_run = 0;
+    c->lin_cnt = LC.cnt; c->lin_marks = LC.marks; c->lin_tail = G.tail;
+    if (!c->lin_tail_defer || !dev_solve) {      // nobody downstream will perform them (host-array entry points; a blend phase enqueued by the host behind this): now, as a kernel
+      hipLaunchKernelGGL(k_lg_ops, dim3(1), dim3(64), 0, c->stream, LC.cnt, LC.marks, c->lin_tail, LC.fault);
+      c->lin_tail.n = 0;
+    }
+    if (!dev_solve) {      // the host's turn follows (Jacobi, blend phase enqueued the ordinary way): the events that phase waits for were marks inside the graphs - the main chain ends behind all of them
       hipEvent_t evs[] = {w->ev_side, c->ev_join2, w->ev_join2, w->ev_rs, w->ev_E, w->ev_prefill, w->ev_cpl, w->ev_fetchA, w->ev_fetch, c->ev_join};
       for (hipEvent_t e : evs) if (e) HIPCHK(hipEventRecord(e, c->stream));
     }
@@ -2736,6 +2814,12 @@ int evb_force_energy(msevb_ctx* c, double* epot_out) {
 
 // frees the per-context EVB scratch (called by msevb_destroy while the context's streams still exist)
 void evb_release(msevb_ctx* c) {
+  if (api_prof_on() && c->evb_calls) {
+    static const char* nm[5] = {"kernel launches", "event records", "stream waits", "fill / copy commands", "graph launches"};
+    fprintf(stderr, "[msevb api us per MS-EVB call (count per call)]");
+    for (int k = 0; k < 5; ++k) fprintf(stderr, " %s %.1f (%.1f)", nm[k], g_api_prof.us[k] / c->evb_calls, (double)g_api_prof.n[k] / c->evb_calls);
+    fprintf(stderr, "\n");
+  }
   if (getenv("MSEVB_HOST_TIMING") && g_ht.n) { fprintf(stderr, "[msevb host us/step]"); for (int k = 0; k < 12; ++k) fprintf(stderr, " %d:%.1f", k, g_ht.t[k] / g_ht.n); fprintf(stderr, "\n"); }
   EvbWork* w = (EvbWork*)c->evb_work;
   if (w) {
@@ -2749,9 +2833,9 @@ void evb_release(msevb_ctx* c) {
     if (w->h_desc) (void)hipHostFree(w->h_desc);
     if (w->h_solve) (void)hipHostFree(w->h_solve);
     if (w->h_flag) (void)hipHostFree(w->h_flag);
-    for (auto& g : w->sg) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    for (auto& g : w->sg) g.drop();
     for (hipEvent_t e : w->ev_gjoin) if (e) (void)hipEventDestroy(e);
-    w->d_sb.release(); w->d_ptab.release(); w->d_plan_order.release(); w->d_plan_near.release(); w->d_plan_cnt.release(); w->d_cps_tmp.release(); w->d_plan_shell.release();
+    w->d_sb.release(); w->d_lin.release(); w->d_ptab.release(); w->d_plan_order.release(); w->d_plan_near.release(); w->d_plan_cnt.release(); w->d_cps_tmp.release(); w->d_plan_shell.release();
     if (w->h_plan_sum) (void)hipHostFree(w->h_plan_sum);
     if (w->ev_plan) (void)hipEventDestroy(w->ev_plan);
     w->d_coef.release(); w->d_plan.release(); w->d_sphere.release(); w->d_check.release(); w->d_refresh_scratch.release(); w->d_chain_done.release();

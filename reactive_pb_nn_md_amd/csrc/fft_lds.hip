@@ -81,7 +81,8 @@ __global__ __launch_bounds__(512) void k_fft_xy_fwd(const double* __restrict__ Q
     if (P.wait_mark) {      // (as evb_wait_mark, evb.hip: 2 s limit, then the sticky fault flag)
       if (t == 0) {
         const long long t0 = wall_clock64();
-        while (__hip_atomic_load(P.wait_mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.wait_seq) {      // (relaxed polls, one acquire behind them)
+        const long long want = P.wait_sb ? P.wait_sb[SB_A] : P.wait_seq;
+        while (__hip_atomic_load(P.wait_mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {      // (relaxed polls, one acquire behind them)
           if (wall_clock64() - t0 > 200000000LL) { if (P.fault) *P.fault = 2.0; break; }
           __builtin_amdgcn_s_sleep(8);
         }

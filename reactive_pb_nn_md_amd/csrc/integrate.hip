@@ -189,7 +189,11 @@ __global__ __launch_bounds__(256) void k_step_first_half(int M, int N, double dt
 // second half: one thread per atom - half kick with the |F| > 1e5 guard (:508-529) and the per-block partial sums of momentum and
 // kinetic energy of the kicked velocities (calculate_kinetic_energy, src/total_energy_forces.f90:106)
 __global__ __launch_bounds__(256) void k_step_second_half(int N, double dt, const double* __restrict__ mass, const double* __restrict__ F, double* __restrict__ v,
-                                                          int* __restrict__ bad, double* __restrict__ part, Langevin L, const int* __restrict__ frozen) {
+                                                          int* __restrict__ bad, double* __restrict__ part, Langevin L, const int* __restrict__ frozen,
+                                                          LinOps tail, long long* lin_cnt, long long* lin_marks, double* lin_fault) {
+  // tail: the waits that close the main chain of a force call that went out as linear graphs (ctx.hpp: LinCap) - everything that adds to the force array has finished;
+  // performed here, by every workgroup, instead of by a one-thread kernel of their own between the gather and this kernel (~5 us on the step's critical path)
+  if (tail.n > 0) { if (threadIdx.x == 0) lin_run_ops(tail, lin_cnt, lin_marks, lin_fault); __syncthreads(); }
   __shared__ double red[7][4];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double p[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -298,7 +302,7 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
     c->refresh_fused_nb = fuse ? nbm8 : 0;      // consumed (once) by the force call that follows
     phase_end(c, PH_INTEGRATE);
     double epot = 0.0;
-    if (use_evb) { CHK(evb_force_energy(c, &epot)); }
+    if (use_evb) { c->lin_tail_defer = true; const int rc_f = evb_force_energy(c, &epot); c->lin_tail_defer = false; CHK(rc_f); }
     else {
       CHK(total_force_enqueue(c));
       while (c->nbr_check_pending) {      // rebuild step: the half kick below must not run on forces from a list with a cut row
@@ -309,7 +313,8 @@ extern "C" int msevb_md_integrate_atomic(msevb_ctx* c, int n_steps, double dt, i
     }
     c->refresh_fused_nb = 0;
     L.kick = c->langevin_tick++;
-    hipLaunchKernelGGL(k_step_second_half, dim3(nba), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p, c->d_partials.p, L, frz);
+    LinOps tail = c->lin_tail; c->lin_tail.n = 0;      // (left by a force call that went out as linear graphs: its closing waits ride in this kernel)
+    hipLaunchKernelGGL(k_step_second_half, dim3(nba), dim3(256), 0, c->stream, N, dt, c->d_mass.p, c->d_force.p, c->d_vel.p, d_bad.p, c->d_partials.p, L, frz, tail, c->lin_cnt, c->lin_marks, c->d_energies.p + S_TIMEOUT);
     HIPCHK(hipGetLastError());
     if (!use_evb || s == n_steps - 1) {      // (inside the EVB loop the next step's first kernel does this)
       CHK(reduce_partials(c, S_PX, nba)); CHK(reduce_partials(c, S_PY, nba)); CHK(reduce_partials(c, S_PZ, nba)); CHK(reduce_partials(c, S_KE, nba));

@@ -636,10 +636,12 @@ int nb_build_finish(msevb_ctx* c, bool defer) {
   // Format of THIS build: half list with tile-local entries (the LDS pair kernel, pair.hip) when the largest half neighbourhood the
   // previous build saw (+ 8 %) fits the pair kernel's LDS tile; a build that meets a larger one is repeated (nb_check_overflow).
   auto decide_format = [&]() {
-    const int cap = ((int)(c->half_tile_max * 1.08) + 63) & ~63;
+    int cap = ((int)(c->half_tile_max * 1.08) + 63) & ~63;
+    if (cap < c->half_tile_cap_seen && (size_t)c->half_tile_cap_seen * PAIR_TILE_ATOM_BYTES + (size_t)c->nt * c->nt * sizeof(PairParam) + 2048 <= (size_t)PAIR_TILE_LDS_BYTES) cap = c->half_tile_cap_seen;      // never smaller than a tile this context has used: the pair kernel's launch (pitch, capacity) stays what a captured force call holds (evb.hip, step graph)
     const size_t bytes = (size_t)cap * PAIR_TILE_ATOM_BYTES + (size_t)c->nt * c->nt * sizeof(PairParam) + 2048;
     c->pair_tiles = tile_build_ok && c->pair_tiles_opt != 0 && c->half_tile_max > 0 && bytes <= (size_t)PAIR_TILE_LDS_BYTES && c->cell_atoms_max <= PAIR_CELL_MAX;
     c->half_tile_cap = c->pair_tiles ? cap : 0;
+    if (c->pair_tiles) c->half_tile_cap_seen = cap;
   };
   auto fill = [&](bool want_inline = false) -> int {
     if (c->d_nbr.alloc((size_t)N * c->nbr_cap)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (neighbour list)");

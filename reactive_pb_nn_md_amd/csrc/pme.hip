@@ -1210,7 +1210,8 @@ int pme_gather(msevb_ctx* c, const double2* grid, const double* chg, double* F_r
       const int ncell = c->ncell[0] * c->ncell[1] * c->ncell[2];
       if (!c->weights_valid && c->weights_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_weights, 0));      // (k_pme_weights filled them in on a side stream meanwhile)
       if (!c->weights_valid && !c->weights_side) {      // k_pme_prep_light ran: per workgroup 192 B of LDS per 8-lane group + 48 B per atom of the largest cell
-        const int cap = std::min(std::max((int)(c->cell_atoms_max * 1.05) + 1, 16), 1024);      // (the largest cell of the last build whose statistics the host has seen)
+        int cap = std::min(((std::max((int)(c->cell_atoms_max * 1.05) + 1, 16) + 15) & ~15), 1024);      // (the largest cell of the last build whose statistics the host has seen; in steps of 16 and never smaller than before: the launch stays what a captured force call holds)
+        cap = c->gather_cap_seen = std::max(cap, c->gather_cap_seen);
         // 256 threads (32 atoms per trip) when the cells hold <= 256 atoms: 49 KB of LDS per workgroup, three per CU - all 729 workgroups of configs[2] resident at once instead of
         // 1.4 rounds of two 512-thread ones (0.4021 against 0.4121 ms per step; 320 and 384 threads: 0.4209 / 0.4170 - HISTORY.md E)
         const int gthreads = c->pme_gather_threads > 0 ? c->pme_gather_threads : (c->cell_atoms_max <= 256 ? 256 : c->pme_tile_threads);
@@ -1259,7 +1260,7 @@ int pme_front(msevb_ctx* c, int slot_recip, bool join_aux) {
   bool capturing = false;
   int nbk = 0;
   if (use_graph && c->pme_graph_exec && memcmp(&key, c->pme_graph_key, sizeof key) == 0) {
-    HIPCHK(hipGraphLaunch((hipGraphExec_t)c->pme_graph_exec, st));
+    { ApiScope aps(4); HIPCHK(hipGraphLaunch((hipGraphExec_t)c->pme_graph_exec, st)); }
     nbk = c->pme_graph_nbk;
   } else {
     if (use_graph) {

@@ -97,6 +97,29 @@ def test_evb_from_scratch_equals_reference_delta(oracle_lib, name):
     assert abs(np.linalg.norm(r["eigvec"]) - 1.0) < 1e-12
 
 
+@pytest.mark.parametrize("name", all_golden("evb_"))
+def test_evb_delta_update_formulation(oracle_lib, name):
+    """The oracle's SECOND formulation of the call - the reference's own delta update (ms_evb_diabat_force_energy, src/ms_evb.f90:1421-1560: donor / acceptor
+    molecules out in the principal topology and in in the diabat's, all-atom scans, modify_Q_grid on a copy of the principal grid, one reciprocal-space pass per
+    diabat :1962-2090), which is what bench.py times as the CPU baseline - against the real reference's Hamiltonian, adiabatic energy / force and per-element force
+    stores, and against the from-scratch formulation."""
+    g = golden(name)
+    o = oracle_lib.Oracle(system.from_golden(g))
+    o.verlet_build()
+    r = o.evb(delta=True)
+    Href = g["evb_hamiltonian"]
+    assert r["D"] == int(g["n_diabat"][0])
+    assert np.abs(r["H"] - Href).max() < 1e-12 * np.abs(Href).max()
+    assert abs(r["E"] - g["E_adiabatic"][0]) < 1e-12 * abs(r["E"]) and np.abs(r["F"] - g["F_adiabatic"]).max() < 1e-9
+    if "evb_forces_store" in g:
+        lk, st = g["evb_forces_lookup_index"], g["evb_forces_store"]
+        for i in range(r["D"]):
+            if lk[i, i] > 0:
+                assert np.abs(r["F_diag"][i] - st[lk[i, i] - 1]).max() < 1e-9, i
+    f = o.evb()
+    assert np.abs(f["H"] - r["H"]).max() < 1e-12 * np.abs(Href).max() and np.abs(f["F"] - r["F"]).max() < 1e-10 and np.abs(f["F_diag"] - r["F_diag"]).max() < 1e-10
+
+
 @pytest.mark.parametrize("name,evb", [("md_std_n6_s4", False), ("md_evb_n6_d2_s5", True), ("md_std_n6_frz_s14", False),
                                       ("md_std_n6_rebuild_s21", False), ("md_evb_n6_d4_rebuild_s24", True), ("md_evb_n6_d4_drop_s22", True),
                                       ("md_evb_n12_d4_s29", True)])

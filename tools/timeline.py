@@ -6,8 +6,10 @@ f = glob.glob(os.path.join(d, "kt", "**", "*results.db"), recursive=True)[0]
 c = sqlite3.connect(f)
 rows = c.execute("select name,start,end,stream_id from kernels order by start").fetchall() if False else None
 cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
-q = "select name,start,end from kernels order by start"
+qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+q = "select name,start,end,%s from kernels order by start" % qcol
 rows = c.execute(q).fetchall()
+qmap = {}
 def short(n): return n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:38]
 # steps are delimited by k_evb_blend launches
 blend = [i for i, r in enumerate(rows) if "k_evb_blend" in r[0]]
@@ -15,6 +17,15 @@ a, b = blend[-3], blend[-2]          # one full step between two blends (skip th
 if len(sys.argv) > 2 and sys.argv[2] == "rebuild":      # the last complete step that rebuilt the Verlet list
     for k in range(len(blend) - 2, 0, -1):
         if any("k_neighbors" in r[0] for r in rows[blend[k - 1]:blend[k] + 1]):
+            a, b = blend[k - 1], blend[k]
+            break
+if len(sys.argv) > 2 and sys.argv[2] in ("graph", "direct"):      # the last complete step without a rebuild that went out as linear graphs (k_lg_tick inside) / as stream launches
+    want = sys.argv[2] == "graph"
+    for k in range(len(blend) - 2, 0, -1):
+        names = [r[0] for r in rows[blend[k - 1]:blend[k] + 1]]
+        if any("k_neighbors" in n for n in names) or len(names) < 20:
+            continue
+        if any("k_lg_tick" in n for n in names) == want:
             a, b = blend[k - 1], blend[k]
             break
 seg = rows[a:b + 1]
@@ -33,4 +44,4 @@ for g in sorted(gaps, reverse=True)[:14]:
     print("  gap %7.1f us at t=%7.1f  after %-38s before %s" % (g[0] / 1e3, g[3], g[1], g[2]))
 print("-- sequence --")
 for r in seg:
-    print("%8.1f %8.1f  %s" % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, short(r[0])))
+    print("%8.1f %8.1f  q%d  %s" % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, qmap.setdefault(r[3], len(qmap)), short(r[0])))

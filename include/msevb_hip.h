@@ -170,6 +170,8 @@ int msevb_calculate_kinetic_energy(msevb_ctx* ctx, double* kinetic_energy);   /*
 int msevb_comm_unique_id(void* id_bytes_128);                                       /* ncclGetUniqueId */
 int msevb_comm_init(msevb_ctx* ctx, const void* id_bytes_128, int rank, int n_ranks); /* ncclCommInitRank (RCCL) */
 int msevb_comm_set_virtual(msevb_ctx* ctx, int rank, int n_ranks);   /* shard without a communicator (tests) */
+int msevb_comm_set_virtual_payload(msevb_ctx* ctx, const double* payloads, int n_doubles);   /* virtual rank: the n_ranks payloads (msevb_evb_payload_pack) an all-gather would deliver - the rank then runs the device-side solve and the pre-enqueued blend of a rank with a communicator (src/ms_evb.f90:242-330 on the gathered Hamiltonian); tests, tools/virtual_rank_times.py */
+int msevb_comm_get_payload(msevb_ctx* ctx, double* payloads, int n_doubles);   /* the all-gather buffer as it is on the device (this rank's slot: what its energy-fetch kernel assembled, src/ms_evb.f90:375-486 for its diabats); tests play the all-gather between virtual ranks with it */
 /* payload of the per-step all-gather as context-free functions (no GPU): P = msevb_evb_payload_size doubles per rank = {H_dd, H_pd} of the
    rank's diabats, H'_11, eight principal energy slots; hamiltonian is D x D row-major (upper triangle), parent[d] 0-based.  Used by the
    library's own RCCL exchange and by the CPU (gloo) test of the protocol */

@@ -369,6 +369,20 @@ class MsEvbHip:
     def comm_set_virtual(self, rank, n_ranks):
         self._chk(self.L.msevb_comm_set_virtual(self.ctx, int(rank), int(n_ranks)))
 
+    def comm_get_payload(self, n_doubles):
+        a = np.zeros(int(n_doubles))
+        self._chk(self.L.msevb_comm_get_payload(self.ctx, _dp(a), int(n_doubles)))
+        return a
+
+    def evb_payload_size(self, n_diabat, n_ranks):
+        return int(self.L.msevb_evb_payload_size(int(n_diabat), int(n_ranks)))
+
+    def comm_set_virtual_payload(self, payloads):
+        """virtual rank: the n_ranks payloads (evb_payload_pack) a real all-gather would deliver, in rank order; the rank then solves the gathered Hamiltonian on the
+        device and blends its share without the caller (None / empty: back to the caller-merged mode)"""
+        a = np.ascontiguousarray(payloads if payloads is not None else [], dtype=np.float64).ravel()
+        self._chk(self.L.msevb_comm_set_virtual_payload(self.ctx, _dp(a) if a.size else None, int(a.size)))
+
     def set_option(self, name, value):
         self._chk(self.L.msevb_set_option(self.ctx, name.encode(), C.c_double(value)))
 

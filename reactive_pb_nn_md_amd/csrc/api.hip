@@ -666,10 +666,22 @@ int msevb_intra_molecular_energy_force(msevb_ctx* c, double* e) {
 }
 
 __global__ void k_stamp(unsigned long long* out) { *out = wall_clock64(); }
+// fixed-address set: stamp 0 also accumulates the time since the PREVIOUS call's blend end (slot 9) in slots 13 / 14 - the part of an MD step that lies between two force calls
+__global__ void k_stamp0_fixed(unsigned long long* h) { const unsigned long long t = wall_clock64(); if (h[9] && t > h[9] && t - h[9] < 100000ull) { h[13] += t - h[9]; h[14] += 1; } h[0] = t; }
 void stamp(msevb_ctx* c, int idx, hipStream_t st) {
-  if (c->stamps_on < 0) c->stamps_on = getenv("MSEVB_STAMPS") ? 1 : 0;
+  if (c->stamps_on < 0) { const char* e = getenv("MSEVB_STAMPS"); c->stamps_on = e ? (e[0] == '2' ? 2 : 1) : 0; }      // 2: ONE set of stamps at fixed addresses - the launches are the same every step, so they can sit inside the linear step graphs
   if (!c->stamps_on) return;
   if (!c->h_stamps) { if (hipHostMalloc((void**)&c->h_stamps, 4 * 16 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { c->stamps_on = 0; return; } memset(c->h_stamps, 0, 512); }
+  if (c->stamps_on == 2) {
+    if (idx == 0 && !(t_step_rec && t_step_rec->mode == 3)) {      // (host side, once per call: the set the previous call left is complete - the host has waited for its energies since)
+      unsigned long long* old = c->h_stamps;
+      bool ok = old[0] && old[9] > old[2] && old[2] > old[1] && old[1] >= old[0] && old[1] - old[0] < 12000ull;
+      for (int k = 1; k < 11 && ok; ++k) if (old[k] && (old[k] < old[0] || old[k] - old[0] > 100000ull)) ok = false;
+      if (ok) { for (int k = 1; k < 16; ++k) if (old[k] >= old[0]) c->stamp_sum[k] += (double)(old[k] - old[0]) * 0.01; c->stamp_n++; }
+    }
+    if (idx == 0) hipLaunchKernelGGL(k_stamp0_fixed, dim3(1), dim3(1), 0, st, c->h_stamps); else hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, st, c->h_stamps + idx);
+    return;
+  }
   if (idx == 0) {      // a ring of four stamp sets: the set written two steps ago is complete by now
     c->stamp_step++;
     unsigned long long* old = c->h_stamps + 16 * ((c->stamp_step + 2) & 3);
@@ -682,10 +694,11 @@ void stamp(msevb_ctx* c, int idx, hipStream_t st) {
   hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, st, c->h_stamps + 16 * (c->stamp_step & 3) + idx);
 }
 void stamps_report(msevb_ctx* c) {
-  if (c->stamps_on != 1 || !c->stamp_n) return;
+  if (c->stamps_on < 1 || !c->stamp_n) return;
   const char* nm[16] = {"step start", "pair start", "pair end", "spec_prep start", "env chain end", "grid chain start", "grid chain end", "coupling chain end", "blend phase start", "blend end", "fetch A published", "", "", "", "", ""};
   fprintf(stderr, "[msevb gpu stamps, us after stamp 0, %ld steps]", c->stamp_n);
   for (int k = 1; k < 11; ++k) fprintf(stderr, " %s %.0f |", nm[k], c->stamp_sum[k] / c->stamp_n);
+  if (c->stamps_on == 2 && c->h_stamps[14]) fprintf(stderr, " between the blend end of a call and stamp 0 of the next %.1f us (%llu pairs of calls)", (double)c->h_stamps[13] * 0.01 / (double)c->h_stamps[14], c->h_stamps[14]);
   fprintf(stderr, "\n");
 }
 
@@ -864,6 +877,7 @@ int msevb_set_option(msevb_ctx* c, const char* name, double v) {
   if (s == "spread_mfma") { c->spread_mfma = v != 0.0; return MSEVB_OK; }
   if (s == "gather_mfma") { c->gather_mfma = v != 0.0; return MSEVB_OK; }
   if (s == "evb_pair_first") { c->evb_pair_first = v != 0.0; return MSEVB_OK; }
+  if (s == "evb_device_solve_ranks") { c->evb_device_solve_ranks = v != 0.0; return MSEVB_OK; }      // more than one rank: 1 = solve on the device behind the all-gather, blend and all-reduce pre-enqueued; 0 = the host's Jacobi between the collectives
   if (s == "evb_pme_split") { c->evb_pme_split = v != 0.0; return MSEVB_OK; }
   if (s == "evb_publish_spin") { c->evb_publish_spin = v != 0.0; return MSEVB_OK; }
   if (s == "evb_region_aside") { c->evb_region_aside = v != 0.0; return MSEVB_OK; }

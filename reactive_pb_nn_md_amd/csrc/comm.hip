@@ -132,6 +132,30 @@ int msevb_comm_allgather_evb(msevb_ctx* c, int with_energies) {
   return MSEVB_OK;
 }
 
+// Device-to-device variants for the path on which the Hamiltonian is solved on the device (evb.hip, dev_solve_mr): nothing is staged through the host and the
+// host does not wait - the collectives are enqueued with the step.  Order of the call's collectives on every rank: all-gather (grid stream, behind the energy-fetch
+// kernel that wrote this rank's slot), all-reduce of the energy slots (descriptor stream, behind their reductions), all-reduce of the forces (main stream, behind the blend).
+}  // extern "C"
+namespace {
+__global__ void k_comm_e8_pack(const double* __restrict__ slots, double* __restrict__ out, int zero_recip) {      // S_ELEC_PAIR .. S_RECIP are contiguous; the replicated reciprocal term counts on rank 0
+  const int k = threadIdx.x;
+  if (k < 8) out[k] = (zero_recip && k == S_RECIP - S_ELEC_PAIR) ? 0.0 : slots[S_ELEC_PAIR + k];
+}
+}  // namespace
+int msevb_comm_allgather_device(msevb_ctx* c, int P, hipStream_t st) {
+  if (!c || !c->nccl_comm) return MSEVB_OK;
+  if (ncclAllGather(c->d_comm_h.p + (size_t)c->rank * P, c->d_comm_h.p, (size_t)P, ncclDouble, (ncclComm_t)c->nccl_comm, st) != ncclSuccess) FAIL(MSEVB_ERR_COMM, "ncclAllGather failed");
+  return MSEVB_OK;
+}
+int msevb_comm_allreduce_e8_device(msevb_ctx* c, hipStream_t st) {
+  if (!c || !c->nccl_comm) return MSEVB_OK;
+  if (c->d_comm_e.alloc(8)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (comm)");
+  hipLaunchKernelGGL(k_comm_e8_pack, dim3(1), dim3(64), 0, st, (const double*)c->d_energies.p, c->d_comm_e.p, c->rank != 0 ? 1 : 0);
+  if (ncclAllReduce(c->d_comm_e.p, c->d_comm_e.p, 8, ncclDouble, ncclSum, (ncclComm_t)c->nccl_comm, st) != ncclSuccess) FAIL(MSEVB_ERR_COMM, "ncclAllReduce failed");
+  return MSEVB_OK;
+}
+extern "C" {
+
 // Stand-alone sum of the eight principal energy slots over the ranks (the EVB force call itself carries them in its all-gather).
 int msevb_comm_allreduce_energies(msevb_ctx* c) {
   if (!c || !c->nccl_comm) return MSEVB_OK;
@@ -162,6 +186,7 @@ void msevb_comm_release(msevb_ctx* c) {
   c->nccl_comm = nullptr;
   if (c->h_comm) { (void)hipHostFree(c->h_comm); c->h_comm = nullptr; c->h_comm_cap = 0; }
   if (c->h_comm_flag) { (void)hipHostFree(c->h_comm_flag); c->h_comm_flag = nullptr; }
+  if (c->h_comm_e8) { (void)hipHostFree(c->h_comm_e8); c->h_comm_e8 = nullptr; }
 }
 
 }  // extern "C"

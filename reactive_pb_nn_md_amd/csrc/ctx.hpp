@@ -86,11 +86,13 @@ struct LinOps { int n = 0; int kind[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int slot[8] =
 struct LinCap {
   hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
   long long* cnt = nullptr; long long* marks = nullptr; double* fault = nullptr;      // device: cnt[4], marks[64]; the sticky time-out flag (S_TIMEOUT)
-  int nev = 0; hipEvent_t ev[60]; int ev_stream[60]; int ev_ord[60];
+  int nev = 0; hipEvent_t ev[60]; int ev_stream[60]; int ev_ord[60]; int ev_kpos[60];      // ev_kpos: kernels the recording stream had been given when the (latest) record was made
+  int kcount[4] = {0, 0, 0, 0}; int waited_kpos[4][4];      // per stream: kernels given so far; per (waiting, producing) stream: the latest position already waited for - a wait for an earlier position of the same stream adds nothing
   unsigned long long need[60];      // bit `ord` of need[slot]: that record of the event is waited for by another stream (learn pass -> capture pass)
   LinOps pend[4];                   // operations a stream has collected since its last kernel
   bool head_open = true; LinOps head;      // the main stream's operations in front of its first kernel: not captured - the step-block kernel, launched in front of the main chain at every replay, performs them
   bool bad = false, verbose = false; const char* why = nullptr; int n_marks = 0, n_waits = 0, n_op_kernels = 0;
+  LinCap() { for (auto& r : waited_kpos) for (int& v : r) v = -1; }
   int stream_index(hipStream_t s) const { for (int b = 0; b < 4; ++b) if (st[b] == s) return b; return -1; }
   int slot_of(hipEvent_t e) const { for (int k = 0; k < nev; ++k) if (ev[k] == e) return k; return -1; }
 };
@@ -119,6 +121,7 @@ inline void lin_flush(LinCap& L, int b) {      // what a stream has collected, a
   if (b == 0 && L.head_open) { L.head = L.pend[0]; L.head_open = false; L.pend[0].n = 0; return; }      // (performed by the step-block kernel)
   LinOps a = L.pend[b];
   L.pend[b].n = 0; L.n_op_kernels++;
+  if (L.verbose) { fprintf(stderr, "[msevb]   chain %d: ops", b); for (int k = 0; k < a.n; ++k) fprintf(stderr, " %s%d", a.kind[k] == 0 ? "tick" : a.kind[k] == 1 ? "mark e" : "wait e", a.kind[k] ? a.slot[k] : 0); fprintf(stderr, "\n"); }
   k_lg_ops<<<dim3(1), dim3(64), 0, L.st[b]>>>(L.cnt + b, L.marks, a, L.fault);
 }
 inline void lin_add_op(LinCap& L, int b, int kind, int slot, int ord) {
@@ -143,8 +146,9 @@ inline void step_launch(K kern, dim3 grid, dim3 block, size_t shm, hipStream_t s
     (step_hash_one(*r, a), ...);
     r->n++;
     if (r->trace) r->trace->push_back({fn, r->hash});
+    if (t_lin && (r->mode == 1 || r->mode == 3)) { const int b_ = t_lin->stream_index(st); if (b_ >= 0) t_lin->kcount[b_]++; }
     if (r->mode >= 2) return;
-    if (r->mode == 1) lin_before_op(st);
+    if (r->mode == 1) { lin_before_op(st); if (t_lin && t_lin->verbose) fprintf(stderr, "[msevb]   chain %d: %s\n", t_lin->stream_index(st), hipKernelNameRefByPtr(fn, st)); }
   }
   ApiScope aps(0);
   kern<<<grid, block, shm, st>>>(std::forward<A>(a)...);
@@ -165,7 +169,7 @@ inline hipError_t step_event_record(hipEvent_t e, hipStream_t s) {
     int k = L->slot_of(e);
     if (k < 0 && L->nev < 60) { k = L->nev++; L->ev[k] = e; L->ev_ord[k] = 0; if (t_step_rec->mode == 3) L->need[k] = 0; }
     if (b < 0 || k < 0 || L->ev_ord[k] >= 62) { L->bad = true; L->why = "event table of the linear capture"; return hipSuccess; }
-    L->ev_stream[k] = b; L->ev_ord[k]++;
+    L->ev_stream[k] = b; L->ev_ord[k]++; L->ev_kpos[k] = L->kcount[b];
 #ifdef __HIPCC__
     if (t_step_rec->mode == 1 && ((L->need[k] >> L->ev_ord[k]) & 1ull)) { L->n_marks++; lin_add_op(*L, b, 1, k, L->ev_ord[k]); }
 #endif
@@ -183,11 +187,11 @@ inline hipError_t step_stream_wait(hipStream_t s, hipEvent_t e, unsigned f) {
     if (b < 0) { L->bad = true; L->why = "a wait on a stream outside the call's four"; return hipSuccess; }
     if (k < 0) { L->bad = true; L->why = "a wait for an event that was not recorded inside the call"; return hipSuccess; }
     if (L->ev_stream[k] == b) return hipSuccess;      // same stream: stream order
+    { int& wk = L->waited_kpos[b][L->ev_stream[k]]; if (L->ev_kpos[k] <= wk) return hipSuccess; wk = L->ev_kpos[k]; }      // this stream already waits for a record the producer made at the same point of its chain or later
     if (t_step_rec->mode == 3) { L->need[k] |= 1ull << L->ev_ord[k]; return hipSuccess; }
 #ifdef __HIPCC__
     lin_add_op(*L, b, 2, k, L->ev_ord[k]); L->n_waits++;
 #endif
-    if (L->verbose) fprintf(stderr, "[msevb]   stream %d waits for event %d (record %d, made on stream %d)\n", b, k, L->ev_ord[k], L->ev_stream[k]);
     return hipSuccess;
   }
   if (skip) return hipSuccess;
@@ -195,9 +199,10 @@ inline hipError_t step_stream_wait(hipStream_t s, hipEvent_t e, unsigned f) {
   return (hipStreamWaitEvent)(s, e, f);
 }
 #ifdef __HIPCC__
-inline hipError_t step_memset_async(void* p, int v, size_t n, hipStream_t s) { if (step_skip(3 + 16 * (v & 0xff), p, s, n)) return hipSuccess; lin_before_op(s); ApiScope aps(3); return (hipMemsetAsync)(p, v, n, s); }
-inline hipError_t step_memset_d32_async(hipDeviceptr_t p, int v, size_t n, hipStream_t s) { if (step_skip(4 + 16 * v, (const void*)p, s, n)) return hipSuccess; lin_before_op(s); ApiScope aps(3); return (hipMemsetD32Async)(p, v, n, s); }
-inline hipError_t step_memcpy_async(void* d, const void* src, size_t n, hipMemcpyKind k, hipStream_t s) { if (step_skip(5 + 16 * (int)k, d, src, n)) return hipSuccess; lin_before_op(s); ApiScope aps(3); return (hipMemcpyAsync)(d, src, n, k, s); }
+inline void lin_count(hipStream_t s) { if (t_lin && t_step_rec && (t_step_rec->mode == 1 || t_step_rec->mode == 3)) { const int b = t_lin->stream_index(s); if (b >= 0) t_lin->kcount[b]++; } }      // (fills and copies are positions of a chain like kernels)
+inline hipError_t step_memset_async(void* p, int v, size_t n, hipStream_t s) { lin_count(s); if (step_skip(3 + 16 * (v & 0xff), p, s, n)) return hipSuccess; lin_before_op(s); ApiScope aps(3); return (hipMemsetAsync)(p, v, n, s); }
+inline hipError_t step_memset_d32_async(hipDeviceptr_t p, int v, size_t n, hipStream_t s) { lin_count(s); if (step_skip(4 + 16 * v, (const void*)p, s, n)) return hipSuccess; lin_before_op(s); ApiScope aps(3); return (hipMemsetD32Async)(p, v, n, s); }
+inline hipError_t step_memcpy_async(void* d, const void* src, size_t n, hipMemcpyKind k, hipStream_t s) { lin_count(s); if (step_skip(5 + 16 * (int)k, d, src, n)) return hipSuccess; lin_before_op(s); ApiScope aps(3); return (hipMemcpyAsync)(d, src, n, k, s); }
 #else
 inline hipError_t step_memset_async(void* p, int v, size_t n, hipStream_t s) { if (step_skip(3 + 16 * (v & 0xff), p, s, n)) return hipSuccess; return (hipMemsetAsync)(p, v, n, s); }
 inline hipError_t step_memset_d32_async(hipDeviceptr_t p, int v, size_t n, hipStream_t s) { if (step_skip(4 + 16 * v, (const void*)p, s, n)) return hipSuccess; return (hipMemsetD32Async)(p, v, n, s); }
@@ -579,9 +584,13 @@ struct msevb_ctx {
   // (profiles/r05_graph_probe.txt) - so the replay saves no host time, and the graph's branches cannot use the device-side marks (3 % of the step)
   bool top2_join_pending = false;      // k_top2_final ran on aux3 and the main stream did not wait for it: whoever publishes the displacement maxima does
   LinOps lin_tail; long long* lin_cnt = nullptr; long long* lin_marks = nullptr; bool lin_tail_defer = false;      // closing waits of a force call that went out as linear graphs: performed by the integrator's second kernel (MD loop: lin_tail_defer) or by a one-thread kernel at the end of the call
-  int evb_step_graph = 1; const long long* step_sb = nullptr; long evb_graph_launches = 0, evb_graph_captures = 0, evb_graph_mismatches = 0;
+  int evb_step_graph = 0;      // option step_graph (off by default: on one GPU the one-thread kernels that order the chains cost more than the host time saved)
+  const long long* step_sb = nullptr; long evb_graph_launches = 0, evb_graph_captures = 0, evb_graph_mismatches = 0;
   void* evb_work = nullptr;            // EvbWork of evb.hip (created by the first EVB force call, freed by evb_release)
   DBuf<double> d_comm_h, d_comm_e;     // staging of the Hamiltonian all-gather / the energy all-reduce (comm.hip)
+  bool evb_device_solve_ranks = true;      // option: with more than one rank the Hamiltonian is solved on the device behind the all-gather and blend + all-reduce are pre-enqueued (0: host Jacobi, round 4's path)
+  std::vector<double> virt_payload; bool virt_payload_dirty = false;      // virtual ranks: the R payloads a real all-gather would deliver (msevb_comm_set_virtual_payload)
+  double* h_comm_e8 = nullptr; bool attr_evb_solve_g = false;      // pinned: the summed principal energy slots (device-side all-reduce)
   double* h_comm = nullptr; size_t h_comm_cap = 0; long long* h_comm_flag = nullptr; long long comm_seq = 0;      // pinned staging of the per-step all-gather (comm.hip)
   DBuf<int> d_bad;                     // 'force too large' flag of the integrator (integrate.hip)
   double* h_ke = nullptr; int h_ke_cap = 0;      // pinned kinetic-energy records of msevb_md_integrate_atomic

@@ -983,6 +983,11 @@ struct SolveArgs {
   const long long* sb;                                    // a captured launch: the mark's number is sb[SB_A]
   volatile long long* done_flag; long long done_seq;      // pinned flag the host spins on
   double* fault;
+  // MORE THAN ONE RANK (diabats sharded): phase 1 (inside the energy-fetch kernel) assembles the Hamiltonian entries of THIS rank's diabats and writes them
+  // into the rank's slot of the all-gather payload (layout of msevb_evb_payload_pack, comm.hip: {H_dd, H_pd} per slot, then H'_11); phase 2 (k_evb_solve_gathered, behind the
+  // all-gather on the same stream) builds H' from the R gathered payloads - the same bytes on every rank -, finds the ground state and writes the coefficients of the rank's
+  // own blend terms.  phase 0: one rank, everything in one go.
+  int phase, R, rank, S, P; double* payload;
 };
 // the descriptor is static for the call: the kernels stage it in LDS BEFORE they wait for the energies (a dozen dependent global loads, ~1 us each, used to sit
 // between the last energy and the blend phase's start)
@@ -1015,8 +1020,10 @@ __device__ __forceinline__ void evb_solve_body(const SolveArgs& sa, const SolveS
   const int nref = sd->unit_off[n];
   for (int q = tid; q < nref; q += nth) { const int iu = q < SOLVE_PRE ? stg->ui[q] : unit_idx[q]; contrib[q] = (q < SOLVE_PRE ? stg->us[q] : unit_sign[q]) * (E[iu] + E[nu + iu]); }
   __syncthreads();
+  const int phase = sa.phase, R = sa.R > 0 ? sa.R : 1;
   for (int d = tid; d < n; d += nth) {
     if (d == 0) { const int iu = sd->unit00; A[0] = sd->Hp_norep + sd->once * (E[iu] + E[nu + iu]); }
+    else if (phase != 0 && (d - 1) % R != sa.rank) continue;      // another rank's diabat: its entries come with the all-gather
     else {
       double e = sd->e_hyd + sd->eref_delta[d];
       for (int q = sd->unit_off[d]; q < sd->unit_off[d + 1]; ++q) e += contrib[q];
@@ -1029,6 +1036,23 @@ __device__ __forceinline__ void evb_solve_body(const SolveArgs& sa, const SolveS
     }
   }
   __syncthreads();
+  if (phase == 1) {      // this rank's slot of the payload; the solve follows the all-gather (k_evb_solve_gathered)
+    double* mine = sa.payload + (size_t)sa.rank * sa.P;
+    for (int k = tid; k < sa.P; k += nth) mine[k] = 0.0;
+    __syncthreads();
+    for (int d = 1 + tid; d < n; d += nth) if ((d - 1) % R == sa.rank) { const int s = (d - 1) / R; mine[2 * s] = A[d * n + d]; mine[2 * s + 1] = A[sd->parent[d] * n + d]; }
+    if (tid == 0) mine[2 * sa.S] = A[0];
+    return;
+  }
+  if (phase == 2) {      // the other ranks' entries (and H'_11 as rank 0 has it: every rank then holds the same matrix, bit for bit)
+    for (int d = 1 + tid; d < n; d += nth) {
+      const int r = (d - 1) % R, s = (d - 1) / R, p = sd->parent[d];
+      const double hdd = sa.payload[(size_t)r * sa.P + 2 * s], hpd = sa.payload[(size_t)r * sa.P + 2 * s + 1];
+      A[d * n + d] = hdd; A[p * n + d] = hpd; A[d * n + p] = hpd;
+    }
+    if (tid == 0) A[0] = sa.payload[2 * sa.S];
+    __syncthreads();
+  }
   for (int k = tid; k < n * n; k += nth) out_host[2 + 2 * n + k] = (k / n <= k % n) ? A[k] : 0.0;      // H' as the host assembles it (upper triangle)
   int status = -1;
   int gfast = -1; double efast = 0.0;
@@ -1582,8 +1606,18 @@ __global__ void k_evb_publish(const double* a, int na, double* __restrict__ ha, 
   for (int k = threadIdx.x; k < nb; k += blockDim.x) hb[k] = b[k];
   if (flag || (sa.on && sa.done_flag)) {
     __threadfence_system(); __syncthreads();
-    if (threadIdx.x == 0) { if (flag) *flag = sb ? sb[sb_flag] : seq; if (sa.on && sa.done_flag) *sa.done_flag = sb ? sb[SB_S] : sa.done_seq; }
+    if (threadIdx.x == 0) { if (flag) *flag = sb ? sb[sb_flag] : seq; if (sa.on && sa.done_flag && sa.phase != 1) *sa.done_flag = sb ? sb[SB_S] : sa.done_seq; }
   }
+}
+
+// more than one rank: Hamiltonian from the gathered payloads, ground state, this rank's blend coefficients (phase 2 of evb_solve_body), on the stream of the all-gather
+// right behind it; the blend phase on the main stream starts on its mark, the host reads eigenvector and H' from pinned memory behind its flag
+__global__ __launch_bounds__(256) void k_evb_solve_gathered(const SolveArgs sa, const long long* __restrict__ sb) {
+  __shared__ SolveStage s_sd;
+  evb_solve_stage(sa, &s_sd);
+  __syncthreads();
+  evb_solve_body(sa, &s_sd);
+  if (sa.done_flag) { __threadfence_system(); __syncthreads(); if (threadIdx.x == 0) *sa.done_flag = sb ? sb[SB_S] : sa.done_seq; }
 }
 
 // step graph: the numbers of THIS call, set on the main stream right in front of the graph launch (by-value arguments of an ordinary launch)
@@ -1658,7 +1692,7 @@ struct EvbWork {   // persistent device scratch of one context
   PlanTables ptab; std::vector<int> region_order; std::vector<PlanFrame> plan_frames; PlanWork plan_work;
   // ... on the device (k_evb_plan): tables, scratch, the summary in pinned memory; solve_desc_dirty: the host-built part of the descriptor block (SolveDesc) has to follow the device-built one
   DBuf<PlanTables> d_ptab; PlanTables ptab_dev; bool ptab_dev_valid = false; DBuf<int> d_plan_order, d_plan_near, d_plan_cnt, d_plan_shell; DBuf<CouplingDesc> d_cps_tmp;
-  PlanSummary* h_plan_sum = nullptr; long long seq_P = 0; hipEvent_t ev_plan = nullptr; bool solve_desc_dirty = false, device_plan_off_once = false;
+  PlanSummary* h_plan_sum = nullptr; long long seq_P = 0; hipEvent_t ev_plan = nullptr; bool solve_desc_dirty = false, solve_desc_on_device = false, device_plan_off_once = false;
   StepGraph sg[2]; hipEvent_t ev_gjoin[3] = {nullptr, nullptr, nullptr}; DBuf<long long> d_sb, d_lin;      // d_lin: the linear graphs' step counters [4] and marks [64]
   LinCap lin; long plan_serial = 0; bool graph_broken = false, graph_skip_once = false; int graph_mismatch_run = 0;
 };
@@ -1779,6 +1813,9 @@ static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, c
 static inline bool owned(const msevb_ctx* c, int d) { return d == 0 || ((d - 1) % c->n_ranks) == c->rank; }
 
 extern "C" int msevb_comm_allgather_evb(msevb_ctx* c, int with_energies);   // comm.hip
+extern "C" int msevb_evb_payload_size(int n_diabat, int n_ranks);
+int msevb_comm_allgather_device(msevb_ctx* c, int P, hipStream_t st);      // comm.hip: in-place all-gather of the payload slots already in d_comm_h
+int msevb_comm_allreduce_e8_device(msevb_ctx* c, hipStream_t st);          // comm.hip: the eight principal energy slots, device to device
 
 // dcoef: coefficients in device memory {c0, grid coefficients, blend terms} written by k_evb_solve (then ev is not needed)
 static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, const int* grid_of, int ngrid, int nra, const RecipAtom* d_ra, const double* dcoef) {
@@ -1970,7 +2007,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   // and replayed with four hipGraphLaunch calls (~3 us each, profiles/r05_graph_probe.txt).
   // gmode 3 = this call learns which event records are waited for across streams (nothing issued, the call is repeated), 1 = this call captures (and launches),
   // 2 = this call replays (the host code below runs for its bookkeeping, the wrappers of ctx.hpp issue nothing and hash what they would have issued).
-  if (c->stamps_on < 0) c->stamps_on = getenv("MSEVB_STAMPS") ? 1 : 0;
+  if (c->stamps_on < 0) { const char* se = getenv("MSEVB_STAMPS"); c->stamps_on = se ? (se[0] == '2' ? 2 : 1) : 0; }
   const int fused_nb_in = c->refresh_fused_nb;
   const int gslot = c->refresh_fused_nb > 0 ? 1 : 0;
   EvbWork::StepGraph& G = w->sg[gslot];
@@ -1978,7 +2015,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   StepRec grec;
   LinCap& LC = w->lin;
   const long alloc_epoch0 = g_alloc_epoch;
-  if (c->evb_step_graph && (c->evb_step_graph >= 2 || !c->nccl_comm) && g_live_contexts.load() == 1 && !w->graph_broken && spec && !c->stamps_on && !c->nbr_check_pending && c->flag_verlet_list != 1 && c->list_valid && c->cells_valid &&
+  if (c->evb_step_graph && (c->evb_step_graph >= 2 || !c->nccl_comm) && g_live_contexts.load() == 1 && !w->graph_broken && spec && c->stamps_on != 1 && !c->nbr_check_pending && c->flag_verlet_list != 1 && c->list_valid && c->cells_valid &&
       !(c->timing && (c->timing_tick % c->timing_stride) == 0) && !w->solve_desc_dirty && !w->delta_dirty && !w->dv_dirty && !w->counters_dirty && w->d_check.p && c->stream && !c->evb_pair_first && !c->evb_molecules_after_pair &&
       fft_lds_usable(c) /* (rocFFT launches on streams of their own: not inside these captures) */ && w->d_Fdelta.p && w->tabs_uploaded) {
     if (w->graph_skip_once) w->graph_skip_once = false;      // (the call that repeats a mismatched replay)
@@ -2025,7 +2062,10 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   // speculative step with couplings: nothing on the device needs the neighbourhood record, only the host's verdict does - the kernel goes to the
   // coupling stream (idle until the descriptors are refreshed; its chain ends with a mark the energy fetch waits for, so the verdict is
   // in pinned memory before the host looks), and the descriptor chain starts with k_evb_refresh instead of behind 24-37 us of scanning
-  const bool dev_solve_early = !c->evb_element_stores && c->n_ranks == 1 && !c->nccl_comm && c->evb_device_solve, pub_spin_early = c->overlap && c->evb_publish_spin;
+  // more than one rank: the device-side solve runs on the GATHERED Hamiltonian entries (k_evb_solve_gathered behind the all-gather, or - virtual ranks of the tests and of
+  // tools/virtual_rank_times.py - behind the payloads msevb_comm_set_virtual_payload left in the all-gather's buffer), the blend phase and the all-reduce are pre-enqueued
+  const bool dev_solve_mr_early = !c->evb_element_stores && (c->n_ranks > 1 || c->nccl_comm || !c->virt_payload.empty()) && c->evb_device_solve && c->evb_device_solve_ranks && c->overlap && (c->nccl_comm || !c->virt_payload.empty()) && c->evb_recip_linear && c->d_green.p;
+  const bool dev_solve_early = !c->evb_element_stores && ((c->n_ranks == 1 && !c->nccl_comm && c->evb_device_solve) || dev_solve_mr_early), pub_spin_early = c->overlap && c->evb_publish_spin;
   const bool region_aside = spec && !c->evb_region_main && c->evb_region_aside && c->evb_publish_spin && !gmode && w->plan.n_cps > 0;
   if (region_aside) { s_reg = c->aux3; HIPCHK(hipStreamWaitEvent(c->aux3, w->ev_in, 0)); }
   hipLaunchKernelGGL(k_evb_region, dim3((M + 1023) / 1024), dim3(1024), 0, s_reg, M, c->hydronium, Rreg * Rreg, c->d_mol_natom.p, c->d_mol_atoms.p, c->d_xyz.p,
@@ -2241,7 +2281,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   CHK(upload_evb_tables(c, w));
   if (nu > MAX_UNITS || ncp > MAX_DIABATS || nra > MAX_DIABATS * MAX_SPEC) FAIL(MSEVB_ERR_LIMIT, "EVB descriptor staging too small");
   // single rank, no per-element stores: the Hamiltonian is assembled and diagonalised on the device (k_evb_solve), its descriptor rides along
-  const bool dev_solve = !c->evb_element_stores && c->n_ranks == 1 && !c->nccl_comm && c->evb_device_solve;
+  const bool dev_solve_mr = dev_solve_mr_early, dev_solve = dev_solve_early;
   int n_unit_refs = 0;
   for (int d = 1; d < D; ++d) n_unit_refs += (int)units_of[d].size();
   const size_t off_u = 0, off_c = off_u + (size_t)nu * sizeof(UnitDesc), off_r = off_c + (size_t)ncp * sizeof(CouplingDesc);
@@ -2267,7 +2307,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     SolveDesc* sd = (SolveDesc*)(w->h_desc + off_s);
     int* ui = (int*)(w->h_desc + off_si); double* us = (double*)(w->h_desc + off_ss);
     sd->D = D; sd->nu = nu; sd->ncp = ncp; sd->ngrid = ngrid; sd->unit00 = units_of[0][0];
-    sd->e_hyd = c->e_ref[c->h_mol_type[c->hydronium]]; sd->Hp_norep = sd->e_hyd; sd->once = 1.0;
+    sd->once = (c->shard_principal && c->n_ranks > 1 && !c->nccl_comm && c->rank != 0) ? 0.0 : 1.0;      // (virtual ranks: replicated terms count once, on rank 0 - as the host's assembly below)
+    sd->e_hyd = c->e_ref[c->h_mol_type[c->hydronium]]; sd->Hp_norep = sd->once * sd->e_hyd;
     int q = 0;
     sd->unit_off[0] = 0; sd->unit_off[1] = 0;
     for (int d = 1; d < D; ++d) {
@@ -2280,8 +2321,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     (void)blend_terms(c, D, nullptr, bt_dev, sd->term_i, sd->term_j);
     sd->nterm = bt_dev.n;
   }
-  if (spec && w->solve_desc_dirty && dev_solve) HIPCHK(hipMemcpyAsync(w->d_desc.p + off_s, w->h_desc + off_s, desc_bytes - off_s, hipMemcpyHostToDevice, ss));      // (units / couplings / reciprocal-space atoms were written by k_evb_plan)
-  w->solve_desc_dirty = false;
+  if (spec && dev_solve && (w->solve_desc_dirty || !w->solve_desc_on_device)) HIPCHK(hipMemcpyAsync(w->d_desc.p + off_s, w->h_desc + off_s, desc_bytes - off_s, hipMemcpyHostToDevice, ss));      // (units / couplings / reciprocal-space atoms were written by k_evb_plan)
+  w->solve_desc_dirty = false; w->solve_desc_on_device = dev_solve;      // (a call without the device-side solve leaves no SolveDesc behind: the first call with it - a virtual rank that has just been given its payloads - uploads one)
   if (!spec) {
     HIPCHK(hipMemcpyAsync(w->d_desc.p, w->h_desc, desc_bytes, hipMemcpyHostToDevice, ss));
     // the plan for the steps that follow (they start from these descriptors): only when everything fitted its fixed-size tables
@@ -2336,6 +2377,40 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipStreamWaitEvent(c->aux, w->ev_fork2, 0));
   }
   HT(6);
+  const hipStream_t sg = c->overlap ? c->aux : c->stream;      // diabat grids: `aux` is free once the principal convolution is done
+  const int nst = 2 * nra;
+  // The grid chain of the linear-response path (stencil records, stencil-pair sums, the principal solve, dots with theta_1).  (Round 5: enqueued in FRONT of the
+  // environment and coupling chains instead of behind them - 2 536 / 2 474 against 2 512 / 2 501 steps/s, noise: the chains' ends are set by the GPU they share with
+  // the pair loop, not by when the host reaches them.)
+  auto grid_chain_linear = [&]() -> int {
+    phase_begin(c, PH_EVB_RECIP, sg);
+    stamp(c, 5, sg);
+    // stencil records of the special atoms (old and new state), their dots with theta_1 and their mutual interaction through G = IFFT(CB):
+    // energies relative to the principal diabat -> E_grid, forces on the special atoms -> the diabats' slots of the delta store
+    // (the stencil records and the stencil-pair sums need no potential: they went out on the descriptor stream right behind the special
+    //  atoms' stencils, step 5; here, behind the principal convolution, only the dots with theta_1 are left)
+    // The stencil records and the stencil-pair sums need the special atoms' stencils only (descriptor stream, ev_fork2 - long done): they
+    // run HERE, on the stream of the principal front end right behind it, with the dots against theta_1 - no event hop in between, and not
+    // behind the environment chain of the descriptor stream, where they used to wait ~100 us for kernels they do not depend on
+    {
+      GridRanges granges; memset(&granges, 0, sizeof granges);
+      { int g = 0; granges.start[0] = 0; for (int e = 0; e < nra; ++e) { while (g < ras[e].grid) granges.start[++g] = 2 * e; } while (g < ngrid) granges.start[++g] = nst; }
+      int max_ns = 0;
+      for (int g = 0; g < ngrid; ++g) max_ns = std::max(max_ns, granges.start[g + 1] - granges.start[g]);
+      if (ht_on && g_ht.n == 3) fprintf(stderr, "[msevb] recip entries %d, grids %d, most stencils per grid %d\n", nra, ngrid, max_ns);
+      hipLaunchKernelGGL(k_evb_stencils, dim3((nra + 63) / 64), dim3(64), 0, sg, nra, d_ra, w->d_obase.p, w->d_ow.p, w->d_odw.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p, w->d_stencils.p);
+      hipLaunchKernelGGL(k_evb_recip_pairs, dim3(max_ns, ngrid), dim3(256), 0, sg, granges, w->d_stencils.p, K, c->d_green.p, c->conv, c->kk[0][0], c->kk[0][1],
+                         c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p + MAX_DIABATS);
+    }
+    CHK(pme_front_finish(c));      // (split front end: the principal solve goes out here, behind the kernels above that do not need its result)
+    hipLaunchKernelGGL(k_evb_recip_linear, dim3((nst + 3) / 4), dim3(256), 0, sg, nst, w->d_stencils.p, K, c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
+                       c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p);
+    HIPCHK(hipGetLastError());
+    if (c->overlap) HIPCHK(hipEventRecord(w->ev_rs, sg));      // the special atoms' forces are in the delta store
+    phase_end(c, PH_EVB_RECIP, sg);
+    stamp(c, 6, sg);
+    return MSEVB_OK;
+  };
   // ---- 6a. real-space / bonded / repulsion deltas of all units (ms_evb_diabat_force_energy, :1421)
   const hipStream_t sr = ss;     // on aux2 behind the descriptors: beside the principal force and the reciprocal space of the diabats
   phase_begin(c, PH_EVB_REAL, sr);
@@ -2410,7 +2485,6 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     w->hE_cap = 2 * nE + 64;      // + 1: the principal reciprocal energy rides along (fetch A)
     HIPCHK(hipHostMalloc((void**)&w->h_E, w->hE_cap * sizeof(double), hipHostMallocDefault));
   }
-  const hipStream_t sg = c->overlap ? c->aux : c->stream;      // diabat grids: `aux` is free once the principal convolution is done
   // The ground-state VECTOR does not depend on the principal diabat's energy E0: it sits on the whole diagonal (H = H' + E0 I).  So the
   // host diagonalises H' from the energies that exist long before the pair loop ends (unit, coupling and grid energies, fetch A) and
   // the blend kernels queue up directly behind the pair loop; E0 (fetch B: the principal energy slots, complete only after the pair
@@ -2454,6 +2528,20 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       sa.E = w->d_E.p; sa.e_recip1 = linear ? w->d_Elq.p + 2 * MAX_DIABATS /* zero: the grid energies are differences already */ : c->d_energies.p + S_RECIP;
       sa.dcoef = w->d_coef.p; sa.out_host = w->h_solve; sa.mark_seq = gmode ? 0 : seqA; sa.sb = sb; sa.done_mark = pub_spin ? w->d_chain_done.p + 3 : (long long*)nullptr;
       sa.done_flag = (volatile long long*)(w->h_flag + 6); sa.done_seq = (++w->seq_S, gmode ? 0LL : w->seq_S); sa.fault = c->d_energies.p + S_TIMEOUT;
+      if (dev_solve_mr) {
+        sa.phase = 1; sa.R = c->n_ranks; sa.rank = c->rank; sa.P = msevb_evb_payload_size(D, c->n_ranks); sa.S = (sa.P - 9) / 2;
+        if (c->d_comm_h.alloc((size_t)sa.R * sa.P)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (comm)");
+        if (!c->nccl_comm) {      // virtual rank: the other ranks' payloads as the caller gave them
+          if (c->virt_payload.size() != (size_t)sa.R * sa.P) FAIL(MSEVB_ERR_ARG, "msevb_comm_set_virtual_payload: the payloads do not have the size of this call's diabat tree and rank count");
+          if (c->virt_payload_dirty) { HIPCHK(hipMemcpyAsync(c->d_comm_h.p, c->virt_payload.data(), c->virt_payload.size() * 8, hipMemcpyHostToDevice, sg)); c->virt_payload_dirty = false; }
+        }
+        sa.payload = c->d_comm_h.p;
+        if (!c->attr_evb_solve_g) {
+          const int Dm = MAX_DIABATS, hm = Dm / 2, most = (2 * Dm * Dm + Dm + 6 * hm + std::max(16 * 16 + 32, MAX_UNITS)) * 8 + 16;
+          HIPCHK(hipFuncSetAttribute((const void*)k_evb_solve_gathered, hipFuncAttributeMaxDynamicSharedMemorySize, most));
+          c->attr_evb_solve_g = true;
+        }
+      }
     }
     hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), lds, sg, w->d_E.p, (int)nE, w->h_E, c->d_energies.p + S_RECIP, 1, w->h_E + nE, (volatile long long*)w->h_flag, gmode ? 0LL : seqA,
                        lin_e ? ngrid : 0, w->d_Elq.p, w->d_Elq.p + MAX_DIABATS, c->conv, E_grid,
@@ -2462,6 +2550,12 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     HIPCHK(hipGetLastError());
     stamp(c, 10, sg);
     if (c->overlap) HIPCHK(hipEventRecord(w->ev_fetchA, sg));
+    if (dev_solve_mr) {      // the ranks' entries meet (in place: this rank's slot is where phase 1 wrote it), then the same solve on every rank
+      if (c->nccl_comm) CHK(msevb_comm_allgather_device(c, sa.P, sg));
+      SolveArgs sa2 = sa; sa2.phase = 2;
+      hipLaunchKernelGGL(k_evb_solve_gathered, dim3(1), dim3(256), lds, sg, sa2, sb);
+      HIPCHK(hipGetLastError());
+    }
     if (dev_solve) HIPCHK(hipEventRecord(w->ev_solve, sg));
     return MSEVB_OK;
   };
@@ -2472,11 +2566,16 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       HIPCHK(hipEventRecord(w->ev_flush, c->stream)); HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_flush, 0));
       if (c->top2_join_pending) { HIPCHK(hipStreamWaitEvent(w->stream2, c->ev_top2, 0)); c->top2_join_pending = false; }
       CHK(flush_range(c, 0, N_SLOTS - 1, w->stream2));
-      HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_E, 0));      // the principal reciprocal energy slot is reduced on the diabat grid stream (fetch A) ...
+      // (the principal reciprocal energy slot is reduced on the diabat grid stream by fetch A's publish kernel: ev_fetchA, recorded behind ev_E on that stream, covers both)
       HIPCHK(hipStreamWaitEvent(w->stream2, w->ev_fetchA, 0));      // ... by its publish kernel
       if (defer_mol || single_join) HIPCHK(hipStreamWaitEvent(w->stream2, c->ev_join2, 0));      // per-molecule energies (aux3)
     }
-    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, ss, c->d_energies.p, (int)N_SLOTS, c->h_energies, (const double*)nullptr, 0, (double*)nullptr,
+    const bool e8 = dev_solve_mr && c->nccl_comm && c->shard_principal;      // the ranks' partial principal energies: summed by a small all-reduce right here (second collective of the call: all-gather, this, the forces)
+    if (e8) {
+      if (!c->h_comm_e8) { HIPCHK(hipHostMalloc((void**)&c->h_comm_e8, 8 * sizeof(double), hipHostMallocDefault)); memset(c->h_comm_e8, 0, 64); }
+      CHK(msevb_comm_allreduce_e8_device(c, ss));
+    }
+    hipLaunchKernelGGL(k_evb_publish, dim3(1), dim3(256), 0, ss, c->d_energies.p, (int)N_SLOTS, c->h_energies, e8 ? (const double*)c->d_comm_e.p : (const double*)nullptr, e8 ? 8 : 0, e8 ? c->h_comm_e8 : (double*)nullptr,
                        (volatile long long*)(w->h_flag + 2), (++w->seq_B, gmode ? 0LL : w->seq_B), 0, (double*)nullptr, (double*)nullptr, 0.0, (double*)nullptr, (const double*)nullptr, 0, (double*)nullptr,
                        (const long long*)nullptr, 0LL, 0, (double*)nullptr, sa_none, sb, (int)SB_B);
     HIPCHK(hipGetLastError());
@@ -2484,34 +2583,12 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     return MSEVB_OK;
   };
   // ---- 6b. reciprocal space of the owned diabats (calculate_reciprocal_space_pme, :1962)
-  if (!(ngrid && linear)) CHK(pme_front_finish(c));      // (no stencil kernels to put in front of it)
-  phase_begin(c, PH_EVB_RECIP, sg);
-  stamp(c, 5, sg);
-  const int nst = 2 * nra;
-  if (ngrid && linear) {
-    // stencil records of the special atoms (old and new state), their dots with theta_1 and their mutual interaction through G = IFFT(CB):
-    // energies relative to the principal diabat -> E_grid, forces on the special atoms -> the diabats' slots of the delta store
-    // (the stencil records and the stencil-pair sums need no potential: they went out on the descriptor stream right behind the special
-    //  atoms' stencils, step 5; here, behind the principal convolution, only the dots with theta_1 are left)
-    // The stencil records and the stencil-pair sums need the special atoms' stencils only (descriptor stream, ev_fork2 - long done): they
-    // run HERE, on the stream of the principal front end right behind it, with the dots against theta_1 - no event hop in between, and not
-    // behind the environment chain of the descriptor stream, where they used to wait ~100 us for kernels they do not depend on
-    {
-      GridRanges granges; memset(&granges, 0, sizeof granges);
-      { int g = 0; granges.start[0] = 0; for (int e = 0; e < nra; ++e) { while (g < ras[e].grid) granges.start[++g] = 2 * e; } while (g < ngrid) granges.start[++g] = nst; }
-      int max_ns = 0;
-      for (int g = 0; g < ngrid; ++g) max_ns = std::max(max_ns, granges.start[g + 1] - granges.start[g]);
-      if (ht_on && g_ht.n == 3) fprintf(stderr, "[msevb] recip entries %d, grids %d, most stencils per grid %d\n", nra, ngrid, max_ns);
-      hipLaunchKernelGGL(k_evb_stencils, dim3((nra + 63) / 64), dim3(64), 0, sg, nra, d_ra, w->d_obase.p, w->d_ow.p, w->d_odw.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p, w->d_stencils.p);
-      hipLaunchKernelGGL(k_evb_recip_pairs, dim3(max_ns, ngrid), dim3(256), 0, sg, granges, w->d_stencils.p, K, c->d_green.p, c->conv, c->kk[0][0], c->kk[0][1],
-                         c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p + MAX_DIABATS);
-    }
-    CHK(pme_front_finish(c));      // (split front end: the principal solve goes out here, behind the kernels above that do not need its result)
-    hipLaunchKernelGGL(k_evb_recip_linear, dim3((nst + 3) / 4), dim3(256), 0, sg, nst, w->d_stencils.p, K, c->d_theta.p, c->conv, c->kk[0][0], c->kk[0][1], c->kk[0][2], c->kk[1][0],
-                       c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p);
-    HIPCHK(hipGetLastError());
-    if (c->overlap) HIPCHK(hipEventRecord(w->ev_rs, sg));      // the special atoms' forces are in the delta store
-  } else if (ngrid) {
+  if (ngrid && linear) CHK(grid_chain_linear());
+  else {
+    CHK(pme_front_finish(c));      // (no stencil kernels to put in front of it)
+    phase_begin(c, PH_EVB_RECIP, sg);
+    stamp(c, 5, sg);
+    if (ngrid) {
     hipLaunchKernelGGL(k_evb_grid_init, dim3(2048), dim3(256), 0, sg, K3, ngrid, c->d_Q.p, w->d_grids.p);
     hipLaunchKernelGGL(k_evb_patch, dim3((nra + 3) / 4), dim3(256), 0, sg, nra, d_ra, K, K3, c->d_base.p, c->d_w.p, w->d_sbase.p, w->d_sw.p, w->d_grids.p);
     HIPCHK(hipGetLastError());
@@ -2522,9 +2599,10 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     CHK(rc_conv);
     hipLaunchKernelGGL(k_sum_rows, dim3(ngrid), dim3(256), 0, sg, ngrid, nbk, part_stride, part_grid, E_grid);
     if (!fast) hipLaunchKernelGGL(k_evb_pack, dim3(2048), dim3(256), 0, sg, K3, ngrid, w->d_grids.p, w->d_pack.p);
+      }
+    phase_end(c, PH_EVB_RECIP, sg);
+    stamp(c, 6, sg);
   }
-  phase_end(c, PH_EVB_RECIP, sg);
-  stamp(c, 6, sg);
   w->pack_prefilled = false;
   if (fast && ngrid && linear && fft_lds_usable(c) && !(fft_lds_can_patch(c) && c->evb_fft_patch)) {      // start value of the blended charge grid (Q_1 on rank 0): needs no coefficient, so it goes out in front of the energy fetch (the stream idles there until the other chains have ended)
     if (!w->ev_prefill) HIPCHK(hipEventCreateWithFlags(&w->ev_prefill, hipEventDisableTiming));
@@ -2586,6 +2664,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     const int rc_b = fast_blend_phase(c, w, D, nullptr, grid_of.data(), ngrid, nra, d_ra, w->d_coef.p);
     w->side_by_mark = false; w->blend_mark = nullptr;
     CHK(rc_b);
+    if (dev_solve_mr && c->nccl_comm) CHK(msevb_comm_allreduce_forces(c));      // third collective of the call, behind the blend on the main stream - enqueued with the step, no host turn in front of it
     phase_end(c, PH_EVB_BLEND);
   }
   if (gmode) {
@@ -2603,8 +2682,12 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       for (int b = 1; b < 4; ++b) { lin_add_op(LC, b, 1, 60 + b, 1); lin_flush(LC, b); }
       for (int b = 1; b < 4; ++b) lin_add_op(LC, 0, 2, 60 + b, 1);
       LC.head_open = false;
-      LinOps tail = LC.pend[0]; LC.pend[0].n = 0;      // the main chain's closing waits are NOT captured: the integrator's second kernel performs them (MD loop), or a kernel of their own behind the chain
-      for (int k = 0; k < tail.n; ++k) if (tail.kind[k] != 2) { LC.bad = true; LC.why = "the main chain ends with something other than waits"; }
+      // the main chain's closing WAITS are not captured: the integrator's second kernel performs them (MD loop), or a kernel of their own behind the chain;
+      // whatever else is pending in front of them (a mark behind the chain's last kernel) is
+      LinOps tail;
+      { const LinOps all = LC.pend[0]; int cut = 0; for (int k = 0; k < all.n; ++k) if (all.kind[k] != 2) cut = k + 1;
+        LC.pend[0].n = cut; lin_flush(LC, 0);
+        for (int k = cut; k < all.n; ++k) { tail.kind[tail.n] = 2; tail.slot[tail.n] = all.slot[k]; tail.ord[tail.n] = all.ord[k]; tail.n++; } }
       t_step_rec = nullptr; t_lin = nullptr; c->step_sb = nullptr;
       hipGraph_t g[4] = {nullptr, nullptr, nullptr, nullptr}; hipGraphExec_t ex[4] = {nullptr, nullptr, nullptr, nullptr};
       const double t_inst0 = now_us();
@@ -2691,7 +2774,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   for (int d = 0; d < D; ++d) w->last_grid_of[d] = grid_of[d];
   // ---- 10. multi-GPU: Hamiltonian entries of the other ranks' diabats
   bool energies_in = false;
-  if (c->nccl_comm) {
+  if (c->nccl_comm && !dev_solve_mr) {
     if (sharded) {      // the ranks' partial principal energies travel with the Hamiltonian entries
       if (c->overlap) { if (spin_wait((volatile long long*)(w->h_flag + 2), w->seq_B, w->ev_fetch, gsync)) HIPCHK(hipErrorUnknown); } else HIPCHK(hipStreamSynchronize(c->stream));
       if (c->rank != 0) c->h_energies[S_RECIP] = 0.0;      // replicated term: counts once
@@ -2703,6 +2786,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   auto principal_energy = [&](double& E0) -> int {
     if (c->overlap) { if (spin_wait((volatile long long*)(w->h_flag + 2), w->seq_B, w->ev_fetch, gsync)) HIPCHK(hipErrorUnknown); } else HIPCHK(hipStreamSynchronize(c->stream));
     if (nb_check_overflow(c)) return MSEVB_RETRY;      // a list row outgrew its stride in this call's rebuild: the whole force call is repeated
+    if (dev_solve_mr && c->nccl_comm && sharded) { for (int k = 0; k < 8; ++k) c->h_energies[S_ELEC_PAIR + k] = c->h_comm_e8[k]; energies_in = true; }      // the sums of the device-side all-reduce (copied out by fetch B's kernel)
     if (sharded && !energies_in && c->rank != 0) c->h_energies[S_RECIP] = 0.0;      // sharded principal diabat: replicated terms count once (rank 0)
     double en[MSEVB_N_ENERGY];
     CHK(total_force_collect(c, en));
@@ -2714,7 +2798,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     w->pl_units_of = units_of; w->pl_grid_of = grid_of; w->pl_cp_of = cp_of; w->pl_eref_delta = eref_delta; w->pl_ngrid = ngrid; w->pl_ncp_big = ncp_big;
     w->plan_valid = true; w->plan_epoch = c->topo_epoch; w->plan_serial++;
   };
-  if (c->n_ranks > 1 && !c->nccl_comm) {   // virtual sharding (tests): leave foreign diabats empty; caller merges
+  if (c->n_ranks > 1 && !c->nccl_comm && !dev_solve_mr) {   // virtual sharding (tests): leave foreign diabats empty; caller merges
     double E0 = 0.0;
     CHK(principal_energy(E0));
     if (!spec && w->plan_fits && c->evb_speculate) remember_plan();      // (round 4: this return used to skip it - virtual ranks never speculated, and tools/virtual_rank_times.py timed the long way round every call)
@@ -2733,6 +2817,10 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     if (hs[0] != 0.0) FAIL(MSEVB_ERR_NUMERIC, "too many iterations in jacobi");
     eg = hs[1];
     for (int i = 0; i < D; ++i) c->eigvec[i] = hs[2 + i];
+    if (dev_solve_mr) {      // the Hamiltonian every rank solved (H' from the gathered entries) and this rank's coupling factors, for the host's records
+      for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) c->H[i][j] = hs[2 + 2 * D + (size_t)i * D + j];
+      for (int d = 1; d < D; ++d) if (owned(c, d)) c->cpl_A[d] = hs[2 + D + d];
+    }
   } else {
     std::vector<double> a((size_t)D * D), ev(D), v((size_t)D * D);
     for (int i = 0; i < D; ++i) for (int j = i; j < D; ++j) { a[(size_t)i * D + j] = c->H[i][j]; a[(size_t)j * D + i] = c->H[i][j]; }
@@ -2751,7 +2839,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     hipLaunchKernelGGL(k_evb_blend, dim3(std::min<size_t>(2048, (n3 + 255) / 256)), dim3(256), 0, c->stream, n3, bt, (const double*)nullptr, w11, c->d_Fdiag.p, c->d_Foff.p, n3, c->d_force.p, 0, (double*)nullptr, (const int*)nullptr, 0);
   }
   HIPCHK(hipGetLastError());
-  if (c->nccl_comm) CHK(msevb_comm_allreduce_forces(c));
+  if (c->nccl_comm && !dev_solve_mr) CHK(msevb_comm_allreduce_forces(c));
   if (!dev_solve) phase_end(c, PH_EVB_BLEND);
   HT(10);
   {   // the blend is enqueued: now the principal energy (it shifts the whole diagonal, not the ground-state vector)
@@ -2922,6 +3010,23 @@ int msevb_get_hop_log(msevb_ctx* c, int* n_hops, int* log, int capacity, long* e
   if (evb_calls) *evb_calls = c->evb_calls;
   if (log) for (int k = 0; k < 3 * std::min(n, capacity); ++k) log[k] = c->hop_log[k];
   if (clear) c->hop_log.clear();
+  return MSEVB_OK;
+}
+// virtual ranks: what a real all-gather would deliver - the R payloads of msevb_evb_payload_pack in rank order (this rank's own slot is overwritten by its energy-fetch
+// kernel every call).  With them a virtual rank runs the SAME device-side path as a rank with a communicator - solve on the gathered entries, pre-enqueued blend - minus the
+// collectives; n_doubles = 0 takes them away again (the caller then merges the ranks' shares with msevb_evb_partial_blend, as before).
+int msevb_comm_set_virtual_payload(msevb_ctx* c, const double* all, int n_doubles) {
+  if (!c || n_doubles < 0 || (n_doubles > 0 && !all)) return MSEVB_ERR_ARG;
+  c->virt_payload.assign(all, all + n_doubles); c->virt_payload_dirty = n_doubles > 0;
+  return MSEVB_OK;
+}
+// ... and what this rank's energy-fetch kernel wrote (all R slots of the buffer as they are on the device; the rank's own slot is the one that is its work): with it
+// a test plays the all-gather between virtual ranks itself
+int msevb_comm_get_payload(msevb_ctx* c, double* out, int n_doubles) {
+  if (!c || !out || n_doubles < 0 || (size_t)n_doubles > c->d_comm_h.n) return MSEVB_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, c->d_comm_h.p, (size_t)n_doubles * 8, hipMemcpyDeviceToHost));
   return MSEVB_OK;
 }
 int msevb_comm_set_virtual(msevb_ctx* c, int r, int n) { if (!c || n < 1 || r < 0 || r >= n) return MSEVB_ERR_ARG; c->rank = r; c->n_ranks = n; return MSEVB_OK; }

@@ -304,6 +304,18 @@ module msevb_hip_c
        type(c_ptr), value :: ctx
        integer(c_int), value :: rank, n_ranks
      end function
+     integer(c_int) function msevb_comm_set_virtual_payload(ctx, payloads, n_doubles) bind(C, name="msevb_comm_set_virtual_payload")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: payloads(*)
+       integer(c_int), value :: n_doubles
+     end function
+     integer(c_int) function msevb_comm_get_payload(ctx, payloads, n_doubles) bind(C, name="msevb_comm_get_payload")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: payloads(*)
+       integer(c_int), value :: n_doubles
+     end function
      integer(c_int) function msevb_evb_payload_size(n_diabat, n_ranks) bind(C, name="msevb_evb_payload_size")
        import :: c_int
        integer(c_int), value :: n_diabat, n_ranks

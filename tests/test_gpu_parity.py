@@ -625,6 +625,84 @@ def test_long_trajectory_to_the_references_own_stop():
     h.close()
 
 
+def _gathered_payloads(spec, n_ranks, opts=None):
+    """the R payloads an all-gather would deliver (msevb_evb_payload_pack layout), made from ONE context that runs the multi-rank device path as rank 0 of 1 (its
+    energy-fetch kernel then writes every diabat's entries into the one slot of the buffer): (payloads [R, P], D, state of that context, its energy and force)"""
+    import ctypes as C
+    h = api.MsEvbHip(spec)
+    for k, v in (opts or {}).items():
+        h.set_option(k, v)
+    h.comm_set_virtual(0, 1)
+    h.ms_evb_calculate_total_force_energy(want_force=False)
+    D = h.evb_state()["D"]
+    P1 = h.evb_payload_size(D, 1)
+    h.comm_set_virtual_payload(np.zeros(P1))      # (rank 0 of 1 owns every slot: nothing of these zeros survives the call)
+    e, F = h.ms_evb_calculate_total_force_energy()
+    st = h.evb_state()
+    one = h.comm_get_payload(P1)
+    Hp = np.zeros((D, D))
+    parent = np.ascontiguousarray(st["coupling_matrix"] - 1, dtype=np.int32)
+    parent[0] = -1
+    h._chk(h.L.msevb_evb_payload_unpack(D, 1, one.ctypes.data_as(C.POINTER(C.c_double)), parent.ctypes.data_as(C.POINTER(C.c_int)), Hp.ctypes.data_as(C.POINTER(C.c_double)), None))
+    P = h.evb_payload_size(D, n_ranks)
+    pay = np.zeros((n_ranks, P))
+    for r in range(n_ranks):
+        h._chk(h.L.msevb_evb_payload_pack(D, n_ranks, r, Hp.ctypes.data_as(C.POINTER(C.c_double)), parent.ctypes.data_as(C.POINTER(C.c_int)), None, pay[r].ctypes.data_as(C.POINTER(C.c_double))))
+    h.close()
+    return pay, D, st, e, F
+
+
+def _virtual_allgather_run(spec, n_ranks, shard_principal, opts=None):
+    """what R ranks with a communicator do, played on one GPU: every virtual rank is handed the R gathered payloads (msevb_comm_set_virtual_payload) and runs its force
+    call - Hamiltonian solved on the device from the gathered entries, blend pre-enqueued, no caller-side merge.  Returns per rank (epot, partial force, state, ...)."""
+    pay, D, st1, e1, F1 = _gathered_payloads(spec, n_ranks, opts)
+    out = []
+    for r in range(n_ranks):
+        h = api.MsEvbHip(spec)
+        for k, v in (opts or {}).items():
+            h.set_option(k, v)
+        if shard_principal:
+            h.set_option("shard_principal", 1)
+        h.comm_set_virtual(r, n_ranks)
+        h.comm_set_virtual_payload(pay)
+        e, F = h.ms_evb_calculate_total_force_energy()
+        e2, F2 = h.ms_evb_calculate_total_force_energy()      # (a second, speculative call: nothing of the first one may be left behind)
+        assert np.abs(F2 - F).max() < 1e-9 and rel(e2, e) < 1e-13, (e, e2)
+        own = h.comm_get_payload(pay.size).reshape(pay.shape)[r]
+        assert np.abs(own[:-9] - pay[r][:-9]).max() < 1e-10 * np.abs(pay).max(), "the rank's own slot is not what the one-rank run computed for the same diabats"      # (the entries of its diabats; H'_11 counts from rank 0's slot)
+        out.append((e, F, h.evb_state(), int(h.info("spec_steps"))))
+        h.close()
+    return out, (e1, F1, st1)
+
+
+@pytest.mark.parametrize("n_ranks,shard", [(2, 1), (3, 0), (4, 1), (8, 1)])
+def test_device_side_solve_on_the_gathered_hamiltonian(n_ranks, shard):
+    """More than one rank (diagonalize_evb_hamiltonian src/ms_evb.f90:242-330 on entries that meet in an all-gather): the rank's energy-fetch kernel
+    assembles the entries of ITS diabats into its payload slot, k_evb_solve_gathered builds H' from the R gathered payloads, finds the ground state and the rank's blend
+    coefficients, the blend phase is pre-enqueued - no host Jacobi, no host turn.  Played with virtual ranks and the test as the all-gather: every rank must arrive at the
+    single-rank Hamiltonian and eigenvector, and the ranks' partial forces must add up to the single-rank Hellmann-Feynman force (what the all-reduce sums)."""
+    g = golden("evb_n6_d8_s1")
+    spec = system.from_golden(g)
+    h = api.MsEvbHip(spec)
+    e1, F1 = h.ms_evb_calculate_total_force_energy()
+    st1 = h.evb_state()
+    h.close()
+    res, one = _virtual_allgather_run(spec, n_ranks, shard)
+    assert rel(one[0], e1) < 1e-13 and np.abs(one[1] - F1).max() < 1e-9      # rank 0 of 1 on the multi-rank path = the one-rank path
+    Fsum = np.zeros_like(F1)
+    for r, (e, F, st, nspec) in enumerate(res):
+        assert st["D"] == st1["D"] and nspec >= 1
+        H1 = st1["H"]
+        # off-diagonal elements and DIFFERENCES of diagonal elements do not depend on the principal energy E0, which a virtual rank holds only in part
+        assert np.abs(np.triu(st["H"], 1) - np.triu(H1, 1)).max() < 1e-10 * np.abs(H1).max(), (r, np.triu(st["H"], 1)[np.triu(H1, 1) != 0], np.triu(H1, 1)[np.triu(H1, 1) != 0], np.diag(st["H"]), np.diag(H1), st["eigvec"], st1["eigvec"])
+        dd, d1 = np.diag(st["H"]) - st["H"][0, 0], np.diag(H1) - H1[0, 0]
+        assert np.abs(dd - d1).max() < 1e-10 * np.abs(H1).max()
+        assert min(np.abs(st["eigvec"] - st1["eigvec"]).max(), np.abs(st["eigvec"] + st1["eigvec"]).max()) < 1e-10
+        Fsum += F
+    assert np.abs(Fsum - F1).max() < 1e-9
+    assert np.abs(Fsum - g["F_adiabatic"]).max() < F_TOL      # ... which is the reference's
+
+
 @pytest.mark.parametrize("n_ranks", [2, 3, 8])
 def test_diabat_sharding_is_a_partition(n_ranks):
     """virtual ranks: every Hamiltonian element is produced by exactly one rank and equals the single-rank result, and the ranks'

@@ -6,7 +6,7 @@ switches on) runs the MS-EVB force call of BASELINE.json configs[2] (98 220 atom
 fixed ground-state vector - everything a rank does between the two collectives of a step, nothing of the collectives themselves (the
 all-gather carries 2S + 9 doubles, the all-reduce 24 B/atom = 2.4 MB).  Reported: the slowest rank's time over the one-rank time.
 
-    python tools/virtual_rank_times.py [calls] [B|C] [R,R,...]      (C = configs[4]'s size: 985 527 atoms, 16 diabats, 128^3; default ranks 1,2,4,8)
+    python tools/virtual_rank_times.py [calls] [B|C] [R,R,...] [host|device] [option=value ...]      (C = configs[4]'s size: 985 527 atoms, 16 diabats, 128^3; default ranks 1,2,4,8)
 """
 import json
 import os
@@ -19,8 +19,58 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from reactive_pb_nn_md_amd import api, forcefield, synth, system  # noqa: E402
 
 
-def rank_time(spec, r, R, eigvec, calls):
+def gathered_payloads(spec, R):
+    """the R payloads an all-gather would deliver, from one context that runs the multi-rank device path as rank 0 of 1 (tests/test_gpu_parity.py: _gathered_payloads)"""
+    import ctypes as C
     h = api.MsEvbHip(spec)
+    for kv in OPTS:
+        k, v = kv.split("=")
+        h.set_option(k, float(v))
+    h.comm_set_virtual(0, 1)
+    h.ms_evb_calculate_total_force_energy(want_force=False)
+    st = h.evb_state()
+    D = st["D"]
+    P1 = h.evb_payload_size(D, 1)
+    h.comm_set_virtual_payload(np.zeros(P1))
+    h.ms_evb_calculate_total_force_energy(want_force=False)
+    one = h.comm_get_payload(P1)
+    Hp = np.zeros((D, D))
+    parent = np.ascontiguousarray(st["coupling_matrix"] - 1, dtype=np.int32)
+    parent[0] = -1
+    dp, ip = (lambda a: a.ctypes.data_as(C.POINTER(C.c_double))), (lambda a: a.ctypes.data_as(C.POINTER(C.c_int)))
+    h._chk(h.L.msevb_evb_payload_unpack(D, 1, dp(one), ip(parent), dp(Hp), None))
+    pay = np.zeros((R, h.evb_payload_size(D, R)))
+    for r in range(R):
+        h._chk(h.L.msevb_evb_payload_pack(D, R, r, dp(Hp), ip(parent), None, dp(pay[r])))
+    h.close()
+    return pay
+
+
+def rank_time(spec, r, R, eigvec, calls):
+    if MODE == "device" and R > 1:      # the path of a rank with a communicator, minus the collectives: solve on the gathered entries on the device, blend pre-enqueued
+        pay = gathered_payloads(spec, R)
+        h = api.MsEvbHip(spec)
+        for kv in OPTS:
+            k, v = kv.split("=")
+            h.set_option(k, float(v))
+        h.set_option("shard_principal", 1)
+        h.comm_set_virtual(r, R)
+        h.comm_set_virtual_payload(pay)
+        h.construct_verlet_list()
+        for _ in range(5):
+            h.ms_evb_calculate_total_force_energy(want_force=False)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            h.ms_evb_calculate_total_force_energy(want_force=False)
+        h.synchronize()
+        dt = (time.perf_counter() - t0) / calls
+        D = h.evb_state()["D"]
+        h.close()
+        return dt, D
+    h = api.MsEvbHip(spec)
+    for kv in OPTS:
+        k, v = kv.split("=")
+        h.set_option(k, float(v))
     if R > 1:
         h.set_option("shard_principal", 1)
         h.comm_set_virtual(r, R)
@@ -38,6 +88,12 @@ def rank_time(spec, r, R, eigvec, calls):
     D = h.evb_state()["D"]
     h.close()
     return dt, D
+
+
+MODE = "host" if "host" in sys.argv[1:] else "device"      # device (default): virtual ranks get the gathered payloads and run the device-side solve + pre-enqueued blend; host: round 4's path (the caller merges with a given eigenvector)
+sys.argv = [a for a in sys.argv if a not in ("host", "device")]
+OPTS = [a for a in sys.argv[1:] if "=" in a]      # library options, name=value (e.g. step_graph=0)
+sys.argv = [a for a in sys.argv if "=" not in a]
 
 
 def main():

@@ -175,6 +175,65 @@ def thermalised_line(args, device):
     return out
 
 
+def long_run_line(args, device, n_steps=2000, block=500):
+    """Third measurement (rank 0, N = 1 only): SUSTAINED throughput.  The hot lattice of `value` lives ~300 steps and the thermalised box ~280 (the acid
+    proton, which has no repulsive wall outside the EVB terms, falls onto a 1-4 sulfonate oxygen of its own molecule once the diabat tree has dissolved - the reference walks
+    the same surface, tests/golden/long_evb_n12_liquid_s40.npz).  With the 1-4 pairs EXCLUDED (n_exclusions = 3, the reference's [ exclusions ] generation,
+    src/intra_bonded_interactions.f90; fixture std_n6_ex3_s12) the same 98 220-atom composition survives: thermalised as `thermalised_box`, then n_steps NVE steps in blocks,
+    timed as a whole - list rebuilds, diabat-count changes, tree changes (device-side re-planning) and the host's per-block bookkeeping included."""
+    KB = 0.0083144626
+    s = synth.make_system(args.n_side, n_diabat=args.diabats, seed=0, max_chain=3 if args.diabats <= 8 else 4, liquid_like=True)
+    p = forcefield.build_params(forcefield.ch3so3h_water_forcefield(), moltype_order=["h2o", "so3h"], n_exclusions=3)
+    spec = system.from_synth(s, p, rc=9.0, rv=10.5, alpha=0.3, pme_grid=args.pme_grid, max_chain=3 if args.diabats <= 8 else 4)
+    h = api.MsEvbHip(spec, device=device)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        h.set_option(k, float(v))
+    h.set_velocities(synth.maxwell_boltzmann(spec.mass, 300.0, 12345))
+    h.ms_evb_calculate_total_force_energy(want_force=False)
+    ndf = 3 * spec.n_atom - 3
+    for _b in range(8):
+        en = h.md_integrate_atomic(20, spec.delta_t, use_evb=True)
+        T = 2 * en[-1, 1] / (ndf * KB)
+        h.set_velocities(h.get_velocities() * np.sqrt(300.0 / max(T, 1.0)))
+    h.ms_evb_calculate_total_force_energy(want_force=False)
+    h.md_integrate_atomic(20, spec.delta_t, use_evb=True)
+    h.set_option("phase_timing", 1.0)      # counts the list rebuilds
+    h.L.msevb_reset_phase_times(h.ctx)
+    info0 = {k: int(h.info(k)) for k in ("evb_calls", "spec_misses", "device_plans", "host_dfs_calls")}
+    dcounts, e_first, e_last, T_last, done, err = set(), None, None, None, 0, None
+    h.synchronize()
+    t0 = time.perf_counter()
+    while done < n_steps:
+        try:
+            tr = h.md_integrate_atomic(min(block, n_steps - done), spec.delta_t, use_evb=True)
+        except api.MsevbError as e:
+            err = str(e)[:160]
+            break
+        done += len(tr)
+        if e_first is None:
+            e_first = float(tr[0].sum())
+        e_last, T_last = float(tr[-1].sum()), 2 * tr[-1, 1] / (ndf * KB)
+        dcounts.add(int(h.evb_state()["D"]))
+    h.synchronize()
+    dt = time.perf_counter() - t0
+    reb = int(h.phase_times().get("verlet list construction", (0, 0))[1])
+    info1 = {k: int(h.info(k)) for k in info0}
+    nh = 0
+    try:
+        nh = int(h.hop_log()[0])
+    except Exception:
+        pass
+    out = {"value": round(done / dt, 3) if done else 0.0, "unit": "steps/s", "ms_per_step": round(dt / max(done, 1) * 1e3, 4), "steps": done, "steps_asked": n_steps,
+           "workload": "same composition (%d atoms, %d^3 grid), 1-4 pairs excluded (n_exclusions = 3), liquid_like start relaxed as thermalised_box; %d NVE steps in blocks of %d timed as a whole" % (spec.n_atom, spec.pme_grid, n_steps, block),
+           "verlet_rebuilds": reb, "principal_diabat_switches": nh, "diabat_counts_seen": sorted(dcounts),
+           "tree_changes_replanned_on_the_device": info1["device_plans"] - info0["device_plans"], "host_dfs_calls": info1["host_dfs_calls"] - info0["host_dfs_calls"],
+           "speculation_misses": info1["spec_misses"] - info0["spec_misses"], "evb_force_calls": info1["evb_calls"] - info0["evb_calls"],
+           "relative_energy_change": None if e_first is None else (e_last - e_first) / abs(e_first), "temperature_last_K": None if T_last is None else round(T_last, 1), "ended_early": err}
+    h.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +246,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-evb", action="store_true")
     ap.add_argument("--no-thermal", action="store_true", help="skip the second (thermalised box) measurement")
+    ap.add_argument("--no-long-run", action="store_true", help="skip the third measurement (2 000 steps of a box that survives: sustained throughput)")
     ap.add_argument("--no-phase-timing", action="store_true", help="skip the per-phase HIP events (roofline block becomes null)")
     ap.add_argument("--rccl-single", action="store_true", help="diagnostic: N=1 with a one-rank RCCL communicator (cost of the two collectives per step)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (msevb_set_option), e.g. pair_tiles=0")
@@ -391,6 +451,8 @@ def main():
     h.close()
     if rank == 0 and world == 1 and use_evb and not args.no_thermal and args.n_side >= 16:
         out["thermalised_box"] = thermalised_line(args, local_rank)
+    if rank == 0 and world == 1 and use_evb and not args.no_long_run and not args.no_thermal and args.n_side >= 16:
+        out["long_run"] = long_run_line(args, local_rank)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -142,8 +142,26 @@ __global__ void k_comm_e8_pack(const double* __restrict__ slots, double* __restr
   if (k < 8) out[k] = (zero_recip && k == S_RECIP - S_ELEC_PAIR) ? 0.0 : slots[S_ELEC_PAIR + k];
 }
 }  // namespace
+// the host's wait for a number a kernel BEHIND a collective writes to pinned memory (eigenvector behind the all-gather, energies behind their all-reduce): like comm_wait it
+// ends - with the number, with an error of the stream, or after comm_timeout_ms, because a peer that died or never entered the collective leaves the stream busy for ever
+int msevb_comm_wait_flag(msevb_ctx* c, volatile long long* flag, long long seq, hipStream_t st, const char* what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (long spins = 1;; ++spins) {
+    if (*flag == seq) return MSEVB_OK;
+    if ((spins & 0x3fff) == 0) {
+      const hipError_t e = hipStreamQuery(st);
+      if (e == hipSuccess) { if (*flag == seq) return MSEVB_OK; FAIL(MSEVB_ERR_COMM, std::string(what) + ": the stream finished without publishing its result"); }
+      if (e != hipErrorNotReady) FAIL(MSEVB_ERR_HIP, std::string("HIP error behind ") + what + ": " + hipGetErrorString(e));
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(c->comm_timeout_ms)) {
+        char b[200]; snprintf(b, sizeof b, "%s: no result after %d ms (a peer rank is missing or has stopped); rank %d of %d", what, c->comm_timeout_ms, c->rank, c->n_ranks);
+        FAIL(MSEVB_ERR_COMM, b);
+      }
+    }
+  }
+}
 int msevb_comm_allgather_device(msevb_ctx* c, int P, hipStream_t st) {
   if (!c || !c->nccl_comm) return MSEVB_OK;
+  if (c->comm_stall_ms > 0) { hipLaunchKernelGGL(k_comm_stall, dim3(1), dim3(1), 0, st, 100000LL * c->comm_stall_ms); c->comm_stall_ms = 0; }      // (one-shot test hook: what a missing peer looks like)
   if (ncclAllGather(c->d_comm_h.p + (size_t)c->rank * P, c->d_comm_h.p, (size_t)P, ncclDouble, (ncclComm_t)c->nccl_comm, st) != ncclSuccess) FAIL(MSEVB_ERR_COMM, "ncclAllGather failed");
   return MSEVB_OK;
 }

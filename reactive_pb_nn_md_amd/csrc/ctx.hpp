@@ -83,17 +83,18 @@ struct ApiScope { int k; double t0; explicit ApiScope(int kind) : k(api_prof_on(
 // 1 = store a mark, 2 = wait for a mark).  Order matters (a record in front of a wait must stay in front of it: two streams that each mark first and wait second would
 // wait for each other otherwise), so the list is kept as issued.
 struct LinOps { int n = 0; int kind[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int slot[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int ord[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
+constexpr int LIN_NST = 4;      // main, grid, descriptor, coupling stream (a fifth stream was tried in round 5 - the stencil kernels beside the charge spreading - and made the step 20 % slower: the runtime's streams share four hardware queues, HISTORY.md F)
 struct LinCap {
-  hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
-  long long* cnt = nullptr; long long* marks = nullptr; double* fault = nullptr;      // device: cnt[4], marks[64]; the sticky time-out flag (S_TIMEOUT)
+  hipStream_t st[LIN_NST] = {nullptr, nullptr, nullptr, nullptr};
+  long long* cnt = nullptr; long long* marks = nullptr; double* fault = nullptr;      // device: cnt[8], marks[64]; the sticky time-out flag (S_TIMEOUT)
   int nev = 0; hipEvent_t ev[60]; int ev_stream[60]; int ev_ord[60]; int ev_kpos[60];      // ev_kpos: kernels the recording stream had been given when the (latest) record was made
-  int kcount[4] = {0, 0, 0, 0}; int waited_kpos[4][4];      // per stream: kernels given so far; per (waiting, producing) stream: the latest position already waited for - a wait for an earlier position of the same stream adds nothing
+  int kcount[LIN_NST] = {0, 0, 0, 0}; int waited_kpos[LIN_NST][LIN_NST];      // per stream: kernels given so far; per (waiting, producing) stream: the latest position already waited for - a wait for an earlier position of the same stream adds nothing
   unsigned long long need[60];      // bit `ord` of need[slot]: that record of the event is waited for by another stream (learn pass -> capture pass)
-  LinOps pend[4];                   // operations a stream has collected since its last kernel
+  LinOps pend[LIN_NST];             // operations a stream has collected since its last kernel
   bool head_open = true; LinOps head;      // the main stream's operations in front of its first kernel: not captured - the step-block kernel, launched in front of the main chain at every replay, performs them
   bool bad = false, verbose = false; const char* why = nullptr; int n_marks = 0, n_waits = 0, n_op_kernels = 0;
   LinCap() { for (auto& r : waited_kpos) for (int& v : r) v = -1; }
-  int stream_index(hipStream_t s) const { for (int b = 0; b < 4; ++b) if (st[b] == s) return b; return -1; }
+  int stream_index(hipStream_t s) const { for (int b = 0; b < LIN_NST; ++b) if (st[b] && st[b] == s) return b; return -1; }
   int slot_of(hipEvent_t e) const { for (int k = 0; k < nev; ++k) if (ev[k] == e) return k; return -1; }
 };
 extern thread_local LinCap* t_lin;      // non-null during the learn (mode 3) and capture (mode 1) passes of a call (evb.hip)

@@ -1680,7 +1680,7 @@ struct EvbWork {   // persistent device scratch of one context
   // step graph (ctx.hpp: StepRec): the enqueue part of a speculative call captured once per diabat tree and replayed with ONE launch; two entries: calls whose refresh of the
   // sorted arrays rode in the integrator's first kernel (MD loop) and calls that refresh themselves (force calls through the host-array entry points)
   struct StepGraph {      // four linear graphs, one per stream (ctx.hpp: LinCap); `need` is what the learn pass found (which event records another stream waits for)
-    hipGraphExec_t exec[4] = {nullptr, nullptr, nullptr, nullptr}; unsigned long long hash = 0; int n = 0; long plan_serial = -1, topo_epoch = -1, alloc_epoch = -1;
+    hipGraphExec_t exec[LIN_NST] = {nullptr, nullptr, nullptr, nullptr}; unsigned long long hash = 0; int n = 0; long plan_serial = -1, topo_epoch = -1, alloc_epoch = -1;
     bool learned = false; long learn_serial = -1, learn_topo = -1; unsigned long long need[60]; int nev = 0;
     std::vector<std::pair<const void*, unsigned long long>> trace;      // (MSEVB_GRAPH_DEBUG)
     LinOps tail;      // ... and its closing waits (integrator's second kernel / a kernel of their own)
@@ -1816,6 +1816,7 @@ extern "C" int msevb_comm_allgather_evb(msevb_ctx* c, int with_energies);   // c
 extern "C" int msevb_evb_payload_size(int n_diabat, int n_ranks);
 int msevb_comm_allgather_device(msevb_ctx* c, int P, hipStream_t st);      // comm.hip: in-place all-gather of the payload slots already in d_comm_h
 int msevb_comm_allreduce_e8_device(msevb_ctx* c, hipStream_t st);          // comm.hip: the eight principal energy slots, device to device
+int msevb_comm_wait_flag(msevb_ctx* c, volatile long long* flag, long long seq, hipStream_t st, const char* what);      // comm.hip: the host's wait behind a collective, with the communicator's time limit
 
 // dcoef: coefficients in device memory {c0, grid coefficients, blend terms} written by k_evb_solve (then ev is not needed)
 static int fast_blend_phase(msevb_ctx* c, EvbWork* w, int D, const double* ev, const int* grid_of, int ngrid, int nra, const RecipAtom* d_ra, const double* dcoef) {
@@ -2021,23 +2022,23 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     if (w->graph_skip_once) w->graph_skip_once = false;      // (the call that repeats a mismatched replay)
     else {
       if (w->d_sb.alloc(SB_N)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (step block)");
-      if (!w->d_lin.p) { if (w->d_lin.alloc(4 + 64)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (marks of the linear graphs)"); HIPCHK((hipMemset)(w->d_lin.p, 0, (4 + 64) * sizeof(long long))); HIPCHK(hipDeviceSynchronize()); }
+      if (!w->d_lin.p) { if (w->d_lin.alloc(8 + 64)) FAIL(MSEVB_ERR_HIP, "hipMalloc failed (marks of the linear graphs)"); HIPCHK((hipMemset)(w->d_lin.p, 0, (8 + 64) * sizeof(long long))); HIPCHK(hipDeviceSynchronize()); }
       const bool have = G.have() && G.plan_serial == w->plan_serial && G.topo_epoch == c->topo_epoch && G.alloc_epoch == g_alloc_epoch;
       gmode = have ? 2 : (G.learned && G.learn_serial == w->plan_serial && G.learn_topo == c->topo_epoch) ? 1 : 3;
       if (gmode != 2) {
         G.drop();
         LC = LinCap();
         LC.st[0] = c->stream; LC.st[1] = c->aux; LC.st[2] = w->stream2; LC.st[3] = c->aux3;
-        LC.cnt = w->d_lin.p; LC.marks = w->d_lin.p + 4; LC.fault = c->d_energies.p + S_TIMEOUT;
+        LC.cnt = w->d_lin.p; LC.marks = w->d_lin.p + 8; LC.fault = c->d_energies.p + S_TIMEOUT;
         if (gmode == 1) { LC.nev = 0; memcpy(LC.need, G.need, sizeof LC.need); LC.verbose = getenv("MSEVB_GRAPH_DEBUG") && c->evb_graph_captures == 0; }
       }
       if (gmode == 1) {
         int nb = 0;
-        for (; nb < 4; ++nb) if (hipStreamBeginCapture(LC.st[nb], hipStreamCaptureModeRelaxed) != hipSuccess) break;
-        if (nb < 4) {      // this runtime cannot capture here: end what has begun, no further attempts
+        for (; nb < LIN_NST; ++nb) if (hipStreamBeginCapture(LC.st[nb], hipStreamCaptureModeRelaxed) != hipSuccess) break;
+        if (nb < LIN_NST) {      // this runtime cannot capture here: end what has begun, no further attempts
           for (int b = 0; b < nb; ++b) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(LC.st[b], &g); if (g) (void)hipGraphDestroy(g); }
           (void)hipGetLastError(); w->graph_broken = true; gmode = 0;
-        } else for (int b = 0; b < 4; ++b) lin_add_op(LC, b, 0, 0, 0);      // first operation of every chain: the stream's step number advances
+        } else for (int b = 0; b < LIN_NST; ++b) lin_add_op(LC, b, 0, 0, 0);      // first operation of every chain: the stream's step number advances
       }
     }
   }
@@ -2048,7 +2049,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     msevb_ctx* c; EvbWork* w;
     ~StepScope() {
       if (t_step_rec && t_step_rec->mode == 1) {      // an error inside the capture
-        for (int b = 0; b < 4; ++b) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(w->lin.st[b], &g); if (g) (void)hipGraphDestroy(g); }
+        for (int b = 0; b < LIN_NST; ++b) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(w->lin.st[b], &g); if (g) (void)hipGraphDestroy(g); }
         (void)hipGetLastError(); w->graph_broken = true;
       }
       t_step_rec = nullptr; t_lin = nullptr; c->step_sb = nullptr;
@@ -2398,8 +2399,11 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       int max_ns = 0;
       for (int g = 0; g < ngrid; ++g) max_ns = std::max(max_ns, granges.start[g + 1] - granges.start[g]);
       if (ht_on && g_ht.n == 3) fprintf(stderr, "[msevb] recip entries %d, grids %d, most stencils per grid %d\n", nra, ngrid, max_ns);
-      hipLaunchKernelGGL(k_evb_stencils, dim3((nra + 63) / 64), dim3(64), 0, sg, nra, d_ra, w->d_obase.p, w->d_ow.p, w->d_odw.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p, w->d_stencils.p);
-      hipLaunchKernelGGL(k_evb_recip_pairs, dim3(max_ns, ngrid), dim3(256), 0, sg, granges, w->d_stencils.p, K, c->d_green.p, c->conv, c->kk[0][0], c->kk[0][1],
+      // (round 5: on a FIFTH stream, beside the charge spreading instead of behind it, these two made the step 20 % slower - 0.482 against 0.408 ms, the grid chain ending
+      //  at 295 instead of 227 us: this runtime maps the process's streams onto four hardware queues, a fifth shares one - and slowed every later context of the process)
+      const hipStream_t sp = sg;
+      hipLaunchKernelGGL(k_evb_stencils, dim3((nra + 63) / 64), dim3(64), 0, sp, nra, d_ra, w->d_obase.p, w->d_ow.p, w->d_odw.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p, w->d_stencils.p);
+      hipLaunchKernelGGL(k_evb_recip_pairs, dim3(max_ns, ngrid), dim3(256), 0, sp, granges, w->d_stencils.p, K, c->d_green.p, c->conv, c->kk[0][0], c->kk[0][1],
                          c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p + MAX_DIABATS);
     }
     CHK(pme_front_finish(c));      // (split front end: the principal solve goes out here, behind the kernels above that do not need its result)
@@ -2679,8 +2683,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     if (gmode == 1) {
       // the end of every chain: the side streams leave a final mark each, the main stream waits for the three - whatever follows the call on the main stream
       // (the integrator's second kernel, the next call's step block) follows all of the call
-      for (int b = 1; b < 4; ++b) { lin_add_op(LC, b, 1, 60 + b, 1); lin_flush(LC, b); }
-      for (int b = 1; b < 4; ++b) lin_add_op(LC, 0, 2, 60 + b, 1);
+      for (int b = 1; b < LIN_NST; ++b) { lin_add_op(LC, b, 1, 59 + b, 1); lin_flush(LC, b); }      // (marks 60 .. 63)
+      for (int b = 1; b < LIN_NST; ++b) lin_add_op(LC, 0, 2, 59 + b, 1);
       LC.head_open = false;
       // the main chain's closing WAITS are not captured: the integrator's second kernel performs them (MD loop), or a kernel of their own behind the chain;
       // whatever else is pending in front of them (a mark behind the chain's last kernel) is
@@ -2689,25 +2693,25 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
         LC.pend[0].n = cut; lin_flush(LC, 0);
         for (int k = cut; k < all.n; ++k) { tail.kind[tail.n] = 2; tail.slot[tail.n] = all.slot[k]; tail.ord[tail.n] = all.ord[k]; tail.n++; } }
       t_step_rec = nullptr; t_lin = nullptr; c->step_sb = nullptr;
-      hipGraph_t g[4] = {nullptr, nullptr, nullptr, nullptr}; hipGraphExec_t ex[4] = {nullptr, nullptr, nullptr, nullptr};
+      hipGraph_t g[LIN_NST] = {nullptr, nullptr, nullptr, nullptr}; hipGraphExec_t ex[LIN_NST] = {nullptr, nullptr, nullptr, nullptr};
       const double t_inst0 = now_us();
       hipError_t e = hipSuccess;
-      for (int b = 0; b < 4; ++b) { const hipError_t eb = hipStreamEndCapture(LC.st[b], &g[b]); if (eb != hipSuccess && e == hipSuccess) e = eb; }
-      size_t nn[4] = {0, 0, 0, 0};
-      for (int b = 0; b < 4 && e == hipSuccess && !LC.bad; ++b) { if (!g[b]) { e = hipErrorUnknown; break; } (void)hipGraphGetNodes(g[b], nullptr, &nn[b]); e = hipGraphInstantiate(&ex[b], g[b], nullptr, nullptr, 0); }
-      for (int b = 0; b < 4; ++b) if (g[b]) (void)hipGraphDestroy(g[b]);
-      if (e != hipSuccess || LC.bad || !ex[3]) {      // this runtime cannot capture the call: nothing has been issued - the call again, the ordinary way, and no further attempts
-        for (int b = 0; b < 4; ++b) if (ex[b]) (void)hipGraphExecDestroy(ex[b]);
+      for (int b = 0; b < LIN_NST; ++b) { const hipError_t eb = hipStreamEndCapture(LC.st[b], &g[b]); if (eb != hipSuccess && e == hipSuccess) e = eb; }
+      size_t nn[LIN_NST] = {0, 0, 0, 0};
+      for (int b = 0; b < LIN_NST && e == hipSuccess && !LC.bad; ++b) { if (!g[b]) { e = hipErrorUnknown; break; } (void)hipGraphGetNodes(g[b], nullptr, &nn[b]); e = hipGraphInstantiate(&ex[b], g[b], nullptr, nullptr, 0); }
+      for (int b = 0; b < LIN_NST; ++b) if (g[b]) (void)hipGraphDestroy(g[b]);
+      if (e != hipSuccess || LC.bad || !ex[LIN_NST - 1]) {      // this runtime cannot capture the call: nothing has been issued - the call again, the ordinary way, and no further attempts
+        for (int b = 0; b < LIN_NST; ++b) if (ex[b]) (void)hipGraphExecDestroy(ex[b]);
         (void)hipGetLastError(); w->graph_broken = true;
         fprintf(stderr, "[msevb] hipGraph capture of the MS-EVB force call failed (%s): option step_graph is off for this context\n", LC.bad ? (LC.why ? LC.why : "?") : hipGetErrorString(e));
         c->refresh_fused_nb = fused_nb_in;
         return MSEVB_RETRY;
       }
-      for (int b = 0; b < 4; ++b) G.exec[b] = ex[b];
+      for (int b = 0; b < LIN_NST; ++b) G.exec[b] = ex[b];
       G.head = LC.head; G.tail = tail;
       G.trace = gtrace;
       G.hash = grec.hash; G.n = grec.n; G.plan_serial = w->plan_serial; G.topo_epoch = c->topo_epoch; G.alloc_epoch = g_alloc_epoch; c->evb_graph_captures++;
-      if (getenv("MSEVB_GRAPH_DEBUG")) fprintf(stderr, "[msevb] MS-EVB call captured as four linear graphs: nodes %zu %zu %zu %zu (main, grid, descriptor, coupling stream); %d events, %d marks and %d waits in %d one-thread kernels (+ the step-block kernel); end of capture + instantiation %.0f us\n", nn[0], nn[1], nn[2], nn[3], LC.nev, LC.n_marks + 3, LC.n_waits + 3, LC.n_op_kernels, now_us() - t_inst0);
+      if (getenv("MSEVB_GRAPH_DEBUG")) fprintf(stderr, "[msevb] MS-EVB call captured as four linear graphs: nodes %zu %zu %zu %zu (main, grid, descriptor, coupling stream); %d events, %d marks and %d waits in %d one-thread kernels (+ the step-block kernel); end of capture + instantiation %.0f us\n", nn[0], nn[1], nn[2], nn[3], LC.nev, LC.n_marks + LIN_NST - 1, LC.n_waits + LIN_NST - 1, LC.n_op_kernels, now_us() - t_inst0);
     } else if (grec.hash != G.hash || grec.n != G.n || g_alloc_epoch != alloc_epoch0) {
       // this call would NOT have enqueued what the graphs hold (an argument, a launch geometry or a buffer changed): nothing has been issued - drop them, repeat the call the ordinary way
       t_step_rec = nullptr; t_lin = nullptr; c->step_sb = nullptr;
@@ -2729,7 +2733,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
     StepBlockVals sv; memset(&sv, 0, sizeof sv);
     sv.v[SB_R] = w->seq_R; sv.v[SB_A] = w->seq_A; sv.v[SB_S] = w->seq_S; sv.v[SB_B] = w->seq_B; sv.v[SB_EPOCH] = c->pair_epoch;
     hipLaunchKernelGGL(k_set_step_block, dim3(1), dim3(64), 0, c->stream, w->d_sb.p, sv, LC.cnt, LC.marks, G.head, LC.fault);      // (every kernel of a side chain that reads the block sits behind a wait for a mark of the main chain)
-    { ApiScope aps(4); for (int b = 0; b < 4; ++b) HIPCHK(hipGraphLaunch(G.exec[b], LC.st[b])); }
+    { ApiScope aps(4); for (int b = 0; b < LIN_NST; ++b) HIPCHK(hipGraphLaunch(G.exec[b], LC.st[b])); }
     c->evb_graph_launches++; if (gmode == 2) w->graph_mismatch_run = 0;
     c->lin_cnt = LC.cnt; c->lin_marks = LC.marks; c->lin_tail = G.tail;
     if (!c->lin_tail_defer || !dev_solve) {      // nobody downstream will perform them (host-array entry points; a blend phase enqueued by the host behind this): now, as a kernel
@@ -2784,7 +2788,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   }
   // E0 = potential energy of the principal diabat (fetch B); added to the diagonal and to the eigenvalue
   auto principal_energy = [&](double& E0) -> int {
-    if (c->overlap) { if (spin_wait((volatile long long*)(w->h_flag + 2), w->seq_B, w->ev_fetch, gsync)) HIPCHK(hipErrorUnknown); } else HIPCHK(hipStreamSynchronize(c->stream));
+    if (dev_solve_mr && c->nccl_comm && sharded) CHK(msevb_comm_wait_flag(c, (volatile long long*)(w->h_flag + 2), w->seq_B, w->stream2, "EVB energy all-reduce"));
+    else if (c->overlap) { if (spin_wait((volatile long long*)(w->h_flag + 2), w->seq_B, w->ev_fetch, gsync)) HIPCHK(hipErrorUnknown); } else HIPCHK(hipStreamSynchronize(c->stream));
     if (nb_check_overflow(c)) return MSEVB_RETRY;      // a list row outgrew its stride in this call's rebuild: the whole force call is repeated
     if (dev_solve_mr && c->nccl_comm && sharded) { for (int k = 0; k < 8; ++k) c->h_energies[S_ELEC_PAIR + k] = c->h_comm_e8[k]; energies_in = true; }      // the sums of the device-side all-reduce (copied out by fetch B's kernel)
     if (sharded && !energies_in && c->rank != 0) c->h_energies[S_RECIP] = 0.0;      // sharded principal diabat: replicated terms count once (rank 0)
@@ -2812,7 +2817,8 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
   // ---- 11. diagonalise H', blend (diagonalize_evb_hamiltonian, :242)
   double eg = 0.0;
   if (dev_solve) {      // eigenvalue and ground-state vector of the device's Jacobi (the blend behind it is running already)
-    if (c->overlap) { if (spin_wait((volatile long long*)(w->h_flag + 6), w->seq_S, w->ev_solve, gsync)) HIPCHK(hipErrorUnknown); } else HIPCHK(hipStreamSynchronize(c->stream));
+    if (dev_solve_mr && c->nccl_comm) CHK(msevb_comm_wait_flag(c, (volatile long long*)(w->h_flag + 6), w->seq_S, c->aux, "EVB all-gather"));      // (behind a collective: a missing peer must end the call, not hang it)
+    else if (c->overlap) { if (spin_wait((volatile long long*)(w->h_flag + 6), w->seq_S, w->ev_solve, gsync)) HIPCHK(hipErrorUnknown); } else HIPCHK(hipStreamSynchronize(c->stream));
     const double* hs = w->h_solve;
     if (hs[0] != 0.0) FAIL(MSEVB_ERR_NUMERIC, "too many iterations in jacobi");
     eg = hs[1];

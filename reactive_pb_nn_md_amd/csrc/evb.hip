@@ -744,22 +744,31 @@ __global__ void k_evb_blend_grids(size_t K3, GridCoefs gc, const double* __restr
 
 // two stencils per recip entry: 2 e = the atom as the principal diabat has it (charge -q_old), 2 e + 1 = its new state (charge +q_new).
 // Charges modify_Q_grid would skip (|q| <= 1e-6, src/pme.f90:296) and entries whose two states are identical get q = 0.
-__global__ void k_evb_stencils(int n, const RecipAtom* __restrict__ ra, const int* __restrict__ obase, const double* __restrict__ ow, const double* __restrict__ odw,
+// one wavefront per special atom (round 5; it was one THREAD per atom - 72 dependent loads and as many stores, 17 us for two workgroups on the chain whose end the energy
+// fetch follows): lane k < 18 moves tap k of the four weight arrays, lanes 0-2 the base points, one ballot decides whether the two states differ at all
+__global__ __launch_bounds__(64) void k_evb_stencils(int n, const RecipAtom* __restrict__ ra, const int* __restrict__ obase, const double* __restrict__ ow, const double* __restrict__ odw,
                                const int* __restrict__ sbase, const double* __restrict__ sw, const double* __restrict__ sdw, Stencil* __restrict__ st) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = blockIdx.x, l = threadIdx.x;
   if (e >= n) return;
-  const RecipAtom r = ra[e];
-  Stencil a, b;
-  a.grid = b.grid = r.grid; a.slot = b.slot = r.slot; a.idx = b.idx = r.idx;
-  bool same = r.q_old == r.q_new;
-  for (int d = 0; d < 3; ++d) { a.base[d] = obase[3 * e + d]; b.base[d] = sbase[3 * e + d]; same = same && a.base[d] == b.base[d]; }
-  for (int k = 0; k < 18; ++k) {
-    a.w[k] = ow[18 * (size_t)e + k]; a.dw[k] = odw[18 * (size_t)e + k]; b.w[k] = sw[18 * (size_t)e + k]; b.dw[k] = sdw[18 * (size_t)e + k];
-    same = same && a.w[k] == b.w[k];
+  const double q_old = ra[e].q_old, q_new = ra[e].q_new;
+  bool differs = false;
+  Stencil& a = st[2 * e]; Stencil& b = st[2 * e + 1];
+  if (l < 18) {
+    const double aw = ow[18 * (size_t)e + l], adw = odw[18 * (size_t)e + l], bw = sw[18 * (size_t)e + l], bdw = sdw[18 * (size_t)e + l];
+    a.w[l] = aw; a.dw[l] = adw; b.w[l] = bw; b.dw[l] = bdw;
+    differs = aw != bw;
+  } else if (l < 21) {
+    const int d = l - 18, ab = obase[3 * e + d], bb = sbase[3 * e + d];
+    a.base[d] = ab; b.base[d] = bb;
+    differs = ab != bb;
   }
-  a.q = (same || fabs(r.q_old) <= 1e-6) ? 0.0 : -r.q_old;
-  b.q = (same || fabs(r.q_new) <= 1e-6) ? 0.0 : r.q_new;
-  st[2 * e] = a; st[2 * e + 1] = b;
+  const bool same = q_old == q_new && __ballot(differs) == 0ull;
+  if (l == 21) {
+    const int grid = ra[e].grid, slot = ra[e].slot, idx = ra[e].idx;
+    a.grid = grid; b.grid = grid; a.slot = slot; b.slot = slot; a.idx = idx; b.idx = idx;
+    a.q = (same || fabs(q_old) <= 1e-6) ? 0.0 : -q_old;
+    b.q = (same || fabs(q_new) <= 1e-6) ? 0.0 : q_new;
+  }
 }
 
 // one wavefront per stencil: its dot with theta_1 (energy, linear term) and the force theta_1 exerts on it -> the diabat's slot of the delta store
@@ -2402,7 +2411,7 @@ static int evb_force_energy_body(msevb_ctx* c, double* epot_out) {
       // (round 5: on a FIFTH stream, beside the charge spreading instead of behind it, these two made the step 20 % slower - 0.482 against 0.408 ms, the grid chain ending
       //  at 295 instead of 227 us: this runtime maps the process's streams onto four hardware queues, a fifth shares one - and slowed every later context of the process)
       const hipStream_t sp = sg;
-      hipLaunchKernelGGL(k_evb_stencils, dim3((nra + 63) / 64), dim3(64), 0, sp, nra, d_ra, w->d_obase.p, w->d_ow.p, w->d_odw.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p, w->d_stencils.p);
+      hipLaunchKernelGGL(k_evb_stencils, dim3(nra), dim3(64), 0, sp, nra, d_ra, w->d_obase.p, w->d_ow.p, w->d_odw.p, w->d_sbase.p, w->d_sw.p, w->d_sdw.p, w->d_stencils.p);
       hipLaunchKernelGGL(k_evb_recip_pairs, dim3(max_ns, ngrid), dim3(256), 0, sp, granges, w->d_stencils.p, K, c->d_green.p, c->conv, c->kk[0][0], c->kk[0][1],
                          c->kk[0][2], c->kk[1][0], c->kk[1][1], c->kk[1][2], c->kk[2][0], c->kk[2][1], c->kk[2][2], w->d_Fdelta.p, n3, w->d_Elq.p + MAX_DIABATS);
     }

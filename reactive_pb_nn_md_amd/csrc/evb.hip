@@ -178,13 +178,9 @@ __global__ __launch_bounds__(256) void k_evb_candidates(int N, double cx, double
 // sum over its q-lanes (one atomic triple per candidate), the force on special atom q accumulates per lane and meets in LDS at the end.
 // The MS-EVB3 repulsion (rare: candidates within the screening radius of the hydronium) is done by the q = 0 lane and adds straight into
 // the LDS table.  No private arrays (the thread-per-candidate version kept the hydronium force block in scratch memory).
-// EVB_ENV_CAP (variant build): at most 64 vector registers per lane, the most that fits beside a pair-loop workgroup on its CU (4 waves x 112 registers per SIMD) - spills to scratch
-#ifdef EVB_ENV_CAP
-#define EVB_ENV_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
-#else
-#define EVB_ENV_ATTR
-#endif
-__global__ __launch_bounds__(256) EVB_ENV_ATTR void k_evb_env(const int* __restrict__ n_cand, const int* __restrict__ cand, int n_units, const UnitDesc* __restrict__ units, const EvbTablesDev* __restrict__ tabs,
+// (round 5, measured: held to 64 vector registers - the most that fits beside a pair-loop workgroup on its CU - by amdgpu_waves_per_eu(8, 8) this kernel spills 115 registers
+//  and the step loses 4-7 %: the spills cost more than the co-residence gives, HISTORY.md F)
+__global__ __launch_bounds__(256) void k_evb_env(const int* __restrict__ n_cand, const int* __restrict__ cand, int n_units, const UnitDesc* __restrict__ units, const EvbTablesDev* __restrict__ tabs,
                                                  const double* __restrict__ xyz, const double* __restrict__ chg, const int* __restrict__ atype,
                                                  const int* __restrict__ mol_of, const PairParam* __restrict__ pairpar, int nt,
                                                  const double2* __restrict__ etab, double inv_dx, const double* __restrict__ tt,

@@ -103,14 +103,10 @@ struct PfTrip {      // what stage A leaves for stage B (per lane)
 // lower row follows from the upper one to 1e-16 (third-order expansion over one table interval, alpha dx = 2.7e-5).
 struct PfRaw { double xj, yj, zj, qj, xi, yi, zi, qi; unsigned ja, aa, pa; };
 
-// PF_VAR (variant builds, measured one against the other on one box): bit 0 - the row atom's {x,y,z,q} stay in registers and are read from the tile again only in
-// trips in which some DPP row has moved on to its next atom (a row lasts ~3 trips: two LDS instructions less in two trips out of three)
-#ifndef PF_VAR
-#define PF_VAR 0
-#endif
-struct PfOwner { double x, y, z, q; unsigned aa; };
+// (round 5, measured: the row atom's {x, y, z, q} kept in registers and re-read only in trips in which a DPP row moves on - two LDS instructions less in two trips out of
+// three, 113 registers instead of 107 - changed nothing: 0.166 against 0.164 ms per stage call.  The LDS is not what a reading launch waits for.)
 template <int P>
-__device__ __forceinline__ void pf_stage_a_read(unsigned e, PfRaw& w, PfOwner& own) {
+__device__ __forceinline__ void pf_stage_a_read(unsigned e, PfRaw& w) {
   w.ja = (e & ((1u << PF_J_BITS) - 1u)) << 3;
   w.aa = (e >> (PF_A_SHIFT - 3)) & (((1u << PF_A_BITS) - 1u) << 3);
   w.pa = ((e >> (PF_T_SHIFT - 5)) & (0x3ffu << 5)) | (e & 0x80000000u);      // bit 31: the pair type has a Lennard-Jones term (set by the rewrite)
@@ -120,13 +116,7 @@ __device__ __forceinline__ void pf_stage_a_read(unsigned e, PfRaw& w, PfOwner& o
 #else
   w.xj = pf_ld(w.ja + X); w.yj = pf_ld(w.ja + X + 8 * P); w.zj = pf_ld(w.ja + X + 16 * P); w.qj = pf_ld(w.ja + X + 24 * P);
 #endif
-#if PF_VAR & 1
-  if (__ballot(w.aa != own.aa)) { own.x = pf_ld(w.aa + X); own.y = pf_ld(w.aa + X + 8 * P); own.z = pf_ld(w.aa + X + 16 * P); own.q = pf_ld(w.aa + X + 24 * P); own.aa = w.aa; }
-  w.xi = own.x; w.yi = own.y; w.zi = own.z; w.qi = own.q;
-#else
-  (void)own;
   w.xi = pf_ld(w.aa + X); w.yi = pf_ld(w.aa + X + 8 * P); w.zi = pf_ld(w.aa + X + 16 * P); w.qi = pf_ld(w.aa + X + 24 * P);
-#endif
 }
 
 template <bool TAYLOR>
@@ -530,26 +520,25 @@ __global__ __launch_bounds__(THREADS, MINW) void k_pair_flat(const PairFlatArgs 
     const int* src = cell_flat + seg_off + lane;
     const unsigned e_none = (unsigned)ntile;
     PfRaw w; PfTrip sa;
-    PfOwner own; own.x = 0.0; own.y = 0.0; own.z = 0.0; own.q = 0.0; own.aa = 0xffffffffu;
     if (PIPE) {
       // Two trips in flight per wave: geometry of trip t + 1 (its table rows requested) in front of the arithmetic of trip t, whose rows were requested a
       // trip ago; the entries of trip t + 2 loading.  (A third stage - tile reads of trip t + 2 issued before the arithmetic of trip t - measured the same
       // and costs 20 registers: the loop is bound by the throughput of the LDS, the vector-memory address path and the fp64 pipe together, not by a wait.)
       PfTrip sb;
       unsigned ea = pf_ld_entry(src + 64), eb;
-      pf_stage_a_read<P>(pf_ld_entry(src), w, own);
+      pf_stage_a_read<P>(pf_ld_entry(src), w);
       ea = t0 + 1 < t1 ? ea : e_none;
       pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sa);
       acc.a_prev = sa.aa;
       for (unsigned t = t0; t < t1; t += 2) {      // two trips per turn: the states swap roles instead of being copied
         eb = pf_ld_entry(src + 128);                                                                                  // entries of trip t + 2
-        pf_stage_a_read<P>(ea, w, own);
+        pf_stage_a_read<P>(ea, w);
         pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sb);                                               // trip t + 1: geometry, table rows requested (behind the last trip: padding)
         pf_stage_b<P, TAYLOR, SAPT>(sa, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, NS, acc, sm.vkind, A.pairpar, A.tt, A.dtt);      // trip t: arithmetic
         eb = t + 2 < t1 ? eb : e_none;
         if (t + 1 >= t1) break;
         ea = pf_ld_entry(src + 192);
-        pf_stage_a_read<P>(eb, w, own);
+        pf_stage_a_read<P>(eb, w);
         pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sa);
         pf_stage_b<P, TAYLOR, SAPT>(sb, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, NS, acc, sm.vkind, A.pairpar, A.tt, A.dtt);
         ea = t + 3 < t1 ? ea : e_none;
@@ -561,7 +550,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_pair_flat(const PairFlatArgs 
       bool first = true;
       for (unsigned t = t0; t < t1; ++t) {
         const unsigned en = pf_ld_entry(src + 64);      // entries of the next trip
-        pf_stage_a_read<P>(e, w, own);
+        pf_stage_a_read<P>(e, w);
         pf_stage_a_math<TAYLOR>(w, A.rc2, A.inv_dx, A.delta, etab, sa);
         if (first) { acc.a_prev = sa.aa; first = false; }
         pf_stage_b<P, TAYLOR, SAPT>(sa, lane, A.rc2, rc2_lo, rc2_hi, A.dx, A.delta, A.box, A.posq, cs, s_lo, s_off, NS, acc, sm.vkind, A.pairpar, A.tt, A.dtt);

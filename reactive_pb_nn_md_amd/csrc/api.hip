@@ -741,7 +741,8 @@ int total_force_enqueue(msevb_ctx* c) {
     else CHK(nb_step_refresh(c, nullptr, self_nb == 0));
   }
   if (c->overlap) {     // independent chains, all adding to the force with fp64 atomics
-    HIPCHK(aux_fork(c));
+    HIPCHK(aux_fork(c));      // (round 5: forking the side streams from the call's ev_pos_ready instead - one signal packet less between the integrator's kernel and the pair loop - is 1.6 % SLOWER:
+                              //  the side kernels then reach the GPU before the pair loop's first workgroups; HISTORY.md F)
     if (self_nb) {
       if (!c->ev_top2) HIPCHK(hipEventCreateWithFlags(&c->ev_top2, hipEventDisableTiming));
       CHK(nb_step_top2(c, self_nb, c->aux3, false));

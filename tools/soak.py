@@ -29,7 +29,12 @@ def main():
     e_ref, F_ref = h.ms_evb_calculate_total_force_energy()
     ev = h.evb_state()["eigvec"].copy()
     h.close()
-    modes = ["default + 12 MD steps", "spread_mfma", "virtual rank of 8", "gather_mfma + stored weights"]      # spread_mfma: + 12 MD steps as well
+    # round 5: the linear step graphs (captures, replays, a tree change on the way) and the device path of a rank with a communicator on a virtual rank of 4
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import virtual_rank_times as vrt
+    vrt.OPTS = []
+    pay4 = vrt.gathered_payloads(spec, 4)
+    modes = ["default + 12 MD steps", "spread_mfma", "virtual rank of 8", "gather_mfma + stored weights", "step_graph + 40 MD steps", "virtual rank of 4, device path"]      # spread_mfma: + 12 MD steps as well
     errors, counts, t0 = [], {m: 0 for m in modes}, time.time()
     for it in range(n_it):
         mode = modes[it % len(modes)]
@@ -43,16 +48,29 @@ def main():
                 h.set_option("pme_weightless", 0)
             elif mode == "virtual rank of 8":
                 h.set_option("shard_principal", 1)
+                h.set_option("evb_device_solve_ranks", 0)
                 h.comm_set_virtual((it // len(modes)) % 8, 8)
+            elif mode == "step_graph + 40 MD steps":
+                h.set_option("step_graph", 1)
+            elif mode == "virtual rank of 4, device path":
+                h.set_option("shard_principal", 1)
+                h.comm_set_virtual((it // len(modes)) % 4, 4)
+                h.comm_set_virtual_payload(pay4)
             for _ in range(3):
                 e, F = h.ms_evb_calculate_total_force_energy()
                 if mode == "virtual rank of 8":
                     h.evb_partial_blend(ev, download=False)
+                elif mode == "virtual rank of 4, device path":
+                    evr = h.evb_state()["eigvec"]
+                    if min(np.abs(evr - ev).max(), np.abs(evr + ev).max()) > 1e-9 or not np.all(np.isfinite(F)):
+                        errors.append({"iteration": it, "mode": mode, "error": "eigenvector of the gathered Hamiltonian differs: %.3e" % min(np.abs(evr - ev).max(), np.abs(evr + ev).max())})
                 elif abs(e - e_ref) > 1e-9 * abs(e_ref) or not np.all(np.isfinite(F)) or np.abs(F - F_ref).max() > 1e-7:
                     errors.append({"iteration": it, "mode": mode, "error": "result differs: dE %.3e max dF %.3e" % (e - e_ref, np.abs(F - F_ref).max())})
-            if mode in ("default + 12 MD steps", "spread_mfma"):      # (the round-3 failure of the spread_mfma test came in its 25-step trajectory)
+            if mode in ("default + 12 MD steps", "spread_mfma", "step_graph + 40 MD steps"):      # (the round-3 failure of the spread_mfma test came in its 25-step trajectory)
                 h.set_velocities(vel)
-                en = h.md_integrate_atomic(12, spec.delta_t, use_evb=True)
+                en = h.md_integrate_atomic(40 if mode.startswith("step_graph") else 12, spec.delta_t, use_evb=True)
+                if mode.startswith("step_graph") and (h.info("graph_launches") < 20 or h.info("graph_mismatches") > 0):
+                    errors.append({"iteration": it, "mode": mode, "error": "graph launches %d, mismatches %d" % (h.info("graph_launches"), h.info("graph_mismatches"))})
                 if not np.all(np.isfinite(en)):
                     errors.append({"iteration": it, "mode": mode, "error": "non-finite trajectory energies"})
             h.close()

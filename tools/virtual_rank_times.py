@@ -90,10 +90,13 @@ def rank_time(spec, r, R, eigvec, calls):
     return dt, D
 
 
-MODE = "host" if "host" in sys.argv[1:] else "device"      # device (default): virtual ranks get the gathered payloads and run the device-side solve + pre-enqueued blend; host: round 4's path (the caller merges with a given eigenvector)
-sys.argv = [a for a in sys.argv if a not in ("host", "device")]
-OPTS = [a for a in sys.argv[1:] if "=" in a]      # library options, name=value (e.g. step_graph=0)
-sys.argv = [a for a in sys.argv if "=" not in a]
+_ARGV = sys.argv if __name__ == "__main__" else [sys.argv[0]]
+MODE = "host" if "host" in _ARGV[1:] else "device"      # device (default): virtual ranks get the gathered payloads and run the device-side solve + pre-enqueued blend; host: round 4's path (the caller merges with a given eigenvector)
+if __name__ == "__main__":
+    sys.argv = [a for a in sys.argv if a not in ("host", "device")]
+OPTS = [a for a in _ARGV[1:] if "=" in a]      # library options, name=value (e.g. step_graph=0)
+if __name__ == "__main__":
+    sys.argv = [a for a in sys.argv if "=" not in a]
 
 
 def main():

@@ -1,7 +1,9 @@
 // Multi-GPU exchange for the diabat-sharded EVB step: one process per GPU, RCCL over xGMI.
-// Diabats d >= 2 live on rank (d-2) mod R.  Per step: one tiny all-gather (Hamiltonian entries + principal energy slots, aux2 stream)
-// and, strictly after it, one all-reduce of the partial Hellmann-Feynman forces (24 B per atom, main stream): the two collectives of a
-// communicator are never in flight together.  Force stores never travel.
+// Diabats d >= 2 live on rank (d-2) mod R.  Per step, since round 5: one tiny all-gather of Hamiltonian entries, in place and device to device on the grid stream
+// (the rank's slot is written by its energy-fetch kernel, the gathered matrix is solved on the device by every rank), one 8-double all-reduce of the principal energy slots on
+// the descriptor stream, one all-reduce of the partial Hellmann-Feynman forces (24 B per atom) on the main stream behind the pre-enqueued blend - issued in this order on every
+// rank and ordered by the data they carry.  Force stores never travel.  Option evb_device_solve_ranks = 0: round 4's step - the all-gather's payload staged through pinned host
+// memory (msevb_comm_allgather_evb, below), the host's Jacobi between it and the all-reduce.
 #include <rccl/rccl.h>
 
 #include <chrono>

@@ -41,13 +41,16 @@ constexpr int WAVE = 64;
 #define FAIL(code, msg) do { c->err = (msg); return (code); } while (0)
 #define CHK(call) do { int r_ = (call); if (r_ != MSEVB_OK) return r_; } while (0)
 
-// ---- capture / replay of a whole MS-EVB force call as ONE hipGraph ("step graph", evb.hip) ------------------------------------
+// ---- capture / replay of a whole MS-EVB force call ("step graph", option step_graph; evb.hip) ------------------------------------
 // Between two changes of the diabat tree a force call enqueues the same ~35 kernels, event records / waits and fills with the same arguments (what changes from
-// call to call - sequence numbers, the pair list's epoch - is read from a device-resident step block).  The call's host code is therefore run in one of three modes:
+// call to call - sequence numbers, the pair list's epoch - is read from a device-resident step block).  The call's host code is therefore run in one of these modes:
 //   0 direct   every launch / event operation goes to its stream (rebuild steps, calls that re-enumerate the tree, timed calls, step_graph = 0);
-//   1 capture  the main stream is in stream capture: the same calls build the graph; every launch is also hashed (function, geometry, stream, argument bytes);
+//   3 learn    a dry pass, nothing issued: which event records are waited for on ANOTHER stream (only those become device-side marks); the call is repeated;
+//   1 capture  every stream of the call is in a stream capture of its OWN (four linear graphs, LinCap below): the same calls build the graphs; every launch is also
+//              hashed (function, geometry, stream, argument bytes);
 //   2 replay   the same host code runs again for its bookkeeping, launches and event operations are NOT issued but hashed; if the hash equals the capture's,
-//              the call is ONE hipGraphLaunch - otherwise the call is repeated in mode 0 (nothing had been issued) and the graph is dropped.
+//              the call is four hipGraphLaunch calls - otherwise the call is repeated in mode 0 (nothing had been issued) and the graphs are dropped.
+// (Round 5's first form - ONE graph holding all four branches - saved no host time: this runtime enqueues a graph with branches node by node.)
 // All device work of the library goes through the wrappers below (the HIP names are redirected to them at the end of this block).
 enum StepBlockSlot { SB_R = 0, SB_A, SB_S, SB_B, SB_EPOCH, SB_N = 8 };      // device-resident step block: what changes between two launches of a captured force call
 struct StepRec { int mode = 0; unsigned long long hash = 0xcbf29ce484222325ull; int n = 0; std::vector<std::pair<const void*, unsigned long long>>* trace = nullptr; /* MSEVB_GRAPH_DEBUG: (kernel or operation tag, running hash) per operation */ };
